@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py — WholeMemory embedding gather on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: wholememory_embedding_gather of `--indices`
+random int64 ids (default 10 M) into an fp32 [n, 128] output, table resident in HBM.
+  N = 1 : config C2 — CHUNKED, 100 M x 128 fp32 (51.2 GB) on one GPU (1 B x 128 = 512 GB does not fit 288 GB)
+  N > 1 : config C3 — DISTRIBUTED, 125 M rows per GPU (1 B x 128 at N = 8), every rank gathers its own 10 M
+          ids (weak scaling, like the reference bench where every rank gathers `gather_size`), ids and rows
+          exchanged by RCCL all-to-all-v over xGMI.
+`value` follows the reference bench convention (cpp/bench/wholememory_ops/gather_scatter_bench.cu:364):
+output bytes / time / 1e9, aggregated over all ranks; `mlookups_per_s` and the algorithmic
+(idx + row read + row write = 1032 B / lookup) rate are reported beside it.
+Launch: python bench.py [--gpus 1]   or   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=0, help="table rows per GPU (default: 100M at N=1, 125M at N>1)")
+    p.add_argument("--dim", type=int, default=128)
+    p.add_argument("--indices", type=int, default=10_000_000)
+    p.add_argument("--dist", choices=["uniform", "zipf", "zipf_clustered"], default="uniform")
+    p.add_argument("--memory-type", default="", help="override: continuous|chunked|distributed")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-check", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    return p.parse_args()
+
+
+def make_indices(n, total_rows, dist, seed):
+    rng = np.random.default_rng(seed)
+    if dist == "uniform":
+        return rng.integers(0, total_rows, n, dtype=np.int64)
+    # Zipf(s = 1.05) popularity rank k; hashed to a row so hot rows spread over owners,
+    # or clustered (idx = k: every hot row on rank 0 = worst-case link skew)
+    k = rng.zipf(1.05, n).astype(np.uint64)
+    if dist == "zipf":
+        return ((k * np.uint64(2654435761)) % np.uint64(total_rows)).astype(np.int64)
+    return (k % np.uint64(total_rows)).astype(np.int64)
+
+
+def fill_table(local, row_start):
+    """value(row r, any col) = float(r & 0xFFFFFF): the reference tests' closed form
+    (cpp/tests/wholememory_ops/embedding_test_utils.cu:197-238), exactly representable."""
+    rows = local.shape[0]
+    chunk = 4 << 20
+    for s in range(0, rows, chunk):
+        e = min(rows, s + chunk)
+        r = torch.arange(row_start + s, row_start + e, device="cuda", dtype=torch.int64) & 0xFFFFFF
+        local[s:e] = r.to(torch.float32).unsqueeze(1)
+    torch.cuda.synchronize()
+
+
+def cpu_baseline(dim, seconds):
+    """The oracle's gather (OpenMP over indices) on a host-resident table on this box's host cores:
+    a bounded sample of the same workload shape (random 512 B rows, int64 ids)."""
+    import oracle
+    rows, n = 8_000_000, 2_000_000
+    table = np.empty((rows, dim), dtype=np.float32)
+    table[:] = (np.arange(rows, dtype=np.int64) & 0xFFFFFF).astype(np.float32)[:, None]
+    tab = oracle.ShardedTable([table], np.array([0, rows], dtype=np.uint64), dim)
+    idx = np.random.default_rng(42).integers(0, rows, n, dtype=np.int64)
+    out = np.empty((n, dim), dtype=np.float32)
+    oracle.gather(tab, idx, out)  # warm
+    t0, passes = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        oracle.gather(tab, idx, out)
+        passes += 1
+    dt = time.perf_counter() - t0
+    lookups = passes * n / dt
+    return {"value": round(lookups * dim * 4 / 1e9, 3), "unit": "GB/s", "cores": oracle.num_threads(), "kind": "port",
+            "mlookups_per_s": round(lookups / 1e6, 2),
+            "sample": "oracle gather (C, OpenMP, %d threads): %d passes of %d random int64 ids over a host "
+                      "%dx%d fp32 table in %.1f s" % (oracle.num_threads(), passes, n, rows, dim, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    import wholegraph_amd.torch as wgth
+    from wholegraph_amd import binding as wmb
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        torch.distributed.init_process_group(backend="nccl", init_method="env://")
+        wgth.init(rank, world, local_rank, world, "warn")
+        comm = wgth.get_global_communicator()
+    else:
+        wmb.check(wmb.lib().wholememory_init(0, wmb.LEVEL_WARN))
+        comm = wgth.create_group_communicator(1)
+    assert wmb.lib().wholememory_ext_backend_name() == b"hip-gfx950"
+
+    rows_per_gpu = a.rows or (100_000_000 if world == 1 else 125_000_000)
+    total_rows = rows_per_gpu * world
+    mt = a.memory_type or ("chunked" if world == 1 else "distributed")
+    emb = wgth.create_embedding(comm, mt, "cuda", torch.float32, [total_rows, a.dim])
+    local, start = emb.get_embedding_tensor().get_local_tensor()
+    fill_table(local, start)
+    idx_np = make_indices(a.indices, total_rows, a.dist, 42 + rank)
+    idx = torch.from_numpy(idx_np).cuda()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(a.warmup):
+        out = emb.gather(idx)
+    barrier()
+    if not a.no_check and out is not None:
+        exp = (idx & 0xFFFFFF).to(torch.float32)
+        ok = bool(torch.equal(out[:, 0], exp) and torch.equal(out[:, a.dim - 1], exp) and
+                  torch.equal(out[::1009].sum(1), exp[::1009] * a.dim))
+        assert ok, "gathered rows differ from the closed-form table"
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        out = emb.gather(idx)
+    ev1.record()
+    barrier()
+    t1 = time.perf_counter()
+    dt = torch.tensor([t1 - t0], device="cuda", dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+    wall = float(dt.item())
+    dev_ms = ev0.elapsed_time(ev1) / a.steps  # HIP events on the stream the kernels were launched on
+
+    if rank == 0:
+        lookups = a.indices * world * a.steps / wall
+        out_bytes = a.dim * 4
+        algo_bytes = 8 + a.dim * 4 + a.dim * 4
+        res = {
+            "metric": "gather_GBps_out (gathered output bytes/s, reference gather_scatter_bench convention)",
+            "value": round(lookups * out_bytes / 1e9, 2),
+            "unit": "GB/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(wall / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "mlookups_per_s": round(lookups / 1e6, 1),
+            "algorithmic_GBps": round(lookups * algo_bytes / 1e9, 2),
+            "config": {"workload": ("C2 chunked 1-GPU %dx%d fp32 table, %d %s int64 ids" if world == 1 else
+                                    "C3 distributed %dx%d fp32 table, %d %s int64 ids per rank, RCCL alltoallv")
+                                   % (total_rows, a.dim, a.indices, a.dist),
+                       "memory_type": mt, "rows_per_gpu": rows_per_gpu, "indices_per_rank": a.indices,
+                       "index_distribution": a.dist},
+        }
+        if world == 1:
+            # dominant kernel = rows_copy_kernel<long,16,true>: the whole step at N=1
+            achieved = a.indices * algo_bytes / (dev_ms * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("gather_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                               "kernel": "rows_copy_kernel<int64,16B,gather>", "kernel_ms": round(dev_ms, 4),
+                               "algorithmic_bytes_per_launch": a.indices * algo_bytes}
+            if not a.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(a.dim, a.cpu_seconds)
+        print(json.dumps(res))
+    wgth.destroy_embedding(emb)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+/*
+ * wholegraph_amd — entry points that do NOT exist in the reference ABI.
+ *
+ *  (1) external-collective communicators: a communicator whose collectives are supplied by the
+ *      host framework instead of RCCL. The product path never needs it on MI355X (RCCL over xGMI
+ *      is the transport); it exists so the SAME orchestration code can be driven at world_size > 1
+ *      over torch.distributed/gloo in the CPU test-suite, and for hosts that already own a
+ *      communicator.
+ *  (2) the raw device stages of the distributed path on plain device pointers (id bucketing,
+ *      owner-side dedup + optimizer step), so parity tests can check each stage against the oracle
+ *      through the C ABI.
+ *  (3) the testing seam for the device backend (see wholegraph_amd/csrc/backend.hpp).
+ */
+#ifndef WHOLEMEMORY_WHOLEGRAPH_AMD_EXT_H_
+#define WHOLEMEMORY_WHOLEGRAPH_AMD_EXT_H_
+
+#include <wholememory/embedding.h>
+#include <wholememory/wholememory_op.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- (1) external collectives ------------------------------------------------------------ */
+/* All byte counts/displacements are in BYTES; every function returns 0 on success. `stream` is the
+ * hipStream_t the library is working on; a provider that stages through the host must order itself
+ * after/before that stream. */
+struct wm_ext_collectives_t {
+  void* ctx;
+  int (*barrier)(void* ctx);
+  /* recv[r*bytes .. (r+1)*bytes) = rank r's send; HOST buffers */
+  int (*allgather_host)(void* ctx, const void* send, void* recv, size_t bytes);
+  /* DEVICE buffers (whatever the installed device backend calls device memory) */
+  int (*alltoallv_device)(void* ctx,
+                          const void* send,
+                          const size_t* send_bytes,
+                          const size_t* send_disp,
+                          void* recv,
+                          const size_t* recv_bytes,
+                          const size_t* recv_disp,
+                          void* stream);
+};
+#ifndef __cplusplus
+typedef struct wm_ext_collectives_t wm_ext_collectives_t;
+#endif
+
+enum wholememory_error_code_t wholememory_create_communicator_ext(
+  wholememory_comm_t* comm, int rank, int size, const struct wm_ext_collectives_t* collectives);
+
+/* ---- (2) raw stages ------------------------------------------------------------------------ */
+/* Owner bucketing of ids (reference bucket_ids_func.cu:51-87 + the grouping effect of
+ * exchange_ids_nccl_func.cu:42-92). entry_offsets: DEVICE uint64[world+1] row offsets. counts:
+ * DEVICE int64[world]. bucketed_ids (index dtype) / raw_indices (int64): DEVICE [n] or both NULL for
+ * counts only. Scratch comes from p_env_fns. Asynchronous on stream. */
+enum wholememory_error_code_t wholememory_ext_bucket_ids(const void* indices,
+                                                         enum wholememory_dtype_t index_dtype,
+                                                         int64_t n,
+                                                         const void* entry_offsets_dev,
+                                                         int world_size,
+                                                         int64_t* counts_dev,
+                                                         void* bucketed_ids_dev,
+                                                         int64_t* raw_indices_dev,
+                                                         struct wholememory_env_func_t* p_env_fns,
+                                                         void* stream);
+
+/* Owner-side "dedup + optimizer step" on received (ids, grads): reference
+ * exchange_embeddings_nccl_func.cu:76-174 followed by embedding_optimizer_func.cu steps, fused.
+ * opt_params: float[6] = {weight_decay, epsilon, beta1, beta2, alpha, adam_w}. State pointers may be
+ * NULL when the optimizer has none. Synchronises `stream` before returning the unique count. */
+enum wholememory_error_code_t wholememory_ext_dedup_apply(const void* recv_ids,
+                                                          enum wholememory_dtype_t index_dtype,
+                                                          int64_t n_recv,
+                                                          const float* recv_grads,
+                                                          int64_t grad_stride,
+                                                          int64_t dim,
+                                                          float* local_table,
+                                                          int64_t table_stride,
+                                                          int64_t local_entry_offset,
+                                                          int64_t local_entry_count,
+                                                          enum wholememory_optimizer_type_t opt_type,
+                                                          const float* opt_params,
+                                                          float lr,
+                                                          float* per_element_state,
+                                                          float* per_row_state,
+                                                          int64_t* n_unique_host,
+                                                          struct wholememory_env_func_t* p_env_fns,
+                                                          void* stream);
+
+/* round-robin id remap (reference map_indices_func.cu:26-106) on raw device pointers */
+enum wholememory_error_code_t wholememory_ext_round_robin_map(const void* ids,
+                                                              void* mapped,
+                                                              enum wholememory_dtype_t index_dtype,
+                                                              int64_t n,
+                                                              int64_t entry_start,
+                                                              int world_size,
+                                                              int round_robin_size,
+                                                              void* stream);
+
+/* name of the installed device backend ("hip-gfx950" in the product) */
+const char* wholememory_ext_backend_name();
+
+/* ---- (3) testing seam ---------------------------------------------------------------------- */
+/* Replaces the device backend. Refuses (WHOLEMEMORY_NOT_SUPPORTED) unless the environment has
+ * WHOLEGRAPH_AMD_TESTING=1. `backend` is a const wm_device_backend* (wholegraph_amd/csrc/backend.hpp);
+ * NULL restores the HIP backend. Never called by product code. */
+enum wholememory_error_code_t wm_testing_install_backend(const void* backend);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def wm_lib():
+    """libwholegraph.so, built if missing. The product library — never the oracle."""
+    from wholegraph_amd import binding
+    if not os.path.exists(binding.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return binding.lib()
+
+
+@pytest.fixture(scope="session")
+def gpu_env(wm_lib):
+    """Initialised library + single-rank communicator on cuda:0."""
+    import torch
+    from wholegraph_amd import binding
+    import wholegraph_amd.torch as wgth
+    assert torch.cuda.is_available(), "gpu tests need a GPU; the library has no CPU fallback"
+    torch.cuda.set_device(0)
+    binding.check(wm_lib.wholememory_init(0, binding.LEVEL_WARN))
+    assert wm_lib.wholememory_ext_backend_name() == b"hip-gfx950"
+    comm = wgth.create_group_communicator(1)
+    yield comm

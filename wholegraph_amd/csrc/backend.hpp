@@ -1,0 +1,115 @@
+// wholegraph_amd — the device seam.
+//
+// Host orchestration (ops.cpp, embedding.cpp, memory_handle.cpp) reaches the GPU only through this
+// table: raw memory management plus one launcher per hand-written gfx950 kernel. The product
+// installs exactly one implementation, the HIP one (kernels/*.hip → hip_backend()); a missing or
+// failing HIP runtime is a hard error, there is no CPU fallback in this library.
+//
+// The table is also the seam that lets tests/ drive the multi-rank orchestration at world_size 2 on
+// a CPU-only box: oracle/test_backend.c (test infrastructure) can be installed through
+// wm_testing_install_backend(), which refuses to act unless WHOLEGRAPH_AMD_TESTING=1 is set.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include <wholememory/global_reference.h>
+#include <wholememory/tensor_description.h>
+
+extern "C" {
+
+// gather: out[i,:] = cast(table[idx[i],:]), idx < 0 skipped. scatter: the mirror image.
+// `gref` addresses the table (continuous or chunked); dims/strides/offsets in ELEMENTS.
+struct wm_rows_args {
+  wholememory_gref_t gref;            // table
+  wholememory_dtype_t table_dtype;
+  int64_t dim;                        // columns moved per row
+  int64_t table_stride;               // elements
+  int64_t table_storage_offset;       // elements
+  const void* indices;                // [n] int32/int64, device
+  wholememory_dtype_t index_dtype;
+  int64_t n;
+  const void* row_map;                // optional [n] (index dtype): plain-side row for entry i; nullptr = i
+  void* plain;                        // output (gather) / input (scatter), device
+  wholememory_dtype_t plain_dtype;
+  int64_t plain_stride;               // elements
+  int64_t plain_storage_offset;       // elements
+  int max_blocks;                     // "gather_sms"/"scatter_sms": -1 = default
+};
+
+// per-rank bucketing of ids (see kernels/bucket.hip)
+struct wm_bucket_args {
+  const void* indices;  // [n] device
+  wholememory_dtype_t index_dtype;
+  int64_t n;
+  const uint64_t* entry_offsets;  // [world+1] device, row offsets
+  int world_size;
+  int64_t* counts;       // [world] device out: ids per owner (negatives not counted)
+  void* bucketed_ids;    // [n] device out (index dtype): ids grouped by owner, stable; may be nullptr
+  int64_t* raw_indices;  // [n] device out: original position of each bucketed id; may be nullptr
+  void* workspace;       // device scratch of bucket_workspace_bytes(n, world)
+};
+
+struct wm_optimizer_args {
+  int type;                    // wholememory_optimizer_type_t
+  const void* ids;             // [count] device: unique global row ids
+  wholememory_dtype_t index_dtype;
+  const int32_t* run_starts;   // [count+1] device: segment starts into order[]
+  const int32_t* order;        // [n_recv] device: receive-buffer positions sorted by (id, position)
+  const float* grads;          // [n_recv, grad_stride] device: received gradient rows
+  int64_t grad_stride;
+  int64_t count;               // number of unique ids (= grid size)
+  float* local_table;          // this rank's first row
+  int64_t table_stride;        // elements
+  int64_t local_entry_offset;  // global id of local row 0
+  int64_t dim;
+  float* per_element_state;    // adam: [rows, 2*stride] (m|v); adagrad/rmsprop: [rows, stride]; else nullptr
+  int64_t per_element_stride;
+  float* per_row_state;        // adam: [rows, 2] (beta1^t, beta2^t); else nullptr
+  float weight_decay, epsilon, beta1, beta2, alpha, lr;
+  int adam_w;
+};
+
+struct wm_device_backend {
+  const char* name;
+  // memory / stream
+  int (*device_count)();
+  int (*malloc_device)(void** p, size_t bytes);
+  int (*free_device)(void* p);
+  int (*malloc_pinned)(void** p, size_t bytes);
+  int (*free_pinned)(void* p);
+  int (*memcpy_async)(void* dst, const void* src, size_t bytes, void* stream);  // any direction (UVA)
+  int (*memset_async)(void* dst, int value, size_t bytes, void* stream);
+  int (*stream_sync)(void* stream);
+  // cross-process mapping of device allocations (hipIpc*): handle is 64 opaque bytes
+  int (*ipc_get_handle)(void* handle64, void* dev_ptr);
+  int (*ipc_open_handle)(void** dev_ptr, const void* handle64);
+  int (*ipc_close_handle)(void* dev_ptr);
+  // make a host range (shared-memory segment) device-visible; *dev_ptr = address kernels may use
+  int (*host_register)(void* host_ptr, size_t bytes, void** dev_ptr);
+  int (*host_unregister)(void* host_ptr);
+  // kernels (all asynchronous on `stream`)
+  int (*gather_rows)(const wm_rows_args* a, void* stream);
+  int (*scatter_rows)(const wm_rows_args* a, void* stream);
+  size_t (*bucket_workspace_bytes)(int64_t n, int world_size);
+  int (*bucket_ids)(const wm_bucket_args* a, void* stream);
+  // sort received ids as SIGNED keys (stable), emit unique ids, run starts and the sorted order.
+  // n_unique_out is a device int64. workspace from sort_workspace_bytes(n).
+  size_t (*dedup_workspace_bytes)(int64_t n, wholememory_dtype_t index_dtype);
+  int (*dedup_ids)(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound,
+                   void* unique_ids, int32_t* run_starts, int32_t* order, int64_t* n_unique_out, void* workspace,
+                   void* stream);
+  // fused duplicate-sum + optimizer update. a->count bounds the launch; when n_unique_dev != nullptr the true
+  // number of unique ids is read from that device scalar (no host sync to learn it).
+  int (*optimizer_step)(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);
+  int (*round_robin_map)(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n,
+                         int64_t entry_start, int world_size, int round_robin_size, void* stream);
+  int (*fill_float)(float* p, float value, int64_t count, void* stream);
+};
+
+}  // extern "C"
+
+namespace wm {
+const wm_device_backend* backend();      // the installed backend (HIP unless a test replaced it)
+const wm_device_backend* hip_backend();  // kernels/backend_hip.hip
+}  // namespace wm

@@ -1,0 +1,397 @@
+// wholegraph_amd — communicator implementation (see communicator.hpp).
+//
+// RCCL provider: one ncclComm_t per communicator, created from the 128-byte unique id that the host
+// framework broadcasts (reference flow: python torch/comm.py:152-167 -> communicator.cpp:703-752).
+// All-to-all-v is a grouped ncclSend/ncclRecv per peer on the CALLER's stream (xGMI is
+// point-to-point: 7 links per GPU, one per peer, so one grouped exchange drives every link at once);
+// the self segment never touches RCCL — it is a device-to-device copy on the same stream.
+// Host-side helpers (barrier, small allgathers) run on a private stream through a staging buffer,
+// like the reference's host_* family (nccl_comms.cpp:48-53,99-120), but there is exactly one
+// host round trip per call.
+#include "communicator.hpp"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "backend.hpp"
+#include "wm_common.hpp"
+
+namespace wm {
+
+#define WM_HIP_TRY(expr)                                                                                  \
+  do {                                                                                                    \
+    hipError_t e__ = (expr);                                                                              \
+    if (e__ != hipSuccess) throw ::wm::hip_error(::wm::format_string("%s -> %s", #expr, hipGetErrorString(e__))); \
+  } while (0)
+
+#define WM_NCCL_TRY(expr)                                                                                   \
+  do {                                                                                                      \
+    ncclResult_t r__ = (expr);                                                                              \
+    if (r__ != ncclSuccess) throw ::wm::comm_error(::wm::format_string("%s -> %s", #expr, ncclGetErrorString(r__))); \
+  } while (0)
+
+namespace {
+
+// order ranks of one color by (key, old rank); shared by every provider's split()
+struct split_entry {
+  int color, key, rank;
+};
+
+void plan_split(const std::vector<split_entry>& all, int color, int my_rank, int* new_rank, int* new_size,
+                std::vector<int>* members)
+{
+  std::vector<split_entry> mine;
+  for (auto& e : all)
+    if (e.color == color) mine.push_back(e);
+  std::stable_sort(mine.begin(), mine.end(), [](const split_entry& a, const split_entry& b) {
+    return a.key != b.key ? a.key < b.key : a.rank < b.rank;
+  });
+  *new_size = static_cast<int>(mine.size());
+  *new_rank = -1;
+  if (members) members->clear();
+  for (int i = 0; i < *new_size; i++) {
+    if (mine[i].rank == my_rank) *new_rank = i;
+    if (members) members->push_back(mine[i].rank);
+  }
+}
+
+class rccl_provider : public collective_provider {
+ public:
+  rccl_provider(ncclComm_t comm, int rank, int size) : comm_(comm), rank_(rank), size_(size)
+  {
+    WM_HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    WM_HIP_TRY(hipMalloc(&dev_stage_, kStageBytes));
+    WM_HIP_TRY(hipHostMalloc(&host_stage_, kStageBytes, hipHostMallocDefault));
+  }
+  ~rccl_provider() override
+  {
+    if (comm_ != nullptr) ncclCommDestroy(comm_);
+    if (dev_stage_) (void)hipFree(dev_stage_);
+    if (host_stage_) (void)hipHostFree(host_stage_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+  }
+  const char* name() const override { return "rccl"; }
+
+  void barrier() override
+  {  // reference nccl_comms.cpp:82-86: 1-int allreduce + sync
+    WM_NCCL_TRY(ncclAllReduce(dev_stage_, dev_stage_, 1, ncclInt32, ncclSum, comm_, stream_));
+    WM_HIP_TRY(hipStreamSynchronize(stream_));
+  }
+
+  void allgather_host(const void* send, void* recv, size_t bytes) override
+  {
+    if (bytes * (size_ + 1) > kStageBytes) throw comm_error("allgather_host payload too large for the staging buffer");
+    char* dsend = static_cast<char*>(dev_stage_);
+    char* drecv = dsend + bytes;
+    memcpy(host_stage_, send, bytes);
+    WM_HIP_TRY(hipMemcpyAsync(dsend, host_stage_, bytes, hipMemcpyHostToDevice, stream_));
+    WM_NCCL_TRY(ncclAllGather(dsend, drecv, bytes, ncclInt8, comm_, stream_));
+    WM_HIP_TRY(hipMemcpyAsync(static_cast<char*>(host_stage_) + bytes, drecv, bytes * size_, hipMemcpyDeviceToHost, stream_));
+    WM_HIP_TRY(hipStreamSynchronize(stream_));
+    memcpy(recv, static_cast<char*>(host_stage_) + bytes, bytes * size_);
+  }
+
+  void alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp, void* recv,
+                        const size_t* recv_bytes, const size_t* recv_disp, void* stream_v) override
+  {
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const char* s      = static_cast<const char*>(send);
+    char* r            = static_cast<char*>(recv);
+    if (send_bytes[rank_] != recv_bytes[rank_]) throw comm_error("alltoallv: self send/recv size mismatch");
+    if (send_bytes[rank_] > 0)
+      WM_HIP_TRY(hipMemcpyAsync(r + recv_disp[rank_], s + send_disp[rank_], send_bytes[rank_], hipMemcpyDeviceToDevice, stream));
+    WM_NCCL_TRY(ncclGroupStart());
+    for (int step = 1; step < size_; step++) {  // skewed order: rank r talks to r+step / r-step
+      int to   = (rank_ + step) % size_;
+      int from = (rank_ - step + size_) % size_;
+      if (recv_bytes[from] > 0) WM_NCCL_TRY(ncclRecv(r + recv_disp[from], recv_bytes[from], ncclInt8, from, comm_, stream));
+      if (send_bytes[to] > 0) WM_NCCL_TRY(ncclSend(s + send_disp[to], send_bytes[to], ncclInt8, to, comm_, stream));
+    }
+    WM_NCCL_TRY(ncclGroupEnd());
+  }
+
+  std::unique_ptr<collective_provider> split(int color, int key, int my_rank, int* new_rank, int* new_size) override
+  {
+    std::vector<split_entry> all(size_);
+    split_entry me{color, key, my_rank};
+    allgather_host(&me, all.data(), sizeof(split_entry));
+    ncclComm_t sub = nullptr;
+    WM_NCCL_TRY(ncclCommSplit(comm_, color < 0 ? NCCL_SPLIT_NOCOLOR : color, key, &sub, nullptr));
+    if (color < 0) {
+      *new_rank = -1, *new_size = 0;
+      return nullptr;
+    }
+    plan_split(all, color, my_rank, new_rank, new_size, nullptr);
+    return std::unique_ptr<collective_provider>(new rccl_provider(sub, *new_rank, *new_size));
+  }
+
+ private:
+  static constexpr size_t kStageBytes = 1 << 20;
+  ncclComm_t comm_                    = nullptr;
+  int rank_, size_;
+  hipStream_t stream_ = nullptr;
+  void* dev_stage_    = nullptr;
+  void* host_stage_   = nullptr;
+};
+
+// Collectives supplied by the host framework (wholegraph_amd_ext.h). A sub-group provider built by
+// split() routes through the parent with the member list applied.
+class ext_provider : public collective_provider {
+ public:
+  ext_provider(const wm_ext_collectives_t& c, int rank, int size) : c_(c), rank_(rank), size_(size) {}
+  const char* name() const override { return "external"; }
+  void barrier() override
+  {
+    if (c_.barrier(c_.ctx) != 0) throw comm_error("external barrier failed");
+  }
+  void allgather_host(const void* send, void* recv, size_t bytes) override
+  {
+    if (c_.allgather_host(c_.ctx, send, recv, bytes) != 0) throw comm_error("external allgather_host failed");
+  }
+  void alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp, void* recv,
+                        const size_t* recv_bytes, const size_t* recv_disp, void* stream) override
+  {
+    if (c_.alltoallv_device(c_.ctx, send, send_bytes, send_disp, recv, recv_bytes, recv_disp, stream) != 0)
+      throw comm_error("external alltoallv_device failed");
+  }
+  std::unique_ptr<collective_provider> split(int, int, int, int*, int*) override
+  {
+    throw logic_error("split is not available on an external-collectives communicator");
+  }
+
+ private:
+  wm_ext_collectives_t c_;
+  int rank_, size_;
+};
+
+int next_comm_id()
+{
+  static std::mutex m;
+  static int id = 0;
+  std::lock_guard<std::mutex> g(m);
+  return id++;
+}
+
+}  // namespace
+}  // namespace wm
+
+// ------------------------------------------------------------------------------------------------
+void wholememory_comm_::barrier()
+{
+  if (world_size > 1) transport->barrier();
+}
+
+void wholememory_comm_::allgather_host(const void* send, void* recv, size_t bytes)
+{
+  if (world_size == 1) {
+    memcpy(recv, send, bytes);
+    return;
+  }
+  transport->allgather_host(send, recv, bytes);
+}
+
+void wholememory_comm_::alltoall_host_i64(const int64_t* send, int64_t* recv)
+{
+  if (world_size == 1) {
+    recv[0] = send[0];
+    return;
+  }
+  // every rank learns the whole W x W matrix in one collective and reads its column
+  std::vector<int64_t> all(static_cast<size_t>(world_size) * world_size);
+  transport->allgather_host(send, all.data(), sizeof(int64_t) * world_size);
+  for (int r = 0; r < world_size; r++) recv[r] = all[static_cast<size_t>(r) * world_size + world_rank];
+}
+
+void wholememory_comm_::alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp,
+                                         void* recv, const size_t* recv_bytes, const size_t* recv_disp, void* stream)
+{
+  if (world_size == 1) {
+    if (send_bytes[0] > 0) {
+      int rc = wm::backend()->memcpy_async(static_cast<char*>(recv) + recv_disp[0],
+                                           static_cast<const char*>(send) + send_disp[0], send_bytes[0], stream);
+      if (rc != 0) throw wm::hip_error("self copy failed in alltoallv");
+    }
+    return;
+  }
+  transport->alltoallv_device(send, send_bytes, send_disp, recv, recv_bytes, recv_disp, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+wholememory_error_code_t wholememory_create_unique_id(wholememory_unique_id_t* unique_id)
+{
+  WM_API_BEGIN
+  if (unique_id == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  static_assert(sizeof(ncclUniqueId) <= WHOLEMEMORY_UNIQUE_ID_BYTES, "unique id does not fit");
+  ncclUniqueId id;
+  WM_NCCL_TRY(ncclGetUniqueId(&id));
+  memset(unique_id->internal, 0, WHOLEMEMORY_UNIQUE_ID_BYTES);
+  memcpy(unique_id->internal, &id, sizeof(id));
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_create_communicator(wholememory_comm_t* comm,
+                                                         wholememory_unique_id_t unique_id,
+                                                         int rank,
+                                                         int size)
+{
+  WM_API_BEGIN
+  if (comm == nullptr || size < 1 || rank < 0 || rank >= size) return WHOLEMEMORY_INVALID_INPUT;
+  auto* c       = new wholememory_comm_();
+  c->world_rank = rank;
+  c->world_size = size;
+  c->local_size = size;
+  c->comm_id    = wm::next_comm_id();
+  if (size > 1) {
+    ncclUniqueId id;
+    memcpy(&id, unique_id.internal, sizeof(id));
+    ncclComm_t nc = nullptr;
+    try {
+      WM_NCCL_TRY(ncclCommInitRank(&nc, size, id, rank));
+      c->transport.reset(new wm::rccl_provider(nc, rank, size));
+    } catch (...) {
+      delete c;
+      throw;
+    }
+  }
+  *comm = c;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_create_communicator_ext(wholememory_comm_t* comm,
+                                                             int rank,
+                                                             int size,
+                                                             const wm_ext_collectives_t* collectives)
+{
+  WM_API_BEGIN
+  if (comm == nullptr || size < 1 || rank < 0 || rank >= size) return WHOLEMEMORY_INVALID_INPUT;
+  if (size > 1 && (collectives == nullptr || collectives->barrier == nullptr ||
+                   collectives->allgather_host == nullptr || collectives->alltoallv_device == nullptr))
+    return WHOLEMEMORY_INVALID_INPUT;
+  auto* c       = new wholememory_comm_();
+  c->world_rank = rank;
+  c->world_size = size;
+  c->local_size = size;
+  c->comm_id    = wm::next_comm_id();
+  if (size > 1) c->transport.reset(new wm::ext_provider(*collectives, rank, size));
+  *comm = c;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_split_communicator(wholememory_comm_t* new_comm,
+                                                        wholememory_comm_t comm,
+                                                        int color,
+                                                        int key)
+{
+  WM_API_BEGIN
+  if (new_comm == nullptr || comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  *new_comm = nullptr;
+  if (comm->world_size == 1) {
+    if (color < 0) return WHOLEMEMORY_SUCCESS;
+    auto* c    = new wholememory_comm_();
+    c->comm_id = wm::next_comm_id();
+    *new_comm  = c;
+    return WHOLEMEMORY_SUCCESS;
+  }
+  int nr = -1, ns = 0;
+  auto sub = comm->transport->split(color, key, comm->world_rank, &nr, &ns);
+  if (color < 0) return WHOLEMEMORY_SUCCESS;
+  auto* c       = new wholememory_comm_();
+  c->world_rank = nr;
+  c->world_size = ns;
+  c->local_size = ns;
+  c->comm_id    = wm::next_comm_id();
+  if (ns > 1) c->transport = std::move(sub);
+  *new_comm = c;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_destroy_communicator(wholememory_comm_t comm)
+{
+  WM_API_BEGIN
+  if (comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (comm->live_handles != 0) WM_WARN("destroying communicator %d with %d live WholeMemory handles", comm->comm_id, comm->live_handles);
+  delete comm;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_communicator_support_type_location(wholememory_comm_t comm,
+                                                                        wholememory_memory_type_t memory_type,
+                                                                        wholememory_memory_location_t memory_location)
+{
+  if (comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (memory_location != WHOLEMEMORY_ML_DEVICE && memory_location != WHOLEMEMORY_ML_HOST) return WHOLEMEMORY_NOT_SUPPORTED;
+  switch (memory_type) {
+    case WHOLEMEMORY_MT_CONTINUOUS:
+    case WHOLEMEMORY_MT_CHUNKED:
+    case WHOLEMEMORY_MT_DISTRIBUTED: return WHOLEMEMORY_SUCCESS;
+    default: return WHOLEMEMORY_NOT_SUPPORTED;  // HIERARCHY: multi-node, out of scope
+  }
+}
+
+wholememory_error_code_t wholememory_communicator_get_rank(int* rank, wholememory_comm_t comm)
+{
+  if (rank == nullptr || comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  *rank = comm->world_rank;
+  return WHOLEMEMORY_SUCCESS;
+}
+wholememory_error_code_t wholememory_communicator_get_size(int* size, wholememory_comm_t comm)
+{
+  if (size == nullptr || comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  *size = comm->world_size;
+  return WHOLEMEMORY_SUCCESS;
+}
+wholememory_error_code_t wholememory_communicator_get_local_size(int* local_size, wholememory_comm_t comm)
+{
+  if (local_size == nullptr || comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  *local_size = comm->local_size;
+  return WHOLEMEMORY_SUCCESS;
+}
+wholememory_error_code_t wholememory_communicator_get_clique_info(clique_info_t* clique_info, wholememory_comm_t comm)
+{
+  if (clique_info == nullptr || comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  *clique_info                  = clique_info_t{};
+  clique_info->is_in_clique     = 0;
+  clique_info->clique_first_rank = -1;
+  clique_info->clique_rank      = -1;
+  clique_info->clique_rank_num  = 0;
+  clique_info->clique_id        = -1;
+  clique_info->clique_num       = 0;
+  return WHOLEMEMORY_SUCCESS;
+}
+bool wholememory_communicator_is_bind_to_nvshmem(wholememory_comm_t) { return false; }
+wholememory_error_code_t wholememory_communicator_set_distributed_backend(wholememory_comm_t comm,
+                                                                          wholememory_distributed_backend_t db)
+{
+  if (comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (db != WHOLEMEMORY_DB_NCCL) return WHOLEMEMORY_NOT_SUPPORTED;  // NVSHMEM has no counterpart here
+  comm->distributed_backend = db;
+  return WHOLEMEMORY_SUCCESS;
+}
+wholememory_distributed_backend_t wholememory_communicator_get_distributed_backend(wholememory_comm_t comm)
+{
+  return comm ? comm->distributed_backend : WHOLEMEMORY_DB_NONE;
+}
+wholememory_error_code_t wholememory_communicator_barrier(wholememory_comm_t comm)
+{
+  WM_API_BEGIN
+  if (comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  comm->barrier();
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+bool wholememory_is_intranode_communicator(wholememory_comm_t comm) { return comm != nullptr && comm->local_size == comm->world_size; }
+bool wholememory_is_intra_mnnvl_communicator(wholememory_comm_t) { return false; }
+bool wholememory_is_build_with_nvshmem() { return false; }
+
+}  // extern "C"

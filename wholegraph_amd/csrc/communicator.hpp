@@ -1,0 +1,50 @@
+// wholegraph_amd — communicator: rank bookkeeping + the collective transport.
+// Replaces the reference's wholememory_comm_ / nccl_comms pair (cpp/src/wholememory/communicator.hpp:38-232,
+// nccl_comms.cpp:82-515). Transport on MI355X is RCCL over xGMI; a world_size==1 communicator needs
+// no transport at all; an external provider (wholegraph_amd_ext.h) can be plugged for tests/hosts.
+#pragma once
+
+#include <cstddef>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include <wholememory/wholegraph_amd_ext.h>
+#include <wholememory/wholememory.h>
+
+namespace wm {
+
+class collective_provider {
+ public:
+  virtual ~collective_provider() = default;
+  virtual const char* name() const = 0;
+  virtual void barrier() = 0;
+  // host buffers: recv[r*bytes..] = rank r's send
+  virtual void allgather_host(const void* send, void* recv, size_t bytes) = 0;
+  // device buffers, byte counts/displacements indexed by peer rank; enqueued on `stream`
+  virtual void alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp, void* recv,
+                                const size_t* recv_bytes, const size_t* recv_disp, void* stream) = 0;
+  // new provider for the sub-group {ranks with the same color}, ordered by (key, old rank);
+  // returns nullptr for color == WHOLEMEMORY_SPILT_NO_COLOR
+  virtual std::unique_ptr<collective_provider> split(int color, int key, int my_rank, int* new_rank, int* new_size) = 0;
+};
+
+}  // namespace wm
+
+struct wholememory_comm_ {
+  int world_rank = 0;
+  int world_size = 1;
+  int local_size = 1;  // ranks on this node (single-node build: == world_size)
+  int comm_id    = 0;
+  wholememory_distributed_backend_t distributed_backend = WHOLEMEMORY_DB_NCCL;
+  std::unique_ptr<wm::collective_provider> transport;  // null when world_size == 1
+  std::mutex mu;                                       // guards handle create/destroy (reference communicator.hpp:226)
+  int live_handles = 0;
+
+  void barrier();
+  void allgather_host(const void* send, void* recv, size_t bytes);
+  // counts exchange: recv[r] = what rank r sends to me (reference host_alltoall, nccl_comms.cpp:383-407)
+  void alltoall_host_i64(const int64_t* send, int64_t* recv);
+  void alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp, void* recv,
+                        const size_t* recv_bytes, const size_t* recv_disp, void* stream);
+};

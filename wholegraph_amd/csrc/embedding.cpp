@@ -1,0 +1,616 @@
+// wholegraph_amd — WholeMemory embedding object + sparse optimizers (host orchestration).
+//
+// Reference: cpp/src/wholememory/embedding.cpp:43-50 (row padding), :87-144 (allocate), :146-323
+// (gather_gradient_apply), :325-448 (optimizer state tensors), :467-484 (round-robin shard size),
+// :946-1121 (C API); embedding_optimizer.cpp:100-538 (optimizer objects, parameters, states).
+//
+// Gradient apply on MI355X: ids are bucketed by owner (one multisplit pass), gradient rows are
+// lined up in send order and exchanged by RCCL all-to-all-v, and the owner runs ONE fused kernel per
+// step (duplicate-sum in the reference's order + optimizer update, kernels/optim.hip) — there is no
+// intermediate de-duplicated gradient buffer and no host sync to learn the unique count.
+// The device LFU cache of the reference (embedding_cache.*) is outside this build's scope:
+// creating an embedding with a cache policy returns WHOLEMEMORY_NOT_IMPLEMENTED.
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <wholememory/embedding.h>
+
+#include "ops_internal.hpp"
+
+struct wholememory_embedding_cache_policy_ {
+  wholememory_comm_t cache_comm;
+  wholememory_memory_type_t cache_memory_type;
+  wholememory_memory_location_t cache_memory_location;
+  wholememory_access_type_t access_type;
+  float cache_ratio;
+};
+
+struct wholememory_embedding_optimizer_ {
+  wholememory_optimizer_type_t type = WHOLEMEMORY_OPT_NONE;
+  // defaults: reference embedding_optimizer.cpp (class member initialisers)
+  float weight_decay = 0.0f;
+  float epsilon      = 1e-8f;
+  float beta1        = 0.9f;
+  float beta2        = 0.999f;
+  float alpha        = 0.99f;
+  float adam_w       = 0.0f;
+  std::vector<const char*> state_names;  // nullptr-terminated
+  std::map<std::string, float*> params;
+};
+
+struct wholememory_embedding_ {
+  wholememory_tensor_t allocated = nullptr;  // padded table [N, stride]
+  wholememory_tensor_t user      = nullptr;  // [N, dim] view handed to callers
+  wholememory_comm_t comm        = nullptr;
+  wholememory_dtype_t dtype      = WHOLEMEMORY_DT_UNKNOWN;
+  int gather_sms                 = -1;
+  int round_robin_size           = 0;
+  wholememory_embedding_optimizer_t optimizer = nullptr;
+  // optimizer state (reference optimizer_state_t)
+  wholememory_embedding_t state_embedding = nullptr;   // per-element states packed side by side
+  wholememory_tensor_t state_local        = nullptr;   // local shard of the packed states
+  std::map<std::string, wholememory_tensor_t> state_views;
+  wholememory_tensor_t per_row_padded = nullptr;       // "beta12t" [N_alloc, 2], DISTRIBUTED
+  wholememory_tensor_t per_row_view   = nullptr;
+  wholememory_tensor_t per_row_local  = nullptr;
+  int64_t state_row_elems             = 0;             // columns of the packed state table
+};
+
+namespace wm {
+namespace {
+
+#define WM_BK(call)                                                                                  \
+  do {                                                                                               \
+    int rc__ = (call);                                                                               \
+    if (rc__ != 0) throw ::wm::hip_error(::wm::format_string("%s failed with code %d", #call, rc__)); \
+  } while (0)
+
+int64_t align_embedding_dim(int64_t dim, size_t element_size)
+{  // rows padded to 16 bytes: reference embedding.cpp:43-50
+  const int64_t a = 16 / static_cast<int64_t>(element_size);
+  return dim % a == 0 ? dim : (dim / a + 1) * a;
+}
+
+int per_element_state_count(wholememory_optimizer_type_t t)
+{
+  switch (t) {
+    case WHOLEMEMORY_OPT_LAZY_ADAM: return 2;  // m, v
+    case WHOLEMEMORY_OPT_ADAGRAD: return 1;    // state_sum
+    case WHOLEMEMORY_OPT_RMSPROP: return 1;    // v
+    default: return 0;
+  }
+}
+
+void destroy_states(wholememory_embedding_* e)
+{
+  for (auto& kv : e->state_views) {
+    if (kv.second != e->per_row_view) wholememory_destroy_tensor(kv.second);
+  }
+  e->state_views.clear();
+  if (e->state_local) wholememory_destroy_tensor(e->state_local);
+  if (e->state_embedding) wholememory_destroy_embedding(e->state_embedding);
+  if (e->per_row_local) wholememory_destroy_tensor(e->per_row_local);
+  if (e->per_row_view) wholememory_destroy_tensor(e->per_row_view);
+  if (e->per_row_padded) wholememory_destroy_tensor(e->per_row_padded);
+  e->state_local = e->per_row_local = e->per_row_view = e->per_row_padded = nullptr;
+  e->state_embedding                                                       = nullptr;
+}
+
+// reference embedding.cpp:325-428 (create_optimizer_states) + init_optimizer_states of each optimizer
+wholememory_error_code_t create_states(wholememory_embedding_* e)
+{
+  const auto* bk   = backend();
+  auto* opt        = e->optimizer;
+  auto* alloc_desc = wholememory_tensor_get_tensor_description(e->allocated);
+  auto* user_desc  = wholememory_tensor_get_tensor_description(e->user);
+  const int64_t dim = user_desc->sizes[1];
+  int W;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_communicator_get_size(&W, e->comm));
+  std::vector<size_t> alloc_part(W), user_part(W);
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_get_entry_partition_sizes(alloc_part.data(), e->allocated));
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_get_entry_partition_sizes(user_part.data(), e->user));
+
+  const int n_states = per_element_state_count(opt->type);
+  if (n_states > 0) {
+    const size_t es       = wholememory_dtype_get_element_size(user_desc->dtype);
+    const int64_t aligned = align_embedding_dim(dim, es);
+    e->state_row_elems    = aligned * n_states;
+    wholememory_tensor_description_t sd = *user_desc;
+    sd.sizes[1]                         = e->state_row_elems;
+    sd.strides[0]                       = e->state_row_elems;
+    auto h  = wholememory_tensor_get_memory_handle(e->allocated);
+    WHOLEMEMORY_RETURN_ON_FAIL(wholememory_create_embedding(&e->state_embedding, &sd, e->comm,
+                                                            wholememory_get_memory_type(h),
+                                                            wholememory_get_memory_location(h), nullptr,
+                                                            user_part.data(), -1, 0));
+    auto state_user = wholememory_embedding_get_embedding_tensor(e->state_embedding);
+    WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_map_local_tensor(state_user, &e->state_local));
+    const char* names_adam[] = {"m", "v"};
+    for (int i = 0; i < n_states; i++) {
+      const char* nm = opt->type == WHOLEMEMORY_OPT_LAZY_ADAM ? names_adam[i]
+                       : opt->type == WHOLEMEMORY_OPT_ADAGRAD ? "state_sum"
+                                                              : "v";
+      int64_t starts[2] = {0, aligned * i};
+      int64_t ends[2]   = {-1, aligned * i + dim};
+      wholememory_tensor_t view;
+      WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_get_subtensor(state_user, starts, ends, &view));
+      e->state_views[nm] = view;
+    }
+    // zero the local shard of the packed states (reference zero_local_state_tensor)
+    auto* ld = wholememory_tensor_get_tensor_description(e->state_local);
+    WM_BK(bk->memset_async(wholememory_tensor_get_data_pointer(e->state_local), 0,
+                           static_cast<size_t>(ld->sizes[0]) * ld->strides[0] * sizeof(float), nullptr));
+  }
+  if (opt->type == WHOLEMEMORY_OPT_LAZY_ADAM) {
+    // per-row [beta1^t, beta2^t]: DISTRIBUTED device tensor partitioned like the table, init 1.0
+    wholememory_tensor_description_t pd = *alloc_desc;
+    pd.dtype                            = WHOLEMEMORY_DT_FLOAT;
+    pd.sizes[1] = pd.strides[0] = 2;
+    WHOLEMEMORY_RETURN_ON_FAIL(wholememory_create_tensor(&e->per_row_padded, &pd, e->comm, WHOLEMEMORY_MT_DISTRIBUTED,
+                                                         WHOLEMEMORY_ML_DEVICE, alloc_part.data()));
+    int64_t starts[2] = {0, 0};
+    int64_t ends[2]   = {user_desc->sizes[0], 2};
+    WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_get_subtensor(e->per_row_padded, starts, ends, &e->per_row_view));
+    WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_map_local_tensor(e->per_row_view, &e->per_row_local));
+    e->state_views["beta12t"] = e->per_row_view;
+    auto* ld = wholememory_tensor_get_tensor_description(e->per_row_local);
+    WM_BK(bk->fill_float(static_cast<float*>(wholememory_tensor_get_data_pointer(e->per_row_local)), 1.0f,
+                         ld->sizes[0] * 2, nullptr));
+  }
+  WM_BK(bk->stream_sync(nullptr));
+  return WHOLEMEMORY_SUCCESS;
+}
+
+void fill_optimizer_args(wm_optimizer_args* a, const wholememory_embedding_optimizer_* o, float lr)
+{
+  a->type         = o->type;
+  a->weight_decay = o->weight_decay;
+  a->epsilon      = o->epsilon;
+  a->beta1        = o->beta1;
+  a->beta2        = o->beta2;
+  a->alpha        = o->alpha;
+  a->adam_w       = o->adam_w > 0.5f ? 1 : 0;
+  a->lr           = lr;
+}
+
+// owner side: sort received ids, then the fused duplicate-sum + optimizer kernel
+void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64_t n_recv, const float* recv_grads,
+                    int64_t grad_stride, wm_optimizer_args* oa, int64_t key_upper_bound, wholememory_env_func_t* env,
+                    void* stream, int64_t* n_unique_host)
+{
+  const auto* bk = backend();
+  if (n_recv == 0) {
+    if (n_unique_host) *n_unique_host = 0;
+    return;
+  }
+  temp_mem unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env), host_n(env);
+  void* d_unique  = unique_ids.device(n_recv, index_dtype);
+  auto* d_starts  = static_cast<int32_t*>(run_starts.device(n_recv + 1, WHOLEMEMORY_DT_INT));
+  auto* d_order   = static_cast<int32_t*>(order.device(n_recv, WHOLEMEMORY_DT_INT));
+  auto* d_nunique = static_cast<int64_t*>(n_unique.device(1, WHOLEMEMORY_DT_INT64));
+  void* d_ws      = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n_recv, index_dtype)), WHOLEMEMORY_DT_INT8);
+  int rc = bk->dedup_ids(recv_ids, index_dtype, n_recv, key_upper_bound, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
+  if (rc == -1) throw logic_error("dedup_ids: unsupported index dtype or more than 2^31 received ids");
+  if (rc != 0) throw hip_error("dedup_ids failed");
+  oa->ids         = d_unique;
+  oa->index_dtype = index_dtype;
+  oa->run_starts  = d_starts;
+  oa->order       = d_order;
+  oa->grads       = recv_grads;
+  oa->grad_stride = grad_stride;
+  oa->count       = n_recv;  // upper bound; the kernel reads the true count from d_nunique
+  rc              = bk->optimizer_step(oa, d_nunique, stream);
+  if (rc != 0) throw hip_error("optimizer_step failed");
+  if (n_unique_host != nullptr) {
+    auto* h = static_cast<int64_t*>(host_n.pinned(1, WHOLEMEMORY_DT_INT64));
+    WM_BK(bk->memcpy_async(h, d_nunique, sizeof(int64_t), stream));
+    WM_BK(bk->stream_sync(stream));
+    *n_unique_host = *h;
+  }
+}
+
+// reference embedding.cpp:146-323
+wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholememory_tensor_t indices,
+                                               wholememory_tensor_t grads, float lr, wholememory_env_func_t* env,
+                                               void* stream)
+{
+  const auto* bk  = backend();
+  auto* idesc     = wholememory_tensor_get_tensor_description(indices);
+  auto* gdesc     = wholememory_tensor_get_tensor_description(grads);
+  auto* adesc     = wholememory_tensor_get_tensor_description(e->allocated);
+  WM_CHECK_ABORT(idesc->dim == 1, "indices must be 1-D");
+  if (e->optimizer == nullptr) {
+    WM_ERROR("gather_gradient_apply: no optimizer set on this embedding");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  wholememory_array_description_t iarr;
+  wholememory_matrix_description_t gmat;
+  if (!wholememory_convert_tensor_desc_to_array(&iarr, idesc) || !wholememory_convert_tensor_desc_to_matrix(&gmat, gdesc))
+    return WHOLEMEMORY_INVALID_INPUT;
+  if (gmat.dtype != WHOLEMEMORY_DT_FLOAT) {
+    WM_ERROR("gradients must be float32 (reference exchange_embeddings_nccl_func.cu:192)");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (gmat.sizes[0] != iarr.size) return WHOLEMEMORY_INVALID_INPUT;
+  auto* udesc       = wholememory_tensor_get_tensor_description(e->user);
+  const int64_t dim = gmat.sizes[1];
+  if (dim != udesc->sizes[1]) return WHOLEMEMORY_INVALID_INPUT;
+
+  std::vector<size_t> entry_offsets(e->comm->world_size + 1);
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_get_entry_offsets(entry_offsets.data(), e->allocated));
+  const size_t ies    = wholememory_dtype_get_element_size(iarr.dtype);
+  const char* idx_ptr = static_cast<const char*>(wholememory_tensor_get_data_pointer(indices));  // data ptr already offset
+
+  id_exchange x(env);
+  bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x);
+  (void)ies;
+
+  // gradient rows in send order, then to their owners (embedding.cpp:205-246)
+  temp_mem send_rows(env), recv_rows(env);
+  auto* send_buf = static_cast<float*>(send_rows.device(dim * x.total_send, WHOLEMEMORY_DT_FLOAT));
+  auto* recv_buf = static_cast<float*>(recv_rows.device(dim * x.total_recv, WHOLEMEMORY_DT_FLOAT));
+  wm_rows_args ga{};
+  ga.gref                 = wholememory_create_continuous_global_reference(wholememory_tensor_get_data_pointer(grads));
+  ga.table_dtype          = WHOLEMEMORY_DT_FLOAT;
+  ga.dim                  = dim;
+  ga.table_stride         = gmat.stride;
+  ga.table_storage_offset = 0;  // data pointer already carries the view offset
+  ga.indices              = x.raw_indices;
+  ga.index_dtype          = WHOLEMEMORY_DT_INT64;
+  ga.n                    = x.total_send;
+  ga.plain                = send_buf;
+  ga.plain_dtype          = WHOLEMEMORY_DT_FLOAT;
+  ga.plain_stride         = dim;
+  ga.max_blocks           = -1;
+  WM_BK(bk->gather_rows(&ga, stream));
+  exchange_rows(e->comm, send_buf, x.send_counts, recv_buf, x.recv_counts, static_cast<size_t>(dim) * sizeof(float), stream);
+
+  // owner: fused dedup + step on the local shard (embedding.cpp:248-318)
+  wholememory_tensor_t local_table;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_map_local_tensor(e->user, &local_table));
+  wm_optimizer_args oa{};
+  fill_optimizer_args(&oa, e->optimizer, lr);
+  oa.local_table        = static_cast<float*>(wholememory_tensor_get_data_pointer(local_table));
+  oa.table_stride       = adesc->strides[0];
+  oa.local_entry_offset = static_cast<int64_t>(entry_offsets[e->comm->world_rank]);
+  oa.dim                = dim;
+  if (e->state_local != nullptr) {
+    oa.per_element_state  = static_cast<float*>(wholememory_tensor_get_data_pointer(e->state_local));
+    oa.per_element_stride = wholememory_tensor_get_tensor_description(e->state_local)->strides[0];
+  }
+  if (e->per_row_local != nullptr)
+    oa.per_row_state = static_cast<float*>(wholememory_tensor_get_data_pointer(e->per_row_local));
+  wholememory_destroy_tensor(local_table);
+  dedup_and_step(x.recv_ids, iarr.dtype, x.total_recv, recv_buf, dim, &oa,
+                 static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr);
+  // temporaries go back to the caller's allocator on return; like the reference's distributed ops
+  // the stream is drained first so nothing in flight still reads them
+  WM_BK(bk->stream_sync(stream));
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t remap_round_robin(wholememory_embedding_* e, wholememory_tensor_t indices, temp_mem* mapped_mem,
+                                           wholememory_tensor_t* mapped, void* stream)
+{
+  auto* idesc = wholememory_tensor_get_tensor_description(indices);
+  void* mp    = mapped_mem->device(idesc->sizes[0], idesc->dtype);
+  wholememory_tensor_description_t md = *idesc;
+  md.storage_offset                   = 0;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_make_tensor_from_pointer(mapped, mp, &md));
+  size_t entry_start = 0;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_get_local_entry_start(&entry_start, e->allocated));
+  int rc = backend()->round_robin_map(wholememory_tensor_get_data_pointer(indices), mp, idesc->dtype, idesc->sizes[0],
+                                      static_cast<int64_t>(entry_start), e->comm->world_size, e->round_robin_size, stream);
+  if (rc != 0) return WHOLEMEMORY_CUDA_ERROR;
+  // reference map_indices_func.cu:56-63 synchronises after the remap
+  return backend()->stream_sync(stream) == 0 ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_CUDA_ERROR;
+}
+
+}  // namespace
+}  // namespace wm
+
+extern "C" {
+
+// ---------------------------------------------------------------- optimizers
+wholememory_error_code_t wholememory_create_embedding_optimizer(wholememory_embedding_optimizer_t* optimizer,
+                                                                wholememory_optimizer_type_t optimizer_type)
+{
+  WM_API_BEGIN
+  if (optimizer == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  auto* o = new wholememory_embedding_optimizer_();
+  o->type = optimizer_type;
+  o->params["weight_decay"] = &o->weight_decay;
+  switch (optimizer_type) {
+    case WHOLEMEMORY_OPT_SGD: o->state_names = {nullptr}; break;
+    case WHOLEMEMORY_OPT_LAZY_ADAM:
+      o->params["epsilon"] = &o->epsilon;
+      o->params["beta1"]   = &o->beta1;
+      o->params["beta2"]   = &o->beta2;
+      o->params["adam_w"]  = &o->adam_w;
+      o->state_names       = {"m", "v", "beta12t", nullptr};
+      break;
+    case WHOLEMEMORY_OPT_ADAGRAD:
+      o->params["epsilon"] = &o->epsilon;
+      o->state_names       = {"state_sum", nullptr};
+      break;
+    case WHOLEMEMORY_OPT_RMSPROP:
+      o->params["epsilon"] = &o->epsilon;
+      o->params["alpha"]   = &o->alpha;
+      o->state_names       = {"v", nullptr};
+      break;
+    default:
+      delete o;
+      return WHOLEMEMORY_NOT_IMPLEMENTED;  // reference embedding_optimizer.cpp:509-516
+  }
+  *optimizer = o;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_optimizer_set_parameter(wholememory_embedding_optimizer_t optimizer,
+                                                             const char* parameter_name,
+                                                             void* value)
+{
+  if (optimizer == nullptr || parameter_name == nullptr || value == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  auto it = optimizer->params.find(parameter_name);
+  if (it == optimizer->params.end()) {
+    WM_ERROR("optimizer has no parameter named '%s'", parameter_name);
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  *it->second = *static_cast<float*>(value);
+  return WHOLEMEMORY_SUCCESS;
+}
+
+void wholememory_destroy_embedding_optimizer(wholememory_embedding_optimizer_t optimizer) { delete optimizer; }
+
+// ---------------------------------------------------------------- cache policy (object only)
+wholememory_error_code_t wholememory_create_embedding_cache_policy(wholememory_embedding_cache_policy_t* cache_policy,
+                                                                   wholememory_comm_t cache_level_comm,
+                                                                   wholememory_memory_type_t memory_type,
+                                                                   wholememory_memory_location_t memory_location,
+                                                                   wholememory_access_type_t access_type,
+                                                                   float cache_ratio)
+{
+  if (cache_policy == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (cache_ratio > 1.0F || cache_ratio < 1.0F / 512) {  // reference embedding.cpp:908-912
+    WM_ERROR("cache_ratio should in range [1/512, 1.0]");
+    return WHOLEMEMORY_INVALID_VALUE;
+  }
+  auto* p                  = new wholememory_embedding_cache_policy_();
+  p->cache_comm            = cache_level_comm;
+  p->cache_memory_type     = memory_type;
+  p->cache_memory_location = memory_location;
+  p->access_type           = access_type;
+  p->cache_ratio           = cache_ratio;
+  *cache_policy            = p;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t wholememory_destroy_embedding_cache_policy(wholememory_embedding_cache_policy_t cache_policy)
+{
+  delete cache_policy;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+// ---------------------------------------------------------------- embedding lifetime
+wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* wholememory_embedding,
+                                                      wholememory_tensor_description_t* embedding_description,
+                                                      wholememory_comm_t comm,
+                                                      wholememory_memory_type_t memory_type,
+                                                      wholememory_memory_location_t memory_location,
+                                                      wholememory_embedding_cache_policy_t cache_policy,
+                                                      size_t* embedding_entry_partition,
+                                                      int user_defined_sms,
+                                                      int round_robin_size)
+{
+  WM_API_BEGIN
+  if (wholememory_embedding == nullptr || embedding_description == nullptr || comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_matrix_description_t md;
+  if (!wholememory_convert_tensor_desc_to_matrix(&md, embedding_description) || embedding_description->dim != 2) {
+    WM_ERROR("wholememory_create_embedding input description must be 2D matrix");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (cache_policy != nullptr) {
+    WM_ERROR("cached embeddings (device LFU cache) are not part of this build — create the embedding without a cache policy");
+    return WHOLEMEMORY_NOT_IMPLEMENTED;
+  }
+  if (embedding_entry_partition != nullptr) {
+    if (round_robin_size != 0) WM_WARN("Parameter 'round_robin_size' is ignored.");
+    round_robin_size = 0;
+  }
+  int W;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_communicator_get_size(&W, comm));
+  std::unique_ptr<wholememory_embedding_> e(new wholememory_embedding_());
+  e->comm             = comm;
+  e->dtype            = md.dtype;
+  e->round_robin_size = round_robin_size;
+  if (round_robin_size != 0) {
+    // every rank holds the same, rr-aligned share: reference embedding.cpp:467-484
+    int64_t total = md.sizes[0];
+    int extra     = static_cast<int>(total % (static_cast<int64_t>(W) * round_robin_size));
+    if (extra > round_robin_size) extra = round_robin_size;
+    int64_t first = total / (static_cast<int64_t>(W) * round_robin_size) * round_robin_size + extra;
+    md.sizes[0]   = first * W;
+  }
+  // reference embedding.cpp:450-463
+  if (user_defined_sms != -1 && (user_defined_sms <= 0 || user_defined_sms > 1568)) {
+    WM_WARN("Illegal SM number for gather/scatter! Will use default size.");
+    user_defined_sms = -1;
+  }
+  e->gather_sms = user_defined_sms;
+
+  wholememory_tensor_description_t padded;
+  wholememory_copy_matrix_desc_to_tensor(&padded, &md);
+  padded.storage_offset = 0;
+  padded.strides[0]     = wm::align_embedding_dim(md.sizes[1], wholememory_dtype_get_element_size(md.dtype));
+  padded.strides[1]     = 1;
+  WHOLEMEMORY_RETURN_ON_FAIL(
+    wholememory_create_tensor(&e->allocated, &padded, comm, memory_type, memory_location, embedding_entry_partition));
+  int64_t starts[2] = {0, 0};
+  int64_t ends[2]   = {md.sizes[0], md.sizes[1]};
+  auto rc           = wholememory_tensor_get_subtensor(e->allocated, starts, ends, &e->user);
+  if (rc != WHOLEMEMORY_SUCCESS) {
+    wholememory_destroy_tensor(e->allocated);
+    return rc;
+  }
+  *wholememory_embedding = e.release();
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_destroy_embedding(wholememory_embedding_t e)
+{
+  WM_API_BEGIN
+  if (e == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  wm::destroy_states(e);
+  if (e->user) wholememory_destroy_tensor(e->user);
+  if (e->allocated) wholememory_destroy_tensor(e->allocated);
+  delete e;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_tensor_t wholememory_embedding_get_embedding_tensor(wholememory_embedding_t e) { return e ? e->user : nullptr; }
+
+wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embedding_t e,
+                                                             wholememory_embedding_optimizer_t optimizer)
+{
+  WM_API_BEGIN
+  if (e == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (e->optimizer != nullptr) {
+    WM_ERROR("optimizer can only be set once.");
+    return WHOLEMEMORY_NOT_SUPPORTED;
+  }
+  if (optimizer == nullptr) return WHOLEMEMORY_SUCCESS;
+  if (e->dtype != WHOLEMEMORY_DT_FLOAT) {
+    WM_ERROR("Only float embedding supports training.");
+    return WHOLEMEMORY_NOT_IMPLEMENTED;
+  }
+  e->optimizer = optimizer;
+  auto rc      = wm::create_states(e);
+  if (rc != WHOLEMEMORY_SUCCESS) {
+    wm::destroy_states(e);
+    e->optimizer = nullptr;
+  }
+  return rc;
+  WM_API_END
+}
+
+// ---------------------------------------------------------------- hot path
+wholememory_error_code_t wholememory_embedding_gather(wholememory_embedding_t e,
+                                                      wholememory_tensor_t indices,
+                                                      wholememory_tensor_t output,
+                                                      bool adjust_cache,
+                                                      wholememory_env_func_t* p_env_fns,
+                                                      int64_t stream_int)
+{
+  WM_API_BEGIN
+  (void)adjust_cache;
+  if (e == nullptr || indices == nullptr || output == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  void* stream = reinterpret_cast<void*>(stream_int);
+  if (e->round_robin_size == 0) return wholememory_gather(e->allocated, indices, output, p_env_fns, stream, e->gather_sms);
+  wm::temp_mem mapped_mem(p_env_fns);
+  wholememory_tensor_t mapped = nullptr;
+  WHOLEMEMORY_RETURN_ON_FAIL(wm::remap_round_robin(e, indices, &mapped_mem, &mapped, stream));
+  auto rc = wholememory_gather(e->allocated, mapped, output, p_env_fns, stream, e->gather_sms);
+  wholememory_destroy_tensor(mapped);
+  return rc;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_embedding_gather_gradient_apply(wholememory_embedding_t e,
+                                                                     wholememory_tensor_t indices,
+                                                                     wholememory_tensor_t grads,
+                                                                     bool adjust_cache,
+                                                                     float lr,
+                                                                     wholememory_env_func_t* p_env_fns,
+                                                                     int64_t stream_int)
+{
+  WM_API_BEGIN
+  (void)adjust_cache;
+  if (e == nullptr || indices == nullptr || grads == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  void* stream = reinterpret_cast<void*>(stream_int);
+  if (e->round_robin_size == 0) return wm::gather_gradient_apply(e, indices, grads, lr, p_env_fns, stream);
+  wm::temp_mem mapped_mem(p_env_fns);
+  wholememory_tensor_t mapped = nullptr;
+  WHOLEMEMORY_RETURN_ON_FAIL(wm::remap_round_robin(e, indices, &mapped_mem, &mapped, stream));
+  auto rc = wm::gather_gradient_apply(e, mapped, grads, lr, p_env_fns, stream);
+  wholememory_destroy_tensor(mapped);
+  return rc;
+  WM_API_END
+}
+
+const char* const* wholememory_embedding_get_optimizer_state_names(wholememory_embedding_t e)
+{
+  static const char* const kNone[] = {nullptr};
+  if (e == nullptr || e->optimizer == nullptr) return kNone;  // reference returns nullptr-terminated list
+  return e->optimizer->state_names.data();
+}
+
+wholememory_tensor_t wholememory_embedding_get_optimizer_state(wholememory_embedding_t e, const char* name)
+{
+  if (e == nullptr || name == nullptr) return nullptr;
+  auto it = e->state_views.find(name);
+  return it == e->state_views.end() ? nullptr : it->second;
+}
+
+wholememory_error_code_t wholememory_embedding_writeback_cache(wholememory_embedding_t e, int64_t)
+{
+  return e ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;  // no cache in this build: nothing to write back
+}
+wholememory_error_code_t wholememory_embedding_drop_all_cache(wholememory_embedding_t e, int64_t)
+{
+  return e ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;
+}
+
+// ---------------------------------------------------------------- raw stage for parity tests
+wholememory_error_code_t wholememory_ext_dedup_apply(const void* recv_ids,
+                                                     wholememory_dtype_t index_dtype,
+                                                     int64_t n_recv,
+                                                     const float* recv_grads,
+                                                     int64_t grad_stride,
+                                                     int64_t dim,
+                                                     float* local_table,
+                                                     int64_t table_stride,
+                                                     int64_t local_entry_offset,
+                                                     int64_t local_entry_count,
+                                                     wholememory_optimizer_type_t opt_type,
+                                                     const float* opt_params,
+                                                     float lr,
+                                                     float* per_element_state,
+                                                     float* per_row_state,
+                                                     int64_t* n_unique_host,
+                                                     wholememory_env_func_t* p_env_fns,
+                                                     void* stream)
+{
+  WM_API_BEGIN
+  if (opt_params == nullptr || local_table == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_embedding_optimizer_ o;
+  o.type         = opt_type;
+  o.weight_decay = opt_params[0];
+  o.epsilon      = opt_params[1];
+  o.beta1        = opt_params[2];
+  o.beta2        = opt_params[3];
+  o.alpha        = opt_params[4];
+  o.adam_w       = opt_params[5];
+  wm_optimizer_args oa{};
+  wm::fill_optimizer_args(&oa, &o, lr);
+  oa.local_table        = local_table;
+  oa.table_stride       = table_stride;
+  oa.local_entry_offset = local_entry_offset;
+  oa.dim                = dim;
+  oa.per_element_state  = per_element_state;
+  oa.per_element_stride = table_stride * wm::per_element_state_count(opt_type);
+  oa.per_row_state      = per_row_state;
+  int64_t nu            = 0;
+  wm::dedup_and_step(recv_ids, index_dtype, n_recv, recv_grads, grad_stride, &oa, local_entry_offset + local_entry_count,
+                     p_env_fns, stream, &nu);
+  if (n_unique_host) *n_unique_host = nu;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+}  // extern "C"

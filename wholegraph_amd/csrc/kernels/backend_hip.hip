@@ -1,0 +1,101 @@
+// wholegraph_amd — the HIP implementation of the device seam (backend.hpp): raw HIP memory /
+// stream calls plus the launchers of the hand-written gfx950 kernels in this directory.
+#include <hip/hip_runtime.h>
+
+#include "../backend.hpp"
+
+namespace wm {
+
+int hip_gather_rows(const wm_rows_args* a, void* stream);
+int hip_scatter_rows(const wm_rows_args* a, void* stream);
+size_t hip_bucket_workspace_bytes(int64_t n, int world_size);
+int hip_bucket_ids(const wm_bucket_args* a, void* stream);
+size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype);
+int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound,
+                  void* unique_ids, int32_t* run_starts, int32_t* order, int64_t* n_unique_out, void* workspace,
+                  void* stream);
+int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);
+int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n, int64_t entry_start,
+                        int world_size, int round_robin_size, void* stream);
+int hip_fill_float(float* p, float value, int64_t count, void* stream);
+
+namespace {
+
+int rc(hipError_t e) { return e == hipSuccess ? 0 : static_cast<int>(e); }
+
+int h_device_count()
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int h_malloc_device(void** p, size_t bytes) { return rc(hipMalloc(p, bytes)); }
+int h_free_device(void* p) { return rc(hipFree(p)); }
+int h_malloc_pinned(void** p, size_t bytes) { return rc(hipHostMalloc(p, bytes, hipHostMallocDefault)); }
+int h_free_pinned(void* p) { return rc(hipHostFree(p)); }
+int h_memcpy_async(void* dst, const void* src, size_t bytes, void* stream)
+{
+  return rc(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
+}
+int h_memset_async(void* dst, int value, size_t bytes, void* stream)
+{
+  return rc(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));
+}
+int h_stream_sync(void* stream) { return rc(hipStreamSynchronize(static_cast<hipStream_t>(stream))); }
+static_assert(sizeof(hipIpcMemHandle_t) <= 64, "ipc handle does not fit the 64-byte slot");
+int h_ipc_get(void* handle64, void* dev_ptr)
+{
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, dev_ptr);
+  if (e == hipSuccess) {
+    __builtin_memset(handle64, 0, 64);
+    __builtin_memcpy(handle64, &h, sizeof(h));
+  }
+  return rc(e);
+}
+int h_ipc_open(void** dev_ptr, const void* handle64)
+{
+  hipIpcMemHandle_t h;
+  __builtin_memcpy(&h, handle64, sizeof(h));
+  return rc(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+}
+int h_ipc_close(void* dev_ptr) { return rc(hipIpcCloseMemHandle(dev_ptr)); }
+int h_host_register(void* host_ptr, size_t bytes, void** dev_ptr)
+{
+  hipError_t e = hipHostRegister(host_ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  if (e != hipSuccess) return rc(e);
+  return rc(hipHostGetDevicePointer(dev_ptr, host_ptr, 0));
+}
+int h_host_unregister(void* host_ptr) { return rc(hipHostUnregister(host_ptr)); }
+
+const wm_device_backend kHipBackend = {
+  "hip-gfx950",
+  h_device_count,
+  h_malloc_device,
+  h_free_device,
+  h_malloc_pinned,
+  h_free_pinned,
+  h_memcpy_async,
+  h_memset_async,
+  h_stream_sync,
+  h_ipc_get,
+  h_ipc_open,
+  h_ipc_close,
+  h_host_register,
+  h_host_unregister,
+  hip_gather_rows,
+  hip_scatter_rows,
+  hip_bucket_workspace_bytes,
+  hip_bucket_ids,
+  hip_dedup_workspace_bytes,
+  hip_dedup_ids,
+  hip_optimizer_step_dev,
+  hip_round_robin_map,
+  hip_fill_float,
+};
+
+}  // namespace
+
+const wm_device_backend* hip_backend() { return &kHipBackend; }
+
+}  // namespace wm

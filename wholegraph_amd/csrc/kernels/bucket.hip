@@ -1,0 +1,247 @@
+// wholegraph_amd — per-owner bucketing of lookup ids for the DISTRIBUTED exchange (gfx950 HIP).
+//
+// Reference behaviour being replaced (cpp/src/wholememory_ops/functions/):
+//   bucket_ids_func.cu:51-87            counts[r] = #{ids owned by rank r}, negatives not counted
+//   exchange_ids_nccl_func.cu:42-92     full-width stable radix sort of (unsigned id, position) so
+//                                       that ids come out grouped by owner (owners hold contiguous
+//                                       id ranges) with `raw_indices` = original positions
+// MI355X design: grouping by owner does not need a sort. A stable W+1-way multisplit (W owners +
+// one trailing bucket for negative ids, which the reference's unsigned sort also parks last and
+// never sends) produces, in two streaming passes over the ids,
+//   bucketed_ids : ids grouped by owner, ORIGINAL ORDER preserved inside each owner's segment
+//   raw_indices  : original position of each bucketed id (int64, as gather_op_impl_nccl.cu:69-70)
+//   counts       : bit-identical to the reference histogram
+// Within an owner segment the reference has ids ascending (ties by position) where this has plain
+// position order; both are stable w.r.t. equal ids, so every user-visible result (gathered rows,
+// and the fp32 summation order of duplicate gradient rows at the owner) is identical.
+// tests/ pin that: sorting each segment of (bucketed_ids, raw_indices) by id, stably, reproduces
+// the oracle's sort_ids() output bit for bit.
+//
+// Kernels: (1) per-block histogram over a contiguous chunk, wave-ballot "peel" loop (one ballot
+// per DISTINCT owner present in the wave, __popcll for the count); (2) one-block exclusive scan of
+// the bucket-major [bucket][block] count matrix; (3) scatter: the same peel loop gives each lane
+// its rank among equal-owner lanes via __popcll(mask & lanemask_lt); wave bases come from a tiny
+// LDS prefix over the 4 waves of the block. Index traffic only: HBM-bound, no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "../backend.hpp"
+
+namespace wm {
+namespace {
+
+constexpr int kBlock      = 256;
+constexpr int kWaves      = kBlock / 64;
+constexpr int kItems      = 4;                       // 64-id groups per wave per block iteration
+constexpr int kIterItems  = kBlock * kItems;         // 1024 ids per block iteration
+constexpr int kMaxBlocks  = 2048;
+constexpr int kMaxBuckets = 257;                     // world_size <= 256
+
+struct bucket_geom {
+  int64_t chunk;  // ids per block (multiple of kIterItems)
+  int blocks;
+};
+
+inline bucket_geom geometry(int64_t n)
+{
+  bucket_geom g;
+  int64_t want = std::max<int64_t>(1, std::min<int64_t>(kMaxBlocks, (n + 4 * kIterItems - 1) / (4 * kIterItems)));
+  g.chunk      = ((n + want - 1) / want + kIterItems - 1) / kIterItems * kIterItems;
+  if (g.chunk < kIterItems) g.chunk = kIterItems;
+  g.blocks = static_cast<int>(std::max<int64_t>(1, (n + g.chunk - 1) / g.chunk));
+  return g;
+}
+
+// owner of a non-negative id: the r with off[r] <= id < off[r+1]; branch-free count of passed
+// boundaries (empty ranks share a boundary and are skipped naturally)
+__device__ __forceinline__ int owner_of(uint64_t id, const uint64_t* s_off, int world)
+{
+  int r = 0;
+  for (int k = 1; k < world; k++) r += (id >= s_off[k]) ? 1 : 0;
+  return r;
+}
+
+template <typename IdxT>
+__device__ __forceinline__ int bucket_of(const IdxT* ids, int64_t i, int64_t n, const uint64_t* s_off, int world,
+                                         IdxT& id_out)
+{
+  if (i >= n) return -1;  // padding lane: belongs to no bucket
+  IdxT id = ids[i];
+  id_out  = id;
+  if (id < 0) return world;  // trailing "never sent" bucket
+  return owner_of(static_cast<uint64_t>(id), s_off, world);
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void bucket_hist_kernel(const IdxT* ids, int64_t n, const uint64_t* entry_offsets,
+                                                             int world, int64_t chunk, int64_t* block_counts)
+{
+  __shared__ uint64_t s_off[kMaxBuckets + 1];
+  __shared__ int s_cnt[kMaxBuckets];
+  const int nb = world + 1;
+  for (int i = threadIdx.x; i <= world; i += kBlock) s_off[i] = entry_offsets[i];
+  for (int i = threadIdx.x; i < nb; i += kBlock) s_cnt[i] = 0;
+  __syncthreads();
+  const int lane      = threadIdx.x & 63;
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * chunk;
+  const int64_t end   = min(begin + chunk, n);
+  for (int64_t base = begin; base < end; base += kBlock) {
+    IdxT id;
+    int b            = bucket_of(ids, base + threadIdx.x, end, s_off, world, id);
+    uint64_t pending = __ballot(b >= 0);
+    while (pending) {  // one trip per distinct bucket present in this wave
+      int leader    = __ffsll(static_cast<long long>(pending)) - 1;
+      int lb        = __shfl(b, leader, 64);
+      uint64_t mask = __ballot(b == lb);
+      if (lane == leader) atomicAdd(&s_cnt[lb], __popcll(mask));
+      pending &= ~mask;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += kBlock)
+    block_counts[static_cast<int64_t>(i) * gridDim.x + blockIdx.x] = s_cnt[i];
+}
+
+// exclusive scan of block_counts (bucket-major) in place; totals of the first `world` buckets to counts[]
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(int64_t* block_counts, int blocks, int world, int64_t* counts)
+{
+  __shared__ int64_t s_part[1024];
+  const int64_t total = static_cast<int64_t>(world + 1) * blocks;
+  const int64_t per   = (total + 1023) / 1024;
+  const int64_t b0    = min(static_cast<int64_t>(threadIdx.x) * per, total);
+  const int64_t b1    = min(b0 + per, total);
+  int64_t sum         = 0;
+  for (int64_t i = b0; i < b1; i++) sum += block_counts[i];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan over 1024 partials
+    int64_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+    __syncthreads();
+    s_part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int64_t run = s_part[threadIdx.x] - sum;  // exclusive prefix of this thread's span
+  for (int64_t i = b0; i < b1; i++) {
+    int64_t c       = block_counts[i];
+    block_counts[i] = run;
+    run += c;
+  }
+  __syncthreads();
+  // bucket totals: offset of next bucket's first block minus own first block
+  for (int r = threadIdx.x; r < world; r += 1024) {
+    int64_t start = block_counts[static_cast<int64_t>(r) * blocks];
+    int64_t next  = block_counts[static_cast<int64_t>(r + 1) * blocks];
+    counts[r]     = next - start;
+  }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void bucket_scatter_kernel(const IdxT* ids, int64_t n,
+                                                                const uint64_t* entry_offsets, int world,
+                                                                int64_t chunk, const int64_t* block_offsets,
+                                                                IdxT* bucketed_ids, int64_t* raw_indices)
+{
+  __shared__ uint64_t s_off[kMaxBuckets + 1];
+  __shared__ int64_t s_run[kMaxBuckets];          // next free slot per bucket for this block
+  __shared__ volatile int s_wcnt[kWaves][kMaxBuckets];  // per-wave counts of the current iteration
+  __shared__ int64_t s_wbase[kWaves][kMaxBuckets];
+  const int nb   = world + 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i <= world; i += kBlock) s_off[i] = entry_offsets[i];
+  for (int i = threadIdx.x; i < nb; i += kBlock)
+    s_run[i] = block_offsets[static_cast<int64_t>(i) * gridDim.x + blockIdx.x];
+  __syncthreads();
+  const int64_t begin    = static_cast<int64_t>(blockIdx.x) * chunk;
+  const int64_t end      = min(begin + chunk, n);
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  for (int64_t it = begin; it < end; it += kIterItems) {
+    for (int i = threadIdx.x; i < kWaves * nb; i += kBlock) s_wcnt[i / nb][i % nb] = 0;
+    __syncthreads();
+    // wave `wave` owns ids [it + wave*256, it + wave*256 + 256) as kItems consecutive 64-groups
+    IdxT id[kItems];
+    int bkt[kItems];
+    int rank[kItems];
+#pragma unroll
+    for (int j = 0; j < kItems; j++) {
+      const int64_t pos = it + static_cast<int64_t>(wave) * (64 * kItems) + j * 64 + lane;
+      bkt[j]            = bucket_of(ids, pos, end, s_off, world, id[j]);
+      rank[j]           = 0;
+      uint64_t pending  = __ballot(bkt[j] >= 0);
+      while (pending) {
+        int leader    = __ffsll(static_cast<long long>(pending)) - 1;
+        int lb        = __shfl(bkt[j], leader, 64);
+        uint64_t mask = __ballot(bkt[j] == lb);
+        int prior     = s_wcnt[wave][lb];  // ids of this bucket in earlier groups of this wave
+        if (bkt[j] == lb) rank[j] = prior + __popcll(mask & lt_mask);
+        if (lane == leader) s_wcnt[wave][lb] = prior + __popcll(mask);
+        pending &= ~mask;
+      }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += kBlock) {
+      int64_t run = s_run[b];
+#pragma unroll
+      for (int w = 0; w < kWaves; w++) {
+        s_wbase[w][b] = run;
+        run += s_wcnt[w][b];
+      }
+      s_run[b] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kItems; j++) {
+      if (bkt[j] >= 0) {
+        const int64_t pos  = it + static_cast<int64_t>(wave) * (64 * kItems) + j * 64 + lane;
+        const int64_t dest = s_wbase[wave][bkt[j]] + rank[j];
+        bucketed_ids[dest] = id[j];
+        raw_indices[dest]  = pos;
+      }
+    }
+    // s_wcnt is re-zeroed behind the barrier at the top of the next iteration; s_wbase is only
+    // rewritten after that barrier too
+  }
+}
+
+template <typename IdxT>
+int run_bucket(const wm_bucket_args* a, hipStream_t stream)
+{
+  bucket_geom g         = geometry(a->n);
+  int64_t* block_counts = static_cast<int64_t*>(a->workspace);
+  const IdxT* ids       = static_cast<const IdxT*>(a->indices);
+  hipLaunchKernelGGL((bucket_hist_kernel<IdxT>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n, a->entry_offsets,
+                     a->world_size, g.chunk, block_counts);
+  hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, block_counts, g.blocks, a->world_size,
+                     a->counts);
+  if (a->bucketed_ids != nullptr && a->raw_indices != nullptr) {
+    hipLaunchKernelGGL((bucket_scatter_kernel<IdxT>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n,
+                       a->entry_offsets, a->world_size, g.chunk, block_counts, static_cast<IdxT*>(a->bucketed_ids),
+                       a->raw_indices);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+size_t hip_bucket_workspace_bytes(int64_t n, int world_size)
+{
+  bucket_geom g = geometry(std::max<int64_t>(n, 1));
+  return static_cast<size_t>(world_size + 2) * static_cast<size_t>(g.blocks) * sizeof(int64_t) + 256;
+}
+
+int hip_bucket_ids(const wm_bucket_args* a, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (a->world_size < 1 || a->world_size + 1 > kMaxBuckets) return -1;
+  if (a->n == 0) {  // reference bucket_ids_func.cu:121-122: counts zeroed, nothing launched
+    return hipMemsetAsync(a->counts, 0, sizeof(int64_t) * a->world_size, stream) == hipSuccess ? 0 : -2;
+  }
+  if (a->index_dtype == WHOLEMEMORY_DT_INT) return run_bucket<int32_t>(a, stream);
+  if (a->index_dtype == WHOLEMEMORY_DT_INT64) return run_bucket<int64_t>(a, stream);
+  return -1;
+}
+
+}  // namespace wm

@@ -1,0 +1,320 @@
+// wholegraph_amd — owner-side gradient de-duplication and sparse optimizer steps (gfx950 HIP).
+//
+// Reference behaviour (cpp/src/wholememory_ops/functions/):
+//   exchange_embeddings_nccl_func.cu:76-174   stable radix sort of received ids (payload = receive
+//        position) -> unique_by_key -> per unique id a SEQUENTIAL fp32 sum of its gradient rows in
+//        sorted order, written to a dedup buffer;
+//   embedding_optimizer_func.cu:178-224 (SGD), :331-421 (lazy Adam/AdamW), :594-658 (AdaGrad),
+//        :791-856 (RMSProp): one block per unique id reads the dedup row and updates the local shard.
+// MI355X design: the dedup buffer never exists. After the sort, ONE kernel walks each run of equal
+// ids, accumulates the duplicates' rows in registers in exactly the reference's order (first row
+// copied, the rest added one by one in receive order) and applies the optimizer to the table row
+// in the same pass: per unique row the HBM traffic is grad rows + 1 table read + 1 table write
+// (+ state), instead of grad rows + dedup write + dedup read + table RMW. Each wave owns one unique
+// id at a time (grid-stride over runs; the run count is read from device memory, so the host
+// never synchronises to learn it). All arithmetic is separate fp32 multiplies and adds in the
+// statement order of the reference kernels (this TU is compiled with -ffp-contract=off); results
+// are bit-identical to oracle/wm_oracle.c. Element-wise math: VALU work, HBM-bound; no MFMA.
+//
+// The id sort itself is rocPRIM's radix sort restricted to the significant key bits
+// (ids at the owner are non-negative and < table rows): same stable order as the reference's
+// full-width signed sort, fewer passes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../backend.hpp"
+#include <wholememory/embedding.h>
+
+namespace wm {
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ void iota_i32_kernel(int32_t* p, int64_t n)
+{
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = static_cast<int32_t>(i);
+}
+
+template <typename KeyT>
+__global__ void head_flags_kernel(const KeyT* sorted, int64_t n, int32_t* flags)
+{
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
+}
+
+template <typename KeyT>
+__global__ void compact_runs_kernel(const KeyT* sorted, const int32_t* flags, const int32_t* run_idx, int64_t n,
+                                    KeyT* unique_ids, int32_t* run_starts, int64_t* n_unique)
+{
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (flags[i]) {
+    unique_ids[run_idx[i]] = sorted[i];
+    run_starts[run_idx[i]] = static_cast<int32_t>(i);
+  }
+  if (i == n - 1) {
+    int32_t total     = run_idx[i] + flags[i];
+    run_starts[total] = static_cast<int32_t>(n);
+    *n_unique         = total;
+  }
+}
+
+inline unsigned significant_bits(int64_t upper_bound, unsigned full)
+{
+  if (upper_bound <= 0) return full;
+  unsigned b = 1;
+  while (b < full && (static_cast<uint64_t>(upper_bound - 1) >> b) != 0) b++;
+  return b;
+}
+
+template <typename KeyT>
+struct dedup_layout {
+  KeyT* sorted;
+  int32_t* iota;
+  int32_t* flags;
+  int32_t* run_idx;
+  void* temp;
+  size_t temp_bytes;
+  size_t total;
+};
+
+template <typename KeyT>
+dedup_layout<KeyT> layout(void* ws, int64_t n)
+{
+  auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  size_t sort_bytes = 0, scan_bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, static_cast<const KeyT*>(nullptr), static_cast<KeyT*>(nullptr),
+                            static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                            static_cast<size_t>(n), 0, 8 * sizeof(KeyT), nullptr);
+  (void)rocprim::exclusive_scan(nullptr, scan_bytes, static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                          0, static_cast<size_t>(n), rocprim::plus<int32_t>(), nullptr);
+  dedup_layout<KeyT> l;
+  char* p      = static_cast<char*>(ws);
+  size_t o     = 0;
+  l.sorted     = reinterpret_cast<KeyT*>(p + o), o += align(sizeof(KeyT) * n);
+  l.iota       = reinterpret_cast<int32_t*>(p + o), o += align(4 * n);
+  l.flags      = reinterpret_cast<int32_t*>(p + o), o += align(4 * n);
+  l.run_idx    = reinterpret_cast<int32_t*>(p + o), o += align(4 * n);
+  l.temp       = p + o;
+  l.temp_bytes = std::max(sort_bytes, scan_bytes);
+  l.total      = o + align(l.temp_bytes) + 256;
+  return l;
+}
+
+template <typename KeyT>
+int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, void* unique_ids, int32_t* run_starts,
+              int32_t* order, int64_t* n_unique_out, void* workspace, hipStream_t stream)
+{
+  using UKey = typename std::make_unsigned<KeyT>::type;
+  auto l     = layout<UKey>(workspace, n);
+  int blocks = static_cast<int>((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(iota_i32_kernel, dim3(blocks), dim3(kBlock), 0, stream, l.iota, n);
+  size_t tb = l.temp_bytes;
+  if (rocprim::radix_sort_pairs(l.temp, tb, static_cast<const UKey*>(ids), l.sorted, l.iota, order,
+                                static_cast<size_t>(n), 0, significant_bits(key_upper_bound, 8 * sizeof(KeyT)),
+                                stream) != hipSuccess)
+    return -2;
+  hipLaunchKernelGGL((head_flags_kernel<UKey>), dim3(blocks), dim3(kBlock), 0, stream, l.sorted, n, l.flags);
+  tb = l.temp_bytes;
+  if (rocprim::exclusive_scan(l.temp, tb, l.flags, l.run_idx, 0, static_cast<size_t>(n), rocprim::plus<int32_t>(),
+                              stream) != hipSuccess)
+    return -2;
+  hipLaunchKernelGGL((compact_runs_kernel<UKey>), dim3(blocks), dim3(kBlock), 0, stream, l.sorted, l.flags, l.run_idx,
+                     n, static_cast<UKey*>(unique_ids), run_starts, n_unique_out);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused duplicate-sum + optimizer step
+// ---------------------------------------------------------------------------------------------
+struct opt_params {
+  wm_optimizer_args a;
+  const int64_t* n_unique;  // device scalar (or nullptr -> a.count)
+};
+
+template <typename IdxT, int OPT>
+__global__ __launch_bounds__(kBlock) void fused_dedup_step_kernel(opt_params p)
+{
+  const wm_optimizer_args& a = p.a;
+  const int lane             = threadIdx.x & 63;
+  const int64_t wave         = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t n_waves      = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  const int64_t count        = p.n_unique ? *p.n_unique : a.count;
+  const IdxT* ids            = static_cast<const IdxT*>(a.ids);
+
+  for (int64_t u = wave; u < count; u += n_waves) {
+    const int64_t local = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
+    const int32_t s0    = a.run_starts[u];
+    const int32_t s1    = a.run_starts[u + 1];
+    float* e_row        = a.local_table + local * a.table_stride;
+    float beta1t = 0.f, beta2t = 0.f;
+    if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) {
+      beta1t = a.per_row_state[local * 2 + 0] * a.beta1;
+      beta2t = a.per_row_state[local * 2 + 1] * a.beta2;
+    }
+    for (int64_t d = lane; d < a.dim; d += 64) {
+      // reference DedupIndiceAndGradientsKernel: first occurrence copied, later ones added in order
+      float grad_value = a.grads[static_cast<int64_t>(a.order[s0]) * a.grad_stride + d];
+      for (int32_t j = s0 + 1; j < s1; j++) grad_value += a.grads[static_cast<int64_t>(a.order[j]) * a.grad_stride + d];
+      float embedding_value = e_row[d];
+      if (OPT == WHOLEMEMORY_OPT_SGD) {
+        grad_value += a.weight_decay * embedding_value;
+        embedding_value -= a.lr * grad_value;
+      } else if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) {
+        float* m_ptr = a.per_element_state + local * a.per_element_stride;
+        float* v_ptr = m_ptr + a.table_stride;
+        if (a.adam_w) {
+          embedding_value -= a.lr * a.weight_decay * embedding_value;
+        } else {
+          grad_value = grad_value + a.weight_decay * embedding_value;
+        }
+        float m         = m_ptr[d];
+        float v         = v_ptr[d];
+        m               = a.beta1 * m + (1 - a.beta1) * grad_value;
+        v               = a.beta2 * v + (1 - a.beta2) * grad_value * grad_value;
+        float mhat      = m / (1 - beta1t);
+        float vhat      = v / (1 - beta2t);
+        embedding_value = embedding_value - a.lr * mhat / (sqrtf(vhat) + a.epsilon);
+        m_ptr[d]        = m;
+        v_ptr[d]        = v;
+      } else if (OPT == WHOLEMEMORY_OPT_ADAGRAD) {
+        float* s_ptr    = a.per_element_state + local * a.per_element_stride;
+        grad_value      = grad_value + a.weight_decay * embedding_value;
+        float state_sum = s_ptr[d];
+        state_sum       = state_sum + grad_value * grad_value;
+        embedding_value = embedding_value - a.lr * grad_value / (sqrtf(state_sum) + a.epsilon);
+        s_ptr[d]        = state_sum;
+      } else if (OPT == WHOLEMEMORY_OPT_RMSPROP) {
+        float* v_ptr    = a.per_element_state + local * a.per_element_stride;
+        grad_value      = grad_value + a.weight_decay * embedding_value;
+        float v         = v_ptr[d];
+        v               = a.alpha * v + (1 - a.alpha) * grad_value * grad_value;
+        embedding_value = embedding_value - a.lr * grad_value / (sqrtf(v) + a.epsilon);
+        v_ptr[d]        = v;
+      }
+      e_row[d] = embedding_value;
+    }
+    if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM && lane == 0) {
+      a.per_row_state[local * 2 + 0] = beta1t;
+      a.per_row_state[local * 2 + 1] = beta2t;
+    }
+  }
+}
+
+template <typename IdxT>
+int launch_step(const opt_params& p, int blocks, hipStream_t stream)
+{
+  switch (p.a.type) {
+    case WHOLEMEMORY_OPT_SGD:
+      hipLaunchKernelGGL((fused_dedup_step_kernel<IdxT, WHOLEMEMORY_OPT_SGD>), dim3(blocks), dim3(kBlock), 0, stream, p);
+      break;
+    case WHOLEMEMORY_OPT_LAZY_ADAM:
+      hipLaunchKernelGGL((fused_dedup_step_kernel<IdxT, WHOLEMEMORY_OPT_LAZY_ADAM>), dim3(blocks), dim3(kBlock), 0,
+                         stream, p);
+      break;
+    case WHOLEMEMORY_OPT_ADAGRAD:
+      hipLaunchKernelGGL((fused_dedup_step_kernel<IdxT, WHOLEMEMORY_OPT_ADAGRAD>), dim3(blocks), dim3(kBlock), 0,
+                         stream, p);
+      break;
+    case WHOLEMEMORY_OPT_RMSPROP:
+      hipLaunchKernelGGL((fused_dedup_step_kernel<IdxT, WHOLEMEMORY_OPT_RMSPROP>), dim3(blocks), dim3(kBlock), 0,
+                         stream, p);
+      break;
+    default: return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename IdxT>
+__global__ void round_robin_map_kernel(const IdxT* ids, IdxT* mapped, int64_t n, int64_t entry_start, int world,
+                                       int rr)
+{
+  // reference functions/map_indices_func.cu:26-45, quirk kept: entry_start is the caller's first row
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t idx = static_cast<int64_t>(ids[i]);
+  int64_t t   = idx / rr;
+  int64_t off = idx % rr;
+  mapped[i]   = static_cast<IdxT>(entry_start + static_cast<int64_t>(rr) * (t / world) + off);
+}
+
+__global__ void fill_float_kernel(float* p, float v, int64_t n)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    p[i] = v;
+}
+
+}  // namespace
+
+size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype)
+{
+  if (n <= 0) return 256;
+  if (index_dtype == WHOLEMEMORY_DT_INT) return layout<uint32_t>(nullptr, n).total;
+  return layout<uint64_t>(nullptr, n).total;
+}
+
+int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound,
+                  void* unique_ids, int32_t* run_starts, int32_t* order, int64_t* n_unique_out, void* workspace,
+                  void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (n >= (1ll << 31)) return -1;  // reference casts the receive count to int (exchange_embeddings_nccl_func.cu:118)
+  if (n == 0) return hipMemsetAsync(n_unique_out, 0, sizeof(int64_t), stream) == hipSuccess ? 0 : -2;
+  if (index_dtype == WHOLEMEMORY_DT_INT)
+    return run_dedup<int32_t>(ids, n, key_upper_bound, unique_ids, run_starts, order, n_unique_out, workspace, stream);
+  if (index_dtype == WHOLEMEMORY_DT_INT64)
+    return run_dedup<int64_t>(ids, n, key_upper_bound, unique_ids, run_starts, order, n_unique_out, workspace, stream);
+  return -1;
+}
+
+// a->count is an UPPER BOUND for the launch geometry; the true run count is read on the device from
+// a->run_starts' companion scalar when `n_unique_dev` is non-null (ids == unique ids from hip_dedup_ids).
+int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (a->count == 0) return 0;
+  opt_params p{*a, n_unique_dev};
+  int64_t waves = a->count;
+  int blocks    = static_cast<int>(std::min<int64_t>((waves + 3) / 4, 256 * 8));
+  if (blocks < 1) blocks = 1;
+  if (a->index_dtype == WHOLEMEMORY_DT_INT) return launch_step<int32_t>(p, blocks, stream);
+  if (a->index_dtype == WHOLEMEMORY_DT_INT64) return launch_step<int64_t>(p, blocks, stream);
+  return -1;
+}
+
+int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n, int64_t entry_start,
+                        int world_size, int round_robin_size, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (n == 0) return 0;
+  int blocks = static_cast<int>((n + kBlock - 1) / kBlock);
+  if (index_dtype == WHOLEMEMORY_DT_INT)
+    hipLaunchKernelGGL((round_robin_map_kernel<int32_t>), dim3(blocks), dim3(kBlock), 0, stream,
+                       static_cast<const int32_t*>(ids), static_cast<int32_t*>(mapped), n, entry_start, world_size,
+                       round_robin_size);
+  else if (index_dtype == WHOLEMEMORY_DT_INT64)
+    hipLaunchKernelGGL((round_robin_map_kernel<int64_t>), dim3(blocks), dim3(kBlock), 0, stream,
+                       static_cast<const int64_t*>(ids), static_cast<int64_t*>(mapped), n, entry_start, world_size,
+                       round_robin_size);
+  else
+    return -1;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int hip_fill_float(float* p, float value, int64_t count, void* stream_v)
+{
+  if (count == 0) return 0;
+  int blocks = static_cast<int>(std::min<int64_t>((count + kBlock - 1) / kBlock, 256 * 16));
+  hipLaunchKernelGGL(fill_float_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream_v), p, value,
+                     count);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace wm

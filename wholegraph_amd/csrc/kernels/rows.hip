@@ -1,0 +1,413 @@
+// wholegraph_amd — row gather / scatter kernels for gfx950 (MI355X), hand-written HIP.
+//
+// Semantics (reference cpp/src/wholememory_ops/functions/gather_scatter_func.cuh:253-316 gather,
+// :519-598 scatter; address rule include/wholememory/device_reference.cuh:41-61):
+//   gather : plain[row_map(i), c] = cast(table[idx[i], c])   c in [0, dim)   (idx[i] < 0: skipped)
+//   scatter: table[idx[i], c]     = cast(plain[row_map(i), c])
+//
+// MI355X design (NOT the reference's warp-per-row + smem staging):
+//  * a wave owns a TILE of 64 consecutive entries: one coalesced 512 B (int64) index load, each
+//    lane resolves ITS entry's owner rank / byte address once (the reference re-derives the rank
+//    with a 64-bit divide per element access, device_reference.cuh:47);
+//  * the tile is then streamed in "steps": LPR = lanes per row (power of two covering
+//    row_bytes / vector bytes, <= 64), 64/LPR rows per step, each lane moving one 16-byte vector
+//    (global_load_dwordx4 / global_store_dwordx4). A 512 B fp32 row is 32 lanes x 16 B, so a step
+//    moves two whole rows as one 1 KiB wave transaction; row base addresses travel between lanes
+//    with ds_bpermute (__shfl), no LDS allocation, no barriers;
+//  * UNROLL steps of loads are issued before the first store, so each wave keeps
+//    UNROLL x 1 KiB of random HBM reads in flight (Little's law: ~10 MB chip-wide are needed to
+//    cover ~2 us of loaded HBM latency at 5-6 TB/s; 8 KiB x 32 waves x 256 CUs = 64 MiB);
+//  * the streamed side (gather output / scatter input) is touched exactly once, so gather stores
+//    are non-temporal to keep L2 / Infinity Cache for table rows (which DO repeat under skew);
+//  * grid = min(tiles/4, 8 x 256 CUs) workgroups of 4 waves, grid-stride over tiles.
+// The path is HBM-bound byte movement: there is no contraction here and MFMA is not used.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../backend.hpp"
+#include "device_common.cuh"
+
+namespace wm {
+namespace {
+
+constexpr int kBlock  = 256;
+constexpr int kWave   = 64;
+constexpr int kUnroll = 8;
+
+template <int BYTES>
+struct vec_of;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <>
+struct vec_of<16> {
+  using type = u32x4;
+};
+template <>
+struct vec_of<8> {
+  using type = u32x2;
+};
+template <>
+struct vec_of<4> {
+  using type = uint32_t;
+};
+template <>
+struct vec_of<2> {
+  using type = uint16_t;
+};
+template <>
+struct vec_of<1> {
+  using type = uint8_t;
+};
+
+struct rows_params {
+  // table side
+  char* base;                      // continuous: flat base; chunked: unused
+  char* const* rank_ptrs;          // chunked: per-rank bases (device array)
+  const size_t* rank_offsets;      // chunked, !same_chunk: byte offsets [world+1] (device array)
+  size_t chunk_stride;             // 0 = continuous; else bytes per rank
+  int world_size;
+  int same_chunk;
+  int64_t table_stride_bytes;
+  int64_t table_offset_bytes;
+  // index side
+  const void* indices;
+  const void* row_map;
+  int64_t n;
+  // plain side (already offset by storage_offset)
+  char* plain;
+  int64_t plain_stride_bytes;
+  // geometry
+  int row_vecs;   // vectors per row (row_bytes / VB  or  dim / V)
+  int lpr_log2;   // log2(lanes per row)
+};
+
+// byte address of the first moved element of table row `idx`
+__device__ __forceinline__ char* resolve_row(const rows_params& p, int64_t idx)
+{
+  size_t off = static_cast<size_t>(p.table_offset_bytes) + static_cast<size_t>(idx) * static_cast<size_t>(p.table_stride_bytes);
+  if (p.chunk_stride == 0) return p.base + off;
+  int rank;
+  size_t rank_start;
+  if (p.same_chunk) {
+    rank       = static_cast<int>(off / p.chunk_stride);
+    rank_start = static_cast<size_t>(rank) * p.chunk_stride;
+  } else {
+    rank = 0;
+    for (int r = 1; r < p.world_size; r++) {
+      if (off >= p.rank_offsets[r]) rank = r;
+    }
+    rank_start = p.rank_offsets[rank];
+  }
+  return p.rank_ptrs[rank] + (off - rank_start);
+}
+
+template <typename IdxT>
+__device__ __forceinline__ void load_tile_entry(const rows_params& p, int64_t entry, char*& tab, char*& pl)
+{
+  tab = nullptr;
+  pl  = nullptr;
+  if (entry < p.n) {
+    int64_t idx = static_cast<int64_t>(static_cast<const IdxT*>(p.indices)[entry]);
+    if (idx >= 0) {
+      tab         = resolve_row(p, idx);
+      int64_t row = p.row_map ? static_cast<int64_t>(static_cast<const IdxT*>(p.row_map)[entry]) : entry;
+      pl          = p.plain + row * p.plain_stride_bytes;
+    }
+  }
+}
+
+__device__ __forceinline__ char* shfl_ptr(char* p, int src_lane)
+{
+  uint64_t v  = reinterpret_cast<uint64_t>(p);
+  uint32_t lo = __shfl(static_cast<uint32_t>(v), src_lane, kWave);
+  uint32_t hi = __shfl(static_cast<uint32_t>(v >> 32), src_lane, kWave);
+  return reinterpret_cast<char*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// same-dtype path: pure byte movement with VB-byte vectors
+// ------------------------------------------------------------------------------------------------
+template <typename IdxT, int VB, bool GATHER>
+__global__ __launch_bounds__(kBlock) void rows_copy_kernel(rows_params p)
+{
+  using vec_t         = typename vec_of<VB>::type;
+  const int lane      = threadIdx.x & (kWave - 1);
+  const int wave      = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int n_waves   = (gridDim.x * kBlock) >> 6;
+  const int lpr       = 1 << p.lpr_log2;
+  const int rps       = kWave >> p.lpr_log2;  // rows per step
+  const int sub       = lane >> p.lpr_log2;   // which row of the step this lane serves
+  const int col       = lane & (lpr - 1);
+  const int64_t tiles = (p.n + kWave - 1) / kWave;
+
+  for (int64_t tile = wave; tile < tiles; tile += n_waves) {
+    char *my_tab, *my_plain;
+    load_tile_entry<IdxT>(p, tile * kWave + lane, my_tab, my_plain);
+    for (int cbase = 0; cbase < p.row_vecs; cbase += lpr) {  // >1 trip only when a row needs > 64 vectors
+      const int c        = cbase + col;
+      const bool col_ok  = c < p.row_vecs;
+      const int64_t coff = static_cast<int64_t>(c) * VB;
+      for (int s0 = 0; s0 < kWave; s0 += rps * kUnroll) {
+        vec_t data[kUnroll];
+        char* dst[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+          const int e = s0 + u * rps + sub;
+          char* t     = shfl_ptr(my_tab, e & (kWave - 1));
+          char* q     = shfl_ptr(my_plain, e & (kWave - 1));
+          const bool ok = col_ok && e < kWave && t != nullptr;
+          char* src   = GATHER ? t : q;
+          dst[u]      = ok ? (GATHER ? q : t) + coff : nullptr;
+          if (ok) data[u] = *reinterpret_cast<const vec_t*>(src + coff);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+          if (dst[u] != nullptr) {
+            if constexpr (GATHER)
+              __builtin_nontemporal_store(data[u], reinterpret_cast<vec_t*>(dst[u]));
+            else
+              *reinterpret_cast<vec_t*>(dst[u]) = data[u];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// converting path: V elements per lane, FromT -> ToT through the reference's conversion chain
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V>
+struct alignas(sizeof(T) * V) elt_vec {
+  T v[V];
+};
+
+template <typename TabT, typename PlainT, typename IdxT, int V, bool GATHER>
+__global__ __launch_bounds__(kBlock) void rows_convert_kernel(rows_params p)
+{
+  using FromT         = typename std::conditional<GATHER, TabT, PlainT>::type;
+  using ToT           = typename std::conditional<GATHER, PlainT, TabT>::type;
+  const int lane      = threadIdx.x & (kWave - 1);
+  const int wave      = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int n_waves   = (gridDim.x * kBlock) >> 6;
+  const int lpr       = 1 << p.lpr_log2;
+  const int rps       = kWave >> p.lpr_log2;
+  const int sub       = lane >> p.lpr_log2;
+  const int col       = lane & (lpr - 1);
+  const int64_t tiles = (p.n + kWave - 1) / kWave;
+  constexpr int kU    = 4;
+
+  for (int64_t tile = wave; tile < tiles; tile += n_waves) {
+    char *my_tab, *my_plain;
+    load_tile_entry<IdxT>(p, tile * kWave + lane, my_tab, my_plain);
+    for (int cbase = 0; cbase < p.row_vecs; cbase += lpr) {
+      const int c       = cbase + col;
+      const bool col_ok = c < p.row_vecs;
+      for (int s0 = 0; s0 < kWave; s0 += rps * kU) {
+        elt_vec<FromT, V> data[kU];
+        char* dst[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          const int e   = s0 + u * rps + sub;
+          char* t       = shfl_ptr(my_tab, e & (kWave - 1));
+          char* q       = shfl_ptr(my_plain, e & (kWave - 1));
+          const bool ok = col_ok && e < kWave && t != nullptr;
+          const char* src = GATHER ? t : q;
+          dst[u]        = ok ? (GATHER ? q : t) + static_cast<int64_t>(c) * V * sizeof(ToT) : nullptr;
+          if (ok) data[u] = *reinterpret_cast<const elt_vec<FromT, V>*>(src + static_cast<int64_t>(c) * V * sizeof(FromT));
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          if (dst[u] != nullptr) {
+            elt_vec<ToT, V> o;
+#pragma unroll
+            for (int k = 0; k < V; k++) o.v[k] = convert_elt<FromT, ToT>(data[u].v[k]);
+            *reinterpret_cast<elt_vec<ToT, V>*>(dst[u]) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+inline int ilog2_ceil(int x)
+{
+  int l = 0;
+  while ((1 << l) < x) l++;
+  return l;
+}
+
+inline int64_t pow2_divisor(int64_t v, int64_t cap)
+{  // largest power of two <= cap dividing v (v == 0 divides everything)
+  int64_t a = cap;
+  while (a > 1 && (v % a) != 0) a >>= 1;
+  return a;
+}
+
+int default_max_blocks()
+{
+  static int cus = 0;
+  if (cus == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    else
+      cus = 256;
+  }
+  return cus * 8;
+}
+
+template <typename IdxT, bool GATHER>
+void launch_copy(const rows_params& p, int vb, int blocks, hipStream_t stream)
+{
+  switch (vb) {
+    case 16: hipLaunchKernelGGL((rows_copy_kernel<IdxT, 16, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((rows_copy_kernel<IdxT, 8, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((rows_copy_kernel<IdxT, 4, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((rows_copy_kernel<IdxT, 2, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p); break;
+    default: hipLaunchKernelGGL((rows_copy_kernel<IdxT, 1, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p); break;
+  }
+}
+
+template <typename TabT, typename PlainT, typename IdxT, bool GATHER>
+void launch_convert_v(const rows_params& p, int v, int blocks, hipStream_t stream)
+{
+  switch (v) {
+    case 4:
+      hipLaunchKernelGGL((rows_convert_kernel<TabT, PlainT, IdxT, 4, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p);
+      break;
+    case 2:
+      hipLaunchKernelGGL((rows_convert_kernel<TabT, PlainT, IdxT, 2, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p);
+      break;
+    default:
+      hipLaunchKernelGGL((rows_convert_kernel<TabT, PlainT, IdxT, 1, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p);
+      break;
+  }
+}
+
+template <typename TabT, typename PlainT, bool GATHER>
+void launch_convert_idx(const rows_params& p, wholememory_dtype_t idx_dt, int v, int blocks, hipStream_t stream)
+{
+  if (idx_dt == WHOLEMEMORY_DT_INT)
+    launch_convert_v<TabT, PlainT, int32_t, GATHER>(p, v, blocks, stream);
+  else
+    launch_convert_v<TabT, PlainT, int64_t, GATHER>(p, v, blocks, stream);
+}
+
+template <typename TabT, bool GATHER>
+bool launch_convert_plain_fp(const rows_params& p, wholememory_dtype_t plain_dt, wholememory_dtype_t idx_dt, int v,
+                             int blocks, hipStream_t stream)
+{
+  switch (plain_dt) {
+    case WHOLEMEMORY_DT_FLOAT: launch_convert_idx<TabT, float, GATHER>(p, idx_dt, v, blocks, stream); return true;
+    case WHOLEMEMORY_DT_HALF: launch_convert_idx<TabT, half_t, GATHER>(p, idx_dt, v, blocks, stream); return true;
+    case WHOLEMEMORY_DT_DOUBLE: launch_convert_idx<TabT, double, GATHER>(p, idx_dt, v, blocks, stream); return true;
+    case WHOLEMEMORY_DT_BF16: launch_convert_idx<TabT, bf16_t, GATHER>(p, idx_dt, v, blocks, stream); return true;
+    default: return false;
+  }
+}
+template <typename TabT, bool GATHER>
+bool launch_convert_plain_int(const rows_params& p, wholememory_dtype_t plain_dt, wholememory_dtype_t idx_dt, int v,
+                              int blocks, hipStream_t stream)
+{
+  switch (plain_dt) {
+    case WHOLEMEMORY_DT_INT8: launch_convert_idx<TabT, int8_t, GATHER>(p, idx_dt, v, blocks, stream); return true;
+    case WHOLEMEMORY_DT_INT16: launch_convert_idx<TabT, int16_t, GATHER>(p, idx_dt, v, blocks, stream); return true;
+    case WHOLEMEMORY_DT_INT: launch_convert_idx<TabT, int32_t, GATHER>(p, idx_dt, v, blocks, stream); return true;
+    case WHOLEMEMORY_DT_INT64: launch_convert_idx<TabT, int64_t, GATHER>(p, idx_dt, v, blocks, stream); return true;
+    default: return false;
+  }
+}
+
+template <bool GATHER>
+bool launch_convert(const rows_params& p, wholememory_dtype_t tab_dt, wholememory_dtype_t plain_dt,
+                    wholememory_dtype_t idx_dt, int v, int blocks, hipStream_t s)
+{
+  switch (tab_dt) {
+    case WHOLEMEMORY_DT_FLOAT: return launch_convert_plain_fp<float, GATHER>(p, plain_dt, idx_dt, v, blocks, s);
+    case WHOLEMEMORY_DT_HALF: return launch_convert_plain_fp<half_t, GATHER>(p, plain_dt, idx_dt, v, blocks, s);
+    case WHOLEMEMORY_DT_DOUBLE: return launch_convert_plain_fp<double, GATHER>(p, plain_dt, idx_dt, v, blocks, s);
+    case WHOLEMEMORY_DT_BF16: return launch_convert_plain_fp<bf16_t, GATHER>(p, plain_dt, idx_dt, v, blocks, s);
+    case WHOLEMEMORY_DT_INT8: return launch_convert_plain_int<int8_t, GATHER>(p, plain_dt, idx_dt, v, blocks, s);
+    case WHOLEMEMORY_DT_INT16: return launch_convert_plain_int<int16_t, GATHER>(p, plain_dt, idx_dt, v, blocks, s);
+    case WHOLEMEMORY_DT_INT: return launch_convert_plain_int<int32_t, GATHER>(p, plain_dt, idx_dt, v, blocks, s);
+    case WHOLEMEMORY_DT_INT64: return launch_convert_plain_int<int64_t, GATHER>(p, plain_dt, idx_dt, v, blocks, s);
+    default: return false;
+  }
+}
+
+template <bool GATHER>
+int rows_op(const wm_rows_args* a, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (a->n == 0 || a->dim == 0) return 0;  // reference gather_func.cu:82
+  const int64_t tes = static_cast<int64_t>(wholememory_dtype_get_element_size(a->table_dtype));
+  const int64_t pes = static_cast<int64_t>(wholememory_dtype_get_element_size(a->plain_dtype));
+  const bool tab_fp = wholememory_dtype_is_floating_number(a->table_dtype);
+  const bool pl_fp  = wholememory_dtype_is_floating_number(a->plain_dtype);
+  if (tab_fp != pl_fp) return -1;  // reference gather_func.cu:79-81
+  if (a->index_dtype != WHOLEMEMORY_DT_INT && a->index_dtype != WHOLEMEMORY_DT_INT64) return -1;
+
+  rows_params p{};
+  p.chunk_stride = a->gref.stride;
+  p.world_size   = a->gref.world_size;
+  p.same_chunk   = a->gref.same_chunk ? 1 : 0;
+  if (a->gref.stride == 0) {
+    p.base = static_cast<char*>(a->gref.pointer);
+  } else {
+    p.rank_ptrs    = static_cast<char* const*>(a->gref.pointer);
+    p.rank_offsets = a->gref.rank_memory_offsets;
+  }
+  p.table_stride_bytes = a->table_stride * tes;
+  p.table_offset_bytes = a->table_storage_offset * tes;
+  p.indices            = a->indices;
+  p.row_map            = a->row_map;
+  p.n                  = a->n;
+  p.plain              = static_cast<char*>(a->plain) + a->plain_storage_offset * pes;
+  p.plain_stride_bytes = a->plain_stride * pes;
+
+  const int64_t tiles = (a->n + kWave - 1) / kWave;
+  int blocks          = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, default_max_blocks()));
+  if (a->max_blocks > 0) blocks = std::min(blocks, a->max_blocks);
+  if (blocks < 1) blocks = 1;
+
+  // widest power-of-two access every address on both sides is aligned to — the reference's
+  // alignment pick (gather_scatter_func.cuh:215-251) plus the base pointers themselves
+  const uint64_t tab_base = a->gref.stride == 0 ? reinterpret_cast<uint64_t>(a->gref.pointer) : 0;
+  if (a->table_dtype == a->plain_dtype) {
+    const int64_t row_bytes = a->dim * tes;
+    int64_t vb              = 16;
+    vb                      = pow2_divisor(row_bytes, vb);
+    vb                      = pow2_divisor(p.table_stride_bytes, vb);
+    vb                      = pow2_divisor(p.table_offset_bytes, vb);
+    vb                      = pow2_divisor(static_cast<int64_t>(tab_base & 15), vb);
+    vb                      = pow2_divisor(p.plain_stride_bytes, vb);
+    vb                      = pow2_divisor(static_cast<int64_t>(reinterpret_cast<uint64_t>(p.plain) & 15), vb);
+    p.row_vecs              = static_cast<int>(row_bytes / vb);
+    p.lpr_log2              = std::min(6, ilog2_ceil(p.row_vecs));
+    if (a->index_dtype == WHOLEMEMORY_DT_INT)
+      launch_copy<int32_t, GATHER>(p, static_cast<int>(vb), blocks, stream);
+    else
+      launch_copy<int64_t, GATHER>(p, static_cast<int>(vb), blocks, stream);
+  } else {
+    int64_t v = 4;
+    v         = pow2_divisor(a->dim, v);
+    v         = pow2_divisor(a->table_stride, v);
+    v         = pow2_divisor(a->table_storage_offset, v);
+    v         = pow2_divisor(a->plain_stride, v);
+    while (v > 1 && ((tab_base % (v * tes)) != 0 || (reinterpret_cast<uint64_t>(p.plain) % (v * pes)) != 0)) v >>= 1;
+    p.row_vecs = static_cast<int>(a->dim / v);
+    p.lpr_log2 = std::min(6, ilog2_ceil(p.row_vecs));
+    if (!launch_convert<GATHER>(p, a->table_dtype, a->plain_dtype, a->index_dtype, static_cast<int>(v), blocks, stream))
+      return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+int hip_gather_rows(const wm_rows_args* a, void* stream) { return rows_op<true>(a, stream); }
+int hip_scatter_rows(const wm_rows_args* a, void* stream) { return rows_op<false>(a, stream); }
+
+}  // namespace wm

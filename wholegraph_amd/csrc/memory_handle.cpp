@@ -1,0 +1,446 @@
+// wholegraph_amd — WholeMemory handles: per-rank allocation, the row partition plan and the
+// cross-rank mapping that backs wholememory_gref_t.
+//
+// Reference: cpp/src/wholememory/memory_handle.cpp (:53-231 base + partition strategy, :312-407
+// distributed, :412-628 host shm, :633-1054 continuous, :1060-1219 chunked, :1603-1636 plan).
+// MI355X layout decisions:
+//  * DEVICE shards are single hipMalloc blocks in HBM (288 GB per GPU: a 1 B x 128 fp32 table is
+//    64 GB per rank on 8 GPUs, one allocation, no sub-chunking);
+//  * CHUNKED over ranks = hipIpc-mapped peer bases; kernels then issue plain global loads that
+//    travel over xGMI (fine-grained peer access), one base pointer per rank in a device table;
+//  * DISTRIBUTED = local shard only; rows move by RCCL all-to-all-v (ops.cpp);
+//  * HOST = one POSIX shared-memory segment mapped by every rank and registered with HIP, so the
+//    same gref shapes work for host-resident tables;
+//  * with ONE rank every type degenerates to a flat allocation and the ops layer hands kernels a
+//    continuous gref (no per-row owner lookup).
+//  * multi-rank CONTINUOUS/DEVICE needs HIP VMM (hipMemCreate/Export/Map) to stitch shards into one
+//    VA range; not built yet in this round -> WHOLEMEMORY_NOT_IMPLEMENTED (CHUNKED covers the same
+//    access pattern).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include <wholememory/wholememory.h>
+
+#include "backend.hpp"
+#include "communicator.hpp"
+#include "wm_common.hpp"
+
+struct wholememory_handle_ {
+  wholememory_comm_t comm                = nullptr;
+  wholememory_memory_type_t type         = WHOLEMEMORY_MT_NONE;
+  wholememory_memory_location_t location = WHOLEMEMORY_ML_NONE;
+  size_t total_size                      = 0;
+  size_t granularity                     = 0;
+  // row partition, in BYTES
+  std::vector<size_t> part_sizes;    // [W]
+  std::vector<size_t> part_offsets;  // [W+1]
+  size_t mem_stride = 0;             // bytes per rank when same_chunk
+  bool same_chunk   = true;
+  // local shard
+  void* local_ptr       = nullptr;
+  size_t local_alloc    = 0;
+  bool local_is_pinned  = false;
+  // mapped views
+  void* global_base = nullptr;        // CONTINUOUS (and HOST chunked): flat pointer usable on device
+  std::vector<void*> rank_ptrs;       // CHUNKED: per-rank bases as seen from this process
+  void** dev_rank_ptrs     = nullptr; // device copy of rank_ptrs
+  size_t* dev_rank_offsets = nullptr; // device copy of part_offsets
+  // host shm
+  void* shm_host_ptr = nullptr;
+  size_t shm_bytes   = 0;
+};
+
+namespace wm {
+namespace {
+
+#define WM_BK(call)                                                                                \
+  do {                                                                                             \
+    int rc__ = (call);                                                                             \
+    if (rc__ != 0) throw ::wm::hip_error(::wm::format_string("%s failed with code %d", #call, rc__)); \
+  } while (0)
+
+void plan_partition(wholememory_handle_* h, const size_t* rank_entry_partition)
+{
+  const int W = h->comm->world_size;
+  h->part_sizes.assign(W, 0);
+  h->part_offsets.assign(W + 1, 0);
+  if (rank_entry_partition != nullptr) {
+    // reference memory_handle.cpp:69-79 + :1605-1616
+    for (int i = 0; i < W; i++) {
+      h->part_sizes[i]       = rank_entry_partition[i] * h->granularity;
+      h->part_offsets[i + 1] = h->part_offsets[i] + h->part_sizes[i];
+    }
+    h->mem_stride = h->total_size / W;
+    h->same_chunk = true;
+    for (int i = 0; i < W - 2; i++) {
+      if (h->part_sizes[i] != h->part_sizes[i + 1]) {
+        h->same_chunk = false;
+        break;
+      }
+    }
+    return;
+  }
+  // equal plan: ceil(slots / W) per rank, clipped (reference memory_handle.cpp:1618-1635)
+  const size_t slots    = h->total_size / h->granularity;
+  const size_t per_rank = (slots + W - 1) / W;
+  for (int i = 0; i < W; i++) {
+    size_t s           = std::min<size_t>(static_cast<size_t>(i) * per_rank, slots);
+    size_t e           = std::min<size_t>(static_cast<size_t>(i + 1) * per_rank, slots);
+    h->part_sizes[i]   = (e - s) * h->granularity;
+    h->part_offsets[i] = s * h->granularity;
+  }
+  h->part_offsets[W] = slots * h->granularity;
+  h->mem_stride      = per_rank * h->granularity;
+  h->same_chunk      = true;
+}
+
+void upload_tables(wholememory_handle_* h)
+{
+  const auto* bk = backend();
+  const int W    = h->comm->world_size;
+  WM_BK(bk->malloc_device(reinterpret_cast<void**>(&h->dev_rank_ptrs), sizeof(void*) * W));
+  WM_BK(bk->malloc_device(reinterpret_cast<void**>(&h->dev_rank_offsets), sizeof(size_t) * (W + 1)));
+  WM_BK(bk->memcpy_async(h->dev_rank_ptrs, h->rank_ptrs.data(), sizeof(void*) * W, nullptr));
+  WM_BK(bk->memcpy_async(h->dev_rank_offsets, h->part_offsets.data(), sizeof(size_t) * (W + 1), nullptr));
+  WM_BK(bk->stream_sync(nullptr));
+}
+
+void alloc_local(wholememory_handle_* h)
+{
+  const auto* bk  = backend();
+  const int rank  = h->comm->world_rank;
+  h->local_alloc  = std::max<size_t>(h->part_sizes[rank], 16);
+  h->local_is_pinned = h->location == WHOLEMEMORY_ML_HOST;
+  if (h->local_is_pinned)
+    WM_BK(bk->malloc_pinned(&h->local_ptr, h->local_alloc));
+  else
+    WM_BK(bk->malloc_device(&h->local_ptr, h->local_alloc));
+}
+
+void map_chunked_device(wholememory_handle_* h)
+{
+  const auto* bk = backend();
+  const int W    = h->comm->world_size;
+  const int rank = h->comm->world_rank;
+  h->rank_ptrs.assign(W, nullptr);
+  h->rank_ptrs[rank] = h->local_ptr;
+  if (W > 1) {
+    std::vector<char> handles(static_cast<size_t>(W) * 64);
+    char mine[64];
+    WM_BK(bk->ipc_get_handle(mine, h->local_ptr));
+    h->comm->allgather_host(mine, handles.data(), 64);
+    for (int r = 0; r < W; r++) {
+      if (r == rank) continue;
+      WM_BK(bk->ipc_open_handle(&h->rank_ptrs[r], handles.data() + static_cast<size_t>(r) * 64));
+    }
+    h->comm->barrier();
+  }
+  upload_tables(h);
+}
+
+// one shm segment holding the whole table; rank 0 names it, everyone maps + registers it
+void map_host_shared(wholememory_handle_* h)
+{
+  const auto* bk = backend();
+  const int W    = h->comm->world_size;
+  const int rank = h->comm->world_rank;
+  char name[64]  = {0};
+  if (rank == 0) {
+    std::random_device rd;
+    snprintf(name, sizeof(name), "/wgamd_%d_%08x%08x", static_cast<int>(getpid()), rd(), rd());
+  }
+  std::vector<char> names(static_cast<size_t>(W) * 64);
+  h->comm->allgather_host(name, names.data(), 64);
+  memcpy(name, names.data(), 64);
+  h->shm_bytes = std::max<size_t>(h->total_size, 16);
+  int fd       = -1;
+  if (rank == 0) {
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, static_cast<off_t>(h->shm_bytes)) != 0) throw logic_error("shm_open/ftruncate failed");
+  }
+  h->comm->barrier();
+  if (rank != 0) {
+    fd = shm_open(name, O_RDWR, 0600);
+    if (fd < 0) throw logic_error("shm_open (attach) failed");
+  }
+  void* p = mmap(nullptr, h->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) throw logic_error("mmap of the shared segment failed");
+  h->comm->barrier();
+  if (rank == 0) shm_unlink(name);
+  h->shm_host_ptr = p;
+  void* dev       = nullptr;
+  WM_BK(bk->host_register(p, h->shm_bytes, &dev));
+  h->global_base = dev;
+  h->local_ptr   = static_cast<char*>(dev) + h->part_offsets[rank];
+  h->rank_ptrs.assign(W, nullptr);
+  for (int r = 0; r < W; r++) h->rank_ptrs[r] = static_cast<char*>(dev) + h->part_offsets[r];
+  upload_tables(h);
+}
+
+void create_memory(wholememory_handle_* h)
+{
+  const int W = h->comm->world_size;
+  if (h->type == WHOLEMEMORY_MT_DISTRIBUTED) {
+    alloc_local(h);
+    return;
+  }
+  if (W == 1) {  // flat allocation serves every mapped type
+    alloc_local(h);
+    h->global_base = h->local_ptr;
+    h->rank_ptrs.assign(1, h->local_ptr);
+    upload_tables(h);
+    return;
+  }
+  if (h->location == WHOLEMEMORY_ML_HOST) {
+    map_host_shared(h);
+    return;
+  }
+  if (h->type == WHOLEMEMORY_MT_CHUNKED) {
+    alloc_local(h);
+    map_chunked_device(h);
+    return;
+  }
+  throw logic_error("multi-rank CONTINUOUS device memory (HIP VMM stitching) is not implemented in this build");
+}
+
+void destroy_memory(wholememory_handle_* h) noexcept
+{
+  const auto* bk = backend();
+  const int W    = h->comm->world_size;
+  const int rank = h->comm->world_rank;
+  if (h->dev_rank_ptrs) bk->free_device(h->dev_rank_ptrs);
+  if (h->dev_rank_offsets) bk->free_device(h->dev_rank_offsets);
+  if (h->shm_host_ptr != nullptr) {
+    bk->host_unregister(h->shm_host_ptr);
+    munmap(h->shm_host_ptr, h->shm_bytes);
+  } else {
+    if (h->type == WHOLEMEMORY_MT_CHUNKED && W > 1) {
+      for (int r = 0; r < W; r++)
+        if (r != rank && h->rank_ptrs.size() == static_cast<size_t>(W) && h->rank_ptrs[r]) bk->ipc_close_handle(h->rank_ptrs[r]);
+      try {
+        h->comm->barrier();  // nobody frees a shard a peer still maps
+      } catch (...) {
+      }
+    }
+    if (h->local_ptr) {
+      if (h->local_is_pinned)
+        bk->free_pinned(h->local_ptr);
+      else
+        bk->free_device(h->local_ptr);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace wm
+
+extern "C" {
+
+wholememory_error_code_t wholememory_malloc(wholememory_handle_t* wholememory_handle_ptr,
+                                            size_t total_size,
+                                            wholememory_comm_t comm,
+                                            wholememory_memory_type_t memory_type,
+                                            wholememory_memory_location_t memory_location,
+                                            size_t data_granularity,
+                                            size_t* rank_entry_partition)
+{
+  if (wholememory_handle_ptr == nullptr || comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  // argument checks of reference memory_handle.cpp:1793-1830
+  if (total_size == 0) {
+    WM_ERROR("wholememory_malloc: total_size must be > 0");
+    return WHOLEMEMORY_INVALID_VALUE;
+  }
+  if (data_granularity == 0 || total_size % data_granularity != 0) {
+    WM_ERROR("wholememory_malloc: total_size=%zu is not a multiple of data_granularity=%zu", total_size, data_granularity);
+    return WHOLEMEMORY_INVALID_VALUE;
+  }
+  if (memory_type != WHOLEMEMORY_MT_CONTINUOUS && memory_type != WHOLEMEMORY_MT_CHUNKED &&
+      memory_type != WHOLEMEMORY_MT_DISTRIBUTED) {
+    WM_ERROR("wholememory_malloc: memory type %d is not supported by this build", static_cast<int>(memory_type));
+    return memory_type == WHOLEMEMORY_MT_HIERARCHY ? WHOLEMEMORY_NOT_SUPPORTED : WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (memory_location != WHOLEMEMORY_ML_DEVICE && memory_location != WHOLEMEMORY_ML_HOST) return WHOLEMEMORY_INVALID_INPUT;
+  if (rank_entry_partition != nullptr) {
+    size_t sum = 0;
+    for (int i = 0; i < comm->world_size; i++) {
+      if (rank_entry_partition[i] == 0) return WHOLEMEMORY_INVALID_VALUE;  // reference memory_handle.cpp:1808
+      sum += rank_entry_partition[i];
+    }
+    if (sum * data_granularity != total_size) {
+      WM_ERROR("wholememory_malloc: rank_entry_partition sums to %zu entries, expected %zu", sum, total_size / data_granularity);
+      return WHOLEMEMORY_INVALID_VALUE;
+    }
+  }
+  WM_API_BEGIN
+  std::lock_guard<std::mutex> guard(comm->mu);
+  auto* h        = new wholememory_handle_();
+  h->comm        = comm;
+  h->type        = memory_type;
+  h->location    = memory_location;
+  h->total_size  = total_size;
+  h->granularity = data_granularity;
+  wm::plan_partition(h, rank_entry_partition);
+  try {
+    wm::create_memory(h);
+  } catch (...) {
+    wm::destroy_memory(h);
+    delete h;
+    throw;
+  }
+  comm->live_handles++;
+  *wholememory_handle_ptr = h;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_free(wholememory_handle_t h)
+{
+  WM_API_BEGIN
+  if (h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  std::lock_guard<std::mutex> guard(h->comm->mu);
+  wm::destroy_memory(h);
+  h->comm->live_handles--;
+  delete h;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_get_communicator(wholememory_comm_t* comm, wholememory_handle_t h)
+{
+  if (comm == nullptr || h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  *comm = h->comm;
+  return WHOLEMEMORY_SUCCESS;
+}
+wholememory_error_code_t wholememory_get_local_communicator(wholememory_comm_t*, wholememory_handle_t)
+{
+  return WHOLEMEMORY_NOT_SUPPORTED;  // HIERARCHY only
+}
+wholememory_error_code_t wholememory_get_cross_communicator(wholememory_comm_t*, wholememory_handle_t)
+{
+  return WHOLEMEMORY_NOT_SUPPORTED;  // HIERARCHY only
+}
+wholememory_memory_type_t wholememory_get_memory_type(wholememory_handle_t h) { return h ? h->type : WHOLEMEMORY_MT_NONE; }
+wholememory_memory_location_t wholememory_get_memory_location(wholememory_handle_t h)
+{
+  return h ? h->location : WHOLEMEMORY_ML_NONE;
+}
+wholememory_distributed_backend_t wholememory_get_distributed_backend(wholememory_handle_t h)
+{
+  return h ? h->comm->distributed_backend : WHOLEMEMORY_DB_NONE;
+}
+size_t wholememory_get_total_size(wholememory_handle_t h) { return h ? h->total_size : 0; }
+size_t wholememory_get_data_granularity(wholememory_handle_t h) { return h ? h->granularity : 0; }
+
+wholememory_error_code_t wholememory_get_local_memory(void** local_ptr,
+                                                      size_t* local_size,
+                                                      size_t* local_offset,
+                                                      wholememory_handle_t h)
+{
+  if (h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  const int rank = h->comm->world_rank;
+  if (local_ptr) *local_ptr = h->local_ptr;
+  if (local_size) *local_size = h->part_sizes[rank];
+  if (local_offset) *local_offset = h->part_offsets[rank];
+  return WHOLEMEMORY_SUCCESS;
+}
+wholememory_error_code_t wholememory_get_local_size(size_t* local_size, wholememory_handle_t h)
+{
+  return wholememory_get_local_memory(nullptr, local_size, nullptr, h);
+}
+wholememory_error_code_t wholememory_get_local_offset(size_t* local_offset, wholememory_handle_t h)
+{
+  return wholememory_get_local_memory(nullptr, nullptr, local_offset, h);
+}
+
+wholememory_error_code_t wholememory_get_rank_memory(void** rank_memory_ptr,
+                                                     size_t* rank_memory_size,
+                                                     size_t* rank_memory_offset,
+                                                     int rank,
+                                                     wholememory_handle_t h)
+{
+  if (h == nullptr || rank < 0 || rank >= h->comm->world_size) return WHOLEMEMORY_INVALID_INPUT;
+  void* p = nullptr;
+  if (rank == h->comm->world_rank)
+    p = h->local_ptr;
+  else if (h->rank_ptrs.size() == static_cast<size_t>(h->comm->world_size))
+    p = h->rank_ptrs[rank];
+  if (p == nullptr) return WHOLEMEMORY_INVALID_INPUT;  // DISTRIBUTED: peers are not mapped
+  if (rank_memory_ptr) *rank_memory_ptr = p;
+  if (rank_memory_size) *rank_memory_size = h->part_sizes[rank];
+  if (rank_memory_offset) *rank_memory_offset = h->part_offsets[rank];
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t wholememory_equal_entry_partition_plan(size_t* entry_per_rank,
+                                                                size_t total_entry_count,
+                                                                int world_size)
+{
+  if (entry_per_rank == nullptr || world_size <= 0) return WHOLEMEMORY_INVALID_INPUT;
+  *entry_per_rank = (total_entry_count + world_size - 1) / world_size;  // reference memory_handle.cpp:2122-2128
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t wholememory_get_global_pointer(void** global_ptr, wholememory_handle_t h)
+{
+  if (global_ptr == nullptr || h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  // CONTINUOUS, or host CHUNKED (one mapped segment) — reference wholememory.h:399-403
+  bool ok = h->type == WHOLEMEMORY_MT_CONTINUOUS || (h->type == WHOLEMEMORY_MT_CHUNKED && h->location == WHOLEMEMORY_ML_HOST);
+  if (!ok || h->global_base == nullptr) {
+    *global_ptr = nullptr;
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  *global_ptr = h->global_base;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t wholememory_get_global_reference(wholememory_gref_t* gref, wholememory_handle_t h)
+{
+  if (gref == nullptr || h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (h->type == WHOLEMEMORY_MT_CONTINUOUS) {
+    *gref = wholememory_create_continuous_global_reference(h->global_base);
+    gref->world_size = h->comm->world_size;
+    return h->global_base ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (h->type == WHOLEMEMORY_MT_CHUNKED) {  // reference memory_handle.cpp:1174-1185
+    gref->pointer             = h->dev_rank_ptrs;
+    gref->rank_memory_offsets = h->dev_rank_offsets;
+    gref->world_size          = h->comm->world_size;
+    gref->stride              = h->mem_stride;
+    gref->same_chunk          = h->same_chunk;
+    return WHOLEMEMORY_SUCCESS;
+  }
+  return WHOLEMEMORY_NOT_SUPPORTED;  // DISTRIBUTED has no global reference
+}
+
+wholememory_error_code_t wholememory_get_rank_partition_sizes(size_t* rank_mem_sizes, wholememory_handle_t h)
+{
+  if (rank_mem_sizes == nullptr || h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  for (int i = 0; i < h->comm->world_size; i++) rank_mem_sizes[i] = h->part_sizes[i];
+  return WHOLEMEMORY_SUCCESS;
+}
+wholememory_error_code_t wholememory_get_rank_partition_offsets(size_t* rank_mem_offsets, wholememory_handle_t h)
+{
+  if (rank_mem_offsets == nullptr || h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  for (int i = 0; i <= h->comm->world_size; i++) rank_mem_offsets[i] = h->part_offsets[i];
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_gref_t wholememory_create_continuous_global_reference(void* ptr)
+{
+  wholememory_gref_t g;
+  g.pointer             = ptr;
+  g.rank_memory_offsets = nullptr;
+  g.world_size          = 1;
+  g.stride              = 0;
+  g.same_chunk          = true;
+  return g;
+}
+
+}  // extern "C"

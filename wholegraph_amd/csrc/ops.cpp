@@ -1,0 +1,447 @@
+// wholegraph_amd — wholememory_gather / wholememory_scatter: validation, dispatch and the
+// DISTRIBUTED orchestration (host side). Kernels live behind backend.hpp.
+//
+// Reference: cpp/src/wholememory_ops/gather_op.cpp:23-131, gather_op_impl_mapped.cu:29-78,
+// gather_op_impl_nccl.cu:34-182, scatter_op.cpp:23-110, scatter_op_impl_nccl.cu:34-181,
+// functions/exchange_ids_nccl_func.cu:157-226.
+//
+// DISTRIBUTED gather on MI355X (one process per GPU, RCCL over xGMI):
+//   1 bucket ids by owner (stable multisplit kernel: counts + grouped ids + raw positions)
+//   2 counts -> pinned host, ONE stream sync, counts all-to-all (the reference pays two syncs and a
+//     staged host_alltoall, exchange_ids_nccl_func.cu:194-207)
+//   3 ids all-to-all-v (grouped ncclSend/ncclRecv on the caller's stream)
+//   4 owner gathers its rows straight into the send buffer, casting to the output dtype there
+//   5 rows all-to-all-v
+//   6 reorder-on-receive: out[raw_indices[j]] = recv[j]
+// DISTRIBUTED scatter mirrors it (rows travel in the input dtype, the owner casts on write) and ends
+// with a stream synchronise like the reference (scatter_op_impl_nccl.cu:168).
+#include "ops_internal.hpp"
+
+#include <cstring>
+
+namespace wm {
+
+#define WM_BK(call)                                                                                  \
+  do {                                                                                               \
+    int rc__ = (call);                                                                               \
+    if (rc__ != 0) throw ::wm::hip_error(::wm::format_string("%s failed with code %d", #call, rc__)); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+temp_mem::temp_mem(wholememory_env_func_t* env) : env_(env)
+{
+  WM_CHECK(env != nullptr, "p_env_fns must not be null");
+  env_->temporary_fns.create_memory_context_fn(&ctx_, env_->temporary_fns.global_context);
+}
+temp_mem::~temp_mem()
+{
+  if (ptr_ != nullptr) env_->temporary_fns.free_fn(ctx_, env_->temporary_fns.global_context);
+  env_->temporary_fns.destroy_memory_context_fn(ctx_, env_->temporary_fns.global_context);
+}
+void* temp_mem::alloc(int64_t elt_count, wholememory_dtype_t dtype, wholememory_memory_allocation_type_t type)
+{
+  WM_CHECK(ptr_ == nullptr, "temp_mem slot reused");
+  wholememory_tensor_description_t d;
+  wholememory_initialize_tensor_desc(&d);
+  d.dim      = 1;
+  d.sizes[0] = elt_count > 0 ? elt_count : 1;  // never hand a zero-size request to the host allocator
+  d.dtype    = dtype;
+  ptr_       = env_->temporary_fns.malloc_fn(&d, type, ctx_, env_->temporary_fns.global_context);
+  if (ptr_ == nullptr) throw std::bad_alloc();
+  return ptr_;
+}
+
+// ------------------------------------------------------------------------------------------------
+void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
+                             const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream,
+                             id_exchange* x)
+{
+  const auto* bk = backend();
+  const int W    = comm->world_size;
+  const size_t ies = wholememory_dtype_get_element_size(index_dtype);
+  x->send_counts.assign(W, 0);
+  x->recv_counts.assign(W, 0);
+  x->send_offsets.assign(W + 1, 0);
+  x->recv_offsets.assign(W + 1, 0);
+
+  temp_mem dev_offsets(env), dev_counts(env), workspace(env), host_counts(env);
+  auto* d_off = static_cast<uint64_t*>(dev_offsets.device(W + 1, WHOLEMEMORY_DT_INT64));
+  auto* d_cnt = static_cast<int64_t*>(dev_counts.device(W, WHOLEMEMORY_DT_INT64));
+  auto* h_cnt = static_cast<int64_t*>(host_counts.pinned(2 * (W + 1), WHOLEMEMORY_DT_INT64));
+  // stage the offsets through pinned memory so the H2D copy is truly asynchronous
+  uint64_t* h_off = reinterpret_cast<uint64_t*>(h_cnt + W);
+  for (int i = 0; i <= W; i++) h_off[i] = entry_offsets[i];
+  WM_BK(bk->memcpy_async(d_off, h_off, sizeof(uint64_t) * (W + 1), stream));
+
+  x->bucketed_ids = x->bucketed_mem.device(n, index_dtype);
+  x->raw_indices  = static_cast<int64_t*>(x->raw_mem.device(n, WHOLEMEMORY_DT_INT64));
+
+  wm_bucket_args ba{};
+  ba.indices       = indices;
+  ba.index_dtype   = index_dtype;
+  ba.n             = n;
+  ba.entry_offsets = d_off;
+  ba.world_size    = W;
+  ba.counts        = d_cnt;
+  ba.bucketed_ids  = x->bucketed_ids;
+  ba.raw_indices   = x->raw_indices;
+  ba.workspace     = workspace.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, W)), WHOLEMEMORY_DT_INT8);
+  WM_BK(bk->bucket_ids(&ba, stream));
+  WM_BK(bk->memcpy_async(h_cnt, d_cnt, sizeof(int64_t) * W, stream));
+  WM_BK(bk->stream_sync(stream));
+  for (int i = 0; i < W; i++) x->send_counts[i] = h_cnt[i];
+  comm->alltoall_host_i64(x->send_counts.data(), x->recv_counts.data());
+  for (int i = 0; i < W; i++) {
+    x->send_offsets[i + 1] = x->send_offsets[i] + x->send_counts[i];
+    x->recv_offsets[i + 1] = x->recv_offsets[i] + x->recv_counts[i];
+  }
+  x->total_send = x->send_offsets[W];
+  x->total_recv = x->recv_offsets[W];
+  x->recv_ids   = x->recv_mem.device(x->total_recv, index_dtype);
+  exchange_rows(comm, x->bucketed_ids, x->send_counts, x->recv_ids, x->recv_counts, ies, stream);
+  if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+}
+
+void exchange_rows(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts, void* recv,
+                   const std::vector<int64_t>& recv_counts, size_t row_bytes, void* stream)
+{
+  const int W = comm->world_size;
+  std::vector<size_t> sb(W), sd(W), rb(W), rd(W);
+  size_t so = 0, ro = 0;
+  for (int i = 0; i < W; i++) {
+    sb[i] = static_cast<size_t>(send_counts[i]) * row_bytes;
+    rb[i] = static_cast<size_t>(recv_counts[i]) * row_bytes;
+    sd[i] = so, rd[i] = ro;
+    so += sb[i], ro += rb[i];
+  }
+  comm->alltoallv_device(send, sb.data(), sd.data(), recv, rb.data(), rd.data(), stream);
+}
+
+std::vector<size_t> entry_offsets_of(wholememory_handle_t handle, size_t entry_bytes)
+{
+  wholememory_comm_t comm;
+  WM_CHECK(wholememory_get_communicator(&comm, handle) == WHOLEMEMORY_SUCCESS, "handle has no communicator");
+  std::vector<size_t> off(comm->world_size + 1);
+  WM_CHECK(wholememory_get_rank_partition_offsets(off.data(), handle) == WHOLEMEMORY_SUCCESS, "partition offsets");
+  for (auto& o : off) {
+    // reference gather_op_impl_nccl.cu:83-93 (NOTHROW check -> abort)
+    WM_CHECK_ABORT(o % entry_bytes == 0, "embedding memory offset %zu is not a multiple of the row size %zu", o, entry_bytes);
+    o /= entry_bytes;
+  }
+  return off;
+}
+
+wholememory_gref_t local_shard_gref(wholememory_handle_t handle)
+{
+  void* p = nullptr;
+  size_t sz, off;
+  WM_CHECK(wholememory_get_local_memory(&p, &sz, &off, handle) == WHOLEMEMORY_SUCCESS, "local memory");
+  // "fake" flat base so that GLOBAL row ids address the local shard (reference gather_op_impl_nccl.cu:122-126)
+  return wholememory_create_continuous_global_reference(static_cast<char*>(p) - off);
+}
+
+namespace {
+
+struct op_descs {
+  wholememory_matrix_description_t table;
+  wholememory_array_description_t indices;
+  wholememory_matrix_description_t plain;
+  void* indices_ptr;
+  void* plain_ptr;
+};
+
+// shared argument validation of gather_op.cpp:36-86 / scatter_op.cpp:36-88
+wholememory_error_code_t check_args(wholememory_tensor_t wm_tensor, wholememory_tensor_t indices_tensor,
+                                    wholememory_tensor_t plain_tensor, const char* plain_name, op_descs* d)
+{
+  if (wm_tensor == nullptr || indices_tensor == nullptr || plain_tensor == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  auto td = *wholememory_tensor_get_tensor_description(wm_tensor);
+  if (td.dim != 1 && td.dim != 2) {
+    WM_ERROR("wholememory_tensor should be 1D or 2D tensor.");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (td.dim == 1 && !wholememory_unsqueeze_tensor(&td, 1)) return WHOLEMEMORY_LOGIC_ERROR;
+  if (!wholememory_convert_tensor_desc_to_matrix(&d->table, &td)) return WHOLEMEMORY_LOGIC_ERROR;
+  if (wholememory_tensor_get_tensor_description(indices_tensor)->dim != 1) {
+    WM_ERROR("indices tensor should be 1D tensor");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  auto pd = *wholememory_tensor_get_tensor_description(plain_tensor);
+  if (pd.dim != wholememory_tensor_get_tensor_description(wm_tensor)->dim) {
+    WM_ERROR("%s tensor should be same dim as wholememory_tensor.", plain_name);
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (pd.dim == 1 && !wholememory_unsqueeze_tensor(&pd, 1)) return WHOLEMEMORY_LOGIC_ERROR;
+  if (!wholememory_convert_tensor_desc_to_array(&d->indices, wholememory_tensor_get_tensor_description(indices_tensor))) {
+    WM_ERROR("Convert indices tensor to array failed.");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (!wholememory_convert_tensor_desc_to_matrix(&d->plain, &pd)) {
+    WM_ERROR("Convert %s tensor to matrix failed.", plain_name);
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  d->indices_ptr = wholememory_tensor_get_data_pointer(indices_tensor);
+  d->plain_ptr   = wholememory_tensor_get_data_pointer(plain_tensor);
+  // functions/gather_func.cu:72-105 / scatter_func.cu: dtype rules
+  if (d->indices.dtype != WHOLEMEMORY_DT_INT && d->indices.dtype != WHOLEMEMORY_DT_INT64) {
+    WM_ERROR("indices must be int32 or int64");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (wholememory_dtype_is_floating_number(d->table.dtype) != wholememory_dtype_is_floating_number(d->plain.dtype)) {
+    WM_ERROR("embedding and %s must both be floating point or both be integer", plain_name);
+    return WHOLEMEMORY_LOGIC_ERROR;  // reference gather_func.cu:79-81 throws logic_error
+  }
+  if (d->plain.sizes[0] < d->indices.size) {
+    WM_ERROR("%s rows (%ld) < indices count (%ld)", plain_name, static_cast<long>(d->plain.sizes[0]),
+             static_cast<long>(d->indices.size));
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (d->plain.sizes[1] != d->table.sizes[1]) {
+    WM_ERROR("%s columns (%ld) != embedding columns (%ld)", plain_name, static_cast<long>(d->plain.sizes[1]),
+             static_cast<long>(d->table.sizes[1]));
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  return WHOLEMEMORY_SUCCESS;
+}
+
+void fill_rows_args(wm_rows_args* a, const wholememory_gref_t& gref, const wholememory_matrix_description_t& table,
+                    const void* indices, wholememory_dtype_t index_dtype, int64_t n, void* plain,
+                    const wholememory_matrix_description_t& plain_desc, int max_blocks)
+{
+  a->gref                 = gref;
+  a->table_dtype          = table.dtype;
+  a->dim                  = table.sizes[1];
+  a->table_stride         = table.stride;
+  a->table_storage_offset = table.storage_offset;
+  a->indices              = indices;
+  a->index_dtype          = index_dtype;
+  a->n                    = n;
+  a->row_map              = nullptr;
+  a->plain                = plain;
+  a->plain_dtype          = plain_desc.dtype;
+  a->plain_stride         = plain_desc.stride;
+  // `plain` comes from wholememory_tensor_get_data_pointer(), which has ALREADY applied the
+  // descriptor's storage_offset. The reference adds it a second time inside its kernels
+  // (gather_scatter_func.cuh:293,564 on top of wholememory_tensor.cpp:290-293) — harmless there only
+  // because every caller passes offset 0 (wholegraph_env.py:173-182). Applied once here.
+  a->plain_storage_offset = 0;
+  a->max_blocks           = max_blocks;
+}
+
+// gref a kernel should use for a mapped tensor: with a single rank everything is one flat block
+wholememory_error_code_t mapped_gref(wholememory_tensor_t t, wholememory_gref_t* gref)
+{
+  if (wholememory_tensor_has_handle(t)) {
+    auto h = wholememory_tensor_get_memory_handle(t);
+    wholememory_comm_t comm;
+    WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, h));
+    if (comm->world_size == 1) {
+      void* p;
+      size_t sz, off;
+      WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_local_memory(&p, &sz, &off, h));
+      *gref = wholememory_create_continuous_global_reference(p);
+      return WHOLEMEMORY_SUCCESS;
+    }
+  }
+  return wholememory_tensor_get_global_reference(t, gref);
+}
+
+wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const op_descs& d,
+                                            wholememory_env_func_t* env, void* stream, int gather_sms)
+{
+  const auto* bk = backend();
+  if (d.table.storage_offset < 0 || d.table.storage_offset + d.table.sizes[1] > d.table.stride)
+    return WHOLEMEMORY_INVALID_INPUT;  // gather_op_impl_nccl.cu:45-48
+  wholememory_comm_t comm;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, handle));
+  const size_t tes         = wholememory_dtype_get_element_size(d.table.dtype);
+  const size_t oes         = wholememory_dtype_get_element_size(d.plain.dtype);
+  const size_t ies         = wholememory_dtype_get_element_size(d.indices.dtype);
+  const int64_t dim        = d.table.sizes[1];
+  auto entry_offsets       = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
+  const char* indices      = static_cast<const char*>(d.indices_ptr);  // data pointer: offset already applied
+  (void)ies;
+
+  id_exchange x(env);
+  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x);
+
+  // owner side: rows of the received ids, already in the output dtype (gather_op_impl_nccl.cu:115-140)
+  temp_mem local_rows(env), recv_rows(env);
+  void* local_buf = local_rows.device(dim * x.total_recv, d.plain.dtype);
+  void* recv_buf  = recv_rows.device(dim * x.total_send, d.plain.dtype);
+  int64_t lsz[2]  = {x.total_recv, dim};
+  auto local_desc = wholememory_create_matrix_desc(lsz, dim, 0, d.plain.dtype);
+  wm_rows_args ga{};
+  fill_rows_args(&ga, local_shard_gref(handle), d.table, x.recv_ids, d.indices.dtype, x.total_recv, local_buf,
+                 local_desc, gather_sms);
+  WM_BK(bk->gather_rows(&ga, stream));
+  if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+
+  // rows travel back along the reverse of the id exchange (gather_op_impl_nccl.cu:141-150)
+  exchange_rows(comm, local_buf, x.recv_counts, recv_buf, x.send_counts, static_cast<size_t>(dim) * oes, stream);
+
+  // reorder on receive: out[raw_indices[j]] = recv[j]  (gather_op_impl_nccl.cu:151-168)
+  int64_t rsz[2] = {x.total_send, dim};
+  auto recv_desc = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
+  wm_rows_args sa{};
+  fill_rows_args(&sa, wholememory_create_continuous_global_reference(d.plain_ptr), d.plain, x.raw_indices,
+                 WHOLEMEMORY_DT_INT64, x.total_send, recv_buf, recv_desc, -1);
+  WM_BK(bk->scatter_rows(&sa, stream));
+  if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const op_descs& d,
+                                             wholememory_env_func_t* env, void* stream, int scatter_sms)
+{
+  const auto* bk = backend();
+  if (d.table.storage_offset < 0 || d.table.storage_offset + d.table.sizes[1] > d.table.stride)
+    return WHOLEMEMORY_INVALID_INPUT;  // scatter_op_impl_nccl.cu:45-48
+  wholememory_comm_t comm;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, handle));
+  const size_t tes    = wholememory_dtype_get_element_size(d.table.dtype);
+  const size_t pes    = wholememory_dtype_get_element_size(d.plain.dtype);
+  const size_t ies    = wholememory_dtype_get_element_size(d.indices.dtype);
+  const int64_t dim   = d.table.sizes[1];
+  auto entry_offsets  = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
+  const char* indices = static_cast<const char*>(d.indices_ptr);  // data pointer: offset already applied
+  (void)ies;
+
+  id_exchange x(env);
+  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x);
+
+  // requester side: input rows lined up in send order (scatter_op_impl_nccl.cu:118-133)
+  temp_mem send_rows(env), recv_rows(env);
+  void* send_buf = send_rows.device(dim * x.total_send, d.plain.dtype);
+  void* recv_buf = recv_rows.device(dim * x.total_recv, d.plain.dtype);
+  int64_t ssz[2] = {x.total_send, dim};
+  auto send_desc = wholememory_create_matrix_desc(ssz, dim, 0, d.plain.dtype);
+  wm_rows_args ga{};
+  fill_rows_args(&ga, wholememory_create_continuous_global_reference(d.plain_ptr), d.plain, x.raw_indices,
+                 WHOLEMEMORY_DT_INT64, x.total_send, send_buf, send_desc, -1);
+  WM_BK(bk->gather_rows(&ga, stream));
+
+  exchange_rows(comm, send_buf, x.send_counts, recv_buf, x.recv_counts, static_cast<size_t>(dim) * pes, stream);
+
+  // owner side: write (and cast) into the local shard (scatter_op_impl_nccl.cu:145-166)
+  int64_t rsz[2] = {x.total_recv, dim};
+  auto recv_desc = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
+  wm_rows_args sa{};
+  fill_rows_args(&sa, local_shard_gref(handle), d.table, x.recv_ids, d.indices.dtype, x.total_recv, recv_buf,
+                 recv_desc, scatter_sms);
+  WM_BK(bk->scatter_rows(&sa, stream));
+  WM_BK(bk->stream_sync(stream));  // scatter_op_impl_nccl.cu:168
+  return WHOLEMEMORY_SUCCESS;
+}
+
+}  // namespace
+}  // namespace wm
+
+extern "C" {
+
+wholememory_error_code_t wholememory_gather(wholememory_tensor_t wholememory_tensor,
+                                            wholememory_tensor_t indices_tensor,
+                                            wholememory_tensor_t output_tensor,
+                                            wholememory_env_func_t* p_env_fns,
+                                            void* stream,
+                                            int gather_sms)
+{
+  WM_API_BEGIN
+  wm::op_descs d;
+  WHOLEMEMORY_RETURN_ON_FAIL(wm::check_args(wholememory_tensor, indices_tensor, output_tensor, "output", &d));
+  const bool has_handle = wholememory_tensor_has_handle(wholememory_tensor);
+  auto mt = has_handle ? wholememory_get_memory_type(wholememory_tensor_get_memory_handle(wholememory_tensor))
+                       : WHOLEMEMORY_MT_NONE;
+  if (has_handle && mt == WHOLEMEMORY_MT_DISTRIBUTED)
+    return wm::gather_distributed(wholememory_tensor_get_memory_handle(wholememory_tensor), d, p_env_fns, stream, gather_sms);
+  if (has_handle && mt != WHOLEMEMORY_MT_CHUNKED && mt != WHOLEMEMORY_MT_CONTINUOUS) return WHOLEMEMORY_NOT_SUPPORTED;
+  wholememory_gref_t gref;
+  WHOLEMEMORY_RETURN_ON_FAIL(wm::mapped_gref(wholememory_tensor, &gref));
+  wm_rows_args a{};
+  wm::fill_rows_args(&a, gref, d.table, d.indices_ptr, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain, gather_sms);
+  int rc = wm::backend()->gather_rows(&a, stream);
+  if (rc == -1) return WHOLEMEMORY_INVALID_INPUT;
+  if (rc != 0) return WHOLEMEMORY_CUDA_ERROR;
+  if (wm::debug_sync_enabled() && wm::backend()->stream_sync(stream) != 0) return WHOLEMEMORY_CUDA_ERROR;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_scatter(wholememory_tensor_t input_tensor,
+                                             wholememory_tensor_t indices_tensor,
+                                             wholememory_tensor_t wholememory_tensor,
+                                             wholememory_env_func_t* p_env_fns,
+                                             void* stream,
+                                             int scatter_sms)
+{
+  WM_API_BEGIN
+  wm::op_descs d;
+  WHOLEMEMORY_RETURN_ON_FAIL(wm::check_args(wholememory_tensor, indices_tensor, input_tensor, "input", &d));
+  const bool has_handle = wholememory_tensor_has_handle(wholememory_tensor);
+  auto mt = has_handle ? wholememory_get_memory_type(wholememory_tensor_get_memory_handle(wholememory_tensor))
+                       : WHOLEMEMORY_MT_NONE;
+  if (has_handle && mt == WHOLEMEMORY_MT_DISTRIBUTED)
+    return wm::scatter_distributed(wholememory_tensor_get_memory_handle(wholememory_tensor), d, p_env_fns, stream, scatter_sms);
+  if (has_handle && mt != WHOLEMEMORY_MT_CHUNKED && mt != WHOLEMEMORY_MT_CONTINUOUS) return WHOLEMEMORY_NOT_SUPPORTED;
+  wholememory_gref_t gref;
+  WHOLEMEMORY_RETURN_ON_FAIL(wm::mapped_gref(wholememory_tensor, &gref));
+  wm_rows_args a{};
+  wm::fill_rows_args(&a, gref, d.table, d.indices_ptr, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain, scatter_sms);
+  int rc = wm::backend()->scatter_rows(&a, stream);
+  if (rc == -1) return WHOLEMEMORY_INVALID_INPUT;
+  if (rc != 0) return WHOLEMEMORY_CUDA_ERROR;
+  if (wm::debug_sync_enabled() && wm::backend()->stream_sync(stream) != 0) return WHOLEMEMORY_CUDA_ERROR;
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_ext_bucket_ids(const void* indices,
+                                                    wholememory_dtype_t index_dtype,
+                                                    int64_t n,
+                                                    const void* entry_offsets_dev,
+                                                    int world_size,
+                                                    int64_t* counts_dev,
+                                                    void* bucketed_ids_dev,
+                                                    int64_t* raw_indices_dev,
+                                                    wholememory_env_func_t* p_env_fns,
+                                                    void* stream)
+{
+  WM_API_BEGIN
+  if (n < 0 || world_size < 1 || counts_dev == nullptr || entry_offsets_dev == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if ((bucketed_ids_dev == nullptr) != (raw_indices_dev == nullptr)) return WHOLEMEMORY_INVALID_INPUT;
+  const auto* bk = wm::backend();
+  wm::temp_mem ws(p_env_fns);
+  wm_bucket_args ba{};
+  ba.indices       = indices;
+  ba.index_dtype   = index_dtype;
+  ba.n             = n;
+  ba.entry_offsets = static_cast<const uint64_t*>(entry_offsets_dev);
+  ba.world_size    = world_size;
+  ba.counts        = counts_dev;
+  ba.bucketed_ids  = bucketed_ids_dev;
+  ba.raw_indices   = raw_indices_dev;
+  ba.workspace     = ws.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, world_size)), WHOLEMEMORY_DT_INT8);
+  int rc           = bk->bucket_ids(&ba, stream);
+  if (rc == -1) return WHOLEMEMORY_INVALID_INPUT;
+  return rc == 0 ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_CUDA_ERROR;
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_ext_round_robin_map(const void* ids,
+                                                         void* mapped,
+                                                         wholememory_dtype_t index_dtype,
+                                                         int64_t n,
+                                                         int64_t entry_start,
+                                                         int world_size,
+                                                         int round_robin_size,
+                                                         void* stream)
+{
+  WM_API_BEGIN
+  if (round_robin_size <= 0 || world_size <= 0) return WHOLEMEMORY_INVALID_INPUT;
+  int rc = wm::backend()->round_robin_map(ids, mapped, index_dtype, n, entry_start, world_size, round_robin_size, stream);
+  if (rc == -1) return WHOLEMEMORY_INVALID_INPUT;
+  return rc == 0 ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_CUDA_ERROR;
+  WM_API_END
+}
+
+}  // extern "C"

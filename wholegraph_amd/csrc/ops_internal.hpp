@@ -1,0 +1,63 @@
+// wholegraph_amd — internals shared by ops.cpp and embedding.cpp (host orchestration helpers).
+#pragma once
+
+#include <vector>
+
+#include <wholememory/wholegraph_amd_ext.h>
+#include <wholememory/wholememory_op.h>
+
+#include "backend.hpp"
+#include "communicator.hpp"
+#include "wm_common.hpp"
+
+namespace wm {
+
+// One scratch allocation obtained through the caller's env functions (reference
+// wholememory_ops/temp_memory_handle.hpp:23-93): create ctx -> malloc -> free -> destroy ctx.
+class temp_mem {
+ public:
+  explicit temp_mem(wholememory_env_func_t* env);
+  ~temp_mem();
+  temp_mem(const temp_mem&)            = delete;
+  temp_mem& operator=(const temp_mem&) = delete;
+  void* alloc(int64_t elt_count, wholememory_dtype_t dtype, wholememory_memory_allocation_type_t type);
+  void* device(int64_t n, wholememory_dtype_t dt) { return alloc(n, dt, WHOLEMEMORY_MA_DEVICE); }
+  void* pinned(int64_t n, wholememory_dtype_t dt) { return alloc(n, dt, WHOLEMEMORY_MA_PINNED); }
+  void* host(int64_t n, wholememory_dtype_t dt) { return alloc(n, dt, WHOLEMEMORY_MA_HOST); }
+  void* get() const { return ptr_; }
+
+ private:
+  wholememory_env_func_t* env_;
+  void* ctx_ = nullptr;
+  void* ptr_ = nullptr;
+};
+
+// Result of bucket + exchange of lookup ids (reference bucket_and_exchange_ids_func,
+// functions/exchange_ids_nccl_func.cu:157-226).
+struct id_exchange {
+  explicit id_exchange(wholememory_env_func_t* env) : bucketed_mem(env), raw_mem(env), recv_mem(env) {}
+  std::vector<int64_t> send_counts, recv_counts;    // per peer
+  std::vector<int64_t> send_offsets, recv_offsets;  // exclusive prefix, W+1
+  int64_t total_send = 0;                           // valid (non-negative) ids of this rank
+  int64_t total_recv = 0;                           // ids this rank owns, from all peers
+  void* bucketed_ids   = nullptr;                   // [n]   ids grouped by owner (index dtype)
+  int64_t* raw_indices = nullptr;                   // [n]   original position of each grouped id
+  void* recv_ids       = nullptr;                   // [total_recv] ids received, peer-major
+  temp_mem bucketed_mem, raw_mem, recv_mem;
+};
+
+void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
+                             const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream,
+                             id_exchange* x);
+
+// all-to-all-v of fixed-size rows: counts in rows, peer-major contiguous on both sides
+void exchange_rows(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts, void* recv,
+                   const std::vector<int64_t>& recv_counts, size_t row_bytes, void* stream);
+
+// row offsets [W+1] of a handle whose rows are entry_bytes wide
+std::vector<size_t> entry_offsets_of(wholememory_handle_t handle, size_t entry_bytes);
+
+// flat gref through which GLOBAL row ids address this rank's shard
+wholememory_gref_t local_shard_gref(wholememory_handle_t handle);
+
+}  // namespace wm

@@ -1,0 +1,307 @@
+"""WholeMemoryEmbedding / WholeMemoryOptimizer — the user-facing embedding table.
+
+Mirrors reference ``python/pylibwholegraph/pylibwholegraph/torch/embedding.py`` (:33-67 optimizer,
+:214-238 autograd function, :241-377 embedding, :380-524 factories, :537-577 module + optimizer
+factories): same names, keyword arguments, autograd contract (backward only stashes (indice, grad);
+``WholeMemoryOptimizer.step(lr)`` applies them through the C ABI and then barriers).
+"""
+import ctypes as C
+from typing import List, Union
+
+import torch
+
+from .. import binding as wmb
+from .comm import WholeMemoryCommunicator, get_global_communicator, get_local_node_communicator, \
+    get_local_device_communicator
+from .tensor import WholeMemoryTensor
+from .utils import (
+    torch_dtype_to_wholememory_dtype,
+    str_to_wmb_wholememory_memory_type,
+    str_to_wmb_wholememory_location,
+    str_to_wmb_wholememory_access_type,
+    str_to_wmb_wholememory_optimizer_type,
+    get_file_size,
+)
+from .wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream
+
+
+class WholeMemoryOptimizer(object):
+    """Sparse optimizer shared by any number of embeddings; create with create_wholememory_optimizer."""
+
+    def __init__(self, global_comm: WholeMemoryCommunicator):
+        super().__init__()
+        self.wmb_opt = C.c_void_p()
+        self.embeddings = []
+        self.global_comm = global_comm
+
+    def add_embedding(self, wm_embedding):
+        assert isinstance(wm_embedding, WholeMemoryEmbedding)
+        if wm_embedding.wmb_optimizer is not None:
+            raise ValueError("optimizer can only be set once.")
+        wm_embedding.wmb_optimizer = self.wmb_opt
+        wm_embedding.dummy_input.requires_grad_(True)
+        wmb.check(wmb.lib().wholememory_embedding_set_optimizer(wm_embedding.wmb_embedding, self.wmb_opt))
+        self.embeddings.append(wm_embedding)
+
+    def step(self, lr: float):
+        for wm_embedding in self.embeddings:
+            if wm_embedding.need_apply:
+                wm_embedding.apply_gradients(lr)
+        self.global_comm.barrier()
+
+
+class WholeMemoryCachePolicy(object):
+    def __init__(self, wmb_cache_policy):
+        super().__init__()
+        self.wmb_cache_policy = wmb_cache_policy
+
+
+def create_wholememory_cache_policy(cache_comm, *, memory_type="chunked", memory_location="cuda",
+                                    access_type="readonly", ratio=0.5):
+    p = C.c_void_p()
+    wmb.check(wmb.lib().wholememory_create_embedding_cache_policy(
+        C.byref(p), cache_comm.wmb_comm, str_to_wmb_wholememory_memory_type(memory_type),
+        str_to_wmb_wholememory_location(memory_location), str_to_wmb_wholememory_access_type(access_type), ratio))
+    return WholeMemoryCachePolicy(p)
+
+
+def destroy_wholememory_cache_policy(cache_policy):
+    wmb.check(wmb.lib().wholememory_destroy_embedding_cache_policy(cache_policy.wmb_cache_policy))
+    cache_policy.wmb_cache_policy = None
+
+
+def create_builtin_cache_policy(builtin_cache_type, embedding_memory_type, embedding_memory_location, access_type,
+                                cache_ratio, *, cache_memory_type="", cache_memory_location=""):
+    """Policy objects can be built; embeddings that USE one are not implemented in this build
+    (create_embedding raises NotImplementedError) — see DESIGN.md, out-of-scope list."""
+    if embedding_memory_type not in ("continuous", "chunked", "distributed", "hierarchy"):
+        raise ValueError(f"embedding_memory_type={embedding_memory_type} is not valid")
+    if embedding_memory_location not in ("cpu", "cuda"):
+        raise ValueError(f"embedding_memory_location={embedding_memory_location} is not valid")
+    if builtin_cache_type == "none":
+        return None
+    if cache_memory_location not in ("", "cpu", "cuda"):
+        raise ValueError(f"cache_memory_location is {cache_memory_location}, should be empty or cpu, cuda")
+    cache_memory_location = "cuda" if cache_memory_location == "" else cache_memory_location
+    if builtin_cache_type == "all_devices":
+        cache_memory_type = embedding_memory_type if cache_memory_type == "" else cache_memory_type
+        return create_wholememory_cache_policy(get_global_communicator(), memory_type=cache_memory_type,
+                                               memory_location=cache_memory_location, access_type=access_type,
+                                               ratio=cache_ratio)
+    if builtin_cache_type == "local_node":
+        cache_memory_type = "chunked" if cache_memory_type == "" else cache_memory_type
+        return create_wholememory_cache_policy(get_local_node_communicator(), memory_type=cache_memory_type,
+                                               memory_location=cache_memory_location, access_type=access_type,
+                                               ratio=cache_ratio)
+    if builtin_cache_type == "local_device":
+        return create_wholememory_cache_policy(get_local_device_communicator(), memory_type="continuous",
+                                               memory_location=cache_memory_location, access_type=access_type,
+                                               ratio=cache_ratio)
+    raise ValueError(f"builtin_cache_type={builtin_cache_type} not supported, "
+                     f"should be none, local_device, local_node or all_devices")
+
+
+class EmbeddingLookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, indice, dummy_input, wm_embedding, is_training=False, force_dtype=None):
+        output_tensor = wm_embedding.gather(indice, is_training=is_training, force_dtype=force_dtype)
+        if is_training and wm_embedding.need_grad():
+            ctx.save_for_backward(indice, output_tensor, dummy_input)
+            ctx.wm_embedding = wm_embedding
+        return output_tensor
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        indice, output_tensor, dummy_input = ctx.saved_tensors
+        wm_embedding = ctx.wm_embedding
+        wm_embedding.add_gradients(indice, grad_outputs)
+        ctx.wm_embedding = None
+        return None, torch.zeros_like(dummy_input), None, None, None
+
+
+class WholeMemoryEmbedding(object):
+    def __init__(self, wmb_embedding, wmb_cache_policy: Union[WholeMemoryCachePolicy, None]):
+        super().__init__()
+        self.wmb_embedding = wmb_embedding  # c_void_p (wholememory_embedding_t)
+        self.embedding_tensor = None
+        self.optimizer_states = dict()
+        self.wmb_cache_policy = wmb_cache_policy
+        self.adjust_cache = True if self.wmb_cache_policy is not None else False
+        self.wmb_optimizer = None
+        self.dummy_input = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
+        self.need_apply = False
+        self.sparse_indices = []
+        self.sparse_grads = []
+
+    def dim(self):
+        return self.get_embedding_tensor().dim()
+
+    @property
+    def shape(self):
+        return self.get_embedding_tensor().shape
+
+    def set_adjust_cache(self, adjust_cache: bool):
+        self.adjust_cache = adjust_cache if self.wmb_cache_policy is not None else False
+
+    def need_grad(self):
+        return self.wmb_embedding is not None
+
+    def gather(self, indice: torch.Tensor, *, is_training: bool = False, force_dtype: Union[torch.dtype, None] = None):
+        assert indice.dim() == 1
+        emb = self.get_embedding_tensor()
+        output_dtype = force_dtype if force_dtype is not None else emb.dtype
+        need_grad = self.need_grad() and is_training
+        output_tensor = torch.empty([indice.shape[0], emb.shape[1]], device="cuda:%d" % torch.cuda.current_device(),
+                                    dtype=output_dtype, requires_grad=need_grad)
+        if need_grad:
+            self.need_apply = True
+        wi, wo = wrap_torch_tensor(indice), wrap_torch_tensor(output_tensor)
+        wmb.check(wmb.lib().wholememory_embedding_gather(self.wmb_embedding, wi.handle, wo.handle, self.adjust_cache,
+                                                         get_wholegraph_env_fns(), get_stream()))
+        return output_tensor
+
+    def add_gradients(self, indice: torch.Tensor, grad_outputs: torch.Tensor):
+        self.sparse_indices.append(indice)
+        self.sparse_grads.append(grad_outputs)
+
+    def apply_gradients(self, lr: float):
+        sparse_indices = torch.cat(self.sparse_indices)
+        sparse_grads = torch.cat(self.sparse_grads).contiguous()
+        wi, wg = wrap_torch_tensor(sparse_indices), wrap_torch_tensor(sparse_grads)
+        wmb.check(wmb.lib().wholememory_embedding_gather_gradient_apply(
+            self.wmb_embedding, wi.handle, wg.handle, self.adjust_cache, lr, get_wholegraph_env_fns(), get_stream()))
+        self.sparse_indices = []
+        self.sparse_grads = []
+        self.need_apply = False
+
+    def writeback_all_cache(self):
+        wmb.check(wmb.lib().wholememory_embedding_writeback_cache(self.wmb_embedding, get_stream(False)))
+
+    def drop_all_cache(self):
+        wmb.check(wmb.lib().wholememory_embedding_drop_all_cache(self.wmb_embedding, get_stream(False)))
+
+    def get_embedding_tensor(self):
+        if self.embedding_tensor is None:
+            self.embedding_tensor = WholeMemoryTensor(
+                C.c_void_p(wmb.lib().wholememory_embedding_get_embedding_tensor(self.wmb_embedding)))
+        return self.embedding_tensor
+
+    def get_optimizer_state_names(self):
+        names = wmb.lib().wholememory_embedding_get_optimizer_state_names(self.wmb_embedding)
+        out, i = [], 0
+        while names and names[i] is not None:
+            out.append(names[i].decode())
+            i += 1
+        return out
+
+    def get_optimizer_state(self, state_name):
+        if state_name not in self.optimizer_states:
+            p = wmb.lib().wholememory_embedding_get_optimizer_state(self.wmb_embedding, state_name.encode())
+            if not p:
+                raise ValueError("no optimizer state named %s" % state_name)
+            self.optimizer_states[state_name] = WholeMemoryTensor(C.c_void_p(p))
+        return self.optimizer_states[state_name]
+
+    def save(self, file_prefix: str):
+        self.get_embedding_tensor().to_file_prefix(file_prefix + "_embedding_tensor")
+        for state_name in self.get_optimizer_state_names():
+            self.get_optimizer_state(state_name).to_file_prefix(file_prefix + "_" + state_name)
+
+    def load(self, file_prefix: str, *, ignore_embedding: bool = False, part_count: Union[int, None] = None):
+        if ignore_embedding is False:
+            self.get_embedding_tensor().from_file_prefix(file_prefix + "_embedding_tensor", part_count)
+        for state_name in self.get_optimizer_state_names():
+            self.get_optimizer_state(state_name).from_file_prefix(file_prefix + "_" + state_name, part_count)
+
+
+def create_embedding(comm: WholeMemoryCommunicator, memory_type: str, memory_location: str, dtype: torch.dtype,
+                     sizes: List[int], *, cache_policy: Union[WholeMemoryCachePolicy, None] = None,
+                     embedding_entry_partition: Union[List[int], None] = None, random_init: bool = False,
+                     gather_sms: int = -1, round_robin_size: int = 0):
+    """Collective. sizes must be 2-D. reference embedding.py:380-459."""
+    assert len(sizes) == 2
+    if embedding_entry_partition is not None and cache_policy is not None:
+        print("embedding_entry_partition is ignored because cache_policy is specified")
+        embedding_entry_partition = None
+    if embedding_entry_partition is not None and round_robin_size != 0:
+        print("round_robin_size is ignored because embedding_entry_partition is specified")
+        round_robin_size = 0
+    desc = wmb.make_tensor_desc(list(sizes), torch_dtype_to_wholememory_dtype(dtype), [sizes[1], 1], 0)
+    e = C.c_void_p()
+    wmb.check(wmb.lib().wholememory_create_embedding(
+        C.byref(e), C.byref(desc), comm.wmb_comm, str_to_wmb_wholememory_memory_type(memory_type),
+        str_to_wmb_wholememory_location(memory_location),
+        cache_policy.wmb_cache_policy if cache_policy is not None else None,
+        wmb.size_t_array(embedding_entry_partition), gather_sms, round_robin_size))
+    wm_embedding = WholeMemoryEmbedding(e, cache_policy)
+    if random_init is True:
+        local_tensor, _ = wm_embedding.get_embedding_tensor().get_local_tensor()
+        if local_tensor.numel() > 0:
+            torch.nn.init.xavier_uniform_(local_tensor)
+    comm.barrier()
+    return wm_embedding
+
+
+def create_embedding_from_filelist(comm, memory_type, memory_location, filelist, dtype, last_dim_size, *,
+                                   cache_policy=None, embedding_entry_partition=None, gather_sms=-1,
+                                   round_robin_size=0):
+    if isinstance(filelist, str):
+        filelist = [filelist]
+    assert last_dim_size > 0
+    if embedding_entry_partition is not None and round_robin_size != 0:
+        print("round_robin_size is ignored because embedding_entry_partition is specified")
+        round_robin_size = 0
+    element_size = torch.tensor([], dtype=dtype).element_size()
+    file_entry_size = element_size * last_dim_size
+    total_file_size = 0
+    for filename in filelist:
+        file_size = get_file_size(filename)
+        if file_size % file_entry_size != 0:
+            raise ValueError("File %s size is %d not mutlple of %d" % (filename, file_size, file_entry_size))
+        total_file_size += file_size
+    total_entry_count = total_file_size // file_entry_size
+    wm_embedding = create_embedding(comm, memory_type, memory_location, dtype, [total_entry_count, last_dim_size],
+                                    cache_policy=cache_policy, embedding_entry_partition=embedding_entry_partition,
+                                    gather_sms=gather_sms, round_robin_size=round_robin_size)
+    wm_embedding.get_embedding_tensor().from_filelist(filelist, round_robin_size)
+    return wm_embedding
+
+
+def destroy_embedding(wm_embedding: WholeMemoryEmbedding):
+    wmb.check(wmb.lib().wholememory_destroy_embedding(wm_embedding.wmb_embedding))
+    wm_embedding.wmb_embedding = None
+    wm_embedding.embedding_tensor = None
+    wm_embedding.optimizer_states = dict()
+
+
+class WholeMemoryEmbeddingModule(torch.nn.Module):
+    """torch.nn.Module wrapper of WholeMemoryEmbedding."""
+
+    def __init__(self, wm_embedding: WholeMemoryEmbedding):
+        super().__init__()
+        self.wm_embedding = wm_embedding
+        self.embedding_gather_fn = EmbeddingLookupFn.apply
+
+    def forward(self, indice: torch.Tensor, force_dtype: Union[torch.dtype, None] = None):
+        return self.embedding_gather_fn(indice, self.wm_embedding.dummy_input, self.wm_embedding, self.training,
+                                        force_dtype)
+
+
+def create_wholememory_optimizer(embeddings, optimizer_type: str, param_dict: dict):
+    wm_optimizer = WholeMemoryOptimizer(get_global_communicator())
+    wmb.check(wmb.lib().wholememory_create_embedding_optimizer(
+        C.byref(wm_optimizer.wmb_opt), str_to_wmb_wholememory_optimizer_type(optimizer_type)))
+    for k, v in (param_dict or {}).items():
+        val = C.c_float(float(v))
+        wmb.check(wmb.lib().wholememory_optimizer_set_parameter(wm_optimizer.wmb_opt, k.encode(), C.byref(val)))
+    if isinstance(embeddings, WholeMemoryEmbedding):
+        wm_optimizer.add_embedding(embeddings)
+    else:
+        for em in embeddings:
+            wm_optimizer.add_embedding(em)
+    return wm_optimizer
+
+
+def destroy_wholememory_optimizer(optimizer: WholeMemoryOptimizer):
+    wmb.lib().wholememory_destroy_embedding_optimizer(optimizer.wmb_opt)
+    optimizer.wmb_opt = None

@@ -1,0 +1,157 @@
+"""Glue between torch-ROCm and the C ABI: the env-function table (scratch memory comes from torch's
+caching allocator), the current HIP stream, and torch.Tensor -> wholememory_tensor_t wrapping.
+
+Reference counterpart: ``python/pylibwholegraph/pylibwholegraph/torch/wholegraph_env.py:27-182`` (Python
+callback env fns; the optional C++ torch extension of the reference is not needed here).
+"""
+import ctypes as C
+import threading
+
+import torch
+
+from .. import binding as wmb
+from .utils import torch_dtype_to_wholememory_dtype, wholememory_dtype_to_torch_dtype
+
+
+def get_stream(use_default=True):
+    """Current torch HIP stream as an integer (0 = the null stream)."""
+    if not torch.cuda.is_available():
+        return 0
+    s = torch.cuda.current_stream().cuda_stream
+    return int(s) if s is not None else 0
+
+
+class _EnvTable(object):
+    """Owns the ctypes callbacks + every live scratch tensor (keyed by a small integer context)."""
+
+    def __init__(self):
+        self._slots = {}
+        self._next = 1
+        self._lock = threading.Lock()
+        self._create = wmb.CREATE_CTX_FN(self._create_ctx)
+        self._destroy = wmb.DESTROY_CTX_FN(self._destroy_ctx)
+        self._malloc = wmb.MALLOC_FN(self._malloc_fn)
+        self._free = wmb.FREE_FN(self._free_fn)
+        self.env = wmb.EnvFunc()
+        self.env.temporary_fns.create_memory_context_fn = self._create
+        self.env.temporary_fns.destroy_memory_context_fn = self._destroy
+        self.env.temporary_fns.malloc_fn = self._malloc
+        self.env.temporary_fns.free_fn = self._free
+        self.env.temporary_fns.global_context = None
+        self.env.output_fns.malloc_fn = self._malloc
+        self.env.output_fns.free_fn = self._free
+        self.env.output_fns.global_context = None
+
+    def _create_ctx(self, p_ctx, _global):
+        with self._lock:
+            key = self._next
+            self._next += 1
+            self._slots[key] = None
+        p_ctx[0] = key
+
+    def _destroy_ctx(self, ctx, _global):
+        with self._lock:
+            self._slots.pop(int(ctx or 0), None)
+
+    def _malloc_fn(self, p_desc, alloc_type, ctx, _global):
+        d = p_desc.contents
+        shape = [int(d.sizes[i]) for i in range(d.dim)]
+        dtype = wholememory_dtype_to_torch_dtype(d.dtype)
+        if alloc_type == wmb.MA_DEVICE:
+            t = torch.empty(shape, dtype=dtype, device="cuda")
+        elif alloc_type == wmb.MA_PINNED:
+            t = torch.empty(shape, dtype=dtype, device="cpu", pin_memory=torch.cuda.is_available())
+        else:
+            t = torch.empty(shape, dtype=dtype, device="cpu")
+        with self._lock:
+            self._slots[int(ctx or 0)] = t
+        return t.data_ptr()
+
+    def _free_fn(self, ctx, _global):
+        with self._lock:
+            if int(ctx or 0) in self._slots:
+                self._slots[int(ctx or 0)] = None
+
+    def tensor_of(self, ctx):
+        return self._slots.get(int(ctx))
+
+
+_default_env = None
+
+
+def get_wholegraph_env_fns(use_default=True):
+    """ctypes pointer to a wholememory_env_func_t backed by torch allocations."""
+    global _default_env
+    if _default_env is None or not use_default:
+        table = _EnvTable()
+        if use_default:
+            _default_env = table
+    else:
+        table = _default_env
+    return C.pointer(table.env)
+
+
+class WrappedLocalTensor(object):
+    """A torch tensor wrapped as a (non-owning) wholememory_tensor_t for the duration of one call."""
+
+    def __init__(self, t):
+        self.torch_tensor = t  # keep the storage alive
+        self.handle = C.c_void_p()
+        if t is None:
+            desc = wmb.make_tensor_desc([], wmb.DT_UNKNOWN)
+            wmb.check(wmb.lib().wholememory_make_tensor_from_pointer(C.byref(self.handle), None, C.byref(desc)))
+            return
+        # shape/stride/dtype + data_ptr(), storage_offset 0 (reference wholegraph_env.py:173-182)
+        desc = wmb.make_tensor_desc(list(t.shape), torch_dtype_to_wholememory_dtype(t.dtype), list(t.stride()), 0)
+        wmb.check(wmb.lib().wholememory_make_tensor_from_pointer(C.byref(self.handle), C.c_void_p(t.data_ptr()),
+                                                                 C.byref(desc)))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                wmb.lib().wholememory_destroy_tensor(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+
+def wrap_torch_tensor(t):
+    return WrappedLocalTensor(t)
+
+
+class _PointerView(object):
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can alias it."""
+
+    def __init__(self, ptr, shape, torch_dtype, strides_elems, owner):
+        import numpy as np
+        np_dtype = {torch.float: "<f4", torch.half: "<f2", torch.double: "<f8", torch.int: "<i4", torch.int64: "<i8",
+                    torch.int16: "<i2", torch.int8: "|i1", torch.bfloat16: "<i2"}[torch_dtype]
+        itemsize = np.dtype(np_dtype).itemsize
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": np_dtype, "data": (int(ptr), False), "version": 3,
+            "strides": tuple(int(s) * itemsize for s in strides_elems),
+        }
+        self._owner = owner
+
+
+def torch_tensor_from_pointer(ptr, shape, torch_dtype, strides_elems, device_memory, owner=None):
+    """Alias `ptr` as a torch tensor (no copy). Device memory -> cuda tensor; host memory -> cpu tensor."""
+    numel = 1
+    for s in shape:
+        numel *= int(s)
+    if numel == 0:
+        return torch.empty(list(shape), dtype=torch_dtype, device="cuda" if device_memory else "cpu")
+    if device_memory:
+        view = _PointerView(ptr, shape, torch_dtype, strides_elems, owner)
+        t = torch.as_tensor(view, device="cuda")
+        if torch_dtype == torch.bfloat16:
+            t = t.view(torch.bfloat16)
+        t._wm_owner = owner
+        return t
+    span = 1 + sum((int(s) - 1) * int(st) for s, st in zip(shape, strides_elems))
+    itemsize = torch.tensor([], dtype=torch_dtype).element_size()
+    buf = (C.c_char * (span * itemsize)).from_address(int(ptr))
+    flat = torch.frombuffer(buf, dtype=torch_dtype, count=span)
+    t = torch.as_strided(flat, list(shape), list(strides_elems))
+    t._wm_owner = owner
+    return t
