@@ -146,13 +146,21 @@ class WholeMemoryEmbedding(object):
     def need_grad(self):
         return self.wmb_embedding is not None
 
-    def gather(self, indice: torch.Tensor, *, is_training: bool = False, force_dtype: Union[torch.dtype, None] = None):
+    def gather(self, indice: torch.Tensor, *, is_training: bool = False, force_dtype: Union[torch.dtype, None] = None,
+               out: Union[torch.Tensor, None] = None):
+        """reference embedding.py:280-311. `out` (extension, not in the reference): gather into a caller-owned
+        [n, dim] cuda tensor instead of allocating one (what the reference's C++ bench does)."""
         assert indice.dim() == 1
         emb = self.get_embedding_tensor()
         output_dtype = force_dtype if force_dtype is not None else emb.dtype
         need_grad = self.need_grad() and is_training
-        output_tensor = torch.empty([indice.shape[0], emb.shape[1]], device="cuda:%d" % torch.cuda.current_device(),
-                                    dtype=output_dtype, requires_grad=need_grad)
+        if out is not None:
+            assert out.dim() == 2 and out.shape[0] >= indice.shape[0] and out.shape[1] == emb.shape[1]
+            output_tensor = out
+        else:
+            output_tensor = torch.empty([indice.shape[0], emb.shape[1]],
+                                        device="cuda:%d" % torch.cuda.current_device(), dtype=output_dtype,
+                                        requires_grad=need_grad)
         if need_grad:
             self.need_apply = True
         wi, wo = wrap_torch_tensor(indice), wrap_torch_tensor(output_tensor)

@@ -102,7 +102,9 @@ class WrappedLocalTensor(object):
             wmb.check(wmb.lib().wholememory_make_tensor_from_pointer(C.byref(self.handle), None, C.byref(desc)))
             return
         # shape/stride/dtype + data_ptr(), storage_offset 0 (reference wholegraph_env.py:173-182)
-        desc = wmb.make_tensor_desc(list(t.shape), torch_dtype_to_wholememory_dtype(t.dtype), list(t.stride()), 0)
+        # (an empty torch tensor may report stride 0: describe it as dense instead)
+        strides = list(t.stride()) if t.numel() > 0 else None
+        desc = wmb.make_tensor_desc(list(t.shape), torch_dtype_to_wholememory_dtype(t.dtype), strides, 0)
         wmb.check(wmb.lib().wholememory_make_tensor_from_pointer(C.byref(self.handle), C.c_void_p(t.data_ptr()),
                                                                  C.byref(desc)))
 
