@@ -206,7 +206,9 @@ int main(int argc, char** argv)
     a.table_dtype = WHOLEMEMORY_DT_FLOAT; a.dim = 128; a.table_stride = 128; a.indices = i; a.index_dtype = WHOLEMEMORY_DT_INT64;
     a.n = n; a.plain = o; a.plain_dtype = WHOLEMEMORY_DT_FLOAT; a.plain_stride = 128; a.max_blocks = blocks;
     if (wm::hip_gather_rows(&a, s) != 0) { printf("product launch failed\n"); exit(1); } }});
-  int grids[] = {2048, 4096, 8192, 16384};
+  const bool pmc_mode = argc > 4 && std::string(argv[4]) == "pmc";
+  std::vector<int> grids = {2048, 4096, 8192, 16384};
+  if (pmc_mode) { vs.erase(vs.begin()); grids = {8192}; iters = 3; }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("rows=%lld n=%lld iters=%d  (algorithmic bytes per launch = %.3f GB)\n", (long long)rows, (long long)n, iters, n * 1032.0 / 1e9);
   for (auto& v : vs) {
@@ -224,7 +226,7 @@ int main(int argc, char** argv)
   // streaming copy of n*512 bytes
   {
     int64_t n16 = n * 32;
-    for (int g : {2048, 8192}) {
+    for (int g : {8192}) {
       CK(hipEventRecord(e0, 0));
       for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, 0, (const u32x4*)tab, (u32x4*)out, n16);
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));

@@ -1,0 +1,246 @@
+// oracle/test_backend.cpp — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// A host-memory implementation of the device seam (wholegraph_amd/csrc/backend.hpp) built from the CPU
+// oracle (wm_oracle.c). It exists for exactly one purpose: letting tests/ drive the product's multi-rank
+// HOST ORCHESTRATION (ops.cpp / embedding.cpp: partition plan, count exchange, all-to-all-v layout,
+// reorder, dedup hand-off) at world_size 2 over torch.distributed/gloo on a CPU-only box. It is installed
+// through wm_testing_install_backend(), which refuses to act unless WHOLEGRAPH_AMD_TESTING=1.
+// Nothing under wholegraph_amd/ links, loads or references this file; kernels are validated separately on a
+// real MI355X against the same oracle (tests -m gpu).
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../wholegraph_amd/csrc/backend.hpp"
+#include <wholememory/embedding.h>
+
+extern "C" {
+size_t wmo_dtype_size(int dtype);
+int wmo_gather(const void* const* shard_ptrs, const uint64_t* entry_offsets, int world_size, int table_dtype,
+               int64_t dim, int64_t stride, int64_t storage_offset, const void* indices, int idx_dtype, int64_t n,
+               const void* raw_indices, void* out, int out_dtype, int64_t out_stride, int64_t out_storage_offset);
+int wmo_scatter(const void* in, int in_dtype, int64_t in_stride, int64_t in_storage_offset, const void* indices,
+                int idx_dtype, int64_t n, void* const* shard_ptrs, const uint64_t* entry_offsets, int world_size,
+                int table_dtype, int64_t dim, int64_t stride, int64_t storage_offset);
+void wmo_bucket_counts(const void* indices, int idx_dtype, int64_t n, const uint64_t* entry_offsets, int world_size,
+                       int64_t* counts);
+void wmo_round_robin_map(const void* indices, int idx_dtype, int64_t n, int64_t entry_start, int world_size,
+                         int round_robin_size, void* mapped);
+void wmo_sgd_step(const void* ids, int idx_dtype, int64_t count, const float* grads, int64_t grad_stride,
+                  float* local_table, int64_t table_stride, int64_t local_entry_offset, int64_t dim, float weight_decay,
+                  float lr);
+void wmo_lazy_adam_step(const void* ids, int idx_dtype, int64_t count, const float* grads, int64_t grad_stride,
+                        float* local_table, float* per_element, float* per_row, int64_t table_stride,
+                        int64_t local_entry_offset, int64_t dim, float weight_decay, float epsilon, float beta1,
+                        float beta2, int adam_w, float lr);
+void wmo_adagrad_step(const void* ids, int idx_dtype, int64_t count, const float* grads, int64_t grad_stride,
+                      float* local_table, float* state_sum_tbl, int64_t table_stride, int64_t local_entry_offset,
+                      int64_t dim, float weight_decay, float epsilon, float lr);
+void wmo_rmsprop_step(const void* ids, int idx_dtype, int64_t count, const float* grads, int64_t grad_stride,
+                      float* local_table, float* v_tbl, int64_t table_stride, int64_t local_entry_offset, int64_t dim,
+                      float weight_decay, float epsilon, float alpha, float lr);
+}
+
+namespace {
+
+int64_t idx_at(const void* p, wholememory_dtype_t dt, int64_t i)
+{
+  return dt == WHOLEMEMORY_DT_INT ? static_cast<const int32_t*>(p)[i] : static_cast<const int64_t*>(p)[i];
+}
+
+int t_device_count() { return 1; }
+int t_malloc(void** p, size_t bytes)
+{
+  *p = malloc(bytes ? bytes : 16);
+  return *p ? 0 : 1;
+}
+int t_free(void* p)
+{
+  free(p);
+  return 0;
+}
+int t_memcpy(void* d, const void* s, size_t n, void*)
+{
+  memmove(d, s, n);
+  return 0;
+}
+int t_memset(void* d, int v, size_t n, void*)
+{
+  memset(d, v, n);
+  return 0;
+}
+int t_sync(void*) { return 0; }
+int t_ipc_get(void*, void*) { return 1; }  // no cross-process mapping of malloc'ed "device" memory
+int t_ipc_open(void**, const void*) { return 1; }
+int t_ipc_close(void*) { return 1; }
+int t_host_register(void* h, size_t, void** d)
+{
+  *d = h;
+  return 0;
+}
+int t_host_unregister(void*) { return 0; }
+
+// flat view of a gref for the oracle: continuous -> one shard at row 0; chunked -> per-rank shards
+struct shard_view {
+  std::vector<const void*> ptrs;
+  std::vector<uint64_t> offs;
+  int world;
+};
+bool make_view(const wm_rows_args* a, shard_view* v)
+{
+  const size_t es = wmo_dtype_size(a->table_dtype);
+  if (a->gref.stride == 0) {
+    v->world = 1;
+    v->ptrs  = {a->gref.pointer};
+    v->offs  = {0, UINT64_MAX};
+    return true;
+  }
+  const size_t row = static_cast<size_t>(a->table_stride) * es;
+  v->world         = a->gref.world_size;
+  v->ptrs.assign(static_cast<void**>(a->gref.pointer), static_cast<void**>(a->gref.pointer) + v->world);
+  v->offs.resize(v->world + 1);
+  for (int r = 0; r <= v->world; r++) {
+    if (a->gref.rank_memory_offsets[r] % row != 0) return false;
+    v->offs[r] = a->gref.rank_memory_offsets[r] / row;
+  }
+  return true;
+}
+
+int t_gather(const wm_rows_args* a, void*)
+{
+  if (a->n == 0 || a->dim == 0) return 0;
+  shard_view v;
+  if (!make_view(a, &v)) return -1;
+  int rc = wmo_gather(v.ptrs.data(), v.offs.data(), v.world, a->table_dtype, a->dim, a->table_stride,
+                      a->table_storage_offset, a->indices, a->index_dtype, a->n, a->row_map, a->plain, a->plain_dtype,
+                      a->plain_stride, a->plain_storage_offset);
+  return rc == 0 ? 0 : -1;
+}
+int t_scatter(const wm_rows_args* a, void*)
+{
+  if (a->n == 0 || a->dim == 0) return 0;
+  if (a->row_map != nullptr) return -1;
+  shard_view v;
+  if (!make_view(a, &v)) return -1;
+  int rc = wmo_scatter(a->plain, a->plain_dtype, a->plain_stride, a->plain_storage_offset, a->indices, a->index_dtype,
+                       a->n, const_cast<void* const*>(v.ptrs.data()), v.offs.data(), v.world, a->table_dtype, a->dim,
+                       a->table_stride, a->table_storage_offset);
+  return rc == 0 ? 0 : -1;
+}
+
+size_t t_bucket_ws(int64_t, int) { return 64; }
+int t_bucket(const wm_bucket_args* a, void*)
+{
+  wmo_bucket_counts(a->indices, a->index_dtype, a->n, a->entry_offsets, a->world_size, a->counts);
+  if (a->bucketed_ids == nullptr) return 0;
+  // stable partition by owner, negatives last (kernels/bucket.hip contract)
+  int64_t pos = 0;
+  for (int r = 0; r <= a->world_size; r++) {
+    for (int64_t i = 0; i < a->n; i++) {
+      int64_t id = idx_at(a->indices, a->index_dtype, i);
+      int owner  = a->world_size;
+      if (id >= 0) {
+        owner = 0;
+        for (int k = 1; k < a->world_size; k++)
+          if (static_cast<uint64_t>(id) >= a->entry_offsets[k]) owner = k;
+      }
+      if (owner != r) continue;
+      if (a->index_dtype == WHOLEMEMORY_DT_INT)
+        static_cast<int32_t*>(a->bucketed_ids)[pos] = static_cast<int32_t>(id);
+      else
+        static_cast<int64_t*>(a->bucketed_ids)[pos] = id;
+      a->raw_indices[pos] = i;
+      pos++;
+    }
+  }
+  return 0;
+}
+
+size_t t_dedup_ws(int64_t, wholememory_dtype_t) { return 64; }
+int t_dedup(const void* ids, wholememory_dtype_t dt, int64_t n, int64_t, void* unique_ids, int32_t* run_starts,
+            int32_t* order, int64_t* n_unique_out, void*, void*)
+{
+  std::vector<int32_t> ord(n);
+  for (int64_t i = 0; i < n; i++) ord[i] = static_cast<int32_t>(i);
+  std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return idx_at(ids, dt, x) < idx_at(ids, dt, y); });
+  int64_t nu = 0;
+  for (int64_t i = 0; i < n; i++) {
+    order[i] = ord[i];
+    if (i == 0 || idx_at(ids, dt, ord[i]) != idx_at(ids, dt, ord[i - 1])) {
+      if (dt == WHOLEMEMORY_DT_INT)
+        static_cast<int32_t*>(unique_ids)[nu] = static_cast<int32_t>(idx_at(ids, dt, ord[i]));
+      else
+        static_cast<int64_t*>(unique_ids)[nu] = idx_at(ids, dt, ord[i]);
+      run_starts[nu] = static_cast<int32_t>(i);
+      nu++;
+    }
+  }
+  run_starts[nu] = static_cast<int32_t>(n);
+  *n_unique_out  = nu;
+  return 0;
+}
+
+int t_step(const wm_optimizer_args* a, const int64_t* n_unique_dev, void*)
+{
+  const int64_t count = n_unique_dev ? *n_unique_dev : a->count;
+  std::vector<float> g(a->dim);
+  for (int64_t u = 0; u < count; u++) {
+    for (int64_t d = 0; d < a->dim; d++) {
+      float acc = a->grads[static_cast<int64_t>(a->order[a->run_starts[u]]) * a->grad_stride + d];
+      for (int32_t j = a->run_starts[u] + 1; j < a->run_starts[u + 1]; j++)
+        acc += a->grads[static_cast<int64_t>(a->order[j]) * a->grad_stride + d];
+      g[d] = acc;
+    }
+    int64_t id64     = idx_at(a->ids, a->index_dtype, u);
+    const void* idp  = &id64;
+    const int idx_dt = WHOLEMEMORY_DT_INT64;
+    switch (a->type) {
+      case WHOLEMEMORY_OPT_SGD:
+        wmo_sgd_step(idp, idx_dt, 1, g.data(), a->dim, a->local_table, a->table_stride, a->local_entry_offset, a->dim,
+                     a->weight_decay, a->lr);
+        break;
+      case WHOLEMEMORY_OPT_LAZY_ADAM:
+        if (a->per_element_stride != 2 * a->table_stride) return -1;
+        wmo_lazy_adam_step(idp, idx_dt, 1, g.data(), a->dim, a->local_table, a->per_element_state, a->per_row_state,
+                           a->table_stride, a->local_entry_offset, a->dim, a->weight_decay, a->epsilon, a->beta1,
+                           a->beta2, a->adam_w, a->lr);
+        break;
+      case WHOLEMEMORY_OPT_ADAGRAD:
+        if (a->per_element_stride != a->table_stride) return -1;
+        wmo_adagrad_step(idp, idx_dt, 1, g.data(), a->dim, a->local_table, a->per_element_state, a->table_stride,
+                         a->local_entry_offset, a->dim, a->weight_decay, a->epsilon, a->lr);
+        break;
+      case WHOLEMEMORY_OPT_RMSPROP:
+        if (a->per_element_stride != a->table_stride) return -1;
+        wmo_rmsprop_step(idp, idx_dt, 1, g.data(), a->dim, a->local_table, a->per_element_state, a->table_stride,
+                         a->local_entry_offset, a->dim, a->weight_decay, a->epsilon, a->alpha, a->lr);
+        break;
+      default: return -1;
+    }
+  }
+  return 0;
+}
+
+int t_rr(const void* ids, void* mapped, wholememory_dtype_t dt, int64_t n, int64_t entry_start, int world, int rr, void*)
+{
+  wmo_round_robin_map(ids, dt, n, entry_start, world, rr, mapped);
+  return 0;
+}
+int t_fill(float* p, float v, int64_t n, void*)
+{
+  for (int64_t i = 0; i < n; i++) p[i] = v;
+  return 0;
+}
+
+const wm_device_backend kTestBackend = {
+  "oracle-test-backend (CPU, tests only)",
+  t_device_count, t_malloc, t_free, t_malloc, t_free, t_memcpy, t_memset, t_sync,
+  t_ipc_get, t_ipc_open, t_ipc_close, t_host_register, t_host_unregister,
+  t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_rr, t_fill,
+};
+
+}  // namespace
+
+extern "C" const void* wm_test_backend() { return &kTestBackend; }

@@ -1,0 +1,173 @@
+"""Worker for tests/test_distributed_cpu.py: one rank of a world_size-N gloo job driving the PRODUCT's
+multi-rank orchestration (libwholegraph.so ops.cpp / embedding.cpp, Python wholegraph_amd.torch) with the
+device seam replaced by the CPU test backend (oracle/test_backend.cpp) and collectives provided by
+torch.distributed/gloo. Every rank recomputes the all-rank expectation with the oracle and checks its own part."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["WHOLEGRAPH_AMD_TESTING"] = "1"
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import oracle
+from wholegraph_amd import binding as wmb
+import wholegraph_amd.torch as wgth
+
+
+def install_test_backend():
+    tb = C.CDLL(os.path.join(ROOT, "oracle", "libwm_test_backend.so"))
+    tb.wm_test_backend.restype = C.c_void_p
+    wmb.check(wmb.lib().wm_testing_install_backend(C.c_void_p(tb.wm_test_backend())))
+    assert wmb.lib().wholememory_ext_backend_name().startswith(b"oracle-test-backend")
+    return tb
+
+
+def shard_views(emb_tensor, rank):
+    local, start = emb_tensor.get_local_tensor(host_view=False)
+    return local, start
+
+
+def gather_all_local(emb_tensor):
+    """this rank's rows as numpy (through the local view)"""
+    local, start = emb_tensor.get_local_tensor()
+    return local.numpy().copy(), start
+
+
+def scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, entries):
+    tt = {np.float32: torch.float32, np.float16: torch.float16, np.int32: torch.int32, np.int64: torch.int64}
+    stride = dim + (3 if dim % 4 else 0)
+    wm = wgth.create_wholememory_tensor(comm, mt, "cuda", [n_rows, stride], tt[tdt], [stride, 1], entries)
+    view = wm.get_sub_tensor([0, 0], [n_rows, dim]) if stride != dim else wm
+    full = oracle.fill_closed_form(tdt, 0, n_rows, dim, stride)
+    tab = oracle.ShardedTable.from_full(full, world, entries)
+    tab.dim = dim
+    local, start = wm.get_local_tensor()
+    assert start == int(tab.entry_offsets[rank])
+    cnt = int(tab.entry_offsets[rank + 1] - tab.entry_offsets[rank])
+    assert local.shape[0] == cnt
+    if cnt:
+        local.copy_(torch.from_numpy(full[start:start + cnt]))
+    comm.barrier()
+    rngs = [np.random.default_rng(100 + r) for r in range(world)]
+    rank_idx = []
+    for r in range(world):
+        n = 0 if (r == 1 and n_rows % 2 == 0) else 500 + 37 * r   # one rank may have nothing to ask
+        ix = rngs[r].integers(0, n_rows, n).astype(idt)
+        if n:
+            ix[::29] = -1
+            ix[:8] = ix[0]
+        rank_idx.append(ix)
+    exp = oracle.distributed_gather(tab, rank_idx, odt, out_init=[np.full((len(ix), dim), 5, dtype=odt) for ix in rank_idx])
+    out = torch.full((len(rank_idx[rank]), dim), 5, dtype=tt[odt])
+    from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream
+    wi, wo = wrap_torch_tensor(torch.from_numpy(rank_idx[rank])), wrap_torch_tensor(out)
+    wmb.check(wmb.lib().wholememory_gather(view.wmb_tensor, wi.handle, wo.handle, get_wholegraph_env_fns(),
+                                           C.c_void_p(get_stream()), -1))
+    assert out.numpy().tobytes() == exp[rank].tobytes(), "distributed gather mismatch on rank %d" % rank
+    # scatter: every rank writes rows of its own ids (closed-form rows: duplicates agree), then everyone checks
+    comm.barrier()
+    if cnt:
+        local.zero_()
+    comm.barrier()
+    ref = oracle.ShardedTable.from_full(np.zeros((n_rows, stride), dtype=tdt), world, entries)
+    ref.dim = dim
+    src = oracle.fill_closed_form(odt, 0, n_rows, dim)
+    for r in range(world):
+        rows = np.zeros((len(rank_idx[r]), dim), dtype=odt)
+        v = rank_idx[r] >= 0
+        rows[v] = src[rank_idx[r][v].astype(np.int64)]
+        oracle.scatter(rows, rank_idx[r], ref)
+        if r == rank:
+            wr, wx = wrap_torch_tensor(torch.from_numpy(rows)), wrap_torch_tensor(torch.from_numpy(rank_idx[r]))
+            wmb.check(wmb.lib().wholememory_scatter(wr.handle, wx.handle, view.wmb_tensor, get_wholegraph_env_fns(),
+                                                    C.c_void_p(get_stream()), -1))
+    comm.barrier()
+    if cnt:
+        assert local.numpy().tobytes() == ref.shards[rank][:cnt].tobytes(), "distributed scatter mismatch on rank %d" % rank
+    comm.barrier()
+    if view is not wm:
+        wgth.destroy_wholememory_tensor(view)
+    wgth.destroy_wholememory_tensor(wm)
+
+
+def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries):
+    n_rows, dim, steps = 1201, 13, 3
+    emb = wgth.create_embedding(comm, "distributed", "cuda", torch.float32, [n_rows, dim],
+                                embedding_entry_partition=entries)
+    stride = emb.get_embedding_tensor().stride()[0]
+    assert stride == 16
+    init = np.random.default_rng(5).standard_normal((n_rows, dim)).astype(np.float32)
+    padded = np.zeros((n_rows, stride), dtype=np.float32)
+    padded[:, :dim] = init
+    tab = oracle.ShardedTable.from_full(padded, world, entries)
+    tab.dim = dim
+    local, start = emb.get_embedding_tensor().get_local_tensor()
+    cnt = int(tab.entry_offsets[rank + 1] - tab.entry_offsets[rank])
+    assert tuple(local.shape) == (cnt, dim) and local.stride(0) == stride
+    local.copy_(torch.from_numpy(init[start:start + cnt]))
+    opt = wgth.create_wholememory_optimizer(emb, kind, params)
+    assert emb.get_optimizer_state_names() == {"sgd": [], "adam": ["m", "v", "beta12t"], "adagrad": ["state_sum"],
+                                               "rmsprop": ["v"]}[kind]
+    ref_opts = [oracle.Optimizer(kind, int(tab.entry_offsets[r + 1] - tab.entry_offsets[r]), stride, **params)
+                for r in range(world)]
+    for step in range(steps):
+        rank_idx, rank_grads = [], []
+        for r in range(world):
+            g = np.random.default_rng(1000 * step + r)
+            ix = g.integers(0, n_rows, 400 + 11 * r).astype(idt)
+            ix[::7] = ix[0]  # heavy duplicates
+            rank_idx.append(ix)
+            rank_grads.append(g.standard_normal((len(ix), dim)).astype(np.float32))
+        emb.add_gradients(torch.from_numpy(rank_idx[rank]), torch.from_numpy(rank_grads[rank]))
+        emb.need_apply = True
+        opt.step(0.05)
+        oracle.gradient_apply(tab, ref_opts, rank_idx, rank_grads, 0.05)
+        got = local.numpy()
+        assert got.tobytes() == tab.shards[rank][:cnt, :dim].tobytes(), \
+            "gradient apply (%s) mismatch on rank %d step %d" % (kind, rank, step)
+    if kind == "adam":
+        m, _ = emb.get_optimizer_state("m").get_local_tensor()
+        assert m.numpy().tobytes() == ref_opts[rank].per_element[:cnt, :dim].tobytes()
+        b, _ = emb.get_optimizer_state("beta12t").get_local_tensor()
+        assert b.numpy().tobytes() == ref_opts[rank].per_row[:cnt].tobytes()
+    comm.barrier()
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+    install_test_backend()
+    wgth.init(rank, world, rank, world, "warn")
+    comm = wgth.get_global_communicator()
+    assert comm.get_rank() == rank and comm.get_size() == world
+    # (1) gather / scatter, equal plan, padded rows, fp32, int64 ids
+    scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)
+    # (2) dtype cast at the owner + int32 ids + an asking-nothing rank
+    scenario_gather_scatter(comm, rank, world, "distributed", 2000, 32, np.float16, np.float32, np.int32, None)
+    # (3) custom partition (python random_partition shape) + ints
+    ent = [int(x) for x in (np.array([0.2, 0.5, 0.3, 0.1, 0.4][:world]) / sum([0.2, 0.5, 0.3, 0.1, 0.4][:world]) * 997).astype(int)]
+    ent[0] += 997 - sum(ent)
+    scenario_gather_scatter(comm, rank, world, "distributed", 997, 8, np.int64, np.int32, np.int64, ent)
+    # (4) trailing ranks empty under the equal plan: N < W * ceil(N / W) only when W > N … use tiny N
+    if world >= 3:
+        scenario_gather_scatter(comm, rank, world, "distributed", 4, 4, np.float32, np.float32, np.int64, None)
+    # (5) gradient apply, all optimizers
+    for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}),
+                         ("adam", {"adam_w": 1.0, "weight_decay": 0.02}), ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]:
+        scenario_gradient_apply(comm, rank, world, kind, params, np.int64 if kind != "adagrad" else np.int32, None)
+    comm.barrier()
+    dist.barrier()
+    print("RANK %d OK" % rank)
+    wgth.finalize()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,7 +22,7 @@ from .utils import (
     str_to_wmb_wholememory_optimizer_type,
     get_file_size,
 )
-from .wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream
+from .wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream, op_device
 
 
 class WholeMemoryOptimizer(object):
@@ -159,7 +159,7 @@ class WholeMemoryEmbedding(object):
             output_tensor = out
         else:
             output_tensor = torch.empty([indice.shape[0], emb.shape[1]],
-                                        device="cuda:%d" % torch.cuda.current_device(), dtype=output_dtype,
+                                        device=op_device(), dtype=output_dtype,
                                         requires_grad=need_grad)
         if need_grad:
             self.need_apply = True

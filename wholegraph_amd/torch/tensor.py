@@ -20,7 +20,8 @@ from .utils import (
     get_part_file_list,
 )
 from .comm import WholeMemoryCommunicator
-from .wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream, torch_tensor_from_pointer
+from .wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream, torch_tensor_from_pointer, \
+    op_device
 
 
 class WholeMemoryTensor(object):
@@ -64,7 +65,7 @@ class WholeMemoryTensor(object):
         assert indice.dim() == 1
         out_dtype = force_dtype if force_dtype is not None else self.dtype
         shape = [indice.shape[0]] + ([self.shape[1]] if self.dim() == 2 else [])
-        output = torch.empty(shape, device="cuda:%d" % torch.cuda.current_device(), dtype=out_dtype, requires_grad=False)
+        output = torch.empty(shape, device=op_device(), dtype=out_dtype, requires_grad=False)
         wi, wo = wrap_torch_tensor(indice), wrap_torch_tensor(output)
         wmb.check(wmb.lib().wholememory_gather(self.wmb_tensor, wi.handle, wo.handle, get_wholegraph_env_fns(),
                                                C.c_void_p(get_stream()), -1))

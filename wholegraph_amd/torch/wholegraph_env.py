@@ -13,6 +13,17 @@ from .. import binding as wmb
 from .utils import torch_dtype_to_wholememory_dtype, wholememory_dtype_to_torch_dtype
 
 
+def device_memory_is_host():
+    """True only under the CPU test backend (oracle/test_backend.cpp, WHOLEGRAPH_AMD_TESTING=1): what the
+    library calls device memory is then plain host memory. Always False in the product."""
+    return wmb.lib().wholememory_ext_backend_name() != b"hip-gfx950"
+
+
+def op_device():
+    """torch device op inputs/outputs live on."""
+    return "cpu" if device_memory_is_host() else "cuda:%d" % torch.cuda.current_device()
+
+
 def get_stream(use_default=True):
     """Current torch HIP stream as an integer (0 = the null stream)."""
     if not torch.cuda.is_available():
@@ -58,7 +69,7 @@ class _EnvTable(object):
         shape = [int(d.sizes[i]) for i in range(d.dim)]
         dtype = wholememory_dtype_to_torch_dtype(d.dtype)
         if alloc_type == wmb.MA_DEVICE:
-            t = torch.empty(shape, dtype=dtype, device="cuda")
+            t = torch.empty(shape, dtype=dtype, device=op_device())
         elif alloc_type == wmb.MA_PINNED:
             t = torch.empty(shape, dtype=dtype, device="cpu", pin_memory=torch.cuda.is_available())
         else:
@@ -138,6 +149,8 @@ class _PointerView(object):
 
 def torch_tensor_from_pointer(ptr, shape, torch_dtype, strides_elems, device_memory, owner=None):
     """Alias `ptr` as a torch tensor (no copy). Device memory -> cuda tensor; host memory -> cpu tensor."""
+    if device_memory and device_memory_is_host():
+        device_memory = False
     numel = 1
     for s in shape:
         numel *= int(s)

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from .. import binding as wmb
-from .wholegraph_env import get_stream, get_wholegraph_env_fns, wrap_torch_tensor
+from .wholegraph_env import get_stream, get_wholegraph_env_fns, wrap_torch_tensor, op_device
 
 
 def _raw(wholememory_tensor):
@@ -19,7 +19,7 @@ def wholememory_gather_forward_functor(wholememory_tensor, indices_tensor, requi
     wt = wholememory_tensor if isinstance(wholememory_tensor, WholeMemoryTensor) else WholeMemoryTensor(_raw(wholememory_tensor))
     if torch_output_dtype is None:
         torch_output_dtype = wt.dtype
-    output_tensor = torch.empty([indices_tensor.shape[0], wt.shape[1]], device="cuda", dtype=torch_output_dtype,
+    output_tensor = torch.empty([indices_tensor.shape[0], wt.shape[1]], device=op_device(), dtype=torch_output_dtype,
                                 requires_grad=requires_grad)
     wi, wo = wrap_torch_tensor(indices_tensor), wrap_torch_tensor(output_tensor)
     wmb.check(wmb.lib().wholememory_gather(wt.wmb_tensor, wi.handle, wo.handle, get_wholegraph_env_fns(),
