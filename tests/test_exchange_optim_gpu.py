@@ -1,0 +1,227 @@
+"""GPU parity of the distributed-path stages through the C ABI, against the CPU oracle:
+
+ * wholememory_ext_bucket_ids  — counts bit-exact vs bucket_ids_func.cu:51-87 restatement; grouped ids /
+   raw_indices: a stable owner-partition whose segments, stably sorted by id, reproduce the reference's
+   full stable sort (exchange_ids_nccl_func.cu:42-92) bit for bit;
+ * wholememory_ext_dedup_apply — sorted-order duplicate sum + SGD / LazyAdam(W) / AdaGrad / RMSProp step,
+   bit-exact vs oracle (wm_oracle.c: dedup + *_step), which itself is pinned to the reference tests'
+   CPUOptimizer within 1e-5 (tests/test_oracle_pinning.py);
+ * WholeMemoryEmbedding end to end on one GPU (DISTRIBUTED runs the full exchange path with world_size 1),
+   including the reference test shapes 400001 x {127,129} (wholememory_embedding_gradient_apply_tests.cu:30-39).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    from wholegraph_amd.torch.wholegraph_env import get_wholegraph_env_fns, get_stream
+    return get_wholegraph_env_fns(), C.c_void_p(get_stream())
+
+
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+@pytest.mark.parametrize("n,world,kind", [(0, 4, "equal"), (1, 1, "equal"), (63, 2, "equal"), (4097, 8, "equal"),
+                                          (100000, 8, "equal"), (250000, 3, "custom"), (99999, 8, "empty_ranks"),
+                                          (300000, 64, "equal"), (1000003, 8, "zipf")])
+def test_bucket_ids(gpu_env, idt, n, world, kind):
+    import torch
+    from wholegraph_amd import binding as wmb
+    rng = np.random.default_rng(n + world)
+    total = 1_000_003
+    if kind == "custom":
+        offs, _ = oracle.custom_partition([400000, 3, 600000])
+    elif kind == "empty_ranks":
+        offs = np.array([0, 10, 10, 10, 500000, 500000, 900000, total, total], dtype=np.uint64)
+    else:
+        _, offs = oracle.equal_partition(total, world)
+    if kind == "zipf":
+        idx = (rng.zipf(1.05, n).astype(np.uint64) * np.uint64(2654435761) % np.uint64(total)).astype(idt)
+    else:
+        idx = rng.integers(0, total, n).astype(idt)
+    if n > 10:
+        idx[rng.integers(0, n, n // 20)] = -1
+        idx[rng.integers(0, n, 5)] = -(2 ** 20)
+        idx[:100] = idx[50]
+    d_idx = torch.from_numpy(idx).cuda()
+    d_off = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_cnt = torch.full((world,), -1, dtype=torch.int64, device="cuda")
+    d_ids = torch.zeros(max(n, 1), dtype=d_idx.dtype, device="cuda")
+    d_raw = torch.zeros(max(n, 1), dtype=torch.int64, device="cuda")
+    env, stream = _env()
+    wmb.check(wmb.lib().wholememory_ext_bucket_ids(d_idx.data_ptr(), wmb.DT_INT if idt == np.int32 else wmb.DT_INT64, n,
+                                                   d_off.data_ptr(), world, d_cnt.data_ptr(), d_ids.data_ptr(),
+                                                   d_raw.data_ptr(), env, stream))
+    torch.cuda.synchronize()
+    counts = d_cnt.cpu().numpy()
+    assert np.array_equal(counts, oracle.bucket_counts(idx, offs)), "per-owner counts differ from the oracle"
+    ids, raw = d_ids.cpu().numpy()[:n], d_raw.cpu().numpy()[:n]
+    assert sorted(raw.tolist()) == list(range(n)), "raw_indices is not a permutation"
+    assert np.array_equal(ids, idx[raw]), "bucketed ids are not idx[raw_indices]"
+    # segments: owner-major, stable
+    seg = np.concatenate([[0], np.cumsum(counts), [n]])
+    for r in range(world + 1):
+        s, e = int(seg[r]), int(seg[r + 1])
+        assert np.all(np.diff(raw[s:e]) > 0), "segment %d is not in original order (not stable)" % r
+        if r < world and e > s:
+            assert ids[s:e].min() >= int(offs[r]) and ids[s:e].max() < int(offs[r + 1])
+        if r == world:
+            assert np.all(ids[s:e] < 0)
+    # canonicalise to the reference order: stable sort by id inside each valid segment
+    ref_sorted, ref_raw = oracle.sort_ids(idx)
+    canon_ids, canon_raw = ids.copy(), raw.copy()
+    nvalid = int(seg[world])
+    o = np.argsort(ids[:nvalid].astype(np.int64), kind="stable")
+    canon_ids[:nvalid], canon_raw[:nvalid] = ids[:nvalid][o], raw[:nvalid][o]
+    assert np.array_equal(canon_ids[:nvalid], ref_sorted[:nvalid])
+    assert np.array_equal(canon_raw[:nvalid], ref_raw[:nvalid])
+    # counts-only call
+    d_cnt2 = torch.full((world,), -1, dtype=torch.int64, device="cuda")
+    wmb.check(wmb.lib().wholememory_ext_bucket_ids(d_idx.data_ptr(), wmb.DT_INT if idt == np.int32 else wmb.DT_INT64, n,
+                                                   d_off.data_ptr(), world, d_cnt2.data_ptr(), None, None, env, stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_cnt2.cpu().numpy(), counts)
+
+
+OPTS = [("sgd", 1, {}), ("sgd", 1, {"weight_decay": 0.05}), ("adam", 2, {}), ("adam", 2, {"weight_decay": 0.01}),
+        ("adam", 2, {"weight_decay": 0.02, "adam_w": 1.0}), ("rmsprop", 3, {"alpha": 0.9, "weight_decay": 0.01}),
+        ("adagrad", 4, {"weight_decay": 0.01})]
+
+
+@pytest.mark.parametrize("kind,code,params", OPTS, ids=lambda x: str(x))
+@pytest.mark.parametrize("dim,n_recv,idt", [(127, 20005, np.int64), (129, 20005, np.int32), (128, 50001, np.int64),
+                                            (392, 5001, np.int64), (4, 3000, np.int64), (128, 0, np.int64)])
+def test_dedup_apply_bit_exact(gpu_env, kind, code, params, dim, n_recv, idt):
+    import torch
+    from wholegraph_amd import binding as wmb
+    if isinstance(kind, tuple):
+        pytest.skip()
+    rng = np.random.default_rng(dim * 7 + n_recv + code)
+    local_rows, local_off = 4001, 123456
+    stride = int(oracle.align_embedding_dim(dim, 4))
+    table = np.zeros((local_rows, stride), np.float32)
+    table[:, :dim] = rng.standard_normal((local_rows, dim)).astype(np.float32)
+    ids = (local_off + rng.integers(0, local_rows, n_recv)).astype(idt)
+    if n_recv:
+        ids[::5] = ids[0]  # a long run of duplicates
+    grads = rng.standard_normal((max(n_recv, 1), dim)).astype(np.float32)[:n_recv]
+    p = dict(weight_decay=0.0, epsilon=1e-8, beta1=0.9, beta2=0.999, alpha=0.99, adam_w=0.0)
+    p.update(params)
+    ref_opt = oracle.Optimizer(kind, local_rows, stride, **params)
+    d_table = torch.from_numpy(table.copy()).cuda()
+    d_pe = d_pr = None
+    if kind == "adam":
+        d_pe = torch.zeros((local_rows, 2 * stride), device="cuda")
+        d_pr = torch.ones((local_rows, 2), device="cuda")
+    elif kind in ("adagrad", "rmsprop"):
+        d_pe = torch.zeros((local_rows, stride), device="cuda")
+    d_ids = torch.from_numpy(ids).cuda()
+    d_grads = torch.from_numpy(grads).cuda() if n_recv else torch.zeros((1, dim), device="cuda")
+    arr = (C.c_float * 6)(p["weight_decay"], p["epsilon"], p["beta1"], p["beta2"], p["alpha"], p["adam_w"])
+    env, stream = _env()
+    ref_table = table.copy()
+    for step in range(3):
+        nu = C.c_int64(-1)
+        wmb.check(wmb.lib().wholememory_ext_dedup_apply(
+            d_ids.data_ptr(), wmb.DT_INT if idt == np.int32 else wmb.DT_INT64, n_recv, d_grads.data_ptr(), dim, dim,
+            d_table.data_ptr(), stride, local_off, local_rows, code, arr, 0.03,
+            d_pe.data_ptr() if d_pe is not None else None, d_pr.data_ptr() if d_pr is not None else None, C.byref(nu),
+            env, stream))
+        torch.cuda.synchronize()
+        uniq, dg = oracle.dedup_grads(ids, grads) if n_recv else (ids[:0], grads[:0])
+        assert nu.value == len(uniq)
+        ref_opt.step(uniq, dg, ref_table, stride, local_off, dim, 0.03)
+        assert d_table.cpu().numpy().tobytes() == ref_table.tobytes(), "%s step %d: table differs from the oracle" % (kind, step)
+    if kind != "sgd":
+        assert d_pe.cpu().numpy().tobytes() == ref_opt.per_element.tobytes()
+    if kind == "adam":
+        assert d_pr.cpu().numpy().tobytes() == ref_opt.per_row.tobytes()
+
+
+@pytest.mark.parametrize("mt", ["continuous", "chunked", "distributed"])
+@pytest.mark.parametrize("kind,params", [("sgd", {"weight_decay": 0.01}), ("adam", {}), ("adagrad", {}), ("rmsprop", {})])
+def test_embedding_training_flow(gpu_env, mt, kind, params):
+    """WholeMemoryEmbeddingModule forward + autograd backward + WholeMemoryOptimizer.step, reference shapes
+    (400001 rows x 127, 100005 ids; wholememory_embedding_gradient_apply_tests.cu:30-39), 2 steps."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    n_rows, dim, n_idx = 400001, 127, 100005
+    emb = wgth.create_embedding(gpu_env, mt, "cuda", torch.float32, [n_rows, dim])
+    assert emb.get_embedding_tensor().stride() == (128, 1) and emb.shape == (n_rows, dim)
+    rng = np.random.default_rng(3)
+    init = rng.standard_normal((n_rows, dim)).astype(np.float32)
+    local, start = emb.get_embedding_tensor().get_local_tensor()
+    local.copy_(torch.from_numpy(init).cuda())
+    opt = wgth.create_wholememory_optimizer(emb, kind, params)
+    module = wgth.WholeMemoryEmbeddingModule(emb)
+    module.train()
+    padded = np.zeros((n_rows, 128), np.float32)
+    padded[:, :dim] = init
+    tab = oracle.ShardedTable.from_full(padded, 1)
+    tab.dim = dim
+    ref_opt = oracle.Optimizer(kind, n_rows, 128, **params)
+    for step in range(2):
+        idx = rng.integers(0, n_rows, n_idx).astype(np.int64)
+        idx[::3] = idx[0]
+        w = rng.standard_normal((n_idx, dim)).astype(np.float32)
+        out = module(torch.from_numpy(idx).cuda())
+        exp_out = np.zeros((n_idx, dim), np.float32)
+        oracle.gather(tab, idx, exp_out)
+        assert out.detach().cpu().numpy().tobytes() == exp_out.tobytes()
+        loss = (out * torch.from_numpy(w).cuda()).sum()
+        loss.backward()
+        opt.step(0.02)
+        oracle.gradient_apply(tab, [ref_opt], [idx], [w], 0.02)
+        torch.cuda.synchronize()
+        assert local.cpu().numpy().tobytes() == tab.shards[0][:, :dim].tobytes(), "step %d" % step
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)
+
+
+def test_round_robin_embedding_gather(gpu_env):
+    """round_robin_size != 0: padded row count (embedding.cpp:467-484) and index remap
+    (map_indices_func.cu:26-45) — at world_size 1 the remap is the identity on [0, N)."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    n_rows, dim, rr = 10007, 32, 16
+    emb = wgth.create_embedding(gpu_env, "chunked", "cuda", torch.float32, [n_rows, dim], round_robin_size=rr)
+    assert emb.shape[0] == oracle.round_robin_total_entries(n_rows, 1, rr)
+    local, _ = emb.get_embedding_tensor().get_local_tensor()
+    full = oracle.fill_closed_form(np.float32, 0, emb.shape[0], dim)
+    local.copy_(torch.from_numpy(full).cuda())
+    idx = np.random.default_rng(0).integers(0, n_rows, 5000).astype(np.int64)
+    out = emb.gather(torch.from_numpy(idx).cuda())
+    mapped = oracle.round_robin_map(idx, 0, 1, rr)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), full[mapped])
+    wgth.destroy_embedding(emb)
+
+
+def test_save_load_roundtrip(gpu_env, tmp_path):
+    """WholeMemoryEmbedding.save/load: "%s_part_%d_of_%d" raw row-major shards (torch/embedding.py:358-377)."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    n_rows, dim = 5003, 11
+    emb = wgth.create_embedding(gpu_env, "distributed", "cuda", torch.float32, [n_rows, dim])
+    opt = wgth.create_wholememory_optimizer(emb, "adam", {})
+    local, _ = emb.get_embedding_tensor().get_local_tensor()
+    data = np.random.default_rng(1).standard_normal((n_rows, dim)).astype(np.float32)
+    local.copy_(torch.from_numpy(data).cuda())
+    m, _ = emb.get_optimizer_state("m").get_local_tensor()
+    m.copy_(torch.from_numpy(data * 2).cuda())
+    torch.cuda.synchronize()
+    prefix = str(tmp_path / "ckpt")
+    emb.save(prefix)
+    raw = np.fromfile(prefix + "_embedding_tensor_part_0_of_1", dtype=np.float32).reshape(n_rows, dim)
+    assert np.array_equal(raw, data)  # file rows are dim wide, not stride wide
+    local.zero_()
+    m.zero_()
+    emb.load(prefix)
+    torch.cuda.synchronize()
+    assert np.array_equal(local.cpu().numpy(), data) and np.array_equal(m.cpu().numpy(), data * 2)
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)
