@@ -175,6 +175,8 @@ def gather(table, indices, out, *, dim=None, out_stride=None, out_storage_offset
     dim = table.dim if dim is None else dim
     if out_stride is None:
         out_stride = out.shape[1] if out.ndim == 2 else 1
+    if raw_indices is not None:
+        raw_indices = np.ascontiguousarray(raw_indices, dtype=np.int64)
     rc = lib().wmo_gather(table._ptrs, _p(table.entry_offsets), table.world, table.dt, dim, table.stride,
                           table.storage_offset, _p(indices), np_to_dt(indices.dtype), indices.size,
                           _p(raw_indices), _p(out), out_dt if out_dt is not None else np_to_dt(out.dtype),

@@ -21,9 +21,10 @@ size_t wmo_dtype_size(int dtype);
 int wmo_gather(const void* const* shard_ptrs, const uint64_t* entry_offsets, int world_size, int table_dtype,
                int64_t dim, int64_t stride, int64_t storage_offset, const void* indices, int idx_dtype, int64_t n,
                const void* raw_indices, void* out, int out_dtype, int64_t out_stride, int64_t out_storage_offset);
-int wmo_scatter(const void* in, int in_dtype, int64_t in_stride, int64_t in_storage_offset, const void* indices,
-                int idx_dtype, int64_t n, void* const* shard_ptrs, const uint64_t* entry_offsets, int world_size,
-                int table_dtype, int64_t dim, int64_t stride, int64_t storage_offset);
+int wmo_scatter_mapped(const void* in, int in_dtype, int64_t in_stride, int64_t in_storage_offset, const void* indices,
+                       int idx_dtype, int64_t n, const int64_t* raw_indices, void* const* shard_ptrs,
+                       const uint64_t* entry_offsets, int world_size, int table_dtype, int64_t dim, int64_t stride,
+                       int64_t storage_offset);
 void wmo_bucket_counts(const void* indices, int idx_dtype, int64_t n, const uint64_t* entry_offsets, int world_size,
                        int64_t* counts);
 void wmo_round_robin_map(const void* indices, int idx_dtype, int64_t n, int64_t entry_start, int world_size,
@@ -121,12 +122,12 @@ int t_gather(const wm_rows_args* a, void*)
 int t_scatter(const wm_rows_args* a, void*)
 {
   if (a->n == 0 || a->dim == 0) return 0;
-  if (a->row_map != nullptr) return -1;
   shard_view v;
   if (!make_view(a, &v)) return -1;
-  int rc = wmo_scatter(a->plain, a->plain_dtype, a->plain_stride, a->plain_storage_offset, a->indices, a->index_dtype,
-                       a->n, const_cast<void* const*>(v.ptrs.data()), v.offs.data(), v.world, a->table_dtype, a->dim,
-                       a->table_stride, a->table_storage_offset);
+  int rc = wmo_scatter_mapped(a->plain, a->plain_dtype, a->plain_stride, a->plain_storage_offset, a->indices,
+                              a->index_dtype, a->n, static_cast<const int64_t*>(a->row_map),
+                              const_cast<void* const*>(v.ptrs.data()), v.offs.data(), v.world, a->table_dtype, a->dim,
+                              a->table_stride, a->table_storage_offset);
   return rc == 0 ? 0 : -1;
 }
 

@@ -283,8 +283,9 @@ static inline int owner_rank(int64_t idx, const uint64_t* entry_offsets, int wor
  *   out[storage_off_out + i*out_stride + c] = cast(table[storage_off + idx[i]*stride + c]),
  *   c in [0, dim); rows with idx[i] < 0 are skipped (output row left untouched, :296).
  * The table is given as per-rank shard base pointers + row offsets (world_size == 1 with
- * entry_offsets {0, N} is the CONTINUOUS / plain-pointer case). raw_indices != NULL reproduces
- * gather_with_sorted_ids (:287-288): row i is written to output row raw_indices[i].
+ * entry_offsets {0, N} is the CONTINUOUS / plain-pointer case). raw_indices != NULL (int64) reproduces the
+ * raw_output_idx indirection of gather_with_sorted_ids (:287-288): row i is written to output row
+ * raw_indices[i] (the reference types that array like the indices; here it is always int64).
  * Returns 0, or -1 on an unsupported dtype pair (functions/gather_func.cu:79-81).
  */
 int wmo_gather(const void* const* shard_ptrs, const uint64_t* entry_offsets, int world_size, int table_dtype,
@@ -300,7 +301,7 @@ int wmo_gather(const void* const* shard_ptrs, const uint64_t* entry_offsets, int
   for (int64_t i = 0; i < n; i++) {
     int64_t idx = load_index(idx_dtype, indices, i);
     if (idx < 0) continue;
-    int64_t out_row = raw_indices ? load_index(idx_dtype, raw_indices, i) : i;
+    int64_t out_row = raw_indices ? ((const int64_t*)raw_indices)[i] : i;
     int r           = owner_rank(idx, entry_offsets, world_size);
     int64_t local   = idx - (int64_t)entry_offsets[r];
     convert_row(table_dtype, shard_ptrs[r], storage_offset + local * stride, out_dtype, out,
@@ -316,9 +317,10 @@ int wmo_gather(const void* const* shard_ptrs, const uint64_t* entry_offsets, int
  * unordered; this restatement is sequential, so the LAST occurrence wins — tests that use
  * duplicates must make equal ids carry equal rows (as the reference tests do).
  */
-int wmo_scatter(const void* in, int in_dtype, int64_t in_stride, int64_t in_storage_offset, const void* indices,
-                int idx_dtype, int64_t n, void* const* shard_ptrs, const uint64_t* entry_offsets, int world_size,
-                int table_dtype, int64_t dim, int64_t stride, int64_t storage_offset)
+int wmo_scatter_mapped(const void* in, int in_dtype, int64_t in_stride, int64_t in_storage_offset, const void* indices,
+                       int idx_dtype, int64_t n, const int64_t* raw_indices, void* const* shard_ptrs,
+                       const uint64_t* entry_offsets, int world_size, int table_dtype, int64_t dim, int64_t stride,
+                       int64_t storage_offset)
 {
   if (!((is_float_dtype(table_dtype) && is_float_dtype(in_dtype)) ||
         (is_int_dtype(table_dtype) && is_int_dtype(in_dtype))))
@@ -329,10 +331,19 @@ int wmo_scatter(const void* in, int in_dtype, int64_t in_stride, int64_t in_stor
     if (idx < 0) continue;
     int r         = owner_rank(idx, entry_offsets, world_size);
     int64_t local = idx - (int64_t)entry_offsets[r];
-    convert_row(in_dtype, in, in_storage_offset + i * in_stride, table_dtype, shard_ptrs[r],
+    int64_t in_row = raw_indices ? raw_indices[i] : i; /* input row feeding entry i */
+    convert_row(in_dtype, in, in_storage_offset + in_row * in_stride, table_dtype, shard_ptrs[r],
                 storage_offset + local * stride, dim);
   }
   return 0;
+}
+
+int wmo_scatter(const void* in, int in_dtype, int64_t in_stride, int64_t in_storage_offset, const void* indices,
+                int idx_dtype, int64_t n, void* const* shard_ptrs, const uint64_t* entry_offsets, int world_size,
+                int table_dtype, int64_t dim, int64_t stride, int64_t storage_offset)
+{
+  return wmo_scatter_mapped(in, in_dtype, in_stride, in_storage_offset, indices, idx_dtype, n, 0, shard_ptrs,
+                            entry_offsets, world_size, table_dtype, dim, stride, storage_offset);
 }
 
 /* ------------------------------ index bucketing / exchange ------------------------------------ */

@@ -29,7 +29,7 @@ struct wm_rows_args {
   const void* indices;                // [n] int32/int64, device
   wholememory_dtype_t index_dtype;
   int64_t n;
-  const void* row_map;                // optional [n] (index dtype): plain-side row for entry i; nullptr = i
+  const void* row_map;                // optional [n] int64: plain-side row for entry i; nullptr = i
   void* plain;                        // output (gather) / input (scatter), device
   wholememory_dtype_t plain_dtype;
   int64_t plain_stride;               // elements

@@ -70,7 +70,7 @@ struct rows_params {
   int64_t table_offset_bytes;
   // index side
   const void* indices;
-  const void* row_map;
+  const int64_t* row_map;
   int64_t n;
   // plain side (already offset by storage_offset)
   char* plain;
@@ -109,7 +109,7 @@ __device__ __forceinline__ void load_tile_entry(const rows_params& p, int64_t en
     int64_t idx = static_cast<int64_t>(static_cast<const IdxT*>(p.indices)[entry]);
     if (idx >= 0) {
       tab         = resolve_row(p, idx);
-      int64_t row = p.row_map ? static_cast<int64_t>(static_cast<const IdxT*>(p.row_map)[entry]) : entry;
+      int64_t row = p.row_map ? p.row_map[entry] : entry;  // row map is always int64 (raw_indices)
       pl          = p.plain + row * p.plain_stride_bytes;
     }
   }
@@ -458,7 +458,7 @@ int rows_op(const wm_rows_args* a, void* stream_v)
   p.table_stride_bytes = a->table_stride * tes;
   p.table_offset_bytes = a->table_storage_offset * tes;
   p.indices            = a->indices;
-  p.row_map            = a->row_map;
+  p.row_map            = static_cast<const int64_t*>(a->row_map);
   p.n                  = a->n;
   p.plain              = static_cast<char*>(a->plain) + a->plain_storage_offset * pes;
   p.plain_stride_bytes = a->plain_stride * pes;

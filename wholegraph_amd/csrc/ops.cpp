@@ -54,7 +54,7 @@ void* temp_mem::alloc(int64_t elt_count, wholememory_dtype_t dtype, wholememory_
 // ------------------------------------------------------------------------------------------------
 void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
                              const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream,
-                             id_exchange* x)
+                             id_exchange* x, bool keep_self_local)
 {
   const auto* bk = backend();
   const int W    = comm->world_size;
@@ -91,6 +91,18 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   WM_BK(bk->stream_sync(stream));
   for (int i = 0; i < W; i++) x->send_counts[i] = h_cnt[i];
   comm->alltoall_host_i64(x->send_counts.data(), x->recv_counts.data());
+  // bucketed layout (all owners, self included) — positions into bucketed_ids / raw_indices
+  x->bucket_offsets.assign(W + 1, 0);
+  for (int i = 0; i < W; i++) x->bucket_offsets[i + 1] = x->bucket_offsets[i] + x->send_counts[i];
+  x->total_valid = x->bucket_offsets[W];
+  x->self_count  = x->send_counts[comm->world_rank];
+  x->self_offset = x->bucket_offsets[comm->world_rank];
+  if (keep_self_local) {
+    // ids this rank owns itself never enter the exchange: the caller serves them straight from / to
+    // the local shard. The wire layout below is the bucketed layout with the self segment cut out.
+    x->send_counts[comm->world_rank] = 0;
+    x->recv_counts[comm->world_rank] = 0;
+  }
   for (int i = 0; i < W; i++) {
     x->send_offsets[i + 1] = x->send_offsets[i] + x->send_counts[i];
     x->recv_offsets[i + 1] = x->recv_offsets[i] + x->recv_counts[i];
@@ -98,8 +110,24 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   x->total_send = x->send_offsets[W];
   x->total_recv = x->recv_offsets[W];
   x->recv_ids   = x->recv_mem.device(x->total_recv, index_dtype);
-  exchange_rows(comm, x->bucketed_ids, x->send_counts, x->recv_ids, x->recv_counts, ies, stream);
+  exchange_segments(comm, x->bucketed_ids, x->send_counts, x->bucket_offsets, x->recv_ids, x->recv_counts,
+                    x->recv_offsets, ies, stream);
   if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+}
+
+void exchange_segments(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts,
+                       const std::vector<int64_t>& send_offsets, void* recv, const std::vector<int64_t>& recv_counts,
+                       const std::vector<int64_t>& recv_offsets, size_t row_bytes, void* stream)
+{
+  const int W = comm->world_size;
+  std::vector<size_t> sb(W), sd(W), rb(W), rd(W);
+  for (int i = 0; i < W; i++) {
+    sb[i] = static_cast<size_t>(send_counts[i]) * row_bytes;
+    rb[i] = static_cast<size_t>(recv_counts[i]) * row_bytes;
+    sd[i] = static_cast<size_t>(send_offsets[i]) * row_bytes;
+    rd[i] = static_cast<size_t>(recv_offsets[i]) * row_bytes;
+  }
+  comm->alltoallv_device(send, sb.data(), sd.data(), recv, rb.data(), rd.data(), stream);
 }
 
 void exchange_rows(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts, void* recv,
@@ -260,33 +288,51 @@ wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const o
   const int64_t dim        = d.table.sizes[1];
   auto entry_offsets       = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
   const char* indices      = static_cast<const char*>(d.indices_ptr);  // data pointer: offset already applied
-  (void)ies;
 
   id_exchange x(env);
-  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x);
+  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x, true);
+  const auto local_gref = local_shard_gref(handle);
 
-  // owner side: rows of the received ids, already in the output dtype (gather_op_impl_nccl.cu:115-140)
+  // (a) ids this rank owns itself: straight from the local shard into their final output rows
+  //     (row_map = raw_indices) — no staging buffer, no copy, no reorder pass for them
+  if (x.self_count > 0) {
+    wm_rows_args sa{};
+    fill_rows_args(&sa, local_gref, d.table, static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset,
+                   d.indices.dtype, x.self_count, d.plain_ptr, d.plain, gather_sms);
+    sa.row_map = x.raw_indices + x.self_offset;
+    WM_BK(bk->gather_rows(&sa, stream));
+  }
+
+  // (b) owner side for the peers: rows of the received ids, already in the output dtype
+  //     (gather_op_impl_nccl.cu:115-140), lined up in send order
   temp_mem local_rows(env), recv_rows(env);
   void* local_buf = local_rows.device(dim * x.total_recv, d.plain.dtype);
-  void* recv_buf  = recv_rows.device(dim * x.total_send, d.plain.dtype);
+  void* recv_buf  = recv_rows.device(dim * x.total_valid, d.plain.dtype);  // bucketed layout (self segment unused)
   int64_t lsz[2]  = {x.total_recv, dim};
   auto local_desc = wholememory_create_matrix_desc(lsz, dim, 0, d.plain.dtype);
   wm_rows_args ga{};
-  fill_rows_args(&ga, local_shard_gref(handle), d.table, x.recv_ids, d.indices.dtype, x.total_recv, local_buf,
-                 local_desc, gather_sms);
+  fill_rows_args(&ga, local_gref, d.table, x.recv_ids, d.indices.dtype, x.total_recv, local_buf, local_desc, gather_sms);
   WM_BK(bk->gather_rows(&ga, stream));
   if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
 
-  // rows travel back along the reverse of the id exchange (gather_op_impl_nccl.cu:141-150)
-  exchange_rows(comm, local_buf, x.recv_counts, recv_buf, x.send_counts, static_cast<size_t>(dim) * oes, stream);
+  // (c) rows travel back along the reverse of the id exchange (gather_op_impl_nccl.cu:141-150) and land at
+  //     their bucketed positions
+  exchange_segments(comm, local_buf, x.recv_counts, x.recv_offsets, recv_buf, x.send_counts, x.bucket_offsets,
+                    static_cast<size_t>(dim) * oes, stream);
 
-  // reorder on receive: out[raw_indices[j]] = recv[j]  (gather_op_impl_nccl.cu:151-168)
-  int64_t rsz[2] = {x.total_send, dim};
-  auto recv_desc = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
-  wm_rows_args sa{};
-  fill_rows_args(&sa, wholememory_create_continuous_global_reference(d.plain_ptr), d.plain, x.raw_indices,
-                 WHOLEMEMORY_DT_INT64, x.total_send, recv_buf, recv_desc, -1);
-  WM_BK(bk->scatter_rows(&sa, stream));
+  // (d) reorder on receive: out[raw_indices[j]] = recv[j] for the remote segments (gather_op_impl_nccl.cu:151-168)
+  const auto out_gref = wholememory_create_continuous_global_reference(d.plain_ptr);
+  for (int seg = 0; seg < 2; seg++) {  // [0, self_offset) and [self_offset + self_count, total_valid)
+    const int64_t s0 = seg == 0 ? 0 : x.self_offset + x.self_count;
+    const int64_t s1 = seg == 0 ? x.self_offset : x.total_valid;
+    if (s1 <= s0) continue;
+    int64_t rsz[2] = {s1 - s0, dim};
+    auto recv_desc = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
+    wm_rows_args ra{};
+    fill_rows_args(&ra, out_gref, d.plain, x.raw_indices + s0, WHOLEMEMORY_DT_INT64, s1 - s0,
+                   static_cast<char*>(recv_buf) + static_cast<size_t>(s0) * dim * oes, recv_desc, -1);
+    WM_BK(bk->scatter_rows(&ra, stream));
+  }
   if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
   return WHOLEMEMORY_SUCCESS;
 }
@@ -305,31 +351,47 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
   const int64_t dim   = d.table.sizes[1];
   auto entry_offsets  = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
   const char* indices = static_cast<const char*>(d.indices_ptr);  // data pointer: offset already applied
-  (void)ies;
 
   id_exchange x(env);
-  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x);
+  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x, true);
+  const auto local_gref = local_shard_gref(handle);
 
-  // requester side: input rows lined up in send order (scatter_op_impl_nccl.cu:118-133)
+  // (a) rows this rank owns itself: input row raw_indices[j] -> local table row, directly
+  if (x.self_count > 0) {
+    wm_rows_args sa{};
+    fill_rows_args(&sa, local_gref, d.table, static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset,
+                   d.indices.dtype, x.self_count, d.plain_ptr, d.plain, scatter_sms);
+    sa.row_map = x.raw_indices + x.self_offset;
+    WM_BK(bk->scatter_rows(&sa, stream));
+  }
+
+  // (b) requester side: input rows of the remote segments lined up in bucketed order (scatter_op_impl_nccl.cu:118-133)
   temp_mem send_rows(env), recv_rows(env);
-  void* send_buf = send_rows.device(dim * x.total_send, d.plain.dtype);
+  void* send_buf = send_rows.device(dim * x.total_valid, d.plain.dtype);
   void* recv_buf = recv_rows.device(dim * x.total_recv, d.plain.dtype);
-  int64_t ssz[2] = {x.total_send, dim};
-  auto send_desc = wholememory_create_matrix_desc(ssz, dim, 0, d.plain.dtype);
-  wm_rows_args ga{};
-  fill_rows_args(&ga, wholememory_create_continuous_global_reference(d.plain_ptr), d.plain, x.raw_indices,
-                 WHOLEMEMORY_DT_INT64, x.total_send, send_buf, send_desc, -1);
-  WM_BK(bk->gather_rows(&ga, stream));
+  const auto in_gref = wholememory_create_continuous_global_reference(d.plain_ptr);
+  for (int seg = 0; seg < 2; seg++) {
+    const int64_t s0 = seg == 0 ? 0 : x.self_offset + x.self_count;
+    const int64_t s1 = seg == 0 ? x.self_offset : x.total_valid;
+    if (s1 <= s0) continue;
+    int64_t ssz[2] = {s1 - s0, dim};
+    auto send_desc = wholememory_create_matrix_desc(ssz, dim, 0, d.plain.dtype);
+    wm_rows_args ga{};
+    fill_rows_args(&ga, in_gref, d.plain, x.raw_indices + s0, WHOLEMEMORY_DT_INT64, s1 - s0,
+                   static_cast<char*>(send_buf) + static_cast<size_t>(s0) * dim * pes, send_desc, -1);
+    WM_BK(bk->gather_rows(&ga, stream));
+  }
 
-  exchange_rows(comm, send_buf, x.send_counts, recv_buf, x.recv_counts, static_cast<size_t>(dim) * pes, stream);
+  // (c) rows to their owners
+  exchange_segments(comm, send_buf, x.send_counts, x.bucket_offsets, recv_buf, x.recv_counts, x.recv_offsets,
+                    static_cast<size_t>(dim) * pes, stream);
 
-  // owner side: write (and cast) into the local shard (scatter_op_impl_nccl.cu:145-166)
+  // (d) owner side: write (and cast) into the local shard (scatter_op_impl_nccl.cu:145-166)
   int64_t rsz[2] = {x.total_recv, dim};
   auto recv_desc = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
-  wm_rows_args sa{};
-  fill_rows_args(&sa, local_shard_gref(handle), d.table, x.recv_ids, d.indices.dtype, x.total_recv, recv_buf,
-                 recv_desc, scatter_sms);
-  WM_BK(bk->scatter_rows(&sa, stream));
+  wm_rows_args wa{};
+  fill_rows_args(&wa, local_gref, d.table, x.recv_ids, d.indices.dtype, x.total_recv, recv_buf, recv_desc, scatter_sms);
+  WM_BK(bk->scatter_rows(&wa, stream));
   WM_BK(bk->stream_sync(stream));  // scatter_op_impl_nccl.cu:168
   return WHOLEMEMORY_SUCCESS;
 }

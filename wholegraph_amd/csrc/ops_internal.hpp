@@ -36,10 +36,14 @@ class temp_mem {
 // functions/exchange_ids_nccl_func.cu:157-226).
 struct id_exchange {
   explicit id_exchange(wholememory_env_func_t* env) : bucketed_mem(env), raw_mem(env), recv_mem(env) {}
-  std::vector<int64_t> send_counts, recv_counts;    // per peer
-  std::vector<int64_t> send_offsets, recv_offsets;  // exclusive prefix, W+1
-  int64_t total_send = 0;                           // valid (non-negative) ids of this rank
-  int64_t total_recv = 0;                           // ids this rank owns, from all peers
+  std::vector<int64_t> send_counts, recv_counts;    // per peer, as they travel (self = 0 when kept local)
+  std::vector<int64_t> send_offsets, recv_offsets;  // exclusive prefix of the above, W+1
+  std::vector<int64_t> bucket_offsets;              // W+1: where each owner's segment starts in bucketed_ids
+  int64_t total_send  = 0;                          // ids that travel
+  int64_t total_recv  = 0;                          // ids received from peers
+  int64_t total_valid = 0;                          // non-negative ids of this rank (all owners)
+  int64_t self_count  = 0;                          // ids of this rank that it owns itself
+  int64_t self_offset = 0;                          // their position in bucketed_ids / raw_indices
   void* bucketed_ids   = nullptr;                   // [n]   ids grouped by owner (index dtype)
   int64_t* raw_indices = nullptr;                   // [n]   original position of each grouped id
   void* recv_ids       = nullptr;                   // [total_recv] ids received, peer-major
@@ -48,7 +52,12 @@ struct id_exchange {
 
 void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
                              const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream,
-                             id_exchange* x);
+                             id_exchange* x, bool keep_self_local = false);
+
+// all-to-all-v of fixed-size rows with explicit per-peer row offsets on both sides
+void exchange_segments(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts,
+                       const std::vector<int64_t>& send_offsets, void* recv, const std::vector<int64_t>& recv_counts,
+                       const std::vector<int64_t>& recv_offsets, size_t row_bytes, void* stream);
 
 // all-to-all-v of fixed-size rows: counts in rows, peer-major contiguous on both sides
 void exchange_rows(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts, void* recv,
