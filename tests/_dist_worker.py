@@ -8,7 +8,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["WHOLEGRAPH_AMD_TESTING"] = "1"
+HIP_MODE = len(sys.argv) > 4 and sys.argv[4] == "hip"   # real kernels on cuda:0, collectives still over gloo
+if not HIP_MODE:
+    os.environ["WHOLEGRAPH_AMD_TESTING"] = "1"
 
 import numpy as np
 import torch
@@ -27,6 +29,15 @@ def install_test_backend():
     return tb
 
 
+def dev(t):
+    """op inputs/outputs live where the installed backend keeps device memory"""
+    return t.cuda() if HIP_MODE else t
+
+
+def host(t):
+    return t.cpu() if HIP_MODE else t
+
+
 def shard_views(emb_tensor, rank):
     local, start = emb_tensor.get_local_tensor(host_view=False)
     return local, start
@@ -38,20 +49,23 @@ def gather_all_local(emb_tensor):
     return local.numpy().copy(), start
 
 
-def scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, entries):
+def scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, entries, loc="cuda"):
     tt = {np.float32: torch.float32, np.float16: torch.float16, np.int32: torch.int32, np.int64: torch.int64}
     stride = dim + (3 if dim % 4 else 0)
-    wm = wgth.create_wholememory_tensor(comm, mt, "cuda", [n_rows, stride], tt[tdt], [stride, 1], entries)
+    wm = wgth.create_wholememory_tensor(comm, mt, loc, [n_rows, stride], tt[tdt], [stride, 1], entries)
+    hv = loc == "cpu"   # host-located tables are filled / checked through their host view
     view = wm.get_sub_tensor([0, 0], [n_rows, dim]) if stride != dim else wm
     full = oracle.fill_closed_form(tdt, 0, n_rows, dim, stride)
     tab = oracle.ShardedTable.from_full(full, world, entries)
     tab.dim = dim
-    local, start = wm.get_local_tensor()
+    local, start = wm.get_local_tensor(host_view=hv)
     assert start == int(tab.entry_offsets[rank])
     cnt = int(tab.entry_offsets[rank + 1] - tab.entry_offsets[rank])
     assert local.shape[0] == cnt
     if cnt:
-        local.copy_(torch.from_numpy(full[start:start + cnt]))
+        local.copy_(torch.from_numpy(full[start:start + cnt]) if hv else dev(torch.from_numpy(full[start:start + cnt])))
+    if HIP_MODE:
+        torch.cuda.synchronize()
     comm.barrier()
     rngs = [np.random.default_rng(100 + r) for r in range(world)]
     rank_idx = []
@@ -63,16 +77,20 @@ def scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, e
             ix[:8] = ix[0]
         rank_idx.append(ix)
     exp = oracle.distributed_gather(tab, rank_idx, odt, out_init=[np.full((len(ix), dim), 5, dtype=odt) for ix in rank_idx])
-    out = torch.full((len(rank_idx[rank]), dim), 5, dtype=tt[odt])
+    out = dev(torch.full((len(rank_idx[rank]), dim), 5, dtype=tt[odt]))
     from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream
-    wi, wo = wrap_torch_tensor(torch.from_numpy(rank_idx[rank])), wrap_torch_tensor(out)
+    wi, wo = wrap_torch_tensor(dev(torch.from_numpy(rank_idx[rank]))), wrap_torch_tensor(out)
     wmb.check(wmb.lib().wholememory_gather(view.wmb_tensor, wi.handle, wo.handle, get_wholegraph_env_fns(),
                                            C.c_void_p(get_stream()), -1))
-    assert out.numpy().tobytes() == exp[rank].tobytes(), "distributed gather mismatch on rank %d" % rank
+    if HIP_MODE:
+        torch.cuda.synchronize()
+    assert host(out).numpy().tobytes() == exp[rank].tobytes(), "%s gather mismatch on rank %d" % (mt, rank)
     # scatter: every rank writes rows of its own ids (closed-form rows: duplicates agree), then everyone checks
     comm.barrier()
     if cnt:
         local.zero_()
+    if HIP_MODE:
+        torch.cuda.synchronize()
     comm.barrier()
     ref = oracle.ShardedTable.from_full(np.zeros((n_rows, stride), dtype=tdt), world, entries)
     ref.dim = dim
@@ -83,12 +101,15 @@ def scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, e
         rows[v] = src[rank_idx[r][v].astype(np.int64)]
         oracle.scatter(rows, rank_idx[r], ref)
         if r == rank:
-            wr, wx = wrap_torch_tensor(torch.from_numpy(rows)), wrap_torch_tensor(torch.from_numpy(rank_idx[r]))
+            wr, wx = wrap_torch_tensor(dev(torch.from_numpy(rows))), wrap_torch_tensor(dev(torch.from_numpy(rank_idx[r])))
             wmb.check(wmb.lib().wholememory_scatter(wr.handle, wx.handle, view.wmb_tensor, get_wholegraph_env_fns(),
                                                     C.c_void_p(get_stream()), -1))
+            if HIP_MODE:
+                torch.cuda.synchronize()
     comm.barrier()
     if cnt:
-        assert local.numpy().tobytes() == ref.shards[rank][:cnt].tobytes(), "distributed scatter mismatch on rank %d" % rank
+        assert (local if hv else host(local)).numpy().tobytes() == ref.shards[rank][:cnt].tobytes(), \
+            "%s/%s scatter mismatch on rank %d" % (mt, loc, rank)
     comm.barrier()
     if view is not wm:
         wgth.destroy_wholememory_tensor(view)
@@ -109,7 +130,7 @@ def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries):
     local, start = emb.get_embedding_tensor().get_local_tensor()
     cnt = int(tab.entry_offsets[rank + 1] - tab.entry_offsets[rank])
     assert tuple(local.shape) == (cnt, dim) and local.stride(0) == stride
-    local.copy_(torch.from_numpy(init[start:start + cnt]))
+    local.copy_(dev(torch.from_numpy(init[start:start + cnt])))
     opt = wgth.create_wholememory_optimizer(emb, kind, params)
     assert emb.get_optimizer_state_names() == {"sgd": [], "adam": ["m", "v", "beta12t"], "adagrad": ["state_sum"],
                                                "rmsprop": ["v"]}[kind]
@@ -123,18 +144,20 @@ def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries):
             ix[::7] = ix[0]  # heavy duplicates
             rank_idx.append(ix)
             rank_grads.append(g.standard_normal((len(ix), dim)).astype(np.float32))
-        emb.add_gradients(torch.from_numpy(rank_idx[rank]), torch.from_numpy(rank_grads[rank]))
+        emb.add_gradients(dev(torch.from_numpy(rank_idx[rank])), dev(torch.from_numpy(rank_grads[rank])))
         emb.need_apply = True
         opt.step(0.05)
         oracle.gradient_apply(tab, ref_opts, rank_idx, rank_grads, 0.05)
-        got = local.numpy()
+        if HIP_MODE:
+            torch.cuda.synchronize()
+        got = host(local).numpy()
         assert got.tobytes() == tab.shards[rank][:cnt, :dim].tobytes(), \
             "gradient apply (%s) mismatch on rank %d step %d" % (kind, rank, step)
     if kind == "adam":
         m, _ = emb.get_optimizer_state("m").get_local_tensor()
-        assert m.numpy().tobytes() == ref_opts[rank].per_element[:cnt, :dim].tobytes()
+        assert host(m).numpy().tobytes() == ref_opts[rank].per_element[:cnt, :dim].tobytes()
         b, _ = emb.get_optimizer_state("beta12t").get_local_tensor()
-        assert b.numpy().tobytes() == ref_opts[rank].per_row[:cnt].tobytes()
+        assert host(b).numpy().tobytes() == ref_opts[rank].per_row[:cnt].tobytes()
     comm.barrier()
     wgth.destroy_wholememory_optimizer(opt)
     wgth.destroy_embedding(emb)
@@ -144,7 +167,11 @@ def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
-    install_test_backend()
+    if HIP_MODE:
+        torch.cuda.set_device(0)   # every rank shares the one GPU of the test box
+        assert wmb.lib().wholememory_ext_backend_name() == b"hip-gfx950"
+    else:
+        install_test_backend()
     wgth.init(rank, world, rank, world, "warn")
     comm = wgth.get_global_communicator()
     assert comm.get_rank() == rank and comm.get_size() == world
@@ -155,10 +182,20 @@ def main():
     # (3) custom partition (python random_partition shape) + ints
     ent = [int(x) for x in (np.array([0.2, 0.5, 0.3, 0.1, 0.4][:world]) / sum([0.2, 0.5, 0.3, 0.1, 0.4][:world]) * 997).astype(int)]
     ent[0] += 997 - sum(ent)
+    ent2 = [2 * e for e in ent]
+    ent2[0] += 2003 - sum(ent2)
     scenario_gather_scatter(comm, rank, world, "distributed", 997, 8, np.int64, np.int32, np.int64, ent)
     # (4) trailing ranks empty under the equal plan: N < W * ceil(N / W) only when W > N … use tiny N
     if world >= 3:
         scenario_gather_scatter(comm, rank, world, "distributed", 4, 4, np.float32, np.float32, np.int64, None)
+    if HIP_MODE:
+        # (4b) CHUNKED over two processes: peers' shards mapped with hipIpc, kernels read them directly;
+        #      host-located tables: one POSIX shm segment registered with HIP on every rank
+        scenario_gather_scatter(comm, rank, world, "chunked", 3001, 128, np.float32, np.float32, np.int64, None)
+        scenario_gather_scatter(comm, rank, world, "chunked", 997, 8, np.int64, np.int32, np.int64, ent)
+        scenario_gather_scatter(comm, rank, world, "chunked", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
+        scenario_gather_scatter(comm, rank, world, "continuous", 2003, 32, np.float32, np.float16, np.int32, ent2, loc="cpu")
+        scenario_gather_scatter(comm, rank, world, "distributed", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
     # (5) gradient apply, all optimizers
     for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}),
                          ("adam", {"adam_w": 1.0, "weight_decay": 0.02}), ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]:

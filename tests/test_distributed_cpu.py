@@ -21,14 +21,10 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_paths_over_gloo(wm_lib, world):
-    tb = os.path.join(ROOT, "oracle", "libwm_test_backend.so")
-    if not os.path.exists(tb):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "test_backend"])
+def run_world(world, mode, extra_env):
     port = str(free_port())
-    env = dict(os.environ, WHOLEGRAPH_AMD_TESTING="1", OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(r), str(world), port],
+    env = dict(os.environ, OMP_NUM_THREADS="1", **extra_env)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(r), str(world), port, mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     for p in procs:
@@ -42,3 +38,20 @@ def test_distributed_paths_over_gloo(wm_lib, world):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("RANK %d OK" % r) in o, "rank %d failed:\n%s" % (
             r, "\n=====\n".join(x[-2500:] for x in outs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_on_one_gpu_hip_kernels(wm_lib, world):
+    """N processes sharing cuda:0: the real HIP kernels + the real multi-rank orchestration, hipIpc-mapped
+    CHUNKED shards across processes, collectives over gloo (RCCL refuses two ranks on one device, and the
+    test boxes have a single GPU)."""
+    run_world(world, "hip", {})
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_paths_over_gloo(wm_lib, world):
+    tb = os.path.join(ROOT, "oracle", "libwm_test_backend.so")
+    if not os.path.exists(tb):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "test_backend"])
+    run_world(world, "cpu", {"WHOLEGRAPH_AMD_TESTING": "1", "HIP_VISIBLE_DEVICES": ""})

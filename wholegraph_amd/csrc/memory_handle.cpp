@@ -76,13 +76,15 @@ void plan_partition(wholememory_handle_* h, const size_t* rank_entry_partition)
       h->part_sizes[i]       = rank_entry_partition[i] * h->granularity;
       h->part_offsets[i + 1] = h->part_offsets[i] + h->part_sizes[i];
     }
-    h->mem_stride = h->total_size / W;
-    h->same_chunk = true;
-    for (int i = 0; i < W - 2; i++) {
-      if (h->part_sizes[i] != h->part_sizes[i + 1]) {
-        h->same_chunk = false;
-        break;
-      }
+    // same_chunk lets kernels find the owner as byte_offset / stride. The reference sets
+    // stride = total / W and same_chunk = "sizes[0..W-2] all equal" (memory_handle.cpp:1605-1616), which
+    // mis-addresses peers whenever that common size is not total / W (always true for W == 2 with an
+    // uneven split). Here the flag is only raised when the division is actually right: every rank but the
+    // last holds exactly sizes[0] bytes and the last holds no more than that.
+    h->mem_stride = h->part_sizes[0];
+    h->same_chunk = h->part_sizes[W - 1] <= h->part_sizes[0];
+    for (int i = 0; i + 1 < W && h->same_chunk; i++) {
+      if (h->part_sizes[i] != h->part_sizes[0]) h->same_chunk = false;
     }
     return;
   }
