@@ -35,6 +35,10 @@ def parse():
     p.add_argument("--indices", type=int, default=10_000_000)
     p.add_argument("--dist", choices=["uniform", "zipf", "zipf_clustered"], default="uniform")
     p.add_argument("--memory-type", default="", help="override: continuous|chunked|distributed")
+    p.add_argument("--location", default="cuda", help="cuda|cpu (HOST-located table, config C1)")
+    p.add_argument("--op", choices=["gather", "scatter", "grad_apply"], default="gather",
+                   help="side measurements; the contract metric is gather")
+    p.add_argument("--optimizer", default="sgd")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-check", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -112,8 +116,8 @@ def main():
     rows_per_gpu = a.rows or (100_000_000 if world == 1 else 125_000_000)
     total_rows = rows_per_gpu * world
     mt = a.memory_type or ("chunked" if world == 1 else "distributed")
-    emb = wgth.create_embedding(comm, mt, "cuda", torch.float32, [total_rows, a.dim])
-    local, start = emb.get_embedding_tensor().get_local_tensor()
+    emb = wgth.create_embedding(comm, mt, a.location, torch.float32, [total_rows, a.dim])
+    local, start = emb.get_embedding_tensor().get_local_tensor(host_view=False)
     fill_table(local, start)
     idx_np = make_indices(a.indices, total_rows, a.dist, 42 + rank)
     idx = torch.from_numpy(idx_np).cuda()
@@ -127,8 +131,25 @@ def main():
     # the output buffer is allocated once, as in the reference bench (gather_scatter_bench.cu:322-343):
     # a fresh 5 GB hipMalloc inside the timed region would cost ~140 ms and is not part of the op
     out = torch.empty((a.indices, a.dim), dtype=torch.float32, device="cuda")
+    opt = None
+    if a.op == "grad_apply":
+        opt = wgth.create_wholememory_optimizer(emb, a.optimizer, {})
+        out.normal_()
+
+    def step():
+        if a.op == "gather":
+            emb.gather(idx, out=out)
+        elif a.op == "scatter":
+            emb.get_embedding_tensor().scatter(out, idx)
+        else:
+            emb.add_gradients(idx, out)
+            emb.need_apply = True
+            emb.apply_gradients(0.01)
+
+    if a.op != "gather":
+        a.no_check = True
     for _ in range(max(a.warmup, 1)):
-        emb.gather(idx, out=out)
+        step()
     barrier()
     if not a.no_check and out is not None:
         exp = (idx & 0xFFFFFF).to(torch.float32)
@@ -140,7 +161,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(a.steps):
-        emb.gather(idx, out=out)
+        step()
     ev1.record()
     barrier()
     t1 = time.perf_counter()
@@ -155,7 +176,8 @@ def main():
         out_bytes = a.dim * 4
         algo_bytes = 8 + a.dim * 4 + a.dim * 4
         res = {
-            "metric": "gather_GBps_out (gathered output bytes/s, reference gather_scatter_bench convention)",
+            "metric": "%s_GBps_out (%s row bytes/s, reference gather_scatter_bench convention)" % (
+                a.op, {"gather": "gathered output", "scatter": "scattered input", "grad_apply": "gradient"}[a.op]),
             "value": round(lookups * out_bytes / 1e9, 2),
             "unit": "GB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -170,7 +192,7 @@ def main():
                        "memory_type": mt, "rows_per_gpu": rows_per_gpu, "indices_per_rank": a.indices,
                        "index_distribution": a.dist},
         }
-        if world == 1:
+        if world == 1 and a.op == "gather":
             # dominant kernel = rows_copy_kernel<long,16,true>: the whole step at N=1
             achieved = a.indices * algo_bytes / (dev_ms * 1e-3) / 1e9
             traffic = None

@@ -193,6 +193,9 @@ def main():
         #      host-located tables: one POSIX shm segment registered with HIP on every rank
         scenario_gather_scatter(comm, rank, world, "chunked", 3001, 128, np.float32, np.float32, np.int64, None)
         scenario_gather_scatter(comm, rank, world, "chunked", 997, 8, np.int64, np.int32, np.int64, ent)
+        scenario_gather_scatter(comm, rank, world, "continuous", 3001, 128, np.float32, np.float32, np.int64, None)
+        scenario_gather_scatter(comm, rank, world, "continuous", 997, 8, np.int64, np.int32, np.int64, ent)
+        scenario_gather_scatter(comm, rank, world, "continuous", 900001, 32, np.float32, np.float32, np.int32, None)
         scenario_gather_scatter(comm, rank, world, "chunked", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
         scenario_gather_scatter(comm, rank, world, "continuous", 2003, 32, np.float32, np.float16, np.int32, ent2, loc="cpu")
         scenario_gather_scatter(comm, rank, world, "distributed", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")

@@ -142,7 +142,7 @@ class rccl_provider : public collective_provider {
 // split() routes through the parent with the member list applied.
 class ext_provider : public collective_provider {
  public:
-  ext_provider(const wm_ext_collectives_t& c, int rank, int size) : c_(c), rank_(rank), size_(size) {}
+  ext_provider(const wm_ext_collectives_t& c, int, int) : c_(c) {}
   const char* name() const override { return "external"; }
   void barrier() override
   {
@@ -165,7 +165,6 @@ class ext_provider : public collective_provider {
 
  private:
   wm_ext_collectives_t c_;
-  int rank_, size_;
 };
 
 int next_comm_id()

@@ -13,9 +13,9 @@
 //    same gref shapes work for host-resident tables;
 //  * with ONE rank every type degenerates to a flat allocation and the ops layer hands kernels a
 //    continuous gref (no per-row owner lookup).
-//  * multi-rank CONTINUOUS/DEVICE needs HIP VMM (hipMemCreate/Export/Map) to stitch shards into one
-//    VA range; not built yet in this round -> WHOLEMEMORY_NOT_IMPLEMENTED (CHUNKED covers the same
-//    access pattern).
+//  * multi-rank CONTINUOUS/DEVICE = HIP VMM: each rank creates its page run (hipMemCreate), exports it as
+//    a dmabuf fd, fds are passed over AF_UNIX sockets, and every rank maps all runs into one reserved VA
+//    range (memory_vmm.cpp).
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -29,6 +29,7 @@
 
 #include "backend.hpp"
 #include "communicator.hpp"
+#include "memory_vmm.hpp"
 #include "wm_common.hpp"
 
 struct wholememory_handle_ {
@@ -54,6 +55,8 @@ struct wholememory_handle_ {
   // host shm
   void* shm_host_ptr = nullptr;
   size_t shm_bytes   = 0;
+  // multi-rank CONTINUOUS device memory (HIP VMM)
+  wm::vmm_mapping vmm;
 };
 
 namespace wm {
@@ -209,7 +212,14 @@ void create_memory(wholememory_handle_* h)
     map_chunked_device(h);
     return;
   }
-  throw logic_error("multi-rank CONTINUOUS device memory (HIP VMM stitching) is not implemented in this build");
+  // multi-rank CONTINUOUS in HBM: every rank's pages stitched into one VA range (memory_vmm.cpp)
+  if (backend() != hip_backend()) throw logic_error("multi-rank CONTINUOUS device memory needs the HIP backend");
+  vmm_continuous_create(h->comm, h->total_size, &h->vmm);
+  h->global_base = h->vmm.base;
+  h->local_ptr   = static_cast<char*>(h->vmm.base) + h->part_offsets[h->comm->world_rank];
+  h->rank_ptrs.assign(W, nullptr);
+  for (int r = 0; r < W; r++) h->rank_ptrs[r] = static_cast<char*>(h->vmm.base) + h->part_offsets[r];
+  upload_tables(h);
 }
 
 void destroy_memory(wholememory_handle_* h) noexcept
@@ -219,7 +229,9 @@ void destroy_memory(wholememory_handle_* h) noexcept
   const int rank = h->comm->world_rank;
   if (h->dev_rank_ptrs) bk->free_device(h->dev_rank_ptrs);
   if (h->dev_rank_offsets) bk->free_device(h->dev_rank_offsets);
-  if (h->shm_host_ptr != nullptr) {
+  if (h->vmm.base != nullptr) {
+    vmm_continuous_destroy(h->comm, &h->vmm);
+  } else if (h->shm_host_ptr != nullptr) {
     bk->host_unregister(h->shm_host_ptr);
     munmap(h->shm_host_ptr, h->shm_bytes);
   } else {
