@@ -65,7 +65,7 @@ def fill_table(local, row_start):
     for s in range(0, rows, chunk):
         e = min(rows, s + chunk)
         r = torch.arange(row_start + s, row_start + e, device="cuda", dtype=torch.int64) & 0xFFFFFF
-        local[s:e] = r.to(torch.float32).unsqueeze(1)
+        local[s:e] = r.to(torch.float32).unsqueeze(1).to(local.device)
     torch.cuda.synchronize()
 
 
@@ -117,7 +117,7 @@ def main():
     total_rows = rows_per_gpu * world
     mt = a.memory_type or ("chunked" if world == 1 else "distributed")
     emb = wgth.create_embedding(comm, mt, a.location, torch.float32, [total_rows, a.dim])
-    local, start = emb.get_embedding_tensor().get_local_tensor(host_view=False)
+    local, start = emb.get_embedding_tensor().get_local_tensor(host_view=(a.location == "cpu"))
     fill_table(local, start)
     idx_np = make_indices(a.indices, total_rows, a.dist, 42 + rank)
     idx = torch.from_numpy(idx_np).cuda()

@@ -224,6 +224,7 @@ int t_step(const wm_optimizer_args* a, const int64_t* n_unique_dev, void*)
   return 0;
 }
 
+size_t t_long_ws(int64_t) { return 64; }
 int t_rr(const void* ids, void* mapped, wholememory_dtype_t dt, int64_t n, int64_t entry_start, int world, int rr, void*)
 {
   wmo_round_robin_map(ids, dt, n, entry_start, world, rr, mapped);
@@ -239,7 +240,7 @@ const wm_device_backend kTestBackend = {
   "oracle-test-backend (CPU, tests only)",
   t_device_count, t_malloc, t_free, t_malloc, t_free, t_memcpy, t_memset, t_sync,
   t_ipc_get, t_ipc_open, t_ipc_close, t_host_register, t_host_unregister,
-  t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_rr, t_fill,
+  t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_long_ws, t_rr, t_fill,
 };
 
 }  // namespace

@@ -68,6 +68,8 @@ struct wm_optimizer_args {
   float* per_row_state;        // adam: [rows, 2] (beta1^t, beta2^t); else nullptr
   float weight_decay, epsilon, beta1, beta2, alpha, lr;
   int adam_w;
+  void* long_run_ws;           // device scratch of long_run_workspace_bytes(n_recv) or nullptr (then every run is
+                               // folded by one wave)
 };
 
 struct wm_device_backend {
@@ -102,6 +104,7 @@ struct wm_device_backend {
   // fused duplicate-sum + optimizer update. a->count bounds the launch; when n_unique_dev != nullptr the true
   // number of unique ids is read from that device scalar (no host sync to learn it).
   int (*optimizer_step)(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);
+  size_t (*long_run_workspace_bytes)(int64_t n_recv);
   int (*round_robin_map)(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n,
                          int64_t entry_start, int world_size, int round_robin_size, void* stream);
   int (*fill_float)(float* p, float value, int64_t count, void* stream);

@@ -186,7 +186,7 @@ void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64
     if (n_unique_host) *n_unique_host = 0;
     return;
   }
-  temp_mem unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env), host_n(env);
+  temp_mem unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env), host_n(env), long_ws(env);
   void* d_unique  = unique_ids.device(n_recv, index_dtype);
   auto* d_starts  = static_cast<int32_t*>(run_starts.device(n_recv + 1, WHOLEMEMORY_DT_INT));
   auto* d_order   = static_cast<int32_t*>(order.device(n_recv, WHOLEMEMORY_DT_INT));
@@ -202,6 +202,7 @@ void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64
   oa->grads       = recv_grads;
   oa->grad_stride = grad_stride;
   oa->count       = n_recv;  // upper bound; the kernel reads the true count from d_nunique
+  oa->long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n_recv)), WHOLEMEMORY_DT_INT8);
   rc              = bk->optimizer_step(oa, d_nunique, stream);
   if (rc != 0) throw hip_error("optimizer_step failed");
   if (n_unique_host != nullptr) {
@@ -245,28 +246,52 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   const char* idx_ptr = static_cast<const char*>(wholememory_tensor_get_data_pointer(indices));  // data ptr already offset
 
   id_exchange x(env);
-  bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x);
+  bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x, true);
   (void)ies;
+  const int rank = e->comm->world_rank;
 
-  // gradient rows in send order, then to their owners (embedding.cpp:205-246)
-  temp_mem send_rows(env), recv_rows(env);
-  auto* send_buf = static_cast<float*>(send_rows.device(dim * x.total_send, WHOLEMEMORY_DT_FLOAT));
-  auto* recv_buf = static_cast<float*>(recv_rows.device(dim * x.total_recv, WHOLEMEMORY_DT_FLOAT));
-  wm_rows_args ga{};
-  ga.gref                 = wholememory_create_continuous_global_reference(wholememory_tensor_get_data_pointer(grads));
-  ga.table_dtype          = WHOLEMEMORY_DT_FLOAT;
-  ga.dim                  = dim;
-  ga.table_stride         = gmat.stride;
-  ga.table_storage_offset = 0;  // data pointer already carries the view offset
-  ga.indices              = x.raw_indices;
-  ga.index_dtype          = WHOLEMEMORY_DT_INT64;
-  ga.n                    = x.total_send;
-  ga.plain                = send_buf;
-  ga.plain_dtype          = WHOLEMEMORY_DT_FLOAT;
-  ga.plain_stride         = dim;
-  ga.max_blocks           = -1;
-  WM_BK(bk->gather_rows(&ga, stream));
-  exchange_rows(e->comm, send_buf, x.send_counts, recv_buf, x.recv_counts, static_cast<size_t>(dim) * sizeof(float), stream);
+  // The owner needs ids and gradient rows of ALL requesters in rank-major receive order (that order defines
+  // the fp32 summation order of duplicates). Peers' rows arrive by all-to-all-v; this rank's own rows are
+  // written straight into their slot of the receive buffers (no send staging, no self copy).
+  std::vector<int64_t> full_recv_counts = x.recv_counts, full_recv_offsets(e->comm->world_size + 1, 0);
+  full_recv_counts[rank]                = x.self_count;
+  for (int i = 0; i < e->comm->world_size; i++) full_recv_offsets[i + 1] = full_recv_offsets[i] + full_recv_counts[i];
+  const int64_t n_recv = full_recv_offsets[e->comm->world_size];
+
+  temp_mem send_rows(env), recv_rows(env), recv_ids_mem(env);
+  auto* send_buf = static_cast<float*>(send_rows.device(dim * x.total_valid, WHOLEMEMORY_DT_FLOAT));
+  auto* recv_buf = static_cast<float*>(recv_rows.device(dim * n_recv, WHOLEMEMORY_DT_FLOAT));
+  char* recv_ids = static_cast<char*>(recv_ids_mem.device(n_recv, iarr.dtype));
+  // ids: peers' segments were received compactly (self cut out) — place them around the self slot
+  for (int r = 0; r < e->comm->world_size; r++) {
+    const char* src = r == rank ? static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset
+                                : static_cast<const char*>(x.recv_ids) + ies * x.recv_offsets[r];
+    if (full_recv_counts[r] > 0)
+      WM_BK(bk->memcpy_async(recv_ids + ies * full_recv_offsets[r], src, ies * full_recv_counts[r], stream));
+  }
+  // gradient rows in bucketed order: remote segments into the send buffer, the self segment into recv_buf
+  const auto grads_gref = wholememory_create_continuous_global_reference(wholememory_tensor_get_data_pointer(grads));
+  auto launch_rows = [&](int64_t s0, int64_t s1, float* dst) {
+    if (s1 <= s0) return;
+    wm_rows_args ga{};
+    ga.gref         = grads_gref;
+    ga.table_dtype  = WHOLEMEMORY_DT_FLOAT;
+    ga.dim          = dim;
+    ga.table_stride = gmat.stride;
+    ga.indices      = x.raw_indices + s0;
+    ga.index_dtype  = WHOLEMEMORY_DT_INT64;
+    ga.n            = s1 - s0;
+    ga.plain        = dst;
+    ga.plain_dtype  = WHOLEMEMORY_DT_FLOAT;
+    ga.plain_stride = dim;
+    ga.max_blocks   = -1;
+    WM_BK(bk->gather_rows(&ga, stream));
+  };
+  launch_rows(0, x.self_offset, send_buf);
+  launch_rows(x.self_offset + x.self_count, x.total_valid, send_buf + (x.self_offset + x.self_count) * dim);
+  launch_rows(x.self_offset, x.self_offset + x.self_count, recv_buf + full_recv_offsets[rank] * dim);
+  exchange_segments(e->comm, send_buf, x.send_counts, x.bucket_offsets, recv_buf, x.recv_counts, full_recv_offsets,
+                    static_cast<size_t>(dim) * sizeof(float), stream);
 
   // owner: fused dedup + step on the local shard (embedding.cpp:248-318)
   wholememory_tensor_t local_table;
@@ -284,7 +309,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   if (e->per_row_local != nullptr)
     oa.per_row_state = static_cast<float*>(wholememory_tensor_get_data_pointer(e->per_row_local));
   wholememory_destroy_tensor(local_table);
-  dedup_and_step(x.recv_ids, iarr.dtype, x.total_recv, recv_buf, dim, &oa,
+  dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa,
                  static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr);
   // temporaries go back to the caller's allocator on return; like the reference's distributed ops
   // the stream is drained first so nothing in flight still reads them

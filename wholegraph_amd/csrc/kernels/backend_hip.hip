@@ -15,6 +15,7 @@ int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, i
                   void* unique_ids, int32_t* run_starts, int32_t* order, int64_t* n_unique_out, void* workspace,
                   void* stream);
 int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);
+size_t hip_long_run_ws_bytes(int64_t n_recv);
 int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n, int64_t entry_start,
                         int world_size, int round_robin_size, void* stream);
 int hip_fill_float(float* p, float value, int64_t count, void* stream);
@@ -90,6 +91,7 @@ const wm_device_backend kHipBackend = {
   hip_dedup_workspace_bytes,
   hip_dedup_ids,
   hip_optimizer_step_dev,
+  hip_long_run_ws_bytes,
   hip_round_robin_map,
   hip_fill_float,
 };

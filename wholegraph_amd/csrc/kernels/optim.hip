@@ -133,14 +133,84 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, void* unique_
 // ---------------------------------------------------------------------------------------------
 // fused duplicate-sum + optimizer step
 // ---------------------------------------------------------------------------------------------
+// Two kernels share the work by run length (a "run" = all received rows of one unique id, in receive order):
+//   step_short_kernel : one wave per run, for runs of <= kLongRun rows (the common case). Lanes own columns;
+//                       the duplicates are folded sequentially (first copied, the rest added one by one — the
+//                       reference order), up to 4 duplicate rows prefetched at a time. Longer runs are only
+//                       RECORDED here (device list) together with their LazyAdam beta powers.
+//   step_long_kernel  : one workgroup per (long run, 32-column slice). 256 threads stream the run's rows through
+//                       double-buffered LDS tiles (256 rows x 128 B, the next tile already in registers while the
+//                       current one is folded), 32 lanes fold their column sequentially out of LDS. Summation
+//                       order per element is still exactly the receive order, so results stay bit-identical; a
+//                       500 k-duplicate hot row (Zipf s = 1.05) costs milliseconds instead of ~0.5 s of dependent
+//                       global loads.
+constexpr int kLongRun   = 32;
+constexpr int kSliceCols = 32;    // 128 B of every row per long-run workgroup
+constexpr int kTileRows  = 256;   // rows per LDS tile (32 KiB), double buffered
+
+struct long_run_entry {
+  int32_t run;
+  float beta1t, beta2t;
+  int32_t pad;
+};
+
 struct opt_params {
   wm_optimizer_args a;
   const int64_t* n_unique;  // device scalar (or nullptr -> a.count)
+  long_run_entry* long_list;
+  int32_t* long_count;
 };
 
-template <typename IdxT, int OPT>
-__global__ __launch_bounds__(kBlock) void fused_dedup_step_kernel(opt_params p)
+// optimizer statement sequences of the reference kernels (embedding_optimizer_func.cu:212-223, 392-415,
+// 644-657, 842-855), one element
+template <int OPT>
+__device__ __forceinline__ void apply_optimizer(const wm_optimizer_args& a, int64_t local, int64_t d, float grad_value,
+                                                float beta1t, float beta2t)
 {
+  float* e_row          = a.local_table + local * a.table_stride;
+  float embedding_value = e_row[d];
+  if (OPT == WHOLEMEMORY_OPT_SGD) {
+    grad_value += a.weight_decay * embedding_value;
+    embedding_value -= a.lr * grad_value;
+  } else if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) {
+    float* m_ptr = a.per_element_state + local * a.per_element_stride;
+    float* v_ptr = m_ptr + a.table_stride;
+    if (a.adam_w) {
+      embedding_value -= a.lr * a.weight_decay * embedding_value;
+    } else {
+      grad_value = grad_value + a.weight_decay * embedding_value;
+    }
+    float m         = m_ptr[d];
+    float v         = v_ptr[d];
+    m               = a.beta1 * m + (1 - a.beta1) * grad_value;
+    v               = a.beta2 * v + (1 - a.beta2) * grad_value * grad_value;
+    float mhat      = m / (1 - beta1t);
+    float vhat      = v / (1 - beta2t);
+    embedding_value = embedding_value - a.lr * mhat / (sqrtf(vhat) + a.epsilon);
+    m_ptr[d]        = m;
+    v_ptr[d]        = v;
+  } else if (OPT == WHOLEMEMORY_OPT_ADAGRAD) {
+    float* s_ptr    = a.per_element_state + local * a.per_element_stride;
+    grad_value      = grad_value + a.weight_decay * embedding_value;
+    float state_sum = s_ptr[d];
+    state_sum       = state_sum + grad_value * grad_value;
+    embedding_value = embedding_value - a.lr * grad_value / (sqrtf(state_sum) + a.epsilon);
+    s_ptr[d]        = state_sum;
+  } else if (OPT == WHOLEMEMORY_OPT_RMSPROP) {
+    float* v_ptr    = a.per_element_state + local * a.per_element_stride;
+    grad_value      = grad_value + a.weight_decay * embedding_value;
+    float v         = v_ptr[d];
+    v               = a.alpha * v + (1 - a.alpha) * grad_value * grad_value;
+    embedding_value = embedding_value - a.lr * grad_value / (sqrtf(v) + a.epsilon);
+    v_ptr[d]        = v;
+  }
+  e_row[d] = embedding_value;
+}
+
+template <typename IdxT, int OPT, int V>
+__global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
+{
+  typedef float vec_t __attribute__((ext_vector_type(V)));
   const wm_optimizer_args& a = p.a;
   const int lane             = threadIdx.x & 63;
   const int64_t wave         = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
@@ -152,83 +222,152 @@ __global__ __launch_bounds__(kBlock) void fused_dedup_step_kernel(opt_params p)
     const int64_t local = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
     const int32_t s0    = a.run_starts[u];
     const int32_t s1    = a.run_starts[u + 1];
-    float* e_row        = a.local_table + local * a.table_stride;
     float beta1t = 0.f, beta2t = 0.f;
     if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) {
       beta1t = a.per_row_state[local * 2 + 0] * a.beta1;
       beta2t = a.per_row_state[local * 2 + 1] * a.beta2;
-    }
-    for (int64_t d = lane; d < a.dim; d += 64) {
-      // reference DedupIndiceAndGradientsKernel: first occurrence copied, later ones added in order
-      float grad_value = a.grads[static_cast<int64_t>(a.order[s0]) * a.grad_stride + d];
-      for (int32_t j = s0 + 1; j < s1; j++) grad_value += a.grads[static_cast<int64_t>(a.order[j]) * a.grad_stride + d];
-      float embedding_value = e_row[d];
-      if (OPT == WHOLEMEMORY_OPT_SGD) {
-        grad_value += a.weight_decay * embedding_value;
-        embedding_value -= a.lr * grad_value;
-      } else if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) {
-        float* m_ptr = a.per_element_state + local * a.per_element_stride;
-        float* v_ptr = m_ptr + a.table_stride;
-        if (a.adam_w) {
-          embedding_value -= a.lr * a.weight_decay * embedding_value;
-        } else {
-          grad_value = grad_value + a.weight_decay * embedding_value;
-        }
-        float m         = m_ptr[d];
-        float v         = v_ptr[d];
-        m               = a.beta1 * m + (1 - a.beta1) * grad_value;
-        v               = a.beta2 * v + (1 - a.beta2) * grad_value * grad_value;
-        float mhat      = m / (1 - beta1t);
-        float vhat      = v / (1 - beta2t);
-        embedding_value = embedding_value - a.lr * mhat / (sqrtf(vhat) + a.epsilon);
-        m_ptr[d]        = m;
-        v_ptr[d]        = v;
-      } else if (OPT == WHOLEMEMORY_OPT_ADAGRAD) {
-        float* s_ptr    = a.per_element_state + local * a.per_element_stride;
-        grad_value      = grad_value + a.weight_decay * embedding_value;
-        float state_sum = s_ptr[d];
-        state_sum       = state_sum + grad_value * grad_value;
-        embedding_value = embedding_value - a.lr * grad_value / (sqrtf(state_sum) + a.epsilon);
-        s_ptr[d]        = state_sum;
-      } else if (OPT == WHOLEMEMORY_OPT_RMSPROP) {
-        float* v_ptr    = a.per_element_state + local * a.per_element_stride;
-        grad_value      = grad_value + a.weight_decay * embedding_value;
-        float v         = v_ptr[d];
-        v               = a.alpha * v + (1 - a.alpha) * grad_value * grad_value;
-        embedding_value = embedding_value - a.lr * grad_value / (sqrtf(v) + a.epsilon);
-        v_ptr[d]        = v;
+      if (lane == 0) {  // every lane has read the old values (same wave, program order) before this store
+        a.per_row_state[local * 2 + 0] = beta1t;
+        a.per_row_state[local * 2 + 1] = beta2t;
       }
-      e_row[d] = embedding_value;
     }
-    if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM && lane == 0) {
-      a.per_row_state[local * 2 + 0] = beta1t;
-      a.per_row_state[local * 2 + 1] = beta2t;
+    if (p.long_list != nullptr && s1 - s0 > kLongRun) {
+      if (lane == 0) {
+        int slot          = atomicAdd(p.long_count, 1);
+        p.long_list[slot] = long_run_entry{static_cast<int32_t>(u), beta1t, beta2t, 0};
+      }
+      continue;
+    }
+    for (int64_t d = static_cast<int64_t>(lane) * V; d < a.dim; d += 64 * V) {
+      // first occurrence copied, later ones added in receive order (DedupIndiceAndGradientsKernel).
+      // Loads are unconditional (index clamped to the run) so they all issue before the first add.
+      vec_t acc = *reinterpret_cast<const vec_t*>(a.grads + static_cast<int64_t>(a.order[s0]) * a.grad_stride + d);
+      for (int32_t j = s0 + 1; j < s1; j += 4) {
+        int32_t o[4];
+        vec_t g[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = a.order[min(j + k, s1 - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          g[k] = *reinterpret_cast<const vec_t*>(a.grads + static_cast<int64_t>(o[k]) * a.grad_stride + d);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (j + k < s1) acc += g[k];
+      }
+#pragma unroll
+      for (int v = 0; v < V; v++) apply_optimizer<OPT>(a, local, d + v, acc[v], beta1t, beta2t);
     }
   }
+}
+
+template <typename IdxT, int OPT, bool VEC4>
+__global__ __launch_bounds__(kBlock) void step_long_kernel(opt_params p)
+{
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float tile[2][kTileRows * kSliceCols];
+  const wm_optimizer_args& a = p.a;
+  const int n_long           = *p.long_count;
+  const IdxT* ids            = static_cast<const IdxT*>(a.ids);
+  const int col0             = blockIdx.y * kSliceCols;
+  const int cols             = min(kSliceCols, static_cast<int>(a.dim) - col0);
+  // a tile is kTileRows x 32 floats. Scalar mapping: thread -> (row t/32 + 8 i, column t%32), 32 loads per thread.
+  // Vector mapping (16-byte aligned rows): thread -> (row t/8 + 32 i, float4 t%8), 8 loads per thread.
+  constexpr int kLoads  = VEC4 ? kTileRows * kSliceCols / 4 / kBlock : kTileRows * kSliceCols / kBlock;
+  constexpr int kRowStep = VEC4 ? kBlock / (kSliceCols / 4) : kBlock / kSliceCols;
+  const int c_ld = VEC4 ? (threadIdx.x & 7) * 4 : (threadIdx.x & (kSliceCols - 1));
+  const int r_ld = VEC4 ? (threadIdx.x >> 3) : (threadIdx.x >> 5);
+  const int c_cl = VEC4 ? c_ld : min(c_ld, cols - 1);  // VEC4 is only chosen when every slice is full
+
+  for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
+    const long_run_entry ent = p.long_list[li];
+    const int64_t u          = ent.run;
+    const int64_t local      = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
+    const int32_t s0         = a.run_starts[u];
+    const int32_t s1         = a.run_starts[u + 1];
+    float acc                = 0.f;
+    typename std::conditional<VEC4, f4, float>::type stage[kLoads];
+    // unconditional loads (row index clamped into the run): all row addresses first, then all rows
+    auto load_tile = [&](int32_t base) {
+      int32_t o[kLoads];
+#pragma unroll
+      for (int i = 0; i < kLoads; i++) o[i] = a.order[min(base + r_ld + kRowStep * i, s1 - 1)];
+#pragma unroll
+      for (int i = 0; i < kLoads; i++) {
+        const float* src = a.grads + static_cast<int64_t>(o[i]) * a.grad_stride + col0 + c_cl;
+        if constexpr (VEC4)
+          stage[i] = *reinterpret_cast<const f4*>(src);
+        else
+          stage[i] = *src;
+      }
+    };
+    load_tile(s0);
+    int buf = 0;
+    for (int32_t base = s0; base < s1; base += kTileRows) {
+#pragma unroll
+      for (int i = 0; i < kLoads; i++) {
+        float* dst = &tile[buf][(r_ld + kRowStep * i) * kSliceCols + c_ld];
+        if constexpr (VEC4)
+          *reinterpret_cast<f4*>(dst) = stage[i];
+        else
+          *dst = stage[i];
+      }
+      __syncthreads();
+      if (base + kTileRows < s1) load_tile(base + kTileRows);  // in flight while this tile is folded
+      if (threadIdx.x < cols) {
+        const int32_t rows = min(kTileRows, s1 - base);
+        int32_t r          = 0;
+        if (base == s0) {
+          acc = tile[buf][threadIdx.x];  // first occurrence is copied, not added to 0
+          r   = 1;
+        }
+        // 16 LDS reads are issued back to back, then folded one by one: the add chain (not the LDS
+        // latency) is what paces a long run
+        for (; r < rows; r += 16) {
+          float v[16];
+#pragma unroll
+          for (int k = 0; k < 16; k++) v[k] = tile[buf][min(r + k, kTileRows - 1) * kSliceCols + threadIdx.x];
+#pragma unroll
+          for (int k = 0; k < 16; k++)
+            if (r + k < rows) acc += v[k];
+        }
+      }
+      buf ^= 1;  // the other buffer was last read before the previous barrier: safe to overwrite
+    }
+    if (threadIdx.x < cols) apply_optimizer<OPT>(a, local, col0 + threadIdx.x, acc, ent.beta1t, ent.beta2t);
+    __syncthreads();
+  }
+}
+
+template <typename IdxT, int OPT>
+int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream)
+{
+  const uint64_t gaddr = reinterpret_cast<uint64_t>(p.a.grads);
+  const bool vec2      = p.a.dim % 2 == 0 && p.a.grad_stride % 2 == 0 && gaddr % 8 == 0;
+  if (vec2)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 2>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  else
+    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  if (p.long_list != nullptr) {
+    const int slices = static_cast<int>((p.a.dim + kSliceCols - 1) / kSliceCols);
+    const bool vec4  = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0;
+    if (vec4)
+      hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, true>), dim3(1024, slices), dim3(kBlock), 0, stream, p);
+    else
+      hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, false>), dim3(1024, slices), dim3(kBlock), 0, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <typename IdxT>
 int launch_step(const opt_params& p, int blocks, hipStream_t stream)
 {
   switch (p.a.type) {
-    case WHOLEMEMORY_OPT_SGD:
-      hipLaunchKernelGGL((fused_dedup_step_kernel<IdxT, WHOLEMEMORY_OPT_SGD>), dim3(blocks), dim3(kBlock), 0, stream, p);
-      break;
-    case WHOLEMEMORY_OPT_LAZY_ADAM:
-      hipLaunchKernelGGL((fused_dedup_step_kernel<IdxT, WHOLEMEMORY_OPT_LAZY_ADAM>), dim3(blocks), dim3(kBlock), 0,
-                         stream, p);
-      break;
-    case WHOLEMEMORY_OPT_ADAGRAD:
-      hipLaunchKernelGGL((fused_dedup_step_kernel<IdxT, WHOLEMEMORY_OPT_ADAGRAD>), dim3(blocks), dim3(kBlock), 0,
-                         stream, p);
-      break;
-    case WHOLEMEMORY_OPT_RMSPROP:
-      hipLaunchKernelGGL((fused_dedup_step_kernel<IdxT, WHOLEMEMORY_OPT_RMSPROP>), dim3(blocks), dim3(kBlock), 0,
-                         stream, p);
-      break;
+    case WHOLEMEMORY_OPT_SGD: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_SGD>(p, blocks, stream);
+    case WHOLEMEMORY_OPT_LAZY_ADAM: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_LAZY_ADAM>(p, blocks, stream);
+    case WHOLEMEMORY_OPT_ADAGRAD: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_ADAGRAD>(p, blocks, stream);
+    case WHOLEMEMORY_OPT_RMSPROP: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_RMSPROP>(p, blocks, stream);
     default: return -1;
   }
-  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <typename IdxT>
@@ -274,13 +413,21 @@ int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, i
   return -1;
 }
 
+size_t hip_long_run_ws_bytes(int64_t n_recv) { return 16 + sizeof(long_run_entry) * static_cast<size_t>(n_recv / (kLongRun + 1) + 2); }
+
 // a->count is an UPPER BOUND for the launch geometry; the true run count is read on the device from
 // a->run_starts' companion scalar when `n_unique_dev` is non-null (ids == unique ids from hip_dedup_ids).
 int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (a->count == 0) return 0;
-  opt_params p{*a, n_unique_dev};
+  opt_params p{*a, n_unique_dev, nullptr, nullptr};
+  if (a->long_run_ws != nullptr && a->dim <= 65535 * kSliceCols) {
+    // [int32 counter | pad to 16 B | entries]; at most count / (kLongRun + 1) long runs can exist
+    p.long_count = static_cast<int32_t*>(a->long_run_ws);
+    p.long_list  = reinterpret_cast<long_run_entry*>(static_cast<char*>(a->long_run_ws) + 16);
+    if (hipMemsetAsync(p.long_count, 0, 16, stream) != hipSuccess) return -2;
+  }
   int64_t waves = a->count;
   int blocks    = static_cast<int>(std::min<int64_t>((waves + 3) / 4, 256 * 8));
   if (blocks < 1) blocks = 1;

@@ -173,8 +173,9 @@ class WholeMemoryEmbedding(object):
         self.sparse_grads.append(grad_outputs)
 
     def apply_gradients(self, lr: float):
-        sparse_indices = torch.cat(self.sparse_indices)
-        sparse_grads = torch.cat(self.sparse_grads).contiguous()
+        # (a single pending batch is used as is: torch.cat would copy the whole gradient matrix)
+        sparse_indices = self.sparse_indices[0] if len(self.sparse_indices) == 1 else torch.cat(self.sparse_indices)
+        sparse_grads = (self.sparse_grads[0] if len(self.sparse_grads) == 1 else torch.cat(self.sparse_grads)).contiguous()
         wi, wg = wrap_torch_tensor(sparse_indices), wrap_torch_tensor(sparse_grads)
         wmb.check(wmb.lib().wholememory_embedding_gather_gradient_apply(
             self.wmb_embedding, wi.handle, wg.handle, self.adjust_cache, lr, get_wholegraph_env_fns(), get_stream()))
