@@ -102,7 +102,8 @@ def main():
     torch.cuda.set_device(local_rank)
     import wholegraph_amd.torch as wgth
     from wholegraph_amd import binding as wmb
-    if world > 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # under torch.distributed.run (any N)
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
         torch.distributed.init_process_group(backend="nccl", init_method="env://")
@@ -124,7 +125,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if launched:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -166,7 +167,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     dt = torch.tensor([t1 - t0], device="cuda", dtype=torch.float64)
-    if world > 1:
+    if launched:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     wall = float(dt.item())
     dev_ms = ev0.elapsed_time(ev1) / a.steps  # HIP events on the stream the kernels were launched on
@@ -210,7 +211,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(a.dim, a.cpu_seconds)
         print(json.dumps(res))
     wgth.destroy_embedding(emb)
-    if world > 1:
+    if launched:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -181,12 +181,12 @@ int next_comm_id()
 // ------------------------------------------------------------------------------------------------
 void wholememory_comm_::barrier()
 {
-  if (world_size > 1) transport->barrier();
+  if (transport) transport->barrier();
 }
 
 void wholememory_comm_::allgather_host(const void* send, void* recv, size_t bytes)
 {
-  if (world_size == 1) {
+  if (!transport) {
     memcpy(recv, send, bytes);
     return;
   }
@@ -195,7 +195,7 @@ void wholememory_comm_::allgather_host(const void* send, void* recv, size_t byte
 
 void wholememory_comm_::alltoall_host_i64(const int64_t* send, int64_t* recv)
 {
-  if (world_size == 1) {
+  if (!transport) {
     recv[0] = send[0];
     return;
   }
@@ -208,7 +208,7 @@ void wholememory_comm_::alltoall_host_i64(const int64_t* send, int64_t* recv)
 void wholememory_comm_::alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp,
                                          void* recv, const size_t* recv_bytes, const size_t* recv_disp, void* stream)
 {
-  if (world_size == 1) {
+  if (!transport) {
     if (send_bytes[0] > 0) {
       int rc = wm::backend()->memcpy_async(static_cast<char*>(recv) + recv_disp[0],
                                            static_cast<const char*>(send) + send_disp[0], send_bytes[0], stream);
@@ -247,7 +247,10 @@ wholememory_error_code_t wholememory_create_communicator(wholememory_comm_t* com
   c->world_size = size;
   c->local_size = size;
   c->comm_id    = wm::next_comm_id();
-  if (size > 1) {
+  // WM_FORCE_RCCL=1 builds the RCCL transport even for a single rank (bring-up / smoke testing of the RCCL
+  // plumbing on a one-GPU box); normally a single-rank communicator needs no transport at all.
+  const char* force = getenv("WM_FORCE_RCCL");
+  if (size > 1 || (force != nullptr && force[0] == '1')) {
     ncclUniqueId id;
     memcpy(&id, unique_id.internal, sizeof(id));
     ncclComm_t nc = nullptr;

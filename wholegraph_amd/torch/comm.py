@@ -210,7 +210,8 @@ def create_group_communicator(group_size=-1, comm_stride=1):
     idx_in_group = idx_in_strided_group // comm_stride
     L = wmb.lib()
     comm = C.c_void_p()
-    if group_size == 1:
+    import os
+    if group_size == 1 and os.environ.get("WM_FORCE_RCCL") != "1":
         uid = wmb.UniqueId()
         wmb.check(L.wholememory_create_communicator(C.byref(comm), uid, 0, 1))
         return WholeMemoryCommunicator(comm)
