@@ -73,6 +73,18 @@ int t_memset(void* d, int v, size_t n, void*)
   return 0;
 }
 int t_sync(void*) { return 0; }
+int t_stream_create(void** s)
+{
+  *s = nullptr;  // everything is synchronous here: one "stream"
+  return 0;
+}
+int t_noop1(void*) { return 0; }
+int t_event_create(void** e)
+{
+  *e = nullptr;
+  return 0;
+}
+int t_noop2(void*, void*) { return 0; }
 int t_ipc_get(void*, void*) { return 1; }  // no cross-process mapping of malloc'ed "device" memory
 int t_ipc_open(void**, const void*) { return 1; }
 int t_ipc_close(void*) { return 1; }
@@ -239,6 +251,7 @@ int t_fill(float* p, float v, int64_t n, void*)
 const wm_device_backend kTestBackend = {
   "oracle-test-backend (CPU, tests only)",
   t_device_count, t_malloc, t_free, t_malloc, t_free, t_memcpy, t_memset, t_sync,
+  t_stream_create, t_noop1, t_event_create, t_noop1, t_noop2, t_noop2,
   t_ipc_get, t_ipc_open, t_ipc_close, t_host_register, t_host_unregister,
   t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_long_ws, t_rr, t_fill,
 };

@@ -41,17 +41,19 @@ def run_world(world, mode, extra_env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunks", ["1", "4"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_multi_rank_on_one_gpu_hip_kernels(wm_lib, world):
+def test_multi_rank_on_one_gpu_hip_kernels(wm_lib, world, chunks):
     """N processes sharing cuda:0: the real HIP kernels + the real multi-rank orchestration, hipIpc-mapped
     CHUNKED shards across processes, collectives over gloo (RCCL refuses two ranks on one device, and the
     test boxes have a single GPU)."""
-    run_world(world, "hip", {})
+    run_world(world, "hip", {"WM_EXCHANGE_CHUNKS": chunks})
 
 
+@pytest.mark.parametrize("chunks", ["1", "3"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_distributed_paths_over_gloo(wm_lib, world):
+def test_distributed_paths_over_gloo(wm_lib, world, chunks):
     tb = os.path.join(ROOT, "oracle", "libwm_test_backend.so")
     if not os.path.exists(tb):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "test_backend"])
-    run_world(world, "cpu", {"WHOLEGRAPH_AMD_TESTING": "1", "HIP_VISIBLE_DEVICES": ""})
+    run_world(world, "cpu", {"WHOLEGRAPH_AMD_TESTING": "1", "HIP_VISIBLE_DEVICES": "", "WM_EXCHANGE_CHUNKS": chunks})

@@ -83,6 +83,13 @@ struct wm_device_backend {
   int (*memcpy_async)(void* dst, const void* src, size_t bytes, void* stream);  // any direction (UVA)
   int (*memset_async)(void* dst, int value, size_t bytes, void* stream);
   int (*stream_sync)(void* stream);
+  // side stream + events (overlap of the all-to-all-v with local kernels)
+  int (*stream_create)(void** stream);
+  int (*stream_destroy)(void* stream);
+  int (*event_create)(void** event);
+  int (*event_destroy)(void* event);
+  int (*event_record)(void* event, void* stream);
+  int (*stream_wait_event)(void* stream, void* event);
   // cross-process mapping of device allocations (hipIpc*): handle is 64 opaque bytes
   int (*ipc_get_handle)(void* handle64, void* dev_ptr);
   int (*ipc_open_handle)(void** dev_ptr, const void* handle64);

@@ -179,6 +179,19 @@ int next_comm_id()
 }  // namespace wm
 
 // ------------------------------------------------------------------------------------------------
+void* wholememory_comm_::get_side_stream()
+{
+  if (side_stream == nullptr) {
+    if (wm::backend()->stream_create(&side_stream) != 0) throw wm::hip_error("cannot create the exchange side stream");
+  }
+  return side_stream;
+}
+
+wholememory_comm_::~wholememory_comm_()
+{
+  if (side_stream != nullptr) wm::backend()->stream_destroy(side_stream);
+}
+
 void wholememory_comm_::barrier()
 {
   if (transport) transport->barrier();

@@ -40,6 +40,9 @@ struct wholememory_comm_ {
   std::unique_ptr<wm::collective_provider> transport;  // null when world_size == 1
   std::mutex mu;                                       // guards handle create/destroy (reference communicator.hpp:226)
   int live_handles = 0;
+  void* side_stream = nullptr;                         // lazily created: carries the chunked all-to-all-v
+  void* get_side_stream();
+  ~wholememory_comm_();
 
   void barrier();
   void allgather_host(const void* send, void* recv, size_t bytes);

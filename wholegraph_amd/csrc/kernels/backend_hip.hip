@@ -43,6 +43,27 @@ int h_memset_async(void* dst, int value, size_t bytes, void* stream)
   return rc(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));
 }
 int h_stream_sync(void* stream) { return rc(hipStreamSynchronize(static_cast<hipStream_t>(stream))); }
+int h_stream_create(void** s)
+{
+  hipStream_t st;
+  hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  *s           = st;
+  return rc(e);
+}
+int h_stream_destroy(void* s) { return rc(hipStreamDestroy(static_cast<hipStream_t>(s))); }
+int h_event_create(void** ev)
+{
+  hipEvent_t e;
+  hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  *ev          = e;
+  return rc(r);
+}
+int h_event_destroy(void* ev) { return rc(hipEventDestroy(static_cast<hipEvent_t>(ev))); }
+int h_event_record(void* ev, void* s) { return rc(hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(s))); }
+int h_stream_wait_event(void* s, void* ev)
+{
+  return rc(hipStreamWaitEvent(static_cast<hipStream_t>(s), static_cast<hipEvent_t>(ev), 0));
+}
 static_assert(sizeof(hipIpcMemHandle_t) <= 64, "ipc handle does not fit the 64-byte slot");
 int h_ipc_get(void* handle64, void* dev_ptr)
 {
@@ -79,6 +100,12 @@ const wm_device_backend kHipBackend = {
   h_memcpy_async,
   h_memset_async,
   h_stream_sync,
+  h_stream_create,
+  h_stream_destroy,
+  h_event_create,
+  h_event_destroy,
+  h_event_record,
+  h_stream_wait_event,
   h_ipc_get,
   h_ipc_open,
   h_ipc_close,

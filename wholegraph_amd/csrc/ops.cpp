@@ -17,6 +17,8 @@
 // with a stream synchronise like the reference (scatter_op_impl_nccl.cu:168).
 #include "ops_internal.hpp"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace wm {
@@ -168,6 +170,26 @@ wholememory_gref_t local_shard_gref(wholememory_handle_t handle)
   return wholememory_create_continuous_global_reference(static_cast<char*>(p) - off);
 }
 
+int exchange_chunks(int world_size, int64_t rows_moved)
+{
+  if (world_size <= 1) return 1;
+  const char* e = getenv("WM_EXCHANGE_CHUNKS");
+  if (e != nullptr && atoi(e) >= 1) return std::min(atoi(e), 16);
+  // below ~256 k rows the exchange is latency-bound and extra launches only add overhead
+  return rows_moved >= (1 << 18) ? 4 : 1;
+}
+
+event_set::event_set(int n) : events_(n, nullptr)
+{
+  for (auto& e : events_)
+    if (backend()->event_create(&e) != 0) throw hip_error("event_create failed");
+}
+event_set::~event_set()
+{
+  for (auto e : events_)
+    if (e != nullptr) backend()->event_destroy(e);
+}
+
 namespace {
 
 struct op_descs {
@@ -303,35 +325,87 @@ wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const o
     WM_BK(bk->gather_rows(&sa, stream));
   }
 
-  // (b) owner side for the peers: rows of the received ids, already in the output dtype
-  //     (gather_op_impl_nccl.cu:115-140), lined up in send order
+  // (b)-(d) the peers' rows, pipelined in C row-chunks so the three legs overlap:
+  //   G_c  owner side: gather chunk c of every peer's requested rows into the send buffer, already cast to the
+  //        output dtype (gather_op_impl_nccl.cu:115-140)                                — HBM, caller's stream
+  //   A_c  rows all-to-all-v of chunk c (gather_op_impl_nccl.cu:141-150)                 — xGMI, side stream
+  //   R_c  reorder on receive: out[raw_indices[j]] = recv[j] (gather_op_impl_nccl.cu:151-168) — HBM, caller's stream
+  // issue order on the caller's stream: G_0 G_1 R_0 G_2 R_1 ... so that G_{c+1} and R_{c-1} run while A_c is on the
+  // links. Chunk c of a segment of n rows is [n*c/C, n*(c+1)/C) on both ends of a pair, so sizes always match.
   temp_mem local_rows(env), recv_rows(env);
-  void* local_buf = local_rows.device(dim * x.total_recv, d.plain.dtype);
-  void* recv_buf  = recv_rows.device(dim * x.total_valid, d.plain.dtype);  // bucketed layout (self segment unused)
-  int64_t lsz[2]  = {x.total_recv, dim};
-  auto local_desc = wholememory_create_matrix_desc(lsz, dim, 0, d.plain.dtype);
-  wm_rows_args ga{};
-  fill_rows_args(&ga, local_gref, d.table, x.recv_ids, d.indices.dtype, x.total_recv, local_buf, local_desc, gather_sms);
-  WM_BK(bk->gather_rows(&ga, stream));
-  if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+  char* local_buf = static_cast<char*>(local_rows.device(dim * x.total_recv, d.plain.dtype));
+  char* recv_buf  = static_cast<char*>(recv_rows.device(dim * x.total_valid, d.plain.dtype));  // bucketed layout
+  const size_t row_bytes = static_cast<size_t>(dim) * oes;
+  const int W            = comm->world_size;
+  const int rank         = comm->world_rank;
+  const int C            = exchange_chunks(W, x.total_recv + x.total_send);
+  const auto out_gref    = wholememory_create_continuous_global_reference(d.plain_ptr);
+  auto chunk_of = [C](int64_t n, int c, int64_t* a, int64_t* b) {
+    *a = n * c / C;
+    *b = n * (c + 1) / C;
+  };
+  auto gather_chunk = [&](int c) {
+    for (int p = 0; p < W; p++) {
+      int64_t a, b;
+      chunk_of(x.recv_counts[p], c, &a, &b);
+      if (b <= a) continue;
+      const int64_t first = x.recv_offsets[p] + a;
+      int64_t lsz[2]      = {b - a, dim};
+      auto local_desc     = wholememory_create_matrix_desc(lsz, dim, 0, d.plain.dtype);
+      wm_rows_args ga{};
+      fill_rows_args(&ga, local_gref, d.table, static_cast<const char*>(x.recv_ids) + ies * first, d.indices.dtype, b - a,
+                     local_buf + row_bytes * first, local_desc, gather_sms);
+      WM_BK(bk->gather_rows(&ga, stream));
+    }
+  };
+  auto exchange_chunk = [&](int c, void* on_stream) {
+    std::vector<int64_t> sc(W), so(W), rc(W), ro(W);
+    for (int p = 0; p < W; p++) {
+      int64_t a, b;
+      chunk_of(x.recv_counts[p], c, &a, &b);  // what this rank serves to p
+      sc[p] = b - a, so[p] = x.recv_offsets[p] + a;
+      chunk_of(x.send_counts[p], c, &a, &b);  // what p serves to this rank
+      rc[p] = b - a, ro[p] = x.bucket_offsets[p] + a;
+    }
+    exchange_segments(comm, local_buf, sc, so, recv_buf, rc, ro, row_bytes, on_stream);
+  };
+  auto reorder_chunk = [&](int c) {
+    for (int p = 0; p < W; p++) {
+      if (p == rank) continue;
+      int64_t a, b;
+      chunk_of(x.send_counts[p], c, &a, &b);
+      if (b <= a) continue;
+      const int64_t first = x.bucket_offsets[p] + a;
+      int64_t rsz[2]      = {b - a, dim};
+      auto recv_desc      = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
+      wm_rows_args ra{};
+      fill_rows_args(&ra, out_gref, d.plain, x.raw_indices + first, WHOLEMEMORY_DT_INT64, b - a,
+                     recv_buf + row_bytes * first, recv_desc, -1);
+      WM_BK(bk->scatter_rows(&ra, stream));
+    }
+  };
 
-  // (c) rows travel back along the reverse of the id exchange (gather_op_impl_nccl.cu:141-150) and land at
-  //     their bucketed positions
-  exchange_segments(comm, local_buf, x.recv_counts, x.recv_offsets, recv_buf, x.send_counts, x.bucket_offsets,
-                    static_cast<size_t>(dim) * oes, stream);
-
-  // (d) reorder on receive: out[raw_indices[j]] = recv[j] for the remote segments (gather_op_impl_nccl.cu:151-168)
-  const auto out_gref = wholememory_create_continuous_global_reference(d.plain_ptr);
-  for (int seg = 0; seg < 2; seg++) {  // [0, self_offset) and [self_offset + self_count, total_valid)
-    const int64_t s0 = seg == 0 ? 0 : x.self_offset + x.self_count;
-    const int64_t s1 = seg == 0 ? x.self_offset : x.total_valid;
-    if (s1 <= s0) continue;
-    int64_t rsz[2] = {s1 - s0, dim};
-    auto recv_desc = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
-    wm_rows_args ra{};
-    fill_rows_args(&ra, out_gref, d.plain, x.raw_indices + s0, WHOLEMEMORY_DT_INT64, s1 - s0,
-                   static_cast<char*>(recv_buf) + static_cast<size_t>(s0) * dim * oes, recv_desc, -1);
-    WM_BK(bk->scatter_rows(&ra, stream));
+  if (C == 1) {
+    gather_chunk(0);
+    if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+    exchange_chunk(0, stream);
+    reorder_chunk(0);
+  } else {
+    void* side = comm->get_side_stream();
+    event_set gathered(C), arrived(C);
+    for (int c = 0; c < C; c++) {
+      gather_chunk(c);
+      WM_BK(bk->event_record(gathered[c], stream));
+      WM_BK(bk->stream_wait_event(side, gathered[c]));
+      exchange_chunk(c, side);
+      WM_BK(bk->event_record(arrived[c], side));
+      if (c >= 1) {
+        WM_BK(bk->stream_wait_event(stream, arrived[c - 1]));
+        reorder_chunk(c - 1);
+      }
+    }
+    WM_BK(bk->stream_wait_event(stream, arrived[C - 1]));  // also orders every side-stream access to the
+    reorder_chunk(C - 1);                                   // scratch buffers before anything later on `stream`
   }
   if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
   return WHOLEMEMORY_SUCCESS;

@@ -63,6 +63,20 @@ void exchange_segments(wholememory_comm_t comm, const void* send, const std::vec
 void exchange_rows(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts, void* recv,
                    const std::vector<int64_t>& recv_counts, size_t row_bytes, void* stream);
 
+// number of row-chunks the rows all-to-all-v is pipelined in (WM_EXCHANGE_CHUNKS overrides; 1 = no pipelining)
+int exchange_chunks(int world_size, int64_t rows_moved);
+
+// RAII bundle of backend events
+class event_set {
+ public:
+  explicit event_set(int n);
+  ~event_set();
+  void* operator[](int i) const { return events_[i]; }
+
+ private:
+  std::vector<void*> events_;
+};
+
 // row offsets [W+1] of a handle whose rows are entry_bytes wide
 std::vector<size_t> entry_offsets_of(wholememory_handle_t handle, size_t entry_bytes);
 
