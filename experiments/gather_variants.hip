@@ -209,6 +209,7 @@ int main(int argc, char** argv)
   const bool pmc_mode = argc > 4 && std::string(argv[4]) == "pmc";
   std::vector<int> grids = {2048, 4096, 8192, 16384};
   if (pmc_mode) { vs.erase(vs.begin()); grids = {8192}; iters = 3; }
+  if (argc > 4 && std::string(argv[4]) == "product") { vs.erase(vs.begin()); grids = {4096, 8192, 16384, 39063}; }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("rows=%lld n=%lld iters=%d  (algorithmic bytes per launch = %.3f GB)\n", (long long)rows, (long long)n, iters, n * 1032.0 / 1e9);
   for (auto& v : vs) {

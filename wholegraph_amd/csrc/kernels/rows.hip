@@ -13,10 +13,10 @@
 //    row_bytes / vector bytes, <= 64), 64/LPR rows per step, each lane moving one 16-byte vector
 //    (global_load_dwordx4 / global_store_dwordx4). A 512 B fp32 row is 32 lanes x 16 B, so a step
 //    moves two whole rows as one 1 KiB wave transaction; row base addresses travel between lanes
-//    with ds_bpermute (__shfl), no LDS allocation, no barriers;
-//  * UNROLL steps of loads are issued before the first store, so each wave keeps
-//    UNROLL x 1 KiB of random HBM reads in flight (Little's law: ~10 MB chip-wide are needed to
-//    cover ~2 us of loaded HBM latency at 5-6 TB/s; 8 KiB x 32 waves x 256 CUs = 64 MiB);
+//    with v_readlane (fast path) or ds_bpermute (generic path): no LDS allocation, no barriers;
+//  * several steps of loads are issued before the first store, so each wave keeps 4-8 KiB of
+//    random HBM reads in flight (Little's law: ~10 MB chip-wide are needed to cover ~2 us of
+//    loaded HBM latency at 5-6 TB/s; 4 KiB x 32 waves x 256 CUs = 32 MiB);
 //  * the streamed side (gather output / scatter input) is touched exactly once, so gather stores
 //    are non-temporal to keep L2 / Infinity Cache for table rows (which DO repeat under skew);
 //  * grid = min(tiles/4, 8 x 256 CUs) workgroups of 4 waves, grid-stride over tiles.
@@ -187,13 +187,17 @@ __device__ __forceinline__ char* readlane_ptr(char* p, int src_lane)
 
 // The hot geometry: 16-byte vectors and rows of >= 512 B (RPS = 2 rows per wave step, 32 lanes each)
 // or >= 1 KiB (RPS = 1). Row bases are broadcast with v_readlane (scalar), kU steps (kU KiB per wave)
-// of random row reads are in flight before the first store, table rows are read with the
+// of random row reads are in flight before the first store (kU = 4 measured best: 4 -> 73.1 %, 8 -> 72.5 %,
+// 16 -> 68.9 % of HBM peak on the 10 M-id gather; occupancy, not per-wave depth, provides the parallelism), table rows are read with the
 // non-temporal hint in gather (each row is used once per batch; under skew the Infinity Cache
 // still serves repeats), the streamed side is written non-temporally.
 template <typename IdxT, bool GATHER, int RPS, bool HAS_MAP>
 __global__ __launch_bounds__(kBlock) void rows_copy16_fast_kernel(rows_params p)
 {
-  constexpr int kU      = 8;
+#ifndef WM_FAST_KU
+#define WM_FAST_KU 4
+#endif
+  constexpr int kU      = WM_FAST_KU;
   constexpr int kLpr    = kWave / RPS;
   const int lane        = threadIdx.x & (kWave - 1);
   const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
