@@ -177,12 +177,15 @@ void fill_optimizer_args(wm_optimizer_args* a, const wholememory_embedding_optim
 }
 
 // owner side: sort received ids, then the fused duplicate-sum + optimizer kernel
+// `rows_ready` (optional event): recorded on another stream when recv_grads is complete; the id sort does not need
+// the rows, so it is issued first and only the step kernel waits for the event.
 void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64_t n_recv, const float* recv_grads,
                     int64_t grad_stride, wm_optimizer_args* oa, int64_t key_upper_bound, wholememory_env_func_t* env,
-                    void* stream, int64_t* n_unique_host)
+                    void* stream, int64_t* n_unique_host, void* rows_ready = nullptr)
 {
   const auto* bk = backend();
   if (n_recv == 0) {
+    if (rows_ready != nullptr) WM_BK(bk->stream_wait_event(stream, rows_ready));  // fence the scratch buffers anyway
     if (n_unique_host) *n_unique_host = 0;
     return;
   }
@@ -203,6 +206,7 @@ void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64
   oa->grad_stride = grad_stride;
   oa->count       = n_recv;  // upper bound; the kernel reads the true count from d_nunique
   oa->long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n_recv)), WHOLEMEMORY_DT_INT8);
+  if (rows_ready != nullptr) WM_BK(bk->stream_wait_event(stream, rows_ready));
   rc              = bk->optimizer_step(oa, d_nunique, stream);
   if (rc != 0) throw hip_error("optimizer_step failed");
   if (n_unique_host != nullptr) {
@@ -287,11 +291,35 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     ga.max_blocks   = -1;
     WM_BK(bk->gather_rows(&ga, stream));
   };
-  launch_rows(0, x.self_offset, send_buf);
-  launch_rows(x.self_offset + x.self_count, x.total_valid, send_buf + (x.self_offset + x.self_count) * dim);
   launch_rows(x.self_offset, x.self_offset + x.self_count, recv_buf + full_recv_offsets[rank] * dim);
-  exchange_segments(e->comm, send_buf, x.send_counts, x.bucket_offsets, recv_buf, x.recv_counts, full_recv_offsets,
-                    static_cast<size_t>(dim) * sizeof(float), stream);
+  // peers' rows: line-up (HBM) and all-to-all-v (xGMI, side stream) pipelined in C row-chunks; the id sort that
+  // follows on the caller's stream overlaps with the tail of the exchange
+  const int W = e->comm->world_size;
+  const int C = exchange_chunks(W, x.total_recv + x.total_send);
+  auto chunk_of = [C](int64_t n, int c, int64_t* a, int64_t* b) {
+    *a = n * c / C;
+    *b = n * (c + 1) / C;
+  };
+  void* side = C > 1 ? e->comm->get_side_stream() : stream;
+  event_set lined_up(C > 1 ? C : 0), arrived(C > 1 ? 1 : 0);
+  for (int c = 0; c < C; c++) {
+    std::vector<int64_t> sc(W), so(W), rc(W), ro(W);
+    for (int p = 0; p < W; p++) {
+      int64_t a, b;
+      chunk_of(x.send_counts[p], c, &a, &b);
+      sc[p] = b - a, so[p] = x.bucket_offsets[p] + a;
+      if (p != rank) launch_rows(so[p], so[p] + sc[p], send_buf + so[p] * dim);
+      chunk_of(x.recv_counts[p], c, &a, &b);
+      rc[p] = b - a, ro[p] = full_recv_offsets[p] + a;
+    }
+    if (C > 1) {
+      WM_BK(bk->event_record(lined_up[c], stream));
+      WM_BK(bk->stream_wait_event(side, lined_up[c]));
+    }
+    exchange_segments(e->comm, send_buf, sc, so, recv_buf, rc, ro, static_cast<size_t>(dim) * sizeof(float), side);
+  }
+  if (C > 1) WM_BK(bk->event_record(arrived[0], side));
+  void* rows_arrived = C > 1 ? arrived[0] : nullptr;
 
   // owner: fused dedup + step on the local shard (embedding.cpp:248-318)
   wholememory_tensor_t local_table;
@@ -310,7 +338,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     oa.per_row_state = static_cast<float*>(wholememory_tensor_get_data_pointer(e->per_row_local));
   wholememory_destroy_tensor(local_table);
   dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa,
-                 static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr);
+                 static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived);
   // temporaries go back to the caller's allocator on return; like the reference's distributed ops
   // the stream is drained first so nothing in flight still reads them
   WM_BK(bk->stream_sync(stream));

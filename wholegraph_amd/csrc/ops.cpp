@@ -439,33 +439,83 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
     WM_BK(bk->scatter_rows(&sa, stream));
   }
 
-  // (b) requester side: input rows of the remote segments lined up in bucketed order (scatter_op_impl_nccl.cu:118-133)
+  // (b)-(d) rows for the peers, pipelined in C row-chunks over two streams (same scheme as the gather):
+  //   L_c  line up chunk c of every peer's input rows in bucketed order (scatter_op_impl_nccl.cu:118-133) — HBM
+  //   A_c  rows all-to-all-v of chunk c                                                              — xGMI, side stream
+  //   S_c  owner writes (and casts) chunk c into its shard (scatter_op_impl_nccl.cu:145-166)          — HBM
   temp_mem send_rows(env), recv_rows(env);
-  void* send_buf = send_rows.device(dim * x.total_valid, d.plain.dtype);
-  void* recv_buf = recv_rows.device(dim * x.total_recv, d.plain.dtype);
-  const auto in_gref = wholememory_create_continuous_global_reference(d.plain_ptr);
-  for (int seg = 0; seg < 2; seg++) {
-    const int64_t s0 = seg == 0 ? 0 : x.self_offset + x.self_count;
-    const int64_t s1 = seg == 0 ? x.self_offset : x.total_valid;
-    if (s1 <= s0) continue;
-    int64_t ssz[2] = {s1 - s0, dim};
-    auto send_desc = wholememory_create_matrix_desc(ssz, dim, 0, d.plain.dtype);
-    wm_rows_args ga{};
-    fill_rows_args(&ga, in_gref, d.plain, x.raw_indices + s0, WHOLEMEMORY_DT_INT64, s1 - s0,
-                   static_cast<char*>(send_buf) + static_cast<size_t>(s0) * dim * pes, send_desc, -1);
-    WM_BK(bk->gather_rows(&ga, stream));
+  char* send_buf = static_cast<char*>(send_rows.device(dim * x.total_valid, d.plain.dtype));
+  char* recv_buf = static_cast<char*>(recv_rows.device(dim * x.total_recv, d.plain.dtype));
+  const size_t row_bytes = static_cast<size_t>(dim) * pes;
+  const int W            = comm->world_size;
+  const int rank         = comm->world_rank;
+  const int C            = exchange_chunks(W, x.total_recv + x.total_send);
+  const auto in_gref     = wholememory_create_continuous_global_reference(d.plain_ptr);
+  auto chunk_of = [C](int64_t n, int c, int64_t* a, int64_t* b) {
+    *a = n * c / C;
+    *b = n * (c + 1) / C;
+  };
+  auto lineup_chunk = [&](int c) {
+    for (int p = 0; p < W; p++) {
+      if (p == rank) continue;
+      int64_t a, b;
+      chunk_of(x.send_counts[p], c, &a, &b);
+      if (b <= a) continue;
+      const int64_t first = x.bucket_offsets[p] + a;
+      int64_t ssz[2]      = {b - a, dim};
+      auto send_desc      = wholememory_create_matrix_desc(ssz, dim, 0, d.plain.dtype);
+      wm_rows_args ga{};
+      fill_rows_args(&ga, in_gref, d.plain, x.raw_indices + first, WHOLEMEMORY_DT_INT64, b - a,
+                     send_buf + row_bytes * first, send_desc, -1);
+      WM_BK(bk->gather_rows(&ga, stream));
+    }
+  };
+  auto exchange_chunk = [&](int c, void* on_stream) {
+    std::vector<int64_t> sc(W), so(W), rc(W), ro(W);
+    for (int p = 0; p < W; p++) {
+      int64_t a, b;
+      chunk_of(x.send_counts[p], c, &a, &b);
+      sc[p] = b - a, so[p] = x.bucket_offsets[p] + a;
+      chunk_of(x.recv_counts[p], c, &a, &b);
+      rc[p] = b - a, ro[p] = x.recv_offsets[p] + a;
+    }
+    exchange_segments(comm, send_buf, sc, so, recv_buf, rc, ro, row_bytes, on_stream);
+  };
+  auto write_chunk = [&](int c) {
+    for (int p = 0; p < W; p++) {
+      int64_t a, b;
+      chunk_of(x.recv_counts[p], c, &a, &b);
+      if (b <= a) continue;
+      const int64_t first = x.recv_offsets[p] + a;
+      int64_t rsz[2]      = {b - a, dim};
+      auto recv_desc      = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
+      wm_rows_args wa{};
+      fill_rows_args(&wa, local_gref, d.table, static_cast<const char*>(x.recv_ids) + ies * first, d.indices.dtype, b - a,
+                     recv_buf + row_bytes * first, recv_desc, scatter_sms);
+      WM_BK(bk->scatter_rows(&wa, stream));
+    }
+  };
+  if (C == 1) {
+    lineup_chunk(0);
+    exchange_chunk(0, stream);
+    write_chunk(0);
+  } else {
+    void* side = comm->get_side_stream();
+    event_set lined_up(C), arrived(C);
+    for (int c = 0; c < C; c++) {
+      lineup_chunk(c);
+      WM_BK(bk->event_record(lined_up[c], stream));
+      WM_BK(bk->stream_wait_event(side, lined_up[c]));
+      exchange_chunk(c, side);
+      WM_BK(bk->event_record(arrived[c], side));
+      if (c >= 1) {
+        WM_BK(bk->stream_wait_event(stream, arrived[c - 1]));
+        write_chunk(c - 1);
+      }
+    }
+    WM_BK(bk->stream_wait_event(stream, arrived[C - 1]));
+    write_chunk(C - 1);
   }
-
-  // (c) rows to their owners
-  exchange_segments(comm, send_buf, x.send_counts, x.bucket_offsets, recv_buf, x.recv_counts, x.recv_offsets,
-                    static_cast<size_t>(dim) * pes, stream);
-
-  // (d) owner side: write (and cast) into the local shard (scatter_op_impl_nccl.cu:145-166)
-  int64_t rsz[2] = {x.total_recv, dim};
-  auto recv_desc = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
-  wm_rows_args wa{};
-  fill_rows_args(&wa, local_gref, d.table, x.recv_ids, d.indices.dtype, x.total_recv, recv_buf, recv_desc, scatter_sms);
-  WM_BK(bk->scatter_rows(&wa, stream));
   WM_BK(bk->stream_sync(stream));  // scatter_op_impl_nccl.cu:168
   return WHOLEMEMORY_SUCCESS;
 }
