@@ -162,55 +162,80 @@ struct opt_params {
 };
 
 // optimizer statement sequences of the reference kernels (embedding_optimizer_func.cu:212-223, 392-415,
-// 644-657, 842-855), one element
+// 644-657, 842-855), one element. Loading and updating are separate so callers can put the loads of several
+// independent rows in flight before the first dependent arithmetic.
+struct opt_elem {
+  float e, s0, s1;  // table value, first / second per-element state (m, v | state_sum | v)
+};
+
 template <int OPT>
-__device__ __forceinline__ void apply_optimizer(const wm_optimizer_args& a, int64_t local, int64_t d, float grad_value,
-                                                float beta1t, float beta2t)
+__device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, int64_t local, int64_t d)
 {
-  float* e_row          = a.local_table + local * a.table_stride;
-  float embedding_value = e_row[d];
+  opt_elem x;
+  x.e  = a.local_table[local * a.table_stride + d];
+  x.s0 = 0.f;
+  x.s1 = 0.f;
+  if (OPT != WHOLEMEMORY_OPT_SGD) {
+    const float* st = a.per_element_state + local * a.per_element_stride;
+    x.s0            = st[d];
+    if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) x.s1 = st[a.table_stride + d];
+  }
+  return x;
+}
+
+template <int OPT>
+__device__ __forceinline__ void update_elem(const wm_optimizer_args& a, int64_t local, int64_t d, opt_elem x,
+                                            float grad_value, float beta1t, float beta2t)
+{
+  float embedding_value = x.e;
+  float* st             = OPT != WHOLEMEMORY_OPT_SGD ? a.per_element_state + local * a.per_element_stride : nullptr;
   if (OPT == WHOLEMEMORY_OPT_SGD) {
     grad_value += a.weight_decay * embedding_value;
     embedding_value -= a.lr * grad_value;
   } else if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) {
-    float* m_ptr = a.per_element_state + local * a.per_element_stride;
-    float* v_ptr = m_ptr + a.table_stride;
     if (a.adam_w) {
       embedding_value -= a.lr * a.weight_decay * embedding_value;
     } else {
       grad_value = grad_value + a.weight_decay * embedding_value;
     }
-    float m         = m_ptr[d];
-    float v         = v_ptr[d];
-    m               = a.beta1 * m + (1 - a.beta1) * grad_value;
-    v               = a.beta2 * v + (1 - a.beta2) * grad_value * grad_value;
-    float mhat      = m / (1 - beta1t);
-    float vhat      = v / (1 - beta2t);
-    embedding_value = embedding_value - a.lr * mhat / (sqrtf(vhat) + a.epsilon);
-    m_ptr[d]        = m;
-    v_ptr[d]        = v;
+    float m              = x.s0;
+    float v              = x.s1;
+    m                    = a.beta1 * m + (1 - a.beta1) * grad_value;
+    v                    = a.beta2 * v + (1 - a.beta2) * grad_value * grad_value;
+    float mhat           = m / (1 - beta1t);
+    float vhat           = v / (1 - beta2t);
+    embedding_value      = embedding_value - a.lr * mhat / (sqrtf(vhat) + a.epsilon);
+    st[d]                = m;
+    st[a.table_stride + d] = v;
   } else if (OPT == WHOLEMEMORY_OPT_ADAGRAD) {
-    float* s_ptr    = a.per_element_state + local * a.per_element_stride;
     grad_value      = grad_value + a.weight_decay * embedding_value;
-    float state_sum = s_ptr[d];
+    float state_sum = x.s0;
     state_sum       = state_sum + grad_value * grad_value;
     embedding_value = embedding_value - a.lr * grad_value / (sqrtf(state_sum) + a.epsilon);
-    s_ptr[d]        = state_sum;
+    st[d]           = state_sum;
   } else if (OPT == WHOLEMEMORY_OPT_RMSPROP) {
-    float* v_ptr    = a.per_element_state + local * a.per_element_stride;
     grad_value      = grad_value + a.weight_decay * embedding_value;
-    float v         = v_ptr[d];
+    float v         = x.s0;
     v               = a.alpha * v + (1 - a.alpha) * grad_value * grad_value;
     embedding_value = embedding_value - a.lr * grad_value / (sqrtf(v) + a.epsilon);
-    v_ptr[d]        = v;
+    st[d]           = v;
   }
-  e_row[d] = embedding_value;
+  a.local_table[local * a.table_stride + d] = embedding_value;
+}
+
+template <int OPT>
+__device__ __forceinline__ void apply_optimizer(const wm_optimizer_args& a, int64_t local, int64_t d, float grad_value,
+                                                float beta1t, float beta2t)
+{
+  update_elem<OPT>(a, local, d, load_elem<OPT>(a, local, d), grad_value, beta1t, beta2t);
 }
 
 template <typename IdxT, int OPT, int V>
 __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
 {
   typedef float vec_t __attribute__((ext_vector_type(V)));
+  constexpr int K            = 4;  // independent runs a wave keeps in flight (the work per run is a chain of
+                                   // dependent loads: run_starts -> order -> gradient row; table row)
   const wm_optimizer_args& a = p.a;
   const int lane             = threadIdx.x & 63;
   const int64_t wave         = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
@@ -218,44 +243,72 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
   const int64_t count        = p.n_unique ? *p.n_unique : a.count;
   const IdxT* ids            = static_cast<const IdxT*>(a.ids);
 
-  for (int64_t u = wave; u < count; u += n_waves) {
-    const int64_t local = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
-    const int32_t s0    = a.run_starts[u];
-    const int32_t s1    = a.run_starts[u + 1];
-    float beta1t = 0.f, beta2t = 0.f;
-    if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) {
-      beta1t = a.per_row_state[local * 2 + 0] * a.beta1;
-      beta2t = a.per_row_state[local * 2 + 1] * a.beta2;
-      if (lane == 0) {  // every lane has read the old values (same wave, program order) before this store
-        a.per_row_state[local * 2 + 0] = beta1t;
-        a.per_row_state[local * 2 + 1] = beta2t;
+  for (int64_t u0 = wave * K; u0 < count; u0 += n_waves * K) {
+    int64_t local[K];
+    int32_t s0[K], s1[K], o0[K];
+    float beta1t[K], beta2t[K];
+    bool live[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int64_t u = min(u0 + k, count - 1);  // clamped: loads stay unconditional
+      live[k]         = u0 + k < count;
+      local[k]        = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
+      s0[k]           = a.run_starts[u];
+      s1[k]           = a.run_starts[u + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      o0[k]     = a.order[s0[k]];
+      beta1t[k] = beta2t[k] = 0.f;
+      if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) {
+        beta1t[k] = a.per_row_state[local[k] * 2 + 0] * a.beta1;
+        beta2t[k] = a.per_row_state[local[k] * 2 + 1] * a.beta2;
       }
     }
-    if (p.long_list != nullptr && s1 - s0 > kLongRun) {
-      if (lane == 0) {
-        int slot          = atomicAdd(p.long_count, 1);
-        p.long_list[slot] = long_run_entry{static_cast<int32_t>(u), beta1t, beta2t, 0};
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM && live[k] && lane == 0) {
+        // every lane has read the old values (same wave, program order) before this store
+        a.per_row_state[local[k] * 2 + 0] = beta1t[k];
+        a.per_row_state[local[k] * 2 + 1] = beta2t[k];
       }
-      continue;
+      if (live[k] && p.long_list != nullptr && s1[k] - s0[k] > kLongRun) {
+        if (lane == 0) {
+          int slot          = atomicAdd(p.long_count, 1);
+          p.long_list[slot] = long_run_entry{static_cast<int32_t>(u0 + k), beta1t[k], beta2t[k], 0};
+        }
+        live[k] = false;  // folded by step_long_kernel
+      }
     }
     for (int64_t d = static_cast<int64_t>(lane) * V; d < a.dim; d += 64 * V) {
-      // first occurrence copied, later ones added in receive order (DedupIndiceAndGradientsKernel).
-      // Loads are unconditional (index clamped to the run) so they all issue before the first add.
-      vec_t acc = *reinterpret_cast<const vec_t*>(a.grads + static_cast<int64_t>(a.order[s0]) * a.grad_stride + d);
-      for (int32_t j = s0 + 1; j < s1; j += 4) {
-        int32_t o[4];
-        vec_t g[4];
+      vec_t acc[K];
+      opt_elem x[K][V];
 #pragma unroll
-        for (int k = 0; k < 4; k++) o[k] = a.order[min(j + k, s1 - 1)];
+      for (int k = 0; k < K; k++) {
+        // first occurrence copied (DedupIndiceAndGradientsKernel); table / state values loaded alongside
+        acc[k] = *reinterpret_cast<const vec_t*>(a.grads + static_cast<int64_t>(o0[k]) * a.grad_stride + d);
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-          g[k] = *reinterpret_cast<const vec_t*>(a.grads + static_cast<int64_t>(o[k]) * a.grad_stride + d);
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (j + k < s1) acc += g[k];
+        for (int v = 0; v < V; v++) x[k][v] = load_elem<OPT>(a, local[k], d + v);
       }
 #pragma unroll
-      for (int v = 0; v < V; v++) apply_optimizer<OPT>(a, local, d + v, acc[v], beta1t, beta2t);
+      for (int k = 0; k < K; k++) {
+        if (!live[k]) continue;
+        // later occurrences added in receive order, 4 rows prefetched at a time (index clamped into the run)
+        for (int32_t j = s0[k] + 1; j < s1[k]; j += 4) {
+          int32_t o[4];
+          vec_t g[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) o[q] = a.order[min(j + q, s1[k] - 1)];
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            g[q] = *reinterpret_cast<const vec_t*>(a.grads + static_cast<int64_t>(o[q]) * a.grad_stride + d);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (j + q < s1[k]) acc[k] += g[q];
+        }
+#pragma unroll
+        for (int v = 0; v < V; v++) update_elem<OPT>(a, local[k], d + v, x[k][v], acc[k][v], beta1t[k], beta2t[k]);
+      }
     }
   }
 }
