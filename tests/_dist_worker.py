@@ -163,6 +163,49 @@ def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries):
     wgth.destroy_embedding(emb)
 
 
+def scenario_file_io(comm, rank, world, tmpdir):
+    """wholememory_load_from_file / store_to_file through the Python surface: files re-sharded over ranks (3 files of
+    uneven size -> W shards), padded rows (file rows are dim wide, memory rows stride wide), round-robin placement,
+    and a save -> load round trip of "%s_part_%d_of_%d" shards (torch/embedding.py:358-377, file_io.cpp:1860,2059)."""
+    n_rows, dim = 1003, 7
+    full = (np.arange(n_rows * dim, dtype=np.float32).reshape(n_rows, dim) * 0.5).astype(np.float32)
+    files = [os.path.join(tmpdir, "feat_%d.bin" % i) for i in range(3)]
+    cuts = [0, 400, 401, n_rows]
+    if rank == 0:
+        os.makedirs(tmpdir, exist_ok=True)
+        for i, f in enumerate(files):
+            full[cuts[i]:cuts[i + 1]].tofile(f)
+    comm.barrier()
+    wm = wgth.create_wholememory_tensor_from_filelist(comm, "distributed", "cuda", files, torch.float32, last_dim_size=dim,
+                                                      last_dim_strides=8)
+    local, start = wm.get_local_tensor()
+    assert local.stride(0) == 8
+    exp = full[start:start + local.shape[0]]
+    assert host(local).numpy().tobytes() == np.ascontiguousarray(exp).tobytes(), "plain load mismatch on rank %d" % rank
+    # store every rank's shard, reload into a fresh tensor through the part files
+    prefix = os.path.join(tmpdir, "ckpt")
+    wm.to_file_prefix(prefix)
+    comm.barrier()
+    wm2 = wgth.create_wholememory_tensor(comm, "distributed", "cuda", [n_rows, dim], torch.float32, [8, 1])
+    wm2.from_file_prefix(prefix)
+    l2, s2 = wm2.get_local_tensor()
+    assert s2 == start and host(l2).numpy().tobytes() == np.ascontiguousarray(exp).tobytes()
+    wgth.destroy_wholememory_tensor(wm2)
+    wgth.destroy_wholememory_tensor(wm)
+    # round-robin placement: local row l of rank r <- file entry ((l // rr) * W + r) * rr + l % rr
+    rr = 4
+    emb = wgth.create_embedding_from_filelist(comm, "distributed", "cuda", files, torch.float32, dim, round_robin_size=rr)
+    assert emb.shape[0] == oracle.round_robin_total_entries(n_rows, world, rr)
+    lt, st = emb.get_embedding_tensor().get_local_tensor()
+    got = host(lt).numpy()
+    for l in range(lt.shape[0]):
+        e = ((l // rr) * world + rank) * rr + l % rr
+        if e < n_rows:
+            assert np.array_equal(got[l], full[e]), "round-robin row %d on rank %d" % (l, rank)
+    comm.barrier()
+    wgth.destroy_embedding(emb)
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
@@ -199,6 +242,7 @@ def main():
         scenario_gather_scatter(comm, rank, world, "chunked", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
         scenario_gather_scatter(comm, rank, world, "continuous", 2003, 32, np.float32, np.float16, np.int32, ent2, loc="cpu")
         scenario_gather_scatter(comm, rank, world, "distributed", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
+    scenario_file_io(comm, rank, world, "/tmp/wgamd_test_%s" % port)
     # (5) gradient apply, all optimizers
     for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}),
                          ("adam", {"adam_w": 1.0, "weight_decay": 0.02}), ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]:
