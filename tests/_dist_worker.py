@@ -223,7 +223,9 @@ def main():
     # (2) dtype cast at the owner + int32 ids + an asking-nothing rank
     scenario_gather_scatter(comm, rank, world, "distributed", 2000, 32, np.float16, np.float32, np.int32, None)
     # (3) custom partition (python random_partition shape) + ints
-    ent = [int(x) for x in (np.array([0.2, 0.5, 0.3, 0.1, 0.4][:world]) / sum([0.2, 0.5, 0.3, 0.1, 0.4][:world]) * 997).astype(int)]
+    w8 = np.random.default_rng(42).uniform(90, 100, world)   # reference python random_partition shape
+    w8[world // 2] *= 0.3                                       # plus one clearly smaller shard
+    ent = [int(x) for x in (w8 / w8.sum() * 997).astype(int)]
     ent[0] += 997 - sum(ent)
     ent2 = [2 * e for e in ent]
     ent2[0] += 2003 - sum(ent2)

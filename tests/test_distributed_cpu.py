@@ -50,8 +50,7 @@ def test_multi_rank_on_one_gpu_hip_kernels(wm_lib, world, chunks):
     run_world(world, "hip", {"WM_EXCHANGE_CHUNKS": chunks})
 
 
-@pytest.mark.parametrize("chunks", ["1", "3"])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,chunks", [(2, "1"), (2, "3"), (3, "1"), (3, "3"), (8, "4")])
 def test_distributed_paths_over_gloo(wm_lib, world, chunks):
     tb = os.path.join(ROOT, "oracle", "libwm_test_backend.so")
     if not os.path.exists(tb):
