@@ -34,8 +34,8 @@ _DT2NP[DT_BF16] = np.dtype(np.uint16)  # bf16 carried as raw bits
 
 def build(force=False):
     """Compile the C oracle (and oracle/_ref when the reference tree is present)."""
-    src = os.path.join(_HERE, "wm_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("wm_oracle.c", "wm_graph_oracle.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libwm_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/cpp/src/wholememory/tensor_description.cpp"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -103,6 +103,20 @@ def lib():
         L.wmo_bf16_to_float.argtypes = [c.c_uint16]
         L.wmo_num_threads.restype = c.c_int
         L.wmo_set_num_threads.argtypes = [c.c_int]
+        # wm_graph_oracle.c
+        L.wmo_pcg_raw.restype = None
+        L.wmo_pcg_raw.argtypes = [c.c_uint64, c.c_uint64, c.c_uint64, c.c_int64, c.c_void_p]
+        L.wmo_random_positive_int.restype = None
+        L.wmo_random_positive_int.argtypes = [c.c_int64, c.c_int64, c.c_int64, c.c_int, c.c_void_p]
+        L.wmo_sample_offsets.restype = c.c_int64
+        L.wmo_sample_offsets.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_int64, c.c_int, c.c_void_p]
+        L.wmo_sample_unweighted.restype = None
+        L.wmo_sample_unweighted.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_int, c.c_int64, c.c_int,
+                                            c.c_uint64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+        L.wmo_append_unique.restype = c.c_int64
+        L.wmo_append_unique.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+        L.wmo_csr_add_self_loop.restype = None
+        L.wmo_csr_add_self_loop.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
         _lib = L
     return _lib
 
@@ -356,3 +370,56 @@ def num_threads():
 
 def set_num_threads(n):
     lib().wmo_set_num_threads(n)
+
+
+# ---------------------------------------------------------------------------------------------- graph ops
+def pcg_raw(seed, subsequence, offset, n):
+    """n raw 32-bit outputs of PCG-XSH-RR 64/32 after init(seed, subsequence) + skip-ahead by offset."""
+    out = np.empty(n, dtype=np.uint32)
+    lib().wmo_pcg_raw(seed, subsequence, offset, n, _p(out))
+    return out
+
+
+def random_positive_int(seed, subsequence, n, np_dtype=np.int32):
+    out = np.empty(n, dtype=np_dtype)
+    lib().wmo_random_positive_int(seed, subsequence, n, 1 if np.dtype(np_dtype) == np.int64 else 0, _p(out))
+    return out
+
+
+def sample_unweighted(row_ptr, col, centers, max_sample, seed, need_lid=True, need_egid=True):
+    """-> offsets int32 [n + 1], ids (col dtype), lid int32 | None, egid int64 | None"""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    col = np.ascontiguousarray(col)
+    centers = np.ascontiguousarray(centers)
+    n = centers.shape[0]
+    offsets = np.empty(n + 1, dtype=np.int32)
+    c64 = 1 if centers.dtype == np.int64 else 0
+    total = lib().wmo_sample_offsets(_p(row_ptr), _p(centers), c64, n, max_sample, _p(offsets))
+    ids = np.empty(total, dtype=np.int64)
+    lid = np.empty(total, dtype=np.int32) if need_lid else None
+    egid = np.empty(total, dtype=np.int64) if need_egid else None
+    lib().wmo_sample_unweighted(_p(row_ptr), _p(col), 1 if col.dtype == np.int64 else 0, _p(centers), c64, n,
+                                max_sample, seed & 0xFFFFFFFFFFFFFFFF, _p(offsets), _p(ids),
+                                _p(lid) if need_lid else None, _p(egid) if need_egid else None)
+    return offsets, ids.astype(col.dtype), lid, egid
+
+
+def append_unique(targets, neighbors):
+    """-> unique (targets first, then new neighbour ids in first-seen order), mapping int32 [n_neighbor]"""
+    dt = np.asarray(targets).dtype
+    t = np.ascontiguousarray(targets, dtype=np.int64)
+    nb = np.ascontiguousarray(neighbors, dtype=np.int64)
+    out = np.empty(t.shape[0] + nb.shape[0], dtype=np.int64)
+    mapping = np.empty(nb.shape[0], dtype=np.int32)
+    cnt = lib().wmo_append_unique(_p(t), t.shape[0], _p(nb), nb.shape[0], _p(out), _p(mapping))
+    return out[:cnt].astype(dt), mapping
+
+
+def csr_add_self_loop(row_ptr, col):
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    n = row_ptr.shape[0] - 1
+    out_row = np.empty(n + 1, dtype=np.int32)
+    out_col = np.empty(col.shape[0] + n, dtype=np.int32)
+    lib().wmo_csr_add_self_loop(_p(row_ptr), _p(col), n, _p(out_row), _p(out_col))
+    return out_row, out_col

@@ -23,8 +23,9 @@ def declared_functions():
         text = re.sub(r"struct\s+\w+\s*\{.*?\};", "", text, flags=re.S)
         for m in re.finditer(r"\b([A-Za-z_]\w*)\s*\(", text):
             n = m.group(1)
-            if n.startswith(("wholememory_", "wm_testing_")) or n in ("get_device_prop", "fork_get_device_count",
-                                                                      "get_wholememory_tensor_count"):
+            if n.startswith(("wholememory_", "wm_testing_", "wholegraph_csr_", "generate_")) or n in (
+                    "get_device_prop", "fork_get_device_count", "get_wholememory_tensor_count", "graph_append_unique",
+                    "csr_add_self_loop"):
                 names.add(n)
     return names
 
@@ -54,6 +55,8 @@ def test_struct_layouts_match_the_c_abi():
 #include <stdio.h>
 #include <stddef.h>
 #include <wholememory/wholegraph_amd_ext.h>
+#include <wholememory/wholegraph_op.h>
+#include <wholememory/graph_op.h>
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu ", sizeof(struct wholememory_tensor_description_t),
          offsetof(struct wholememory_tensor_description_t, strides), offsetof(struct wholememory_tensor_description_t, storage_offset),

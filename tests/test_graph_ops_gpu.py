@@ -1,0 +1,210 @@
+"""GPU parity of neighbour sampling / append_unique / add_csr_self_loop through the C ABI vs the CPU oracle.
+
+Parameter sets follow the reference's tests:
+  cpp/tests/wholegraph_ops/wholegraph_csr_unweighted_sample_without_replacement_tests.cu:290-375
+      (memory types continuous/chunked x host/device, max_sample_count 10/30/40/128/500/1025..., int32/int64 ids)
+  python/.../tests/wholegraph_torch/ops/test_wholegraph_unweighted_sample.py:196-245
+  cpp/tests/graph_ops/append_unique_tests.cu, csr_add_self_loop_tests.cu, python test_graph_append_unique.py
+Bit-exact: samples are a pure function of (seed, center position, max_sample_count, CSR row).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from test_graph_oracle import make_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _wm_csr(comm, mt, loc, row_ptr, col):
+    import torch
+    import wholegraph_amd.torch as wgth
+    tensors = []
+    for arr in (row_ptr, col):
+        t = wgth.create_wholememory_tensor(comm, mt, loc, [arr.shape[0]], torch.from_numpy(arr).dtype, [1])
+        local, start = t.get_local_tensor(host_view=(loc == "cpu"))
+        local.copy_(torch.from_numpy(arr))
+        tensors.append(t)
+    torch.cuda.synchronize()
+    return tensors
+
+
+GRAPH = None
+
+
+def _graph(col_dtype):
+    global GRAPH
+    if GRAPH is None:
+        GRAPH = make_csr(3000, 90, 123, np.int64,
+                         heavy=[(7, 5000), (8, 1024), (9, 1025), (10, 1026), (11, 2048), (12, 0), (13, 1), (14, 30), (15, 31)])
+    return GRAPH[0], GRAPH[1].astype(col_dtype)
+
+
+@pytest.mark.parametrize("mt,loc", [("continuous", "cuda"), ("chunked", "cuda"), ("continuous", "cpu"), ("chunked", "cpu")])
+@pytest.mark.parametrize("center_dtype,col_dtype", [(np.int64, np.int64), (np.int32, np.int32), (np.int64, np.int32),
+                                                    (np.int32, np.int64)])
+def test_unweighted_sample_parity(gpu_env, mt, loc, center_dtype, col_dtype):
+    import torch
+    import wholegraph_amd.torch as wgth
+    row_ptr, col = _graph(col_dtype)
+    wrow, wcol = _wm_csr(gpu_env, mt, loc, row_ptr, col)
+    rng = np.random.default_rng(17)
+    centers = np.concatenate([np.arange(0, 20), rng.integers(0, 3000, 1500)]).astype(center_dtype)
+    g = wgth.GraphStructure()
+    g.set_csr_graph(wrow, wcol)
+    for m in (-1, 1, 10, 30, 32, 33, 40, 64, 65, 128, 500, 1024, 1025, 1500):
+        seed = 1000003 * (m + 5) + 12345678901234567
+        off, ids, lid, egid = g.unweighted_sample_without_replacement_one_hop(
+            torch.from_numpy(centers).cuda(), m, random_seed=seed, need_center_local_output=True, need_edge_output=True)
+        o_off, o_ids, o_lid, o_egid = oracle.sample_unweighted(row_ptr, col, centers, m, seed)
+        assert off.dtype == torch.int32 and lid.dtype == torch.int32 and egid.dtype == torch.int64
+        assert ids.dtype == torch.from_numpy(col).dtype
+        assert np.array_equal(off.cpu().numpy(), o_off), "offsets differ at max_sample_count=%d" % m
+        assert np.array_equal(egid.cpu().numpy(), o_egid), "edge ids differ at max_sample_count=%d" % m
+        assert np.array_equal(ids.cpu().numpy(), o_ids), "sampled ids differ at max_sample_count=%d" % m
+        assert np.array_equal(lid.cpu().numpy(), o_lid)
+    wgth.destroy_wholememory_tensor(wrow)
+    wgth.destroy_wholememory_tensor(wcol)
+
+
+def test_unweighted_sample_output_variants_and_plain_tensors(gpu_env):
+    """Optional outputs; CSR held in plain device tensors (no WholeMemory handle) wrapped on the fly."""
+    import torch
+    import wholegraph_amd.torch.wholegraph_ops as wops
+    from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor
+    row_ptr, col = _graph(np.int64)
+    drow, dcol = torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda()
+    wr, wc = wrap_torch_tensor(drow), wrap_torch_tensor(dcol)
+    centers = np.array([7, 8, 12, 13, 100, 200, 7], dtype=np.int64)
+    o_off, o_ids, o_lid, o_egid = oracle.sample_unweighted(row_ptr, col, centers, 25, 42)
+    dc = torch.from_numpy(centers).cuda()
+    r = wops.unweighted_sample_without_replacement(wr.handle, wc.handle, dc, 25, 42)
+    assert len(r) == 2 and np.array_equal(r[1].cpu().numpy(), o_ids) and np.array_equal(r[0].cpu().numpy(), o_off)
+    r = wops.unweighted_sample_without_replacement(wr.handle, wc.handle, dc, 25, 42, need_center_local_output=True)
+    assert len(r) == 3 and np.array_equal(r[2].cpu().numpy(), o_lid)
+    r = wops.unweighted_sample_without_replacement(wr.handle, wc.handle, dc, 25, 42, need_edge_output=True)
+    assert len(r) == 3 and np.array_equal(r[2].cpu().numpy(), o_egid)
+    # no center nodes, and center nodes without neighbours
+    r = wops.unweighted_sample_without_replacement(wr.handle, wc.handle, dc[:0], 25, 42, need_edge_output=True)
+    assert r[0].cpu().tolist() == [0] and r[1].numel() == 0 and r[2].numel() == 0
+    r = wops.unweighted_sample_without_replacement(wr.handle, wc.handle, torch.tensor([12, 12], device="cuda"), 25, 42)
+    assert r[0].cpu().tolist() == [0, 0, 0] and r[1].numel() == 0
+    # a random seed is drawn when none is given: two calls differ (5000-neighbour node, 25 samples)
+    a = wops.unweighted_sample_without_replacement(wr.handle, wc.handle, dc[:1], 25)[1]
+    b = wops.unweighted_sample_without_replacement(wr.handle, wc.handle, dc[:1], 25)[1]
+    assert not torch.equal(a, b)
+
+
+def test_unweighted_sample_is_uniform(gpu_env):
+    """Every neighbour of a node is picked with probability M/N (chi-square over 4000 seeds)."""
+    import torch
+    import wholegraph_amd.torch.wholegraph_ops as wops
+    from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor
+    n_nb, m, trials = 50, 10, 4000
+    row_ptr = np.arange(0, (trials + 1) * n_nb, n_nb, dtype=np.int64)   # `trials` nodes with the same 50 neighbours
+    col = np.tile(np.arange(n_nb, dtype=np.int32), trials)
+    wr, wc = wrap_torch_tensor(torch.from_numpy(row_ptr).cuda()), wrap_torch_tensor(torch.from_numpy(col).cuda())
+    centers = torch.arange(trials, device="cuda", dtype=torch.int32)
+    off, ids = wops.unweighted_sample_without_replacement(wr.handle, wc.handle, centers, m, 20260928)
+    ids = ids.cpu().numpy().reshape(trials, m)
+    assert all(len(set(r.tolist())) == m for r in ids)
+    counts = np.bincount(ids.ravel(), minlength=n_nb).astype(np.float64)
+    expect = trials * m / n_nb
+    chi2 = ((counts - expect) ** 2 / expect).sum()
+    assert chi2 < 100.0, "chi-square %.1f over 49 dof" % chi2   # p(chi2 > 100) ~ 2e-5
+    # position i of the sample is itself uniform
+    first = np.bincount(ids[:, 0], minlength=n_nb).astype(np.float64)
+    assert ((first - trials / n_nb) ** 2 / (trials / n_nb)).sum() < 100.0
+
+
+def test_sample_argument_errors(gpu_env):
+    import torch
+    from wholegraph_amd import binding as wmb
+    import wholegraph_amd.torch.wholegraph_ops as wops
+    from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor
+    row = torch.tensor([0, 2, 4], device="cuda", dtype=torch.int64)
+    col = torch.tensor([1, 0, 1, 0], device="cuda", dtype=torch.int64)
+    centers = torch.tensor([0, 1], device="cuda")
+    wr, wc = wrap_torch_tensor(row), wrap_torch_tensor(col)
+    wr32 = wrap_torch_tensor(row.int())
+    with pytest.raises(wmb.WholeMemoryError):   # row_ptr must be int64
+        wops.unweighted_sample_without_replacement(wr32.handle, wc.handle, centers, 2, 1)
+    with pytest.raises(wmb.WholeMemoryError):   # float ids
+        wops.unweighted_sample_without_replacement(wr.handle, wc.handle, centers.float(), 2, 1)
+    with pytest.raises(wmb.WholeMemoryError) as e:
+        wops.weighted_sample_without_replacement(wr.handle, wc.handle, wc.handle, centers, 2, 1)
+    assert "NOT_IMPLEMENTED" in str(e.value)
+
+
+@pytest.mark.parametrize("np_dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("nt,nn,universe", [(700, 9000, 5000), (1, 1, 10), (0, 5000, 300), (3000, 0, 10 ** 6),
+                                            (50000, 400000, 150000), (1000, 20000, 2 ** 31 - 1)])
+def test_append_unique_parity(gpu_env, np_dtype, nt, nn, universe):
+    import torch
+    import wholegraph_amd.torch.graph_ops as gops
+    rng = np.random.default_rng(nt + nn)
+    if universe > 4 * nt:
+        targets = np.unique(rng.integers(0, universe, 2 * nt + 8))
+        rng.shuffle(targets)
+        targets = targets[:nt].astype(np_dtype)
+    else:
+        targets = rng.permutation(universe)[:nt].astype(np_dtype)
+    neighbors = rng.integers(0, universe, nn).astype(np_dtype)
+    o_uniq, o_map = oracle.append_unique(targets, neighbors)
+    uniq, mapping = gops.append_unique(torch.from_numpy(targets).cuda(), torch.from_numpy(neighbors).cuda(), True)
+    assert uniq.dtype == torch.from_numpy(targets).dtype and mapping.dtype == torch.int32
+    assert np.array_equal(uniq.cpu().numpy(), o_uniq)
+    assert np.array_equal(mapping.cpu().numpy(), o_map)
+    only = gops.append_unique(torch.from_numpy(targets).cuda(), torch.from_numpy(neighbors).cuda())
+    assert torch.equal(only, uniq)
+
+
+def test_append_unique_reference_docstring_example(gpu_env):
+    import torch
+    import wholegraph_amd.torch.graph_ops as gops
+    t = torch.tensor([3, 11, 2, 10], device="cuda")
+    n = torch.tensor([4, 5, 2, 11, 6, 9, 10, 5], device="cuda")
+    uniq, mapping = gops.append_unique(t, n, True)
+    assert uniq.tolist() == [3, 11, 2, 10, 4, 5, 6, 9]          # a valid order of the reference's "may be" answer
+    assert mapping.tolist() == [4, 5, 2, 1, 6, 7, 3, 5]
+    assert torch.equal(uniq[mapping.long()], n)
+
+
+@pytest.mark.parametrize("n_nodes,max_degree", [(1, 0), (1, 5), (200, 9), (5000, 300)])
+def test_add_csr_self_loop_parity(gpu_env, n_nodes, max_degree):
+    import torch
+    import wholegraph_amd.torch.graph_ops as gops
+    row_ptr, col = make_csr(n_nodes, max_degree, n_nodes + max_degree, np.int32)
+    o_row, o_col = oracle.csr_add_self_loop(row_ptr, col)
+    row, colo = gops.add_csr_self_loop(torch.from_numpy(row_ptr.astype(np.int32)).cuda(), torch.from_numpy(col).cuda())
+    assert np.array_equal(row.cpu().numpy(), o_row) and np.array_equal(colo.cpu().numpy(), o_col)
+
+
+def test_multilayer_sample(gpu_env):
+    """3-hop [30, 30, 30]-style sampling (BASELINE config 5 sampler) = chained one-hop + append_unique; checked
+    hop by hop against the oracle driven with the same seeds."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    row_ptr, col = _graph(np.int64)
+    wrow, wcol = _wm_csr(gpu_env, "chunked", "cuda", row_ptr, col)
+    g = wgth.GraphStructure()
+    g.set_csr_graph(wrow, wcol)
+    seeds = torch.from_numpy(np.random.default_rng(1).permutation(3000)[:256]).cuda()
+    target_gids, edge_indice, csr_row_ptr, csr_col_ind = g.multilayer_sample_without_replacement(seeds, [5, 4, 3])
+    assert len(target_gids) == 4 and torch.equal(target_gids[3], seeds)
+    for i in (2, 1, 0):
+        inner, outer = target_gids[i + 1], target_gids[i]
+        assert torch.equal(outer[:inner.numel()], inner)                    # targets stay in front
+        assert outer.unique().numel() == outer.numel()
+        off, colind = csr_row_ptr[i], csr_col_ind[i]
+        assert off.numel() == inner.numel() + 1 and int(off[-1]) == colind.numel()
+        fan = [5, 4, 3][2 - i]
+        deg = torch.from_numpy(row_ptr[1:] - row_ptr[:-1]).cuda()[inner]
+        assert torch.equal((off[1:] - off[:-1]).long(), torch.clamp(deg, max=fan))
+        # every sampled edge (center -> outer[colind]) exists in the graph
+        src = inner[edge_indice[i][1].long()].cpu().numpy()
+        dst = outer[edge_indice[i][0].long()].cpu().numpy()
+        for s, d in list(zip(src, dst))[:2000]:
+            assert d in col[row_ptr[s]:row_ptr[s + 1]]
+    wgth.destroy_wholememory_tensor(wrow)
+    wgth.destroy_wholememory_tensor(wcol)

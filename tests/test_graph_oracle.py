@@ -1,0 +1,166 @@
+"""CPU tests of the graph-op oracle (oracle/wm_graph_oracle.c) and of the product library's HOST random helpers.
+
+Pinning:
+  * the PCG-XSH-RR 64/32 core against the published pcg32 known-answer vector (pcg32-demo, seed 42, stream 54);
+  * skip-ahead against stepping;
+  * the sampler against the reference's own host statement of index sampling (Q = iota; a[i] = Q[r[i]];
+    Q[r[i]] = Q[N-1-i], tests/wholegraph_ops/graph_sampling_test_utils.cu:306-321) re-derived here in numpy from
+    the same draws;
+  * append_unique / add_self_loop against independent numpy statements (reference test oracles
+    tests/graph_ops/append_unique_test_utils.cu:27-80, csr_add_self_loop_utils.cu).
+raft's wrapping of the generator stays "parity unpinned" (oracle/wm_graph_oracle.c header).
+"""
+import numpy as np
+import pytest
+
+import oracle
+
+
+def test_pcg32_known_answer():
+    # O'Neill's pcg32-demo: pcg32_srandom_r(&rng, 42u, 54u) -> first six outputs
+    want = [0xA15C02B7, 0x7B47F409, 0xBA1D3330, 0x83D2F293, 0xBFA4784B, 0xCBED606E]
+    assert [int(x) for x in oracle.pcg_raw(42, 54, 0, 6)] == want
+
+
+@pytest.mark.parametrize("skip", [1, 2, 7, 64, 1000, 12345])
+def test_pcg_skipahead_equals_stepping(skip):
+    full = oracle.pcg_raw(2024, 77, 0, skip + 8)
+    assert np.array_equal(oracle.pcg_raw(2024, 77, skip, 8), full[skip:])
+
+
+def test_random_positive_int_layout():
+    # generator(seed, subsequence) = init(seed, subsequence, offset = subsequence); int32 = output & 0x7fffffff,
+    # int64 = (lo | hi << 32) & (2^63 - 1)
+    raw = oracle.pcg_raw(9, 5, 5, 16).astype(np.uint64)
+    assert np.array_equal(oracle.random_positive_int(9, 5, 16), (raw & 0x7FFFFFFF).astype(np.int32))
+    want64 = ((raw[0::2] | (raw[1::2] << np.uint64(32))) & np.uint64(0x7FFFFFFFFFFFFFFF)).astype(np.int64)
+    assert np.array_equal(oracle.random_positive_int(9, 5, 8, np.int64), want64)
+
+
+def _geometry(m):
+    warps = [1, 1, 1, 2, 2, 2, 4, 4, 4, 4, 4, 4] + [8] * 20
+    items = [1, 2, 3, 2, 3, 3, 2, 2, 3, 3, 3, 3, 2, 2, 2, 2] + [3] * 8 + [4] * 8
+    f = (m - 1) // 32
+    return warps[f] * 32, items[f]
+
+
+def _numpy_sample(row_ptr, col, centers, m, seed):
+    """The reference host statement, from draws obtained one virtual thread at a time."""
+    out, lid, egid = [], [], []
+    for c, nid in enumerate(centers):
+        s, e = int(row_ptr[nid]), int(row_ptr[nid + 1])
+        n = e - s
+        if m <= 0 or n <= m:
+            a = list(range(n))
+        elif m > 1024:
+            a = list(range(m))
+            for t in range(32):
+                idxs = list(range(m + t, n, 32))
+                draws = oracle.random_positive_int(seed, c * 32 + t, len(idxs))
+                for idx, d in zip(idxs, draws):
+                    r = int(d) % (idx + 1)
+                    if r < m:
+                        a[r] = max(a[r], idx)
+        else:
+            T, items = _geometry(m)
+            r = [0] * m
+            for t in range(min(T, m)):
+                draws = oracle.random_positive_int(seed, c * T + t, items)
+                for k in range(items):
+                    idx = k * T + t
+                    if idx < m:
+                        r[idx] = int(draws[k]) % (n - idx)
+            q = list(range(n))
+            a = []
+            for i in range(m):
+                a.append(q[r[i]])
+                q[r[i]] = q[n - 1 - i]
+        out += [int(col[s + x]) for x in a]
+        lid += [c] * len(a)
+        egid += [s + x for x in a]
+    return np.array(out, dtype=col.dtype), np.array(lid, dtype=np.int32), np.array(egid, dtype=np.int64)
+
+
+def make_csr(n_nodes, max_degree, seed, col_dtype=np.int64, heavy=()):
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, max_degree + 1, n_nodes)
+    for node, d in heavy:
+        deg[node] = d
+    row_ptr = np.zeros(n_nodes + 1, dtype=np.int64)
+    np.cumsum(deg, out=row_ptr[1:])
+    col = rng.integers(0, n_nodes, int(row_ptr[-1])).astype(col_dtype)
+    return row_ptr, col
+
+
+@pytest.mark.parametrize("m", [-1, 1, 5, 30, 32, 33, 97, 200, 1024, 1025, 1500])
+def test_oracle_sampler_matches_reference_host_statement(m):
+    row_ptr, col = make_csr(60, 70, 3 + max(m, 0), heavy=[(3, 2100), (17, 1300), (40, 1024), (41, 1025)])
+    centers = np.array([3, 17, 0, 40, 41, 5, 3, 59, 22], dtype=np.int64)
+    off, ids, lid, egid = oracle.sample_unweighted(row_ptr, col, centers, m, 0xDEADBEEFCAFE)
+    want_ids, want_lid, want_egid = _numpy_sample(row_ptr, col, centers, m, 0xDEADBEEFCAFE)
+    deg = row_ptr[centers + 1] - row_ptr[centers]
+    cnt = deg if m <= 0 else np.minimum(deg, m)
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32))
+    assert np.array_equal(ids, want_ids) and np.array_equal(lid, want_lid) and np.array_equal(egid, want_egid)
+    # without replacement: edge ids of one center node are distinct and inside its row
+    for c in range(len(centers)):
+        e = egid[off[c]:off[c + 1]]
+        assert len(set(e.tolist())) == len(e)
+        assert np.all((e >= row_ptr[centers[c]]) & (e < row_ptr[centers[c] + 1]))
+
+
+def test_oracle_append_unique():
+    rng = np.random.default_rng(5)
+    targets = rng.permutation(5000)[:700].astype(np.int64)
+    neighbors = rng.integers(0, 5000, 9000).astype(np.int64)
+    uniq, mapping = oracle.append_unique(targets, neighbors)
+    assert np.array_equal(uniq[:700], targets)
+    tail = uniq[700:]
+    # first-seen order of the neighbour ids that are not targets
+    seen, want = set(targets.tolist()), []
+    for v in neighbors.tolist():
+        if v not in seen:
+            seen.add(v)
+            want.append(v)
+    assert tail.tolist() == want
+    assert np.array_equal(uniq[mapping], neighbors)
+    # the docstring example of the reference (python/.../torch/graph_ops.py:29-35)
+    uniq, mapping = oracle.append_unique(np.array([3, 11, 2, 10]), np.array([4, 5, 2, 11, 6, 9, 10, 5]))
+    assert sorted(uniq.tolist()) == sorted([3, 11, 2, 10, 6, 4, 9, 5]) and uniq[:4].tolist() == [3, 11, 2, 10]
+    assert np.array_equal(uniq[mapping], [4, 5, 2, 11, 6, 9, 10, 5])
+
+
+def test_oracle_add_self_loop():
+    row_ptr, col = make_csr(200, 9, 11, np.int32)
+    out_row, out_col = oracle.csr_add_self_loop(row_ptr.astype(np.int32), col)
+    assert np.array_equal(out_row, row_ptr + np.arange(201))
+    for r in range(200):
+        seg = out_col[out_row[r]:out_row[r + 1]]
+        assert seg[0] == r and np.array_equal(seg[1:], col[row_ptr[r]:row_ptr[r + 1]])
+
+
+# ---- the product library's host helpers (no GPU needed: they only touch host tensors) ----
+def test_library_random_positive_int_matches_oracle(wm_lib):
+    import wholegraph_amd.torch.wholegraph_ops as wops
+    for seed, sub, n in [(1, 0, 10), (12345, 7, 100), (2 ** 40 + 3, 1000, 33)]:
+        got = wops.generate_random_positive_int_cpu(seed, sub, n).numpy()
+        assert np.array_equal(got, oracle.random_positive_int(seed, sub, n))
+        assert got.min() >= 0
+
+
+def test_library_exponential_helper(wm_lib):
+    import wholegraph_amd.torch.wholegraph_ops as wops
+    v = wops.generate_exponential_distribution_negative_float_cpu(99, 3, 20000).numpy().astype(np.float64)
+    assert np.all(v < 0) and np.all(np.isfinite(v))
+    # log2 of a uniform(0,1): mean -1/ln2, P(v < -1) = 1/2
+    assert abs(v.mean() + 1 / np.log(2)) < 0.05
+    assert abs((v < -1).mean() - 0.5) < 0.02
+    again = wops.generate_exponential_distribution_negative_float_cpu(99, 3, 20000).numpy()
+    assert np.array_equal(again.astype(np.float64), v)
+
+
+def test_weighted_sampler_reports_not_implemented(wm_lib):
+    from wholegraph_amd import binding as wmb
+    rc = wm_lib.wholegraph_csr_weighted_sample_without_replacement(None, None, None, None, 1, None, None, None, None, 0,
+                                                                   None, None)
+    assert wmb.ERROR_NAMES[rc] == "WHOLEMEMORY_NOT_IMPLEMENTED"

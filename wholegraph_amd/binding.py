@@ -231,6 +231,16 @@ PROTOTYPES = {
     "wholememory_embedding_get_optimizer_state": (_vp, [_vp, C.c_char_p]),
     "wholememory_embedding_writeback_cache": (_i, [_vp, _i64]),
     "wholememory_embedding_drop_all_cache": (_i, [_vp, _i64]),
+    # wholegraph_op.h
+    "wholegraph_csr_unweighted_sample_without_replacement": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.c_ulonglong,
+                                                                 _P(EnvFunc), _vp]),
+    "wholegraph_csr_weighted_sample_without_replacement": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+                                                               C.c_ulonglong, _P(EnvFunc), _vp]),
+    "generate_random_positive_int_cpu": (_i, [_i64, _i64, _vp]),
+    "generate_exponential_distribution_negative_float_cpu": (_i, [_i64, _i64, _vp]),
+    # graph_op.h
+    "graph_append_unique": (_i, [_vp, _vp, _vp, _vp, _P(EnvFunc), _vp]),
+    "csr_add_self_loop": (_i, [_vp, _vp, _vp, _vp, _vp]),
     # wholegraph_amd_ext.h
     "wholememory_create_communicator_ext": (_i, [_P(_vp), _i, _i, _P(ExtCollectives)]),
     "wholememory_ext_bucket_ids": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _vp, _P(EnvFunc), _vp]),

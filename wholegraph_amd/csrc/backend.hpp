@@ -72,6 +72,22 @@ struct wm_optimizer_args {
                                // folded by one wave)
 };
 
+// neighbour sampling on a CSR graph whose arrays are mapped (flat or chunked) in this process
+struct wm_sample_args {
+  wholememory_gref_t row_gref, col_gref;  // csr_row_ptr (int64), csr_col_ptr (col_dtype)
+  int64_t row_storage_offset, col_storage_offset;  // elements
+  wholememory_dtype_t col_dtype;
+  const void* centers;  // [n_center] device
+  wholememory_dtype_t center_dtype;
+  int n_center;
+  int max_sample_count;  // <= 0: every neighbour
+  uint64_t random_seed;
+  const int* sample_offsets;  // [n_center + 1] device, exclusive prefix of the per-center counts
+  void* out_ids;              // [total] col_dtype
+  int* out_center_lid;        // [total] or nullptr
+  int64_t* out_edge_gid;      // [total] or nullptr
+};
+
 struct wm_device_backend {
   const char* name;
   // memory / stream
@@ -115,6 +131,21 @@ struct wm_device_backend {
   int (*round_robin_map)(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n,
                          int64_t entry_start, int world_size, int round_robin_size, void* stream);
   int (*fill_float)(float* p, float value, int64_t count, void* stream);
+  // ---- graph ops (kernels/graph.hip); nullptr in a backend that does not provide them ----
+  // counts[i] = min(degree(center i), max_sample) for i < n, counts[n] = 0
+  int (*sample_counts)(const wholememory_gref_t* row_gref, int64_t row_storage_offset, const void* centers,
+                       wholememory_dtype_t center_dtype, int n, int max_sample, int* counts, void* stream);
+  size_t (*scan_i32_workspace_bytes)(int64_t n);
+  int (*exclusive_scan_i32)(const int* in, int* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
+  int (*sample_unweighted)(const wm_sample_args* a, void* stream);
+  // append_unique in two phases around the host learning the output size: phase 1 leaves the number of neighbour ids
+  // that are not targets in *new_count_dev, phase 2 writes the unique array and the raw->unique mapping
+  size_t (*append_unique_workspace_bytes)(int n_target, int n_neighbor, wholememory_dtype_t dtype);
+  int (*append_unique_phase1)(const void* targets, int n_target, const void* neighbors, int n_neighbor,
+                              wholememory_dtype_t dtype, void* workspace, int* new_count_dev, void* stream);
+  int (*append_unique_phase2)(const void* targets, int n_target, int n_neighbor, wholememory_dtype_t dtype, void* workspace,
+                              void* out_unique, int* mapping, void* stream);
+  int (*csr_add_self_loop)(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
 };
 
 }  // extern "C"

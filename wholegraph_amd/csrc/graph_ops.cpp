@@ -1,0 +1,330 @@
+// wholegraph_amd — host side of neighbour sampling and the small graph utilities (the C ABI of
+// include/wholememory/wholegraph_op.h and graph_op.h). Kernels: kernels/graph.hip.
+//
+// Reference call stacks: wholegraph_csr_unweighted_sample_without_replacement
+//   cpp/src/wholegraph_ops/unweighted_sample_without_replacement.cpp:24-190 (validation, dispatch on memory type)
+//   -> ..._impl_mapped.cu -> ..._func.cuh:283-470 (count, scan, D2H of the total, output allocation, sample kernel);
+// graph_append_unique cpp/src/graph_ops/append_unique.cpp:23-83 -> append_unique_func.cuh:300-353;
+// csr_add_self_loop cpp/src/graph_ops/csr_add_self_loop.cpp:22-80.
+#include <cmath>
+#include <cstring>
+
+#include <wholememory/graph_op.h>
+#include <wholememory/wholegraph_op.h>
+
+#include "ops_internal.hpp"
+#include "pcg.hpp"
+
+namespace {
+
+using namespace wm;
+
+#define WM_BK(call)                                                                   \
+  do {                                                                                \
+    int rc__ = (call);                                                                \
+    if (rc__ != 0) throw wm::hip_error(wm::format_string("%s failed: %d", #call, rc__)); \
+  } while (0)
+
+// one variable-size result handed to the caller's allocator (reference output_memory_handle.hpp:23-93)
+void* output_alloc(wholememory_env_func_t* env, void* memory_context, int64_t count, wholememory_dtype_t dtype)
+{
+  wholememory_tensor_description_t d;
+  wholememory_initialize_tensor_desc(&d);
+  d.dim            = 1;
+  d.sizes[0]       = count;
+  d.strides[0]     = 1;
+  d.dtype          = dtype;
+  d.storage_offset = 0;
+  return env->output_fns.malloc_fn(&d, WHOLEMEMORY_MA_DEVICE, memory_context, env->output_fns.global_context);
+}
+
+bool array_of(wholememory_tensor_t t, const char* what, wholememory_array_description_t* out, wholememory_error_code_t* err)
+{
+  if (t == nullptr) {
+    *err = WHOLEMEMORY_INVALID_INPUT;
+    return false;
+  }
+  auto desc = *wholememory_tensor_get_tensor_description(t);
+  auto* td  = &desc;
+  if (td->dim != 1) {
+    WM_ERROR("%s should be 1D tensor.", what);
+    *err = WHOLEMEMORY_INVALID_INPUT;
+    return false;
+  }
+  if (!wholememory_convert_tensor_desc_to_array(out, td)) {
+    WM_ERROR("%s convert to array failed.", what);
+    *err = WHOLEMEMORY_LOGIC_ERROR;
+    return false;
+  }
+  return true;
+}
+
+bool is_index_dtype(wholememory_dtype_t d) { return d == WHOLEMEMORY_DT_INT || d == WHOLEMEMORY_DT_INT64; }
+
+wholememory_memory_type_t memory_type_of(wholememory_tensor_t t)
+{
+  if (!wholememory_tensor_has_handle(t)) return WHOLEMEMORY_MT_NONE;
+  return wholememory_get_memory_type(wholememory_tensor_get_memory_handle(t));
+}
+
+const wm_device_backend* graph_backend()
+{
+  const auto* bk = backend();
+  if (bk->sample_unweighted == nullptr || bk->append_unique_phase1 == nullptr) return nullptr;
+  return bk;
+}
+
+}  // namespace
+
+extern "C" {
+
+wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replacement(
+  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor,
+  wholememory_tensor_t center_nodes_tensor, int max_sample_count, wholememory_tensor_t output_sample_offset_tensor,
+  void* output_dest_memory_context, void* output_center_localid_memory_context, void* output_edge_gid_memory_context,
+  unsigned long long random_seed, wholememory_env_func_t* p_env_fns, void* stream)
+{
+  WM_API_BEGIN
+  const auto* bk = graph_backend();
+  if (bk == nullptr) return WHOLEMEMORY_NOT_SUPPORTED;
+  if (p_env_fns == nullptr || output_dest_memory_context == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_error_code_t err = WHOLEMEMORY_SUCCESS;
+  wholememory_array_description_t row_desc, col_desc, center_desc, offset_desc;
+  if (!array_of(wm_csr_row_ptr_tensor, "wm_csr_row_ptr_tensor", &row_desc, &err)) return err;
+  if (!array_of(wm_csr_col_ptr_tensor, "wm_csr_col_ptr_tensor", &col_desc, &err)) return err;
+  if (!array_of(center_nodes_tensor, "center_nodes_tensor", &center_desc, &err)) return err;
+  if (!array_of(output_sample_offset_tensor, "output_sample_offset_tensor", &offset_desc, &err)) return err;
+  const auto row_mt = memory_type_of(wm_csr_row_ptr_tensor), col_mt = memory_type_of(wm_csr_col_ptr_tensor);
+  if (row_mt == WHOLEMEMORY_MT_HIERARCHY || col_mt == WHOLEMEMORY_MT_HIERARCHY) {
+    WM_ERROR("Memory type not supported.");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (row_mt == WHOLEMEMORY_MT_DISTRIBUTED || col_mt == WHOLEMEMORY_MT_DISTRIBUTED) {
+    // reference ..._impl_nccl.cu (gather of row_ptr pairs and of the sampled columns over NCCL): not built yet
+    WM_ERROR("neighbour sampling on DISTRIBUTED CSR tensors is not implemented in this build");
+    return WHOLEMEMORY_NOT_IMPLEMENTED;
+  }
+  // dtype rules of ..._func.cuh:304-314 and the dispatch table of ..._impl_mapped.cu (logic_error there)
+  if (row_desc.dtype != WHOLEMEMORY_DT_INT64) {
+    WM_ERROR("wm_csr_row_ptr_tensor must be int64, got %d", static_cast<int>(row_desc.dtype));
+    return WHOLEMEMORY_LOGIC_ERROR;
+  }
+  if (offset_desc.dtype != WHOLEMEMORY_DT_INT) {
+    WM_ERROR("output_sample_offset_tensor must be int32, got %d", static_cast<int>(offset_desc.dtype));
+    return WHOLEMEMORY_LOGIC_ERROR;
+  }
+  if (!is_index_dtype(col_desc.dtype) || !is_index_dtype(center_desc.dtype)) {
+    WM_ERROR("center nodes and csr_col_ptr must be int32 or int64");
+    return WHOLEMEMORY_LOGIC_ERROR;
+  }
+  const int64_t n = center_desc.size;
+  if (n >= (INT64_C(1) << 31) - 1) return WHOLEMEMORY_INVALID_INPUT;
+  if (offset_desc.size < n + 1) {
+    WM_ERROR("output_sample_offset_tensor needs %ld entries, has %ld", static_cast<long>(n + 1),
+             static_cast<long>(offset_desc.size));
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  wm_sample_args a{};
+  WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_row_ptr_tensor, &a.row_gref));
+  WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_col_ptr_tensor, &a.col_gref));
+  a.row_storage_offset = row_desc.storage_offset;
+  a.col_storage_offset = col_desc.storage_offset;
+  a.col_dtype          = col_desc.dtype;
+  a.centers            = wholememory_tensor_get_data_pointer(center_nodes_tensor);
+  a.center_dtype       = center_desc.dtype;
+  a.n_center           = static_cast<int>(n);
+  a.max_sample_count   = max_sample_count;
+  a.random_seed        = random_seed;
+  int* offsets         = static_cast<int*>(wholememory_tensor_get_data_pointer(output_sample_offset_tensor));
+  a.sample_offsets     = offsets;
+
+  // per-center counts -> exclusive scan into the caller's offset tensor -> total on the host
+  temp_mem counts_mem(p_env_fns), scan_mem(p_env_fns);
+  int* counts           = static_cast<int*>(counts_mem.device(n + 1, WHOLEMEMORY_DT_INT));
+  const size_t scan_ws  = bk->scan_i32_workspace_bytes(n + 1);
+  void* scan_ws_ptr     = scan_mem.device(static_cast<int64_t>(scan_ws), WHOLEMEMORY_DT_INT8);
+  WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, a.centers, a.center_dtype, a.n_center, max_sample_count, counts,
+                          stream));
+  WM_BK(bk->exclusive_scan_i32(counts, offsets, n + 1, scan_ws_ptr, scan_ws, stream));
+  int total = 0;
+  WM_BK(bk->memcpy_async(&total, offsets + n, sizeof(int), stream));
+  WM_BK(bk->stream_sync(stream));
+
+  a.out_ids = output_alloc(p_env_fns, output_dest_memory_context, total, col_desc.dtype);
+  if (output_center_localid_memory_context != nullptr)
+    a.out_center_lid = static_cast<int*>(output_alloc(p_env_fns, output_center_localid_memory_context, total, WHOLEMEMORY_DT_INT));
+  if (output_edge_gid_memory_context != nullptr)
+    a.out_edge_gid = static_cast<int64_t*>(output_alloc(p_env_fns, output_edge_gid_memory_context, total, WHOLEMEMORY_DT_INT64));
+  if (total > 0) {
+    if (a.out_ids == nullptr) return WHOLEMEMORY_OUT_OF_MEMORY;
+    WM_BK(bk->sample_unweighted(&a, stream));
+  }
+  WM_BK(bk->stream_sync(stream));  // the reference returns with the samples complete (:385,:404)
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t wholegraph_csr_weighted_sample_without_replacement(
+  wholememory_tensor_t, wholememory_tensor_t, wholememory_tensor_t, wholememory_tensor_t, int, wholememory_tensor_t, void*,
+  void*, void*, unsigned long long, wholememory_env_func_t*, void*)
+{
+  WM_ERROR("weighted neighbour sampling is not implemented in this build");
+  return WHOLEMEMORY_NOT_IMPLEMENTED;
+}
+
+wholememory_error_code_t generate_random_positive_int_cpu(int64_t random_seed, int64_t subsequence, wholememory_tensor_t output)
+{
+  WM_API_BEGIN
+  if (output == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  const auto d = *wholememory_tensor_get_tensor_description(output);
+  if (d.dim != 1) {
+    WM_ERROR("output should be 1D tensor.");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (!is_index_dtype(d.dtype)) {
+    WM_ERROR("output should be int64 or int32 tensor.");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  void* p = wholememory_tensor_get_data_pointer(output);
+  pcg32 rng(static_cast<uint64_t>(random_seed), 0, static_cast<uint64_t>(subsequence));
+  for (int64_t i = 0; i < d.sizes[0]; i++) {
+    if (d.dtype == WHOLEMEMORY_DT_INT)
+      static_cast<int32_t*>(p)[i] = rng.next_i32();
+    else
+      static_cast<int64_t*>(p)[i] = rng.next_i64();
+  }
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t generate_exponential_distribution_negative_float_cpu(int64_t random_seed, int64_t subsequence,
+                                                                              wholememory_tensor_t output)
+{
+  WM_API_BEGIN
+  if (output == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  const auto d = *wholememory_tensor_get_tensor_description(output);
+  if (d.dim != 1) {
+    WM_ERROR("output should be 1D tensor.");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (d.dtype != WHOLEMEMORY_DT_FLOAT) {
+    WM_ERROR("output should be float.");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  float* p = static_cast<float*>(wholememory_tensor_get_data_pointer(output));
+  pcg32 rng(static_cast<uint64_t>(random_seed), 0, static_cast<uint64_t>(subsequence));
+  // log2 of a uniform in (0,1) built from a mantissa in [0.5,1) and a geometric exponent = the number of leading zero
+  // bits of a 64-bit stream (redrawn while it is all zeros): raft_random_gen.cu:83-105
+  for (int64_t i = 0; i < d.sizes[0]; i++) {
+    float u = rng.next_float();
+    u       = static_cast<float>(-(0.5 + 0.5 * static_cast<double>(u)));
+    uint64_t bits;
+    int redraws = -1;
+    do {
+      bits = rng.next_u64();
+      redraws++;
+    } while (bits == 0);
+    const int zeros = __builtin_clzll(bits) + redraws * 64;
+    u               = static_cast<float>(static_cast<double>(u) * std::pow(2.0, -zeros));
+    p[i]            = static_cast<float>(std::log1p(static_cast<double>(u)) / std::log(2.0));
+  }
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t graph_append_unique(wholememory_tensor_t target_nodes_tensor,
+                                             wholememory_tensor_t neighbor_nodes_tensor,
+                                             void* output_unique_node_memory_context,
+                                             wholememory_tensor_t output_neighbor_raw_to_unique_mapping_tensor,
+                                             wholememory_env_func_t* p_env_fns, void* stream)
+{
+  WM_API_BEGIN
+  const auto* bk = graph_backend();
+  if (bk == nullptr) return WHOLEMEMORY_NOT_SUPPORTED;
+  if (p_env_fns == nullptr || output_unique_node_memory_context == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_error_code_t err = WHOLEMEMORY_SUCCESS;
+  wholememory_array_description_t target_desc, neighbor_desc;
+  if (!array_of(target_nodes_tensor, "target_nodes_tensor", &target_desc, &err)) return err;
+  if (!array_of(neighbor_nodes_tensor, "neighbor_nodes_tensor", &neighbor_desc, &err)) return err;
+  if (target_desc.dtype != neighbor_desc.dtype) {  // append_unique.cpp:45-49
+    WM_ERROR("target_nodes_dtype should be the same with neighbor_nodes_dtype");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (!is_index_dtype(target_desc.dtype)) {
+    WM_ERROR("node ids must be int32 or int64");
+    return WHOLEMEMORY_LOGIC_ERROR;
+  }
+  int* mapping = nullptr;
+  if (output_neighbor_raw_to_unique_mapping_tensor != nullptr) {
+    wholememory_array_description_t map_desc;
+    if (!array_of(output_neighbor_raw_to_unique_mapping_tensor, "output_neighbor_raw_to_unique_mapping_tensor", &map_desc, &err))
+      return err;
+    if (map_desc.size != neighbor_desc.size) {  // append_unique.cpp:63-68
+      WM_ERROR("output_neighbor_raw_to_unique_mapping size should be the same as neighbor_nodes");
+      return WHOLEMEMORY_INVALID_INPUT;
+    }
+    if (map_desc.dtype != WHOLEMEMORY_DT_INT) {
+      WM_ERROR("output_neighbor_raw_to_unique_mapping must be int32");
+      return WHOLEMEMORY_LOGIC_ERROR;
+    }
+    mapping = static_cast<int*>(wholememory_tensor_get_data_pointer(output_neighbor_raw_to_unique_mapping_tensor));
+  }
+  if (target_desc.size + neighbor_desc.size >= (INT64_C(1) << 31) - 1) return WHOLEMEMORY_INVALID_INPUT;
+  const int nt = static_cast<int>(target_desc.size), nn = static_cast<int>(neighbor_desc.size);
+  const void* targets   = wholememory_tensor_get_data_pointer(target_nodes_tensor);
+  const void* neighbors = wholememory_tensor_get_data_pointer(neighbor_nodes_tensor);
+  if (nt + nn == 0) {
+    (void)output_alloc(p_env_fns, output_unique_node_memory_context, 0, target_desc.dtype);
+    return WHOLEMEMORY_SUCCESS;
+  }
+  temp_mem ws_mem(p_env_fns), count_mem(p_env_fns);
+  void* ws       = ws_mem.device(static_cast<int64_t>(bk->append_unique_workspace_bytes(nt, nn, target_desc.dtype)), WHOLEMEMORY_DT_INT8);
+  int* count_dev = static_cast<int*>(count_mem.device(1, WHOLEMEMORY_DT_INT));
+  WM_BK(bk->append_unique_phase1(targets, nt, neighbors, nn, target_desc.dtype, ws, count_dev, stream));
+  int new_count = 0;
+  WM_BK(bk->memcpy_async(&new_count, count_dev, sizeof(int), stream));
+  WM_BK(bk->stream_sync(stream));
+  void* out = output_alloc(p_env_fns, output_unique_node_memory_context, static_cast<int64_t>(nt) + new_count, target_desc.dtype);
+  if (out == nullptr) return WHOLEMEMORY_OUT_OF_MEMORY;
+  WM_BK(bk->append_unique_phase2(targets, nt, nn, target_desc.dtype, ws, out, mapping, stream));
+  WM_BK(bk->stream_sync(stream));
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+wholememory_error_code_t csr_add_self_loop(wholememory_tensor_t csr_row_ptr_tensor, wholememory_tensor_t csr_col_ptr_tensor,
+                                           wholememory_tensor_t output_csr_row_ptr_tensor,
+                                           wholememory_tensor_t output_csr_col_ptr_tensor, void* stream)
+{
+  WM_API_BEGIN
+  const auto* bk = graph_backend();
+  if (bk == nullptr) return WHOLEMEMORY_NOT_SUPPORTED;
+  wholememory_error_code_t err = WHOLEMEMORY_SUCCESS;
+  wholememory_array_description_t row_desc, col_desc, out_row_desc, out_col_desc;
+  if (!array_of(csr_row_ptr_tensor, "csr_row_ptr_tensor", &row_desc, &err)) return err;
+  if (!array_of(csr_col_ptr_tensor, "csr_col_ptr_tensor", &col_desc, &err)) return err;
+  if (!array_of(output_csr_row_ptr_tensor, "output_csr_row_ptr_tensor", &out_row_desc, &err)) return err;
+  if (!array_of(output_csr_col_ptr_tensor, "output_csr_col_ptr_tensor", &out_col_desc, &err)) return err;
+  // int32 only: csr_add_self_loop.cpp:32-63
+  if (row_desc.dtype != WHOLEMEMORY_DT_INT || col_desc.dtype != WHOLEMEMORY_DT_INT || out_row_desc.dtype != WHOLEMEMORY_DT_INT ||
+      out_col_desc.dtype != WHOLEMEMORY_DT_INT) {
+    WM_ERROR("csr_add_self_loop works on int32 CSR arrays");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  // the reference launches without looking at the output sizes; writing past a short output is refused here
+  if (row_desc.size < 1 || out_row_desc.size < row_desc.size || out_col_desc.size < col_desc.size + row_desc.size - 1) {
+    WM_ERROR("csr_add_self_loop outputs need %ld row and %ld col entries", static_cast<long>(row_desc.size),
+             static_cast<long>(col_desc.size + row_desc.size - 1));
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  WM_BK(bk->csr_add_self_loop(static_cast<const int*>(wholememory_tensor_get_data_pointer(csr_row_ptr_tensor)),
+                              static_cast<const int*>(wholememory_tensor_get_data_pointer(csr_col_ptr_tensor)),
+                              static_cast<int*>(wholememory_tensor_get_data_pointer(output_csr_row_ptr_tensor)),
+                              static_cast<int*>(wholememory_tensor_get_data_pointer(output_csr_col_ptr_tensor)),
+                              static_cast<int>(row_desc.size - 1), stream));
+  WM_BK(bk->stream_sync(stream));
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+}  // extern "C"

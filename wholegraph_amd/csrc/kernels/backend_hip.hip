@@ -19,6 +19,17 @@ size_t hip_long_run_ws_bytes(int64_t n_recv);
 int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n, int64_t entry_start,
                         int world_size, int round_robin_size, void* stream);
 int hip_fill_float(float* p, float value, int64_t count, void* stream);
+int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const void* centers, wholememory_dtype_t id_dtype,
+                      int n, int max_sample, int* counts, void* stream);
+size_t hip_scan_i32_ws_bytes(int64_t n);
+int hip_exclusive_scan_i32(const int* in, int* out, int64_t n, void* ws, size_t ws_bytes, void* stream);
+int hip_sample_unweighted(const wm_sample_args* a, void* stream);
+size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt);
+int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, wholememory_dtype_t dt, void* ws,
+                             int* new_count_dev, void* stream);
+int hip_append_unique_phase2(const void* targets, int nt, int nn, wholememory_dtype_t dt, void* ws, void* out_unique,
+                             int* mapping, void* stream);
+int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
 
 namespace {
 
@@ -121,6 +132,14 @@ const wm_device_backend kHipBackend = {
   hip_long_run_ws_bytes,
   hip_round_robin_map,
   hip_fill_float,
+  hip_sample_counts,
+  hip_scan_i32_ws_bytes,
+  hip_exclusive_scan_i32,
+  hip_sample_unweighted,
+  hip_append_unique_ws_bytes,
+  hip_append_unique_phase1,
+  hip_append_unique_phase2,
+  hip_csr_add_self_loop,
 };
 
 }  // namespace

@@ -1,0 +1,470 @@
+// wholegraph_amd — neighbour sampling and small graph utilities (gfx950 HIP).
+//
+// Reference behaviour (cpp/src/wholegraph_ops/unweighted_sample_without_replacement_func.cuh:40-300,
+// cpp/src/graph_ops/append_unique_func.cuh:212-353, csr_add_self_loop_func.cuh:24-58):
+//   * per center node, min(degree, M) distinct neighbours. For degree > M the reference draws r[i] =
+//     rand_i % (N - i), i < M, from per-"thread" PCG streams and resolves the sequential index-sampling recurrence
+//         Q = iota(N);  a[i] = Q[r[i]];  Q[r[i]] = Q[N - 1 - i]
+//     (its own host statement: tests/wholegraph_ops/graph_sampling_test_utils.cu:306-321) with a block radix sort
+//     + pointer-jumping chain in shared memory; for M > 1024 it switches to a reservoir with atomicMax.
+//   * the random stream of draw i is fixed by the reference's LAUNCH geometry: virtual thread j = i % T of block b
+//     uses PCG stream b*T + j and its (i / T)-th draw (T, items per thread from max_sample_count).
+// MI355X design: ONE WAVE PER CENTER NODE, no block-wide sort. The recurrence touches at most 2M positions of Q, so Q
+// is kept as a sparse (position -> value) list in LDS and each of the M sequential steps looks its two positions up
+// with a 64-lane parallel scan + ballot (M = 30 fan-out: 30 steps x 1 scan). Draws are produced in parallel, each
+// lane building the PCG stream of the virtual thread that owns its draw. Results are a pure function of
+// (seed, center index, M, CSR row) and identical to the recurrence above; no atomics, no sort.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../backend.hpp"
+#include "../pcg.hpp"
+
+namespace wm {
+namespace {
+
+constexpr int kBlock        = 256;
+constexpr int kWavesPerBlk  = kBlock / 64;
+constexpr int kMaxSparse    = 1024;  // M <= 1024 on the sparse-recurrence path (the reference's small-sample limit)
+
+struct gref_view {
+  char* base;
+  char* const* rank_ptrs;
+  const size_t* rank_offsets;
+  size_t chunk_stride;
+  int world_size;
+  int same_chunk;
+};
+
+inline gref_view make_view(const wholememory_gref_t& g)
+{
+  gref_view v{};
+  v.chunk_stride = g.stride;
+  v.world_size   = g.world_size;
+  v.same_chunk   = g.same_chunk ? 1 : 0;
+  if (g.stride == 0) {
+    v.base = static_cast<char*>(g.pointer);
+  } else {
+    v.rank_ptrs    = static_cast<char* const*>(g.pointer);
+    v.rank_offsets = g.rank_memory_offsets;
+  }
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T gref_load(const gref_view& v, int64_t elem_index)
+{
+  const size_t off = static_cast<size_t>(elem_index) * sizeof(T);
+  if (v.chunk_stride == 0) return *reinterpret_cast<const T*>(v.base + off);
+  int rank;
+  size_t start;
+  if (v.same_chunk) {
+    rank  = static_cast<int>(off / v.chunk_stride);
+    start = static_cast<size_t>(rank) * v.chunk_stride;
+  } else {
+    rank = 0;
+    for (int r = 1; r < v.world_size; r++)
+      if (off >= v.rank_offsets[r]) rank = r;
+    start = v.rank_offsets[rank];
+  }
+  return *reinterpret_cast<const T*>(v.rank_ptrs[rank] + (off - start));
+}
+
+// ------------------------------------------------------------------------------------------------ counts
+template <typename IdT>
+__global__ void sample_count_kernel(gref_view row_ptr, int64_t row_off, const IdT* centers, int n, int max_sample,
+                                    int* counts)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    counts[n] = 0;  // the scan runs over n + 1 entries (reference :334-338)
+    return;
+  }
+  const int64_t nid = static_cast<int64_t>(centers[i]);
+  const int64_t s   = gref_load<int64_t>(row_ptr, row_off + nid);
+  const int64_t e   = gref_load<int64_t>(row_ptr, row_off + nid + 1);
+  int deg           = static_cast<int>(e - s);
+  if (max_sample > 0) deg = min(deg, max_sample);  // <= 0 means "all neighbours"
+  counts[i] = deg;
+}
+
+// ------------------------------------------------------------------------------------------------ sampling
+struct sample_params {
+  gref_view row_ptr, col_ptr;
+  int64_t row_off, col_off;  // storage offsets (elements)
+  const void* centers;
+  int n_center;
+  int max_sample;
+  uint64_t seed;
+  const int* offsets;  // [n + 1]
+  void* out_ids;       // ColT
+  int* out_lid;        // optional
+  int64_t* out_egid;   // optional
+};
+
+template <typename IdT, typename ColT>
+__global__ __launch_bounds__(kBlock) void sample_sparse_kernel(sample_params p)
+{
+  // per wave: draws r[], sampled positions a[] and the sparse image of Q
+  extern __shared__ int lds[];
+  const int M       = p.max_sample;
+  const int wave_in = threadIdx.x >> 6;
+  const int lane    = threadIdx.x & 63;
+  int* r_s          = lds + wave_in * (4 * M);
+  int* a_s          = r_s + M;
+  int* qpos         = a_s + M;
+  int* qval         = qpos + M;
+  const int center  = blockIdx.x * kWavesPerBlk + wave_in;
+  if (center >= p.n_center) return;
+  const IdT* centers = static_cast<const IdT*>(p.centers);
+  ColT* out          = static_cast<ColT*>(p.out_ids);
+  const int64_t nid  = static_cast<int64_t>(centers[center]);
+  const int64_t s    = gref_load<int64_t>(p.row_ptr, p.row_off + nid);
+  const int64_t e    = gref_load<int64_t>(p.row_ptr, p.row_off + nid + 1);
+  const int N        = static_cast<int>(e - s);
+  if (N <= 0) return;
+  const int off = p.offsets[center];
+  if (M <= 0 || N <= M) {  // every neighbour (reference sample_all_kernel / the `neighbor_count <= max` branches)
+    for (int i = lane; i < N; i += 64) {
+      out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
+      if (p.out_lid) p.out_lid[off + i] = center;
+      if (p.out_egid) p.out_egid[off + i] = s + i;
+    }
+    return;
+  }
+  // draws: id i belongs to virtual thread j = i % T (stream center*T + j), its (i / T)-th draw
+  const sample_geometry g = sample_geometry_for(M);
+  for (int i = lane; i < M; i += 64) {
+    const int j = i % g.threads, k = i / g.threads;
+    pcg32 rng(p.seed, 0, static_cast<uint64_t>(center) * g.threads + j);
+    int32_t v = 0;
+    for (int q = 0; q <= k; q++) v = rng.next_i32();
+    r_s[i] = v % (N - i);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // the recurrence, sequential in i, each lookup a parallel scan of the sparse list
+  int cnt = 0;  // wave-uniform
+  auto lookup = [&](int pos, int* idx_out) -> int {  // value of Q[pos]; *idx_out = list slot or -1
+    int found = -1;
+    for (int b = 0; b < cnt; b += 64) {
+      const int t         = b + lane;
+      const bool hit      = t < cnt && qpos[t] == pos;
+      const uint64_t mask = __ballot(hit);
+      if (mask) {
+        found = b + (__ffsll(static_cast<long long>(mask)) - 1);
+        break;
+      }
+    }
+    *idx_out = found;
+    return found >= 0 ? qval[found] : pos;
+  };
+  for (int i = 0; i < M; i++) {
+    const int x = r_s[i];
+    int ix, iy;
+    const int vx = lookup(x, &ix);
+    const int vy = lookup(N - 1 - i, &iy);
+    if (lane == 0) {
+      a_s[i] = vx;
+      if (ix >= 0) {
+        qval[ix] = vy;
+      } else {
+        qpos[cnt] = x;
+        qval[cnt] = vy;
+      }
+    }
+    if (ix < 0) cnt++;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int i = lane; i < M; i += 64) {
+    const int ai = a_s[i];
+    out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + ai);
+    if (p.out_lid) p.out_lid[off + i] = center;
+    if (p.out_egid) p.out_egid[off + i] = s + ai;
+  }
+}
+
+// M > 1024 (reference large_sample_kernel :62-130): reservoir of M slots; candidate idx >= M replaces slot
+// rand % (idx + 1) when that is < M, the LARGEST idx wins a slot. 32 virtual threads per center node (streams
+// center*32 + t), thread t visits idx = M + t, M + t + 32, ... with consecutive draws. One wave per center node,
+// lanes 0..31 play the virtual threads; like the reference, the slots live in the (>= 4-byte) output elements.
+template <typename IdT, typename ColT>
+__global__ __launch_bounds__(64) void sample_large_kernel(sample_params p)
+{
+  const int center = blockIdx.x;
+  const int lane   = threadIdx.x;
+  const int M      = p.max_sample;
+  const IdT* centers = static_cast<const IdT*>(p.centers);
+  ColT* out          = static_cast<ColT*>(p.out_ids);
+  const int64_t nid  = static_cast<int64_t>(centers[center]);
+  const int64_t s    = gref_load<int64_t>(p.row_ptr, p.row_off + nid);
+  const int64_t e    = gref_load<int64_t>(p.row_ptr, p.row_off + nid + 1);
+  const int N        = static_cast<int>(e - s);
+  if (N <= 0) return;
+  const int off = p.offsets[center];
+  if (N <= M) {
+    for (int i = lane; i < N; i += 64) {
+      out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
+      if (p.out_lid) p.out_lid[off + i] = center;
+      if (p.out_egid) p.out_egid[off + i] = s + i;
+    }
+    return;
+  }
+  auto slot = [&](int i) { return reinterpret_cast<int*>(out + off + i); };
+  for (int i = lane; i < M; i += 64) {
+    *slot(i) = i;
+    if (p.out_lid) p.out_lid[off + i] = center;
+  }
+  __syncthreads();
+  if (lane < 32) {
+    pcg32 rng(p.seed, 0, static_cast<uint64_t>(center) * 32 + lane);
+    for (int idx = M + lane; idx < N; idx += 32) {
+      const int32_t rnd = rng.next_i32() % (idx + 1);
+      if (rnd < M) atomicMax(slot(rnd), idx);
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < M; i += 64) {
+    const int ai = __hip_atomic_load(slot(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + ai);
+    if (p.out_egid) p.out_egid[off + i] = s + ai;
+  }
+}
+
+template <typename IdT, typename ColT>
+int launch_sample(const sample_params& p, hipStream_t stream)
+{
+  if (p.n_center == 0) return 0;
+  if (p.max_sample > kMaxSparse) {
+    hipLaunchKernelGGL((sample_large_kernel<IdT, ColT>), dim3(p.n_center), dim3(64), 0, stream, p);
+  } else {
+    const int M       = std::max(p.max_sample, 1);
+    const size_t lds  = static_cast<size_t>(kWavesPerBlk) * 4 * M * sizeof(int);
+    const int blocks  = (p.n_center + kWavesPerBlk - 1) / kWavesPerBlk;
+    hipLaunchKernelGGL((sample_sparse_kernel<IdT, ColT>), dim3(blocks), dim3(kBlock), lds, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ------------------------------------------------------------------------------------------------ append_unique
+template <typename KeyT>
+__global__ void concat_keys_kernel(const KeyT* targets, int nt, const KeyT* neighbors, int nn, KeyT* keys, int* pos)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nt + nn) return;
+  keys[i] = i < nt ? targets[i] : neighbors[i - nt];
+  pos[i]  = i;
+}
+
+template <typename KeyT>
+__global__ void run_heads_kernel(const KeyT* sorted, int n, int* head_index)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  head_index[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? i : 0;  // max-scan turns this into "index of my run head"
+}
+
+// first_flag[p] = 1 for a neighbour position p (0-based in the neighbour array) that is the first occurrence of an id
+// which is not a target
+__global__ void mark_new_kernel(const int* head_of, const int* sorted_pos, int n, int nt, int* first_flag)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (head_of[i] == i) {  // run head: the smallest original position of this id (stable sort)
+    const int p0 = sorted_pos[i];
+    if (p0 >= nt) first_flag[p0 - nt] = 1;
+  }
+}
+
+template <typename KeyT>
+__global__ void emit_unique_kernel(const KeyT* sorted, const int* head_of, const int* sorted_pos, const int* new_rank,
+                                   int n, int nt, KeyT* out_unique, int* mapping)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int h  = head_of[i];
+  const int p0 = sorted_pos[h];
+  const int uid = p0 < nt ? p0 : nt + new_rank[p0 - nt];
+  if (h == i && p0 >= nt) out_unique[uid] = sorted[i];
+  const int me = sorted_pos[i];
+  if (mapping != nullptr && me >= nt) mapping[me - nt] = uid;
+}
+
+struct max_op {
+  __host__ __device__ int operator()(int a, int b) const { return a > b ? a : b; }
+};
+
+template <typename KeyT>
+struct au_layout {
+  KeyT *keys, *sorted;
+  int *pos, *sorted_pos, *head, *first_flag, *new_rank;
+  void* temp;
+  size_t temp_bytes, total;
+};
+
+template <typename KeyT>
+au_layout<KeyT> au_plan(void* ws, int nt, int nn)
+{
+  const size_t n = static_cast<size_t>(nt) + nn;
+  auto al        = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  size_t sort_b = 0, scan_b = 0, scan2_b = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_b, static_cast<const KeyT*>(nullptr), static_cast<KeyT*>(nullptr),
+                                  static_cast<const int*>(nullptr), static_cast<int*>(nullptr), n, 0, 8 * sizeof(KeyT),
+                                  nullptr);
+  (void)rocprim::inclusive_scan(nullptr, scan_b, static_cast<const int*>(nullptr), static_cast<int*>(nullptr), n, max_op(),
+                                nullptr);
+  (void)rocprim::exclusive_scan(nullptr, scan2_b, static_cast<const int*>(nullptr), static_cast<int*>(nullptr), 0,
+                                static_cast<size_t>(nn) + 1, rocprim::plus<int>(), nullptr);
+  au_layout<KeyT> l;
+  char* p  = static_cast<char*>(ws);
+  size_t o = 0;
+  l.keys = reinterpret_cast<KeyT*>(p + o), o += al(sizeof(KeyT) * n);
+  l.sorted = reinterpret_cast<KeyT*>(p + o), o += al(sizeof(KeyT) * n);
+  l.pos = reinterpret_cast<int*>(p + o), o += al(4 * n);
+  l.sorted_pos = reinterpret_cast<int*>(p + o), o += al(4 * n);
+  l.head = reinterpret_cast<int*>(p + o), o += al(4 * n);
+  l.first_flag = reinterpret_cast<int*>(p + o), o += al(4 * (static_cast<size_t>(nn) + 1));
+  l.new_rank = reinterpret_cast<int*>(p + o), o += al(4 * (static_cast<size_t>(nn) + 1));
+  l.temp       = p + o;
+  l.temp_bytes = std::max(sort_b, std::max(scan_b, scan2_b));
+  l.total      = o + al(l.temp_bytes) + 256;
+  return l;
+}
+
+template <typename KeyT>
+int au_phase1(const void* targets, int nt, const void* neighbors, int nn, void* ws, int* new_count_dev, hipStream_t stream)
+{
+  using UKey     = typename std::make_unsigned<KeyT>::type;
+  auto l         = au_plan<UKey>(ws, nt, nn);
+  const int n    = nt + nn;
+  const int blks = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL((concat_keys_kernel<UKey>), dim3(blks), dim3(kBlock), 0, stream, static_cast<const UKey*>(targets), nt,
+                     static_cast<const UKey*>(neighbors), nn, l.keys, l.pos);
+  size_t tb = l.temp_bytes;
+  if (rocprim::radix_sort_pairs(l.temp, tb, l.keys, l.sorted, l.pos, l.sorted_pos, static_cast<size_t>(n), 0,
+                                8 * sizeof(KeyT), stream) != hipSuccess)
+    return -2;
+  hipLaunchKernelGGL((run_heads_kernel<UKey>), dim3(blks), dim3(kBlock), 0, stream, l.sorted, n, l.head);
+  tb = l.temp_bytes;
+  if (rocprim::inclusive_scan(l.temp, tb, l.head, l.head, static_cast<size_t>(n), max_op(), stream) != hipSuccess) return -2;
+  if (hipMemsetAsync(l.first_flag, 0, sizeof(int) * (static_cast<size_t>(nn) + 1), stream) != hipSuccess) return -2;
+  hipLaunchKernelGGL(mark_new_kernel, dim3(blks), dim3(kBlock), 0, stream, l.head, l.sorted_pos, n, nt, l.first_flag);
+  tb = l.temp_bytes;
+  if (rocprim::exclusive_scan(l.temp, tb, l.first_flag, l.new_rank, 0, static_cast<size_t>(nn) + 1, rocprim::plus<int>(),
+                              stream) != hipSuccess)
+    return -2;
+  // new_rank[nn] = number of new unique neighbours
+  if (hipMemcpyAsync(new_count_dev, l.new_rank + nn, sizeof(int), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -2;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename KeyT>
+int au_phase2(const void* targets, int nt, int nn, void* ws, void* out_unique, int* mapping, hipStream_t stream)
+{
+  using UKey     = typename std::make_unsigned<KeyT>::type;
+  auto l         = au_plan<UKey>(ws, nt, nn);
+  const int n    = nt + nn;
+  const int blks = (n + kBlock - 1) / kBlock;
+  if (nt > 0 && hipMemcpyAsync(out_unique, targets, sizeof(KeyT) * nt, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -2;
+  hipLaunchKernelGGL((emit_unique_kernel<UKey>), dim3(blks), dim3(kBlock), 0, stream, l.sorted, l.head, l.sorted_pos,
+                     l.new_rank, n, nt, static_cast<UKey*>(out_unique), mapping);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+__global__ void add_self_loop_kernel(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows)
+{
+  // reference csr_add_self_loop_func.cuh:24-44: block per row, the node itself first, then its neighbours
+  const int row = blockIdx.x;
+  const int s = row_ptr[row], e = row_ptr[row + 1];
+  if (threadIdx.x == 0) {
+    out_row[row] = s + row;
+    if (row == n_rows - 1) out_row[row + 1] = e + row + 1;
+  }
+  for (int k = threadIdx.x; k <= e - s; k += blockDim.x) out_col[s + row + k] = k == 0 ? row : col[s + k - 1];
+}
+
+}  // namespace
+
+// ---- launchers exported to backend_hip ----
+int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const void* centers, wholememory_dtype_t id_dtype,
+                      int n, int max_sample, int* counts, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  gref_view rv       = make_view(*row_gref);
+  const int blocks   = (n + 1 + 127) / 128;
+  if (id_dtype == WHOLEMEMORY_DT_INT)
+    hipLaunchKernelGGL((sample_count_kernel<int32_t>), dim3(blocks), dim3(128), 0, stream, rv, row_off,
+                       static_cast<const int32_t*>(centers), n, max_sample, counts);
+  else if (id_dtype == WHOLEMEMORY_DT_INT64)
+    hipLaunchKernelGGL((sample_count_kernel<int64_t>), dim3(blocks), dim3(128), 0, stream, rv, row_off,
+                       static_cast<const int64_t*>(centers), n, max_sample, counts);
+  else
+    return -1;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+size_t hip_scan_i32_ws_bytes(int64_t n)
+{
+  size_t b = 0;
+  (void)rocprim::exclusive_scan(nullptr, b, static_cast<const int*>(nullptr), static_cast<int*>(nullptr), 0,
+                                static_cast<size_t>(n), rocprim::plus<int>(), nullptr);
+  return b + 256;
+}
+int hip_exclusive_scan_i32(const int* in, int* out, int64_t n, void* ws, size_t ws_bytes, void* stream)
+{
+  size_t b = ws_bytes;
+  return rocprim::exclusive_scan(ws, b, in, out, 0, static_cast<size_t>(n), rocprim::plus<int>(),
+                                 static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -2;
+}
+
+int hip_sample_unweighted(const wm_sample_args* a, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  sample_params p{};
+  p.row_ptr = make_view(a->row_gref), p.col_ptr = make_view(a->col_gref);
+  p.row_off = a->row_storage_offset, p.col_off = a->col_storage_offset;
+  p.centers = a->centers, p.n_center = a->n_center, p.max_sample = a->max_sample_count;
+  p.seed = a->random_seed, p.offsets = a->sample_offsets;
+  p.out_ids = a->out_ids, p.out_lid = a->out_center_lid, p.out_egid = a->out_edge_gid;
+  const bool id32 = a->center_dtype == WHOLEMEMORY_DT_INT, col32 = a->col_dtype == WHOLEMEMORY_DT_INT;
+  if ((!id32 && a->center_dtype != WHOLEMEMORY_DT_INT64) || (!col32 && a->col_dtype != WHOLEMEMORY_DT_INT64)) return -1;
+  if (id32 && col32) return launch_sample<int32_t, int32_t>(p, stream);
+  if (id32) return launch_sample<int32_t, int64_t>(p, stream);
+  if (col32) return launch_sample<int64_t, int32_t>(p, stream);
+  return launch_sample<int64_t, int64_t>(p, stream);
+}
+
+size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt)
+{
+  return dt == WHOLEMEMORY_DT_INT ? au_plan<uint32_t>(nullptr, nt, nn).total : au_plan<uint64_t>(nullptr, nt, nn).total;
+}
+int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, wholememory_dtype_t dt, void* ws,
+                             int* new_count_dev, void* stream)
+{
+  if (dt == WHOLEMEMORY_DT_INT) return au_phase1<int32_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream));
+  if (dt == WHOLEMEMORY_DT_INT64) return au_phase1<int64_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream));
+  return -1;
+}
+int hip_append_unique_phase2(const void* targets, int nt, int nn, wholememory_dtype_t dt, void* ws, void* out_unique,
+                             int* mapping, void* stream)
+{
+  if (dt == WHOLEMEMORY_DT_INT) return au_phase2<int32_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream));
+  if (dt == WHOLEMEMORY_DT_INT64) return au_phase2<int64_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream));
+  return -1;
+}
+int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream)
+{
+  if (n_rows <= 0) return 0;
+  hipLaunchKernelGGL(add_self_loop_kernel, dim3(n_rows), dim3(64), 0, static_cast<hipStream_t>(stream), row_ptr, col, out_row,
+                     out_col, n_rows);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace wm

@@ -170,6 +170,11 @@ wholememory_gref_t local_shard_gref(wholememory_handle_t handle)
   return wholememory_create_continuous_global_reference(static_cast<char*>(p) - off);
 }
 
+namespace {
+wholememory_error_code_t mapped_gref(wholememory_tensor_t t, wholememory_gref_t* gref);
+}
+wholememory_error_code_t tensor_mapped_gref(wholememory_tensor_t t, wholememory_gref_t* gref) { return mapped_gref(t, gref); }
+
 int exchange_chunks(int world_size, int64_t rows_moved)
 {
   if (world_size <= 1) return 1;

@@ -83,4 +83,7 @@ std::vector<size_t> entry_offsets_of(wholememory_handle_t handle, size_t entry_b
 // flat gref through which GLOBAL row ids address this rank's shard
 wholememory_gref_t local_shard_gref(wholememory_handle_t handle);
 
+// gref a kernel should use for a tensor mapped in this process (CONTINUOUS / CHUNKED handle or a plain pointer)
+wholememory_error_code_t tensor_mapped_gref(wholememory_tensor_t t, wholememory_gref_t* gref);
+
 }  // namespace wm

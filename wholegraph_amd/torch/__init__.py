@@ -1,6 +1,7 @@
 """wholegraph_amd.torch — drop-in for the comm / initialize / tensor / embedding / ops subset of
 ``pylibwholegraph.torch`` (reference ``python/pylibwholegraph/pylibwholegraph/torch/__init__.py:14-78``).
-The graph-sampling / GNN-model / launcher helpers of the reference are outside this build's scope."""
+plus unweighted neighbour sampling / append_unique / add_csr_self_loop and GraphStructure. The GNN-model and
+launcher helpers of the reference are outside this build's scope."""
 from .comm import (
     WholeMemoryCommunicator,
     create_group_communicator,
@@ -35,3 +36,5 @@ from .tensor import (
 from .utils import get_part_file_name, get_part_file_list
 from .utils import wholememory_dtype_to_torch_dtype, torch_dtype_to_wholememory_dtype
 from .wholememory_ops import wholememory_gather_forward_functor, wholememory_scatter_functor
+from .graph_structure import GraphStructure
+from . import graph_ops, wholegraph_ops

@@ -6,6 +6,7 @@ callback env fns; the optional C++ torch extension of the reference is not neede
 """
 import ctypes as C
 import threading
+import weakref
 
 import torch
 
@@ -30,6 +31,42 @@ def get_stream(use_default=True):
         return 0
     s = torch.cuda.current_stream().cuda_stream
     return int(s) if s is not None else 0
+
+
+# Output memory contexts (variable-size results of sampling / append_unique): the caller creates one, passes its
+# integer key as the `void* memory_context` of the C call, and reads the tensor the library allocated through
+# output_fns.malloc_fn afterwards. reference wholegraph_env.py:42-82
+_OUTPUT_KEY_BASE = 1 << 40
+_output_contexts = weakref.WeakValueDictionary()
+_output_key_lock = threading.Lock()
+_output_next_key = [_OUTPUT_KEY_BASE]
+
+
+class TorchMemoryContext(object):
+    def __init__(self):
+        self.tensor = None
+        with _output_key_lock:
+            self.handle = _output_next_key[0]
+            _output_next_key[0] += 1
+        _output_contexts[self.handle] = self
+
+    def get_c_context(self):
+        return self.handle
+
+    def get_handle(self):
+        return self.handle
+
+    def set_tensor(self, t):
+        self.tensor = t
+
+    def get_tensor(self):
+        return self.tensor
+
+    def free(self):
+        self.tensor = None
+
+    def free_data(self):
+        self.tensor = None
 
 
 class _EnvTable(object):
@@ -74,11 +111,22 @@ class _EnvTable(object):
             t = torch.empty(shape, dtype=dtype, device="cpu", pin_memory=torch.cuda.is_available())
         else:
             t = torch.empty(shape, dtype=dtype, device="cpu")
+        key = int(ctx or 0)
+        if key >= _OUTPUT_KEY_BASE:
+            out = _output_contexts.get(key)
+            if out is not None:
+                out.set_tensor(t)
+            return t.data_ptr()
         with self._lock:
-            self._slots[int(ctx or 0)] = t
+            self._slots[key] = t
         return t.data_ptr()
 
     def _free_fn(self, ctx, _global):
+        if int(ctx or 0) >= _OUTPUT_KEY_BASE:
+            out = _output_contexts.get(int(ctx))
+            if out is not None:
+                out.set_tensor(None)
+            return
         with self._lock:
             if int(ctx or 0) in self._slots:
                 self._slots[int(ctx or 0)] = None

@@ -1,0 +1,91 @@
+"""Neighbour sampling on CSR graphs stored in WholeMemory.
+
+Mirror of ``python/pylibwholegraph/pylibwholegraph/torch/wholegraph_ops.py:27-209`` over the C ABI of
+``include/wholememory/wholegraph_op.h``. `wm_csr_*_tensor` arguments are `wholememory_tensor_t` handles
+(``WholeMemoryTensor.wmb_tensor``), exactly what the reference functions take."""
+import ctypes as C
+import random
+from typing import Union
+
+import torch
+
+from .. import binding as wmb
+from .wholegraph_env import TorchMemoryContext, get_stream, get_wholegraph_env_fns, op_device, wrap_torch_tensor
+
+
+def _handle(t):
+    return t.wmb_tensor if hasattr(t, "wmb_tensor") else t
+
+
+def _tensor_dim(h):
+    return int(wmb.lib().wholememory_tensor_get_tensor_description(h).contents.dim)
+
+
+def _sample_outputs(offset, dest, lid, egid, need_center_local_output, need_edge_output):
+    if need_edge_output and need_center_local_output:
+        return offset, dest.get_tensor(), lid.get_tensor(), egid.get_tensor()
+    if need_center_local_output:
+        return offset, dest.get_tensor(), lid.get_tensor()
+    if need_edge_output:
+        return offset, dest.get_tensor(), egid.get_tensor()
+    return offset, dest.get_tensor()
+
+
+def unweighted_sample_without_replacement(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, center_nodes_tensor: torch.Tensor,
+                                          max_sample_count: int, random_seed: Union[int, None] = None,
+                                          need_center_local_output: bool = False, need_edge_output: bool = False):
+    """For every center node, min(degree, max_sample_count) distinct neighbours (all when max_sample_count <= 0).
+    Returns (sample_offset int32 [n + 1], sampled node ids[, center local id int32][, edge id int64])."""
+    row, col = _handle(wm_csr_row_ptr_tensor), _handle(wm_csr_col_ptr_tensor)
+    assert _tensor_dim(row) == 1
+    assert _tensor_dim(col) == 1
+    assert center_nodes_tensor.dim() == 1
+    if random_seed is None:
+        random_seed = random.getrandbits(64)
+    offset = torch.empty(center_nodes_tensor.shape[0] + 1, device=op_device(), dtype=torch.int)
+    dest = TorchMemoryContext()
+    lid = TorchMemoryContext() if need_center_local_output else None
+    egid = TorchMemoryContext() if need_edge_output else None
+    wc, wo = wrap_torch_tensor(center_nodes_tensor), wrap_torch_tensor(offset)
+    wmb.check(wmb.lib().wholegraph_csr_unweighted_sample_without_replacement(
+        row, col, wc.handle, int(max_sample_count), wo.handle, C.c_void_p(dest.get_c_context()),
+        C.c_void_p(lid.get_c_context() if lid else 0), C.c_void_p(egid.get_c_context() if egid else 0),
+        C.c_ulonglong(random_seed & 0xFFFFFFFFFFFFFFFF), get_wholegraph_env_fns(), C.c_void_p(get_stream())))
+    return _sample_outputs(offset, dest, lid, egid, need_center_local_output, need_edge_output)
+
+
+def weighted_sample_without_replacement(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, wm_csr_weight_ptr_tensor,
+                                        center_nodes_tensor: torch.Tensor, max_sample_count: int,
+                                        random_seed: Union[int, None] = None, need_center_local_output: bool = False,
+                                        need_edge_output: bool = False):
+    """Weighted sampling: the entry point exists, the library answers WHOLEMEMORY_NOT_IMPLEMENTED (raises)."""
+    row, col, wgt = _handle(wm_csr_row_ptr_tensor), _handle(wm_csr_col_ptr_tensor), _handle(wm_csr_weight_ptr_tensor)
+    assert center_nodes_tensor.dim() == 1
+    if random_seed is None:
+        random_seed = random.getrandbits(64)
+    offset = torch.empty(center_nodes_tensor.shape[0] + 1, device=op_device(), dtype=torch.int)
+    dest = TorchMemoryContext()
+    lid = TorchMemoryContext() if need_center_local_output else None
+    egid = TorchMemoryContext() if need_edge_output else None
+    wc, wo = wrap_torch_tensor(center_nodes_tensor), wrap_torch_tensor(offset)
+    wmb.check(wmb.lib().wholegraph_csr_weighted_sample_without_replacement(
+        row, col, wgt, wc.handle, int(max_sample_count), wo.handle, C.c_void_p(dest.get_c_context()),
+        C.c_void_p(lid.get_c_context() if lid else 0), C.c_void_p(egid.get_c_context() if egid else 0),
+        C.c_ulonglong(random_seed & 0xFFFFFFFFFFFFFFFF), get_wholegraph_env_fns(), C.c_void_p(get_stream())))
+    return _sample_outputs(offset, dest, lid, egid, need_center_local_output, need_edge_output)
+
+
+def generate_random_positive_int_cpu(random_seed, sub_sequence, output_random_value_count):
+    output = torch.empty((output_random_value_count,), dtype=torch.int)
+    w = wrap_torch_tensor(output)
+    wmb.check(wmb.lib().generate_random_positive_int_cpu(int(random_seed), int(sub_sequence), w.handle))
+    return output
+
+
+def generate_exponential_distribution_negative_float_cpu(random_seed: int, sub_sequence: int,
+                                                         output_random_value_count: int):
+    output = torch.empty((output_random_value_count,), dtype=torch.float)
+    w = wrap_torch_tensor(output)
+    wmb.check(wmb.lib().generate_exponential_distribution_negative_float_cpu(int(random_seed), int(sub_sequence),
+                                                                             w.handle))
+    return output
