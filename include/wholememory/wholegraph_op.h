@@ -2,9 +2,9 @@
  * wholegraph_amd — neighbour sampling on CSR graphs held in WholeMemory (the step before the feature gather in
  * BASELINE config 5). Replaces reference cpp/include/wholememory/wholegraph_op.h:39-105.
  *
- * Built in this round: unweighted sampling without replacement on mapped (CONTINUOUS / CHUNKED / plain-pointer)
- * CSR tensors and the two host random helpers. The weighted sampler and the DISTRIBUTED-CSR variant return
- * WHOLEMEMORY_NOT_IMPLEMENTED. Random streams: see wholegraph_amd/csrc/pcg.hpp (parity with raft unpinned).
+ * Built: unweighted and weighted (max_sample_count <= 1024) sampling without replacement on mapped (CONTINUOUS /
+ * CHUNKED / plain-pointer) CSR tensors and the two host random helpers. DISTRIBUTED CSR tensors and weighted sampling
+ * of more than 1024 neighbours return WHOLEMEMORY_NOT_IMPLEMENTED. Random streams: see wholegraph_amd/csrc/pcg.hpp (parity with raft unpinned).
  */
 #ifndef WHOLEMEMORY_WHOLEGRAPH_OP_H_
 #define WHOLEMEMORY_WHOLEGRAPH_OP_H_
@@ -38,7 +38,11 @@ enum wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replaceme
   struct wholememory_env_func_t* p_env_fns,
   void* stream);
 
-/* reference wholegraph_op.h:70-82 — not built: WHOLEMEMORY_NOT_IMPLEMENTED */
+/*
+ * Weighted variant (A-Res: key = log2(u) / weight per neighbour, the max_sample_count largest keys win).
+ * wm_csr_weight_ptr_tensor: float32/float64 [n_edges]. Samples of one center node come out key-descending.
+ * max_sample_count > 1024 -> WHOLEMEMORY_NOT_IMPLEMENTED. reference wholegraph_op.h:70-82
+ */
 enum wholememory_error_code_t wholegraph_csr_weighted_sample_without_replacement(
   wholememory_tensor_t wm_csr_row_ptr_tensor,
   wholememory_tensor_t wm_csr_col_ptr_tensor,

@@ -113,6 +113,13 @@ def lib():
         L.wmo_sample_unweighted.restype = None
         L.wmo_sample_unweighted.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_int, c.c_int64, c.c_int,
                                             c.c_uint64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+        L.wmo_det_log2_1p.restype = c.c_double
+        L.wmo_det_log2_1p.argtypes = [c.c_double]
+        L.wmo_weighted_keys.restype = None
+        L.wmo_weighted_keys.argtypes = [c.c_uint64, c.c_uint64, c.c_int64, c.c_void_p, c.c_void_p]
+        L.wmo_sample_weighted.restype = None
+        L.wmo_sample_weighted.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_int, c.c_void_p, c.c_int,
+                                          c.c_int64, c.c_int, c.c_uint64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
         L.wmo_append_unique.restype = c.c_int64
         L.wmo_append_unique.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
         L.wmo_csr_add_self_loop.restype = None
@@ -401,6 +408,39 @@ def sample_unweighted(row_ptr, col, centers, max_sample, seed, need_lid=True, ne
     lib().wmo_sample_unweighted(_p(row_ptr), _p(col), 1 if col.dtype == np.int64 else 0, _p(centers), c64, n,
                                 max_sample, seed & 0xFFFFFFFFFFFFFFFF, _p(offsets), _p(ids),
                                 _p(lid) if need_lid else None, _p(egid) if need_egid else None)
+    return offsets, ids.astype(col.dtype), lid, egid
+
+
+def det_log2_1p(x):
+    return lib().wmo_det_log2_1p(float(x))
+
+
+def weighted_keys(seed, subsequence, weights):
+    """consecutive A-Res keys log2(u)/w of one PCG stream"""
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    keys = np.empty(w.shape[0], dtype=np.float32)
+    lib().wmo_weighted_keys(seed & 0xFFFFFFFFFFFFFFFF, subsequence, w.shape[0], _p(w), _p(keys))
+    return keys
+
+
+def sample_weighted(row_ptr, col, weights, centers, max_sample, seed, need_lid=True, need_egid=True):
+    """-> offsets, ids (key-descending per center), lid, egid"""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    col = np.ascontiguousarray(col)
+    weights = np.ascontiguousarray(weights)
+    assert weights.dtype in (np.float32, np.float64)
+    centers = np.ascontiguousarray(centers)
+    n = centers.shape[0]
+    offsets = np.empty(n + 1, dtype=np.int32)
+    c64 = 1 if centers.dtype == np.int64 else 0
+    total = lib().wmo_sample_offsets(_p(row_ptr), _p(centers), c64, n, max_sample, _p(offsets))
+    ids = np.empty(total, dtype=np.int64)
+    lid = np.empty(total, dtype=np.int32) if need_lid else None
+    egid = np.empty(total, dtype=np.int64) if need_egid else None
+    lib().wmo_sample_weighted(_p(row_ptr), _p(col), 1 if col.dtype == np.int64 else 0, _p(weights),
+                              1 if weights.dtype == np.float64 else 0, _p(centers), c64, n, max_sample,
+                              seed & 0xFFFFFFFFFFFFFFFF, _p(offsets), _p(ids), _p(lid) if need_lid else None,
+                              _p(egid) if need_egid else None)
     return offsets, ids.astype(col.dtype), lid, egid
 
 

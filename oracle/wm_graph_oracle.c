@@ -233,3 +233,111 @@ void wmo_csr_add_self_loop(const int32_t* row_ptr, const int32_t* col, int64_t n
   }
   out_row[n_rows] = row_ptr[n_rows] + (int32_t)n_rows;
 }
+
+/* ---- weighted sampling (A-Res), weighted_sample_without_replacement_func.cuh:44-63,183-300 and the reference's host
+ * statement tests/wholegraph_ops/graph_sampling_test_utils.cu:548-660 (virtual block of 128 threads, 256 when
+ * max_sample > 256; thread j keys neighbours j, j + block, ... from stream center * block + j; the max_sample largest
+ * keys win).
+ * The key needs log2(1 + x): the product computes it with a fixed sequence of +, *, / in double so that host and
+ * device agree bit for bit (wholegraph_amd/csrc/pcg.hpp:det_log2_1p); the same sequence is restated here, and
+ * tests/test_graph_oracle.py checks it against libm to 1e-15. Ties (never equal composite keys: the neighbour index is
+ * part of the key) break towards the smaller index; output order is key-descending. */
+double wmo_det_log2_1p(double x)
+{
+  const double inv_ln2 = 1.4426950408889634074, ln2 = 0.69314718055994530942;
+  if (x > -7.450580596923828125e-9) return (x - x * x * 0.5) * inv_ln2;
+  double U = 1.0 + x;
+  if (!(U > 0.0)) return -__builtin_inf();
+  uint64_t bits;
+  memcpy(&bits, &U, 8);
+  int e = (int)((bits >> 52) & 0x7ff) - 1023;
+  bits  = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+  double f;
+  memcpy(&f, &bits, 8);
+  if (f > 1.4142135623730951) {
+    f *= 0.5;
+    e += 1;
+  }
+  double s = (f - 1.0) / (f + 1.0), s2 = s * s, p = 2.0 / 27.0;
+  for (int k = 25; k >= 3; k -= 2) p = p * s2 + 2.0 / (double)k;
+  p = p * s2 + 2.0;
+  return ((double)e * ln2 + p * s) * inv_ln2;
+}
+
+static float weighted_key(pcg_t* g, float weight)
+{
+  float u0 = (float)(pcg_next(g) >> 8) / (float)(1u << 24);
+  float m  = (float)(-(0.5 + 0.5 * (double)u0));
+  uint64_t stream;
+  int redraws = -1;
+  do {
+    uint64_t lo = pcg_next(g), hi = pcg_next(g);
+    stream      = lo | (hi << 32);
+    redraws++;
+  } while (stream == 0);
+  int zeros = redraws * 64 + __builtin_clzll(stream);
+  double scale = 1.0;
+  for (int z = zeros; z > 0;) {
+    int step = z > 30 ? 30 : z;
+    scale *= 1.0 / (double)(1u << step);
+    z -= step;
+  }
+  float log2u = (float)wmo_det_log2_1p((double)m * scale);
+  return log2u * (1.0f / weight);
+}
+
+void wmo_weighted_keys(uint64_t seed, uint64_t subsequence, int64_t n, const float* weights, float* keys)
+{
+  pcg_t g;
+  pcg_for_thread(&g, seed, subsequence);
+  for (int64_t i = 0; i < n; i++) keys[i] = weighted_key(&g, weights[i]);
+}
+
+typedef struct {
+  float key;
+  int idx;
+} wkey_t;
+
+static int wkey_cmp(const void* a, const void* b)
+{
+  const wkey_t *x = (const wkey_t*)a, *y = (const wkey_t*)b;
+  if (x->key > y->key) return -1;
+  if (x->key < y->key) return 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+void wmo_sample_weighted(const int64_t* row_ptr, const void* col, int col_is64, const void* weights, int weight_is_double,
+                         const void* centers, int center_is64, int64_t n, int max_sample, uint64_t seed,
+                         const int32_t* offsets, int64_t* out_ids, int32_t* out_lid, int64_t* out_egid)
+{
+  int block = max_sample > 256 ? 256 : 128;
+  for (int64_t c = 0; c < n; c++) {
+    int64_t nid   = center_is64 ? ((const int64_t*)centers)[c] : ((const int32_t*)centers)[c];
+    int64_t start = row_ptr[nid], end = row_ptr[nid + 1];
+    int N = (int)(end - start), M = max_sample, off = offsets[c];
+    if (N <= 0) continue;
+    int take  = (M <= 0 || N <= M) ? N : M;
+    wkey_t* k = (wkey_t*)malloc(sizeof(wkey_t) * (size_t)N);
+    if (M <= 0 || N <= M) {
+      for (int i = 0; i < N; i++) k[i].idx = i;
+    } else {
+      for (int t = 0; t < block; t++) {
+        pcg_t g;
+        pcg_for_thread(&g, seed, (uint64_t)c * (uint64_t)block + (uint64_t)t);
+        for (int id = t; id < N; id += block) {
+          float w  = weight_is_double ? (float)((const double*)weights)[start + id] : ((const float*)weights)[start + id];
+          k[id].key = weighted_key(&g, w);
+          k[id].idx = id;
+        }
+      }
+      qsort(k, (size_t)N, sizeof(wkey_t), wkey_cmp);
+    }
+    for (int i = 0; i < take; i++) {
+      int64_t e       = start + k[i].idx;
+      out_ids[off + i] = col_is64 ? ((const int64_t*)col)[e] : ((const int32_t*)col)[e];
+      if (out_lid) out_lid[off + i] = (int32_t)c;
+      if (out_egid) out_egid[off + i] = e;
+    }
+    free(k);
+  }
+}

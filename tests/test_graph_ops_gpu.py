@@ -131,9 +131,71 @@ def test_sample_argument_errors(gpu_env):
         wops.unweighted_sample_without_replacement(wr32.handle, wc.handle, centers, 2, 1)
     with pytest.raises(wmb.WholeMemoryError):   # float ids
         wops.unweighted_sample_without_replacement(wr.handle, wc.handle, centers.float(), 2, 1)
-    with pytest.raises(wmb.WholeMemoryError) as e:
-        wops.weighted_sample_without_replacement(wr.handle, wc.handle, wc.handle, centers, 2, 1)
+    ww = wrap_torch_tensor(torch.ones(4, device="cuda"))
+    with pytest.raises(wmb.WholeMemoryError) as e:     # the in-LDS weighted selection covers 1..1024
+        wops.weighted_sample_without_replacement(wr.handle, wc.handle, ww.handle, centers, 1025, 1)
     assert "NOT_IMPLEMENTED" in str(e.value)
+    with pytest.raises(wmb.WholeMemoryError):          # integer weights
+        wops.weighted_sample_without_replacement(wr.handle, wc.handle, wc.handle, centers, 2, 1)
+    wshort = wrap_torch_tensor(torch.ones(3, device="cuda"))
+    with pytest.raises(wmb.WholeMemoryError):          # one weight per edge
+        wops.weighted_sample_without_replacement(wr.handle, wc.handle, wshort.handle, centers, 2, 1)
+
+
+@pytest.mark.parametrize("mt,loc", [("continuous", "cuda"), ("chunked", "cuda"), ("chunked", "cpu")])
+@pytest.mark.parametrize("center_dtype,col_dtype,wdtype", [(np.int64, np.int64, np.float32), (np.int32, np.int32, np.float64),
+                                                           (np.int64, np.int32, np.float32)])
+def test_weighted_sample_parity(gpu_env, mt, loc, center_dtype, col_dtype, wdtype):
+    """cpp/tests/wholegraph_ops/wholegraph_csr_weighted_sample_without_replacement_tests.cu:438-470 (memory types,
+    max_sample_count 10 / 300, int32 / int64 centers); keys are bit-identical on device and in the oracle, so the
+    comparison is exact and ordered (the reference compares per-center sorted sets)."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    row_ptr, col = _graph(col_dtype)
+    weights = (np.random.default_rng(99).random(col.shape[0]) * 3 + 0.01).astype(wdtype)
+    wrow, wcol = _wm_csr(gpu_env, mt, loc, row_ptr, col)
+    wwgt = wgth.create_wholememory_tensor(gpu_env, mt, loc, [weights.shape[0]], torch.from_numpy(weights).dtype, [1])
+    wwgt.get_local_tensor(host_view=(loc == "cpu"))[0].copy_(torch.from_numpy(weights))
+    torch.cuda.synchronize()
+    g = wgth.GraphStructure()
+    g.set_csr_graph(wrow, wcol)
+    g.set_edge_attribute("w", wwgt)
+    rng = np.random.default_rng(3)
+    centers = np.concatenate([np.arange(0, 20), rng.integers(0, 3000, 700)]).astype(center_dtype)
+    for m in (-1, 1, 10, 30, 64, 65, 128, 256, 257, 300, 1000, 1024):
+        seed = 77 * (m + 3) + 987654321987
+        off, ids, lid, egid = g.weighted_sample_without_replacement_one_hop(
+            "w", torch.from_numpy(centers).cuda(), m, random_seed=seed, need_center_local_output=True, need_edge_output=True)
+        o_off, o_ids, o_lid, o_egid = oracle.sample_weighted(row_ptr, col, weights, centers, m, seed)
+        assert np.array_equal(off.cpu().numpy(), o_off)
+        assert np.array_equal(egid.cpu().numpy(), o_egid), "edge ids differ at max_sample_count=%d" % m
+        assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(lid.cpu().numpy(), o_lid)
+    for t in (wrow, wcol, wwgt):
+        wgth.destroy_wholememory_tensor(t)
+
+
+def test_weighted_sample_follows_the_weights(gpu_env):
+    """With one sample per node, neighbour i is picked with probability w_i / sum(w)."""
+    import torch
+    import wholegraph_amd.torch.wholegraph_ops as wops
+    from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor
+    n_nb, trials = 8, 40000
+    w = np.array([1, 2, 3, 4, 5, 6, 7, 12], dtype=np.float32)
+    row_ptr = np.arange(0, (trials + 1) * n_nb, n_nb, dtype=np.int64)
+    col = np.tile(np.arange(n_nb, dtype=np.int32), trials)
+    wts = np.tile(w, trials)
+    hold = [torch.from_numpy(a).cuda() for a in (row_ptr, col, wts)]
+    wr, wc, ww = [wrap_torch_tensor(t) for t in hold]
+    centers = torch.arange(trials, device="cuda", dtype=torch.int32)
+    off, ids = wops.weighted_sample_without_replacement(wr.handle, wc.handle, ww.handle, centers, 1, 424242)
+    counts = np.bincount(ids.cpu().numpy(), minlength=n_nb).astype(np.float64)
+    expect = trials * w / w.sum()
+    chi2 = ((counts - expect) ** 2 / expect).sum()
+    assert chi2 < 40.0, "chi-square %.1f over 7 dof" % chi2   # p ~ 1e-6
+    # and without replacement: 3 of 8, all distinct
+    off, ids = wops.weighted_sample_without_replacement(wr.handle, wc.handle, ww.handle, centers, 3, 7)
+    ids = ids.cpu().numpy().reshape(trials, 3)
+    assert all(len(set(r.tolist())) == 3 for r in ids[:5000])
 
 
 @pytest.mark.parametrize("np_dtype", [np.int32, np.int64])

@@ -159,8 +159,63 @@ def test_library_exponential_helper(wm_lib):
     assert np.array_equal(again.astype(np.float64), v)
 
 
-def test_weighted_sampler_reports_not_implemented(wm_lib):
+def test_samplers_reject_null_arguments(wm_lib):
     from wholegraph_amd import binding as wmb
     rc = wm_lib.wholegraph_csr_weighted_sample_without_replacement(None, None, None, None, 1, None, None, None, None, 0,
                                                                    None, None)
-    assert wmb.ERROR_NAMES[rc] == "WHOLEMEMORY_NOT_IMPLEMENTED"
+    assert wmb.ERROR_NAMES[rc] == "WHOLEMEMORY_INVALID_INPUT"
+    rc = wm_lib.wholegraph_csr_unweighted_sample_without_replacement(None, None, None, 1, None, None, None, None, 0,
+                                                                     None, None)
+    assert wmb.ERROR_NAMES[rc] == "WHOLEMEMORY_INVALID_INPUT"
+
+
+# ---- weighted sampling ----
+def test_det_log2_1p_matches_libm():
+    rng = np.random.default_rng(0)
+    # the sampler only ever passes x = -(24-bit mantissa in [0.5, 1]) * 2^-k, for which 1 + x is exact
+    m24 = (0.5 + 0.5 * rng.random(6000).astype(np.float32)).astype(np.float32).astype(np.float64)
+    xs = np.concatenate([-m24[:2000], -m24[2000:] * 2.0 ** -rng.integers(1, 80, 4000).astype(np.float64),
+                         [-0.5, -0.25, -2.0 ** -27, -2.0 ** -28, -(1 - 2.0 ** -24) * 2.0 ** -3]])
+    for x in xs:
+        want = np.log1p(x) / np.log(2.0)
+        got = oracle.det_log2_1p(x)
+        assert abs(got - want) <= 1e-15 * abs(want) + 1e-300, (x, got, want)
+    assert oracle.det_log2_1p(-1.0) == -np.inf
+
+
+def test_weighted_keys_are_log2_uniform_over_weight():
+    w = np.ones(200000, dtype=np.float32)
+    k = oracle.weighted_keys(5, 11, w).astype(np.float64)
+    assert np.all(k < 0)
+    # -ln(2) * key ~ Exp(1): mean 1, P(> 1) = 1/e
+    x = -np.log(2.0) * k
+    assert abs(x.mean() - 1.0) < 0.01 and abs((x > 1.0).mean() - np.exp(-1)) < 0.005
+    # weight w scales the key by 1/w (same stream, same uniforms)
+    k4 = oracle.weighted_keys(5, 11, np.full(1000, 4.0, dtype=np.float32))
+    assert np.array_equal(k4, (k[:1000].astype(np.float32) * np.float32(0.25)))
+
+
+@pytest.mark.parametrize("m", [1, 7, 30, 128, 256, 257, 300])
+@pytest.mark.parametrize("wdtype", [np.float32, np.float64])
+def test_oracle_weighted_sampler_matches_reference_host_statement(m, wdtype):
+    row_ptr, col = make_csr(40, 60, 77 + m, heavy=[(2, 900), (9, 257), (10, 256), (11, 1)])
+    weights = (np.random.default_rng(m).random(col.shape[0]) + 0.05).astype(wdtype)
+    centers = np.array([2, 9, 10, 11, 0, 2, 33], dtype=np.int32)
+    seed = 0x1234567 + m
+    off, ids, lid, egid = oracle.sample_weighted(row_ptr, col, weights, centers, m, seed)
+    block = 256 if m > 256 else 128
+    want = []
+    for c, nid in enumerate(centers):
+        s, e = int(row_ptr[nid]), int(row_ptr[nid + 1])
+        n = e - s
+        if n <= m:
+            want += list(range(s, e))
+            continue
+        keys = np.empty(n, dtype=np.float32)
+        for t in range(min(block, n)):   # virtual thread t keys neighbours t, t + block, ... consecutively
+            sel = np.arange(t, n, block)
+            keys[sel] = oracle.weighted_keys(seed, c * block + t, weights[s + sel].astype(np.float32))
+        order = np.lexsort((np.arange(n), -keys.astype(np.float64)))[:m]
+        want += [s + int(i) for i in order]
+    assert np.array_equal(egid, np.array(want, dtype=np.int64))
+    assert np.array_equal(ids, col[egid]) and np.array_equal(lid, np.repeat(np.arange(len(centers)), np.diff(off)))

@@ -70,21 +70,18 @@ wholememory_memory_type_t memory_type_of(wholememory_tensor_t t)
 const wm_device_backend* graph_backend()
 {
   const auto* bk = backend();
-  if (bk->sample_unweighted == nullptr || bk->append_unique_phase1 == nullptr) return nullptr;
+  if (bk->sample_unweighted == nullptr || bk->sample_weighted == nullptr || bk->append_unique_phase1 == nullptr) return nullptr;
   return bk;
 }
 
-}  // namespace
-
-extern "C" {
-
-wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replacement(
+// shared body of the two samplers; wm_csr_weight_ptr_tensor == nullptr selects the unweighted one
+wholememory_error_code_t sample_without_replacement(
   wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor,
-  wholememory_tensor_t center_nodes_tensor, int max_sample_count, wholememory_tensor_t output_sample_offset_tensor,
-  void* output_dest_memory_context, void* output_center_localid_memory_context, void* output_edge_gid_memory_context,
-  unsigned long long random_seed, wholememory_env_func_t* p_env_fns, void* stream)
+  wholememory_tensor_t wm_csr_weight_ptr_tensor, bool weighted, wholememory_tensor_t center_nodes_tensor,
+  int max_sample_count, wholememory_tensor_t output_sample_offset_tensor, void* output_dest_memory_context,
+  void* output_center_localid_memory_context, void* output_edge_gid_memory_context, unsigned long long random_seed,
+  wholememory_env_func_t* p_env_fns, void* stream)
 {
-  WM_API_BEGIN
   const auto* bk = graph_backend();
   if (bk == nullptr) return WHOLEMEMORY_NOT_SUPPORTED;
   if (p_env_fns == nullptr || output_dest_memory_context == nullptr) return WHOLEMEMORY_INVALID_INPUT;
@@ -125,6 +122,34 @@ wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replacement(
     return WHOLEMEMORY_INVALID_INPUT;
   }
   wm_sample_args a{};
+  if (weighted) {
+    wholememory_array_description_t weight_desc;
+    if (!array_of(wm_csr_weight_ptr_tensor, "wm_csr_weight_ptr_tensor", &weight_desc, &err)) return err;
+    const auto wmt = memory_type_of(wm_csr_weight_ptr_tensor);
+    if (wmt == WHOLEMEMORY_MT_HIERARCHY) return WHOLEMEMORY_INVALID_INPUT;
+    if (wmt == WHOLEMEMORY_MT_DISTRIBUTED) {
+      WM_ERROR("neighbour sampling on DISTRIBUTED CSR tensors is not implemented in this build");
+      return WHOLEMEMORY_NOT_IMPLEMENTED;
+    }
+    if (weight_desc.dtype != WHOLEMEMORY_DT_FLOAT && weight_desc.dtype != WHOLEMEMORY_DT_DOUBLE) {
+      WM_ERROR("wm_csr_weight_ptr_tensor must be float or double");
+      return WHOLEMEMORY_LOGIC_ERROR;
+    }
+    if (weight_desc.size != col_desc.size) {
+      WM_ERROR("wm_csr_weight_ptr_tensor must have one weight per edge (%ld vs %ld)", static_cast<long>(weight_desc.size),
+               static_cast<long>(col_desc.size));
+      return WHOLEMEMORY_INVALID_INPUT;
+    }
+    if (max_sample_count > 1024) {
+      // reference: key generation + cub segmented sort for > 256 samples (func.cuh:470-560); the in-LDS selection
+      // built here covers 1..1024
+      WM_ERROR("weighted sampling with max_sample_count > 1024 is not implemented in this build");
+      return WHOLEMEMORY_NOT_IMPLEMENTED;
+    }
+    WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_weight_ptr_tensor, &a.weight_gref));
+    a.weight_storage_offset = weight_desc.storage_offset;
+    a.weight_dtype          = weight_desc.dtype;
+  }
   WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_row_ptr_tensor, &a.row_gref));
   WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_col_ptr_tensor, &a.col_gref));
   a.row_storage_offset = row_desc.storage_offset;
@@ -157,19 +182,43 @@ wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replacement(
     a.out_edge_gid = static_cast<int64_t*>(output_alloc(p_env_fns, output_edge_gid_memory_context, total, WHOLEMEMORY_DT_INT64));
   if (total > 0) {
     if (a.out_ids == nullptr) return WHOLEMEMORY_OUT_OF_MEMORY;
-    WM_BK(bk->sample_unweighted(&a, stream));
+    WM_BK(weighted ? bk->sample_weighted(&a, stream) : bk->sample_unweighted(&a, stream));
   }
   WM_BK(bk->stream_sync(stream));  // the reference returns with the samples complete (:385,:404)
   return WHOLEMEMORY_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replacement(
+  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor,
+  wholememory_tensor_t center_nodes_tensor, int max_sample_count, wholememory_tensor_t output_sample_offset_tensor,
+  void* output_dest_memory_context, void* output_center_localid_memory_context, void* output_edge_gid_memory_context,
+  unsigned long long random_seed, wholememory_env_func_t* p_env_fns, void* stream)
+{
+  WM_API_BEGIN
+  return sample_without_replacement(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, nullptr, false, center_nodes_tensor,
+                                    max_sample_count, output_sample_offset_tensor, output_dest_memory_context,
+                                    output_center_localid_memory_context, output_edge_gid_memory_context, random_seed,
+                                    p_env_fns, stream);
   WM_API_END
 }
 
 wholememory_error_code_t wholegraph_csr_weighted_sample_without_replacement(
-  wholememory_tensor_t, wholememory_tensor_t, wholememory_tensor_t, wholememory_tensor_t, int, wholememory_tensor_t, void*,
-  void*, void*, unsigned long long, wholememory_env_func_t*, void*)
+  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor,
+  wholememory_tensor_t wm_csr_weight_ptr_tensor, wholememory_tensor_t center_nodes_tensor, int max_sample_count,
+  wholememory_tensor_t output_sample_offset_tensor, void* output_dest_memory_context,
+  void* output_center_localid_memory_context, void* output_edge_gid_memory_context, unsigned long long random_seed,
+  wholememory_env_func_t* p_env_fns, void* stream)
 {
-  WM_ERROR("weighted neighbour sampling is not implemented in this build");
-  return WHOLEMEMORY_NOT_IMPLEMENTED;
+  WM_API_BEGIN
+  return sample_without_replacement(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, wm_csr_weight_ptr_tensor, true,
+                                    center_nodes_tensor, max_sample_count, output_sample_offset_tensor,
+                                    output_dest_memory_context, output_center_localid_memory_context,
+                                    output_edge_gid_memory_context, random_seed, p_env_fns, stream);
+  WM_API_END
 }
 
 wholememory_error_code_t generate_random_positive_int_cpu(int64_t random_seed, int64_t subsequence, wholememory_tensor_t output)

@@ -24,6 +24,7 @@ int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const
 size_t hip_scan_i32_ws_bytes(int64_t n);
 int hip_exclusive_scan_i32(const int* in, int* out, int64_t n, void* ws, size_t ws_bytes, void* stream);
 int hip_sample_unweighted(const wm_sample_args* a, void* stream);
+int hip_sample_weighted(const wm_sample_args* a, void* stream);
 size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt);
 int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, wholememory_dtype_t dt, void* ws,
                              int* new_count_dev, void* stream);
@@ -136,6 +137,7 @@ const wm_device_backend kHipBackend = {
   hip_scan_i32_ws_bytes,
   hip_exclusive_scan_i32,
   hip_sample_unweighted,
+  hip_sample_weighted,
   hip_append_unique_ws_bytes,
   hip_append_unique_phase1,
   hip_append_unique_phase2,

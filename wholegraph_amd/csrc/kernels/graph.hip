@@ -253,6 +253,126 @@ int launch_sample(const sample_params& p, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ------------------------------------------------------------------------------------------------ weighted sampling
+// A-Res (weighted_sample_without_replacement_func.cuh:183-300): every neighbour gets key = log2(u) / weight, the
+// max_sample_count largest keys win. Which stream feeds which neighbour follows the reference geometry: virtual thread
+// j of a block of `vthreads` (128, or 256 when max_sample_count > 256) visits neighbours j, j + vthreads, ... with
+// consecutive keys of stream center * vthreads + j. The reference keeps the winners in raft's warp-sort queues; here
+// ONE WAVE per center node keeps a candidate list of composite keys (orderable key bits << 32 | ~neighbour index —
+// unique, so ties break towards the smaller index) in LDS, filters new keys against the running M-th largest and
+// compacts with an in-LDS bitonic sort whenever the list fills up. Output order: key descending (deterministic; the
+// reference leaves the order to its queues and its tests compare per-center sets).
+struct weighted_params {
+  sample_params sp;
+  gref_view weight_ptr;
+  int64_t weight_off;
+  int vthreads;
+  int capacity;  // P: power of two >= 2 * max_sample, >= 128
+};
+
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t* a, int P, int lane)
+{
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < (P >> 1); t += 64) {
+        const int i    = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l    = i | j;
+        const uint64_t x = a[i], y = a[l];
+        const bool desc  = (i & k) == 0;
+        if ((x < y) == desc) {
+          a[i] = y;
+          a[l] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <typename IdT, typename ColT, typename WT>
+__global__ __launch_bounds__(64) void sample_weighted_kernel(weighted_params w)
+{
+  extern __shared__ uint64_t cand[];
+  const sample_params& p = w.sp;
+  const int center       = blockIdx.x;
+  const int lane         = threadIdx.x;
+  const int M            = p.max_sample;
+  const IdT* centers     = static_cast<const IdT*>(p.centers);
+  ColT* out              = static_cast<ColT*>(p.out_ids);
+  const int64_t nid      = static_cast<int64_t>(centers[center]);
+  const int64_t s        = gref_load<int64_t>(p.row_ptr, p.row_off + nid);
+  const int64_t e        = gref_load<int64_t>(p.row_ptr, p.row_off + nid + 1);
+  const int N            = static_cast<int>(e - s);
+  if (N <= 0) return;
+  const int off = p.offsets[center];
+  if (M <= 0 || N <= M) {
+    for (int i = lane; i < N; i += 64) {
+      out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
+      if (p.out_lid) p.out_lid[off + i] = center;
+      if (p.out_egid) p.out_egid[off + i] = s + i;
+    }
+    return;
+  }
+  const int P          = w.capacity;
+  int cnt              = 0;  // wave-uniform
+  uint64_t threshold   = 0;  // composite keys are > 0; accept only keys above the current M-th largest
+  const uint64_t lt    = (1ull << lane) - 1;
+  auto compact = [&]() {
+    for (int i = cnt + lane; i < P; i += 64) cand[i] = 0;
+    __syncthreads();
+    bitonic_sort_desc(cand, P, lane);
+    if (cnt >= M) {
+      cnt       = M;
+      threshold = cand[M - 1];
+    }
+  };
+  for (int vbase = 0; vbase < w.vthreads; vbase += 64) {
+    const int vt = vbase + lane;
+    pcg32 rng(p.seed, 0, static_cast<uint64_t>(center) * w.vthreads + vt);
+    for (int id0 = vbase; id0 < N; id0 += w.vthreads) {
+      const int id = id0 + lane;
+      bool accept  = false;
+      uint64_t comp = 0;
+      if (id < N) {
+        const float wt  = static_cast<float>(gref_load<WT>(w.weight_ptr, w.weight_off + s + id));
+        const float key = weighted_sample_key(rng, wt);
+        comp            = (static_cast<uint64_t>(orderable_float(key)) << 32) | (0xffffffffu - static_cast<uint32_t>(id));
+        accept          = comp > threshold;
+      }
+      const uint64_t mask = __ballot(accept);
+      if (accept) cand[cnt + __popcll(mask & lt)] = comp;
+      cnt += __popcll(mask);
+      __syncthreads();
+      if (cnt > P - 64) compact();
+    }
+  }
+  compact();
+  for (int i = lane; i < M; i += 64) {
+    const int ai = static_cast<int>(0xffffffffu - static_cast<uint32_t>(cand[i]));
+    out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + ai);
+    if (p.out_lid) p.out_lid[off + i] = center;
+    if (p.out_egid) p.out_egid[off + i] = s + ai;
+  }
+}
+
+template <typename IdT, typename ColT, typename WT>
+int launch_weighted(const weighted_params& w, hipStream_t stream)
+{
+  if (w.sp.n_center == 0) return 0;
+  const size_t lds = static_cast<size_t>(w.capacity) * sizeof(uint64_t);
+  hipLaunchKernelGGL((sample_weighted_kernel<IdT, ColT, WT>), dim3(w.sp.n_center), dim3(64), lds, stream, w);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename WT>
+int dispatch_weighted(const weighted_params& w, bool id32, bool col32, hipStream_t stream)
+{
+  if (id32 && col32) return launch_weighted<int32_t, int32_t, WT>(w, stream);
+  if (id32) return launch_weighted<int32_t, int64_t, WT>(w, stream);
+  if (col32) return launch_weighted<int64_t, int32_t, WT>(w, stream);
+  return launch_weighted<int64_t, int64_t, WT>(w, stream);
+}
+
 // ------------------------------------------------------------------------------------------------ append_unique
 template <typename KeyT>
 __global__ void concat_keys_kernel(const KeyT* targets, int nt, const KeyT* neighbors, int nn, KeyT* keys, int* pos)
@@ -439,6 +559,30 @@ int hip_sample_unweighted(const wm_sample_args* a, void* stream_v)
   if (id32) return launch_sample<int32_t, int64_t>(p, stream);
   if (col32) return launch_sample<int64_t, int32_t>(p, stream);
   return launch_sample<int64_t, int64_t>(p, stream);
+}
+
+int hip_sample_weighted(const wm_sample_args* a, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (a->max_sample_count > kMaxSparse) return -3;  // host side reports NOT_IMPLEMENTED before getting here
+  weighted_params w{};
+  sample_params& p = w.sp;
+  p.row_ptr = make_view(a->row_gref), p.col_ptr = make_view(a->col_gref);
+  p.row_off = a->row_storage_offset, p.col_off = a->col_storage_offset;
+  p.centers = a->centers, p.n_center = a->n_center, p.max_sample = a->max_sample_count;
+  p.seed = a->random_seed, p.offsets = a->sample_offsets;
+  p.out_ids = a->out_ids, p.out_lid = a->out_center_lid, p.out_egid = a->out_edge_gid;
+  w.weight_ptr = make_view(a->weight_gref);
+  w.weight_off = a->weight_storage_offset;
+  w.vthreads   = a->max_sample_count > 256 ? 256 : 128;  // reference block sizes (func.cuh:540-560, test utils :597-598)
+  int P        = 128;
+  while (P < 2 * a->max_sample_count) P <<= 1;
+  w.capacity      = P;
+  const bool id32 = a->center_dtype == WHOLEMEMORY_DT_INT, col32 = a->col_dtype == WHOLEMEMORY_DT_INT;
+  if ((!id32 && a->center_dtype != WHOLEMEMORY_DT_INT64) || (!col32 && a->col_dtype != WHOLEMEMORY_DT_INT64)) return -1;
+  if (a->weight_dtype == WHOLEMEMORY_DT_FLOAT) return dispatch_weighted<float>(w, id32, col32, stream);
+  if (a->weight_dtype == WHOLEMEMORY_DT_DOUBLE) return dispatch_weighted<double>(w, id32, col32, stream);
+  return -1;
 }
 
 size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt)

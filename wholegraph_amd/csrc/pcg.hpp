@@ -71,6 +71,83 @@ struct pcg32 {
   WM_HD float next_float() { return static_cast<float>(next_u32() >> 8) / static_cast<float>(1u << 24); }
 };
 
+// log2(1 + x) for x in [-1, 0), in double, built from +, *, / only (no libm), so that host and device round every step
+// identically (both are compiled with -ffp-contract=off): the weighted sampler ranks neighbours by keys that contain
+// this value, and "device == oracle" must not depend on two math libraries agreeing in the last bit.
+//   tiny |x|: x - x^2/2;   else U = 1 + x (exact: x carries 24 significant bits), U = f * 2^e with f in [sqrt(1/2),
+//   sqrt(2)), ln U = e ln2 + 2 atanh((f-1)/(f+1)), atanh by its odd series to s^27 (|s| <= 0.172 -> < 1e-20).
+WM_HD double det_log2_1p(double x)
+{
+  const double kInvLn2 = 1.4426950408889634074;
+  const double kLn2    = 0.69314718055994530942;
+  if (x > -7.450580596923828125e-9) return (x - x * x * 0.5) * kInvLn2;  // |x| < 2^-27
+  const double U = 1.0 + x;
+  if (!(U > 0.0)) return -__builtin_inf();
+  uint64_t bits;
+  __builtin_memcpy(&bits, &U, 8);
+  int e = static_cast<int>((bits >> 52) & 0x7ff) - 1023;
+  bits  = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+  double f;
+  __builtin_memcpy(&f, &bits, 8);  // [1, 2)
+  if (f > 1.4142135623730951) {
+    f *= 0.5;
+    e += 1;
+  }
+  const double s  = (f - 1.0) / (f + 1.0);
+  const double s2 = s * s;
+  double p        = 2.0 / 27.0;
+  p               = p * s2 + 2.0 / 25.0;
+  p               = p * s2 + 2.0 / 23.0;
+  p               = p * s2 + 2.0 / 21.0;
+  p               = p * s2 + 2.0 / 19.0;
+  p               = p * s2 + 2.0 / 17.0;
+  p               = p * s2 + 2.0 / 15.0;
+  p               = p * s2 + 2.0 / 13.0;
+  p               = p * s2 + 2.0 / 11.0;
+  p               = p * s2 + 2.0 / 9.0;
+  p               = p * s2 + 2.0 / 7.0;
+  p               = p * s2 + 2.0 / 5.0;
+  p               = p * s2 + 2.0 / 3.0;
+  p               = p * s2 + 2.0;
+  return (static_cast<double>(e) * kLn2 + p * s) * kInvLn2;
+}
+
+// A-Res key of one neighbour: log2(u) / weight with u uniform in (0,1) assembled from a 24-bit mantissa in [0.5, 1)
+// and a geometric exponent (leading zero bits of a 64-bit stream, redrawn while it is all zeros) — the construction
+// of weighted_sample_without_replacement_func.cuh:44-63. Larger key = more likely kept.
+WM_HD float weighted_sample_key(pcg32& rng, float weight)
+{
+  const float u0 = rng.next_float();
+  const float m  = static_cast<float>(-(0.5 + 0.5 * static_cast<double>(u0)));  // [-1, -0.5]
+  uint64_t stream;
+  int redraws = -1;
+  do {
+    stream = rng.next_u64();
+    redraws++;
+  } while (stream == 0);
+  int zeros = redraws * 64;
+  while ((stream >> 63) == 0) {  // count leading zeros without a builtin that differs between host and device
+    stream <<= 1;
+    zeros++;
+  }
+  double scale = 1.0;
+  for (int z = zeros; z > 0;) {  // 2^-zeros, exact
+    const int step = z > 30 ? 30 : z;
+    scale *= 1.0 / static_cast<double>(1u << step);
+    z -= step;
+  }
+  const float log2u = static_cast<float>(det_log2_1p(static_cast<double>(m) * scale));
+  return log2u * (1.0f / weight);
+}
+
+// order-preserving map float -> uint32 (larger float = larger integer; -inf lowest)
+WM_HD uint32_t orderable_float(float v)
+{
+  uint32_t b;
+  __builtin_memcpy(&b, &v, 4);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
 // Launch geometry the reference derives from max_sample_count (unweighted_sample_without_replacement_func.cuh:
 // 407-445): the sampler's random streams are keyed by (center node, thread), so the SAME virtual geometry must be
 // used to reproduce the same samples, whatever the physical kernel looks like.
