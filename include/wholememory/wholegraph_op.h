@@ -2,9 +2,10 @@
  * wholegraph_amd — neighbour sampling on CSR graphs held in WholeMemory (the step before the feature gather in
  * BASELINE config 5). Replaces reference cpp/include/wholememory/wholegraph_op.h:39-105.
  *
- * Built: unweighted and weighted (max_sample_count <= 1024) sampling without replacement on mapped (CONTINUOUS /
- * CHUNKED / plain-pointer) CSR tensors and the two host random helpers. DISTRIBUTED CSR tensors and weighted sampling
- * of more than 1024 neighbours return WHOLEMEMORY_NOT_IMPLEMENTED. Random streams: see wholegraph_amd/csrc/pcg.hpp (parity with raft unpinned).
+ * Built: unweighted sampling without replacement on every memory type (DISTRIBUTED CSR tensors are read through
+ * collective wholememory_gather calls: every rank of the CSR's communicator must take part), weighted sampling
+ * (max_sample_count <= 1024, mapped CSR tensors) and the two host random helpers. Weighted sampling of more than 1024
+ * neighbours or on DISTRIBUTED tensors returns WHOLEMEMORY_NOT_IMPLEMENTED. Random streams: see wholegraph_amd/csrc/pcg.hpp (parity with raft unpinned).
  */
 #ifndef WHOLEMEMORY_WHOLEGRAPH_OP_H_
 #define WHOLEMEMORY_WHOLEGRAPH_OP_H_

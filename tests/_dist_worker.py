@@ -206,6 +206,42 @@ def scenario_file_io(comm, rank, world, tmpdir):
     wgth.destroy_embedding(emb)
 
 
+def scenario_sampling(comm, rank, world, mt, col_dt, loc="cuda"):
+    """Neighbour sampling on a CSR spread over the ranks (HIP mode): DISTRIBUTED goes through two collective gathers
+    (row bounds, sampled columns), CHUNKED / CONTINUOUS read peers' shards directly. Bit-exact vs the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_graph_oracle import make_csr
+    row_ptr, col = make_csr(1500, 60, 4242, col_dt, heavy=[(5, 1400), (6, 0), (1499, 300)])
+    tensors = []
+    for arr in (row_ptr, col):
+        t = wgth.create_wholememory_tensor(comm, mt, loc, [arr.shape[0]], torch.from_numpy(arr).dtype, [1])
+        local, start = t.get_local_tensor(host_view=(loc == "cpu"))
+        local.copy_(torch.from_numpy(arr[start:start + local.shape[0]]))
+        tensors.append(t)
+    if HIP_MODE:
+        torch.cuda.synchronize()
+    comm.barrier()
+    g = wgth.GraphStructure()
+    g.set_csr_graph(tensors[0], tensors[1])
+    rng = np.random.default_rng(900 + rank)
+    n_center = 0 if rank == world - 1 else 400 + 17 * rank          # the last rank asks for nothing
+    centers = np.concatenate([[5, 6, 1499], rng.integers(0, 1500, n_center)])[:n_center + (3 if n_center else 0)]
+    centers = centers.astype(np.int64 if rank % 2 == 0 else np.int32)
+    for m in (5, 40, -1, 1100):
+        seed = 31337 * (m + 2) + rank
+        off, ids, lid, egid = g.unweighted_sample_without_replacement_one_hop(
+            dev(torch.from_numpy(centers)), m, random_seed=seed, need_center_local_output=True, need_edge_output=True)
+        o_off, o_ids, o_lid, o_egid = oracle.sample_unweighted(row_ptr, col, centers, m, seed)
+        assert np.array_equal(host(off).numpy(), o_off), (mt, m)
+        assert np.array_equal(host(egid).numpy(), o_egid), (mt, m)
+        assert np.array_equal(host(ids).numpy(), o_ids) and np.array_equal(host(lid).numpy(), o_lid), (mt, m)
+        off2, ids2 = g.unweighted_sample_without_replacement_one_hop(dev(torch.from_numpy(centers)), m, random_seed=seed)
+        assert torch.equal(ids2, ids) and torch.equal(off2, off)
+    comm.barrier()
+    for t in tensors:
+        wgth.destroy_wholememory_tensor(t)
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
@@ -244,6 +280,12 @@ def main():
         scenario_gather_scatter(comm, rank, world, "chunked", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
         scenario_gather_scatter(comm, rank, world, "continuous", 2003, 32, np.float32, np.float16, np.int32, ent2, loc="cpu")
         scenario_gather_scatter(comm, rank, world, "distributed", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
+        # (4c) neighbour sampling on a CSR spread over the ranks
+        scenario_sampling(comm, rank, world, "distributed", np.int64)
+        scenario_sampling(comm, rank, world, "distributed", np.int32)
+        scenario_sampling(comm, rank, world, "chunked", np.int32)
+        scenario_sampling(comm, rank, world, "continuous", np.int64)
+        scenario_sampling(comm, rank, world, "distributed", np.int64, loc="cpu")
     scenario_file_io(comm, rank, world, "/tmp/wgamd_test_%s" % port)
     # (5) gradient apply, all optimizers
     for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}),

@@ -40,7 +40,8 @@ def _graph(col_dtype):
     return GRAPH[0], GRAPH[1].astype(col_dtype)
 
 
-@pytest.mark.parametrize("mt,loc", [("continuous", "cuda"), ("chunked", "cuda"), ("continuous", "cpu"), ("chunked", "cpu")])
+@pytest.mark.parametrize("mt,loc", [("continuous", "cuda"), ("chunked", "cuda"), ("continuous", "cpu"), ("chunked", "cpu"),
+                                    ("distributed", "cuda"), ("distributed", "cpu")])
 @pytest.mark.parametrize("center_dtype,col_dtype", [(np.int64, np.int64), (np.int32, np.int32), (np.int64, np.int32),
                                                     (np.int32, np.int64)])
 def test_unweighted_sample_parity(gpu_env, mt, loc, center_dtype, col_dtype):

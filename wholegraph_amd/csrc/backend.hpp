@@ -77,6 +77,8 @@ struct wm_sample_args {
   wholememory_gref_t row_gref, col_gref;  // csr_row_ptr (int64), csr_col_ptr (col_dtype)
   int64_t row_storage_offset, col_storage_offset;  // elements
   wholememory_dtype_t col_dtype;
+  const int64_t* row_pairs;  // optional [2 * n_center] device: (row_ptr[c], row_ptr[c + 1]) fetched beforehand (DISTRIBUTED
+                             // CSR); then out_ids must be nullptr and only out_edge_gid / out_center_lid are written
   const void* centers;  // [n_center] device
   wholememory_dtype_t center_dtype;
   int n_center;
@@ -137,8 +139,11 @@ struct wm_device_backend {
   int (*fill_float)(float* p, float value, int64_t count, void* stream);
   // ---- graph ops (kernels/graph.hip); nullptr in a backend that does not provide them ----
   // counts[i] = min(degree(center i), max_sample) for i < n, counts[n] = 0
-  int (*sample_counts)(const wholememory_gref_t* row_gref, int64_t row_storage_offset, const void* centers,
-                       wholememory_dtype_t center_dtype, int n, int max_sample, int* counts, void* stream);
+  // (row bounds from row_pairs when it is not nullptr, else through row_gref)
+  int (*sample_counts)(const wholememory_gref_t* row_gref, int64_t row_storage_offset, const int64_t* row_pairs,
+                       const void* centers, wholememory_dtype_t center_dtype, int n, int max_sample, int* counts, void* stream);
+  // ids[2i] = center i, ids[2i + 1] = center i + 1
+  int (*sample_pair_ids)(const void* centers, wholememory_dtype_t center_dtype, int n, int64_t* ids, void* stream);
   size_t (*scan_i32_workspace_bytes)(int64_t n);
   int (*exclusive_scan_i32)(const int* in, int* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
   int (*sample_unweighted)(const wm_sample_args* a, void* stream);

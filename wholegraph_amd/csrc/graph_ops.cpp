@@ -8,6 +8,7 @@
 // csr_add_self_loop cpp/src/graph_ops/csr_add_self_loop.cpp:22-80.
 #include <cmath>
 #include <cstring>
+#include <new>
 
 #include <wholememory/graph_op.h>
 #include <wholememory/wholegraph_op.h>
@@ -67,6 +68,28 @@ wholememory_memory_type_t memory_type_of(wholememory_tensor_t t)
   return wholememory_get_memory_type(wholememory_tensor_get_memory_handle(t));
 }
 
+// a caller-side device array wrapped as a wholememory_tensor_t for the duration of one call
+struct local_tensor {
+  wholememory_tensor_t handle = nullptr;
+  local_tensor(void* ptr, int64_t count, wholememory_dtype_t dtype)
+  {
+    wholememory_tensor_description_t d;
+    wholememory_initialize_tensor_desc(&d);
+    d.dim            = 1;
+    d.sizes[0]       = count;
+    d.strides[0]     = 1;
+    d.dtype          = dtype;
+    d.storage_offset = 0;
+    if (wholememory_make_tensor_from_pointer(&handle, ptr, &d) != WHOLEMEMORY_SUCCESS) throw std::bad_alloc();
+  }
+  ~local_tensor()
+  {
+    if (handle != nullptr) wholememory_destroy_tensor(handle);
+  }
+  local_tensor(const local_tensor&)            = delete;
+  local_tensor& operator=(const local_tensor&) = delete;
+};
+
 const wm_device_backend* graph_backend()
 {
   const auto* bk = backend();
@@ -96,9 +119,11 @@ wholememory_error_code_t sample_without_replacement(
     WM_ERROR("Memory type not supported.");
     return WHOLEMEMORY_INVALID_INPUT;
   }
-  if (row_mt == WHOLEMEMORY_MT_DISTRIBUTED || col_mt == WHOLEMEMORY_MT_DISTRIBUTED) {
-    // reference ..._impl_nccl.cu (gather of row_ptr pairs and of the sampled columns over NCCL): not built yet
-    WM_ERROR("neighbour sampling on DISTRIBUTED CSR tensors is not implemented in this build");
+  // DISTRIBUTED CSR (reference ..._impl_nccl.cu / ..._nccl_func.cuh:196-390): the arrays are not addressable from this
+  // rank, so row bounds and sampled columns travel through wholememory_gather (collective over the CSR's communicator)
+  const bool via_gather = row_mt == WHOLEMEMORY_MT_DISTRIBUTED || col_mt == WHOLEMEMORY_MT_DISTRIBUTED;
+  if (via_gather && weighted) {
+    WM_ERROR("weighted sampling on DISTRIBUTED CSR tensors is not implemented (the reference has no such path either)");
     return WHOLEMEMORY_NOT_IMPLEMENTED;
   }
   // dtype rules of ..._func.cuh:304-314 and the dispatch table of ..._impl_mapped.cu (logic_error there)
@@ -150,8 +175,10 @@ wholememory_error_code_t sample_without_replacement(
     a.weight_storage_offset = weight_desc.storage_offset;
     a.weight_dtype          = weight_desc.dtype;
   }
-  WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_row_ptr_tensor, &a.row_gref));
-  WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_col_ptr_tensor, &a.col_gref));
+  if (!via_gather) {
+    WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_row_ptr_tensor, &a.row_gref));
+    WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_col_ptr_tensor, &a.col_gref));
+  }
   a.row_storage_offset = row_desc.storage_offset;
   a.col_storage_offset = col_desc.storage_offset;
   a.col_dtype          = col_desc.dtype;
@@ -168,8 +195,18 @@ wholememory_error_code_t sample_without_replacement(
   int* counts           = static_cast<int*>(counts_mem.device(n + 1, WHOLEMEMORY_DT_INT));
   const size_t scan_ws  = bk->scan_i32_workspace_bytes(n + 1);
   void* scan_ws_ptr     = scan_mem.device(static_cast<int64_t>(scan_ws), WHOLEMEMORY_DT_INT8);
-  WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, a.centers, a.center_dtype, a.n_center, max_sample_count, counts,
-                          stream));
+  temp_mem pair_ids_mem(p_env_fns), pairs_mem(p_env_fns), egid_mem(p_env_fns);
+  if (via_gather) {
+    // (row_ptr[c], row_ptr[c + 1]) of every center node in one gather
+    int64_t* pair_ids = static_cast<int64_t*>(pair_ids_mem.device(2 * n, WHOLEMEMORY_DT_INT64));
+    int64_t* pairs    = static_cast<int64_t*>(pairs_mem.device(2 * n, WHOLEMEMORY_DT_INT64));
+    WM_BK(bk->sample_pair_ids(a.centers, a.center_dtype, a.n_center, pair_ids, stream));
+    local_tensor ids_t(pair_ids, 2 * n, WHOLEMEMORY_DT_INT64), pairs_t(pairs, 2 * n, WHOLEMEMORY_DT_INT64);
+    WHOLEMEMORY_RETURN_ON_FAIL(wholememory_gather(wm_csr_row_ptr_tensor, ids_t.handle, pairs_t.handle, p_env_fns, stream, -1));
+    a.row_pairs = pairs;
+  }
+  WM_BK(bk->sample_counts(via_gather ? nullptr : &a.row_gref, a.row_storage_offset, a.row_pairs, a.centers, a.center_dtype,
+                          a.n_center, max_sample_count, counts, stream));
   WM_BK(bk->exclusive_scan_i32(counts, offsets, n + 1, scan_ws_ptr, scan_ws, stream));
   int total = 0;
   WM_BK(bk->memcpy_async(&total, offsets + n, sizeof(int), stream));
@@ -180,8 +217,16 @@ wholememory_error_code_t sample_without_replacement(
     a.out_center_lid = static_cast<int*>(output_alloc(p_env_fns, output_center_localid_memory_context, total, WHOLEMEMORY_DT_INT));
   if (output_edge_gid_memory_context != nullptr)
     a.out_edge_gid = static_cast<int64_t*>(output_alloc(p_env_fns, output_edge_gid_memory_context, total, WHOLEMEMORY_DT_INT64));
-  if (total > 0) {
-    if (a.out_ids == nullptr) return WHOLEMEMORY_OUT_OF_MEMORY;
+  if (total > 0 && a.out_ids == nullptr) return WHOLEMEMORY_OUT_OF_MEMORY;
+  if (via_gather) {
+    // positions first (edge ids), then the columns by one more gather; every rank takes part even with nothing to sample
+    void* out_ids = a.out_ids;
+    a.out_ids     = nullptr;
+    if (a.out_edge_gid == nullptr) a.out_edge_gid = static_cast<int64_t*>(egid_mem.device(total, WHOLEMEMORY_DT_INT64));
+    if (total > 0) WM_BK(bk->sample_unweighted(&a, stream));
+    local_tensor egid_t(a.out_edge_gid, total, WHOLEMEMORY_DT_INT64), out_t(out_ids, total, col_desc.dtype);
+    WHOLEMEMORY_RETURN_ON_FAIL(wholememory_gather(wm_csr_col_ptr_tensor, egid_t.handle, out_t.handle, p_env_fns, stream, -1));
+  } else if (total > 0) {
     WM_BK(weighted ? bk->sample_weighted(&a, stream) : bk->sample_unweighted(&a, stream));
   }
   WM_BK(bk->stream_sync(stream));  // the reference returns with the samples complete (:385,:404)

@@ -19,8 +19,9 @@ size_t hip_long_run_ws_bytes(int64_t n_recv);
 int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n, int64_t entry_start,
                         int world_size, int round_robin_size, void* stream);
 int hip_fill_float(float* p, float value, int64_t count, void* stream);
-int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const void* centers, wholememory_dtype_t id_dtype,
-                      int n, int max_sample, int* counts, void* stream);
+int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const int64_t* row_pairs, const void* centers,
+                      wholememory_dtype_t id_dtype, int n, int max_sample, int* counts, void* stream);
+int hip_sample_pair_ids(const void* centers, wholememory_dtype_t id_dtype, int n, int64_t* ids, void* stream);
 size_t hip_scan_i32_ws_bytes(int64_t n);
 int hip_exclusive_scan_i32(const int* in, int* out, int64_t n, void* ws, size_t ws_bytes, void* stream);
 int hip_sample_unweighted(const wm_sample_args* a, void* stream);
@@ -134,6 +135,7 @@ const wm_device_backend kHipBackend = {
   hip_round_robin_map,
   hip_fill_float,
   hip_sample_counts,
+  hip_sample_pair_ids,
   hip_scan_i32_ws_bytes,
   hip_exclusive_scan_i32,
   hip_sample_unweighted,

@@ -76,9 +76,20 @@ __device__ __forceinline__ T gref_load(const gref_view& v, int64_t elem_index)
 }
 
 // ------------------------------------------------------------------------------------------------ counts
+// ids[2i] = center i, ids[2i+1] = center i + 1: the row_ptr entries a DISTRIBUTED CSR has to fetch per center node
 template <typename IdT>
-__global__ void sample_count_kernel(gref_view row_ptr, int64_t row_off, const IdT* centers, int n, int max_sample,
-                                    int* counts)
+__global__ void pair_ids_kernel(const IdT* centers, int n, int64_t* ids)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t nid = static_cast<int64_t>(centers[i]);
+  ids[2 * i]        = nid;
+  ids[2 * i + 1]    = nid + 1;
+}
+
+template <typename IdT>
+__global__ void sample_count_kernel(gref_view row_ptr, int64_t row_off, const int64_t* pairs, const IdT* centers, int n,
+                                    int max_sample, int* counts)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
@@ -86,9 +97,14 @@ __global__ void sample_count_kernel(gref_view row_ptr, int64_t row_off, const Id
     counts[n] = 0;  // the scan runs over n + 1 entries (reference :334-338)
     return;
   }
-  const int64_t nid = static_cast<int64_t>(centers[i]);
-  const int64_t s   = gref_load<int64_t>(row_ptr, row_off + nid);
-  const int64_t e   = gref_load<int64_t>(row_ptr, row_off + nid + 1);
+  int64_t s, e;
+  if (pairs != nullptr) {
+    s = pairs[2 * i], e = pairs[2 * i + 1];
+  } else {
+    const int64_t nid = static_cast<int64_t>(centers[i]);
+    s                 = gref_load<int64_t>(row_ptr, row_off + nid);
+    e                 = gref_load<int64_t>(row_ptr, row_off + nid + 1);
+  }
   int deg           = static_cast<int>(e - s);
   if (max_sample > 0) deg = min(deg, max_sample);  // <= 0 means "all neighbours"
   counts[i] = deg;
@@ -98,15 +114,30 @@ __global__ void sample_count_kernel(gref_view row_ptr, int64_t row_off, const Id
 struct sample_params {
   gref_view row_ptr, col_ptr;
   int64_t row_off, col_off;  // storage offsets (elements)
+  const int64_t* pairs;  // optional [2n]: (row_ptr[c], row_ptr[c+1]) already fetched (DISTRIBUTED CSR); then
+                         // out_ids must be nullptr and the kernels only emit positions (edge ids)
   const void* centers;
   int n_center;
   int max_sample;
   uint64_t seed;
   const int* offsets;  // [n + 1]
-  void* out_ids;       // ColT
+  void* out_ids;       // ColT, or nullptr
   int* out_lid;        // optional
   int64_t* out_egid;   // optional
 };
+
+template <typename IdT>
+__device__ __forceinline__ void row_bounds(const sample_params& p, int center, int64_t* s, int64_t* e)
+{
+  if (p.pairs != nullptr) {
+    *s = p.pairs[2 * center];
+    *e = p.pairs[2 * center + 1];
+    return;
+  }
+  const int64_t nid = static_cast<int64_t>(static_cast<const IdT*>(p.centers)[center]);
+  *s                = gref_load<int64_t>(p.row_ptr, p.row_off + nid);
+  *e                = gref_load<int64_t>(p.row_ptr, p.row_off + nid + 1);
+}
 
 template <typename IdT, typename ColT>
 __global__ __launch_bounds__(kBlock) void sample_sparse_kernel(sample_params p)
@@ -122,17 +153,15 @@ __global__ __launch_bounds__(kBlock) void sample_sparse_kernel(sample_params p)
   int* qval         = qpos + M;
   const int center  = blockIdx.x * kWavesPerBlk + wave_in;
   if (center >= p.n_center) return;
-  const IdT* centers = static_cast<const IdT*>(p.centers);
   ColT* out          = static_cast<ColT*>(p.out_ids);
-  const int64_t nid  = static_cast<int64_t>(centers[center]);
-  const int64_t s    = gref_load<int64_t>(p.row_ptr, p.row_off + nid);
-  const int64_t e    = gref_load<int64_t>(p.row_ptr, p.row_off + nid + 1);
+  int64_t s, e;
+  row_bounds<IdT>(p, center, &s, &e);
   const int N        = static_cast<int>(e - s);
   if (N <= 0) return;
   const int off = p.offsets[center];
   if (M <= 0 || N <= M) {  // every neighbour (reference sample_all_kernel / the `neighbor_count <= max` branches)
     for (int i = lane; i < N; i += 64) {
-      out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
+      if (out) out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
       if (p.out_lid) p.out_lid[off + i] = center;
       if (p.out_egid) p.out_egid[off + i] = s + i;
     }
@@ -185,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void sample_sparse_kernel(sample_params p)
   }
   for (int i = lane; i < M; i += 64) {
     const int ai = a_s[i];
-    out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + ai);
+    if (out) out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + ai);
     if (p.out_lid) p.out_lid[off + i] = center;
     if (p.out_egid) p.out_egid[off + i] = s + ai;
   }
@@ -201,23 +230,22 @@ __global__ __launch_bounds__(64) void sample_large_kernel(sample_params p)
   const int center = blockIdx.x;
   const int lane   = threadIdx.x;
   const int M      = p.max_sample;
-  const IdT* centers = static_cast<const IdT*>(p.centers);
   ColT* out          = static_cast<ColT*>(p.out_ids);
-  const int64_t nid  = static_cast<int64_t>(centers[center]);
-  const int64_t s    = gref_load<int64_t>(p.row_ptr, p.row_off + nid);
-  const int64_t e    = gref_load<int64_t>(p.row_ptr, p.row_off + nid + 1);
+  int64_t s, e;
+  row_bounds<IdT>(p, center, &s, &e);
   const int N        = static_cast<int>(e - s);
   if (N <= 0) return;
   const int off = p.offsets[center];
   if (N <= M) {
     for (int i = lane; i < N; i += 64) {
-      out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
+      if (out) out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
       if (p.out_lid) p.out_lid[off + i] = center;
       if (p.out_egid) p.out_egid[off + i] = s + i;
     }
     return;
   }
-  auto slot = [&](int i) { return reinterpret_cast<int*>(out + off + i); };
+  // the reservoir slots live in the output elements (>= 4 bytes each); in positions-only mode in the edge-id elements
+  auto slot = [&](int i) { return out ? reinterpret_cast<int*>(out + off + i) : reinterpret_cast<int*>(p.out_egid + off + i); };
   for (int i = lane; i < M; i += 64) {
     *slot(i) = i;
     if (p.out_lid) p.out_lid[off + i] = center;
@@ -233,7 +261,7 @@ __global__ __launch_bounds__(64) void sample_large_kernel(sample_params p)
   __syncthreads();
   for (int i = lane; i < M; i += 64) {
     const int ai = __hip_atomic_load(slot(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + ai);
+    if (out) out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + ai);
     if (p.out_egid) p.out_egid[off + i] = s + ai;
   }
 }
@@ -297,17 +325,15 @@ __global__ __launch_bounds__(64) void sample_weighted_kernel(weighted_params w)
   const int center       = blockIdx.x;
   const int lane         = threadIdx.x;
   const int M            = p.max_sample;
-  const IdT* centers     = static_cast<const IdT*>(p.centers);
   ColT* out              = static_cast<ColT*>(p.out_ids);
-  const int64_t nid      = static_cast<int64_t>(centers[center]);
-  const int64_t s        = gref_load<int64_t>(p.row_ptr, p.row_off + nid);
-  const int64_t e        = gref_load<int64_t>(p.row_ptr, p.row_off + nid + 1);
+  int64_t s, e;
+  row_bounds<IdT>(p, center, &s, &e);
   const int N            = static_cast<int>(e - s);
   if (N <= 0) return;
   const int off = p.offsets[center];
   if (M <= 0 || N <= M) {
     for (int i = lane; i < N; i += 64) {
-      out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
+      if (out) out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
       if (p.out_lid) p.out_lid[off + i] = center;
       if (p.out_egid) p.out_egid[off + i] = s + i;
     }
@@ -349,7 +375,7 @@ __global__ __launch_bounds__(64) void sample_weighted_kernel(weighted_params w)
   compact();
   for (int i = lane; i < M; i += 64) {
     const int ai = static_cast<int>(0xffffffffu - static_cast<uint32_t>(cand[i]));
-    out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + ai);
+    if (out) out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + ai);
     if (p.out_lid) p.out_lid[off + i] = center;
     if (p.out_egid) p.out_egid[off + i] = s + ai;
   }
@@ -513,18 +539,33 @@ __global__ void add_self_loop_kernel(const int* row_ptr, const int* col, int* ou
 }  // namespace
 
 // ---- launchers exported to backend_hip ----
-int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const void* centers, wholememory_dtype_t id_dtype,
-                      int n, int max_sample, int* counts, void* stream_v)
+int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const int64_t* row_pairs, const void* centers,
+                      wholememory_dtype_t id_dtype, int n, int max_sample, int* counts, void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
-  gref_view rv       = make_view(*row_gref);
-  const int blocks   = (n + 1 + 127) / 128;
+  gref_view rv{};
+  if (row_pairs == nullptr) rv = make_view(*row_gref);
+  const int blocks = (n + 1 + 127) / 128;
   if (id_dtype == WHOLEMEMORY_DT_INT)
-    hipLaunchKernelGGL((sample_count_kernel<int32_t>), dim3(blocks), dim3(128), 0, stream, rv, row_off,
+    hipLaunchKernelGGL((sample_count_kernel<int32_t>), dim3(blocks), dim3(128), 0, stream, rv, row_off, row_pairs,
                        static_cast<const int32_t*>(centers), n, max_sample, counts);
   else if (id_dtype == WHOLEMEMORY_DT_INT64)
-    hipLaunchKernelGGL((sample_count_kernel<int64_t>), dim3(blocks), dim3(128), 0, stream, rv, row_off,
+    hipLaunchKernelGGL((sample_count_kernel<int64_t>), dim3(blocks), dim3(128), 0, stream, rv, row_off, row_pairs,
                        static_cast<const int64_t*>(centers), n, max_sample, counts);
+  else
+    return -1;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int hip_sample_pair_ids(const void* centers, wholememory_dtype_t id_dtype, int n, int64_t* ids, void* stream_v)
+{
+  if (n <= 0) return 0;
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const int blocks   = (n + 255) / 256;
+  if (id_dtype == WHOLEMEMORY_DT_INT)
+    hipLaunchKernelGGL((pair_ids_kernel<int32_t>), dim3(blocks), dim3(256), 0, stream, static_cast<const int32_t*>(centers), n, ids);
+  else if (id_dtype == WHOLEMEMORY_DT_INT64)
+    hipLaunchKernelGGL((pair_ids_kernel<int64_t>), dim3(blocks), dim3(256), 0, stream, static_cast<const int64_t*>(centers), n, ids);
   else
     return -1;
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -548,11 +589,17 @@ int hip_sample_unweighted(const wm_sample_args* a, void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   sample_params p{};
-  p.row_ptr = make_view(a->row_gref), p.col_ptr = make_view(a->col_gref);
-  p.row_off = a->row_storage_offset, p.col_off = a->col_storage_offset;
   p.centers = a->centers, p.n_center = a->n_center, p.max_sample = a->max_sample_count;
   p.seed = a->random_seed, p.offsets = a->sample_offsets;
   p.out_ids = a->out_ids, p.out_lid = a->out_center_lid, p.out_egid = a->out_edge_gid;
+  if (a->row_pairs != nullptr) {
+    // positions only: row bounds come from the fetched pairs, the caller gathers the columns by edge id afterwards
+    if (a->out_ids != nullptr || a->out_edge_gid == nullptr) return -1;
+    p.pairs = a->row_pairs;
+    return launch_sample<int64_t, int64_t>(p, stream);
+  }
+  p.row_ptr = make_view(a->row_gref), p.col_ptr = make_view(a->col_gref);
+  p.row_off = a->row_storage_offset, p.col_off = a->col_storage_offset;
   const bool id32 = a->center_dtype == WHOLEMEMORY_DT_INT, col32 = a->col_dtype == WHOLEMEMORY_DT_INT;
   if ((!id32 && a->center_dtype != WHOLEMEMORY_DT_INT64) || (!col32 && a->col_dtype != WHOLEMEMORY_DT_INT64)) return -1;
   if (id32 && col32) return launch_sample<int32_t, int32_t>(p, stream);
