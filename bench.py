@@ -69,10 +69,23 @@ def fill_table(local, row_start):
     torch.cuda.synchronize()
 
 
+def usable_cores():
+    """cores this process may really use: affinity mask, capped by a cgroup CPU quota when there is one"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(dim, seconds):
     """The oracle's gather (OpenMP over indices) on a host-resident table on this box's host cores:
     a bounded sample of the same workload shape (random 512 B rows, int64 ids)."""
     import oracle
+    oracle.set_num_threads(usable_cores())
     rows, n = 8_000_000, 2_000_000
     table = np.empty((rows, dim), dtype=np.float32)
     table[:] = (np.arange(rows, dtype=np.int64) & 0xFFFFFF).astype(np.float32)[:, None]
@@ -86,10 +99,30 @@ def cpu_baseline(dim, seconds):
         passes += 1
     dt = time.perf_counter() - t0
     lookups = passes * n / dt
-    return {"value": round(lookups * dim * 4 / 1e9, 3), "unit": "GB/s", "cores": oracle.num_threads(), "kind": "port",
-            "mlookups_per_s": round(lookups / 1e6, 2),
-            "sample": "oracle gather (C, OpenMP, %d threads): %d passes of %d random int64 ids over a host "
-                      "%dx%d fp32 table in %.1f s" % (oracle.num_threads(), passes, n, rows, dim, dt)}
+    threads = oracle.num_threads()
+    res = {"value": round(lookups * dim * 4 / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+           "mlookups_per_s": round(lookups / 1e6, 2),
+           "sample": "oracle gather (C, OpenMP, %d threads): %d passes of %d random int64 ids over a host "
+                     "%dx%d fp32 table in %.1f s" % (threads, passes, n, rows, dim, dt)}
+    # the two other host numbers SURVEY 8(d) asks for, a few seconds each: the same loop on ONE core, and what a user of
+    # the reference gets from get_global_tensor(host_view=True)[idx] (torch.index_select on a CPU tensor)
+    oracle.set_num_threads(1)
+    t0, passes = time.perf_counter(), 0
+    while time.perf_counter() - t0 < min(3.0, seconds):
+        oracle.gather(tab, idx, out)
+        passes += 1
+    res["single_thread_GBps"] = round(passes * n * dim * 4 / (time.perf_counter() - t0) / 1e9, 3)
+    oracle.set_num_threads(threads)
+    tt, ti = torch.from_numpy(table), torch.from_numpy(idx)
+    to = torch.from_numpy(out)
+    torch.index_select(tt, 0, ti, out=to)
+    t0, passes = time.perf_counter(), 0
+    while time.perf_counter() - t0 < min(3.0, seconds):
+        torch.index_select(tt, 0, ti, out=to)
+        passes += 1
+    res["torch_index_select_GBps"] = round(passes * n * dim * 4 / (time.perf_counter() - t0) / 1e9, 3)
+    res["torch_threads"] = torch.get_num_threads()
+    return res
 
 
 def main():

@@ -280,6 +280,12 @@ def main():
         scenario_gather_scatter(comm, rank, world, "chunked", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
         scenario_gather_scatter(comm, rank, world, "continuous", 2003, 32, np.float32, np.float16, np.int32, ent2, loc="cpu")
         scenario_gather_scatter(comm, rank, world, "distributed", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
+        # (4b') the same CHUNKED / CONTINUOUS tables served through the explicit all-to-all-v route
+        os.environ["WM_MAPPED_VIA_EXCHANGE"] = "1"
+        scenario_gather_scatter(comm, rank, world, "chunked", 3001, 128, np.float32, np.float32, np.int64, None)
+        scenario_gather_scatter(comm, rank, world, "continuous", 997, 8, np.int64, np.int32, np.int64, ent)
+        scenario_gather_scatter(comm, rank, world, "chunked", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
+        del os.environ["WM_MAPPED_VIA_EXCHANGE"]
         # (4c) neighbour sampling on a CSR spread over the ranks
         scenario_sampling(comm, rank, world, "distributed", np.int64)
         scenario_sampling(comm, rank, world, "distributed", np.int32)

@@ -175,6 +175,20 @@ wholememory_error_code_t mapped_gref(wholememory_tensor_t t, wholememory_gref_t*
 }
 wholememory_error_code_t tensor_mapped_gref(wholememory_tensor_t t, wholememory_gref_t* gref) { return mapped_gref(t, gref); }
 
+// WM_MAPPED_VIA_EXCHANGE=1: CHUNKED / CONTINUOUS tables shared by several ranks are served by the explicit
+// bucket -> all-to-all-v -> owner-side kernel route of the DISTRIBUTED type instead of loads / stores through the peer
+// mappings. The op then becomes COLLECTIVE over the table's communicator (every rank must call), which is why it is
+// opt-in: by default mapped gathers / scatters stay rank-local and asynchronous like the reference's.
+bool mapped_via_exchange(wholememory_tensor_t t, wholememory_memory_type_t mt)
+{
+  if (mt != WHOLEMEMORY_MT_CHUNKED && mt != WHOLEMEMORY_MT_CONTINUOUS) return false;
+  const char* e = getenv("WM_MAPPED_VIA_EXCHANGE");
+  if (e == nullptr || e[0] != '1') return false;
+  wholememory_comm_t comm;
+  if (wholememory_get_communicator(&comm, wholememory_tensor_get_memory_handle(t)) != WHOLEMEMORY_SUCCESS) return false;
+  return comm->world_size > 1;
+}
+
 int exchange_chunks(int world_size, int64_t rows_moved)
 {
   if (world_size <= 1) return 1;
@@ -543,7 +557,7 @@ wholememory_error_code_t wholememory_gather(wholememory_tensor_t wholememory_ten
   const bool has_handle = wholememory_tensor_has_handle(wholememory_tensor);
   auto mt = has_handle ? wholememory_get_memory_type(wholememory_tensor_get_memory_handle(wholememory_tensor))
                        : WHOLEMEMORY_MT_NONE;
-  if (has_handle && mt == WHOLEMEMORY_MT_DISTRIBUTED)
+  if (has_handle && (mt == WHOLEMEMORY_MT_DISTRIBUTED || wm::mapped_via_exchange(wholememory_tensor, mt)))
     return wm::gather_distributed(wholememory_tensor_get_memory_handle(wholememory_tensor), d, p_env_fns, stream, gather_sms);
   if (has_handle && mt != WHOLEMEMORY_MT_CHUNKED && mt != WHOLEMEMORY_MT_CONTINUOUS) return WHOLEMEMORY_NOT_SUPPORTED;
   wholememory_gref_t gref;
@@ -571,7 +585,7 @@ wholememory_error_code_t wholememory_scatter(wholememory_tensor_t input_tensor,
   const bool has_handle = wholememory_tensor_has_handle(wholememory_tensor);
   auto mt = has_handle ? wholememory_get_memory_type(wholememory_tensor_get_memory_handle(wholememory_tensor))
                        : WHOLEMEMORY_MT_NONE;
-  if (has_handle && mt == WHOLEMEMORY_MT_DISTRIBUTED)
+  if (has_handle && (mt == WHOLEMEMORY_MT_DISTRIBUTED || wm::mapped_via_exchange(wholememory_tensor, mt)))
     return wm::scatter_distributed(wholememory_tensor_get_memory_handle(wholememory_tensor), d, p_env_fns, stream, scatter_sms);
   if (has_handle && mt != WHOLEMEMORY_MT_CHUNKED && mt != WHOLEMEMORY_MT_CONTINUOUS) return WHOLEMEMORY_NOT_SUPPORTED;
   wholememory_gref_t gref;

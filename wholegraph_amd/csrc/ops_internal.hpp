@@ -86,4 +86,7 @@ wholememory_gref_t local_shard_gref(wholememory_handle_t handle);
 // gref a kernel should use for a tensor mapped in this process (CONTINUOUS / CHUNKED handle or a plain pointer)
 wholememory_error_code_t tensor_mapped_gref(wholememory_tensor_t t, wholememory_gref_t* gref);
 
+// true when a CHUNKED / CONTINUOUS table should be served through the all-to-all-v route (WM_MAPPED_VIA_EXCHANGE=1)
+bool mapped_via_exchange(wholememory_tensor_t t, wholememory_memory_type_t mt);
+
 }  // namespace wm
