@@ -242,6 +242,16 @@ def main():
                                "algorithmic_bytes_per_launch": a.indices * algo_bytes}
             if not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(a.dim, a.cpu_seconds)
+        if world > 1 and a.op == "gather" and mt == "distributed":
+            # the step is bound by the point-to-point xGMI links: every rank pulls (W-1)/W of its rows from peers,
+            # one link per peer. Uniform ids -> n/W rows + ids per ordered pair per step.
+            pair_bytes = a.indices / world * (out_bytes + 8) if a.dist == "uniform" else None
+            res["exchange"] = {"bound": "xgmi", "link_peak_GBps_per_direction": 76.8,
+                               "bytes_per_ordered_pair_per_step": pair_bytes,
+                               "achieved_GBps_per_link_direction":
+                                   round(pair_bytes / (wall / a.steps) / 1e9, 2) if pair_bytes else None,
+                               "note": "rows all-to-all-v over RCCL grouped send/recv, pipelined in row chunks with the "
+                                       "owner-side gather and the reorder-on-receive kernels"}
         print(json.dumps(res))
     wgth.destroy_embedding(emb)
     if launched:

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -234,7 +235,10 @@ template <typename IdxT, int OPT, int V>
 __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
 {
   typedef float vec_t __attribute__((ext_vector_type(V)));
-  constexpr int K            = 4;  // independent runs a wave keeps in flight (the work per run is a chain of
+#ifndef WM_STEP_K
+#define WM_STEP_K 4
+#endif
+  constexpr int K            = WM_STEP_K;  // independent runs a wave keeps in flight (the work per run is a chain of
                                    // dependent loads: run_starts -> order -> gradient row; table row)
   const wm_optimizer_args& a = p.a;
   const int lane             = threadIdx.x & 63;
@@ -482,7 +486,9 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
     if (hipMemsetAsync(p.long_count, 0, 16, stream) != hipSuccess) return -2;
   }
   int64_t waves = a->count;
-  int blocks    = static_cast<int>(std::min<int64_t>((waves + 3) / 4, 256 * 8));
+  int max_blocks = 256 * 8;
+  if (const char* e = getenv("WM_STEP_BLOCKS")) max_blocks = std::max(1, atoi(e));
+  int blocks = static_cast<int>(std::min<int64_t>((waves + 3) / 4, max_blocks));
   if (blocks < 1) blocks = 1;
   if (a->index_dtype == WHOLEMEMORY_DT_INT) return launch_step<int32_t>(p, blocks, stream);
   if (a->index_dtype == WHOLEMEMORY_DT_INT64) return launch_step<int64_t>(p, blocks, stream);
