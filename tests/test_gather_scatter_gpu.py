@@ -74,6 +74,19 @@ GATHER_CASES = [
     (20011, 64, 64, "i8", "i64", "i64", 5000, 64),
     (20011, 33, 33, "i16", "i8", "i64", 5000, 33),
     (20011, 64, 64, "i64", "i64", "i64", 5000, 64),
+    # row shapes served by the flat-stream kernel (rows.hip:rows_flat_kernel): not a power of two, 1 KiB, and rows
+    # that are only a multiple of 4 bytes (unaligned 16-byte accesses + dword tail)
+    (20011, 100, 100, "f32", "f32", "i64", 20000, 100),   # 400 B (ogbn-products)
+    (20011, 100, 100, "f32", "f32", "i32", 20000, 100),
+    (20011, 200, 200, "f32", "f32", "i64", 9000, 200),    # 800 B
+    (20011, 256, 256, "f32", "f32", "i64", 9000, 256),    # 1 KiB
+    (20011, 300, 300, "f32", "f32", "i64", 9000, 300),    # 1200 B
+    (9011, 602, 604, "f32", "f32", "i64", 5000, 602),     # reddit: 2408 B rows in a 16-byte-padded table, dense output
+    (9011, 602, 602, "f32", "f32", "i64", 5000, 602),     # both sides 8-byte aligned only
+    (9011, 300, 300, "f32", "f32", "i64", 5000, 301),     # output stride 301: rows 4-byte aligned only
+    (9011, 602, 602, "f16", "f16", "i64", 5000, 602),     # 1204 B rows of halves
+    (9011, 1023, 1023, "f16", "f16", "i64", 3000, 1023),  # 2046 B: 2-byte granularity, NOT flat (stays on 2-byte vectors)
+    (5011, 4100, 4100, "f32", "f32", "i64", 1000, 4100),  # 16400 B
 ]
 
 
@@ -141,6 +154,48 @@ def test_scatter_then_gather_roundtrip(gpu_env, mt, loc, tdt, idt, pdt):
     exp = np.zeros((n_idx, dim), dtype=NP[pdt])
     oracle.gather(ref, idx, exp)
     assert np.array_equal(back.cpu().numpy()[valid], exp[valid])
+    wgth.destroy_wholememory_tensor(root)
+
+
+@pytest.mark.parametrize("flat", ["default", "1", "0"])
+@pytest.mark.parametrize("mt", ["chunked", "distributed"])
+@pytest.mark.parametrize("dim,stride,np_dt", [(100, 100, "f32"), (256, 256, "f32"), (300, 300, "f32"), (602, 604, "f32"),
+                                              (602, 602, "f32"), (513, 513, "f32"), (602, 602, "f16"), (33, 33, "f32"),
+                                              (128, 128, "f32")])
+def test_scatter_row_shapes(gpu_env, monkeypatch, mt, dim, stride, np_dt, flat):
+    """scatter (and the gather back) over the row shapes above, with the kernel choice forced both ways
+    (WM_ROWS_FLAT=1: flat-stream kernel wherever it is legal, 0: never) — all three must agree with the oracle."""
+    torch = _torch()
+    import wholegraph_amd.torch as wgth
+    if flat != "default":
+        monkeypatch.setenv("WM_ROWS_FLAT", flat)
+    n_rows, n_idx = 7001, 6000
+    root = wgth.create_wholememory_tensor(gpu_env, mt, "cuda", [n_rows, stride], _tt(NP[np_dt]), [stride, 1])
+    view = root.get_sub_tensor([0, 0], [n_rows, dim]) if dim != stride else root
+    local, _ = root.get_local_tensor()
+    local.zero_()
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(dim * 7 + stride)
+    idx = rng.permutation(n_rows)[:n_idx].astype(np.int64)      # unique ids: scatter order does not matter
+    idx[::37] = -1
+    rows = rng.integers(-100, 100, (n_idx, dim)).astype(NP[np_dt])
+    view.scatter(torch.from_numpy(rows).cuda(), torch.from_numpy(idx).cuda())
+    torch.cuda.synchronize()
+    exp = np.zeros((n_rows, stride), dtype=NP[np_dt])
+    exp[idx[idx >= 0], :dim] = rows[idx >= 0]
+    assert local.cpu().numpy().tobytes() == exp.tobytes(), "table after scatter differs (pad columns must stay untouched)"
+    back = torch.full((n_idx, dim), 7, dtype=_tt(NP[np_dt]), device="cuda")
+    from wholegraph_amd import binding as wmb
+    from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream
+    wi, wo = wrap_torch_tensor(torch.from_numpy(idx).cuda()), wrap_torch_tensor(back)
+    wmb.check(wmb.lib().wholememory_gather(view.wmb_tensor, wi.handle, wo.handle, get_wholegraph_env_fns(),
+                                           C.c_void_p(get_stream()), -1))
+    torch.cuda.synchronize()
+    want = np.full((n_idx, dim), 7, dtype=NP[np_dt])
+    want[idx >= 0] = rows[idx >= 0]
+    assert back.cpu().numpy().tobytes() == want.tobytes()
+    if view is not root:
+        wgth.destroy_wholememory_tensor(view)
     wgth.destroy_wholememory_tensor(root)
 
 

@@ -24,6 +24,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "../backend.hpp"
 #include "device_common.cuh"
 
@@ -78,6 +81,10 @@ struct rows_params {
   // geometry
   int row_vecs;   // vectors per row (row_bytes / VB  or  dim / V)
   int lpr_log2;   // log2(lanes per row)
+  // flat-stream geometry (rows_flat_kernel): 16-byte slots per row, bytes in the last slot (4..16), 1 / slots
+  int flat_slots;
+  int flat_tail;
+  float flat_rcp;
 };
 
 // byte address of the first moved element of table row `idx`
@@ -273,6 +280,84 @@ __global__ __launch_bounds__(kBlock) void rows_copy16_fast_kernel(rows_params p)
   }
 }
 
+// Rows whose size is not a power of two (400 B, 1200 B, 2408 B ... : dims 100 / 300 / 602 of common GNN datasets), and
+// 1 KiB rows. The pow-of-two lane mapping above leaves lanes idle and walks a big row in several passes; here the tile is
+// a FLAT STREAM of 16-byte slots: slot v of the tile belongs to row v / S, column v % S (S slots per row), lane l of
+// step k owns slot 64 k + l. Every lane is busy whatever S is, a row is walked front to back once (DRAM page locality),
+// and a dense output is written as one contiguous stream. Row bases travel with ds_bpermute. Rows whose byte count is
+// only a multiple of 4 use full 16-byte accesses at their natural (4-byte) alignment — legal on gfx950 global memory —
+// plus a dword tail in the last slot, instead of dropping the whole row to 4- or 8-byte vectors.
+// Measured (10 M random ids, 8 GB table, % of 8 TB/s algorithmic): gather 400 B 54 -> 60, 800 B 57 -> 64, 1 KiB 60 -> 72,
+// 1200 B 47 -> 65, 2408 B 42 -> 59, 516 B 27 -> 54; scatter 2408 B 42 -> 55, 516 B 27 -> 47 (for 16-byte-multiple rows
+// scatter keeps the kernels above).
+template <typename IdxT, bool GATHER, bool HAS_MAP>
+__global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
+{
+  constexpr int kU      = 4;
+  const int lane        = threadIdx.x & (kWave - 1);
+  const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  const int64_t tiles   = (p.n + kWave - 1) / kWave;
+  const int S           = p.flat_slots;
+  const int n_slots     = kWave * S;
+  const bool ragged     = p.flat_tail != 16;
+
+  for (int64_t tile = wave; tile < tiles; tile += n_waves) {
+    char *my_tab, *my_plain;
+    load_tile_entry<IdxT>(p, tile * kWave + lane, my_tab, my_plain);
+    char* const plain_tile = p.plain + tile * kWave * p.plain_stride_bytes;
+#pragma unroll 1
+    for (int v0 = 0; v0 < n_slots; v0 += kWave * kU) {
+      u32x4 data[kU];
+      char* dst[kU];
+      bool part[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        const int v = v0 + u * kWave + lane;
+        int row     = static_cast<int>(static_cast<float>(v) * p.flat_rcp);  // v / S, fixed up below
+        int col     = v - row * S;
+        if (col < 0) {
+          row--;
+          col += S;
+        }
+        if (col >= S) {
+          row++;
+          col -= S;
+        }
+        char* t         = shfl_ptr(my_tab, row & (kWave - 1));
+        char* q         = HAS_MAP ? shfl_ptr(my_plain, row & (kWave - 1)) : plain_tile + row * p.plain_stride_bytes;
+        const bool ok   = v < n_slots && t != nullptr;  // entries past n and negative ids carry a null base
+        part[u]         = ragged && col == S - 1;
+        const char* src = (GATHER ? t : q) + col * 16;
+        dst[u]          = ok ? (GATHER ? q : t) + col * 16 : nullptr;
+        if (ok) {
+          if (!part[u]) {
+            if constexpr (GATHER)
+              data[u] = *reinterpret_cast<const u32x4*>(src);  // rows share cache lines with their neighbours: keep them
+            else
+              data[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+          } else {
+#pragma unroll
+            for (int w = 0; w < 3; w++)
+              if (w * 4 < p.flat_tail) data[u][w] = reinterpret_cast<const uint32_t*>(src)[w];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        if (dst[u] == nullptr) continue;
+        if (!part[u]) {
+          __builtin_nontemporal_store(data[u], reinterpret_cast<u32x4*>(dst[u]));
+        } else {
+#pragma unroll
+          for (int w = 0; w < 3; w++)
+            if (w * 4 < p.flat_tail) reinterpret_cast<uint32_t*>(dst[u])[w] = data[u][w];
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // converting path: V elements per lane, FromT -> ToT through the reference's conversion chain
 // ------------------------------------------------------------------------------------------------
@@ -357,9 +442,42 @@ int default_max_blocks()
   return cus * 32;  // measured: 8192 workgroups (32 per CU) beat 2048 by ~2% on the 10 M-id gather
 }
 
+// 0 = never, 1 = always when legal, -1 (default) = by the measured rule in want_flat()
+int flat_override()
+{
+  const char* e = getenv("WM_ROWS_FLAT");
+  return e == nullptr ? -1 : atoi(e);
+}
+
+// flat-stream kernel or the pow-of-two lane mappings? (rule from experiments/dim_sweep.py, see rows_flat_kernel)
+bool want_flat(bool gather, int vb, int64_t row_bytes)
+{
+  const int ov = flat_override();
+  if (ov == 0) return false;
+  if (ov == 1) return true;
+  const bool pow2 = (row_bytes & (row_bytes - 1)) == 0;
+  if (vb == 16) return gather && row_bytes > 256 && (!pow2 || row_bytes == 1024);
+  // 4- / 8-byte-multiple rows: 16-byte accesses at 4-byte alignment beat 4- / 8-byte vectors from ~320 B up
+  // (508 B: 37 -> 46 %, 516 B: 27 -> 54 %, 2408 B: 42 -> 59 %; 200 B: 44 -> 41 %, so small rows stay on the old path)
+  return row_bytes >= 320;
+}
+
+template <typename IdxT, bool GATHER>
+void launch_flat(const rows_params& p, int blocks, hipStream_t stream)
+{
+  if (p.row_map != nullptr)
+    hipLaunchKernelGGL((rows_flat_kernel<IdxT, GATHER, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  else
+    hipLaunchKernelGGL((rows_flat_kernel<IdxT, GATHER, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
+}
+
 template <typename IdxT, bool GATHER>
 void launch_copy(const rows_params& p, int vb, int blocks, hipStream_t stream)
 {
+  if (p.flat_slots > 0) {
+    launch_flat<IdxT, GATHER>(p, blocks, stream);
+    return;
+  }
   if (vb == 16 && p.row_vecs >= 32) {  // rows of >= 512 B: readlane fast path
     const bool one_row = p.row_vecs > 32;  // > 512 B: a full wave per row
     const bool has_map = p.row_map != nullptr;
@@ -498,6 +616,13 @@ int rows_op(const wm_rows_args* a, void* stream_v)
     vb                      = pow2_divisor(static_cast<int64_t>(reinterpret_cast<uint64_t>(p.plain) & 15), vb);
     p.row_vecs              = static_cast<int>(row_bytes / vb);
     p.lpr_log2              = std::min(6, ilog2_ceil(p.row_vecs));
+    // flat-stream kernel: needs every address 4-byte aligned (then 16-byte accesses are legal at any such address)
+    const bool dword_ok = vb >= 4 && row_bytes < (INT64_C(1) << 24);
+    if (dword_ok && want_flat(GATHER, static_cast<int>(vb), row_bytes)) {
+      p.flat_slots = static_cast<int>((row_bytes + 15) / 16);
+      p.flat_tail  = static_cast<int>(row_bytes - 16 * static_cast<int64_t>(p.flat_slots - 1));
+      p.flat_rcp   = 1.0f / static_cast<float>(p.flat_slots);
+    }
     if (a->index_dtype == WHOLEMEMORY_DT_INT)
       launch_copy<int32_t, GATHER>(p, static_cast<int>(vb), blocks, stream);
     else
