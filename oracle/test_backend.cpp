@@ -201,9 +201,12 @@ int t_step(const wm_optimizer_args* a, const int64_t* n_unique_dev, void*)
   std::vector<float> g(a->dim);
   for (int64_t u = 0; u < count; u++) {
     for (int64_t d = 0; d < a->dim; d++) {
-      float acc = a->grads[static_cast<int64_t>(a->order[a->run_starts[u]]) * a->grad_stride + d];
-      for (int32_t j = a->run_starts[u] + 1; j < a->run_starts[u + 1]; j++)
-        acc += a->grads[static_cast<int64_t>(a->order[j]) * a->grad_stride + d];
+      auto row = [&](int32_t o) {  // wm_optimizer_args::self_grads: negative entries address the caller's own rows
+        return o >= 0 ? a->grads + static_cast<int64_t>(o) * a->grad_stride
+                      : a->self_grads + (-(static_cast<int64_t>(o) + 1)) * a->self_grad_stride;
+      };
+      float acc = row(a->order[a->run_starts[u]])[d];
+      for (int32_t j = a->run_starts[u] + 1; j < a->run_starts[u + 1]; j++) acc += row(a->order[j])[d];
       g[d] = acc;
     }
     int64_t id64     = idx_at(a->ids, a->index_dtype, u);
@@ -237,6 +240,14 @@ int t_step(const wm_optimizer_args* a, const int64_t* n_unique_dev, void*)
 }
 
 size_t t_long_ws(int64_t) { return 64; }
+int t_remap_self(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count, const int64_t* self_rows, void*)
+{
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t pos = order[i] - self_begin;
+    if (pos >= 0 && pos < self_count) order[i] = static_cast<int32_t>(-(self_rows[pos] + 1));
+  }
+  return 0;
+}
 int t_rr(const void* ids, void* mapped, wholememory_dtype_t dt, int64_t n, int64_t entry_start, int world, int rr, void*)
 {
   wmo_round_robin_map(ids, dt, n, entry_start, world, rr, mapped);
@@ -253,7 +264,7 @@ const wm_device_backend kTestBackend = {
   t_device_count, t_malloc, t_free, t_malloc, t_free, t_memcpy, t_memset, t_sync,
   t_stream_create, t_noop1, t_event_create, t_noop1, t_noop2, t_noop2,
   t_ipc_get, t_ipc_open, t_ipc_close, t_host_register, t_host_unregister,
-  t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_long_ws, t_rr, t_fill,
+  t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_long_ws, t_remap_self, t_rr, t_fill,
 };
 
 }  // namespace

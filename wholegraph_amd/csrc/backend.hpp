@@ -58,6 +58,10 @@ struct wm_optimizer_args {
   const int32_t* order;        // [n_recv] device: receive-buffer positions sorted by (id, position)
   const float* grads;          // [n_recv, grad_stride] device: received gradient rows
   int64_t grad_stride;
+  // order[] entries >= 0 address rows of `grads`; an entry < 0 addresses row -(entry + 1) of `self_grads` — gradient rows
+  // of ids this rank owns itself, read where the caller left them instead of being copied into the receive buffer
+  const float* self_grads;
+  int64_t self_grad_stride;
   int64_t count;               // number of unique ids (= grid size)
   float* local_table;          // this rank's first row
   int64_t table_stride;        // elements
@@ -134,6 +138,9 @@ struct wm_device_backend {
   // number of unique ids is read from that device scalar (no host sync to learn it).
   int (*optimizer_step)(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);
   size_t (*long_run_workspace_bytes)(int64_t n_recv);
+  // order[i] in [self_begin, self_begin + self_count)  ->  -(self_rows[order[i] - self_begin] + 1)   (see self_grads)
+  int (*remap_self_order)(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count, const int64_t* self_rows,
+                          void* stream);
   int (*round_robin_map)(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n,
                          int64_t entry_start, int world_size, int round_robin_size, void* stream);
   int (*fill_float)(float* p, float value, int64_t count, void* stream);

@@ -10,6 +10,7 @@
 // intermediate de-duplicated gradient buffer and no host sync to learn the unique count.
 // The device LFU cache of the reference (embedding_cache.*) is outside this build's scope:
 // creating an embedding with a cache policy returns WHOLEMEMORY_NOT_IMPLEMENTED.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -179,9 +180,18 @@ void fill_optimizer_args(wm_optimizer_args* a, const wholememory_embedding_optim
 // owner side: sort received ids, then the fused duplicate-sum + optimizer kernel
 // `rows_ready` (optional event): recorded on another stream when recv_grads is complete; the id sort does not need
 // the rows, so it is issued first and only the step kernel waits for the event.
+// gradient rows of ids this rank owns itself, left in the caller's tensor: receive positions
+// [begin, begin + count) stand for rows `rows[i]` of `grads` (see wm_optimizer_args::self_grads)
+struct self_rows_ref {
+  int64_t begin = 0, count = 0;
+  const int64_t* rows = nullptr;
+  const float* grads  = nullptr;
+  int64_t stride      = 0;
+};
+
 void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64_t n_recv, const float* recv_grads,
                     int64_t grad_stride, wm_optimizer_args* oa, int64_t key_upper_bound, wholememory_env_func_t* env,
-                    void* stream, int64_t* n_unique_host, void* rows_ready = nullptr)
+                    void* stream, int64_t* n_unique_host, void* rows_ready = nullptr, const self_rows_ref* self = nullptr)
 {
   const auto* bk = backend();
   if (n_recv == 0) {
@@ -204,6 +214,11 @@ void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64
   oa->order       = d_order;
   oa->grads       = recv_grads;
   oa->grad_stride = grad_stride;
+  if (self != nullptr && self->count > 0) {
+    WM_BK(bk->remap_self_order(d_order, n_recv, self->begin, self->count, self->rows, stream));
+    oa->self_grads       = self->grads;
+    oa->self_grad_stride = self->stride;
+  }
   oa->count       = n_recv;  // upper bound; the kernel reads the true count from d_nunique
   oa->long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n_recv)), WHOLEMEMORY_DT_INT8);
   if (rows_ready != nullptr) WM_BK(bk->stream_wait_event(stream, rows_ready));
@@ -291,7 +306,21 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     ga.max_blocks   = -1;
     WM_BK(bk->gather_rows(&ga, stream));
   };
-  launch_rows(x.self_offset, x.self_offset + x.self_count, recv_buf + full_recv_offsets[rank] * dim);
+  // this rank's own rows are not copied at all: the step kernels read them where the caller left them (the receive
+  // positions of the self segment are remapped to caller rows after the sort). WM_GRAD_SELF_COPY=1 restores the copy.
+  const char* self_copy_env = getenv("WM_GRAD_SELF_COPY");
+  const bool self_direct    = x.self_count > 0 && bk->remap_self_order != nullptr &&
+                           !(self_copy_env != nullptr && self_copy_env[0] == '1');
+  self_rows_ref self_ref;
+  if (self_direct) {
+    self_ref.begin  = full_recv_offsets[rank];
+    self_ref.count  = x.self_count;
+    self_ref.rows   = x.raw_indices + x.self_offset;
+    self_ref.grads  = static_cast<const float*>(wholememory_tensor_get_data_pointer(grads));
+    self_ref.stride = gmat.stride;
+  } else {
+    launch_rows(x.self_offset, x.self_offset + x.self_count, recv_buf + full_recv_offsets[rank] * dim);
+  }
   // peers' rows: line-up (HBM) and all-to-all-v (xGMI, side stream) pipelined in C row-chunks; the id sort that
   // follows on the caller's stream overlaps with the tail of the exchange
   const int W = e->comm->world_size;
@@ -338,7 +367,8 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     oa.per_row_state = static_cast<float*>(wholememory_tensor_get_data_pointer(e->per_row_local));
   wholememory_destroy_tensor(local_table);
   dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa,
-                 static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived);
+                 static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived,
+                 self_direct ? &self_ref : nullptr);
   // temporaries go back to the caller's allocator on return; like the reference's distributed ops
   // the stream is drained first so nothing in flight still reads them
   WM_BK(bk->stream_sync(stream));

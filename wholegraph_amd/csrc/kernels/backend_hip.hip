@@ -16,6 +16,8 @@ int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, i
                   void* stream);
 int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);
 size_t hip_long_run_ws_bytes(int64_t n_recv);
+int hip_remap_self_order(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count, const int64_t* self_rows,
+                         void* stream);
 int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n, int64_t entry_start,
                         int world_size, int round_robin_size, void* stream);
 int hip_fill_float(float* p, float value, int64_t count, void* stream);
@@ -132,6 +134,7 @@ const wm_device_backend kHipBackend = {
   hip_dedup_ids,
   hip_optimizer_step_dev,
   hip_long_run_ws_bytes,
+  hip_remap_self_order,
   hip_round_robin_map,
   hip_fill_float,
   hip_sample_counts,

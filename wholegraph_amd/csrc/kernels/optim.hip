@@ -169,6 +169,13 @@ struct opt_elem {
   float e, s0, s1;  // table value, first / second per-element state (m, v | state_sum | v)
 };
 
+// gradient row addressed by an order[] entry (wm_optimizer_args::self_grads)
+__device__ __forceinline__ const float* grad_row(const wm_optimizer_args& a, int32_t o)
+{
+  return o >= 0 ? a.grads + static_cast<int64_t>(o) * a.grad_stride
+                : a.self_grads + (-(static_cast<int64_t>(o) + 1)) * a.self_grad_stride;
+}
+
 template <int OPT>
 __device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, int64_t local, int64_t d)
 {
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
 #pragma unroll
       for (int k = 0; k < K; k++) {
         // first occurrence copied (DedupIndiceAndGradientsKernel); table / state values loaded alongside
-        acc[k] = *reinterpret_cast<const vec_t*>(a.grads + static_cast<int64_t>(r_cur.o0[k]) * a.grad_stride + d);
+        acc[k] = *reinterpret_cast<const vec_t*>(grad_row(a, r_cur.o0[k]) + d);
 #pragma unroll
         for (int v = 0; v < V; v++) x[k][v] = load_elem<OPT>(a, m_cur.local[k], d + v);
       }
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
           for (int q = 0; q < 4; q++) o[q] = a.order[min(j + q, m_cur.s1[k] - 1)];
 #pragma unroll
           for (int q = 0; q < 4; q++)
-            g[q] = *reinterpret_cast<const vec_t*>(a.grads + static_cast<int64_t>(o[q]) * a.grad_stride + d);
+            g[q] = *reinterpret_cast<const vec_t*>(grad_row(a, o[q]) + d);
 #pragma unroll
           for (int q = 0; q < 4; q++)
             if (j + q < m_cur.s1[k]) acc[k] += g[q];
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void step_long_kernel(opt_params p)
       for (int i = 0; i < kLoads; i++) o[i] = a.order[min(base + r_ld + kRowStep * i, s1 - 1)];
 #pragma unroll
       for (int i = 0; i < kLoads; i++) {
-        const float* src = a.grads + static_cast<int64_t>(o[i]) * a.grad_stride + col0 + c_cl;
+        const float* src = grad_row(a, o[i]) + col0 + c_cl;
         if constexpr (VEC4)
           stage[i] = *reinterpret_cast<const f4*>(src);
         else
@@ -437,8 +444,10 @@ __global__ __launch_bounds__(kBlock) void step_long_kernel(opt_params p)
 template <typename IdxT, int OPT>
 int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream)
 {
-  const uint64_t gaddr = reinterpret_cast<uint64_t>(p.a.grads);
-  const bool vec2      = p.a.dim % 2 == 0 && p.a.grad_stride % 2 == 0 && gaddr % 8 == 0;
+  const uint64_t gaddr = reinterpret_cast<uint64_t>(p.a.grads) | reinterpret_cast<uint64_t>(p.a.self_grads);
+  const bool self_ok2  = p.a.self_grads == nullptr || p.a.self_grad_stride % 2 == 0;
+  const bool self_ok4  = p.a.self_grads == nullptr || p.a.self_grad_stride % 4 == 0;
+  const bool vec2      = p.a.dim % 2 == 0 && p.a.grad_stride % 2 == 0 && gaddr % 8 == 0 && self_ok2;
   // (a float4-per-lane variant, two runs per wave instruction, was measured too: no gain for SGD, 10-15 % slower for the
   // stateful optimizers through register pressure — 8 bytes per lane stay)
   if (vec2)
@@ -447,7 +456,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream)
     hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1>), dim3(blocks), dim3(kBlock), 0, stream, p);
   if (p.long_list != nullptr) {
     const int slices = static_cast<int>((p.a.dim + kSliceCols - 1) / kSliceCols);
-    const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0;
+    const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4;
     if (long4)
       hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, true>), dim3(1024, slices), dim3(kBlock), 0, stream, p);
     else
@@ -534,6 +543,25 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   if (a->index_dtype == WHOLEMEMORY_DT_INT) return launch_step<int32_t>(p, blocks, stream);
   if (a->index_dtype == WHOLEMEMORY_DT_INT64) return launch_step<int64_t>(p, blocks, stream);
   return -1;
+}
+
+__global__ void remap_self_order_kernel(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count,
+                                        const int64_t* self_rows)
+{
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t pos = order[i] - self_begin;
+  if (pos >= 0 && pos < self_count) order[i] = static_cast<int32_t>(-(self_rows[pos] + 1));
+}
+
+int hip_remap_self_order(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count, const int64_t* self_rows,
+                         void* stream)
+{
+  if (n == 0 || self_count == 0) return 0;
+  const int blocks = static_cast<int>((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(remap_self_order_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), order, n,
+                     self_begin, self_count, self_rows);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n, int64_t entry_start,
