@@ -94,7 +94,8 @@ OPTS = [("sgd", 1, {}), ("sgd", 1, {"weight_decay": 0.05}), ("adam", 2, {}), ("a
 
 @pytest.mark.parametrize("kind,code,params", OPTS, ids=lambda x: str(x))
 @pytest.mark.parametrize("dim,n_recv,idt", [(127, 20005, np.int64), (129, 20005, np.int32), (128, 50001, np.int64),
-                                            (392, 5001, np.int64), (4, 3000, np.int64), (128, 0, np.int64)])
+                                            (392, 5001, np.int64), (4, 3000, np.int64), (128, 0, np.int64), (256, 100003, np.int64),
+                                            (64, 41000, np.int32)])
 def test_dedup_apply_bit_exact(gpu_env, kind, code, params, dim, n_recv, idt):
     import torch
     from wholegraph_amd import binding as wmb

@@ -441,6 +441,136 @@ __global__ __launch_bounds__(kBlock) void step_long_kernel(opt_params p)
   }
 }
 
+// step_long_kernel restructured for rows of whole float4s. Two facts pace a long run (measured on the Zipf(1.05)
+// batch whose hottest id has ~490 k duplicates, 8.8 ms in the kernel above):
+//   (1) one CU pulls at most ~10-13 B/cycle (~25-30 GB/s) out of HBM, whatever it keeps in flight (a 128-column,
+//       whole-row variant of this kernel with a 3-tile LDS-DMA ring ran at 23 GB/s per workgroup and was SLOWER,
+//       11 ms): the fetch of one run has to be spread over CUs, so a workgroup takes a narrow column slice — WM_LONG_SLICE
+//       columns, one workgroup per (run, slice) — and more slices = more CUs on the same run;
+//   (2) the kernel above keeps ONE tile in flight and pays two dependent HBM latencies per tile (order[] entries, then
+//       rows): 7 GB/s per workgroup, a quarter of (1).
+// So: tiles travel global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction = 256 / S rows of the
+// slice) into a ring of kRing tile buffers — no staging registers, and because the compiler does not track LDS-DMA
+// results the waits are hand-counted `s_waitcnt vmcnt(N)` + raw `s_barrier`, so kRing - 1 tiles really stay in flight
+// while one is folded (a register ring does not survive hipcc's s_waitcnt placement: it drains at every loop trip).
+// Loads return in issue order (vmcnt), so order[] reads interleaved with row reads would drain the ring: the order[]
+// entries of a CHUNK of 4096 rows are staged in LDS once and row addresses then come out of LDS. One wave folds a tile,
+// unpredicated for full tiles. Summation order per element is unchanged (receive order, first row copied): results
+// stay bit-identical.
+#ifndef WM_LONG_SLICE
+#define WM_LONG_SLICE 32
+#endif
+constexpr int kOrdChunk  = 4096;
+constexpr int kRing      = 4;
+constexpr int kSlice4    = WM_LONG_SLICE;        // columns per workgroup (16 or 32)
+constexpr int kTile4Rows = 8192 / kSlice4;       // rows per LDS tile: 32 KiB
+constexpr size_t kLong4LdsBytes = static_cast<size_t>(kRing) * kTile4Rows * kSlice4 * 4 + kOrdChunk * 4;
+
+constexpr int kLongProducers = 4;                          // waves that only fetch
+constexpr int kLongBlock     = 64 * (kLongProducers + 1);  // + wave 0, which only folds
+
+template <typename IdxT, int OPT>
+__global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
+{
+  extern __shared__ __attribute__((aligned(16))) float lds4[];
+  float* const tiles   = lds4;                                                           // [kRing][kTile4Rows][kSlice4]
+  int32_t* const ord_s = reinterpret_cast<int32_t*>(lds4 + kRing * kTile4Rows * kSlice4);  // [kOrdChunk]
+  const wm_optimizer_args& a = p.a;
+  const int n_long           = *p.long_count;
+  const IdxT* ids            = static_cast<const IdxT*>(a.ids);
+  const int col0             = blockIdx.y * kSlice4;
+  const int cols             = min(kSlice4, static_cast<int>(a.dim) - col0);  // multiple of 4
+  constexpr int kLpr         = kSlice4 / 4;                                   // lanes per row (16-byte pieces)
+  constexpr int kRpp         = 64 / kLpr;                                     // rows per wave instruction
+  constexpr int kLoads       = kTile4Rows / (kRpp * kLongProducers);          // pieces per producer lane per tile (8)
+  static_assert(kLoads * (kRing - 2) < 64, "vmcnt field");
+  const int lane             = threadIdx.x & 63;
+  // wave 0 folds, waves 1 .. kLongProducers fetch: the fetch side of a tile (8 x [ord_s read -> address -> M0 ->
+  // LDS-DMA issue] per wave) costs about as much wave time as folding it, and a wave doing both was the pacing item
+  const int wave_id   = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const bool producer = wave_id > 0;
+  const int wv        = wave_id - 1;
+  const int c_safe    = min((lane % kLpr) * 4, cols - 4);  // lanes past a narrow slice re-read its last float4
+  const int r_lane    = lane / kLpr;
+  const bool folder   = threadIdx.x < cols;  // one column per lane of wave 0
+
+  for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
+    const long_run_entry ent = p.long_list[li];
+    const int64_t u          = ent.run;
+    const int64_t local      = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
+    const int32_t s0         = a.run_starts[u];
+    const int32_t s1         = a.run_starts[u + 1];
+    float acc                = 0.f;
+    for (int32_t chunk = s0; chunk < s1; chunk += kOrdChunk) {
+      const int32_t chunk_rows = min(kOrdChunk, s1 - chunk);
+      const int n_tiles        = (chunk_rows + kTile4Rows - 1) / kTile4Rows;
+      __syncthreads();  // previous chunk fully folded; nothing of it is in flight (its last wait was vmcnt(0))
+      for (int i = threadIdx.x; i < kOrdChunk; i += kLongBlock) ord_s[i] = a.order[min(chunk + i, s1 - 1)];
+      __syncthreads();
+      // tile t -> ring slot t % kRing: kLoads LDS-DMA pieces per producer lane; producer w, piece i lands as the kRpp
+      // adjacent tile rows starting at kRpp (w + kLongProducers i) (wave-uniform LDS base + lane * 16 B). Rows are
+      // clamped into the chunk: tiles past its end re-read the last row, harmlessly — so every producer always has
+      // the same number of pieces in flight.
+      auto issue = [&](int t) {
+        float* slot = tiles + (t % kRing) * (kTile4Rows * kSlice4);
+        int32_t o[kLoads];
+#pragma unroll
+        for (int i = 0; i < kLoads; i++)
+          o[i] = ord_s[min(t * kTile4Rows + kRpp * (wv + kLongProducers * i) + r_lane, chunk_rows - 1)];
+#pragma unroll
+        for (int i = 0; i < kLoads; i++) {
+          const float* src = grad_row(a, o[i]) + col0 + c_safe;
+          typedef __attribute__((address_space(1))) void gvoid;
+          typedef __attribute__((address_space(3))) void lvoid;
+          __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(slot + kRpp * (wv + kLongProducers * i) * kSlice4), 16, 0,
+                                           0);
+        }
+      };
+      if (producer) {
+#pragma unroll
+        for (int j = 0; j < kRing - 1; j++) issue(j);
+      }
+      for (int tt = 0; tt < n_tiles; tt++) {
+        // producers: tiles tt .. tt + kRing - 2 are in flight (kLoads pieces each, oldest first): tile tt has landed
+        // once at most kLoads * (kRing - 2) pieces remain; the barrier extends that to every producer's pieces and
+        // tells them that wave 0 is done with tile tt - 1, whose slot the next tile reuses
+        if (producer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads * (kRing - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (producer) {
+          issue(tt + kRing - 1);
+        } else if (folder) {
+          const int32_t rows = min(kTile4Rows, chunk_rows - tt * kTile4Rows);
+          const float* src   = tiles + (tt % kRing) * (kTile4Rows * kSlice4) + threadIdx.x;
+          if (rows == kTile4Rows && !(chunk == s0 && tt == 0)) {
+            // the hot loop, no predicates. A lone wave sees ~200 cycles from an LDS read to its use: 64 rows are read
+            // back to back (hipcc waits for all of them — its lgkmcnt placement does not keep a second batch in
+            // flight), then folded by 64 dependent adds
+#pragma unroll 1
+            for (int32_t r = 0; r < kTile4Rows; r += 64) {
+              float v[64];
+#pragma unroll
+              for (int k = 0; k < 64; k++) v[k] = src[(r + k) * kSlice4];
+#pragma unroll
+              for (int k = 0; k < 64; k++) acc += v[k];
+            }
+          } else {
+            int32_t r = 0;
+            if (chunk == s0 && tt == 0) {
+              acc = src[0];  // first occurrence is copied, not added to 0
+              r   = 1;
+            }
+            for (; r < rows; r++) acc += src[r * kSlice4];
+          }
+        }
+      }
+      if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // clamped tail tiles must not land in the next chunk
+    }
+    if (!producer && folder) apply_optimizer<OPT>(a, local, col0 + threadIdx.x, acc, ent.beta1t, ent.beta2t);
+    __syncthreads();
+  }
+}
+
 template <typename IdxT, int OPT>
 int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream)
 {
@@ -457,7 +587,22 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream)
   if (p.long_list != nullptr) {
     const int slices = static_cast<int>((p.a.dim + kSliceCols - 1) / kSliceCols);
     const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4;
-    if (long4)
+    const bool rows4 = p.a.dim % 4 == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4 &&
+                       p.a.dim <= 65535 * kSlice4;
+    static const bool old_long = getenv("WM_STEP_LONG_OLD") != nullptr;
+    if (rows4 && !old_long) {
+      static const bool lds_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, OPT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLong4LdsBytes)) == hipSuccess;
+      if (!lds_ok) return -2;
+      // 144 KiB of LDS = one workgroup per CU: launch one resident wave of workgroups (256 CUs) and let each walk the
+      // run list — with more workgroups than CUs the hottest run may only START after several rounds of others
+      const int slices4 = static_cast<int>((p.a.dim + kSlice4 - 1) / kSlice4);
+      int gx            = std::max(1, 256 / slices4);
+      if (const char* e = getenv("WM_LONG_GRID")) gx = std::max(1, atoi(e));
+      hipLaunchKernelGGL((step_long4_kernel<IdxT, OPT>), dim3(gx, slices4), dim3(kLongBlock), kLong4LdsBytes, stream, p);
+    }
+    else if (long4)
       hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, true>), dim3(1024, slices), dim3(kBlock), 0, stream, p);
     else
       hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, false>), dim3(1024, slices), dim3(kBlock), 0, stream, p);
