@@ -39,6 +39,8 @@ def parse():
     p.add_argument("--op", choices=["gather", "scatter", "grad_apply"], default="gather",
                    help="side measurements; the contract metric is gather")
     p.add_argument("--optimizer", default="sgd")
+    p.add_argument("--dtype", choices=["f32", "f16", "bf16"], default="f32",
+                   help="table dtype (side measurements; the contract metric is f32)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-check", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -65,7 +67,7 @@ def fill_table(local, row_start):
     for s in range(0, rows, chunk):
         e = min(rows, s + chunk)
         r = torch.arange(row_start + s, row_start + e, device="cuda", dtype=torch.int64) & 0xFFFFFF
-        local[s:e] = r.to(torch.float32).unsqueeze(1).to(local.device)
+        local[s:e] = r.to(torch.float32).unsqueeze(1).to(local.dtype).to(local.device)
     torch.cuda.synchronize()
 
 
@@ -150,7 +152,9 @@ def main():
     rows_per_gpu = a.rows or (100_000_000 if world == 1 else 125_000_000)
     total_rows = rows_per_gpu * world
     mt = a.memory_type or ("chunked" if world == 1 else "distributed")
-    emb = wgth.create_embedding(comm, mt, a.location, torch.float32, [total_rows, a.dim])
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
+    es = 4 if a.dtype == "f32" else 2
+    emb = wgth.create_embedding(comm, mt, a.location, tdt, [total_rows, a.dim])
     local, start = emb.get_embedding_tensor().get_local_tensor(host_view=(a.location == "cpu"))
     fill_table(local, start)
     idx_np = make_indices(a.indices, total_rows, a.dist, 42 + rank)
@@ -164,7 +168,7 @@ def main():
 
     # the output buffer is allocated once, as in the reference bench (gather_scatter_bench.cu:322-343):
     # a fresh 5 GB hipMalloc inside the timed region would cost ~140 ms and is not part of the op
-    out = torch.empty((a.indices, a.dim), dtype=torch.float32, device="cuda")
+    out = torch.empty((a.indices, a.dim), dtype=tdt, device="cuda")
     opt = None
     if a.op == "grad_apply":
         opt = wgth.create_wholememory_optimizer(emb, a.optimizer, {})
@@ -180,7 +184,7 @@ def main():
             emb.need_apply = True
             emb.apply_gradients(0.01)
 
-    if a.op != "gather":
+    if a.op != "gather" or a.dtype != "f32":
         a.no_check = True
     for _ in range(max(a.warmup, 1)):
         step()
@@ -207,8 +211,8 @@ def main():
 
     if rank == 0:
         lookups = a.indices * world * a.steps / wall
-        out_bytes = a.dim * 4
-        algo_bytes = 8 + a.dim * 4 + a.dim * 4
+        out_bytes = a.dim * es
+        algo_bytes = 8 + a.dim * es + a.dim * es
         res = {
             "metric": "%s_GBps_out (%s row bytes/s, reference gather_scatter_bench convention)" % (
                 a.op, {"gather": "gathered output", "scatter": "scattered input", "grad_apply": "gradient"}[a.op]),
@@ -217,16 +221,17 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(wall / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": a.dtype, "data": "synthetic",
             "mlookups_per_s": round(lookups / 1e6, 1),
             "algorithmic_GBps": round(lookups * algo_bytes / 1e9, 2),
-            "config": {"workload": ("C2 chunked 1-GPU %dx%d fp32 table, %d %s int64 ids" if world == 1 else
-                                    "C3 distributed %dx%d fp32 table, %d %s int64 ids per rank, RCCL alltoallv")
-                                   % (total_rows, a.dim, a.indices, a.dist),
+            "config": {"workload": ("C2 chunked 1-GPU %dx%d %s table, %d %s int64 ids" if world == 1 else
+                                    "C3 distributed %dx%d %s table, %d %s int64 ids per rank, RCCL alltoallv")
+                                   % (total_rows, a.dim, {"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[a.dtype],
+                                      a.indices, a.dist),
                        "memory_type": mt, "rows_per_gpu": rows_per_gpu, "indices_per_rank": a.indices,
                        "index_distribution": a.dist},
         }
-        if world == 1 and a.op == "gather":
+        if world == 1 and a.op == "gather" and a.dtype == "f32":
             # dominant kernel = rows_copy_kernel<long,16,true>: the whole step at N=1
             achieved = a.indices * algo_bytes / (dev_ms * 1e-3) / 1e9
             traffic = None

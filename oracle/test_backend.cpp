@@ -197,13 +197,17 @@ int t_dedup(const void* ids, wholememory_dtype_t dt, int64_t n, int64_t, void* u
 
 int t_step(const wm_optimizer_args* a, const int64_t* n_unique_dev, void*)
 {
+  if (a->value_dtype != WHOLEMEMORY_DT_FLOAT && a->value_dtype != WHOLEMEMORY_DT_UNKNOWN) return -1;  // fp32 only here
   const int64_t count = n_unique_dev ? *n_unique_dev : a->count;
+  const float* grads      = static_cast<const float*>(a->grads);
+  const float* self_grads = static_cast<const float*>(a->self_grads);
+  float* local_table      = static_cast<float*>(a->local_table);
   std::vector<float> g(a->dim);
   for (int64_t u = 0; u < count; u++) {
     for (int64_t d = 0; d < a->dim; d++) {
       auto row = [&](int32_t o) {  // wm_optimizer_args::self_grads: negative entries address the caller's own rows
-        return o >= 0 ? a->grads + static_cast<int64_t>(o) * a->grad_stride
-                      : a->self_grads + (-(static_cast<int64_t>(o) + 1)) * a->self_grad_stride;
+        return o >= 0 ? grads + static_cast<int64_t>(o) * a->grad_stride
+                      : self_grads + (-(static_cast<int64_t>(o) + 1)) * a->self_grad_stride;
       };
       float acc = row(a->order[a->run_starts[u]])[d];
       for (int32_t j = a->run_starts[u] + 1; j < a->run_starts[u + 1]; j++) acc += row(a->order[j])[d];
@@ -214,23 +218,23 @@ int t_step(const wm_optimizer_args* a, const int64_t* n_unique_dev, void*)
     const int idx_dt = WHOLEMEMORY_DT_INT64;
     switch (a->type) {
       case WHOLEMEMORY_OPT_SGD:
-        wmo_sgd_step(idp, idx_dt, 1, g.data(), a->dim, a->local_table, a->table_stride, a->local_entry_offset, a->dim,
+        wmo_sgd_step(idp, idx_dt, 1, g.data(), a->dim, local_table, a->table_stride, a->local_entry_offset, a->dim,
                      a->weight_decay, a->lr);
         break;
       case WHOLEMEMORY_OPT_LAZY_ADAM:
         if (a->per_element_stride != 2 * a->table_stride) return -1;
-        wmo_lazy_adam_step(idp, idx_dt, 1, g.data(), a->dim, a->local_table, a->per_element_state, a->per_row_state,
+        wmo_lazy_adam_step(idp, idx_dt, 1, g.data(), a->dim, local_table, a->per_element_state, a->per_row_state,
                            a->table_stride, a->local_entry_offset, a->dim, a->weight_decay, a->epsilon, a->beta1,
                            a->beta2, a->adam_w, a->lr);
         break;
       case WHOLEMEMORY_OPT_ADAGRAD:
         if (a->per_element_stride != a->table_stride) return -1;
-        wmo_adagrad_step(idp, idx_dt, 1, g.data(), a->dim, a->local_table, a->per_element_state, a->table_stride,
+        wmo_adagrad_step(idp, idx_dt, 1, g.data(), a->dim, local_table, a->per_element_state, a->table_stride,
                          a->local_entry_offset, a->dim, a->weight_decay, a->epsilon, a->lr);
         break;
       case WHOLEMEMORY_OPT_RMSPROP:
         if (a->per_element_stride != a->table_stride) return -1;
-        wmo_rmsprop_step(idp, idx_dt, 1, g.data(), a->dim, a->local_table, a->per_element_state, a->table_stride,
+        wmo_rmsprop_step(idp, idx_dt, 1, g.data(), a->dim, local_table, a->per_element_state, a->table_stride,
                          a->local_entry_offset, a->dim, a->weight_decay, a->epsilon, a->alpha, a->lr);
         break;
       default: return -1;

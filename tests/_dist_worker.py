@@ -163,6 +163,48 @@ def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries):
     wgth.destroy_embedding(emb)
 
 
+def scenario_sgd16(comm, rank, world, tdt, dim, lr, wd):
+    """HALF / BF16 table trained with SGD over several ranks (HIP mode): gradient rows travel in the table dtype, the
+    owner sums duplicates in fp32 in rank-major receive order and rounds once. Oracle = the fp32 multi-rank oracle
+    wrapped in exact widenings and that one rounding."""
+    n_rows, steps = 1501, 2
+    emb = wgth.create_embedding(comm, "distributed", "cuda", tdt, [n_rows, dim])
+    stride = emb.get_embedding_tensor().stride()[0]
+    init16 = torch.from_numpy(np.random.default_rng(8).standard_normal((n_rows, dim)).astype(np.float32)).to(tdt)
+    padded = np.zeros((n_rows, stride), dtype=np.float32)
+    padded[:, :dim] = init16.float().numpy()
+    tab = oracle.ShardedTable.from_full(padded, world, None)
+    tab.dim = dim
+    local, start = emb.get_embedding_tensor().get_local_tensor()
+    cnt = int(tab.entry_offsets[rank + 1] - tab.entry_offsets[rank])
+    local.copy_(dev(init16[start:start + cnt]))
+    opt = wgth.create_wholememory_optimizer(emb, "sgd", {"weight_decay": wd})
+    ref_opts = [oracle.Optimizer("sgd", int(tab.entry_offsets[r + 1] - tab.entry_offsets[r]), stride, weight_decay=wd)
+                for r in range(world)]
+    for step in range(steps):
+        rank_idx, rank_g16 = [], []
+        for r in range(world):
+            g = np.random.default_rng(500 * step + r)
+            ix = g.integers(0, n_rows, 6000 + 13 * r).astype(np.int64)
+            ix[::2] = ix[0]  # ~3000 duplicates per rank of one id: a long run at its owner
+            rank_idx.append(ix)
+            rank_g16.append(torch.from_numpy(g.standard_normal((len(ix), dim)).astype(np.float32)).to(tdt))
+        emb.add_gradients(dev(torch.from_numpy(rank_idx[rank])), dev(rank_g16[rank]))
+        emb.need_apply = True
+        opt.step(lr)
+        oracle.gradient_apply(tab, ref_opts, rank_idx, [g.float().numpy() for g in rank_g16], lr)
+        for r in range(world):
+            sh = tab.shards[r]
+            sh[:, :dim] = torch.from_numpy(sh[:, :dim].copy()).to(tdt).float().numpy()   # the one rounding
+        torch.cuda.synchronize()
+        want = torch.from_numpy(tab.shards[rank][:cnt, :dim].copy()).to(tdt)
+        assert torch.equal(host(local).view(torch.int16), want.view(torch.int16)), \
+            "16-bit SGD mismatch on rank %d step %d" % (rank, step)
+    comm.barrier()
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)
+
+
 def scenario_file_io(comm, rank, world, tmpdir):
     """wholememory_load_from_file / store_to_file through the Python surface: files re-sharded over ranks (3 files of
     uneven size -> W shards), padded rows (file rows are dim wide, memory rows stride wide), round-robin placement,
@@ -297,6 +339,10 @@ def main():
     for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}),
                          ("adam", {"adam_w": 1.0, "weight_decay": 0.02}), ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]:
         scenario_gradient_apply(comm, rank, world, kind, params, np.int64 if kind != "adagrad" else np.int32, None)
+    if HIP_MODE:
+        # (6) extension: SGD on 16-bit tables (fp16 scatter-add = lr -1, wd 0)
+        scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0)
+        scenario_sgd16(comm, rank, world, torch.bfloat16, 40, 0.05, 0.01)
     comm.barrier()
     dist.barrier()
     print("RANK %d OK" % rank)

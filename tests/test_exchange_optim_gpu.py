@@ -183,6 +183,53 @@ def test_embedding_training_flow(gpu_env, mt, kind, params):
     wgth.destroy_embedding(emb)
 
 
+@pytest.mark.parametrize("mt", ["chunked", "distributed"])
+@pytest.mark.parametrize("tdt_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("dim,lr,wd", [(256, -1.0, 0.0), (256, 0.05, 0.01), (100, -1.0, 0.0), (33, -1.0, 0.0), (64, 0.1, 0.0)])
+def test_sgd_on_16bit_tables(gpu_env, mt, tdt_name, dim, lr, wd):
+    """Extension (BASELINE config 4, "fp16 scatter-add"): HALF / BF16 embeddings trained with SGD; lr = -1, wd = 0 is
+    scatter-add. The reference trains fp32 tables only (embedding.cpp:61-63), so the semantics are this repo's:
+    duplicates summed in fp32 in receive order, e' = e - lr (g + wd e) in fp32 from fp32(e), ONE rounding to the table
+    dtype. The oracle is the fp32 oracle wrapped in exact widenings and that one rounding. dim 256 = 512 B rows (C4
+    shape), a hot id with ~17 k duplicates exercises the LDS-DMA long-run kernel, dim 100 / 33 the shapes without it."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    tdt = getattr(torch, tdt_name)
+    n_rows, n_idx = 20011, 50001
+    emb = wgth.create_embedding(gpu_env, mt, "cuda", tdt, [n_rows, dim])
+    stride = emb.get_embedding_tensor().stride()[0]
+    rng = np.random.default_rng(1000 + dim + int(lr * 100))
+    init16 = torch.from_numpy(rng.standard_normal((n_rows, dim)).astype(np.float32)).to(tdt)
+    local, _ = emb.get_embedding_tensor().get_local_tensor()
+    local.copy_(init16.cuda())
+    opt = wgth.create_wholememory_optimizer(emb, "sgd", {"weight_decay": wd})
+    padded = np.zeros((n_rows, stride), np.float32)
+    padded[:, :dim] = init16.float().numpy()
+    tab = oracle.ShardedTable.from_full(padded, 1)
+    tab.dim = dim
+    ref_opt = oracle.Optimizer("sgd", n_rows, stride, weight_decay=wd)
+    for step in range(2):
+        idx = rng.integers(0, n_rows, n_idx).astype(np.int64)
+        idx[::3] = idx[1]                       # one id with ~17 k duplicates
+        g16 = torch.from_numpy(rng.standard_normal((n_idx, dim)).astype(np.float32)).to(tdt)
+        emb.add_gradients(torch.from_numpy(idx).cuda(), g16.cuda())
+        emb.need_apply = True
+        opt.step(lr)
+        oracle.gradient_apply(tab, [ref_opt], [idx], [g16.float().numpy()], lr)
+        rounded = torch.from_numpy(tab.shards[0][:, :dim].copy()).to(tdt)     # the one rounding
+        tab.shards[0][:, :dim] = rounded.float().numpy()
+        torch.cuda.synchronize()
+        assert torch.equal(local.cpu().view(torch.int16), rounded.view(torch.int16)), "step %d" % step
+    # every other optimizer is refused on 16-bit tables
+    emb2 = wgth.create_embedding(gpu_env, mt, "cuda", tdt, [128, 8])
+    from wholegraph_amd import binding as wmb
+    with pytest.raises(wmb.WholeMemoryError):
+        wgth.create_wholememory_optimizer(emb2, "adam", {})
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)
+    wgth.destroy_embedding(emb2)
+
+
 def test_round_robin_embedding_gather(gpu_env):
     """round_robin_size != 0: padded row count (embedding.cpp:467-484) and index remap
     (map_indices_func.cu:26-45) — at world_size 1 the remap is the identity on [0, N)."""

@@ -56,14 +56,18 @@ struct wm_optimizer_args {
   wholememory_dtype_t index_dtype;
   const int32_t* run_starts;   // [count+1] device: segment starts into order[]
   const int32_t* order;        // [n_recv] device: receive-buffer positions sorted by (id, position)
-  const float* grads;          // [n_recv, grad_stride] device: received gradient rows
+  // dtype of the table AND of the gradient rows: FLOAT (every optimizer; 0 / UNKNOWN is read as FLOAT) or HALF / BF16
+  // (SGD only — an extension, the reference trains fp32 tables only: duplicates are summed in fp32 in receive order,
+  // the update is computed in fp32 from fp32(e) and rounded once to the table dtype)
+  wholememory_dtype_t value_dtype;
+  const void* grads;           // [n_recv, grad_stride] device: received gradient rows
   int64_t grad_stride;
   // order[] entries >= 0 address rows of `grads`; an entry < 0 addresses row -(entry + 1) of `self_grads` — gradient rows
   // of ids this rank owns itself, read where the caller left them instead of being copied into the receive buffer
-  const float* self_grads;
+  const void* self_grads;
   int64_t self_grad_stride;
   int64_t count;               // number of unique ids (= grid size)
-  float* local_table;          // this rank's first row
+  void* local_table;           // this rank's first row
   int64_t table_stride;        // elements
   int64_t local_entry_offset;  // global id of local row 0
   int64_t dim;

@@ -185,11 +185,11 @@ void fill_optimizer_args(wm_optimizer_args* a, const wholememory_embedding_optim
 struct self_rows_ref {
   int64_t begin = 0, count = 0;
   const int64_t* rows = nullptr;
-  const float* grads  = nullptr;
+  const void* grads   = nullptr;
   int64_t stride      = 0;
 };
 
-void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64_t n_recv, const float* recv_grads,
+void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64_t n_recv, const void* recv_grads,
                     int64_t grad_stride, wm_optimizer_args* oa, int64_t key_upper_bound, wholememory_env_func_t* env,
                     void* stream, int64_t* n_unique_host, void* rows_ready = nullptr, const self_rows_ref* self = nullptr)
 {
@@ -250,10 +250,14 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   wholememory_matrix_description_t gmat;
   if (!wholememory_convert_tensor_desc_to_array(&iarr, idesc) || !wholememory_convert_tensor_desc_to_matrix(&gmat, gdesc))
     return WHOLEMEMORY_INVALID_INPUT;
-  if (gmat.dtype != WHOLEMEMORY_DT_FLOAT) {
-    WM_ERROR("gradients must be float32 (reference exchange_embeddings_nccl_func.cu:192)");
+  // reference: float32 tables and gradients only (exchange_embeddings_nccl_func.cu:192, embedding.cpp:61-63).
+  // Extension: HALF / BF16 tables trained with SGD take gradients of the table's own dtype.
+  const wholememory_dtype_t vdt = e->dtype;
+  if (gmat.dtype != vdt) {
+    WM_ERROR("gradients must have the embedding's dtype (float32; float16 / bfloat16 for SGD on 16-bit tables)");
     return WHOLEMEMORY_INVALID_INPUT;
   }
+  const size_t ves = wholememory_dtype_get_element_size(vdt);
   if (gmat.sizes[0] != iarr.size) return WHOLEMEMORY_INVALID_INPUT;
   auto* udesc       = wholememory_tensor_get_tensor_description(e->user);
   const int64_t dim = gmat.sizes[1];
@@ -278,8 +282,9 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   const int64_t n_recv = full_recv_offsets[e->comm->world_size];
 
   temp_mem send_rows(env), recv_rows(env), recv_ids_mem(env);
-  auto* send_buf = static_cast<float*>(send_rows.device(dim * x.total_valid, WHOLEMEMORY_DT_FLOAT));
-  auto* recv_buf = static_cast<float*>(recv_rows.device(dim * n_recv, WHOLEMEMORY_DT_FLOAT));
+  auto* send_buf = static_cast<char*>(send_rows.device(dim * x.total_valid, vdt));
+  auto* recv_buf = static_cast<char*>(recv_rows.device(dim * n_recv, vdt));
+  const size_t row_bytes = static_cast<size_t>(dim) * ves;
   char* recv_ids = static_cast<char*>(recv_ids_mem.device(n_recv, iarr.dtype));
   // ids: peers' segments were received compactly (self cut out) — place them around the self slot
   for (int r = 0; r < e->comm->world_size; r++) {
@@ -290,18 +295,18 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   }
   // gradient rows in bucketed order: remote segments into the send buffer, the self segment into recv_buf
   const auto grads_gref = wholememory_create_continuous_global_reference(wholememory_tensor_get_data_pointer(grads));
-  auto launch_rows = [&](int64_t s0, int64_t s1, float* dst) {
+  auto launch_rows = [&](int64_t s0, int64_t s1, char* dst) {
     if (s1 <= s0) return;
     wm_rows_args ga{};
     ga.gref         = grads_gref;
-    ga.table_dtype  = WHOLEMEMORY_DT_FLOAT;
+    ga.table_dtype  = vdt;
     ga.dim          = dim;
     ga.table_stride = gmat.stride;
     ga.indices      = x.raw_indices + s0;
     ga.index_dtype  = WHOLEMEMORY_DT_INT64;
     ga.n            = s1 - s0;
     ga.plain        = dst;
-    ga.plain_dtype  = WHOLEMEMORY_DT_FLOAT;
+    ga.plain_dtype  = vdt;
     ga.plain_stride = dim;
     ga.max_blocks   = -1;
     WM_BK(bk->gather_rows(&ga, stream));
@@ -316,10 +321,10 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     self_ref.begin  = full_recv_offsets[rank];
     self_ref.count  = x.self_count;
     self_ref.rows   = x.raw_indices + x.self_offset;
-    self_ref.grads  = static_cast<const float*>(wholememory_tensor_get_data_pointer(grads));
+    self_ref.grads  = wholememory_tensor_get_data_pointer(grads);
     self_ref.stride = gmat.stride;
   } else {
-    launch_rows(x.self_offset, x.self_offset + x.self_count, recv_buf + full_recv_offsets[rank] * dim);
+    launch_rows(x.self_offset, x.self_offset + x.self_count, recv_buf + full_recv_offsets[rank] * row_bytes);
   }
   // peers' rows: line-up (HBM) and all-to-all-v (xGMI, side stream) pipelined in C row-chunks; the id sort that
   // follows on the caller's stream overlaps with the tail of the exchange
@@ -337,7 +342,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
       int64_t a, b;
       chunk_of(x.send_counts[p], c, &a, &b);
       sc[p] = b - a, so[p] = x.bucket_offsets[p] + a;
-      if (p != rank) launch_rows(so[p], so[p] + sc[p], send_buf + so[p] * dim);
+      if (p != rank) launch_rows(so[p], so[p] + sc[p], send_buf + so[p] * row_bytes);
       chunk_of(x.recv_counts[p], c, &a, &b);
       rc[p] = b - a, ro[p] = full_recv_offsets[p] + a;
     }
@@ -345,7 +350,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
       WM_BK(bk->event_record(lined_up[c], stream));
       WM_BK(bk->stream_wait_event(side, lined_up[c]));
     }
-    exchange_segments(e->comm, send_buf, sc, so, recv_buf, rc, ro, static_cast<size_t>(dim) * sizeof(float), side);
+    exchange_segments(e->comm, send_buf, sc, so, recv_buf, rc, ro, row_bytes, side);
   }
   if (C > 1) WM_BK(bk->event_record(arrived[0], side));
   void* rows_arrived = C > 1 ? arrived[0] : nullptr;
@@ -355,7 +360,8 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_map_local_tensor(e->user, &local_table));
   wm_optimizer_args oa{};
   fill_optimizer_args(&oa, e->optimizer, lr);
-  oa.local_table        = static_cast<float*>(wholememory_tensor_get_data_pointer(local_table));
+  oa.local_table        = wholememory_tensor_get_data_pointer(local_table);
+  oa.value_dtype        = vdt;
   oa.table_stride       = adesc->strides[0];
   oa.local_entry_offset = static_cast<int64_t>(entry_offsets[e->comm->world_rank]);
   oa.dim                = dim;
@@ -568,8 +574,12 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
     return WHOLEMEMORY_NOT_SUPPORTED;
   }
   if (optimizer == nullptr) return WHOLEMEMORY_SUCCESS;
-  if (e->dtype != WHOLEMEMORY_DT_FLOAT) {
-    WM_ERROR("Only float embedding supports training.");
+  // reference embedding.cpp:61-63: "Only float embedding supports training." Extension (BASELINE config 4, fp16
+  // scatter-add): HALF / BF16 embeddings accept the stateless optimizer, SGD (see backend.hpp value_dtype).
+  const bool sgd16 = (e->dtype == WHOLEMEMORY_DT_HALF || e->dtype == WHOLEMEMORY_DT_BF16) &&
+                     optimizer->type == WHOLEMEMORY_OPT_SGD;
+  if (e->dtype != WHOLEMEMORY_DT_FLOAT && !sgd16) {
+    WM_ERROR("Only float embedding supports training (float16 / bfloat16: SGD only).");
     return WHOLEMEMORY_NOT_IMPLEMENTED;
   }
   e->optimizer = optimizer;

@@ -29,6 +29,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "../backend.hpp"
+#include "device_common.cuh"
 #include <wholememory/embedding.h>
 
 namespace wm {
@@ -170,17 +171,43 @@ struct opt_elem {
 };
 
 // gradient row addressed by an order[] entry (wm_optimizer_args::self_grads)
-__device__ __forceinline__ const float* grad_row(const wm_optimizer_args& a, int32_t o)
+template <typename T = float>
+__device__ __forceinline__ const T* grad_row(const wm_optimizer_args& a, int32_t o)
 {
-  return o >= 0 ? a.grads + static_cast<int64_t>(o) * a.grad_stride
-                : a.self_grads + (-(static_cast<int64_t>(o) + 1)) * a.self_grad_stride;
+  return o >= 0 ? static_cast<const T*>(a.grads) + static_cast<int64_t>(o) * a.grad_stride
+                : static_cast<const T*>(a.self_grads) + (-(static_cast<int64_t>(o) + 1)) * a.self_grad_stride;
 }
 
-template <int OPT>
+// V consecutive elements of a gradient row as fp32 (16-bit types are widened exactly)
+template <typename T, int V>
+__device__ __forceinline__ auto load_vec(const T* p)
+{
+  typedef float fvec __attribute__((ext_vector_type(V)));
+  if constexpr (std::is_same<T, float>::value) {
+    return *reinterpret_cast<const fvec*>(p);
+  } else {
+    typedef uint16_t rvec __attribute__((ext_vector_type(V)));
+    const rvec raw = *reinterpret_cast<const rvec*>(p);
+    fvec out;
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+      const uint16_t bits = raw[i];
+      out[i]              = load_wide<T>(__builtin_bit_cast(T, bits));
+    }
+    return out;
+  }
+}
+template <typename T>
+__device__ __forceinline__ float load_vec1(const T* p)
+{
+  return load_wide<T>(*p);
+}
+
+template <int OPT, typename T = float>
 __device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, int64_t local, int64_t d)
 {
   opt_elem x;
-  x.e  = a.local_table[local * a.table_stride + d];
+  x.e  = load_wide<T>(static_cast<const T*>(a.local_table)[local * a.table_stride + d]);
   x.s0 = 0.f;
   x.s1 = 0.f;
   if (OPT != WHOLEMEMORY_OPT_SGD) {
@@ -191,7 +218,7 @@ __device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, int64_
   return x;
 }
 
-template <int OPT>
+template <int OPT, typename T = float>
 __device__ __forceinline__ void update_elem(const wm_optimizer_args& a, int64_t local, int64_t d, opt_elem x,
                                             float grad_value, float beta1t, float beta2t)
 {
@@ -229,14 +256,17 @@ __device__ __forceinline__ void update_elem(const wm_optimizer_args& a, int64_t 
     st[d]           = v;
   }
   // the updated row is not read again in this pass: non-temporal store (merged into one wide store per lane)
-  __builtin_nontemporal_store(embedding_value, &a.local_table[local * a.table_stride + d]);
+  if constexpr (std::is_same<T, float>::value)
+    __builtin_nontemporal_store(embedding_value, &static_cast<float*>(a.local_table)[local * a.table_stride + d]);
+  else  // 16-bit tables (SGD extension): one rounding from the fp32 result
+    static_cast<T*>(a.local_table)[local * a.table_stride + d] = store_narrow<T>(embedding_value);
 }
 
-template <int OPT>
+template <int OPT, typename T = float>
 __device__ __forceinline__ void apply_optimizer(const wm_optimizer_args& a, int64_t local, int64_t d, float grad_value,
                                                 float beta1t, float beta2t)
 {
-  update_elem<OPT>(a, local, d, load_elem<OPT>(a, local, d), grad_value, beta1t, beta2t);
+  update_elem<OPT, T>(a, local, d, load_elem<OPT, T>(a, local, d), grad_value, beta1t, beta2t);
 }
 
 // The work per run is a chain of dependent loads (ids / run_starts -> order -> gradient row; ids -> table row), and the
@@ -254,7 +284,7 @@ __device__ __forceinline__ void apply_optimizer(const wm_optimizer_args& a, int6
 #ifndef WM_STEP_K
 #define WM_STEP_K 4
 #endif
-template <typename IdxT, int OPT, int V>
+template <typename IdxT, int OPT, int V, typename T = float>
 __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
 {
   typedef float vec_t __attribute__((ext_vector_type(V)));
@@ -332,9 +362,9 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
 #pragma unroll
       for (int k = 0; k < K; k++) {
         // first occurrence copied (DedupIndiceAndGradientsKernel); table / state values loaded alongside
-        acc[k] = *reinterpret_cast<const vec_t*>(grad_row(a, r_cur.o0[k]) + d);
+        acc[k] = load_vec<T, V>(grad_row<T>(a, r_cur.o0[k]) + d);
 #pragma unroll
-        for (int v = 0; v < V; v++) x[k][v] = load_elem<OPT>(a, m_cur.local[k], d + v);
+        for (int v = 0; v < V; v++) x[k][v] = load_elem<OPT, T>(a, m_cur.local[k], d + v);
       }
 #pragma unroll
       for (int k = 0; k < K; k++) {
@@ -347,14 +377,14 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
           for (int q = 0; q < 4; q++) o[q] = a.order[min(j + q, m_cur.s1[k] - 1)];
 #pragma unroll
           for (int q = 0; q < 4; q++)
-            g[q] = *reinterpret_cast<const vec_t*>(grad_row(a, o[q]) + d);
+            g[q] = load_vec<T, V>(grad_row<T>(a, o[q]) + d);
 #pragma unroll
           for (int q = 0; q < 4; q++)
             if (j + q < m_cur.s1[k]) acc[k] += g[q];
         }
 #pragma unroll
         for (int v = 0; v < V; v++)
-          update_elem<OPT>(a, m_cur.local[k], d + v, x[k][v], acc[k][v], r_cur.beta1t[k], r_cur.beta2t[k]);
+          update_elem<OPT, T>(a, m_cur.local[k], d + v, x[k][v], acc[k][v], r_cur.beta1t[k], r_cur.beta2t[k]);
       }
     }
     m_cur = m_nxt;
@@ -469,17 +499,19 @@ constexpr size_t kLong4LdsBytes = static_cast<size_t>(kRing) * kTile4Rows * kSli
 constexpr int kLongProducers = 4;                          // waves that only fetch
 constexpr int kLongBlock     = 64 * (kLongProducers + 1);  // + wave 0, which only folds
 
-template <typename IdxT, int OPT>
+template <typename IdxT, int OPT, typename T = float>
 __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
 {
   extern __shared__ __attribute__((aligned(16))) float lds4[];
-  float* const tiles   = lds4;                                                           // [kRing][kTile4Rows][kSlice4]
+  constexpr int S      = kSlice4 * 4 / static_cast<int>(sizeof(T));  // columns per slice: 128 B of every row
+  constexpr int kE16   = 16 / static_cast<int>(sizeof(T));           // elements per 16-byte piece
+  T* const tiles       = reinterpret_cast<T*>(lds4);                                     // [kRing][kTile4Rows][S]
   int32_t* const ord_s = reinterpret_cast<int32_t*>(lds4 + kRing * kTile4Rows * kSlice4);  // [kOrdChunk]
   const wm_optimizer_args& a = p.a;
   const int n_long           = *p.long_count;
   const IdxT* ids            = static_cast<const IdxT*>(a.ids);
-  const int col0             = blockIdx.y * kSlice4;
-  const int cols             = min(kSlice4, static_cast<int>(a.dim) - col0);  // multiple of 4
+  const int col0             = blockIdx.y * S;
+  const int cols             = min(S, static_cast<int>(a.dim) - col0);  // a whole number of 16-byte pieces
   constexpr int kLpr         = kSlice4 / 4;                                   // lanes per row (16-byte pieces)
   constexpr int kRpp         = 64 / kLpr;                                     // rows per wave instruction
   constexpr int kLoads       = kTile4Rows / (kRpp * kLongProducers);          // pieces per producer lane per tile (8)
@@ -490,7 +522,7 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
   const int wave_id   = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const bool producer = wave_id > 0;
   const int wv        = wave_id - 1;
-  const int c_safe    = min((lane % kLpr) * 4, cols - 4);  // lanes past a narrow slice re-read its last float4
+  const int c_safe    = min((lane % kLpr) * kE16, cols - kE16);  // lanes past a narrow slice re-read its last piece
   const int r_lane    = lane / kLpr;
   const bool folder   = threadIdx.x < cols;  // one column per lane of wave 0
 
@@ -512,17 +544,17 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
       // clamped into the chunk: tiles past its end re-read the last row, harmlessly — so every producer always has
       // the same number of pieces in flight.
       auto issue = [&](int t) {
-        float* slot = tiles + (t % kRing) * (kTile4Rows * kSlice4);
+        T* slot = tiles + (t % kRing) * (kTile4Rows * S);
         int32_t o[kLoads];
 #pragma unroll
         for (int i = 0; i < kLoads; i++)
           o[i] = ord_s[min(t * kTile4Rows + kRpp * (wv + kLongProducers * i) + r_lane, chunk_rows - 1)];
 #pragma unroll
         for (int i = 0; i < kLoads; i++) {
-          const float* src = grad_row(a, o[i]) + col0 + c_safe;
+          const T* src = grad_row<T>(a, o[i]) + col0 + c_safe;
           typedef __attribute__((address_space(1))) void gvoid;
           typedef __attribute__((address_space(3))) void lvoid;
-          __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(slot + kRpp * (wv + kLongProducers * i) * kSlice4), 16, 0,
+          __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(slot + kRpp * (wv + kLongProducers * i) * S), 16, 0,
                                            0);
         }
       };
@@ -541,7 +573,7 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
           issue(tt + kRing - 1);
         } else if (folder) {
           const int32_t rows = min(kTile4Rows, chunk_rows - tt * kTile4Rows);
-          const float* src   = tiles + (tt % kRing) * (kTile4Rows * kSlice4) + threadIdx.x;
+          const T* src       = tiles + (tt % kRing) * (kTile4Rows * S) + threadIdx.x;
           if (rows == kTile4Rows && !(chunk == s0 && tt == 0)) {
             // the hot loop, no predicates. A lone wave sees ~200 cycles from an LDS read to its use: 64 rows are read
             // back to back (hipcc waits for all of them — its lgkmcnt placement does not keep a second batch in
@@ -550,23 +582,23 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
             for (int32_t r = 0; r < kTile4Rows; r += 64) {
               float v[64];
 #pragma unroll
-              for (int k = 0; k < 64; k++) v[k] = src[(r + k) * kSlice4];
+              for (int k = 0; k < 64; k++) v[k] = load_wide<T>(src[(r + k) * S]);
 #pragma unroll
               for (int k = 0; k < 64; k++) acc += v[k];
             }
           } else {
             int32_t r = 0;
             if (chunk == s0 && tt == 0) {
-              acc = src[0];  // first occurrence is copied, not added to 0
+              acc = load_wide<T>(src[0]);  // first occurrence is copied, not added to 0
               r   = 1;
             }
-            for (; r < rows; r++) acc += src[r * kSlice4];
+            for (; r < rows; r++) acc += load_wide<T>(src[r * S]);
           }
         }
       }
       if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // clamped tail tiles must not land in the next chunk
     }
-    if (!producer && folder) apply_optimizer<OPT>(a, local, col0 + threadIdx.x, acc, ent.beta1t, ent.beta2t);
+    if (!producer && folder) apply_optimizer<OPT, T>(a, local, col0 + threadIdx.x, acc, ent.beta1t, ent.beta2t);
     __syncthreads();
   }
 }
@@ -610,9 +642,44 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// HALF / BF16 tables with gradients of the same dtype: SGD only (see wm_optimizer_args::value_dtype)
+template <typename IdxT, typename T>
+int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream)
+{
+  constexpr int kOpt   = WHOLEMEMORY_OPT_SGD;
+  constexpr int kS     = kSlice4 * 4 / static_cast<int>(sizeof(T));  // columns per long-run slice
+  const uint64_t gaddr = reinterpret_cast<uint64_t>(p.a.grads) | reinterpret_cast<uint64_t>(p.a.self_grads);
+  const int64_t sstr   = p.a.self_grads == nullptr ? 0 : p.a.self_grad_stride;
+  const bool vec4      = p.a.dim % 4 == 0 && p.a.grad_stride % 4 == 0 && sstr % 4 == 0 && p.a.table_stride % 4 == 0 &&
+                    gaddr % 8 == 0 && reinterpret_cast<uint64_t>(p.a.local_table) % 8 == 0;
+  const bool rows16    = p.a.dim % 8 == 0 && p.a.grad_stride % 8 == 0 && sstr % 8 == 0 && gaddr % 16 == 0 &&
+                      p.a.dim <= 65535 * kS;
+  if (!rows16) p.long_list = nullptr;  // no LDS-DMA path for this shape: the wave-per-run kernel folds every run itself
+  if (vec4)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 4, T>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  else
+    hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 1, T>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  if (p.long_list != nullptr) {
+    static const bool lds_ok =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, kOpt, T>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLong4LdsBytes)) == hipSuccess;
+    if (!lds_ok) return -2;
+    const int slices = static_cast<int>((p.a.dim + kS - 1) / kS);
+    const int gx     = std::max(1, 256 / slices);
+    hipLaunchKernelGGL((step_long4_kernel<IdxT, kOpt, T>), dim3(gx, slices), dim3(kLongBlock), kLong4LdsBytes, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <typename IdxT>
 int launch_step(const opt_params& p, int blocks, hipStream_t stream)
 {
+  if (p.a.value_dtype == WHOLEMEMORY_DT_HALF || p.a.value_dtype == WHOLEMEMORY_DT_BF16) {
+    if (p.a.type != WHOLEMEMORY_OPT_SGD) return -1;
+    return p.a.value_dtype == WHOLEMEMORY_DT_HALF ? launch_step_sgd16<IdxT, half_t>(p, blocks, stream)
+                                                  : launch_step_sgd16<IdxT, bf16_t>(p, blocks, stream);
+  }
+  if (p.a.value_dtype != WHOLEMEMORY_DT_FLOAT && p.a.value_dtype != WHOLEMEMORY_DT_UNKNOWN) return -1;
   switch (p.a.type) {
     case WHOLEMEMORY_OPT_SGD: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_SGD>(p, blocks, stream);
     case WHOLEMEMORY_OPT_LAZY_ADAM: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_LAZY_ADAM>(p, blocks, stream);
