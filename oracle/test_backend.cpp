@@ -244,6 +244,14 @@ int t_step(const wm_optimizer_args* a, const int64_t* n_unique_dev, void*)
 }
 
 size_t t_long_ws(int64_t) { return 64; }
+int t_run_inverse(const int32_t* run_starts, const int32_t* order, const void* unique_ids, wholememory_dtype_t dt,
+                  const int64_t* n_unique, int64_t n, int64_t* inverse, void*)
+{
+  for (int64_t u = 0; u < *n_unique; u++)
+    for (int32_t j = run_starts[u]; j < run_starts[u + 1]; j++) inverse[order[j]] = idx_at(unique_ids, dt, u) < 0 ? -1 : u;
+  (void)n;
+  return 0;
+}
 int t_remap_self(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count, const int64_t* self_rows, void*)
 {
   for (int64_t i = 0; i < n; i++) {
@@ -268,7 +276,7 @@ const wm_device_backend kTestBackend = {
   t_device_count, t_malloc, t_free, t_malloc, t_free, t_memcpy, t_memset, t_sync,
   t_stream_create, t_noop1, t_event_create, t_noop1, t_noop2, t_noop2,
   t_ipc_get, t_ipc_open, t_ipc_close, t_host_register, t_host_unregister,
-  t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_long_ws, t_remap_self, t_rr, t_fill,
+  t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_long_ws, t_run_inverse, t_remap_self, t_rr, t_fill,
 };
 
 }  // namespace

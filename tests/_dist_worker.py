@@ -311,6 +311,12 @@ def main():
     # (4) trailing ranks empty under the equal plan: N < W * ceil(N / W) only when W > N … use tiny N
     if world >= 3:
         scenario_gather_scatter(comm, rank, world, "distributed", 4, 4, np.float32, np.float32, np.int64, None)
+    # (4a) the same gathers with request de-duplication before the exchange (WM_GATHER_DEDUP=1)
+    os.environ["WM_GATHER_DEDUP"] = "1"
+    scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)
+    scenario_gather_scatter(comm, rank, world, "distributed", 2000, 32, np.float16, np.float32, np.int32, None)
+    scenario_gather_scatter(comm, rank, world, "distributed", 997, 8, np.int64, np.int32, np.int64, ent)
+    del os.environ["WM_GATHER_DEDUP"]
     if HIP_MODE:
         # (4b) CHUNKED over two processes: peers' shards mapped with hipIpc, kernels read them directly;
         #      host-located tables: one POSIX shm segment registered with HIP on every rank

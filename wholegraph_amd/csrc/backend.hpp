@@ -142,6 +142,10 @@ struct wm_device_backend {
   // number of unique ids is read from that device scalar (no host sync to learn it).
   int (*optimizer_step)(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);
   size_t (*long_run_workspace_bytes)(int64_t n_recv);
+  // inverse of a dedup: inverse[order[j]] = index of the run that sorted position j belongs to, or -1 when that run's
+  // id is negative (n_unique_dev: device scalar written by dedup_ids)
+  int (*run_inverse)(const int32_t* run_starts, const int32_t* order, const void* unique_ids, wholememory_dtype_t index_dtype,
+                     const int64_t* n_unique_dev, int64_t n, int64_t* inverse, void* stream);
   // order[i] in [self_begin, self_begin + self_count)  ->  -(self_rows[order[i] - self_begin] + 1)   (see self_grads)
   int (*remap_self_order)(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count, const int64_t* self_rows,
                           void* stream);

@@ -757,6 +757,40 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   return -1;
 }
 
+template <typename IdxT>
+__global__ void run_inverse_kernel(const int32_t* run_starts, const int32_t* order, const IdxT* unique_ids,
+                                   const int64_t* n_unique, int64_t n, int64_t* inverse)
+{
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  // the run of sorted position j: last u with run_starts[u] <= j
+  int64_t lo = 0, hi = *n_unique - 1;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (run_starts[mid] <= j)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  inverse[order[j]] = unique_ids[lo] < 0 ? -1 : lo;
+}
+
+int hip_run_inverse(const int32_t* run_starts, const int32_t* order, const void* unique_ids, wholememory_dtype_t index_dtype,
+                    const int64_t* n_unique_dev, int64_t n, int64_t* inverse, void* stream)
+{
+  if (n == 0) return 0;
+  const int blocks = static_cast<int>((n + kBlock - 1) / kBlock);
+  if (index_dtype == WHOLEMEMORY_DT_INT)
+    hipLaunchKernelGGL((run_inverse_kernel<int32_t>), dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       run_starts, order, static_cast<const int32_t*>(unique_ids), n_unique_dev, n, inverse);
+  else if (index_dtype == WHOLEMEMORY_DT_INT64)
+    hipLaunchKernelGGL((run_inverse_kernel<int64_t>), dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       run_starts, order, static_cast<const int64_t*>(unique_ids), n_unique_dev, n, inverse);
+  else
+    return -1;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 __global__ void remap_self_order_kernel(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count,
                                         const int64_t* self_rows)
 {

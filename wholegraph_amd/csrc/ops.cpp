@@ -315,8 +315,64 @@ wholememory_error_code_t mapped_gref(wholememory_tensor_t t, wholememory_gref_t*
   return wholememory_tensor_get_global_reference(t, gref);
 }
 
+wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, const op_descs& d,
+                                                 wholememory_env_func_t* env, void* stream, int gather_sms);
+
+// WM_GATHER_DEDUP=1 (not in the reference): a skewed batch asks for the same hot rows over and over — Zipf(1.05),
+// 10 M ids: 49 % unique — and every copy crosses xGMI. With this switch the requester de-duplicates its ids first
+// (radix sort + run detection, the same primitive as the gradient path), fetches each distinct row ONCE through the
+// exchange, and expands locally: out[i] = fetched[run of i] (one more pass over the output in HBM, which a link-bound
+// multi-GPU step hides many times over). For uniform ids it only costs, which is why it is a switch.
 wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const op_descs& d,
                                             wholememory_env_func_t* env, void* stream, int gather_sms)
+{
+  const auto* bk = backend();
+  const char* sw = getenv("WM_GATHER_DEDUP");
+  wholememory_comm_t comm;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, handle));
+  const int64_t n = d.indices.size;
+  const bool on = sw != nullptr && (sw[0] == '2' || (sw[0] == '1' && comm->world_size > 1));  // 2: also at world 1 (to measure)
+  if (!on || n == 0 || bk->run_inverse == nullptr || n >= (INT64_C(1) << 31))
+    return gather_distributed_rows(handle, d, env, stream, gather_sms);
+
+  const int64_t dim = d.table.sizes[1];
+  temp_mem unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env), host_n(env), rows(env), inverse(env);
+  void* d_unique  = unique_ids.device(n, d.indices.dtype);
+  auto* d_starts  = static_cast<int32_t*>(run_starts.device(n + 1, WHOLEMEMORY_DT_INT));
+  auto* d_order   = static_cast<int32_t*>(order.device(n, WHOLEMEMORY_DT_INT));
+  auto* d_nunique = static_cast<int64_t*>(n_unique.device(1, WHOLEMEMORY_DT_INT64));
+  void* d_ws = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n, d.indices.dtype)), WHOLEMEMORY_DT_INT8);
+  // full-width keys: negative ("skip me") ids must stay distinct from every valid id
+  int rc = bk->dedup_ids(d.indices_ptr, d.indices.dtype, n, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
+  if (rc != 0) return rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR;
+  auto* h_n = static_cast<int64_t*>(host_n.pinned(1, WHOLEMEMORY_DT_INT64));
+  WM_BK(bk->memcpy_async(h_n, d_nunique, sizeof(int64_t), stream));
+  WM_BK(bk->stream_sync(stream));
+  const int64_t nu = *h_n;
+
+  // (1) each distinct id once, through the exchange, into a dense [nu, dim] buffer of the output dtype
+  char* uniq_rows = static_cast<char*>(rows.device(dim * nu, d.plain.dtype));
+  op_descs du     = d;
+  du.indices_ptr  = d_unique;
+  du.indices.size = nu;
+  du.indices.storage_offset = 0;
+  du.plain_ptr    = uniq_rows;
+  int64_t usz[2]  = {nu, dim};
+  du.plain        = wholememory_create_matrix_desc(usz, dim, 0, d.plain.dtype);
+  WHOLEMEMORY_RETURN_ON_FAIL(gather_distributed_rows(handle, du, env, stream, gather_sms));
+  // (2) expand: out[i] = uniq_rows[run of i]; positions of negative ids get -1 and stay untouched
+  auto* inv = static_cast<int64_t*>(inverse.device(n, WHOLEMEMORY_DT_INT64));
+  WM_BK(bk->run_inverse(d_starts, d_order, d_unique, d.indices.dtype, d_nunique, n, inv, stream));
+  wm_rows_args ea{};
+  fill_rows_args(&ea, wholememory_create_continuous_global_reference(uniq_rows), du.plain, inv, WHOLEMEMORY_DT_INT64, n,
+                 d.plain_ptr, d.plain, gather_sms);
+  WM_BK(bk->gather_rows(&ea, stream));
+  WM_BK(bk->stream_sync(stream));  // scratch buffers return to the caller's allocator
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, const op_descs& d,
+                                                 wholememory_env_func_t* env, void* stream, int gather_sms)
 {
   const auto* bk = backend();
   if (d.table.storage_offset < 0 || d.table.storage_offset + d.table.sizes[1] > d.table.stride)
