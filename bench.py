@@ -129,6 +129,11 @@ def cpu_baseline(dim, seconds):
 
 def main():
     a = parse()
+    # stdout carries exactly one line, the JSON record: native libraries (RCCL prints "Librccl path : ..." on load)
+    # write to fd 1 directly, so fd 1 points at stderr until the record is printed
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -257,7 +262,8 @@ def main():
                                    round(pair_bytes / (wall / a.steps) / 1e9, 2) if pair_bytes else None,
                                "note": "rows all-to-all-v over RCCL grouped send/recv, pipelined in row chunks with the "
                                        "owner-side gather and the reorder-on-receive kernels"}
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     wgth.destroy_embedding(emb)
     if launched:
         torch.distributed.barrier()
