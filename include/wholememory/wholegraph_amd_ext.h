@@ -105,6 +105,12 @@ const char* wholememory_ext_backend_name();
  * NULL restores the HIP backend. Never called by product code. */
 enum wholememory_error_code_t wm_testing_install_backend(const void* backend);
 
+/* Occupancy / effectiveness of an embedding's device row cache: slots, occupied slots, modified slots, lookups served
+ * from the cache and lookups seen so far (this rank). INVALID_INPUT for an embedding without cache. */
+enum wholememory_error_code_t wholememory_ext_embedding_cache_info(wholememory_embedding_t embedding, int64_t* slots,
+                                                                   int64_t* occupied, int64_t* dirty, int64_t* hits,
+                                                                   int64_t* lookups);
+
 #ifdef __cplusplus
 }
 #endif

@@ -247,6 +247,7 @@ PROTOTYPES = {
     "wholememory_ext_dedup_apply": (_i, [_vp, _i, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i, _P(_f), _f, _vp,
                                         _vp, _P(_i64), _P(EnvFunc), _vp]),
     "wholememory_ext_round_robin_map": (_i, [_vp, _vp, _i, _i64, _i64, _i, _i, _vp]),
+    "wholememory_ext_embedding_cache_info": (_i, [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)]),
     "wholememory_ext_backend_name": (C.c_char_p, []),
     "wm_testing_install_backend": (_i, [_vp]),
 }

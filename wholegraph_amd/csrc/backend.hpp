@@ -102,6 +102,23 @@ struct wm_sample_args {
   wholememory_dtype_t weight_dtype;
 };
 
+// device row cache of an embedding (kernels/cache.hip): direct map row -> slot, 64-slot LFU sets
+struct wm_cache_args {
+  int32_t* slot_of;     // [cover_rows] slot of a covered row or -1
+  int32_t* count;       // [cover_rows] access counter
+  int64_t* row_of;      // [64 * n_sets] covered-row index resident in a slot or -1
+  uint8_t* dirty;       // [64 * n_sets]
+  char* data;           // [64 * n_sets, row_bytes] cache lines
+  int64_t cover_start;  // first GLOBAL row this cache may hold
+  int64_t cover_rows;
+  int64_t n_sets;
+  int64_t set_cover;    // rows per set: set s covers [s * set_cover, (s + 1) * set_cover) of the covered range
+  int64_t row_bytes;    // bytes per cache line = padded row (multiple of 16)
+  wholememory_gref_t raw_gref;  // the raw table, addressed by GLOBAL row
+  int64_t raw_row_stride_bytes;
+  int64_t raw_row_offset_bytes;
+};
+
 struct wm_device_backend {
   const char* name;
   // memory / stream
@@ -171,6 +188,16 @@ struct wm_device_backend {
   int (*append_unique_phase2)(const void* targets, int n_target, int n_neighbor, wholememory_dtype_t dtype, void* workspace,
                               void* out_unique, int* mapping, void* stream);
   int (*csr_add_self_loop)(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
+  // ---- embedding row cache (kernels/cache.hip); nullptr in a backend that does not provide it ----
+  // unique_rows / run_starts / n_unique_dev: output of dedup_ids on the batch's ids (full-width keys); adds the batch to
+  // the access counters and replaces least-frequently-used residents by more frequently used missing rows
+  int (*cache_update)(const wm_cache_args* c, const void* unique_rows, wholememory_dtype_t index_dtype,
+                      const int32_t* run_starts, const int64_t* n_unique_dev, int64_t n_upper, void* stream);
+  // cache_idx[i] = slot of ids[i] or -1; raw_idx[i] = ids[i] if it misses (or is negative) else -1; *hits_dev += hits
+  int (*cache_split)(const wm_cache_args* c, const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t* cache_idx,
+                     void* raw_idx, unsigned long long* hits_dev, void* stream);
+  int (*cache_writeback)(const wm_cache_args* c, int drop, void* stream);
+  int (*cache_info)(const wm_cache_args* c, unsigned long long* occupied_dirty_dev, void* stream);
 };
 
 }  // extern "C"

@@ -8,8 +8,7 @@
 // lined up in send order and exchanged by RCCL all-to-all-v, and the owner runs ONE fused kernel per
 // step (duplicate-sum in the reference's order + optimizer update, kernels/optim.hip) — there is no
 // intermediate de-duplicated gradient buffer and no host sync to learn the unique count.
-// The device LFU cache of the reference (embedding_cache.*) is outside this build's scope:
-// creating an embedding with a cache policy returns WHOLEMEMORY_NOT_IMPLEMENTED.
+// Cached embeddings: embedding_cache.{hpp,cpp} + kernels/cache.hip (a device row cache with a direct row -> slot map).
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -19,15 +18,8 @@
 
 #include <wholememory/embedding.h>
 
+#include "embedding_cache.hpp"
 #include "ops_internal.hpp"
-
-struct wholememory_embedding_cache_policy_ {
-  wholememory_comm_t cache_comm;
-  wholememory_memory_type_t cache_memory_type;
-  wholememory_memory_location_t cache_memory_location;
-  wholememory_access_type_t access_type;
-  float cache_ratio;
-};
 
 struct wholememory_embedding_optimizer_ {
   wholememory_optimizer_type_t type = WHOLEMEMORY_OPT_NONE;
@@ -58,6 +50,7 @@ struct wholememory_embedding_ {
   wholememory_tensor_t per_row_view   = nullptr;
   wholememory_tensor_t per_row_local  = nullptr;
   int64_t state_row_elems             = 0;             // columns of the packed state table
+  wm::row_cache* cache                = nullptr;       // device row cache (cache policy given at creation)
 };
 
 namespace wm {
@@ -503,8 +496,32 @@ wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* w
     return WHOLEMEMORY_INVALID_INPUT;
   }
   if (cache_policy != nullptr) {
-    WM_ERROR("cached embeddings (device LFU cache) are not part of this build — create the embedding without a cache policy");
-    return WHOLEMEMORY_NOT_IMPLEMENTED;
+    // reference embedding.cpp:966-1016
+    if (memory_type == WHOLEMEMORY_MT_HIERARCHY) {
+      WM_ERROR("Cache is not supported now in hierarchy memory type.");
+      return WHOLEMEMORY_NOT_SUPPORTED;
+    }
+    if (cache_policy->cache_comm == comm) {
+      if (cache_policy->cache_memory_location != WHOLEMEMORY_ML_DEVICE) {
+        WM_ERROR("Cache has same communicator with raw embedding, should be device cached host embedding, but cache memory "
+                 "location is not WHOLEMEMORY_ML_DEVICE.");
+        return WHOLEMEMORY_INVALID_INPUT;
+      }
+      if (cache_policy->cache_memory_type < memory_type) {
+        WM_ERROR("For device cached host memory, raw embedding should cover cache's address modes.");
+        return WHOLEMEMORY_INVALID_INPUT;
+      }
+    } else {
+      if (cache_policy->cache_memory_type == WHOLEMEMORY_MT_DISTRIBUTED) {
+        WM_ERROR("For local cached global readonly embedding, cache_memory_type should be chunked or continuous.");
+        return WHOLEMEMORY_INVALID_INPUT;
+      }
+      if (cache_policy->access_type != WHOLEMEMORY_AT_READONLY) {
+        WM_ERROR("Only ReadOnly access type supported for local cached global readonly embedding.");
+        return WHOLEMEMORY_INVALID_INPUT;
+      }
+    }
+    embedding_entry_partition = nullptr;
   }
   if (embedding_entry_partition != nullptr) {
     if (round_robin_size != 0) WM_WARN("Parameter 'round_robin_size' is ignored.");
@@ -545,6 +562,14 @@ wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* w
     wholememory_destroy_tensor(e->allocated);
     return rc;
   }
+  if (cache_policy != nullptr) {
+    rc = wm::create_row_cache(&e->cache, cache_policy, e->allocated, comm);
+    if (rc != WHOLEMEMORY_SUCCESS) {
+      wholememory_destroy_tensor(e->user);
+      wholememory_destroy_tensor(e->allocated);
+      return rc;
+    }
+  }
   *wholememory_embedding = e.release();
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
@@ -555,6 +580,7 @@ wholememory_error_code_t wholememory_destroy_embedding(wholememory_embedding_t e
   WM_API_BEGIN
   if (e == nullptr) return WHOLEMEMORY_INVALID_INPUT;
   wm::destroy_states(e);
+  delete e->cache;
   if (e->user) wholememory_destroy_tensor(e->user);
   if (e->allocated) wholememory_destroy_tensor(e->allocated);
   delete e;
@@ -574,6 +600,14 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
     return WHOLEMEMORY_NOT_SUPPORTED;
   }
   if (optimizer == nullptr) return WHOLEMEMORY_SUCCESS;
+  if (e->cache != nullptr && !e->cache->writable) {
+    WM_ERROR("a read-only cached embedding cannot be trained");
+    return WHOLEMEMORY_NOT_SUPPORTED;
+  }
+  if (e->cache != nullptr) {
+    WM_ERROR("training a cached embedding is not implemented in this build");
+    return WHOLEMEMORY_NOT_IMPLEMENTED;
+  }
   // reference embedding.cpp:61-63: "Only float embedding supports training." Extension (BASELINE config 4, fp16
   // scatter-add): HALF / BF16 embeddings accept the stateless optimizer, SGD (see backend.hpp value_dtype).
   const bool sgd16 = (e->dtype == WHOLEMEMORY_DT_HALF || e->dtype == WHOLEMEMORY_DT_BF16) &&
@@ -601,14 +635,18 @@ wholememory_error_code_t wholememory_embedding_gather(wholememory_embedding_t e,
                                                       int64_t stream_int)
 {
   WM_API_BEGIN
-  (void)adjust_cache;
   if (e == nullptr || indices == nullptr || output == nullptr) return WHOLEMEMORY_INVALID_INPUT;
   void* stream = reinterpret_cast<void*>(stream_int);
-  if (e->round_robin_size == 0) return wholememory_gather(e->allocated, indices, output, p_env_fns, stream, e->gather_sms);
+  auto do_gather = [&](wholememory_tensor_t ids) {
+    return e->cache != nullptr
+             ? wm::gather_cached(e->allocated, ids, output, p_env_fns, stream, e->gather_sms, e->cache, adjust_cache)
+             : wholememory_gather(e->allocated, ids, output, p_env_fns, stream, e->gather_sms);
+  };
+  if (e->round_robin_size == 0) return do_gather(indices);
   wm::temp_mem mapped_mem(p_env_fns);
   wholememory_tensor_t mapped = nullptr;
   WHOLEMEMORY_RETURN_ON_FAIL(wm::remap_round_robin(e, indices, &mapped_mem, &mapped, stream));
-  auto rc = wholememory_gather(e->allocated, mapped, output, p_env_fns, stream, e->gather_sms);
+  auto rc = do_gather(mapped);
   wholememory_destroy_tensor(mapped);
   return rc;
   WM_API_END
@@ -650,13 +688,30 @@ wholememory_tensor_t wholememory_embedding_get_optimizer_state(wholememory_embed
   return it == e->state_views.end() ? nullptr : it->second;
 }
 
-wholememory_error_code_t wholememory_embedding_writeback_cache(wholememory_embedding_t e, int64_t)
+wholememory_error_code_t wholememory_embedding_writeback_cache(wholememory_embedding_t e, int64_t stream_int)
 {
-  return e ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;  // no cache in this build: nothing to write back
+  WM_API_BEGIN
+  if (e == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (e->cache == nullptr) return WHOLEMEMORY_SUCCESS;  // reference embedding.cpp:1090-1098: nothing to do without a cache
+  return wm::row_cache_writeback(e->cache, false, reinterpret_cast<void*>(stream_int));
+  WM_API_END
 }
-wholememory_error_code_t wholememory_embedding_drop_all_cache(wholememory_embedding_t e, int64_t)
+wholememory_error_code_t wholememory_embedding_drop_all_cache(wholememory_embedding_t e, int64_t stream_int)
 {
-  return e ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;
+  WM_API_BEGIN
+  if (e == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (e->cache == nullptr) return WHOLEMEMORY_SUCCESS;
+  return wm::row_cache_writeback(e->cache, true, reinterpret_cast<void*>(stream_int));
+  WM_API_END
+}
+
+wholememory_error_code_t wholememory_ext_embedding_cache_info(wholememory_embedding_t e, int64_t* slots, int64_t* occupied,
+                                                              int64_t* dirty, int64_t* hits, int64_t* lookups)
+{
+  WM_API_BEGIN
+  if (e == nullptr || e->cache == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  return wm::row_cache_info(e->cache, slots, occupied, dirty, hits, lookups, nullptr);
+  WM_API_END
 }
 
 // ---------------------------------------------------------------- raw stage for parity tests

@@ -37,6 +37,13 @@ int hip_append_unique_phase2(const void* targets, int nt, int nn, wholememory_dt
                              int* mapping, void* stream);
 int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
 
+int hip_cache_update(const wm_cache_args* c, const void* unique_rows, wholememory_dtype_t dt, const int32_t* run_starts,
+                     const int64_t* n_unique_dev, int64_t n_upper, void* stream);
+int hip_cache_split(const wm_cache_args* c, const void* ids, wholememory_dtype_t dt, int64_t n, int64_t* cache_idx, void* raw_idx,
+                    unsigned long long* hits_dev, void* stream);
+int hip_cache_writeback(const wm_cache_args* c, int drop, void* stream);
+int hip_cache_info(const wm_cache_args* c, unsigned long long* out2_dev, void* stream);
+
 namespace {
 
 int rc(hipError_t e) { return e == hipSuccess ? 0 : static_cast<int>(e); }
@@ -150,6 +157,10 @@ const wm_device_backend kHipBackend = {
   hip_append_unique_phase1,
   hip_append_unique_phase2,
   hip_csr_add_self_loop,
+  hip_cache_update,
+  hip_cache_split,
+  hip_cache_writeback,
+  hip_cache_info,
 };
 
 }  // namespace

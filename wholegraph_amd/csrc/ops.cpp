@@ -16,6 +16,7 @@
 // DISTRIBUTED scatter mirrors it (rows travel in the input dtype, the owner casts on write) and ends
 // with a stream synchronise like the reference (scatter_op_impl_nccl.cu:168).
 #include "ops_internal.hpp"
+#include "embedding_cache.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -316,7 +317,8 @@ wholememory_error_code_t mapped_gref(wholememory_tensor_t t, wholememory_gref_t*
 }
 
 wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, const op_descs& d,
-                                                 wholememory_env_func_t* env, void* stream, int gather_sms);
+                                                 wholememory_env_func_t* env, void* stream, int gather_sms,
+                                                 row_cache* cache = nullptr, bool adjust_cache = false);
 
 // WM_GATHER_DEDUP=1 (not in the reference): a skewed batch asks for the same hot rows over and over — Zipf(1.05),
 // 10 M ids: 49 % unique — and every copy crosses xGMI. With this switch the requester de-duplicates its ids first
@@ -371,8 +373,12 @@ wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const o
   return WHOLEMEMORY_SUCCESS;
 }
 
+// `cache` (optional): this rank's device row cache of its own shard — the owner-side gathers then read resident rows
+// from the cache lines and only the others from the raw shard (reference device_cached_host_embedding::gather,
+// embedding.cpp:576-760); with adjust_cache the ids that arrive at this owner update the cache first.
 wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, const op_descs& d,
-                                                 wholememory_env_func_t* env, void* stream, int gather_sms)
+                                                 wholememory_env_func_t* env, void* stream, int gather_sms,
+                                                 row_cache* cache, bool adjust_cache)
 {
   const auto* bk = backend();
   if (d.table.storage_offset < 0 || d.table.storage_offset + d.table.sizes[1] > d.table.stride)
@@ -389,6 +395,20 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   id_exchange x(env);
   bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x, true);
   const auto local_gref = local_shard_gref(handle);
+  // owner-side row gather: through the cache when there is one
+  auto local_gather = [&](const wm_rows_args& ga) {
+    if (cache == nullptr) {
+      WM_BK(bk->gather_rows(&ga, stream));
+    } else if (row_cache_gather(cache, ga, env, stream) != WHOLEMEMORY_SUCCESS) {
+      throw hip_error("cached gather failed");
+    }
+  };
+  if (cache != nullptr && adjust_cache) {
+    const int64_t total_rows = static_cast<int64_t>(entry_offsets[comm->world_size]);
+    WHOLEMEMORY_RETURN_ON_FAIL(row_cache_update(cache, static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset,
+                                                d.indices.dtype, x.self_count, total_rows, env, stream));
+    WHOLEMEMORY_RETURN_ON_FAIL(row_cache_update(cache, x.recv_ids, d.indices.dtype, x.total_recv, total_rows, env, stream));
+  }
 
   // (a) ids this rank owns itself: straight from the local shard into their final output rows
   //     (row_map = raw_indices) — no staging buffer, no copy, no reorder pass for them
@@ -397,7 +417,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
     fill_rows_args(&sa, local_gref, d.table, static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset,
                    d.indices.dtype, x.self_count, d.plain_ptr, d.plain, gather_sms);
     sa.row_map = x.raw_indices + x.self_offset;
-    WM_BK(bk->gather_rows(&sa, stream));
+    local_gather(sa);
   }
 
   // (b)-(d) the peers' rows, pipelined in C row-chunks so the three legs overlap:
@@ -430,7 +450,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
       wm_rows_args ga{};
       fill_rows_args(&ga, local_gref, d.table, static_cast<const char*>(x.recv_ids) + ies * first, d.indices.dtype, b - a,
                      local_buf + row_bytes * first, local_desc, gather_sms);
-      WM_BK(bk->gather_rows(&ga, stream));
+      local_gather(ga);
     }
   };
   auto exchange_chunk = [&](int c, void* on_stream) {
@@ -485,6 +505,29 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
   return WHOLEMEMORY_SUCCESS;
 }
+
+}  // namespace
+
+// gather of an embedding that has a device row cache (embedding.cpp)
+wholememory_error_code_t gather_cached(wholememory_tensor_t table, wholememory_tensor_t indices_tensor,
+                                       wholememory_tensor_t output_tensor, wholememory_env_func_t* env, void* stream,
+                                       int gather_sms, row_cache* cache, bool adjust_cache)
+{
+  op_descs d;
+  WHOLEMEMORY_RETURN_ON_FAIL(check_args(table, indices_tensor, output_tensor, "output", &d));
+  auto handle = wholememory_tensor_get_memory_handle(table);
+  if (cache->same_comm)  // owners serve their shard (cache first), rows travel by all-to-all-v — for every memory type
+    return gather_distributed_rows(handle, d, env, stream, gather_sms, cache, adjust_cache);
+  // local read-only cache of a table that is addressable from here
+  if (adjust_cache)
+    WHOLEMEMORY_RETURN_ON_FAIL(row_cache_update(cache, d.indices_ptr, d.indices.dtype, d.indices.size, 0, env, stream));
+  wm_rows_args a{};
+  fill_rows_args(&a, cache->args.raw_gref, d.table, d.indices_ptr, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain,
+                 gather_sms);
+  return row_cache_gather(cache, a, env, stream);
+}
+
+namespace {
 
 wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const op_descs& d,
                                              wholememory_env_func_t* env, void* stream, int scatter_sms)

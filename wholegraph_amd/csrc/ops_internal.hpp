@@ -86,6 +86,12 @@ wholememory_gref_t local_shard_gref(wholememory_handle_t handle);
 // gref a kernel should use for a tensor mapped in this process (CONTINUOUS / CHUNKED handle or a plain pointer)
 wholememory_error_code_t tensor_mapped_gref(wholememory_tensor_t t, wholememory_gref_t* gref);
 
+struct row_cache;
+// gather of an embedding with a device row cache (embedding_cache.hpp)
+wholememory_error_code_t gather_cached(wholememory_tensor_t table, wholememory_tensor_t indices_tensor,
+                                       wholememory_tensor_t output_tensor, wholememory_env_func_t* env, void* stream,
+                                       int gather_sms, row_cache* cache, bool adjust_cache);
+
 // true when a CHUNKED / CONTINUOUS table should be served through the all-to-all-v route (WM_MAPPED_VIA_EXCHANGE=1)
 bool mapped_via_exchange(wholememory_tensor_t t, wholememory_memory_type_t mt);
 
