@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--optimizer", default="sgd")
     p.add_argument("--dtype", choices=["f32", "f16", "bf16"], default="f32",
                    help="table dtype (side measurements; the contract metric is f32)")
+    p.add_argument("--cache-ratio", type=float, default=0.0,
+                   help="side measurement: give the embedding a device row cache of this ratio (HOST tables)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-check", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -159,7 +161,12 @@ def main():
     mt = a.memory_type or ("chunked" if world == 1 else "distributed")
     tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
     es = 4 if a.dtype == "f32" else 2
-    emb = wgth.create_embedding(comm, mt, a.location, tdt, [total_rows, a.dim])
+    policy = None
+    if a.cache_ratio > 0:
+        policy = wgth.create_wholememory_cache_policy(comm, memory_type=mt, memory_location="cuda",
+                                                      access_type="readwrite" if a.op == "grad_apply" else "readonly",
+                                                      ratio=a.cache_ratio)
+    emb = wgth.create_embedding(comm, mt, a.location, tdt, [total_rows, a.dim], cache_policy=policy)
     local, start = emb.get_embedding_tensor().get_local_tensor(host_view=(a.location == "cpu"))
     fill_table(local, start)
     idx_np = make_indices(a.indices, total_rows, a.dist, 42 + rank)

@@ -205,6 +205,49 @@ def scenario_sgd16(comm, rank, world, tdt, dim, lr, wd):
     wgth.destroy_embedding(emb)
 
 
+def scenario_cached_embedding(comm, rank, world, mt):
+    """HOST embedding with a read-write device cache on every rank (HIP mode): owners serve lookups cache-first through
+    the exchange, train through the cache, write back. Bit-exact vs the uncached multi-rank oracle."""
+    n_rows, dim, steps = 9001, 24, 3
+    policy = wgth.create_wholememory_cache_policy(comm, memory_type=mt, memory_location="cuda", access_type="readwrite",
+                                                  ratio=0.15)
+    emb = wgth.create_embedding(comm, mt, "cpu", torch.float32, [n_rows, dim], cache_policy=policy)
+    stride = emb.get_embedding_tensor().stride()[0]
+    init = np.random.default_rng(21).standard_normal((n_rows, dim)).astype(np.float32)
+    padded = np.zeros((n_rows, stride), dtype=np.float32)
+    padded[:, :dim] = init
+    tab = oracle.ShardedTable.from_full(padded, world, None)
+    tab.dim = dim
+    local, start = emb.get_embedding_tensor().get_local_tensor(host_view=True)
+    cnt = int(tab.entry_offsets[rank + 1] - tab.entry_offsets[rank])
+    local.copy_(torch.from_numpy(init[start:start + cnt]))
+    comm.barrier()
+    opt = wgth.create_wholememory_optimizer(emb, "adam", {})
+    ref_opts = [oracle.Optimizer("adam", int(tab.entry_offsets[r + 1] - tab.entry_offsets[r]), stride) for r in range(world)]
+    for step in range(steps):
+        rank_idx, rank_grads = [], []
+        for r in range(world):
+            g = np.random.default_rng(77 * step + r)
+            k = g.zipf(1.3, 3000 + 50 * r).astype(np.uint64)
+            ix = ((k * np.uint64(2654435761)) % np.uint64(n_rows)).astype(np.int64)
+            rank_idx.append(ix)
+            rank_grads.append(g.standard_normal((len(ix), dim)).astype(np.float32))
+        exp = oracle.distributed_gather(tab, rank_idx, np.float32)
+        got = emb.gather(dev(torch.from_numpy(rank_idx[rank])))
+        torch.cuda.synchronize()
+        assert host(got).numpy().tobytes() == exp[rank].tobytes(), "cached gather mismatch rank %d step %d" % (rank, step)
+        emb.add_gradients(dev(torch.from_numpy(rank_idx[rank])), dev(torch.from_numpy(rank_grads[rank])))
+        emb.need_apply = True
+        opt.step(0.03)
+        oracle.gradient_apply(tab, ref_opts, rank_idx, rank_grads, 0.03)
+    emb.writeback_all_cache()
+    comm.barrier()
+    assert local.numpy().tobytes() == tab.shards[rank][:cnt, :dim].tobytes(), "table after write-back, rank %d" % rank
+    comm.barrier()
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)
+
+
 def scenario_file_io(comm, rank, world, tmpdir):
     """wholememory_load_from_file / store_to_file through the Python surface: files re-sharded over ranks (3 files of
     uneven size -> W shards), padded rows (file rows are dim wide, memory rows stride wide), round-robin placement,
@@ -346,6 +389,9 @@ def main():
                          ("adam", {"adam_w": 1.0, "weight_decay": 0.02}), ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]:
         scenario_gradient_apply(comm, rank, world, kind, params, np.int64 if kind != "adagrad" else np.int32, None)
     if HIP_MODE:
+        # (7) device row caches: HOST tables served and trained through per-rank caches
+        scenario_cached_embedding(comm, rank, world, "distributed")
+        scenario_cached_embedding(comm, rank, world, "chunked")
         # (6) extension: SGD on 16-bit tables (fp16 scatter-add = lr -1, wd 0)
         scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0)
         scenario_sgd16(comm, rank, world, torch.bfloat16, 40, 0.05, 0.01)

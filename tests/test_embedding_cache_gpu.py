@@ -119,3 +119,68 @@ def test_cache_policy_validation(gpu_env):
             wgth.create_embedding(gpu_env, mt, "cpu", torch.float32, [1000, 16], cache_policy=policy)
     with pytest.raises(wmb.WholeMemoryError):
         wgth.create_wholememory_cache_policy(gpu_env, ratio=0.0001)
+
+
+@pytest.mark.parametrize("kind,params", [("sgd", {"weight_decay": 0.01}), ("adam", {})])
+@pytest.mark.parametrize("mt", ["chunked", "distributed"])
+def test_readwrite_cache_training_and_writeback(gpu_env, mt, kind, params):
+    """Training a HOST embedding through its read-write device cache (reference device_cached_host_embedding with
+    WHOLEMEMORY_AT_READWRITE): resident rows are updated in the cache and marked modified, gathers see the new values at
+    once, the raw table catches up at write-back. Every value is compared bit for bit with the uncached oracle."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    n_rows, dim, n_idx = 40009, 32, 30000
+    policy = wgth.create_wholememory_cache_policy(gpu_env, memory_type=mt, memory_location="cuda", access_type="readwrite",
+                                                  ratio=0.2)
+    emb = wgth.create_embedding(gpu_env, mt, "cpu", torch.float32, [n_rows, dim], cache_policy=policy)
+    rng = np.random.default_rng(11)
+    init = rng.standard_normal((n_rows, dim)).astype(np.float32)
+    local, _ = emb.get_embedding_tensor().get_local_tensor(host_view=True)
+    local.copy_(torch.from_numpy(init))
+    opt = wgth.create_wholememory_optimizer(emb, kind, params)
+    tab = oracle.ShardedTable.from_full(init.copy(), 1)
+    ref_opt = oracle.Optimizer(kind, n_rows, dim, **params)
+    for step in range(4):
+        idx = _zipf(rng, n_idx, n_rows)
+        got = emb.gather(torch.from_numpy(idx).cuda(), is_training=True)       # also warms the cache (adjust_cache)
+        exp = np.zeros((n_idx, dim), np.float32)
+        oracle.gather(tab, idx, exp)
+        assert got.detach().cpu().numpy().tobytes() == exp.tobytes(), "gather before step %d" % step
+        g = rng.standard_normal((n_idx, dim)).astype(np.float32)
+        emb.add_gradients(torch.from_numpy(idx).cuda(), torch.from_numpy(g).cuda())
+        opt.step(0.05)
+        oracle.gradient_apply(tab, [ref_opt], [idx], [g], 0.05)
+        probe = _zipf(np.random.default_rng(step), 5000, n_rows)
+        emb.set_adjust_cache(False)
+        got = emb.gather(torch.from_numpy(probe).cuda())
+        emb.set_adjust_cache(True)
+        exp = np.zeros((len(probe), dim), np.float32)
+        oracle.gather(tab, probe, exp)
+        assert got.cpu().numpy().tobytes() == exp.tobytes(), "gather after step %d" % step
+    info = _info(emb)
+    assert info["dirty"] > 0 and info["occupied"] >= info["dirty"]
+    torch.cuda.synchronize()
+    assert local.numpy().tobytes() != tab.shards[0].tobytes(), "raw table should lag behind the modified cache lines"
+    emb.writeback_all_cache()
+    assert _info(emb)["dirty"] == 0
+    assert local.numpy().tobytes() == tab.shards[0].tobytes(), "raw table after write-back differs from the oracle"
+    emb.drop_all_cache()
+    assert _info(emb)["occupied"] == 0
+    probe = rng.integers(0, n_rows, 4000)
+    got = emb.gather(torch.from_numpy(probe).cuda())
+    assert np.array_equal(got.cpu().numpy(), tab.shards[0][probe])
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)
+    wgth.destroy_wholememory_cache_policy(policy)
+
+
+def test_readonly_cache_refuses_training(gpu_env):
+    import torch
+    import wholegraph_amd.torch as wgth
+    from wholegraph_amd import binding as wmb
+    policy = wgth.create_wholememory_cache_policy(gpu_env, memory_type="chunked", memory_location="cuda",
+                                                  access_type="readonly", ratio=0.2)
+    emb = wgth.create_embedding(gpu_env, "chunked", "cpu", torch.float32, [1000, 16], cache_policy=policy)
+    with pytest.raises(wmb.WholeMemoryError):
+        wgth.create_wholememory_optimizer(emb, "sgd", {})
+    wgth.destroy_embedding(emb)

@@ -67,6 +67,12 @@ struct wm_optimizer_args {
   const void* self_grads;
   int64_t self_grad_stride;
   int64_t count;               // number of unique ids (= grid size)
+  // optional device row cache of the local shard (kernels/cache.hip): row `local` lives in cache line cache_slot_of[local]
+  // when that is >= 0 (the update then goes there and the line is marked modified), else in local_table
+  const int32_t* cache_slot_of;
+  void* cache_data;
+  uint8_t* cache_dirty;
+  int64_t cache_row_elems;
   void* local_table;           // this rank's first row
   int64_t table_stride;        // elements
   int64_t local_entry_offset;  // global id of local row 0

@@ -228,7 +228,7 @@ void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64
 // reference embedding.cpp:146-323
 wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholememory_tensor_t indices,
                                                wholememory_tensor_t grads, float lr, wholememory_env_func_t* env,
-                                               void* stream)
+                                               void* stream, bool adjust_cache = false)
 {
   const auto* bk  = backend();
   auto* idesc     = wholememory_tensor_get_tensor_description(indices);
@@ -365,6 +365,18 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   if (e->per_row_local != nullptr)
     oa.per_row_state = static_cast<float*>(wholememory_tensor_get_data_pointer(e->per_row_local));
   wholememory_destroy_tensor(local_table);
+  if (e->cache != nullptr) {
+    // read-write device cache of this rank's shard (reference: the optimizer kernels work through the cache,
+    // embedding_optimizer_func.cu + embedding.cpp:146-323): resident rows are updated in their cache line and marked
+    // modified, the others in the raw table; the optimizer states are not cached in this build
+    if (adjust_cache)
+      WHOLEMEMORY_RETURN_ON_FAIL(wm::row_cache_update(e->cache, recv_ids, iarr.dtype, n_recv,
+                                                      static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream));
+    oa.cache_slot_of   = e->cache->args.slot_of;
+    oa.cache_data      = e->cache->args.data;
+    oa.cache_dirty     = e->cache->args.dirty;
+    oa.cache_row_elems = e->cache->row_elems;
+  }
   dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa,
                  static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived,
                  self_direct ? &self_ref : nullptr);
@@ -604,10 +616,6 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
     WM_ERROR("a read-only cached embedding cannot be trained");
     return WHOLEMEMORY_NOT_SUPPORTED;
   }
-  if (e->cache != nullptr) {
-    WM_ERROR("training a cached embedding is not implemented in this build");
-    return WHOLEMEMORY_NOT_IMPLEMENTED;
-  }
   // reference embedding.cpp:61-63: "Only float embedding supports training." Extension (BASELINE config 4, fp16
   // scatter-add): HALF / BF16 embeddings accept the stateless optimizer, SGD (see backend.hpp value_dtype).
   const bool sgd16 = (e->dtype == WHOLEMEMORY_DT_HALF || e->dtype == WHOLEMEMORY_DT_BF16) &&
@@ -661,14 +669,14 @@ wholememory_error_code_t wholememory_embedding_gather_gradient_apply(wholememory
                                                                      int64_t stream_int)
 {
   WM_API_BEGIN
-  (void)adjust_cache;
   if (e == nullptr || indices == nullptr || grads == nullptr) return WHOLEMEMORY_INVALID_INPUT;
   void* stream = reinterpret_cast<void*>(stream_int);
-  if (e->round_robin_size == 0) return wm::gather_gradient_apply(e, indices, grads, lr, p_env_fns, stream);
+  if (e->cache != nullptr && !e->cache->same_comm) return WHOLEMEMORY_NOT_SUPPORTED;  // local caches are read-only
+  if (e->round_robin_size == 0) return wm::gather_gradient_apply(e, indices, grads, lr, p_env_fns, stream, adjust_cache);
   wm::temp_mem mapped_mem(p_env_fns);
   wholememory_tensor_t mapped = nullptr;
   WHOLEMEMORY_RETURN_ON_FAIL(wm::remap_round_robin(e, indices, &mapped_mem, &mapped, stream));
-  auto rc = wm::gather_gradient_apply(e, mapped, grads, lr, p_env_fns, stream);
+  auto rc = wm::gather_gradient_apply(e, mapped, grads, lr, p_env_fns, stream, adjust_cache);
   wholememory_destroy_tensor(mapped);
   return rc;
   WM_API_END

@@ -203,11 +203,23 @@ __device__ __forceinline__ float load_vec1(const T* p)
   return load_wide<T>(*p);
 }
 
+// where row `local` of the shard lives: its cache line when it is resident in the device row cache, else the table
+template <typename T = float>
+__device__ __forceinline__ T* table_row_at(const wm_optimizer_args& a, int64_t local, int32_t slot)
+{
+  return slot >= 0 ? static_cast<T*>(a.cache_data) + static_cast<int64_t>(slot) * a.cache_row_elems
+                   : static_cast<T*>(a.local_table) + local * a.table_stride;
+}
+__device__ __forceinline__ int32_t cache_slot(const wm_optimizer_args& a, int64_t local)
+{
+  return a.cache_slot_of != nullptr ? a.cache_slot_of[local] : -1;
+}
+
 template <int OPT, typename T = float>
-__device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, int64_t local, int64_t d)
+__device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, const T* row, int64_t local, int64_t d)
 {
   opt_elem x;
-  x.e  = load_wide<T>(static_cast<const T*>(a.local_table)[local * a.table_stride + d]);
+  x.e  = load_wide<T>(row[d]);
   x.s0 = 0.f;
   x.s1 = 0.f;
   if (OPT != WHOLEMEMORY_OPT_SGD) {
@@ -219,7 +231,7 @@ __device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, int64_
 }
 
 template <int OPT, typename T = float>
-__device__ __forceinline__ void update_elem(const wm_optimizer_args& a, int64_t local, int64_t d, opt_elem x,
+__device__ __forceinline__ void update_elem(const wm_optimizer_args& a, T* row, int64_t local, int64_t d, opt_elem x,
                                             float grad_value, float beta1t, float beta2t)
 {
   float embedding_value = x.e;
@@ -257,16 +269,19 @@ __device__ __forceinline__ void update_elem(const wm_optimizer_args& a, int64_t 
   }
   // the updated row is not read again in this pass: non-temporal store (merged into one wide store per lane)
   if constexpr (std::is_same<T, float>::value)
-    __builtin_nontemporal_store(embedding_value, &static_cast<float*>(a.local_table)[local * a.table_stride + d]);
+    __builtin_nontemporal_store(embedding_value, &row[d]);
   else  // 16-bit tables (SGD extension): one rounding from the fp32 result
-    static_cast<T*>(a.local_table)[local * a.table_stride + d] = store_narrow<T>(embedding_value);
+    row[d] = store_narrow<T>(embedding_value);
 }
 
 template <int OPT, typename T = float>
 __device__ __forceinline__ void apply_optimizer(const wm_optimizer_args& a, int64_t local, int64_t d, float grad_value,
                                                 float beta1t, float beta2t)
 {
-  update_elem<OPT, T>(a, local, d, load_elem<OPT, T>(a, local, d), grad_value, beta1t, beta2t);
+  const int32_t slot = cache_slot(a, local);
+  T* row             = table_row_at<T>(a, local, slot);
+  if (slot >= 0) a.cache_dirty[slot] = 1;
+  update_elem<OPT, T>(a, row, local, d, load_elem<OPT, T>(a, row, local, d), grad_value, beta1t, beta2t);
 }
 
 // The work per run is a chain of dependent loads (ids / run_starts -> order -> gradient row; ids -> table row), and the
@@ -304,6 +319,7 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
   };
   struct stage2 {
     int32_t o0[K];
+    int32_t slot[K];  // cache line of the row, or -1
     float beta1t[K], beta2t[K];
   };
   auto load1 = [&](int64_t u0) {
@@ -322,6 +338,7 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
 #pragma unroll
     for (int k = 0; k < K; k++) {
       r.o0[k]     = a.order[m.s0[k]];
+      r.slot[k]   = cache_slot(a, m.local[k]);
       r.beta1t[k] = r.beta2t[k] = 0.f;
       if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) {
         r.beta1t[k] = a.per_row_state[m.local[k] * 2 + 0] * a.beta1;
@@ -356,6 +373,12 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
         live[k] = false;  // folded by step_long_kernel
       }
     }
+    T* row[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      row[k] = table_row_at<T>(a, m_cur.local[k], r_cur.slot[k]);
+      if (live[k] && r_cur.slot[k] >= 0 && lane == 0) a.cache_dirty[r_cur.slot[k]] = 1;
+    }
     for (int64_t d = static_cast<int64_t>(lane) * V; d < a.dim; d += 64 * V) {
       vec_t acc[K];
       opt_elem x[K][V];
@@ -364,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
         // first occurrence copied (DedupIndiceAndGradientsKernel); table / state values loaded alongside
         acc[k] = load_vec<T, V>(grad_row<T>(a, r_cur.o0[k]) + d);
 #pragma unroll
-        for (int v = 0; v < V; v++) x[k][v] = load_elem<OPT, T>(a, m_cur.local[k], d + v);
+        for (int v = 0; v < V; v++) x[k][v] = load_elem<OPT, T>(a, row[k], m_cur.local[k], d + v);
       }
 #pragma unroll
       for (int k = 0; k < K; k++) {
@@ -384,7 +407,7 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
         }
 #pragma unroll
         for (int v = 0; v < V; v++)
-          update_elem<OPT, T>(a, m_cur.local[k], d + v, x[k][v], acc[k][v], r_cur.beta1t[k], r_cur.beta2t[k]);
+          update_elem<OPT, T>(a, row[k], m_cur.local[k], d + v, x[k][v], acc[k][v], r_cur.beta1t[k], r_cur.beta2t[k]);
       }
     }
     m_cur = m_nxt;

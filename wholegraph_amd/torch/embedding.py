@@ -72,8 +72,7 @@ def destroy_wholememory_cache_policy(cache_policy):
 
 def create_builtin_cache_policy(builtin_cache_type, embedding_memory_type, embedding_memory_location, access_type,
                                 cache_ratio, *, cache_memory_type="", cache_memory_location=""):
-    """Policy objects can be built; embeddings that USE one are not implemented in this build
-    (create_embedding raises NotImplementedError) — see DESIGN.md, out-of-scope list."""
+    """reference embedding.py:139-209. The cache behind the policy is a device row cache."""
     if embedding_memory_type not in ("continuous", "chunked", "distributed", "hierarchy"):
         raise ValueError(f"embedding_memory_type={embedding_memory_type} is not valid")
     if embedding_memory_location not in ("cpu", "cuda"):
