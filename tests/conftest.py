@@ -19,8 +19,9 @@ def wm_lib():
     if not os.path.exists(binding.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
-    elif os.path.exists("/opt/rocm/bin/hipcc"):
-        # keep the in-tree library in step with the sources (no-op when up to date)
+    elif os.path.isdir(os.path.join(ROOT, "build", "obj")):
+        # development tree (objects present; the GPU box only receives the built .so): keep the in-tree library in step
+        # with the sources — a no-op when it is up to date
         import subprocess
         subprocess.call(["make", "-C", os.path.join(ROOT, "wholegraph_amd", "csrc"), "-j8"], stdout=subprocess.DEVNULL)
     return binding.lib()
