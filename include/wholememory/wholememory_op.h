@@ -35,6 +35,21 @@ enum wholememory_error_code_t wholememory_scatter(wholememory_tensor_t input_ten
                                                   void* stream,
                                                   int scatter_sms WM_DEFAULT(-1));
 
+/*
+ * Self-test of the env functions: output[i, :] = T(float(i)) + input[:], computed in scratch memory from
+ * p_env_fns->temporary_fns, copied to output_fixed_tensor ([output_variable_entry_count, len(input)], dense) and to
+ * device / pinned / host tensors allocated through p_env_fns->output_fns for each non-null memory context.
+ * reference wholememory_op.h:58-79
+ */
+enum wholememory_error_code_t wholememory_env_test_op(wholememory_tensor_t input_tensor,
+                                                      wholememory_tensor_t output_fixed_tensor,
+                                                      void* output_variable_device_tensor_handle,
+                                                      void* output_variable_pinned_tensor_handle,
+                                                      void* output_variable_host_tensor_handle,
+                                                      int64_t output_variable_entry_count,
+                                                      struct wholememory_env_func_t* p_env_fns,
+                                                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

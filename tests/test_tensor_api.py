@@ -135,3 +135,28 @@ def test_subtensor_known_answers_handle_backed(gpu_env):
     assert lib.wholememory_tensor_get_entry_offsets(offs, root) == 0 and list(offs) == [0, row]
     assert lib.wholememory_get_total_size(h) == row * col * 4 and lib.wholememory_get_data_granularity(h) == col * 4
     assert lib.wholememory_destroy_tensor(root) == 0
+
+
+@pytest.mark.gpu
+def test_env_test_op(gpu_env):
+    """wholememory_env_test_op (reference wholememory_test_op.cu): out[i, :] = T(float(i)) + input[:], delivered to a
+    fixed tensor and to device / pinned / host tensors allocated through the env output functions."""
+    import ctypes as C
+    import torch
+    from wholegraph_amd import binding as wmb
+    from wholegraph_amd.torch.wholegraph_env import (TorchMemoryContext, get_stream, get_wholegraph_env_fns,
+                                                     wrap_torch_tensor)
+    for dt in (torch.float32, torch.int64, torch.float16):
+        inp = (torch.arange(37, device="cuda") % 5).to(dt)
+        n = 11
+        fixed = torch.zeros((n, 37), dtype=dt, device="cuda")
+        ctxs = [TorchMemoryContext() for _ in range(3)]
+        wi, wf = wrap_torch_tensor(inp), wrap_torch_tensor(fixed)
+        wmb.check(wmb.lib().wholememory_env_test_op(wi.handle, wf.handle, *[C.c_void_p(c.get_c_context()) for c in ctxs], n,
+                                                    get_wholegraph_env_fns(), C.c_void_p(get_stream())))
+        want = torch.arange(n, device="cuda").to(dt).unsqueeze(1) + inp.unsqueeze(0)
+        assert torch.equal(fixed, want)
+        dev, pinned, host = [c.get_tensor() for c in ctxs]
+        assert dev.is_cuda and not pinned.is_cuda and not host.is_cuda
+        for t in (dev, pinned, host):
+            assert torch.equal(t.cuda(), want)

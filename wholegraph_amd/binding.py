@@ -231,6 +231,7 @@ PROTOTYPES = {
     "wholememory_embedding_get_optimizer_state": (_vp, [_vp, C.c_char_p]),
     "wholememory_embedding_writeback_cache": (_i, [_vp, _i64]),
     "wholememory_embedding_drop_all_cache": (_i, [_vp, _i64]),
+    "wholememory_env_test_op": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _P(EnvFunc), _vp]),
     # wholegraph_op.h
     "wholegraph_csr_unweighted_sample_without_replacement": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.c_ulonglong,
                                                                  _P(EnvFunc), _vp]),

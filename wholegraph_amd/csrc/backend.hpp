@@ -194,6 +194,9 @@ struct wm_device_backend {
   int (*append_unique_phase2)(const void* targets, int n_target, int n_neighbor, wholememory_dtype_t dtype, void* workspace,
                               void* out_unique, int* mapping, void* stream);
   int (*csr_add_self_loop)(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
+  // out[i, c] = T(float(i)) + in[c] (wholememory_env_test_op)
+  int (*env_test_fill)(const void* in, void* out, wholememory_dtype_t dtype, int64_t dim, int64_t entries, int64_t stride,
+                       void* stream);
   // ---- embedding row cache (kernels/cache.hip); nullptr in a backend that does not provide it ----
   // unique_rows / run_starts / n_unique_dev: output of dedup_ids on the batch's ids (full-width keys); adds the batch to
   // the access counters and replaces least-frequently-used residents by more frequently used missing rows

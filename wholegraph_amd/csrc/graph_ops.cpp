@@ -12,6 +12,7 @@
 
 #include <wholememory/graph_op.h>
 #include <wholememory/wholegraph_op.h>
+#include <wholememory/wholememory_op.h>
 
 #include "ops_internal.hpp"
 #include "pcg.hpp"
@@ -417,6 +418,49 @@ wholememory_error_code_t csr_add_self_loop(wholememory_tensor_t csr_row_ptr_tens
                               static_cast<int*>(wholememory_tensor_get_data_pointer(output_csr_col_ptr_tensor)),
                               static_cast<int>(row_desc.size - 1), stream));
   WM_BK(bk->stream_sync(stream));
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+// Self-test of the env functions (reference wholememory_op.h:58-79, wholememory_test_op.cu:60-160): computes
+// out[i, :] = T(float(i)) + input[:] into a scratch buffer obtained through p_env_fns->temporary_fns, then copies it to
+// the fixed output tensor and to device / pinned / host outputs allocated through p_env_fns->output_fns for every
+// non-null memory context.
+wholememory_error_code_t wholememory_env_test_op(wholememory_tensor_t input_tensor, wholememory_tensor_t output_fixed_tensor,
+                                                 void* output_variable_device_tensor_handle,
+                                                 void* output_variable_pinned_tensor_handle,
+                                                 void* output_variable_host_tensor_handle, int64_t output_variable_entry_count,
+                                                 wholememory_env_func_t* p_env_fns, void* stream)
+{
+  WM_API_BEGIN
+  const auto* bk = backend();
+  if (bk->env_test_fill == nullptr) return WHOLEMEMORY_NOT_SUPPORTED;
+  if (input_tensor == nullptr || output_fixed_tensor == nullptr || p_env_fns == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  auto in_desc  = *wholememory_tensor_get_tensor_description(input_tensor);
+  auto out_desc = *wholememory_tensor_get_tensor_description(output_fixed_tensor);
+  if (in_desc.dim != 1 || out_desc.dim != 2 || out_desc.sizes[0] != output_variable_entry_count ||
+      out_desc.sizes[1] != in_desc.sizes[0] || in_desc.dtype != out_desc.dtype)
+    return WHOLEMEMORY_INVALID_INPUT;  // the reference aborts on these (WHOLEMEMORY_CHECK_NOTHROW)
+  const int64_t dim = in_desc.sizes[0], n = output_variable_entry_count;
+  temp_mem scratch(p_env_fns);
+  void* tmp = scratch.device(n * dim, in_desc.dtype);
+  int rc    = bk->env_test_fill(wholememory_tensor_get_data_pointer(input_tensor), tmp, in_desc.dtype, dim, n, dim, stream);
+  if (rc == -1) return WHOLEMEMORY_INVALID_INPUT;
+  if (rc != 0) return WHOLEMEMORY_CUDA_ERROR;
+  const size_t bytes = static_cast<size_t>(n) * dim * wholememory_dtype_get_element_size(in_desc.dtype);
+  auto out_alloc = [&](void* ctx, wholememory_memory_allocation_type_t type) -> void* {
+    if (ctx == nullptr) return nullptr;
+    auto d = out_desc;
+    d.strides[0] = dim, d.strides[1] = 1, d.storage_offset = 0;
+    return p_env_fns->output_fns.malloc_fn(&d, type, ctx, p_env_fns->output_fns.global_context);
+  };
+  void* dsts[4] = {wholememory_tensor_get_data_pointer(output_fixed_tensor),
+                   out_alloc(output_variable_device_tensor_handle, WHOLEMEMORY_MA_DEVICE),
+                   out_alloc(output_variable_pinned_tensor_handle, WHOLEMEMORY_MA_PINNED),
+                   out_alloc(output_variable_host_tensor_handle, WHOLEMEMORY_MA_HOST)};
+  for (void* dst : dsts)
+    if (dst != nullptr && bytes > 0) WM_BK(bk->memcpy_async(dst, tmp, bytes, stream));
+  WM_BK(bk->stream_sync(stream));  // the scratch buffer returns to the caller's allocator
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
 }

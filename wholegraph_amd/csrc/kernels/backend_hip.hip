@@ -37,6 +37,7 @@ int hip_append_unique_phase2(const void* targets, int nt, int nn, wholememory_dt
                              int* mapping, void* stream);
 int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
 
+int hip_env_test_fill(const void* in, void* out, wholememory_dtype_t dt, int64_t dim, int64_t entries, int64_t stride, void* stream);
 int hip_cache_update(const wm_cache_args* c, const void* unique_rows, wholememory_dtype_t dt, const int32_t* run_starts,
                      const int64_t* n_unique_dev, int64_t n_upper, void* stream);
 int hip_cache_split(const wm_cache_args* c, const void* ids, wholememory_dtype_t dt, int64_t n, int64_t* cache_idx, void* raw_idx,
@@ -157,6 +158,7 @@ const wm_device_backend kHipBackend = {
   hip_append_unique_phase1,
   hip_append_unique_phase2,
   hip_csr_add_self_loop,
+  hip_env_test_fill,
   hip_cache_update,
   hip_cache_split,
   hip_cache_writeback,

@@ -536,7 +536,37 @@ __global__ void add_self_loop_kernel(const int* row_ptr, const int* col, int* ou
   for (int k = threadIdx.x; k <= e - s; k += blockDim.x) out_col[s + row + k] = k == 0 ? row : col[s + k - 1];
 }
 
+// out[i, c] = T(float(i)) + in[c]: the arithmetic of the env-function self-test op (wholememory_test_op.cu:25-37)
+template <typename T>
+__global__ void env_test_kernel(const T* in, T* out, int64_t dim, int64_t stride)
+{
+  const int id = blockIdx.x;
+  const float f_id = static_cast<float>(id);
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) out[stride * id + c] = static_cast<T>(static_cast<T>(f_id) + in[c]);
+}
+
 }  // namespace
+
+int hip_env_test_fill(const void* in, void* out, wholememory_dtype_t dt, int64_t dim, int64_t entries, int64_t stride, void* stream_v)
+{
+  if (entries == 0 || dim == 0) return 0;
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const int threads  = static_cast<int>(std::min<int64_t>(dim, 512));
+#define WM_ENV_TEST(T) \
+  hipLaunchKernelGGL((env_test_kernel<T>), dim3(entries), dim3(threads), 0, stream, static_cast<const T*>(in), static_cast<T*>(out), dim, stride)
+  switch (dt) {
+    case WHOLEMEMORY_DT_FLOAT: WM_ENV_TEST(float); break;
+    case WHOLEMEMORY_DT_DOUBLE: WM_ENV_TEST(double); break;
+    case WHOLEMEMORY_DT_HALF: WM_ENV_TEST(_Float16); break;
+    case WHOLEMEMORY_DT_INT8: WM_ENV_TEST(int8_t); break;
+    case WHOLEMEMORY_DT_INT16: WM_ENV_TEST(int16_t); break;
+    case WHOLEMEMORY_DT_INT: WM_ENV_TEST(int32_t); break;
+    case WHOLEMEMORY_DT_INT64: WM_ENV_TEST(int64_t); break;
+    default: return -1;
+  }
+#undef WM_ENV_TEST
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 // ---- launchers exported to backend_hip ----
 int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const int64_t* row_pairs, const void* centers,
