@@ -384,6 +384,10 @@ def main():
         scenario_sampling(comm, rank, world, "continuous", np.int64)
         scenario_sampling(comm, rank, world, "distributed", np.int64, loc="cpu")
     scenario_file_io(comm, rank, world, "/tmp/wgamd_test_%s" % port)
+    # the same with the loader's threads forced on and a chunk of a single row (WG_LOAD_* as in the reference)
+    os.environ["WG_LOAD_THREADS_PER_RANK"] = "3"
+    scenario_file_io(comm, rank, world, "/tmp/wgamd_test_t_%s" % port)
+    del os.environ["WG_LOAD_THREADS_PER_RANK"]
     # (5) gradient apply, all optimizers
     for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}),
                          ("adam", {"adam_w": 1.0, "weight_decay": 0.02}), ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]:

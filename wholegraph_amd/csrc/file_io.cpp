@@ -3,11 +3,17 @@
 // (load_file_to_handle) and :2059 (store_handle_to_file). Buffered readers only: every rank reads exactly
 // the file bytes that land in its own shard (files are logically concatenated and may be re-sharded: any
 // number of files, any sizes; entries of file_entry_size bytes are placed at memory_entry_size strides),
-// with plain or round-robin placement, and stores its own shard. The reference's O_DIRECT and multi-threaded
-// variants of the same readers (WG_LOAD_USE_DIRECTIO, WG_LOAD_THREADS_PER_RANK) are not built.
+// with plain or round-robin placement, and stores its own shard. Reads are multi-threaded (WG_LOAD_THREADS_PER_RANK,
+// WG_LOAD_BUFFER_SIZE_MB as in the reference) through pinned double buffers; the O_DIRECT variant
+// (WG_LOAD_USE_DIRECTIO) is not built.
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include <wholememory/wholememory.h>
@@ -66,29 +72,69 @@ wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
   const size_t local_first = local_offset / memory_entry_size;
   const size_t local_rows  = local_size / memory_entry_size;
 
-  // rows are assembled at memory stride in a host staging buffer (pre-filled from the shard, so padding,
-  // neighbouring columns and rows without a file entry are preserved) and copied back chunk by chunk
-  constexpr size_t kChunkRows = 1 << 14;
-  std::vector<char> staging(kChunkRows * memory_entry_size);
-  std::vector<FILE*> fps(file_count, nullptr);
-  auto close_all = [&]() {
-    for (auto* f : fps)
-      if (f) fclose(f);
+  // Rows are assembled at memory stride in PINNED staging buffers and copied to the shard chunk by chunk; two buffers
+  // alternate so that the copy of one chunk overlaps the reads of the next. A chunk that the files do not fully
+  // overwrite (padding columns, a column offset, rows without a file entry) is pre-filled from the shard first, so
+  // whatever the files do not cover is preserved. The reads of a chunk are split over WG_LOAD_THREADS_PER_RANK threads
+  // (reference file_io.cpp:1954; default 8, capped by the chunk's rows) using pread on shared descriptors.
+  const size_t chunk_bytes_target = [] {
+    const char* e = getenv("WG_LOAD_BUFFER_SIZE_MB");  // reference file_io.cpp:1975
+    const long mb = e != nullptr ? atol(e) : 32;
+    return static_cast<size_t>(std::max<long>(mb, 1)) << 20;
+  }();
+  const size_t kChunkRows = std::max<size_t>(1, chunk_bytes_target / memory_entry_size);
+  int n_threads             = 8;
+  size_t min_rows_per_thread = 1024;  // below that a thread is not worth starting — unless the caller asked for threads
+  if (const char* e = getenv("WG_LOAD_THREADS_PER_RANK")) {
+    n_threads           = std::max(1, atoi(e));
+    min_rows_per_thread = 1;
+  }
+  char* staging[2] = {nullptr, nullptr};
+  std::vector<int> fds(file_count, -1);
+  auto cleanup = [&]() {
+    for (int fd : fds)
+      if (fd >= 0) close(fd);
+    for (char* p : staging)
+      if (p != nullptr) bk->free_pinned(p);
   };
-  // logical file entries [e0, e1) -> staging rows starting at `row`
-  auto read_entries = [&](size_t e0, size_t e1, size_t row) -> bool {
+  for (auto& p : staging) {
+    void* v = nullptr;
+    if (bk->malloc_pinned(&v, kChunkRows * memory_entry_size) != 0) {
+      cleanup();
+      return WHOLEMEMORY_OUT_OF_MEMORY;
+    }
+    p = static_cast<char*>(v);
+  }
+  for (int f = 0; f < file_count; f++) {
+    if ((fds[f] = open(file_names[f], O_RDONLY)) < 0) {
+      WM_ERROR("input_file[%d] %s cannot be opened for read.", f, file_names[f]);
+      cleanup();
+      return WHOLEMEMORY_INVALID_INPUT;
+    }
+  }
+  auto pread_all = [](int fd, char* dst, size_t bytes, off_t off) -> bool {
+    while (bytes > 0) {
+      const ssize_t got = pread(fd, dst, bytes, off);
+      if (got <= 0) return false;
+      dst += got, off += got, bytes -= static_cast<size_t>(got);
+    }
+    return true;
+  };
+  // logical file entries [e0, e1) -> rows of `buf` starting at `row` (thread-safe: pread, no shared cursor)
+  auto read_entries = [&](char* buf, size_t e0, size_t e1, size_t row) -> bool {
     int f = 0;
     while (e0 < e1) {
       while (f < file_count && e0 >= file_first[f + 1]) f++;
       if (f >= file_count) return false;
-      if (fps[f] == nullptr && (fps[f] = fopen(file_names[f], "rb")) == nullptr) return false;
-      const size_t n = std::min(e1, file_first[f + 1]) - e0;
-      if (fseeko(fps[f], static_cast<off_t>((e0 - file_first[f]) * file_entry_size), SEEK_SET) != 0) return false;
+      const size_t n  = std::min(e1, file_first[f + 1]) - e0;
+      const off_t off = static_cast<off_t>((e0 - file_first[f]) * file_entry_size);
       if (file_entry_size == memory_entry_size) {
-        if (fread(staging.data() + row * memory_entry_size, file_entry_size, n, fps[f]) != n) return false;
+        if (!pread_all(fds[f], buf + row * memory_entry_size, n * file_entry_size, off)) return false;
       } else {
         for (size_t i = 0; i < n; i++)
-          if (fread(staging.data() + (row + i) * memory_entry_size + memory_offset, file_entry_size, 1, fps[f]) != 1) return false;
+          if (!pread_all(fds[f], buf + (row + i) * memory_entry_size + memory_offset, file_entry_size,
+                         off + static_cast<off_t>(i * file_entry_size)))
+            return false;
       }
       e0 += n;
       row += n;
@@ -97,47 +143,70 @@ wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
   };
   const size_t W = static_cast<size_t>(comm->world_size), rank = static_cast<size_t>(comm->world_rank);
   const size_t rr = static_cast<size_t>(round_robin_size);
-  for (size_t c = 0; c < local_rows; c += kChunkRows) {
+  // file entries of local rows [l0, l1) of a chunk that starts at local row c: returns false on I/O error
+  auto read_rows = [&](char* buf, size_t c, size_t l0, size_t l1) -> bool {
+    if (rr == 0) {
+      const size_t e0 = local_first + l0, e1 = std::min(local_first + l1, total_entries);
+      return e0 >= e1 || read_entries(buf, e0, e1, l0 - c);
+    }
+    // round-robin placement (the inverse of map_indices_func.cu:34-43): local row l of rank r holds file entry
+    // ((l / rr) * W + r) * rr + l % rr; rows past the end of the files are left as they are
+    for (size_t l = l0; l < l1;) {
+      const size_t run_end = std::min(l1, (l / rr + 1) * rr);
+      const size_t e0      = ((l / rr) * W + rank) * rr + l % rr;
+      const size_t e1      = std::min(e0 + (run_end - l), total_entries);
+      if (e0 < e1 && !read_entries(buf, e0, e1, l - c)) return false;
+      l = run_end;
+    }
+    return true;
+  };
+  // does the chunk [c, c + n) receive a file entry in EVERY byte of every row?
+  auto fully_overwritten = [&](size_t c, size_t n) {
+    if (file_entry_size != memory_entry_size || memory_offset != 0) return false;
+    if (rr == 0) return local_first + c + n <= total_entries;
+    for (size_t l = c; l < c + n; l = (l / rr + 1) * rr) {
+      const size_t run_end = std::min(c + n, (l / rr + 1) * rr);
+      if (((l / rr) * W + rank) * rr + l % rr + (run_end - l) > total_entries) return false;
+    }
+    return true;
+  };
+  bool in_flight[2] = {false, false};
+  bool failed_io = false, failed_dev = false;
+  int which = 0;
+  for (size_t c = 0; c < local_rows && !failed_io && !failed_dev; c += kChunkRows, which ^= 1) {
     const size_t n = std::min(kChunkRows, local_rows - c);
     char* dst      = static_cast<char*>(local_ptr) + c * memory_entry_size;
-    if (bk->memcpy_async(staging.data(), dst, n * memory_entry_size, nullptr) != 0 || bk->stream_sync(nullptr) != 0) {
-      close_all();
-      return WHOLEMEMORY_CUDA_ERROR;
+    char* buf      = staging[which];
+    // this buffer's previous copy (two chunks ago) must have left it; copies are issued on the null stream in order
+    if (in_flight[which] || !fully_overwritten(c, n)) {
+      if (bk->stream_sync(nullptr) != 0) failed_dev = true;
+      in_flight[0] = in_flight[1] = false;
     }
-    bool touched = false;
-    if (rr == 0) {
-      const size_t e0 = local_first + c, e1 = std::min(local_first + c + n, total_entries);
-      if (e0 < e1) {
-        touched = true;
-        if (!read_entries(e0, e1, 0)) {
-          close_all();
-          return WHOLEMEMORY_SYSTEM_ERROR;
-        }
-      }
+    if (!failed_dev && !fully_overwritten(c, n)) {
+      if (bk->memcpy_async(buf, dst, n * memory_entry_size, nullptr) != 0 || bk->stream_sync(nullptr) != 0) failed_dev = true;
+    }
+    if (failed_dev) break;
+    const int T = static_cast<int>(std::min<size_t>(static_cast<size_t>(n_threads), std::max<size_t>(1, n / min_rows_per_thread)));
+    if (T <= 1) {
+      failed_io = !read_rows(buf, c, c, c + n);
     } else {
-      // round-robin placement (the inverse of map_indices_func.cu:34-43): local row l of rank r holds file entry
-      // ((l / rr) * W + r) * rr + l % rr; rows past the end of the files are left as they are
-      for (size_t l = c; l < c + n;) {
-        const size_t run_end = std::min(c + n, (l / rr + 1) * rr);
-        const size_t e0      = ((l / rr) * W + rank) * rr + l % rr;
-        const size_t e1      = std::min(e0 + (run_end - l), total_entries);
-        if (e0 < e1) {
-          touched = true;
-          if (!read_entries(e0, e1, l - c)) {
-            close_all();
-            return WHOLEMEMORY_SYSTEM_ERROR;
-          }
-        }
-        l = run_end;
+      std::vector<std::thread> workers;
+      std::vector<char> ok(T, 1);
+      for (int t = 0; t < T; t++) {
+        const size_t l0 = c + n * t / T, l1 = c + n * (t + 1) / T;
+        workers.emplace_back([&, t, l0, l1] { ok[t] = read_rows(buf, c, l0, l1) ? 1 : 0; });
       }
+      for (auto& w : workers) w.join();
+      for (char o : ok) failed_io |= (o == 0);
     }
-    if (!touched) continue;
-    if (bk->memcpy_async(dst, staging.data(), n * memory_entry_size, nullptr) != 0 || bk->stream_sync(nullptr) != 0) {
-      close_all();
-      return WHOLEMEMORY_CUDA_ERROR;
-    }
+    if (failed_io) break;
+    if (bk->memcpy_async(dst, buf, n * memory_entry_size, nullptr) != 0) failed_dev = true;
+    in_flight[which] = true;
   }
-  close_all();
+  if (bk->stream_sync(nullptr) != 0) failed_dev = true;
+  cleanup();
+  if (failed_io) return WHOLEMEMORY_SYSTEM_ERROR;
+  if (failed_dev) return WHOLEMEMORY_CUDA_ERROR;
   comm->barrier();
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
