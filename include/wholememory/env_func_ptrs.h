@@ -26,15 +26,12 @@ typedef enum wholememory_memory_allocation_type_t wholememory_memory_allocation_
 #endif
 
 /* reference env_func_ptrs.h:43-56: a memory_context is one allocation slot */
-typedef void (*wholememory_create_memory_context_func_t)(void** memory_context,
-                                                         void* global_context);
-typedef void (*wholememory_destroy_memory_context_func_t)(void* memory_context,
-                                                          void* global_context);
-typedef void* (*wholememory_malloc_func_t)(struct wholememory_tensor_description_t* desc,
-                                           enum wholememory_memory_allocation_type_t type,
-                                           void* memory_context,
-                                           void* global_context);
-typedef void (*wholememory_free_func_t)(void* memory_context, void* global_context);
+typedef void (*wholememory_create_memory_context_func_t)(void** slot_out, void* global);
+typedef void (*wholememory_destroy_memory_context_func_t)(void* slot, void* global);
+/* allocates what `shape` describes in the given kind of memory, remembers it in `slot`, returns the data pointer */
+typedef void* (*wholememory_malloc_func_t)(struct wholememory_tensor_description_t* shape,
+                                           enum wholememory_memory_allocation_type_t kind, void* slot, void* global);
+typedef void (*wholememory_free_func_t)(void* slot, void* global);
 
 struct wholememory_temp_memory_func_t { /* reference env_func_ptrs.h:58-64 */
   wholememory_create_memory_context_func_t create_memory_context_fn;

@@ -21,34 +21,26 @@
 extern "C" {
 #endif
 
-enum wholememory_error_code_t wholememory_gather(wholememory_tensor_t wholememory_tensor,
-                                                 wholememory_tensor_t indices_tensor,
-                                                 wholememory_tensor_t output_tensor,
-                                                 struct wholememory_env_func_t* p_env_fns,
-                                                 void* stream,
-                                                 int gather_sms WM_DEFAULT(-1));
+/* output[i, :] = cast(table[indices[i], :]); negative indices leave their output row untouched. `table` is a
+ * WholeMemory tensor of any memory type (DISTRIBUTED: collective) or a plain device tensor; sms caps the grid (-1 =
+ * default). reference wholememory_op.h:36-43 */
+enum wholememory_error_code_t wholememory_gather(wholememory_tensor_t table, wholememory_tensor_t indices,
+                                                 wholememory_tensor_t output, struct wholememory_env_func_t* env,
+                                                 void* stream, int sms WM_DEFAULT(-1));
 
-enum wholememory_error_code_t wholememory_scatter(wholememory_tensor_t input_tensor,
-                                                  wholememory_tensor_t indices_tensor,
-                                                  wholememory_tensor_t wholememory_tensor,
-                                                  struct wholememory_env_func_t* p_env_fns,
-                                                  void* stream,
-                                                  int scatter_sms WM_DEFAULT(-1));
+/* table[indices[i], :] = cast(input[i, :]); overwrite, unordered for duplicate indices. reference :47-54 */
+enum wholememory_error_code_t wholememory_scatter(wholememory_tensor_t input, wholememory_tensor_t indices,
+                                                  wholememory_tensor_t table, struct wholememory_env_func_t* env,
+                                                  void* stream, int sms WM_DEFAULT(-1));
 
 /*
- * Self-test of the env functions: output[i, :] = T(float(i)) + input[:], computed in scratch memory from
- * p_env_fns->temporary_fns, copied to output_fixed_tensor ([output_variable_entry_count, len(input)], dense) and to
- * device / pinned / host tensors allocated through p_env_fns->output_fns for each non-null memory context.
- * reference wholememory_op.h:58-79
+ * Self-test of the env functions: fixed_out[i, :] = T(float(i)) + input[:], computed in scratch memory from
+ * env->temporary_fns, copied to fixed_out ([entries, len(input)], dense) and to device / pinned / host tensors
+ * allocated through env->output_fns for each non-null memory context. reference wholememory_op.h:58-79
  */
-enum wholememory_error_code_t wholememory_env_test_op(wholememory_tensor_t input_tensor,
-                                                      wholememory_tensor_t output_fixed_tensor,
-                                                      void* output_variable_device_tensor_handle,
-                                                      void* output_variable_pinned_tensor_handle,
-                                                      void* output_variable_host_tensor_handle,
-                                                      int64_t output_variable_entry_count,
-                                                      struct wholememory_env_func_t* p_env_fns,
-                                                      void* stream);
+enum wholememory_error_code_t wholememory_env_test_op(wholememory_tensor_t input, wholememory_tensor_t fixed_out,
+                                                      void* device_ctx, void* pinned_ctx, void* host_ctx, int64_t entries,
+                                                      struct wholememory_env_func_t* env, void* stream);
 
 #ifdef __cplusplus
 }
