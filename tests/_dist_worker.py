@@ -248,6 +248,43 @@ def scenario_cached_embedding(comm, rank, world, mt):
     wgth.destroy_embedding(emb)
 
 
+def scenario_local_cache(comm, rank, world, mt):
+    """Every rank keeps its own read-only cache (cache communicator of size 1) of a table spread over all ranks. For a
+    DISTRIBUTED table the cache fills and the misses travel through the collective exchange."""
+    n_rows, dim = 7001, 40
+    local_comm = wgth.create_group_communicator(1)
+    policy = wgth.create_wholememory_cache_policy(local_comm, memory_type="continuous", memory_location="cuda",
+                                                  access_type="readonly", ratio=0.2)
+    emb = wgth.create_embedding(comm, mt, "cuda", torch.float32, [n_rows, dim], cache_policy=policy)
+    stride = emb.get_embedding_tensor().stride()[0]
+    full = oracle.fill_closed_form(np.float32, 0, n_rows, dim, stride)
+    tab = oracle.ShardedTable.from_full(full, world, None)
+    tab.dim = dim
+    local, start = emb.get_embedding_tensor().get_local_tensor()
+    cnt = int(tab.entry_offsets[rank + 1] - tab.entry_offsets[rank])
+    local.copy_(dev(torch.from_numpy(full[start:start + cnt, :dim])))
+    torch.cuda.synchronize()
+    comm.barrier()
+    for step in range(4):
+        rank_idx = []
+        for r in range(world):
+            g = np.random.default_rng(31 * step + r)
+            k = g.zipf(1.3, 2500 + 100 * r).astype(np.uint64)
+            ix = ((k * np.uint64(2654435761)) % np.uint64(n_rows)).astype(np.int64)
+            ix[::41] = -1
+            rank_idx.append(ix)
+        exp = oracle.distributed_gather(tab, rank_idx, np.float32, out_init=[np.full((len(ix), dim), 3, np.float32) for ix in rank_idx])
+        out = dev(torch.full((len(rank_idx[rank]), dim), 3.0))
+        got = emb.gather(dev(torch.from_numpy(rank_idx[rank])), out=out)
+        torch.cuda.synchronize()
+        assert host(got).numpy().tobytes() == exp[rank].tobytes(), "local cache (%s) gather mismatch rank %d step %d" % (mt, rank, step)
+    v = [C.c_int64() for _ in range(5)]
+    wmb.check(wmb.lib().wholememory_ext_embedding_cache_info(emb.wmb_embedding, *[C.byref(x) for x in v]))
+    assert v[1].value > 0 and v[3].value > 0, "cache should hold rows and serve hits: %s" % [x.value for x in v]
+    comm.barrier()
+    wgth.destroy_embedding(emb)
+
+
 def scenario_file_io(comm, rank, world, tmpdir):
     """wholememory_load_from_file / store_to_file through the Python surface: files re-sharded over ranks (3 files of
     uneven size -> W shards), padded rows (file rows are dim wide, memory rows stride wide), round-robin placement,
@@ -396,6 +433,8 @@ def main():
         # (7) device row caches: HOST tables served and trained through per-rank caches
         scenario_cached_embedding(comm, rank, world, "distributed")
         scenario_cached_embedding(comm, rank, world, "chunked")
+        scenario_local_cache(comm, rank, world, "distributed")
+        scenario_local_cache(comm, rank, world, "chunked")
         # (6) extension: SGD on 16-bit tables (fp16 scatter-add = lr -1, wd 0)
         scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0)
         scenario_sgd16(comm, rank, world, torch.bfloat16, 40, 0.05, 0.01)

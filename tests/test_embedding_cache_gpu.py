@@ -80,7 +80,7 @@ def test_device_cache_of_own_shard_readonly(gpu_env, mt, loc, idt):
     wgth.destroy_wholememory_cache_policy(policy)
 
 
-@pytest.mark.parametrize("mt,loc", [("chunked", "cuda"), ("continuous", "cpu")])
+@pytest.mark.parametrize("mt,loc", [("chunked", "cuda"), ("continuous", "cpu"), ("distributed", "cuda")])
 def test_local_cache_of_global_table(gpu_env, mt, loc):
     """cache communicator != embedding communicator: each rank keeps its own read-only cache of the whole table."""
     import torch
@@ -112,7 +112,6 @@ def test_cache_policy_validation(gpu_env):
         (wgth.create_wholememory_cache_policy(gpu_env, memory_type="continuous", memory_location="cuda", access_type="readonly", ratio=0.2), "distributed"),
         (wgth.create_wholememory_cache_policy(other, memory_type="chunked", memory_location="cuda", access_type="readwrite", ratio=0.2), "chunked"),
         (wgth.create_wholememory_cache_policy(other, memory_type="distributed", memory_location="cuda", access_type="readonly", ratio=0.2), "chunked"),
-        (wgth.create_wholememory_cache_policy(other, memory_type="chunked", memory_location="cuda", access_type="readonly", ratio=0.2), "distributed"),
     ]
     for policy, mt in bad:
         with pytest.raises(wmb.WholeMemoryError):

@@ -200,8 +200,12 @@ struct wm_device_backend {
   // ---- embedding row cache (kernels/cache.hip); nullptr in a backend that does not provide it ----
   // unique_rows / run_starts / n_unique_dev: output of dedup_ids on the batch's ids (full-width keys); adds the batch to
   // the access counters and replaces least-frequently-used residents by more frequently used missing rows
+  // fill_rows != nullptr ("plan" mode, read-only caches whose raw table is not addressable from this rank): no row is
+  // moved; each decided (global row, slot) pair is appended to fill_rows / fill_slots (room for n_upper), *fill_count
+  // (device, zeroed by the caller) counts them, and the caller fetches and installs the rows
   int (*cache_update)(const wm_cache_args* c, const void* unique_rows, wholememory_dtype_t index_dtype,
-                      const int32_t* run_starts, const int64_t* n_unique_dev, int64_t n_upper, void* stream);
+                      const int32_t* run_starts, const int64_t* n_unique_dev, int64_t n_upper, int64_t* fill_rows,
+                      int64_t* fill_slots, int* fill_count, void* stream);
   // cache_idx[i] = slot of ids[i] or -1; raw_idx[i] = ids[i] if it misses (or is negative) else -1; *hits_dev += hits
   int (*cache_split)(const wm_cache_args* c, const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t* cache_idx,
                      void* raw_idx, unsigned long long* hits_dev, void* stream);

@@ -36,6 +36,7 @@ wholememory_error_code_t create_row_cache(row_cache** out, const wholememory_emb
   c->writable  = policy->access_type == WHOLEMEMORY_AT_READWRITE;
   c->dtype     = desc->dtype;
   c->row_elems = desc->strides[0];
+  c->raw       = raw;
   const size_t es = wholememory_dtype_get_element_size(desc->dtype);
   auto& a         = c->args;
   a.row_bytes     = c->row_elems * static_cast<int64_t>(es);
@@ -50,13 +51,14 @@ wholememory_error_code_t create_row_cache(row_cache** out, const wholememory_emb
     a.raw_gref              = local_shard_gref(h);
   } else {
     // each rank caches rows of the whole table for its own lookups: the raw table must be addressable from here
-    if (wholememory_get_memory_type(h) == WHOLEMEMORY_MT_DISTRIBUTED) {
-      WM_ERROR("a local cache of a DISTRIBUTED raw embedding is not implemented (the rows are not addressable from this rank)");
-      return WHOLEMEMORY_NOT_IMPLEMENTED;
-    }
     a.cover_start = 0;
     a.cover_rows  = desc->sizes[0];
-    WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(raw, &a.raw_gref));
+    if (wholememory_get_memory_type(h) == WHOLEMEMORY_MT_DISTRIBUTED && embedding_comm->world_size > 1) {
+      c->raw_addressable = false;  // rows arrive through the exchange (ops.cpp:gather_cached)
+      a.raw_gref         = wholememory_create_continuous_global_reference(nullptr);
+    } else {
+      WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(raw, &a.raw_gref));
+    }
   }
   if (a.cover_rows >= (INT64_C(1) << 31)) return WHOLEMEMORY_NOT_SUPPORTED;
   // reference embedding_cache.cpp: cache_ratio of the covered rows, in whole sets
@@ -96,9 +98,68 @@ wholememory_error_code_t row_cache_update(row_cache* c, const void* ids, wholeme
   void* d_ws      = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n, index_dtype)), WHOLEMEMORY_DT_INT8);
   int rc = bk->dedup_ids(ids, index_dtype, n, key_upper_bound, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
   if (rc != 0) return rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR;
-  rc = bk->cache_update(&c->args, d_unique, index_dtype, d_starts, d_nunique, n, stream);
+  rc = bk->cache_update(&c->args, d_unique, index_dtype, d_starts, d_nunique, n, nullptr, nullptr, nullptr, stream);
   if (rc != 0) return rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR;
   WM_BK(bk->stream_sync(stream));  // scratch buffers return to the caller's allocator
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t row_cache_plan(row_cache* c, const void* ids, wholememory_dtype_t index_dtype, int64_t n,
+                                        wholememory_env_func_t* env, void* stream, temp_mem* rows_mem, temp_mem* slots_mem,
+                                        int64_t* n_fill)
+{
+  const auto* bk = backend();
+  *n_fill        = 0;
+  auto* fill_rows  = static_cast<int64_t*>(rows_mem->device(n, WHOLEMEMORY_DT_INT64));
+  auto* fill_slots = static_cast<int64_t*>(slots_mem->device(n, WHOLEMEMORY_DT_INT64));
+  if (n == 0 || c->args.n_sets == 0) return WHOLEMEMORY_SUCCESS;
+  if (n >= (INT64_C(1) << 31) || c->writable) return WHOLEMEMORY_INVALID_INPUT;
+  temp_mem unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env), count(env), host_n(env);
+  void* d_unique  = unique_ids.device(n, index_dtype);
+  auto* d_starts  = static_cast<int32_t*>(run_starts.device(n + 1, WHOLEMEMORY_DT_INT));
+  auto* d_order   = static_cast<int32_t*>(order.device(n, WHOLEMEMORY_DT_INT));
+  auto* d_nunique = static_cast<int64_t*>(n_unique.device(1, WHOLEMEMORY_DT_INT64));
+  void* d_ws      = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n, index_dtype)), WHOLEMEMORY_DT_INT8);
+  auto* d_count   = static_cast<int*>(count.device(1, WHOLEMEMORY_DT_INT));
+  WM_BK(bk->memset_async(d_count, 0, sizeof(int), stream));
+  int rc = bk->dedup_ids(ids, index_dtype, n, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
+  if (rc != 0) return rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR;
+  rc = bk->cache_update(&c->args, d_unique, index_dtype, d_starts, d_nunique, n, fill_rows, fill_slots, d_count, stream);
+  if (rc != 0) return rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR;
+  auto* h = static_cast<int*>(host_n.pinned(1, WHOLEMEMORY_DT_INT));
+  WM_BK(bk->memcpy_async(h, d_count, sizeof(int), stream));
+  WM_BK(bk->stream_sync(stream));
+  *n_fill = *h;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t row_cache_install(row_cache* c, const void* rows_data, const int64_t* slots, int64_t n_fill,
+                                           void* stream)
+{
+  const auto* bk = backend();
+  if (n_fill == 0) return WHOLEMEMORY_SUCCESS;
+  wm_rows_args a{};  // scatter of dense rows into the cache lines
+  a.gref          = wholememory_create_continuous_global_reference(c->args.data);
+  a.table_dtype   = c->dtype;
+  a.dim           = c->row_elems;
+  a.table_stride  = c->row_elems;
+  a.indices       = slots;
+  a.index_dtype   = WHOLEMEMORY_DT_INT64;
+  a.n             = n_fill;
+  a.plain         = const_cast<void*>(rows_data);
+  a.plain_dtype   = c->dtype;
+  a.plain_stride  = c->row_elems;
+  a.max_blocks    = -1;
+  WM_BK(bk->scatter_rows(&a, stream));
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t row_cache_split(row_cache* c, const void* ids, wholememory_dtype_t index_dtype, int64_t n,
+                                         int64_t* cache_idx, void* raw_idx, void* stream)
+{
+  int rc = backend()->cache_split(&c->args, ids, index_dtype, n, cache_idx, raw_idx, c->counters_dev, stream);
+  if (rc != 0) return rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR;
+  c->lookups += n;
   return WHOLEMEMORY_SUCCESS;
 }
 
@@ -109,9 +170,7 @@ wholememory_error_code_t row_cache_gather(row_cache* c, const wm_rows_args& a, w
   temp_mem cache_idx_mem(env), raw_idx_mem(env);
   auto* cache_idx = static_cast<int64_t*>(cache_idx_mem.device(a.n, WHOLEMEMORY_DT_INT64));
   void* raw_idx   = raw_idx_mem.device(a.n, a.index_dtype);
-  int rc = bk->cache_split(&c->args, a.indices, a.index_dtype, a.n, cache_idx, raw_idx, c->counters_dev, stream);
-  if (rc != 0) return rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR;
-  c->lookups += a.n;
+  WHOLEMEMORY_RETURN_ON_FAIL(row_cache_split(c, a.indices, a.index_dtype, a.n, cache_idx, raw_idx, stream));
   // hits: out of the cache lines (a dense [slots, row_elems] table of the raw dtype)
   wm_rows_args hit        = a;
   hit.gref                = wholememory_create_continuous_global_reference(c->args.data);

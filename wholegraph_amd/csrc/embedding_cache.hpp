@@ -24,6 +24,9 @@ struct row_cache {
                            // (reference device_cached_host_embedding); otherwise each rank caches any row of the global
                            // table for its own lookups, read-only (reference local_cached_global_readonly_embedding)
   bool writable  = false;
+  bool raw_addressable = true;  // false: the raw table is DISTRIBUTED and this is a local cache of it — rows are fetched
+                                // through the exchange (collectively) and only then installed
+  wholememory_tensor_t raw = nullptr;  // the embedding's padded table (borrowed)
   wholememory_dtype_t dtype = WHOLEMEMORY_DT_UNKNOWN;
   int64_t row_elems         = 0;  // elements per cache line (= padded row)
   unsigned long long* counters_dev = nullptr;  // [0] hits, [1..2] scratch of cache_info
@@ -43,6 +46,19 @@ wholememory_error_code_t row_cache_update(row_cache* c, const void* ids, wholeme
 // out rows of `ids` from the cache where resident, from the raw table (through `raw_gref`, GLOBAL row ids) otherwise;
 // a: rows args prepared for the RAW table (indices, row_map, plain side, dtypes) — see ops.cpp:fill_rows_args
 wholememory_error_code_t row_cache_gather(row_cache* c, const wm_rows_args& a, wholememory_env_func_t* env, void* stream);
+
+// plan mode of row_cache_update (raw table not addressable): counts the batch, decides the replacements and returns
+// them as device lists (global rows / cache slots, *n_fill of them) WITHOUT moving data; the caller fetches the rows and
+// calls row_cache_install. The lists live in `rows_mem` / `slots_mem`.
+wholememory_error_code_t row_cache_plan(row_cache* c, const void* ids, wholememory_dtype_t index_dtype, int64_t n,
+                                        wholememory_env_func_t* env, void* stream, temp_mem* rows_mem, temp_mem* slots_mem,
+                                        int64_t* n_fill);
+// cache_line[slots[k]] = rows_data[k] for k < n_fill (rows_data: dense [n_fill, row_elems] of the raw dtype)
+wholememory_error_code_t row_cache_install(row_cache* c, const void* rows_data, const int64_t* slots, int64_t n_fill,
+                                           void* stream);
+// the two index lists of a lookup (see wm_device_backend::cache_split); counts the lookups
+wholememory_error_code_t row_cache_split(row_cache* c, const void* ids, wholememory_dtype_t index_dtype, int64_t n,
+                                         int64_t* cache_idx, void* raw_idx, void* stream);
 
 wholememory_error_code_t row_cache_writeback(row_cache* c, bool drop, void* stream);
 wholememory_error_code_t row_cache_info(row_cache* c, int64_t* slots, int64_t* occupied, int64_t* dirty, int64_t* hits,

@@ -39,7 +39,8 @@ int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int*
 
 int hip_env_test_fill(const void* in, void* out, wholememory_dtype_t dt, int64_t dim, int64_t entries, int64_t stride, void* stream);
 int hip_cache_update(const wm_cache_args* c, const void* unique_rows, wholememory_dtype_t dt, const int32_t* run_starts,
-                     const int64_t* n_unique_dev, int64_t n_upper, void* stream);
+                     const int64_t* n_unique_dev, int64_t n_upper, int64_t* fill_rows, int64_t* fill_slots, int* fill_count,
+                     void* stream);
 int hip_cache_split(const wm_cache_args* c, const void* ids, wholememory_dtype_t dt, int64_t n, int64_t* cache_idx, void* raw_idx,
                     unsigned long long* hits_dev, void* stream);
 int hip_cache_writeback(const wm_cache_args* c, int drop, void* stream);

@@ -107,9 +107,17 @@ __global__ void cache_count_kernel(cache_dev c, const IdxT* unique_rows, const i
 }
 
 // one wave per set: bring in the batch's missing rows that beat the set's least frequently used residents
+// fill list of the PLAN mode (raw table not addressable from this rank, e.g. DISTRIBUTED): the kernel only decides —
+// which row goes into which slot — and the host fetches the rows through the exchange and installs them afterwards
+struct fill_list {
+  int64_t* rows;   // GLOBAL rows to fetch
+  int64_t* slots;  // the cache line each of them goes to
+  int* count;      // device counter
+};
+
 template <typename IdxT>
 __global__ __launch_bounds__(kBlock) void cache_update_kernel(cache_dev c, raw_view raw, const IdxT* unique_rows,
-                                                              const int64_t* n_unique_p)
+                                                              const int64_t* n_unique_p, fill_list fill)
 {
   const int lane    = threadIdx.x & 63;
   const int64_t set = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
@@ -154,10 +162,16 @@ __global__ __launch_bounds__(kBlock) void cache_update_kernel(cache_dev c, raw_v
     char* line          = c.data + vslot * c.row_bytes;
     const int64_t old   = __shfl(my_row, victim, 64);
     if (old >= 0) {
-      if (c.dirty[vslot]) wave_copy_row(raw_row(raw, c.cover_start + old), line, c.row_bytes, lane);
+      if (fill.rows == nullptr && c.dirty[vslot]) wave_copy_row(raw_row(raw, c.cover_start + old), line, c.row_bytes, lane);
       if (lane == 0) c.slot_of[old] = -1;
     }
-    wave_copy_row(line, raw_row(raw, g), c.row_bytes, lane);
+    if (fill.rows == nullptr) {
+      wave_copy_row(line, raw_row(raw, g), c.row_bytes, lane);
+    } else if (lane == 0) {  // plan mode (read-only caches: nothing to write back): record, the host installs
+      const int k   = atomicAdd(fill.count, 1);
+      fill.rows[k]  = g;
+      fill.slots[k] = vslot;
+    }
     if (lane == 0) {
       c.slot_of[r]    = static_cast<int32_t>(vslot);
       c.row_of[vslot] = r;
@@ -226,8 +240,10 @@ __global__ void cache_info_kernel(cache_dev c, unsigned long long* out)
 }  // namespace
 
 int hip_cache_update(const wm_cache_args* c, const void* unique_rows, wholememory_dtype_t dt, const int32_t* run_starts,
-                     const int64_t* n_unique_dev, int64_t n_upper, void* stream_v)
+                     const int64_t* n_unique_dev, int64_t n_upper, int64_t* fill_rows, int64_t* fill_slots, int* fill_count,
+                     void* stream_v)
 {
+  const fill_list fill{fill_rows, fill_slots, fill_count};
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (n_upper == 0 || c->n_sets == 0) return 0;
   const cache_dev d = make_dev(*c);
@@ -236,10 +252,10 @@ int hip_cache_update(const wm_cache_args* c, const void* unique_rows, wholememor
   const int ub      = static_cast<int>((c->n_sets * 64 + kBlock - 1) / kBlock);
   if (dt == WHOLEMEMORY_DT_INT) {
     hipLaunchKernelGGL((cache_count_kernel<int32_t>), dim3(cb), dim3(kBlock), 0, stream, d, static_cast<const int32_t*>(unique_rows), run_starts, n_unique_dev);
-    hipLaunchKernelGGL((cache_update_kernel<int32_t>), dim3(ub), dim3(kBlock), 0, stream, d, rv, static_cast<const int32_t*>(unique_rows), n_unique_dev);
+    hipLaunchKernelGGL((cache_update_kernel<int32_t>), dim3(ub), dim3(kBlock), 0, stream, d, rv, static_cast<const int32_t*>(unique_rows), n_unique_dev, fill);
   } else if (dt == WHOLEMEMORY_DT_INT64) {
     hipLaunchKernelGGL((cache_count_kernel<int64_t>), dim3(cb), dim3(kBlock), 0, stream, d, static_cast<const int64_t*>(unique_rows), run_starts, n_unique_dev);
-    hipLaunchKernelGGL((cache_update_kernel<int64_t>), dim3(ub), dim3(kBlock), 0, stream, d, rv, static_cast<const int64_t*>(unique_rows), n_unique_dev);
+    hipLaunchKernelGGL((cache_update_kernel<int64_t>), dim3(ub), dim3(kBlock), 0, stream, d, rv, static_cast<const int64_t*>(unique_rows), n_unique_dev, fill);
   } else {
     return -1;
   }

@@ -518,13 +518,54 @@ wholememory_error_code_t gather_cached(wholememory_tensor_t table, wholememory_t
   auto handle = wholememory_tensor_get_memory_handle(table);
   if (cache->same_comm)  // owners serve their shard (cache first), rows travel by all-to-all-v — for every memory type
     return gather_distributed_rows(handle, d, env, stream, gather_sms, cache, adjust_cache);
-  // local read-only cache of a table that is addressable from here
-  if (adjust_cache)
-    WHOLEMEMORY_RETURN_ON_FAIL(row_cache_update(cache, d.indices_ptr, d.indices.dtype, d.indices.size, 0, env, stream));
-  wm_rows_args a{};
-  fill_rows_args(&a, cache->args.raw_gref, d.table, d.indices_ptr, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain,
-                 gather_sms);
-  return row_cache_gather(cache, a, env, stream);
+  if (cache->raw_addressable) {  // local read-only cache of a table that is addressable from here
+    if (adjust_cache)
+      WHOLEMEMORY_RETURN_ON_FAIL(row_cache_update(cache, d.indices_ptr, d.indices.dtype, d.indices.size, 0, env, stream));
+    wm_rows_args a{};
+    fill_rows_args(&a, cache->args.raw_gref, d.table, d.indices_ptr, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain,
+                   gather_sms);
+    return row_cache_gather(cache, a, env, stream);
+  }
+  // local read-only cache of a DISTRIBUTED table (reference local_cached_global_readonly_embedding over NCCL,
+  // embedding.cpp:762-892): rows only reach this rank through the exchange, so every step that touches the raw table is
+  // a collective distributed gather — the fill of newly chosen cache lines and the lookups that miss. Every rank of the
+  // embedding's communicator calls this together (as for any gather of a DISTRIBUTED embedding), even with nothing to do.
+  const auto* bk     = backend();
+  const int64_t n    = d.indices.size;
+  const int64_t dim  = d.table.sizes[1];
+  if (adjust_cache) {
+    temp_mem rows_mem(env), slots_mem(env), staging(env);
+    int64_t n_fill = 0;
+    WHOLEMEMORY_RETURN_ON_FAIL(row_cache_plan(cache, d.indices_ptr, d.indices.dtype, n, env, stream, &rows_mem, &slots_mem, &n_fill));
+    char* rows_data = static_cast<char*>(staging.device(n_fill * cache->row_elems, d.table.dtype));
+    op_descs df     = d;
+    df.indices_ptr  = rows_mem.get();
+    df.indices      = wholememory_create_array_desc(n_fill, 0, WHOLEMEMORY_DT_INT64);
+    df.plain_ptr    = rows_data;
+    int64_t fsz[2]  = {n_fill, dim};
+    df.plain        = wholememory_create_matrix_desc(fsz, cache->row_elems, 0, d.table.dtype);
+    WHOLEMEMORY_RETURN_ON_FAIL(gather_distributed_rows(handle, df, env, stream, gather_sms));
+    WHOLEMEMORY_RETURN_ON_FAIL(row_cache_install(cache, rows_data, static_cast<const int64_t*>(slots_mem.get()), n_fill, stream));
+    WM_BK(bk->stream_sync(stream));
+  }
+  temp_mem cache_idx_mem(env), raw_idx_mem(env);
+  auto* cache_idx = static_cast<int64_t*>(cache_idx_mem.device(n, WHOLEMEMORY_DT_INT64));
+  void* raw_idx   = raw_idx_mem.device(n, d.indices.dtype);
+  WHOLEMEMORY_RETURN_ON_FAIL(row_cache_split(cache, d.indices_ptr, d.indices.dtype, n, cache_idx, raw_idx, stream));
+  if (n > 0) {  // hits: out of the cache lines
+    wm_rows_args hit{};
+    fill_rows_args(&hit, wholememory_create_continuous_global_reference(cache->args.data), d.table, cache_idx,
+                   WHOLEMEMORY_DT_INT64, n, d.plain_ptr, d.plain, gather_sms);
+    hit.table_stride         = cache->row_elems;
+    hit.table_storage_offset = 0;
+    WM_BK(bk->gather_rows(&hit, stream));
+  }
+  op_descs dm    = d;  // misses (hits and negative ids are -1 in raw_idx and skipped): through the exchange
+  dm.indices_ptr = raw_idx;
+  dm.indices.storage_offset = 0;
+  WHOLEMEMORY_RETURN_ON_FAIL(gather_distributed(handle, dm, env, stream, gather_sms));
+  WM_BK(bk->stream_sync(stream));
+  return WHOLEMEMORY_SUCCESS;
 }
 
 namespace {
