@@ -243,6 +243,8 @@ def scenario_cached_embedding(comm, rank, world, mt):
     emb.writeback_all_cache()
     comm.barrier()
     assert local.numpy().tobytes() == tab.shards[rank][:cnt, :dim].tobytes(), "table after write-back, rank %d" % rank
+    m_local, _ = emb.get_optimizer_state("m").get_local_tensor(host_view=True)
+    assert m_local.numpy().tobytes() == ref_opts[rank].per_element[:cnt, :dim].tobytes(), "state m after write-back"
     comm.barrier()
     wgth.destroy_wholememory_optimizer(opt)
     wgth.destroy_embedding(emb)

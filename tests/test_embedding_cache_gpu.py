@@ -160,9 +160,16 @@ def test_readwrite_cache_training_and_writeback(gpu_env, mt, kind, params):
     assert info["dirty"] > 0 and info["occupied"] >= info["dirty"]
     torch.cuda.synchronize()
     assert local.numpy().tobytes() != tab.shards[0].tobytes(), "raw table should lag behind the modified cache lines"
+    if kind == "adam":   # the per-element states of resident rows live in the cache too and lag in the raw state table
+        m_local, _ = emb.get_optimizer_state("m").get_local_tensor(host_view=True)
+        assert m_local.numpy().tobytes() != ref_opt.per_element[:, :dim].tobytes()
     emb.writeback_all_cache()
     assert _info(emb)["dirty"] == 0
     assert local.numpy().tobytes() == tab.shards[0].tobytes(), "raw table after write-back differs from the oracle"
+    if kind == "adam":
+        v_local, _ = emb.get_optimizer_state("v").get_local_tensor(host_view=True)
+        assert m_local.numpy().tobytes() == ref_opt.per_element[:, :dim].tobytes(), "state m after write-back"
+        assert v_local.numpy().tobytes() == ref_opt.per_element[:, dim:2 * dim].tobytes(), "state v after write-back"
     emb.drop_all_cache()
     assert _info(emb)["occupied"] == 0
     probe = rng.integers(0, n_rows, 4000)

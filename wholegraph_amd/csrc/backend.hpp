@@ -73,6 +73,8 @@ struct wm_optimizer_args {
   void* cache_data;
   uint8_t* cache_dirty;
   int64_t cache_row_elems;
+  float* cache_state_data;       // companion lines of per_element_state (same slots) or nullptr
+  int64_t cache_state_row_elems;
   void* local_table;           // this rank's first row
   int64_t table_stride;        // elements
   int64_t local_entry_offset;  // global id of local row 0
@@ -123,6 +125,12 @@ struct wm_cache_args {
   wholememory_gref_t raw_gref;  // the raw table, addressed by GLOBAL row
   int64_t raw_row_stride_bytes;
   int64_t raw_row_offset_bytes;
+  // optional companion table that shares the slots (the packed per-element optimizer states of the same rows): its
+  // lines move in and out together with the embedding's
+  char* data2;                   // [64 * n_sets, row_bytes2] or nullptr
+  int64_t row_bytes2;
+  wholememory_gref_t raw2_gref;  // addressed by GLOBAL row like raw_gref
+  int64_t raw2_row_stride_bytes;
 };
 
 struct wm_device_backend {

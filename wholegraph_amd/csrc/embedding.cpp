@@ -137,6 +137,9 @@ wholememory_error_code_t create_states(wholememory_embedding_* e)
     auto* ld = wholememory_tensor_get_tensor_description(e->state_local);
     WM_BK(bk->memset_async(wholememory_tensor_get_data_pointer(e->state_local), 0,
                            static_cast<size_t>(ld->sizes[0]) * ld->strides[0] * sizeof(float), nullptr));
+    WM_BK(bk->stream_sync(nullptr));
+    // a read-write device cache also holds the states of its resident rows (reference: cachable optimizer states)
+    if (e->cache != nullptr && e->cache->writable) WHOLEMEMORY_RETURN_ON_FAIL(wm::row_cache_attach_states(e->cache, e->state_local));
   }
   if (opt->type == WHOLEMEMORY_OPT_LAZY_ADAM) {
     // per-row [beta1^t, beta2^t]: DISTRIBUTED device tensor partitioned like the table, init 1.0
@@ -368,7 +371,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   if (e->cache != nullptr) {
     // read-write device cache of this rank's shard (reference: the optimizer kernels work through the cache,
     // embedding_optimizer_func.cu + embedding.cpp:146-323): resident rows are updated in their cache line and marked
-    // modified, the others in the raw table; the optimizer states are not cached in this build
+    // modified, the others in the raw table; the packed per-element states of resident rows live in companion cache lines
     if (adjust_cache)
       WHOLEMEMORY_RETURN_ON_FAIL(wm::row_cache_update(e->cache, recv_ids, iarr.dtype, n_recv,
                                                       static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream));
@@ -376,6 +379,10 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     oa.cache_data      = e->cache->args.data;
     oa.cache_dirty     = e->cache->args.dirty;
     oa.cache_row_elems = e->cache->row_elems;
+    if (e->cache->args.data2 != nullptr) {
+      oa.cache_state_data      = reinterpret_cast<float*>(e->cache->args.data2);
+      oa.cache_state_row_elems = e->cache->args.row_bytes2 / static_cast<int64_t>(sizeof(float));
+    }
   }
   dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa,
                  static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived,

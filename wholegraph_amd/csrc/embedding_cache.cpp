@@ -21,6 +21,7 @@ row_cache::~row_cache()
   if (args.row_of) bk->free_device(args.row_of);
   if (args.dirty) bk->free_device(args.dirty);
   if (args.data) bk->free_device(args.data);
+  if (args.data2) bk->free_device(args.data2);
   if (counters_dev) bk->free_device(counters_dev);
 }
 
@@ -184,6 +185,26 @@ wholememory_error_code_t row_cache_gather(row_cache* c, const wm_rows_args& a, w
   miss.indices      = raw_idx;
   WM_BK(bk->gather_rows(&miss, stream));
   WM_BK(bk->stream_sync(stream));  // the two index lists return to the caller's allocator
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t row_cache_attach_states(row_cache* c, wholememory_tensor_t state_local)
+{
+  const auto* bk = backend();
+  if (!c->same_comm || !c->writable || c->args.data2 != nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  WHOLEMEMORY_RETURN_ON_FAIL(row_cache_writeback(c, true, nullptr));
+  auto* d = wholememory_tensor_get_tensor_description(state_local);
+  if (d->dtype != WHOLEMEMORY_DT_FLOAT || d->dim != 2) return WHOLEMEMORY_INVALID_INPUT;
+  auto& a                 = c->args;
+  a.row_bytes2            = d->strides[0] * static_cast<int64_t>(sizeof(float));
+  a.raw2_row_stride_bytes = a.row_bytes2;
+  if (a.row_bytes2 % 16 != 0) return WHOLEMEMORY_LOGIC_ERROR;
+  // flat base through which GLOBAL row ids address this rank's state shard
+  char* local = static_cast<char*>(wholememory_tensor_get_data_pointer(state_local));
+  a.raw2_gref = wholememory_create_continuous_global_reference(local - a.cover_start * a.row_bytes2);
+  void* p     = nullptr;
+  WM_BK(bk->malloc_device(&p, std::max<size_t>(static_cast<size_t>(a.n_sets) * 64 * a.row_bytes2, 16)));
+  a.data2 = static_cast<char*>(p);
   return WHOLEMEMORY_SUCCESS;
 }
 

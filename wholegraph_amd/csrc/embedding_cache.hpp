@@ -60,6 +60,11 @@ wholememory_error_code_t row_cache_install(row_cache* c, const void* rows_data, 
 wholememory_error_code_t row_cache_split(row_cache* c, const void* ids, wholememory_dtype_t index_dtype, int64_t n,
                                          int64_t* cache_idx, void* raw_idx, void* stream);
 
+// Lets the packed per-element optimizer states of the cached rows share the cache: `state_local` is this rank's shard
+// of the state table ([local rows, state_row_elems] fp32, same row partition as the embedding). The cache is emptied
+// first, so every line that becomes resident afterwards carries its state line with it.
+wholememory_error_code_t row_cache_attach_states(row_cache* c, wholememory_tensor_t state_local);
+
 wholememory_error_code_t row_cache_writeback(row_cache* c, bool drop, void* stream);
 wholememory_error_code_t row_cache_info(row_cache* c, int64_t* slots, int64_t* occupied, int64_t* dirty, int64_t* hits,
                                         int64_t* lookups, void* stream);

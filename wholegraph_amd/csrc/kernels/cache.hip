@@ -36,6 +36,16 @@ struct raw_view {
   int64_t row_offset_bytes;   // storage offset of the raw table view
 };
 
+// the companion table (optimizer states): flat per-rank base addressed by GLOBAL row
+struct raw2_view {
+  char* base;
+  int64_t row_stride_bytes;
+};
+inline raw2_view make_raw2(const wm_cache_args& c)
+{
+  return raw2_view{c.data2 != nullptr ? static_cast<char*>(c.raw2_gref.pointer) : nullptr, c.raw2_row_stride_bytes};
+}
+
 inline raw_view make_raw(const wm_cache_args& c)
 {
   raw_view v{};
@@ -87,12 +97,14 @@ struct cache_dev {
   char* data;
   int64_t cover_start, cover_rows, n_sets, set_cover;
   int row_bytes;
+  char* data2;
+  int row_bytes2;
 };
 
 inline cache_dev make_dev(const wm_cache_args& c)
 {
   return cache_dev{c.slot_of, c.count, c.row_of, c.dirty, c.data, c.cover_start, c.cover_rows, c.n_sets, c.set_cover,
-                   static_cast<int>(c.row_bytes)};
+                   static_cast<int>(c.row_bytes), c.data2, static_cast<int>(c.row_bytes2)};
 }
 
 // counters: count[row] += multiplicity of the row in the batch (unique sorted rows + run starts from dedup_ids)
@@ -116,8 +128,9 @@ struct fill_list {
 };
 
 template <typename IdxT>
-__global__ __launch_bounds__(kBlock) void cache_update_kernel(cache_dev c, raw_view raw, const IdxT* unique_rows,
-                                                              const int64_t* n_unique_p, fill_list fill)
+__global__ __launch_bounds__(kBlock) void cache_update_kernel(cache_dev c, raw_view raw, raw2_view raw2,
+                                                              const IdxT* unique_rows, const int64_t* n_unique_p,
+                                                              fill_list fill)
 {
   const int lane    = threadIdx.x & 63;
   const int64_t set = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
@@ -162,11 +175,17 @@ __global__ __launch_bounds__(kBlock) void cache_update_kernel(cache_dev c, raw_v
     char* line          = c.data + vslot * c.row_bytes;
     const int64_t old   = __shfl(my_row, victim, 64);
     if (old >= 0) {
-      if (fill.rows == nullptr && c.dirty[vslot]) wave_copy_row(raw_row(raw, c.cover_start + old), line, c.row_bytes, lane);
+      if (fill.rows == nullptr && c.dirty[vslot]) {
+        wave_copy_row(raw_row(raw, c.cover_start + old), line, c.row_bytes, lane);
+        if (c.data2 != nullptr)
+          wave_copy_row(raw2.base + (c.cover_start + old) * raw2.row_stride_bytes, c.data2 + vslot * c.row_bytes2, c.row_bytes2, lane);
+      }
       if (lane == 0) c.slot_of[old] = -1;
     }
     if (fill.rows == nullptr) {
       wave_copy_row(line, raw_row(raw, g), c.row_bytes, lane);
+      if (c.data2 != nullptr)
+        wave_copy_row(c.data2 + vslot * c.row_bytes2, raw2.base + g * raw2.row_stride_bytes, c.row_bytes2, lane);
     } else if (lane == 0) {  // plan mode (read-only caches: nothing to write back): record, the host installs
       const int k   = atomicAdd(fill.count, 1);
       fill.rows[k]  = g;
@@ -208,14 +227,18 @@ __global__ void cache_split_kernel(cache_dev c, const IdxT* ids, int64_t n, int6
 }
 
 // write modified lines back to the raw table; with `drop` also empty the cache and clear the counters
-__global__ __launch_bounds__(kBlock) void cache_writeback_kernel(cache_dev c, raw_view raw, int drop)
+__global__ __launch_bounds__(kBlock) void cache_writeback_kernel(cache_dev c, raw_view raw, raw2_view raw2, int drop)
 {
   const int lane     = threadIdx.x & 63;
   const int64_t slot = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
   if (slot >= c.n_sets * 64) return;
   const int64_t r = c.row_of[slot];
   if (r < 0) return;
-  if (c.dirty[slot]) wave_copy_row(raw_row(raw, c.cover_start + r), c.data + slot * c.row_bytes, c.row_bytes, lane);
+  if (c.dirty[slot]) {
+    wave_copy_row(raw_row(raw, c.cover_start + r), c.data + slot * c.row_bytes, c.row_bytes, lane);
+    if (c.data2 != nullptr)
+      wave_copy_row(raw2.base + (c.cover_start + r) * raw2.row_stride_bytes, c.data2 + slot * c.row_bytes2, c.row_bytes2, lane);
+  }
   if (lane == 0) {
     c.dirty[slot] = 0;
     if (drop) {
@@ -252,10 +275,10 @@ int hip_cache_update(const wm_cache_args* c, const void* unique_rows, wholememor
   const int ub      = static_cast<int>((c->n_sets * 64 + kBlock - 1) / kBlock);
   if (dt == WHOLEMEMORY_DT_INT) {
     hipLaunchKernelGGL((cache_count_kernel<int32_t>), dim3(cb), dim3(kBlock), 0, stream, d, static_cast<const int32_t*>(unique_rows), run_starts, n_unique_dev);
-    hipLaunchKernelGGL((cache_update_kernel<int32_t>), dim3(ub), dim3(kBlock), 0, stream, d, rv, static_cast<const int32_t*>(unique_rows), n_unique_dev, fill);
+    hipLaunchKernelGGL((cache_update_kernel<int32_t>), dim3(ub), dim3(kBlock), 0, stream, d, rv, make_raw2(*c), static_cast<const int32_t*>(unique_rows), n_unique_dev, fill);
   } else if (dt == WHOLEMEMORY_DT_INT64) {
     hipLaunchKernelGGL((cache_count_kernel<int64_t>), dim3(cb), dim3(kBlock), 0, stream, d, static_cast<const int64_t*>(unique_rows), run_starts, n_unique_dev);
-    hipLaunchKernelGGL((cache_update_kernel<int64_t>), dim3(ub), dim3(kBlock), 0, stream, d, rv, static_cast<const int64_t*>(unique_rows), n_unique_dev, fill);
+    hipLaunchKernelGGL((cache_update_kernel<int64_t>), dim3(ub), dim3(kBlock), 0, stream, d, rv, make_raw2(*c), static_cast<const int64_t*>(unique_rows), n_unique_dev, fill);
   } else {
     return -1;
   }
@@ -283,7 +306,7 @@ int hip_cache_writeback(const wm_cache_args* c, int drop, void* stream_v)
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (c->n_sets == 0) return 0;
   const int blocks = static_cast<int>((c->n_sets * 64 * 64 + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(cache_writeback_kernel, dim3(blocks), dim3(kBlock), 0, stream, make_dev(*c), make_raw(*c), drop);
+  hipLaunchKernelGGL(cache_writeback_kernel, dim3(blocks), dim3(kBlock), 0, stream, make_dev(*c), make_raw(*c), make_raw2(*c), drop);
   if (drop && hipMemsetAsync(c->count, 0, sizeof(int32_t) * c->cover_rows, stream) != hipSuccess) return -2;
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

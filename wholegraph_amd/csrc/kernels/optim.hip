@@ -215,15 +215,23 @@ __device__ __forceinline__ int32_t cache_slot(const wm_optimizer_args& a, int64_
   return a.cache_slot_of != nullptr ? a.cache_slot_of[local] : -1;
 }
 
+// per-element optimizer state of row `local`: the companion cache line of its slot when the row is resident in the
+// device row cache (and the states are cached with it), else the state table
+__device__ __forceinline__ float* state_row_at(const wm_optimizer_args& a, int64_t local, int32_t slot)
+{
+  if (a.per_element_state == nullptr) return nullptr;
+  return slot >= 0 && a.cache_state_data != nullptr ? a.cache_state_data + static_cast<int64_t>(slot) * a.cache_state_row_elems
+                                                    : a.per_element_state + local * a.per_element_stride;
+}
+
 template <int OPT, typename T = float>
-__device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, const T* row, int64_t local, int64_t d)
+__device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, const T* row, const float* st, int64_t d)
 {
   opt_elem x;
   x.e  = load_wide<T>(row[d]);
   x.s0 = 0.f;
   x.s1 = 0.f;
   if (OPT != WHOLEMEMORY_OPT_SGD) {
-    const float* st = a.per_element_state + local * a.per_element_stride;
     x.s0            = st[d];
     if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) x.s1 = st[a.table_stride + d];
   }
@@ -231,11 +239,10 @@ __device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, const 
 }
 
 template <int OPT, typename T = float>
-__device__ __forceinline__ void update_elem(const wm_optimizer_args& a, T* row, int64_t local, int64_t d, opt_elem x,
+__device__ __forceinline__ void update_elem(const wm_optimizer_args& a, T* row, float* st, int64_t d, opt_elem x,
                                             float grad_value, float beta1t, float beta2t)
 {
   float embedding_value = x.e;
-  float* st             = OPT != WHOLEMEMORY_OPT_SGD ? a.per_element_state + local * a.per_element_stride : nullptr;
   if (OPT == WHOLEMEMORY_OPT_SGD) {
     grad_value += a.weight_decay * embedding_value;
     embedding_value -= a.lr * grad_value;
@@ -280,8 +287,9 @@ __device__ __forceinline__ void apply_optimizer(const wm_optimizer_args& a, int6
 {
   const int32_t slot = cache_slot(a, local);
   T* row             = table_row_at<T>(a, local, slot);
+  float* st          = state_row_at(a, local, slot);
   if (slot >= 0) a.cache_dirty[slot] = 1;
-  update_elem<OPT, T>(a, row, local, d, load_elem<OPT, T>(a, row, local, d), grad_value, beta1t, beta2t);
+  update_elem<OPT, T>(a, row, st, d, load_elem<OPT, T>(a, row, st, d), grad_value, beta1t, beta2t);
 }
 
 // The work per run is a chain of dependent loads (ids / run_starts -> order -> gradient row; ids -> table row), and the
@@ -374,9 +382,11 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
       }
     }
     T* row[K];
+    float* st[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
       row[k] = table_row_at<T>(a, m_cur.local[k], r_cur.slot[k]);
+      st[k]  = state_row_at(a, m_cur.local[k], r_cur.slot[k]);
       if (live[k] && r_cur.slot[k] >= 0 && lane == 0) a.cache_dirty[r_cur.slot[k]] = 1;
     }
     for (int64_t d = static_cast<int64_t>(lane) * V; d < a.dim; d += 64 * V) {
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
         // first occurrence copied (DedupIndiceAndGradientsKernel); table / state values loaded alongside
         acc[k] = load_vec<T, V>(grad_row<T>(a, r_cur.o0[k]) + d);
 #pragma unroll
-        for (int v = 0; v < V; v++) x[k][v] = load_elem<OPT, T>(a, row[k], m_cur.local[k], d + v);
+        for (int v = 0; v < V; v++) x[k][v] = load_elem<OPT, T>(a, row[k], st[k], d + v);
       }
 #pragma unroll
       for (int k = 0; k < K; k++) {
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
         }
 #pragma unroll
         for (int v = 0; v < V; v++)
-          update_elem<OPT, T>(a, row[k], m_cur.local[k], d + v, x[k][v], acc[k][v], r_cur.beta1t[k], r_cur.beta2t[k]);
+          update_elem<OPT, T>(a, row[k], st[k], d + v, x[k][v], acc[k][v], r_cur.beta1t[k], r_cur.beta2t[k]);
       }
     }
     m_cur = m_nxt;
