@@ -4,7 +4,7 @@
  *
  * Built: unweighted sampling without replacement on every memory type (DISTRIBUTED CSR tensors are read through
  * collective wholememory_gather calls: every rank of the CSR's communicator must take part), weighted sampling
- * (max_sample_count <= 1024, mapped CSR tensors) and the two host random helpers. Weighted sampling of more than 1024
+ * (max_sample_count <= 8192, mapped CSR tensors) and the two host random helpers. Weighted sampling of more than 8192
  * neighbours or on DISTRIBUTED tensors returns WHOLEMEMORY_NOT_IMPLEMENTED.
  * Random streams: see wholegraph_amd/csrc/pcg.hpp (parity with raft unpinned).
  */
@@ -38,7 +38,7 @@ enum wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replaceme
 /*
  * Weighted variant (A-Res: key = log2(u) / weight per neighbour, the `fanout` largest keys win).
  * weights: float32/float64 [n_edges]. Samples of one center node come out key-descending.
- * fanout > 1024 -> WHOLEMEMORY_NOT_IMPLEMENTED. reference wholegraph_op.h:70-82
+ * fanout > 8192 -> WHOLEMEMORY_NOT_IMPLEMENTED. reference wholegraph_op.h:70-82
  */
 enum wholememory_error_code_t wholegraph_csr_weighted_sample_without_replacement(
   wholememory_tensor_t row_ptr, wholememory_tensor_t col_idx, wholememory_tensor_t weights, wholememory_tensor_t centers,

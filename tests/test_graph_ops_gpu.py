@@ -133,8 +133,8 @@ def test_sample_argument_errors(gpu_env):
     with pytest.raises(wmb.WholeMemoryError):   # float ids
         wops.unweighted_sample_without_replacement(wr.handle, wc.handle, centers.float(), 2, 1)
     ww = wrap_torch_tensor(torch.ones(4, device="cuda"))
-    with pytest.raises(wmb.WholeMemoryError) as e:     # the in-LDS weighted selection covers 1..1024
-        wops.weighted_sample_without_replacement(wr.handle, wc.handle, ww.handle, centers, 1025, 1)
+    with pytest.raises(wmb.WholeMemoryError) as e:     # the in-LDS weighted selection covers 1..8192
+        wops.weighted_sample_without_replacement(wr.handle, wc.handle, ww.handle, centers, 8193, 1)
     assert "NOT_IMPLEMENTED" in str(e.value)
     with pytest.raises(wmb.WholeMemoryError):          # integer weights
         wops.weighted_sample_without_replacement(wr.handle, wc.handle, wc.handle, centers, 2, 1)
@@ -163,7 +163,7 @@ def test_weighted_sample_parity(gpu_env, mt, loc, center_dtype, col_dtype, wdtyp
     g.set_edge_attribute("w", wwgt)
     rng = np.random.default_rng(3)
     centers = np.concatenate([np.arange(0, 20), rng.integers(0, 3000, 700)]).astype(center_dtype)
-    for m in (-1, 1, 10, 30, 64, 65, 128, 256, 257, 300, 1000, 1024):
+    for m in (-1, 1, 10, 30, 64, 65, 128, 256, 257, 300, 1000, 1024, 1025, 3000, 4999):
         seed = 77 * (m + 3) + 987654321987
         off, ids, lid, egid = g.weighted_sample_without_replacement_one_hop(
             "w", torch.from_numpy(centers).cuda(), m, random_seed=seed, need_center_local_output=True, need_edge_output=True)

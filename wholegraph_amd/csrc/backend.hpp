@@ -193,7 +193,7 @@ struct wm_device_backend {
   size_t (*scan_i32_workspace_bytes)(int64_t n);
   int (*exclusive_scan_i32)(const int* in, int* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
   int (*sample_unweighted)(const wm_sample_args* a, void* stream);
-  int (*sample_weighted)(const wm_sample_args* a, void* stream);  // max_sample_count in [1, 1024]
+  int (*sample_weighted)(const wm_sample_args* a, void* stream);  // max_sample_count in [1, 8192]
   // append_unique in two phases around the host learning the output size: phase 1 leaves the number of neighbour ids
   // that are not targets in *new_count_dev, phase 2 writes the unique array and the raw->unique mapping
   size_t (*append_unique_workspace_bytes)(int n_target, int n_neighbor, wholememory_dtype_t dtype);

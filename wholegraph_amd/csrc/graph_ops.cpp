@@ -166,10 +166,10 @@ wholememory_error_code_t sample_without_replacement(
                static_cast<long>(col_desc.size));
       return WHOLEMEMORY_INVALID_INPUT;
     }
-    if (max_sample_count > 1024) {
+    if (max_sample_count > 8192) {
       // reference: key generation + cub segmented sort for > 256 samples (func.cuh:470-560); the in-LDS selection
-      // built here covers 1..1024
-      WM_ERROR("weighted sampling with max_sample_count > 1024 is not implemented in this build");
+      // built here covers 1..8192 (a candidate list of 2 M keys must fit the 160 KiB of LDS)
+      WM_ERROR("weighted sampling with max_sample_count > 8192 is not implemented in this build");
       return WHOLEMEMORY_NOT_IMPLEMENTED;
     }
     WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_weight_ptr_tensor, &a.weight_gref));

@@ -30,7 +30,8 @@ namespace {
 
 constexpr int kBlock        = 256;
 constexpr int kWavesPerBlk  = kBlock / 64;
-constexpr int kMaxSparse    = 1024;  // M <= 1024 on the sparse-recurrence path (the reference's small-sample limit)
+constexpr int kMaxSparse    = 1024;
+constexpr int kMaxWeighted  = 8192;  // weighted selection: candidate list of 2 M composite keys in LDS (<= 128 KiB)  // M <= 1024 on the sparse-recurrence path (the reference's small-sample limit)
 
 struct gref_view {
   char* base;
@@ -386,6 +387,11 @@ int launch_weighted(const weighted_params& w, hipStream_t stream)
 {
   if (w.sp.n_center == 0) return 0;
   const size_t lds = static_cast<size_t>(w.capacity) * sizeof(uint64_t);
+  if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: raise it once per instantiation
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_weighted_kernel<IdT, ColT, WT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMaxWeighted * 8) == hipSuccess;
+    if (!ok) return -2;
+  }
   hipLaunchKernelGGL((sample_weighted_kernel<IdT, ColT, WT>), dim3(w.sp.n_center), dim3(64), lds, stream, w);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -641,7 +647,7 @@ int hip_sample_unweighted(const wm_sample_args* a, void* stream_v)
 int hip_sample_weighted(const wm_sample_args* a, void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
-  if (a->max_sample_count > kMaxSparse) return -3;  // host side reports NOT_IMPLEMENTED before getting here
+  if (a->max_sample_count > kMaxWeighted) return -3;  // host side reports NOT_IMPLEMENTED before getting here
   weighted_params w{};
   sample_params& p = w.sp;
   p.row_ptr = make_view(a->row_gref), p.col_ptr = make_view(a->col_gref);

@@ -59,7 +59,7 @@ def weighted_sample_without_replacement(wm_csr_row_ptr_tensor, wm_csr_col_ptr_te
                                         random_seed: Union[int, None] = None, need_center_local_output: bool = False,
                                         need_edge_output: bool = False):
     """A-Res weighted sampling: neighbours are kept with probability proportional to their edge weight
-    (wm_csr_weight_ptr_tensor: float32/float64, one per edge). max_sample_count <= 1024."""
+    (wm_csr_weight_ptr_tensor: float32/float64, one per edge). max_sample_count <= 8192."""
     row, col, wgt = _handle(wm_csr_row_ptr_tensor), _handle(wm_csr_col_ptr_tensor), _handle(wm_csr_weight_ptr_tensor)
     assert center_nodes_tensor.dim() == 1
     if random_seed is None:
