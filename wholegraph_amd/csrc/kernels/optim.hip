@@ -508,8 +508,8 @@ __global__ __launch_bounds__(kBlock) void step_long_kernel(opt_params p)
 // batch whose hottest id has ~490 k duplicates, 8.8 ms in the kernel above):
 //   (1) one CU pulls at most ~10-13 B/cycle (~25-30 GB/s) out of HBM, whatever it keeps in flight (a 128-column,
 //       whole-row variant of this kernel with a 3-tile LDS-DMA ring ran at 23 GB/s per workgroup and was SLOWER,
-//       11 ms): the fetch of one run has to be spread over CUs, so a workgroup takes a narrow column slice — WM_LONG_SLICE
-//       columns, one workgroup per (run, slice) — and more slices = more CUs on the same run;
+//       11 ms): the fetch of one run has to be spread over CUs, so a workgroup takes a column slice — 64 columns, one
+//       workgroup per (run, slice);
 //   (2) the kernel above keeps ONE tile in flight and pays two dependent HBM latencies per tile (order[] entries, then
 //       rows): 7 GB/s per workgroup, a quarter of (1).
 // So: tiles travel global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction = 256 / S rows of the
@@ -520,14 +520,13 @@ __global__ __launch_bounds__(kBlock) void step_long_kernel(opt_params p)
 // entries of a CHUNK of 4096 rows are staged in LDS once and row addresses then come out of LDS. One wave folds a tile,
 // unpredicated for full tiles. Summation order per element is unchanged (receive order, first row copied): results
 // stay bit-identical.
-#ifndef WM_LONG_SLICE
-#define WM_LONG_SLICE 32
-#endif
+
 constexpr int kOrdChunk  = 4096;
 constexpr int kRing      = 4;
-constexpr int kSlice4    = WM_LONG_SLICE;        // columns per workgroup (16 or 32)
-constexpr int kTile4Rows = 8192 / kSlice4;       // rows per LDS tile: 32 KiB
-constexpr size_t kLong4LdsBytes = static_cast<size_t>(kRing) * kTile4Rows * kSlice4 * 4 + kOrdChunk * 4;
+constexpr int kSlice4    = 64;     // columns per workgroup = lanes of the folding wave (measured on the Zipf batch, fp32:
+                                   // 16 columns 6.8 ms, 32 columns 5.1 ms, 64 columns 4.5 ms)
+constexpr int kTileBytes = 32768;  // one LDS tile
+constexpr size_t kLong4LdsBytes = static_cast<size_t>(kRing) * kTileBytes + kOrdChunk * 4;
 
 constexpr int kLongProducers = 4;                          // waves that only fetch
 constexpr int kLongBlock     = 64 * (kLongProducers + 1);  // + wave 0, which only folds
@@ -536,16 +535,18 @@ template <typename IdxT, int OPT, typename T = float>
 __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
 {
   extern __shared__ __attribute__((aligned(16))) float lds4[];
-  constexpr int S      = kSlice4 * 4 / static_cast<int>(sizeof(T));  // columns per slice: 128 B of every row
-  constexpr int kE16   = 16 / static_cast<int>(sizeof(T));           // elements per 16-byte piece
-  T* const tiles       = reinterpret_cast<T*>(lds4);                                     // [kRing][kTile4Rows][S]
-  int32_t* const ord_s = reinterpret_cast<int32_t*>(lds4 + kRing * kTile4Rows * kSlice4);  // [kOrdChunk]
+  constexpr int S          = kSlice4;                                   // columns per slice
+  constexpr int kRowBytes  = S * static_cast<int>(sizeof(T));           // 256 B (fp32) / 128 B (16-bit) of every row
+  constexpr int kTile4Rows = kTileBytes / kRowBytes;                    // rows per LDS tile
+  constexpr int kE16       = 16 / static_cast<int>(sizeof(T));          // elements per 16-byte piece
+  T* const tiles       = reinterpret_cast<T*>(lds4);                                        // [kRing][kTile4Rows][S]
+  int32_t* const ord_s = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(lds4) + kRing * kTileBytes);  // [kOrdChunk]
   const wm_optimizer_args& a = p.a;
   const int n_long           = *p.long_count;
   const IdxT* ids            = static_cast<const IdxT*>(a.ids);
   const int col0             = blockIdx.y * S;
   const int cols             = min(S, static_cast<int>(a.dim) - col0);  // a whole number of 16-byte pieces
-  constexpr int kLpr         = kSlice4 / 4;                                   // lanes per row (16-byte pieces)
+  constexpr int kLpr         = kRowBytes / 16;                                // lanes per row (16-byte pieces)
   constexpr int kRpp         = 64 / kLpr;                                     // rows per wave instruction
   constexpr int kLoads       = kTile4Rows / (kRpp * kLongProducers);          // pieces per producer lane per tile (8)
   static_assert(kLoads * (kRing - 2) < 64, "vmcnt field");
@@ -680,7 +681,7 @@ template <typename IdxT, typename T>
 int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream)
 {
   constexpr int kOpt   = WHOLEMEMORY_OPT_SGD;
-  constexpr int kS     = kSlice4 * 4 / static_cast<int>(sizeof(T));  // columns per long-run slice
+  constexpr int kS     = kSlice4;  // columns per long-run slice
   const uint64_t gaddr = reinterpret_cast<uint64_t>(p.a.grads) | reinterpret_cast<uint64_t>(p.a.self_grads);
   const int64_t sstr   = p.a.self_grads == nullptr ? 0 : p.a.self_grad_stride;
   const bool vec4      = p.a.dim % 4 == 0 && p.a.grad_stride % 4 == 0 && sstr % 4 == 0 && p.a.table_stride % 4 == 0 &&
