@@ -54,6 +54,23 @@ def main():
     print("append_unique %d + %d -> %d unique: %.3f ms" % (n_center, ids.numel(), uniq.numel(), ms2))
     ms3, _ = timed(lambda: gs.multilayer_sample_without_replacement(centers[:1024], [fanout] * 3), reps=10)
     print("3-hop [%d]*3 from 1024 seeds: %.3f ms" % (fanout, ms3))
+    if os.environ.get("C5", "0") == "1":
+        # BASELINE config 5 shape: 2-hop sample from a batch of 1024 seeds + gather of the 128-wide fp32 features of
+        # every node of the sampled sub-graph (features in a second WholeMemory table)
+        feat = wgth.create_embedding(comm, "chunked", "cuda", torch.float32, [nodes, 128])
+
+        def step():
+            tg, ei, rp, ci = gs.multilayer_sample_without_replacement(centers[:1024], [fanout, fanout])
+            return feat.gather(tg[0]), tg[0].numel()
+        ms5, (x, n_nodes) = timed(step, reps=20)
+        print("C5 step (2-hop [%d,%d] from 1024 seeds + feature gather of %d nodes x 128 fp32): %.3f ms" % (
+            fanout, fanout, n_nodes, ms5))
+        for bs in (8192, 65536):
+            def step_b():
+                tg, ei, rp, ci = gs.multilayer_sample_without_replacement(centers[:bs], [fanout, fanout])
+                return feat.gather(tg[0]), tg[0].numel()
+            msb, (x, n_nodes) = timed(step_b, reps=10)
+            print("  batch %6d seeds: %d nodes, %.3f ms" % (bs, n_nodes, msb))
     if os.environ.get("CPU_BASELINE", "1") == "1":
         import oracle
         rp, cl = row.cpu().numpy(), lc.cpu().numpy()
