@@ -391,6 +391,15 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   const int64_t dim        = d.table.sizes[1];
   auto entry_offsets       = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
   const char* indices      = static_cast<const char*>(d.indices_ptr);  // data pointer: offset already applied
+  if (comm->world_size == 1 && cache == nullptr) {
+    // one rank owns every row: nothing to bucket or exchange, the gather kernel itself skips negative ids
+    wm_rows_args a{};
+    fill_rows_args(&a, local_shard_gref(handle), d.table, indices, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain,
+                   gather_sms);
+    WM_BK(bk->gather_rows(&a, stream));
+    if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+    return WHOLEMEMORY_SUCCESS;
+  }
 
   id_exchange x(env);
   bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x, true);
@@ -584,6 +593,15 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
   const int64_t dim   = d.table.sizes[1];
   auto entry_offsets  = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
   const char* indices = static_cast<const char*>(d.indices_ptr);  // data pointer: offset already applied
+  if (comm->world_size == 1) {
+    // one rank owns every row: a plain scatter (negative ids are skipped by the kernel), then the reference's sync
+    wm_rows_args a{};
+    fill_rows_args(&a, local_shard_gref(handle), d.table, indices, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain,
+                   scatter_sms);
+    WM_BK(bk->scatter_rows(&a, stream));
+    WM_BK(bk->stream_sync(stream));
+    return WHOLEMEMORY_SUCCESS;
+  }
 
   id_exchange x(env);
   bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x, true);
