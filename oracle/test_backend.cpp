@@ -271,12 +271,34 @@ int t_fill(float* p, float v, int64_t n, void*)
   return 0;
 }
 
+template <typename T>
+void env_test_rows(const void* in, void* out, int64_t dim, int64_t entries, int64_t stride)
+{
+  for (int64_t i = 0; i < entries; i++)
+    for (int64_t c = 0; c < dim; c++)
+      static_cast<T*>(out)[stride * i + c] = static_cast<T>(static_cast<T>(static_cast<float>(i)) + static_cast<const T*>(in)[c]);
+}
+// wholememory_env_test_op arithmetic (reference wholememory_test_op.cu:25-37) for the dtypes a CPU can do natively
+int t_env_test(const void* in, void* out, wholememory_dtype_t dt, int64_t dim, int64_t entries, int64_t stride, void*)
+{
+  switch (dt) {
+    case WHOLEMEMORY_DT_FLOAT: env_test_rows<float>(in, out, dim, entries, stride); return 0;
+    case WHOLEMEMORY_DT_DOUBLE: env_test_rows<double>(in, out, dim, entries, stride); return 0;
+    case WHOLEMEMORY_DT_INT: env_test_rows<int32_t>(in, out, dim, entries, stride); return 0;
+    case WHOLEMEMORY_DT_INT64: env_test_rows<int64_t>(in, out, dim, entries, stride); return 0;
+    default: return -1;
+  }
+}
+
 const wm_device_backend kTestBackend = {
   "oracle-test-backend (CPU, tests only)",
   t_device_count, t_malloc, t_free, t_malloc, t_free, t_memcpy, t_memset, t_sync,
   t_stream_create, t_noop1, t_event_create, t_noop1, t_noop2, t_noop2,
   t_ipc_get, t_ipc_open, t_ipc_close, t_host_register, t_host_unregister,
   t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_long_ws, t_run_inverse, t_remap_self, t_rr, t_fill,
+  // graph ops: not provided by the CPU backend
+  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+  t_env_test,
 };
 
 }  // namespace
