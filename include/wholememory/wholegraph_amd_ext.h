@@ -63,6 +63,22 @@ enum wholememory_error_code_t wholememory_ext_bucket_ids(const void* indices,
                                                          struct wholememory_env_func_t* p_env_fns,
                                                          void* stream);
 
+/* The same with more row ranges than buckets: entry_offsets has owner_count+1 entries (owner_count >= bucket_count) and
+ * an id of range o goes to bucket o % bucket_count — the first hop of the HIERARCHY gather (ranges = ranks of every node,
+ * buckets = ranks of this node; reference bucket_and_reorder_ids_for_hierarchy_func, gather_op_impl_hierarchy.cu:194-205).
+ * counts: DEVICE int64[bucket_count]. */
+enum wholememory_error_code_t wholememory_ext_bucket_ids_folded(const void* indices,
+                                                                enum wholememory_dtype_t index_dtype,
+                                                                int64_t n,
+                                                                const void* entry_offsets_dev,
+                                                                int owner_count,
+                                                                int bucket_count,
+                                                                int64_t* counts_dev,
+                                                                void* bucketed_ids_dev,
+                                                                int64_t* raw_indices_dev,
+                                                                struct wholememory_env_func_t* p_env_fns,
+                                                                void* stream);
+
 /* Owner-side "dedup + optimizer step" on received (ids, grads): reference
  * exchange_embeddings_nccl_func.cu:76-174 followed by embedding_optimizer_func.cu steps, fused.
  * opt_params: float[6] = {weight_decay, epsilon, beta1, beta2, alpha, adam_w}. State pointers may be

@@ -53,7 +53,7 @@ enum wholememory_memory_type_t {
   WHOLEMEMORY_MT_CONTINUOUS,  /* all shards mapped into one flat VA range (HIP VMM) */
   WHOLEMEMORY_MT_CHUNKED,     /* one mapped base pointer per rank (hipIpc) */
   WHOLEMEMORY_MT_DISTRIBUTED, /* peers not mapped; RCCL all-to-all-v moves ids and rows */
-  WHOLEMEMORY_MT_HIERARCHY,   /* multi-node two-level type of the reference: NOT_SUPPORTED here */
+  WHOLEMEMORY_MT_HIERARCHY,   /* owned as DISTRIBUTED; gathers go node-local relay -> cross-node rail (multi-node) */
 };
 
 /* reference wholememory.h:75-79 */

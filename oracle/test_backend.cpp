@@ -146,20 +146,33 @@ int t_scatter(const wm_rows_args* a, void*)
 size_t t_bucket_ws(int64_t, int) { return 64; }
 int t_bucket(const wm_bucket_args* a, void*)
 {
-  wmo_bucket_counts(a->indices, a->index_dtype, a->n, a->entry_offsets, a->world_size, a->counts);
+  const int owners = a->owner_count > 0 ? a->owner_count : a->world_size;
+  // bucket of id i: its owner (the oracle's range search), or owner % world_size in the owner_count mode; negatives go to
+  // the trailing bucket `world_size`
+  auto bucket_of = [&](int64_t i) {
+    int64_t id = idx_at(a->indices, a->index_dtype, i);
+    if (id < 0) return a->world_size;
+    int owner = 0;
+    for (int k = 1; k < owners; k++)
+      if (static_cast<uint64_t>(id) >= a->entry_offsets[k]) owner = k;
+    return owners == a->world_size ? owner : owner % a->world_size;
+  };
+  if (a->owner_count <= 0) {
+    wmo_bucket_counts(a->indices, a->index_dtype, a->n, a->entry_offsets, a->world_size, a->counts);
+  } else {
+    for (int r = 0; r < a->world_size; r++) a->counts[r] = 0;
+    for (int64_t i = 0; i < a->n; i++) {
+      int b = bucket_of(i);
+      if (b < a->world_size) a->counts[b]++;
+    }
+  }
   if (a->bucketed_ids == nullptr) return 0;
-  // stable partition by owner, negatives last (kernels/bucket.hip contract)
+  // stable partition by bucket, negatives last (kernels/bucket.hip contract)
   int64_t pos = 0;
   for (int r = 0; r <= a->world_size; r++) {
     for (int64_t i = 0; i < a->n; i++) {
+      if (bucket_of(i) != r) continue;
       int64_t id = idx_at(a->indices, a->index_dtype, i);
-      int owner  = a->world_size;
-      if (id >= 0) {
-        owner = 0;
-        for (int k = 1; k < a->world_size; k++)
-          if (static_cast<uint64_t>(id) >= a->entry_offsets[k]) owner = k;
-      }
-      if (owner != r) continue;
       if (a->index_dtype == WHOLEMEMORY_DT_INT)
         static_cast<int32_t*>(a->bucketed_ids)[pos] = static_cast<int32_t>(id);
       else

@@ -8,7 +8,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-HIP_MODE = len(sys.argv) > 4 and sys.argv[4] == "hip"   # real kernels on cuda:0, collectives still over gloo
+MODE = sys.argv[4] if len(sys.argv) > 4 else "cpu"
+HIP_MODE = MODE.startswith("hip")   # real kernels on cuda:0, collectives still over gloo
+HIER_MODE = MODE.endswith("-hier")  # HIERARCHY tables on a pretended multi-node layout (WM_LOCAL_SIZE ranks per node)
 if not HIP_MODE:
     os.environ["WHOLEGRAPH_AMD_TESTING"] = "1"
 
@@ -116,9 +118,9 @@ def scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, e
     wgth.destroy_wholememory_tensor(wm)
 
 
-def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries):
+def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries, mt="distributed"):
     n_rows, dim, steps = 1201, 13, 3
-    emb = wgth.create_embedding(comm, "distributed", "cuda", torch.float32, [n_rows, dim],
+    emb = wgth.create_embedding(comm, mt, "cuda", torch.float32, [n_rows, dim],
                                 embedding_entry_partition=entries)
     stride = emb.get_embedding_tensor().stride()[0]
     assert stride == 16
@@ -366,6 +368,42 @@ def scenario_sampling(comm, rank, world, mt, col_dt, loc="cuda"):
         wgth.destroy_wholememory_tensor(t)
 
 
+def hierarchy_scenarios(comm, rank, world):
+    """HIERARCHY tables: rows owned as in DISTRIBUTED, gathered in two hops (inside the node to the relay with the
+    owner's local rank, then between nodes along that rail). The node layout is pretended through WM_LOCAL_SIZE."""
+    L = int(os.environ["WM_LOCAL_SIZE"])
+    local_size = C.c_int(0)
+    wmb.check(wmb.lib().wholememory_communicator_get_local_size(C.byref(local_size), comm.wmb_comm))
+    assert local_size.value == L
+    S = wmb.lib().wholememory_communicator_support_type_location
+    assert S(comm.wmb_comm, wmb.MT_HIERARCHY, wmb.ML_DEVICE) == 0 and S(comm.wmb_comm, wmb.MT_DISTRIBUTED, wmb.ML_HOST) == 0
+    # peer mappings stop at the node boundary
+    assert (S(comm.wmb_comm, wmb.MT_CHUNKED, wmb.ML_DEVICE) == 0) == (L == world)
+    # the handle carries the two sub-communicators: my node, my rail
+    t = wgth.create_wholememory_tensor(comm, "hierarchy", "cuda", [64, 4], torch.float32, [4, 1])
+    h = wmb.lib().wholememory_tensor_get_memory_handle(t.wmb_tensor)
+    lc, cc, r, n = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+    wmb.check(wmb.lib().wholememory_get_local_communicator(C.byref(lc), C.c_void_p(h)))
+    wmb.check(wmb.lib().wholememory_get_cross_communicator(C.byref(cc), C.c_void_p(h)))
+    for sub, want_rank, want_size in ((lc, rank % L, L), (cc, rank // L, world // L)):
+        wmb.check(wmb.lib().wholememory_communicator_get_rank(C.byref(r), sub))
+        wmb.check(wmb.lib().wholememory_communicator_get_size(C.byref(n), sub))
+        assert (r.value, n.value) == (want_rank, want_size)
+    wgth.destroy_wholememory_tensor(t)
+    w8 = np.random.default_rng(42).uniform(90, 100, world)
+    w8[world // 2] *= 0.3
+    ent = [int(x) for x in (w8 / w8.sum() * 997).astype(int)]
+    ent[0] += 997 - sum(ent)
+    scenario_gather_scatter(comm, rank, world, "hierarchy", 1003, 11, np.float32, np.float32, np.int64, None)
+    scenario_gather_scatter(comm, rank, world, "hierarchy", 2000, 32, np.float16, np.float32, np.int32, None)
+    scenario_gather_scatter(comm, rank, world, "hierarchy", 997, 8, np.int64, np.int32, np.int64, ent)
+    scenario_gather_scatter(comm, rank, world, "hierarchy", 5, 4, np.float32, np.float32, np.int64, None)  # empty ranks
+    scenario_gather_scatter(comm, rank, world, "hierarchy", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
+    scenario_gradient_apply(comm, rank, world, "adam", {"weight_decay": 0.01}, np.int64, None, mt="hierarchy")
+    # plain DISTRIBUTED is unaffected by the node layout
+    scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
@@ -375,9 +413,16 @@ def main():
         assert wmb.lib().wholememory_ext_backend_name() == b"hip-gfx950"
     else:
         install_test_backend()
-    wgth.init(rank, world, rank, world, "warn")
+    wgth.init(rank, world, rank, world, os.environ.get("WM_TEST_LOG", "warn"))
     comm = wgth.get_global_communicator()
     assert comm.get_rank() == rank and comm.get_size() == world
+    if HIER_MODE:
+        hierarchy_scenarios(comm, rank, world)
+        comm.barrier()
+        dist.barrier()
+        print("RANK %d OK" % rank)
+        wgth.finalize()
+        return
     # (1) gather / scatter, equal plan, padded rows, fp32, int64 ids
     scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)
     # (2) dtype cast at the owner + int32 ids + an asking-nothing rank

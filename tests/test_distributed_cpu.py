@@ -56,3 +56,18 @@ def test_distributed_paths_over_gloo(wm_lib, world, chunks):
     # header changes (a no-op when it is up to date)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "test_backend"], stdout=subprocess.DEVNULL)
     run_world(world, "cpu", {"WHOLEGRAPH_AMD_TESTING": "1", "HIP_VISIBLE_DEVICES": "", "WM_EXCHANGE_CHUNKS": chunks})
+
+
+@pytest.mark.parametrize("world,local,chunks", [(4, 2, "1"), (6, 3, "2"), (6, 2, "1"), (4, 1, "1"), (3, 3, "1")])
+def test_hierarchy_gather_over_gloo(wm_lib, world, local, chunks):
+    """HIERARCHY tables on a pretended `world / local` nodes x `local` ranks layout: ids relayed inside the node, distinct
+    rows fetched along the rails, results bit-identical to the oracle's DISTRIBUTED gather."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "test_backend"], stdout=subprocess.DEVNULL)
+    run_world(world, "cpu-hier", {"WHOLEGRAPH_AMD_TESTING": "1", "HIP_VISIBLE_DEVICES": "", "WM_EXCHANGE_CHUNKS": chunks,
+                                  "WM_LOCAL_SIZE": str(local)})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,local", [(4, 2), (3, 3)])
+def test_hierarchy_gather_hip_kernels(wm_lib, world, local):
+    run_world(world, "hip-hier", {"WM_LOCAL_SIZE": str(local)})

@@ -92,6 +92,43 @@ OPTS = [("sgd", 1, {}), ("sgd", 1, {"weight_decay": 0.05}), ("adam", 2, {}), ("a
         ("adagrad", 4, {"weight_decay": 0.01})]
 
 
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+@pytest.mark.parametrize("n,owners,buckets", [(0, 8, 2), (777, 4, 2), (100000, 16, 8), (250001, 24, 3), (400000, 512, 8),
+                                              (50000, 1024, 1)])
+def test_bucket_ids_folded(gpu_env, idt, n, owners, buckets):
+    """First hop of the HIERARCHY gather: `owners` row ranges folded onto `buckets` ranks by owner % buckets — stable,
+    negatives last, counts exact (numpy restatement: searchsorted over the range offsets)."""
+    import torch
+    from wholegraph_amd import binding as wmb
+    rng = np.random.default_rng(n + owners)
+    total = 1_000_003
+    _, offs = oracle.equal_partition(total, owners)
+    if owners == 24:   # unequal ranges with empty ones in between
+        cuts = np.sort(rng.integers(0, total, owners - 1))
+        cuts[5] = cuts[4]
+        offs = np.concatenate([[0], cuts, [total]]).astype(np.uint64)
+    idx = rng.integers(0, total, n).astype(idt)
+    if n > 10:
+        idx[rng.integers(0, n, n // 20)] = -1
+        idx[:100] = idx[50]
+    d_idx = torch.from_numpy(idx).cuda()
+    d_off = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_cnt = torch.full((buckets,), -1, dtype=torch.int64, device="cuda")
+    d_ids = torch.zeros(max(n, 1), dtype=d_idx.dtype, device="cuda")
+    d_raw = torch.zeros(max(n, 1), dtype=torch.int64, device="cuda")
+    env, stream = _env()
+    wmb.check(wmb.lib().wholememory_ext_bucket_ids_folded(
+        d_idx.data_ptr(), wmb.DT_INT if idt == np.int32 else wmb.DT_INT64, n, d_off.data_ptr(), owners, buckets,
+        d_cnt.data_ptr(), d_ids.data_ptr(), d_raw.data_ptr(), env, stream))
+    torch.cuda.synchronize()
+    owner = np.searchsorted(offs[1:].astype(np.int64), idx.astype(np.int64), side="right")   # the r with off[r] <= id < off[r+1]
+    bucket = np.where(idx >= 0, owner % buckets, buckets)
+    want_raw = np.argsort(bucket, kind="stable")
+    assert np.array_equal(d_cnt.cpu().numpy(), np.bincount(bucket, minlength=buckets + 1)[:buckets])
+    assert np.array_equal(d_raw.cpu().numpy()[:n], want_raw)
+    assert np.array_equal(d_ids.cpu().numpy()[:n], idx[want_raw])
+
+
 @pytest.mark.parametrize("kind,code,params", OPTS, ids=lambda x: str(x))
 @pytest.mark.parametrize("dim,n_recv,idt", [(127, 20005, np.int64), (129, 20005, np.int32), (128, 50001, np.int64),
                                             (392, 5001, np.int64), (4, 3000, np.int64), (128, 0, np.int64), (256, 100003, np.int64),

@@ -245,6 +245,7 @@ PROTOTYPES = {
     # wholegraph_amd_ext.h
     "wholememory_create_communicator_ext": (_i, [_P(_vp), _i, _i, _P(ExtCollectives)]),
     "wholememory_ext_bucket_ids": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _vp, _P(EnvFunc), _vp]),
+    "wholememory_ext_bucket_ids_folded": (_i, [_vp, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _P(EnvFunc), _vp]),
     "wholememory_ext_dedup_apply": (_i, [_vp, _i, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i, _P(_f), _f, _vp,
                                         _vp, _P(_i64), _P(EnvFunc), _vp]),
     "wholememory_ext_round_robin_map": (_i, [_vp, _vp, _i, _i64, _i64, _i, _i, _vp]),

@@ -48,6 +48,10 @@ struct wm_bucket_args {
   void* bucketed_ids;    // [n] device out (index dtype): ids grouped by owner, stable; may be nullptr
   int64_t* raw_indices;  // [n] device out: original position of each bucketed id; may be nullptr
   void* workspace;       // device scratch of bucket_workspace_bytes(n, world)
+  // 0: one bucket per owner (entry_offsets has world+1 entries). > 0: entry_offsets describes owner_count >= world_size
+  // owners (owner_count+1 entries) and an id of owner o goes to bucket o % world_size — first hop of the HIERARCHY
+  // gather, where the buckets are the ranks of this node and the owners the ranks of every node
+  int owner_count;
 };
 
 struct wm_optimizer_args {

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -114,7 +116,8 @@ class rccl_provider : public collective_provider {
     WM_NCCL_TRY(ncclGroupEnd());
   }
 
-  std::unique_ptr<collective_provider> split(int color, int key, int my_rank, int* new_rank, int* new_size) override
+  std::unique_ptr<collective_provider> split(int color, int key, int my_rank, int* new_rank, int* new_size,
+                                             std::vector<int>* members) override
   {
     std::vector<split_entry> all(size_);
     split_entry me{color, key, my_rank};
@@ -125,7 +128,7 @@ class rccl_provider : public collective_provider {
       *new_rank = -1, *new_size = 0;
       return nullptr;
     }
-    plan_split(all, color, my_rank, new_rank, new_size, nullptr);
+    plan_split(all, color, my_rank, new_rank, new_size, members);
     return std::unique_ptr<collective_provider>(new rccl_provider(sub, *new_rank, *new_size));
   }
 
@@ -138,11 +141,62 @@ class rccl_provider : public collective_provider {
   void* host_stage_   = nullptr;
 };
 
-// Collectives supplied by the host framework (wholegraph_amd_ext.h). A sub-group provider built by
-// split() routes through the parent with the member list applied.
+// Sub-group of an external-collectives communicator: every collective is carried by the ROOT provider with the member
+// list applied (non-members get zero-byte segments). This only works when all groups of one split run the same sequence
+// of collectives at the same time — true for the one user, the HIERARCHY gather, where every node (every rail) runs the
+// same steps — and it makes a sub-group barrier a root barrier. The root provider must outlive the sub-group.
+class ext_group_provider : public collective_provider {
+ public:
+  ext_group_provider(collective_provider* root, int root_size, std::vector<int> members)
+    : root_(root), root_size_(root_size), members_(std::move(members))
+  {
+  }
+  const char* name() const override { return "external (sub-group)"; }
+  void barrier() override { root_->barrier(); }
+  void allgather_host(const void* send, void* recv, size_t bytes) override
+  {
+    std::vector<char> all(static_cast<size_t>(root_size_) * bytes);
+    root_->allgather_host(send, all.data(), bytes);
+    for (size_t i = 0; i < members_.size(); i++)
+      memcpy(static_cast<char*>(recv) + i * bytes, all.data() + static_cast<size_t>(members_[i]) * bytes, bytes);
+  }
+  void alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp, void* recv,
+                        const size_t* recv_bytes, const size_t* recv_disp, void* stream) override
+  {
+    std::vector<size_t> sb(root_size_, 0), sd(root_size_, 0), rb(root_size_, 0), rd(root_size_, 0);
+    for (size_t i = 0; i < members_.size(); i++) {
+      const int r = members_[i];
+      sb[r] = send_bytes[i], sd[r] = send_disp[i], rb[r] = recv_bytes[i], rd[r] = recv_disp[i];
+    }
+    root_->alltoallv_device(send, sb.data(), sd.data(), recv, rb.data(), rd.data(), stream);
+  }
+  std::unique_ptr<collective_provider> split(int color, int key, int my_rank, int* new_rank, int* new_size,
+                                             std::vector<int>* members) override
+  {
+    std::vector<split_entry> all(members_.size());
+    split_entry me{color, key, my_rank};
+    allgather_host(&me, all.data(), sizeof(split_entry));
+    if (color < 0) {
+      *new_rank = -1, *new_size = 0;
+      return nullptr;
+    }
+    std::vector<int> sub;
+    plan_split(all, color, my_rank, new_rank, new_size, &sub);
+    if (members) *members = sub;
+    for (auto& r : sub) r = members_[r];  // ranks of this group -> ranks of the root
+    return std::unique_ptr<collective_provider>(new ext_group_provider(root_, root_size_, std::move(sub)));
+  }
+
+ private:
+  collective_provider* root_;
+  int root_size_;
+  std::vector<int> members_;
+};
+
+// Collectives supplied by the host framework (wholegraph_amd_ext.h). split() yields ext_group_provider sub-groups.
 class ext_provider : public collective_provider {
  public:
-  ext_provider(const wm_ext_collectives_t& c, int, int) : c_(c) {}
+  ext_provider(const wm_ext_collectives_t& c, int, int size) : c_(c), size_(size) {}
   const char* name() const override { return "external"; }
   void barrier() override
   {
@@ -158,13 +212,25 @@ class ext_provider : public collective_provider {
     if (c_.alltoallv_device(c_.ctx, send, send_bytes, send_disp, recv, recv_bytes, recv_disp, stream) != 0)
       throw comm_error("external alltoallv_device failed");
   }
-  std::unique_ptr<collective_provider> split(int, int, int, int*, int*) override
+  std::unique_ptr<collective_provider> split(int color, int key, int my_rank, int* new_rank, int* new_size,
+                                             std::vector<int>* members) override
   {
-    throw logic_error("split is not available on an external-collectives communicator");
+    std::vector<split_entry> all(size_);
+    split_entry me{color, key, my_rank};
+    allgather_host(&me, all.data(), sizeof(split_entry));
+    if (color < 0) {
+      *new_rank = -1, *new_size = 0;
+      return nullptr;
+    }
+    std::vector<int> sub;
+    plan_split(all, color, my_rank, new_rank, new_size, &sub);
+    if (members) *members = sub;
+    return std::unique_ptr<collective_provider>(new ext_group_provider(this, size_, std::move(sub)));
   }
 
  private:
   wm_ext_collectives_t c_;
+  int size_;
 };
 
 int next_comm_id()
@@ -192,6 +258,66 @@ wholememory_comm_::~wholememory_comm_()
   if (side_stream != nullptr) wm::backend()->stream_destroy(side_stream);
 }
 
+// Which ranks share a node: every rank publishes (host name, boot id) and nodes are numbered in order of their first
+// rank (the reference exchanges the same identity, communicator.cpp:405-500,548-580). WM_LOCAL_SIZE=n overrides the detection
+// with "n consecutive ranks per node" (bring-up of the multi-node paths on one box; must divide the world size).
+void wholememory_comm_::detect_nodes()
+{
+  node_of_rank.assign(world_size, 0);
+  local_size    = world_size;
+  regular_nodes = true;
+  if (world_size == 1) return;
+  const char* forced = getenv("WM_LOCAL_SIZE");
+  if (forced != nullptr && atoi(forced) > 0) {
+    const int n = atoi(forced);
+    if (world_size % n != 0) throw wm::logic_error("WM_LOCAL_SIZE must divide the communicator size");
+    for (int r = 0; r < world_size; r++) node_of_rank[r] = r / n;
+    local_size = n;
+    return;
+  }
+  constexpr size_t kIdBytes = 128;
+  char mine[kIdBytes]       = {0};
+  gethostname(mine, 63);
+  mine[63] = 0;
+  if (FILE* f = fopen("/proc/sys/kernel/random/boot_id", "r")) {
+    size_t got = fread(mine + 64, 1, 63, f);
+    (void)got;
+    fclose(f);
+  }
+  std::vector<char> all(static_cast<size_t>(world_size) * kIdBytes);
+  allgather_host(mine, all.data(), kIdBytes);
+  int nodes = 0;
+  for (int r = 0; r < world_size; r++) {
+    int found = -1;
+    for (int q = 0; q < r && found < 0; q++)
+      if (memcmp(&all[q * kIdBytes], &all[r * kIdBytes], kIdBytes) == 0) found = node_of_rank[q];
+    node_of_rank[r] = found >= 0 ? found : nodes++;
+  }
+  local_size = 0;
+  for (int r = 0; r < world_size; r++) local_size += node_of_rank[r] == node_of_rank[world_rank] ? 1 : 0;
+  for (int r = 0; r < world_size; r++)
+    if (world_size % local_size != 0 || node_of_rank[r] != r / local_size) regular_nodes = false;
+}
+
+// node layout of a sub-communicator: `members` lists the parent ranks in their new order
+void wholememory_comm_::adopt_nodes(const wholememory_comm_& parent, const std::vector<int>& members)
+{
+  const int n = static_cast<int>(members.size());
+  node_of_rank.assign(n, 0);
+  int nodes = 0;
+  for (int i = 0; i < n; i++) {
+    int found = -1;
+    for (int j = 0; j < i && found < 0; j++)
+      if (parent.node_of_rank[members[j]] == parent.node_of_rank[members[i]]) found = node_of_rank[j];
+    node_of_rank[i] = found >= 0 ? found : nodes++;
+  }
+  local_size    = 0;
+  regular_nodes = true;
+  for (int i = 0; i < n; i++) local_size += node_of_rank[i] == node_of_rank[world_rank] ? 1 : 0;
+  for (int i = 0; i < n; i++)
+    if (n % local_size != 0 || node_of_rank[i] != i / local_size) regular_nodes = false;
+}
+
 void wholememory_comm_::barrier()
 {
   if (transport) transport->barrier();
@@ -206,8 +332,9 @@ void wholememory_comm_::allgather_host(const void* send, void* recv, size_t byte
   transport->allgather_host(send, recv, bytes);
 }
 
-void wholememory_comm_::alltoall_host_i64(const int64_t* send, int64_t* recv)
+void wholememory_comm_::alltoall_host_i64(const int64_t* send, int64_t* recv, int64_t* between_ranks)
 {
+  if (between_ranks) *between_ranks = 0;
   if (!transport) {
     recv[0] = send[0];
     return;
@@ -216,6 +343,10 @@ void wholememory_comm_::alltoall_host_i64(const int64_t* send, int64_t* recv)
   std::vector<int64_t> all(static_cast<size_t>(world_size) * world_size);
   transport->allgather_host(send, all.data(), sizeof(int64_t) * world_size);
   for (int r = 0; r < world_size; r++) recv[r] = all[static_cast<size_t>(r) * world_size + world_rank];
+  if (between_ranks)
+    for (int s = 0; s < world_size; s++)
+      for (int r = 0; r < world_size; r++)
+        if (s != r) *between_ranks += all[static_cast<size_t>(s) * world_size + r];
 }
 
 void wholememory_comm_::alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp,
@@ -270,6 +401,7 @@ wholememory_error_code_t wholememory_create_communicator(wholememory_comm_t* com
     try {
       WM_NCCL_TRY(ncclCommInitRank(&nc, size, id, rank));
       c->transport.reset(new wm::rccl_provider(nc, rank, size));
+      c->detect_nodes();
     } catch (...) {
       delete c;
       throw;
@@ -295,7 +427,15 @@ wholememory_error_code_t wholememory_create_communicator_ext(wholememory_comm_t*
   c->world_size = size;
   c->local_size = size;
   c->comm_id    = wm::next_comm_id();
-  if (size > 1) c->transport.reset(new wm::ext_provider(*collectives, rank, size));
+  if (size > 1) {
+    c->transport.reset(new wm::ext_provider(*collectives, rank, size));
+    try {
+      c->detect_nodes();
+    } catch (...) {
+      delete c;
+      throw;
+    }
+  }
   *comm = c;
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
@@ -317,13 +457,14 @@ wholememory_error_code_t wholememory_split_communicator(wholememory_comm_t* new_
     return WHOLEMEMORY_SUCCESS;
   }
   int nr = -1, ns = 0;
-  auto sub = comm->transport->split(color, key, comm->world_rank, &nr, &ns);
+  std::vector<int> members;
+  auto sub = comm->transport->split(color, key, comm->world_rank, &nr, &ns, &members);
   if (color < 0) return WHOLEMEMORY_SUCCESS;
   auto* c       = new wholememory_comm_();
   c->world_rank = nr;
   c->world_size = ns;
-  c->local_size = ns;
   c->comm_id    = wm::next_comm_id();
+  c->adopt_nodes(*comm, members);
   if (ns > 1) c->transport = std::move(sub);
   *new_comm = c;
   return WHOLEMEMORY_SUCCESS;
@@ -346,11 +487,15 @@ wholememory_error_code_t wholememory_communicator_support_type_location(wholemem
 {
   if (comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
   if (memory_location != WHOLEMEMORY_ML_DEVICE && memory_location != WHOLEMEMORY_ML_HOST) return WHOLEMEMORY_NOT_SUPPORTED;
+  const bool one_node = comm->local_size == comm->world_size;
   switch (memory_type) {
     case WHOLEMEMORY_MT_CONTINUOUS:
-    case WHOLEMEMORY_MT_CHUNKED:
+    case WHOLEMEMORY_MT_CHUNKED:  // peer mappings (hipIpc / VMM / shared segment) do not cross nodes (communicator.cpp:357-373)
+      return one_node ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_NOT_SUPPORTED;
     case WHOLEMEMORY_MT_DISTRIBUTED: return WHOLEMEMORY_SUCCESS;
-    default: return WHOLEMEMORY_NOT_SUPPORTED;  // HIERARCHY: multi-node, out of scope
+    case WHOLEMEMORY_MT_HIERARCHY:  // needs nodes of equal size holding consecutive ranks (memory_handle.cpp:1780-1783)
+      return comm->regular_nodes ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_NOT_SUPPORTED;
+    default: return WHOLEMEMORY_NOT_SUPPORTED;
   }
 }
 

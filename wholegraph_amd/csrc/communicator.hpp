@@ -24,9 +24,10 @@ class collective_provider {
   // device buffers, byte counts/displacements indexed by peer rank; enqueued on `stream`
   virtual void alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp, void* recv,
                                 const size_t* recv_bytes, const size_t* recv_disp, void* stream) = 0;
-  // new provider for the sub-group {ranks with the same color}, ordered by (key, old rank);
-  // returns nullptr for color == WHOLEMEMORY_SPILT_NO_COLOR
-  virtual std::unique_ptr<collective_provider> split(int color, int key, int my_rank, int* new_rank, int* new_size) = 0;
+  // new provider for the sub-group {ranks with the same color}, ordered by (key, old rank); `members` receives the
+  // parent ranks of the sub-group in their new order. Returns nullptr for color == WHOLEMEMORY_SPILT_NO_COLOR
+  virtual std::unique_ptr<collective_provider> split(int color, int key, int my_rank, int* new_rank, int* new_size,
+                                                     std::vector<int>* members) = 0;
 };
 
 }  // namespace wm
@@ -34,7 +35,15 @@ class collective_provider {
 struct wholememory_comm_ {
   int world_rank = 0;
   int world_size = 1;
-  int local_size = 1;  // ranks on this node (single-node build: == world_size)
+  int local_size = 1;  // ranks of this communicator that run on this rank's node
+  // node index of every rank (nodes numbered in order of their first rank); filled by detect_nodes() at creation
+  // (reference communicator.cpp:405-500,548-580 exchanges host names / boot ids to the same end)
+  std::vector<int> node_of_rank{0};
+  // every node holds the same number of consecutive ranks: rank r is local rank r % local_size of node r / local_size
+  // (what the HIERARCHY memory type needs)
+  bool regular_nodes = true;
+  void detect_nodes();
+  void adopt_nodes(const wholememory_comm_& parent, const std::vector<int>& members);
   int comm_id    = 0;
   wholememory_distributed_backend_t distributed_backend = WHOLEMEMORY_DB_NCCL;
   std::unique_ptr<wm::collective_provider> transport;  // null when world_size == 1
@@ -47,7 +56,9 @@ struct wholememory_comm_ {
   void barrier();
   void allgather_host(const void* send, void* recv, size_t bytes);
   // counts exchange: recv[r] = what rank r sends to me (reference host_alltoall, nccl_comms.cpp:383-407)
-  void alltoall_host_i64(const int64_t* send, int64_t* recv);
+  // between_ranks (optional): sum of the off-diagonal of the whole matrix — the same number on every rank, which makes it
+  // a safe input for decisions all ranks must take alike
+  void alltoall_host_i64(const int64_t* send, int64_t* recv, int64_t* between_ranks = nullptr);
   void alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp, void* recv,
                         const size_t* recv_bytes, const size_t* recv_disp, void* stream);
 };

@@ -325,7 +325,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   // peers' rows: line-up (HBM) and all-to-all-v (xGMI, side stream) pipelined in C row-chunks; the id sort that
   // follows on the caller's stream overlaps with the tail of the exchange
   const int W = e->comm->world_size;
-  const int C = exchange_chunks(W, x.total_recv + x.total_send);
+  const int C = exchange_chunks(W, x.global_moved);
   auto chunk_of = [C](int64_t n, int c, int64_t* a, int64_t* b) {
     *a = n * c / C;
     *b = n * (c + 1) / C;

@@ -38,6 +38,7 @@ constexpr int kItems      = 4;                       // 64-id groups per wave pe
 constexpr int kIterItems  = kBlock * kItems;         // 1024 ids per block iteration
 constexpr int kMaxBlocks  = 2048;
 constexpr int kMaxBuckets = 257;                     // world_size <= 256
+constexpr int kMaxOwners  = 1024;                    // ranges searched per id (== buckets unless owner_count is set)
 
 struct bucket_geom {
   int64_t chunk;  // ids per block (multiple of kIterItems)
@@ -56,32 +57,43 @@ inline bucket_geom geometry(int64_t n)
 
 // owner of a non-negative id: the r with off[r] <= id < off[r+1]; branch-free count of passed
 // boundaries (empty ranks share a boundary and are skipped naturally)
-__device__ __forceinline__ int owner_of(uint64_t id, const uint64_t* s_off, int world)
+__device__ __forceinline__ int owner_of(uint64_t id, const uint64_t* s_off, int owners)
 {
-  int r = 0;
-  for (int k = 1; k < world; k++) r += (id >= s_off[k]) ? 1 : 0;
-  return r;
+  if (owners <= 16) {
+    int r = 0;
+    for (int k = 1; k < owners; k++) r += (id >= s_off[k]) ? 1 : 0;
+    return r;
+  }
+  int lo = 0, hi = owners;  // largest lo with s_off[lo] <= id: the same r as the count above (offsets are monotone)
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (id >= s_off[mid]) lo = mid; else hi = mid;
+  }
+  return lo;
 }
 
+// bucket of an id: its owner, or — when there are more owners than buckets (wm_bucket_args::owner_count) — owner % world
 template <typename IdxT>
 __device__ __forceinline__ int bucket_of(const IdxT* ids, int64_t i, int64_t n, const uint64_t* s_off, int world,
-                                         IdxT& id_out)
+                                         int owners, IdxT& id_out)
 {
   if (i >= n) return -1;  // padding lane: belongs to no bucket
   IdxT id = ids[i];
   id_out  = id;
   if (id < 0) return world;  // trailing "never sent" bucket
-  return owner_of(static_cast<uint64_t>(id), s_off, world);
+  int o = owner_of(static_cast<uint64_t>(id), s_off, owners);
+  return owners == world ? o : o % world;
 }
 
 template <typename IdxT>
 __global__ __launch_bounds__(kBlock) void bucket_hist_kernel(const IdxT* ids, int64_t n, const uint64_t* entry_offsets,
-                                                             int world, int64_t chunk, int64_t* block_counts)
+                                                             int world, int owners, int64_t chunk,
+                                                             int64_t* block_counts)
 {
-  __shared__ uint64_t s_off[kMaxBuckets + 1];
+  __shared__ uint64_t s_off[kMaxOwners + 1];
   __shared__ int s_cnt[kMaxBuckets];
   const int nb = world + 1;
-  for (int i = threadIdx.x; i <= world; i += kBlock) s_off[i] = entry_offsets[i];
+  for (int i = threadIdx.x; i <= owners; i += kBlock) s_off[i] = entry_offsets[i];
   for (int i = threadIdx.x; i < nb; i += kBlock) s_cnt[i] = 0;
   __syncthreads();
   const int lane      = threadIdx.x & 63;
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void bucket_hist_kernel(const IdxT* ids, in
   const int64_t end   = min(begin + chunk, n);
   for (int64_t base = begin; base < end; base += kBlock) {
     IdxT id;
-    int b            = bucket_of(ids, base + threadIdx.x, end, s_off, world, id);
+    int b            = bucket_of(ids, base + threadIdx.x, end, s_off, world, owners, id);
     uint64_t pending = __ballot(b >= 0);
     while (pending) {  // one trip per distinct bucket present in this wave
       int leader    = __ffsll(static_cast<long long>(pending)) - 1;
@@ -140,17 +152,18 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(int64_t* block_counts
 template <typename IdxT>
 __global__ __launch_bounds__(kBlock) void bucket_scatter_kernel(const IdxT* ids, int64_t n,
                                                                 const uint64_t* entry_offsets, int world,
-                                                                int64_t chunk, const int64_t* block_offsets,
-                                                                IdxT* bucketed_ids, int64_t* raw_indices)
+                                                                int owners, int64_t chunk,
+                                                                const int64_t* block_offsets, IdxT* bucketed_ids,
+                                                                int64_t* raw_indices)
 {
-  __shared__ uint64_t s_off[kMaxBuckets + 1];
+  __shared__ uint64_t s_off[kMaxOwners + 1];
   __shared__ int64_t s_run[kMaxBuckets];          // next free slot per bucket for this block
   __shared__ volatile int s_wcnt[kWaves][kMaxBuckets];  // per-wave counts of the current iteration
   __shared__ int64_t s_wbase[kWaves][kMaxBuckets];
   const int nb   = world + 1;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i <= world; i += kBlock) s_off[i] = entry_offsets[i];
+  for (int i = threadIdx.x; i <= owners; i += kBlock) s_off[i] = entry_offsets[i];
   for (int i = threadIdx.x; i < nb; i += kBlock)
     s_run[i] = block_offsets[static_cast<int64_t>(i) * gridDim.x + blockIdx.x];
   __syncthreads();
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void bucket_scatter_kernel(const IdxT* ids,
 #pragma unroll
     for (int j = 0; j < kItems; j++) {
       const int64_t pos = it + static_cast<int64_t>(wave) * (64 * kItems) + j * 64 + lane;
-      bkt[j]            = bucket_of(ids, pos, end, s_off, world, id[j]);
+      bkt[j]            = bucket_of(ids, pos, end, s_off, world, owners, id[j]);
       rank[j]           = 0;
       uint64_t pending  = __ballot(bkt[j] >= 0);
       while (pending) {
@@ -212,14 +225,15 @@ int run_bucket(const wm_bucket_args* a, hipStream_t stream)
   bucket_geom g         = geometry(a->n);
   int64_t* block_counts = static_cast<int64_t*>(a->workspace);
   const IdxT* ids       = static_cast<const IdxT*>(a->indices);
+  const int owners      = a->owner_count > 0 ? a->owner_count : a->world_size;
   hipLaunchKernelGGL((bucket_hist_kernel<IdxT>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n, a->entry_offsets,
-                     a->world_size, g.chunk, block_counts);
+                     a->world_size, owners, g.chunk, block_counts);
   hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, block_counts, g.blocks, a->world_size,
                      a->counts);
   if (a->bucketed_ids != nullptr && a->raw_indices != nullptr) {
     hipLaunchKernelGGL((bucket_scatter_kernel<IdxT>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n,
-                       a->entry_offsets, a->world_size, g.chunk, block_counts, static_cast<IdxT*>(a->bucketed_ids),
-                       a->raw_indices);
+                       a->entry_offsets, a->world_size, owners, g.chunk, block_counts,
+                       static_cast<IdxT*>(a->bucketed_ids), a->raw_indices);
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -236,6 +250,7 @@ int hip_bucket_ids(const wm_bucket_args* a, void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (a->world_size < 1 || a->world_size + 1 > kMaxBuckets) return -1;
+  if (a->owner_count > kMaxOwners || (a->owner_count > 0 && a->owner_count < a->world_size)) return -1;
   if (a->n == 0) {  // reference bucket_ids_func.cu:121-122: counts zeroed, nothing launched
     return hipMemsetAsync(a->counts, 0, sizeof(int64_t) * a->world_size, stream) == hipSuccess ? 0 : -2;
   }

@@ -57,6 +57,10 @@ struct wholememory_handle_ {
   size_t shm_bytes   = 0;
   // multi-rank CONTINUOUS device memory (HIP VMM)
   wm::vmm_mapping vmm;
+  // HIERARCHY: ranks of this node / ranks with this local rank on every node (owned by the handle;
+  // reference hierarchy_wholememory_impl, memory_handle.cpp:1756-1790,1899-1912)
+  wholememory_comm_t local_comm = nullptr;
+  wholememory_comm_t cross_comm = nullptr;
 };
 
 namespace wm {
@@ -196,6 +200,18 @@ void create_memory(wholememory_handle_* h)
     alloc_local(h);
     return;
   }
+  if (h->type == WHOLEMEMORY_MT_HIERARCHY) {
+    // stored like DISTRIBUTED (every rank holds its own range, nothing mapped); what differs is the route of a gather:
+    // within the node first, then between nodes along the "rail" of equal local ranks (ops.cpp gather_hierarchy)
+    const int L = h->comm->local_size;
+    if (wholememory_split_communicator(&h->local_comm, h->comm, h->comm->world_rank / L, h->comm->world_rank % L) !=
+          WHOLEMEMORY_SUCCESS ||
+        wholememory_split_communicator(&h->cross_comm, h->comm, h->comm->world_rank % L, h->comm->world_rank / L) !=
+          WHOLEMEMORY_SUCCESS)
+      throw logic_error("cannot split the communicator for a HIERARCHY allocation");
+    alloc_local(h);
+    return;
+  }
   if (W == 1) {  // flat allocation serves every mapped type
     alloc_local(h);
     h->global_base = h->local_ptr;
@@ -227,6 +243,9 @@ void destroy_memory(wholememory_handle_* h) noexcept
   const auto* bk = backend();
   const int W    = h->comm->world_size;
   const int rank = h->comm->world_rank;
+  if (h->local_comm != nullptr) wholememory_destroy_communicator(h->local_comm);
+  if (h->cross_comm != nullptr) wholememory_destroy_communicator(h->cross_comm);
+  h->local_comm = h->cross_comm = nullptr;
   if (h->dev_rank_ptrs) bk->free_device(h->dev_rank_ptrs);
   if (h->dev_rank_offsets) bk->free_device(h->dev_rank_offsets);
   if (h->vmm.base != nullptr) {
@@ -276,11 +295,17 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* wholememory_ha
     return WHOLEMEMORY_INVALID_VALUE;
   }
   if (memory_type != WHOLEMEMORY_MT_CONTINUOUS && memory_type != WHOLEMEMORY_MT_CHUNKED &&
-      memory_type != WHOLEMEMORY_MT_DISTRIBUTED) {
-    WM_ERROR("wholememory_malloc: memory type %d is not supported by this build", static_cast<int>(memory_type));
-    return memory_type == WHOLEMEMORY_MT_HIERARCHY ? WHOLEMEMORY_NOT_SUPPORTED : WHOLEMEMORY_INVALID_INPUT;
+      memory_type != WHOLEMEMORY_MT_DISTRIBUTED && memory_type != WHOLEMEMORY_MT_HIERARCHY) {
+    WM_ERROR("wholememory_malloc: unknown memory type %d", static_cast<int>(memory_type));
+    return WHOLEMEMORY_INVALID_INPUT;
   }
   if (memory_location != WHOLEMEMORY_ML_DEVICE && memory_location != WHOLEMEMORY_ML_HOST) return WHOLEMEMORY_INVALID_INPUT;
+  if (wholememory_communicator_support_type_location(comm, memory_type, memory_location) != WHOLEMEMORY_SUCCESS) {
+    WM_ERROR("wholememory_malloc: memory type %d is not available on this communicator (%d ranks, %d on this node%s)",
+             static_cast<int>(memory_type), comm->world_size, comm->local_size,
+             comm->regular_nodes ? "" : ", nodes of unequal size or interleaved ranks");
+    return WHOLEMEMORY_NOT_SUPPORTED;
+  }
   if (rank_entry_partition != nullptr) {
     size_t sum = 0;
     for (int i = 0; i < comm->world_size; i++) {
@@ -332,13 +357,20 @@ wholememory_error_code_t wholememory_get_communicator(wholememory_comm_t* comm, 
   *comm = h->comm;
   return WHOLEMEMORY_SUCCESS;
 }
-wholememory_error_code_t wholememory_get_local_communicator(wholememory_comm_t*, wholememory_handle_t)
+// HIERARCHY handles only (reference memory_handle.cpp:1988-2017: other memory types answer NOT_SUPPORTED)
+wholememory_error_code_t wholememory_get_local_communicator(wholememory_comm_t* comm, wholememory_handle_t h)
 {
-  return WHOLEMEMORY_NOT_SUPPORTED;  // HIERARCHY only
+  if (comm == nullptr || h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (h->type != WHOLEMEMORY_MT_HIERARCHY) return WHOLEMEMORY_NOT_SUPPORTED;
+  *comm = h->local_comm;
+  return WHOLEMEMORY_SUCCESS;
 }
-wholememory_error_code_t wholememory_get_cross_communicator(wholememory_comm_t*, wholememory_handle_t)
+wholememory_error_code_t wholememory_get_cross_communicator(wholememory_comm_t* comm, wholememory_handle_t h)
 {
-  return WHOLEMEMORY_NOT_SUPPORTED;  // HIERARCHY only
+  if (comm == nullptr || h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (h->type != WHOLEMEMORY_MT_HIERARCHY) return WHOLEMEMORY_NOT_SUPPORTED;
+  *comm = h->cross_comm;
+  return WHOLEMEMORY_SUCCESS;
 }
 wholememory_memory_type_t wholememory_get_memory_type(wholememory_handle_t h) { return h ? h->type : WHOLEMEMORY_MT_NONE; }
 wholememory_memory_location_t wholememory_get_memory_location(wholememory_handle_t h)

@@ -67,14 +67,18 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   x->send_offsets.assign(W + 1, 0);
   x->recv_offsets.assign(W + 1, 0);
 
+  // entry_offsets describes `owners` row ranges. Normally owners == W (one bucket per rank of `comm`); with more
+  // owners than ranks an id of owner o travels to rank o % W (first hop of the HIERARCHY gather)
+  const int owners = static_cast<int>(entry_offsets.size()) - 1;
+  WM_CHECK(owners >= W, "bucket_and_exchange_ids: fewer row ranges than ranks");
   temp_mem dev_offsets(env), dev_counts(env), workspace(env), host_counts(env);
-  auto* d_off = static_cast<uint64_t*>(dev_offsets.device(W + 1, WHOLEMEMORY_DT_INT64));
+  auto* d_off = static_cast<uint64_t*>(dev_offsets.device(owners + 1, WHOLEMEMORY_DT_INT64));
   auto* d_cnt = static_cast<int64_t*>(dev_counts.device(W, WHOLEMEMORY_DT_INT64));
-  auto* h_cnt = static_cast<int64_t*>(host_counts.pinned(2 * (W + 1), WHOLEMEMORY_DT_INT64));
+  auto* h_cnt = static_cast<int64_t*>(host_counts.pinned(W + owners + 1, WHOLEMEMORY_DT_INT64));
   // stage the offsets through pinned memory so the H2D copy is truly asynchronous
   uint64_t* h_off = reinterpret_cast<uint64_t*>(h_cnt + W);
-  for (int i = 0; i <= W; i++) h_off[i] = entry_offsets[i];
-  WM_BK(bk->memcpy_async(d_off, h_off, sizeof(uint64_t) * (W + 1), stream));
+  for (int i = 0; i <= owners; i++) h_off[i] = entry_offsets[i];
+  WM_BK(bk->memcpy_async(d_off, h_off, sizeof(uint64_t) * (owners + 1), stream));
 
   x->bucketed_ids = x->bucketed_mem.device(n, index_dtype);
   x->raw_indices  = static_cast<int64_t*>(x->raw_mem.device(n, WHOLEMEMORY_DT_INT64));
@@ -85,6 +89,7 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   ba.n             = n;
   ba.entry_offsets = d_off;
   ba.world_size    = W;
+  ba.owner_count   = owners == W ? 0 : owners;
   ba.counts        = d_cnt;
   ba.bucketed_ids  = x->bucketed_ids;
   ba.raw_indices   = x->raw_indices;
@@ -93,7 +98,7 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   WM_BK(bk->memcpy_async(h_cnt, d_cnt, sizeof(int64_t) * W, stream));
   WM_BK(bk->stream_sync(stream));
   for (int i = 0; i < W; i++) x->send_counts[i] = h_cnt[i];
-  comm->alltoall_host_i64(x->send_counts.data(), x->recv_counts.data());
+  comm->alltoall_host_i64(x->send_counts.data(), x->recv_counts.data(), &x->global_moved);
   // bucketed layout (all owners, self included) — positions into bucketed_ids / raw_indices
   x->bucket_offsets.assign(W + 1, 0);
   for (int i = 0; i < W; i++) x->bucket_offsets[i + 1] = x->bucket_offsets[i] + x->send_counts[i];
@@ -190,13 +195,15 @@ bool mapped_via_exchange(wholememory_tensor_t t, wholememory_memory_type_t mt)
   return comm->world_size > 1;
 }
 
-int exchange_chunks(int world_size, int64_t rows_moved)
+// Every rank of the exchange must arrive at the same number (each chunk is one collective call), so the decision may only
+// use what all ranks know alike: the world size, the environment and id_exchange::global_moved.
+int exchange_chunks(int world_size, int64_t global_moved)
 {
   if (world_size <= 1) return 1;
   const char* e = getenv("WM_EXCHANGE_CHUNKS");
   if (e != nullptr && atoi(e) >= 1) return std::min(atoi(e), 16);
-  // below ~256 k rows the exchange is latency-bound and extra launches only add overhead
-  return rows_moved >= (1 << 18) ? 4 : 1;
+  // below ~256 k rows in and out of the average rank the exchange is latency-bound and extra launches only add overhead
+  return 2 * global_moved / world_size >= (1 << 18) ? 4 : 1;
 }
 
 event_set::event_set(int n) : events_(n, nullptr)
@@ -316,9 +323,16 @@ wholememory_error_code_t mapped_gref(wholememory_tensor_t t, wholememory_gref_t*
   return wholememory_tensor_get_global_reference(t, gref);
 }
 
+// the exchange normally runs over the handle's communicator with its per-rank row ranges; a `route` substitutes another
+// communicator and another set of ranges over the same local shard (second hop of the HIERARCHY gather)
+struct route {
+  wholememory_comm_t comm;
+  std::vector<size_t> offsets;  // comm->world_size + 1 row offsets
+};
 wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, const op_descs& d,
                                                  wholememory_env_func_t* env, void* stream, int gather_sms,
-                                                 row_cache* cache = nullptr, bool adjust_cache = false);
+                                                 row_cache* cache = nullptr, bool adjust_cache = false,
+                                                 const route* via = nullptr);
 
 // WM_GATHER_DEDUP=1 (not in the reference): a skewed batch asks for the same hot rows over and over — Zipf(1.05),
 // 10 M ids: 49 % unique — and every copy crosses xGMI. With this switch the requester de-duplicates its ids first
@@ -378,7 +392,7 @@ wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const o
 // embedding.cpp:576-760); with adjust_cache the ids that arrive at this owner update the cache first.
 wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, const op_descs& d,
                                                  wholememory_env_func_t* env, void* stream, int gather_sms,
-                                                 row_cache* cache, bool adjust_cache)
+                                                 row_cache* cache, bool adjust_cache, const route* via)
 {
   const auto* bk = backend();
   if (d.table.storage_offset < 0 || d.table.storage_offset + d.table.sizes[1] > d.table.stride)
@@ -390,6 +404,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   const size_t ies         = wholememory_dtype_get_element_size(d.indices.dtype);
   const int64_t dim        = d.table.sizes[1];
   auto entry_offsets       = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
+  if (via != nullptr) comm = via->comm, entry_offsets = via->offsets;
   const char* indices      = static_cast<const char*>(d.indices_ptr);  // data pointer: offset already applied
   if (comm->world_size == 1 && cache == nullptr) {
     // one rank owns every row: nothing to bucket or exchange, the gather kernel itself skips negative ids
@@ -442,7 +457,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   const size_t row_bytes = static_cast<size_t>(dim) * oes;
   const int W            = comm->world_size;
   const int rank         = comm->world_rank;
-  const int C            = exchange_chunks(W, x.total_recv + x.total_send);
+  const int C            = exchange_chunks(W, x.global_moved);
   const auto out_gref    = wholememory_create_continuous_global_reference(d.plain_ptr);
   auto chunk_of = [C](int64_t n, int c, int64_t* a, int64_t* b) {
     *a = n * c / C;
@@ -512,6 +527,109 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
     reorder_chunk(C - 1);                                   // scratch buffers before anything later on `stream`
   }
   if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+  return WHOLEMEMORY_SUCCESS;
+}
+
+// HIERARCHY tables (reference wholememory_gather_hierarchy, gather_op_impl_hierarchy.cu:117-352): rows are owned as in
+// DISTRIBUTED, but a request reaches a remote node in two hops so that traffic between nodes only ever flows between
+// equal local ranks ("rails") and every distinct row crosses the network once per node-local relay:
+//   A  ids -> the rank of MY node whose local rank equals the owner's (all-to-all-v inside the node, xGMI)
+//   B  the relay de-duplicates what it received and fetches each distinct row from its owner — same local rank, another
+//      node — by the ordinary exchange over the cross-node communicator (ids out, rows back), then expands the
+//      duplicates again
+//   A' rows return to the requesters inside the node and are placed by their original positions
+// Results are those of a DISTRIBUTED gather; only the route differs. Collective over the table's communicator: every
+// rank must call, also one that asks for nothing (it still relays and serves).
+wholememory_error_code_t gather_hierarchy(wholememory_handle_t handle, const op_descs& d, wholememory_env_func_t* env,
+                                          void* stream, int gather_sms)
+{
+  const auto* bk = backend();
+  if (d.table.storage_offset < 0 || d.table.storage_offset + d.table.sizes[1] > d.table.stride)
+    return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_comm_t comm, local_comm, cross_comm;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, handle));
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_local_communicator(&local_comm, handle));
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_cross_communicator(&cross_comm, handle));
+  const int L = local_comm->world_size, X = cross_comm->world_size;
+  WM_CHECK(L * X == comm->world_size, "HIERARCHY: local size x cross size != world size");
+  const size_t tes   = wholememory_dtype_get_element_size(d.table.dtype);
+  const size_t oes   = wholememory_dtype_get_element_size(d.plain.dtype);
+  const int64_t dim  = d.table.sizes[1];
+  const int64_t n    = d.indices.size;
+  auto entry_offsets = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
+  route rail{cross_comm, std::vector<size_t>(X + 1)};  // hop B: node k holds the rows of ranks [k*L, (k+1)*L)
+  for (int k = 0; k <= X; k++) rail.offsets[k] = entry_offsets[static_cast<size_t>(k) * L];
+  if (L == 1)  // one rank per node: no relay, the rail exchange is the whole gather
+    return gather_distributed_rows(handle, d, env, stream, gather_sms, nullptr, false, &rail);
+
+  // ---- hop A: ids to the relay (all W row ranges, folded onto the L ranks of this node by owner % L) ----
+  id_exchange xa(env);
+  bucket_and_exchange_ids(local_comm, d.indices_ptr, d.indices.dtype, n, entry_offsets, env, stream, &xa, false);
+  const int64_t n_relay = xa.total_recv;
+
+  // ---- relay: distinct ids only (reference sort_unique_ids_for_hierarchy_func) ----
+  temp_mem unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env), host_n(env), inverse(env);
+  const bool dedup = n_relay > 0 && n_relay < (INT64_C(1) << 31) && bk->run_inverse != nullptr;
+  void* fetch_ids  = xa.recv_ids;
+  int64_t n_fetch  = n_relay;
+  int64_t* inv     = nullptr;
+  if (dedup) {
+    void* d_unique  = unique_ids.device(n_relay, d.indices.dtype);
+    auto* d_starts  = static_cast<int32_t*>(run_starts.device(n_relay + 1, WHOLEMEMORY_DT_INT));
+    auto* d_order   = static_cast<int32_t*>(order.device(n_relay, WHOLEMEMORY_DT_INT));
+    auto* d_nunique = static_cast<int64_t*>(n_unique.device(1, WHOLEMEMORY_DT_INT64));
+    void* d_ws = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n_relay, d.indices.dtype)), WHOLEMEMORY_DT_INT8);
+    int rc = bk->dedup_ids(xa.recv_ids, d.indices.dtype, n_relay, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
+    if (rc != 0) throw hip_error("dedup of relayed ids failed");  // not a return: the peers are already committed to hop B
+    inv = static_cast<int64_t*>(inverse.device(n_relay, WHOLEMEMORY_DT_INT64));
+    WM_BK(bk->run_inverse(d_starts, d_order, d_unique, d.indices.dtype, d_nunique, n_relay, inv, stream));
+    auto* h_n = static_cast<int64_t*>(host_n.pinned(1, WHOLEMEMORY_DT_INT64));
+    WM_BK(bk->memcpy_async(h_n, d_nunique, sizeof(int64_t), stream));
+    WM_BK(bk->stream_sync(stream));
+    fetch_ids = d_unique;
+    n_fetch   = *h_n;
+  }
+
+  // ---- hop B: each distinct row from its owner over the rail, already in the output dtype ----
+  temp_mem fetched(env), relay_rows(env), back_rows(env);
+  char* fetched_buf = static_cast<char*>(fetched.device(dim * n_fetch, d.plain.dtype));
+  op_descs db       = d;
+  db.indices_ptr    = fetch_ids;
+  db.indices        = wholememory_create_array_desc(n_fetch, 0, d.indices.dtype);
+  db.plain_ptr      = fetched_buf;
+  int64_t fsz[2]    = {n_fetch, dim};
+  db.plain          = wholememory_create_matrix_desc(fsz, dim, 0, d.plain.dtype);
+  WHOLEMEMORY_RETURN_ON_FAIL(gather_distributed_rows(handle, db, env, stream, gather_sms, nullptr, false, &rail));
+
+  // ---- expand the duplicates: relay_rows[j] = fetched[run of j], in the order the ids arrived in hop A ----
+  char* send_buf = fetched_buf;
+  WM_DEBUG("HIERARCHY gather: rank %d (local %d of %d, node %d of %d) asked %ld ids, relays %ld, fetches %ld distinct",
+           comm->world_rank, local_comm->world_rank, L, cross_comm->world_rank, X, static_cast<long>(n),
+           static_cast<long>(n_relay), static_cast<long>(n_fetch));
+  if (dedup) {
+    send_buf       = static_cast<char*>(relay_rows.device(dim * n_relay, d.plain.dtype));
+    int64_t rsz[2] = {n_relay, dim};
+    auto relay_desc = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
+    wm_rows_args ea{};
+    fill_rows_args(&ea, wholememory_create_continuous_global_reference(fetched_buf), db.plain, inv, WHOLEMEMORY_DT_INT64,
+                   n_relay, send_buf, relay_desc, gather_sms);
+    WM_BK(bk->gather_rows(&ea, stream));
+  }
+
+  // ---- hop A': rows back inside the node, then out[raw_indices[j]] = row j of the bucketed layout ----
+  const size_t row_bytes = static_cast<size_t>(dim) * oes;
+  char* back_buf = static_cast<char*>(back_rows.device(dim * xa.total_valid, d.plain.dtype));
+  exchange_segments(local_comm, send_buf, xa.recv_counts, xa.recv_offsets, back_buf, xa.send_counts, xa.bucket_offsets,
+                    row_bytes, stream);
+  if (xa.total_valid > 0) {
+    int64_t bsz[2] = {xa.total_valid, dim};
+    auto back_desc = wholememory_create_matrix_desc(bsz, dim, 0, d.plain.dtype);
+    wm_rows_args ra{};
+    fill_rows_args(&ra, wholememory_create_continuous_global_reference(d.plain_ptr), d.plain, xa.raw_indices,
+                   WHOLEMEMORY_DT_INT64, xa.total_valid, back_buf, back_desc, -1);
+    WM_BK(bk->scatter_rows(&ra, stream));
+  }
+  WM_BK(bk->stream_sync(stream));  // scratch buffers return to the caller's allocator
   return WHOLEMEMORY_SUCCESS;
 }
 
@@ -626,7 +744,7 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
   const size_t row_bytes = static_cast<size_t>(dim) * pes;
   const int W            = comm->world_size;
   const int rank         = comm->world_rank;
-  const int C            = exchange_chunks(W, x.total_recv + x.total_send);
+  const int C            = exchange_chunks(W, x.global_moved);
   const auto in_gref     = wholememory_create_continuous_global_reference(d.plain_ptr);
   auto chunk_of = [C](int64_t n, int c, int64_t* a, int64_t* b) {
     *a = n * c / C;
@@ -717,6 +835,8 @@ wholememory_error_code_t wholememory_gather(wholememory_tensor_t wholememory_ten
                        : WHOLEMEMORY_MT_NONE;
   if (has_handle && (mt == WHOLEMEMORY_MT_DISTRIBUTED || wm::mapped_via_exchange(wholememory_tensor, mt)))
     return wm::gather_distributed(wholememory_tensor_get_memory_handle(wholememory_tensor), d, p_env_fns, stream, gather_sms);
+  if (has_handle && mt == WHOLEMEMORY_MT_HIERARCHY)  // gather_op.cpp:96-107
+    return wm::gather_hierarchy(wholememory_tensor_get_memory_handle(wholememory_tensor), d, p_env_fns, stream, gather_sms);
   if (has_handle && mt != WHOLEMEMORY_MT_CHUNKED && mt != WHOLEMEMORY_MT_CONTINUOUS) return WHOLEMEMORY_NOT_SUPPORTED;
   wholememory_gref_t gref;
   WHOLEMEMORY_RETURN_ON_FAIL(wm::mapped_gref(wholememory_tensor, &gref));
@@ -743,7 +863,10 @@ wholememory_error_code_t wholememory_scatter(wholememory_tensor_t input_tensor,
   const bool has_handle = wholememory_tensor_has_handle(wholememory_tensor);
   auto mt = has_handle ? wholememory_get_memory_type(wholememory_tensor_get_memory_handle(wholememory_tensor))
                        : WHOLEMEMORY_MT_NONE;
-  if (has_handle && (mt == WHOLEMEMORY_MT_DISTRIBUTED || wm::mapped_via_exchange(wholememory_tensor, mt)))
+  // HIERARCHY rows are owned exactly as DISTRIBUTED rows, and a scatter has nothing to de-duplicate on the way: it takes
+  // the direct exchange (the reference rejects scatter on HIERARCHY tables, scatter_op.cpp:94-97)
+  if (has_handle && (mt == WHOLEMEMORY_MT_DISTRIBUTED || mt == WHOLEMEMORY_MT_HIERARCHY ||
+                     wm::mapped_via_exchange(wholememory_tensor, mt)))
     return wm::scatter_distributed(wholememory_tensor_get_memory_handle(wholememory_tensor), d, p_env_fns, stream, scatter_sms);
   if (has_handle && mt != WHOLEMEMORY_MT_CHUNKED && mt != WHOLEMEMORY_MT_CONTINUOUS) return WHOLEMEMORY_NOT_SUPPORTED;
   wholememory_gref_t gref;
@@ -769,8 +892,25 @@ wholememory_error_code_t wholememory_ext_bucket_ids(const void* indices,
                                                     wholememory_env_func_t* p_env_fns,
                                                     void* stream)
 {
+  return wholememory_ext_bucket_ids_folded(indices, index_dtype, n, entry_offsets_dev, world_size, world_size, counts_dev,
+                                           bucketed_ids_dev, raw_indices_dev, p_env_fns, stream);
+}
+
+wholememory_error_code_t wholememory_ext_bucket_ids_folded(const void* indices,
+                                                           wholememory_dtype_t index_dtype,
+                                                           int64_t n,
+                                                           const void* entry_offsets_dev,
+                                                           int owner_count,
+                                                           int world_size,
+                                                           int64_t* counts_dev,
+                                                           void* bucketed_ids_dev,
+                                                           int64_t* raw_indices_dev,
+                                                           wholememory_env_func_t* p_env_fns,
+                                                           void* stream)
+{
   WM_API_BEGIN
   if (n < 0 || world_size < 1 || counts_dev == nullptr || entry_offsets_dev == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (owner_count < world_size) return WHOLEMEMORY_INVALID_INPUT;
   if ((bucketed_ids_dev == nullptr) != (raw_indices_dev == nullptr)) return WHOLEMEMORY_INVALID_INPUT;
   const auto* bk = wm::backend();
   wm::temp_mem ws(p_env_fns);
@@ -780,6 +920,7 @@ wholememory_error_code_t wholememory_ext_bucket_ids(const void* indices,
   ba.n             = n;
   ba.entry_offsets = static_cast<const uint64_t*>(entry_offsets_dev);
   ba.world_size    = world_size;
+  ba.owner_count   = owner_count == world_size ? 0 : owner_count;
   ba.counts        = counts_dev;
   ba.bucketed_ids  = bucketed_ids_dev;
   ba.raw_indices   = raw_indices_dev;

@@ -42,6 +42,7 @@ struct id_exchange {
   int64_t total_send  = 0;                          // ids that travel
   int64_t total_recv  = 0;                          // ids received from peers
   int64_t total_valid = 0;                          // non-negative ids of this rank (all owners)
+  int64_t global_moved = 0;                         // ids that change rank, summed over ALL ranks (same on every rank)
   int64_t self_count  = 0;                          // ids of this rank that it owns itself
   int64_t self_offset = 0;                          // their position in bucketed_ids / raw_indices
   void* bucketed_ids   = nullptr;                   // [n]   ids grouped by owner (index dtype)
@@ -63,8 +64,9 @@ void exchange_segments(wholememory_comm_t comm, const void* send, const std::vec
 void exchange_rows(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts, void* recv,
                    const std::vector<int64_t>& recv_counts, size_t row_bytes, void* stream);
 
-// number of row-chunks the rows all-to-all-v is pipelined in (WM_EXCHANGE_CHUNKS overrides; 1 = no pipelining)
-int exchange_chunks(int world_size, int64_t rows_moved);
+// number of row-chunks the rows all-to-all-v is pipelined in (WM_EXCHANGE_CHUNKS overrides; 1 = no pipelining);
+// global_moved = id_exchange::global_moved, so that every rank decides alike
+int exchange_chunks(int world_size, int64_t global_moved);
 
 // RAII bundle of backend events
 class event_set {
