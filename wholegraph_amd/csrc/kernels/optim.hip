@@ -307,7 +307,10 @@ __device__ __forceinline__ void apply_optimizer(const wm_optimizer_args& a, int6
 #ifndef WM_STEP_K
 #define WM_STEP_K 4
 #endif
-template <typename IdxT, int OPT, int V, typename T = float>
+// CACHED: the table has a device row cache (wm_optimizer_args::cache_slot_of) and every row is addressed through its
+// slot map. Compiled out otherwise: with the per-row select between two bases in the way, hipcc keeps the row addresses
+// in VGPR pairs instead of scalar base + lane offset, and the plain kernel lost a quarter of its speed (3.1 -> 3.9 ms).
+template <typename IdxT, int OPT, int V, typename T = float, bool CACHED = true>
 __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
 {
   typedef float vec_t __attribute__((ext_vector_type(V)));
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
 #pragma unroll
     for (int k = 0; k < K; k++) {
       r.o0[k]     = a.order[m.s0[k]];
-      r.slot[k]   = cache_slot(a, m.local[k]);
+      r.slot[k]   = CACHED ? cache_slot(a, m.local[k]) : -1;
       r.beta1t[k] = r.beta2t[k] = 0.f;
       if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) {
         r.beta1t[k] = a.per_row_state[m.local[k] * 2 + 0] * a.beta1;
@@ -385,9 +388,14 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
     float* st[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
-      row[k] = table_row_at<T>(a, m_cur.local[k], r_cur.slot[k]);
-      st[k]  = state_row_at(a, m_cur.local[k], r_cur.slot[k]);
-      if (live[k] && r_cur.slot[k] >= 0 && lane == 0) a.cache_dirty[r_cur.slot[k]] = 1;
+      if (CACHED) {
+        row[k] = table_row_at<T>(a, m_cur.local[k], r_cur.slot[k]);
+        st[k]  = state_row_at(a, m_cur.local[k], r_cur.slot[k]);
+        if (live[k] && r_cur.slot[k] >= 0 && lane == 0) a.cache_dirty[r_cur.slot[k]] = 1;
+      } else {
+        row[k] = static_cast<T*>(a.local_table) + m_cur.local[k] * a.table_stride;
+        st[k]  = OPT != WHOLEMEMORY_OPT_SGD ? a.per_element_state + m_cur.local[k] * a.per_element_stride : nullptr;
+      }
     }
     for (int64_t d = static_cast<int64_t>(lane) * V; d < a.dim; d += 64 * V) {
       vec_t acc[K];
@@ -516,17 +524,24 @@ __global__ __launch_bounds__(kBlock) void step_long_kernel(opt_params p)
 // slice) into a ring of kRing tile buffers — no staging registers, and because the compiler does not track LDS-DMA
 // results the waits are hand-counted `s_waitcnt vmcnt(N)` + raw `s_barrier`, so kRing - 1 tiles really stay in flight
 // while one is folded (a register ring does not survive hipcc's s_waitcnt placement: it drains at every loop trip).
-// Loads return in issue order (vmcnt), so order[] reads interleaved with row reads would drain the ring: the order[]
-// entries of a CHUNK of 4096 rows are staged in LDS once and row addresses then come out of LDS. One wave folds a tile,
-// unpredicated for full tiles. Summation order per element is unchanged (receive order, first row copied): results
-// stay bit-identical.
+// Loads return in issue order (vmcnt), so order[] reads interleaved with row reads would drain the ring: row addresses
+// come out of LDS, where the order[] entries are kept a chunk of 2048 rows at a time in two alternating buffers — the
+// folding wave fetches chunk c + 1 into registers while chunk c is folded and drops it into the free buffer, so the tile
+// ring runs through a whole run without draining (with one buffer refilled between chunks a 527 k-row run lost ~8 us
+// per 4096 rows, 1.1 of 4.5 ms, to the refill and the restart of the ring). One wave folds a tile, unpredicated for
+// full tiles; in-situ counters on that run: fold 11.5 cycles per row (6 for the LDS reads, 6 for the dependent add — a
+// single wave overlaps neither with the other, experiments/fold_microbench.hip), fetch of the 256-byte slices at
+// ~38 GB/s per CU, i.e. both sides now take about the same 2.5-3.5 ms. Summation order per element is unchanged
+// (receive order, first row copied): results stay bit-identical.
 
-constexpr int kOrdChunk  = 4096;
+constexpr int kOrdChunk  = 2048;   // order[] entries per LDS buffer (two buffers)
 constexpr int kRing      = 4;
-constexpr int kSlice4    = 64;     // columns per workgroup = lanes of the folding wave (measured on the Zipf batch, fp32:
-                                   // 16 columns 6.8 ms, 32 columns 5.1 ms, 64 columns 4.5 ms)
+constexpr int kSlice4    = 64;     // columns per workgroup = lanes of the folding wave. Narrower slices spread the fetch of a
+                                   // run over more CUs but the fold costs the same per ROW whatever its width, and more
+                                   // with rows that are not 256 B apart in LDS (no ds_read2st64): measured on the Zipf
+                                   // batch, fp32, 32 columns 4.0 ms, 64 columns 3.5 ms
 constexpr int kTileBytes = 32768;  // one LDS tile
-constexpr size_t kLong4LdsBytes = static_cast<size_t>(kRing) * kTileBytes + kOrdChunk * 4;
+constexpr size_t kLong4LdsBytes = static_cast<size_t>(kRing) * kTileBytes + 2 * kOrdChunk * 4;
 
 constexpr int kLongProducers = 4;                          // waves that only fetch
 constexpr int kLongBlock     = 64 * (kLongProducers + 1);  // + wave 0, which only folds
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
   constexpr int kTile4Rows = kTileBytes / kRowBytes;                    // rows per LDS tile
   constexpr int kE16       = 16 / static_cast<int>(sizeof(T));          // elements per 16-byte piece
   T* const tiles       = reinterpret_cast<T*>(lds4);                                        // [kRing][kTile4Rows][S]
-  int32_t* const ord_s = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(lds4) + kRing * kTileBytes);  // [kOrdChunk]
+  int32_t* const ord_s = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(lds4) + kRing * kTileBytes);  // [2][kOrdChunk]
   const wm_optimizer_args& a = p.a;
   const int n_long           = *p.long_count;
   const IdxT* ids            = static_cast<const IdxT*>(a.ids);
@@ -560,58 +575,88 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
   const int r_lane    = lane / kLpr;
   const bool folder   = threadIdx.x < cols;  // one column per lane of wave 0
 
+  constexpr int kTpc   = kOrdChunk / kTile4Rows;  // tiles per chunk of order[] entries
+  constexpr int kPre   = kOrdChunk / 64;          // entries per lane of wave 0 when it carries a whole chunk in registers
+  static_assert((kOrdChunk & (kOrdChunk - 1)) == 0 && kOrdChunk % kTile4Rows == 0 && kTpc > kRing, "a chunk is a whole number of tiles, more than the ring holds");
+
   for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
     const long_run_entry ent = p.long_list[li];
     const int64_t u          = ent.run;
     const int64_t local      = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
     const int32_t s0         = a.run_starts[u];
     const int32_t s1         = a.run_starts[u + 1];
+    const int32_t run_rows   = s1 - s0;
+    const int n_tiles        = (run_rows + kTile4Rows - 1) / kTile4Rows;
+    const int n_chunks       = (run_rows + kOrdChunk - 1) / kOrdChunk;
     float acc                = 0.f;
-    for (int32_t chunk = s0; chunk < s1; chunk += kOrdChunk) {
-      const int32_t chunk_rows = min(kOrdChunk, s1 - chunk);
-      const int n_tiles        = (chunk_rows + kTile4Rows - 1) / kTile4Rows;
-      __syncthreads();  // previous chunk fully folded; nothing of it is in flight (its last wait was vmcnt(0))
-      for (int i = threadIdx.x; i < kOrdChunk; i += kLongBlock) ord_s[i] = a.order[min(chunk + i, s1 - 1)];
-      __syncthreads();
-      // tile t -> ring slot t % kRing: kLoads LDS-DMA pieces per producer lane; producer w, piece i lands as the kRpp
-      // adjacent tile rows starting at kRpp (w + kLongProducers i) (wave-uniform LDS base + lane * 16 B). Rows are
-      // clamped into the chunk: tiles past its end re-read the last row, harmlessly — so every producer always has
-      // the same number of pieces in flight.
-      auto issue = [&](int t) {
-        T* slot = tiles + (t % kRing) * (kTile4Rows * S);
-        int32_t o[kLoads];
+    // order[] entries reach the producers through two LDS buffers of one chunk each (chunk c in buffer c % 2), so the
+    // tile ring never drains inside a run: chunk 0 is staged by everybody, every later chunk is fetched by wave 0 into
+    // registers a whole chunk ahead (plain loads — wave 0 has no LDS-DMA of its own to keep count of) and dropped into
+    // its buffer while chunk c - 1 is being folded. Entries past the end of the run repeat its last row.
+    __syncthreads();  // previous run: every tile folded, every LDS-DMA piece landed (vmcnt(0) below)
+    for (int i = threadIdx.x; i < min(kOrdChunk, run_rows); i += kLongBlock) ord_s[i] = a.order[s0 + i];
+    int32_t pre[kPre];
+    auto prefetch_chunk = [&](int c) {  // wave 0 only
 #pragma unroll
-        for (int i = 0; i < kLoads; i++)
-          o[i] = ord_s[min(t * kTile4Rows + kRpp * (wv + kLongProducers * i) + r_lane, chunk_rows - 1)];
+      for (int k = 0; k < kPre; k++) pre[k] = a.order[min(s0 + c * kOrdChunk + k * 64 + lane, s1 - 1)];
+    };
+    auto drop_chunk = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < kLoads; i++) {
-          const T* src = grad_row<T>(a, o[i]) + col0 + c_safe;
-          typedef __attribute__((address_space(1))) void gvoid;
-          typedef __attribute__((address_space(3))) void lvoid;
-          __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(slot + kRpp * (wv + kLongProducers * i) * S), 16, 0,
-                                           0);
-        }
-      };
-      if (producer) {
+      for (int k = 0; k < kPre; k++) ord_s[(c & 1) * kOrdChunk + k * 64 + lane] = pre[k];
+    };
+    if (!producer && n_chunks > 1) prefetch_chunk(1);
+    __syncthreads();
+    // tile t -> ring slot t % kRing: kLoads LDS-DMA pieces per producer lane; producer w, piece i lands as the kRpp
+    // adjacent tile rows starting at kRpp (w + kLongProducers i) (wave-uniform LDS base + lane * 16 B). Rows are
+    // clamped into the run: tiles past its end re-read the last row, harmlessly — so every producer always has
+    // the same number of pieces in flight.
+    auto issue = [&](int t) {
+      T* slot = tiles + (t % kRing) * (kTile4Rows * S);
+      int32_t o[kLoads];
 #pragma unroll
-        for (int j = 0; j < kRing - 1; j++) issue(j);
+      for (int i = 0; i < kLoads; i++) {
+        const int32_t row = min(t * kTile4Rows + kRpp * (wv + kLongProducers * i) + r_lane, run_rows - 1);
+        o[i]              = ord_s[row & (2 * kOrdChunk - 1)];  // chunk c lives in buffer c % 2
       }
-      for (int tt = 0; tt < n_tiles; tt++) {
-        // producers: tiles tt .. tt + kRing - 2 are in flight (kLoads pieces each, oldest first): tile tt has landed
-        // once at most kLoads * (kRing - 2) pieces remain; the barrier extends that to every producer's pieces and
-        // tells them that wave 0 is done with tile tt - 1, whose slot the next tile reuses
-        if (producer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads * (kRing - 2)) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (producer) {
-          issue(tt + kRing - 1);
-        } else if (folder) {
-          const int32_t rows = min(kTile4Rows, chunk_rows - tt * kTile4Rows);
+#pragma unroll
+      for (int i = 0; i < kLoads; i++) {
+        const T* src = grad_row<T>(a, o[i]) + col0 + c_safe;
+        typedef __attribute__((address_space(1))) void gvoid;
+        typedef __attribute__((address_space(3))) void lvoid;
+        __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(slot + kRpp * (wv + kLongProducers * i) * S), 16, 0, 0);
+      }
+    };
+    if (producer) {
+#pragma unroll
+      for (int j = 0; j < kRing - 1; j++) issue(j);
+    }
+    for (int tt = 0; tt < n_tiles; tt++) {
+      // producers: tiles tt .. tt + kRing - 2 are in flight (kLoads pieces each, oldest first): tile tt has landed
+      // once at most kLoads * (kRing - 2) pieces remain; the barrier extends that to every producer's pieces and
+      // tells them that wave 0 is done with tile tt - 1, whose slot the next tile reuses
+      if (producer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads * (kRing - 2)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (producer) {
+        issue(tt + kRing - 1);
+      } else {
+        // first tile of chunk c: buffer (c + 1) % 2 was last read for the tiles of chunk c - 1, all issued before the
+        // barrier just passed (kTpc > kRing); its new content is first read kTpc - kRing + 1 barriers from now
+        if (tt % kTpc == 0) {
+          const int c = tt / kTpc;
+          if (c + 1 < n_chunks) {
+            drop_chunk(c + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in LDS before this wave reaches the next barrier
+            if (c + 2 < n_chunks) prefetch_chunk(c + 2);
+          }
+        }
+        if (folder) {
+          const int32_t rows = min(kTile4Rows, run_rows - tt * kTile4Rows);
           const T* src       = tiles + (tt % kRing) * (kTile4Rows * S) + threadIdx.x;
-          if (rows == kTile4Rows && !(chunk == s0 && tt == 0)) {
-            // the hot loop, no predicates. A lone wave sees ~200 cycles from an LDS read to its use: 64 rows are read
-            // back to back (hipcc waits for all of them — its lgkmcnt placement does not keep a second batch in
-            // flight), then folded by 64 dependent adds
+          if (rows == kTile4Rows && tt != 0) {
+            // the hot loop, no predicates. One wave pays ~6 cycles per row for its LDS reads (ds_read2st64_b32 when the
+            // rows are 256 B apart) and ~6 for each dependent add, and the two do not overlap inside one wave however
+            // the reads are scheduled (experiments/fold_microbench.hip): 64 rows are read back to back, then folded
 #pragma unroll 1
             for (int32_t r = 0; r < kTile4Rows; r += 64) {
               float v[64];
@@ -622,7 +667,7 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
             }
           } else {
             int32_t r = 0;
-            if (chunk == s0 && tt == 0) {
+            if (tt == 0) {
               acc = load_wide<T>(src[0]);  // first occurrence is copied, not added to 0
               r   = 1;
             }
@@ -630,10 +675,9 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
           }
         }
       }
-      if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // clamped tail tiles must not land in the next chunk
     }
+    if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // clamped tail tiles must not land in the next run
     if (!producer && folder) apply_optimizer<OPT, T>(a, local, col0 + threadIdx.x, acc, ent.beta1t, ent.beta2t);
-    __syncthreads();
   }
 }
 
@@ -646,10 +690,15 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream)
   const bool vec2      = p.a.dim % 2 == 0 && p.a.grad_stride % 2 == 0 && gaddr % 8 == 0 && self_ok2;
   // (a float4-per-lane variant, two runs per wave instruction, was measured too: no gain for SGD, 10-15 % slower for the
   // stateful optimizers through register pressure — 8 bytes per lane stay)
-  if (vec2)
-    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 2>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  const bool cached = p.a.cache_slot_of != nullptr;
+  if (vec2 && !cached)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 2, float, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  else if (vec2)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 2, float, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  else if (!cached)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1, float, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
   else
-    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1>), dim3(blocks), dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1, float, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
   if (p.long_list != nullptr) {
     const int slices = static_cast<int>((p.a.dim + kSliceCols - 1) / kSliceCols);
     const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4;
@@ -689,10 +738,15 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream)
   const bool rows16    = p.a.dim % 8 == 0 && p.a.grad_stride % 8 == 0 && sstr % 8 == 0 && gaddr % 16 == 0 &&
                       p.a.dim <= 65535 * kS;
   if (!rows16) p.long_list = nullptr;  // no LDS-DMA path for this shape: the wave-per-run kernel folds every run itself
-  if (vec4)
-    hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 4, T>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  const bool cached = p.a.cache_slot_of != nullptr;
+  if (vec4 && !cached)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 4, T, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  else if (vec4)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 4, T, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  else if (!cached)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 1, T, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
   else
-    hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 1, T>), dim3(blocks), dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 1, T, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
   if (p.long_list != nullptr) {
     static const bool lds_ok =
       hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, kOpt, T>),
