@@ -138,8 +138,9 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, void* unique_
 // Two kernels share the work by run length (a "run" = all received rows of one unique id, in receive order):
 //   step_short_kernel : one wave per run, for runs of <= kLongRun rows (the common case). Lanes own columns;
 //                       the duplicates are folded sequentially (first copied, the rest added one by one — the
-//                       reference order), up to 4 duplicate rows prefetched at a time. Longer runs are only
-//                       RECORDED here (device list) together with their LazyAdam beta powers.
+//                       reference order), up to 4 duplicate rows prefetched at a time. Longer runs are skipped here:
+//                       mark_long_runs_kernel lists them (with their LazyAdam beta powers) for the long-run kernel,
+//                       which runs on a second stream next to this one.
 //   step_long_kernel  : one workgroup per (long run, 32-column slice). 256 threads stream the run's rows through
 //                       double-buffered LDS tiles (256 rows x 128 B, the next tile already in registers while the
 //                       current one is folded), 32 lanes fold their column sequentially out of LDS. Summation
@@ -371,17 +372,13 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
 #pragma unroll
     for (int k = 0; k < K; k++) {
       live[k] = u0 + k < count;
+      // runs of more than kLongRun rows belong to the long-run kernel (listed by mark_long_runs_kernel, which also
+      // advances their LazyAdam beta powers): nothing of them is touched here
+      if (p.long_list != nullptr && m_cur.s1[k] - m_cur.s0[k] > kLongRun) live[k] = false;
       if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM && live[k] && lane == 0) {
         // every lane has read the old values (same wave, program order) before this store
         a.per_row_state[m_cur.local[k] * 2 + 0] = r_cur.beta1t[k];
         a.per_row_state[m_cur.local[k] * 2 + 1] = r_cur.beta2t[k];
-      }
-      if (live[k] && p.long_list != nullptr && m_cur.s1[k] - m_cur.s0[k] > kLongRun) {
-        if (lane == 0) {
-          int slot          = atomicAdd(p.long_count, 1);
-          p.long_list[slot] = long_run_entry{static_cast<int32_t>(u0 + k), r_cur.beta1t[k], r_cur.beta2t[k], 0};
-        }
-        live[k] = false;  // folded by step_long_kernel
       }
     }
     T* row[K];
@@ -681,25 +678,87 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
   }
 }
 
+// Lists the runs of more than kLongRun rows for the long-run kernel, with their LazyAdam beta powers (advanced here, the
+// same two multiplications step_short_kernel does for the rows it owns). A kernel of its own so that the long-run kernel
+// does not have to wait for step_short_kernel: the two then run side by side on two streams (see long_lane) — one is a
+// handful of workgroups chewing through a few very long dependent chains, the other wants the whole memory system.
+template <typename IdxT>
+__global__ void mark_long_runs_kernel(opt_params p)
+{
+  const wm_optimizer_args& a = p.a;
+  const int64_t count        = p.n_unique ? *p.n_unique : a.count;
+  const IdxT* ids            = static_cast<const IdxT*>(a.ids);
+  for (int64_t u = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; u < count;
+       u += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    if (a.run_starts[u + 1] - a.run_starts[u] <= kLongRun) continue;
+    float beta1t = 0.f, beta2t = 0.f;
+    if (a.type == WHOLEMEMORY_OPT_LAZY_ADAM) {
+      const int64_t local             = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
+      beta1t                          = a.per_row_state[local * 2 + 0] * a.beta1;
+      beta2t                          = a.per_row_state[local * 2 + 1] * a.beta2;
+      a.per_row_state[local * 2 + 0] = beta1t;
+      a.per_row_state[local * 2 + 1] = beta2t;
+    }
+    const int slot    = atomicAdd(p.long_count, 1);
+    p.long_list[slot] = long_run_entry{static_cast<int32_t>(u), beta1t, beta2t, 0};
+  }
+}
+
+// Side stream + fork/join events for the long-run kernels, created once per process. fork(): the side stream waits for
+// everything the caller's stream has queued so far; join(): the caller's stream waits for the side stream.
+struct long_lane {
+  hipStream_t stream = nullptr;
+  hipEvent_t forked = nullptr, marked = nullptr, joined = nullptr;
+  bool ok = false;
+  long_lane()
+  {
+    int least = 0, greatest = 0;  // the side stream gets the highest priority: its few workgroups must not queue up behind
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);  // the thousands of step_short_kernel
+    ok = hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest) == hipSuccess &&
+         hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&marked, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess;
+  }
+  static long_lane& get()
+  {
+    static long_lane lane;
+    return lane;
+  }
+  bool fork(hipStream_t from)
+  {
+    return ok && hipEventRecord(forked, from) == hipSuccess && hipStreamWaitEvent(stream, forked, 0) == hipSuccess;
+  }
+  bool join(hipStream_t into)
+  {
+    return hipEventRecord(joined, stream) == hipSuccess && hipStreamWaitEvent(into, joined, 0) == hipSuccess;
+  }
+};
+
+// step_short_kernel fills every wave slot of the chip with persistent waves: whatever is to run NEXT to it has to be on
+// the machine first. So the caller's stream waits for the (tiny) listing kernel; the long-run kernel is then queued on
+// the high-priority side stream at the moment step_short_kernel is queued on the caller's.
+template <typename IdxT>
+void launch_mark_long_runs(const opt_params& p, hipStream_t stream, hipStream_t lstream)
+{
+  // one run per thread, no loop: the kernel is two coalesced reads of run_starts[] and sits on the caller's critical path
+  const int blocks = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, INT64_C(1) << 22));
+  hipLaunchKernelGGL((mark_long_runs_kernel<IdxT>), dim3(std::max(blocks, 1)), dim3(256), 0, lstream, p);
+  if (lstream != stream) {
+    (void)hipEventRecord(long_lane::get().marked, lstream);
+    (void)hipStreamWaitEvent(stream, long_lane::get().marked, 0);
+  }
+}
+
 template <typename IdxT, int OPT>
-int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream)
+int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStream_t lstream)
 {
   const uint64_t gaddr = reinterpret_cast<uint64_t>(p.a.grads) | reinterpret_cast<uint64_t>(p.a.self_grads);
   const bool self_ok2  = p.a.self_grads == nullptr || p.a.self_grad_stride % 2 == 0;
   const bool self_ok4  = p.a.self_grads == nullptr || p.a.self_grad_stride % 4 == 0;
   const bool vec2      = p.a.dim % 2 == 0 && p.a.grad_stride % 2 == 0 && gaddr % 8 == 0 && self_ok2;
-  // (a float4-per-lane variant, two runs per wave instruction, was measured too: no gain for SGD, 10-15 % slower for the
-  // stateful optimizers through register pressure — 8 bytes per lane stay)
-  const bool cached = p.a.cache_slot_of != nullptr;
-  if (vec2 && !cached)
-    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 2, float, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
-  else if (vec2)
-    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 2, float, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
-  else if (!cached)
-    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1, float, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
-  else
-    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1, float, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  // the long runs first, on their own stream: they are listed, then folded while step_short_kernel does the rest
   if (p.long_list != nullptr) {
+    launch_mark_long_runs<IdxT>(p, stream, lstream);
     const int slices = static_cast<int>((p.a.dim + kSliceCols - 1) / kSliceCols);
     const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4;
     const bool rows4 = p.a.dim % 4 == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4 &&
@@ -715,19 +774,30 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream)
       const int slices4 = static_cast<int>((p.a.dim + kSlice4 - 1) / kSlice4);
       int gx            = std::max(1, 256 / slices4);
       if (const char* e = getenv("WM_LONG_GRID")) gx = std::max(1, atoi(e));
-      hipLaunchKernelGGL((step_long4_kernel<IdxT, OPT>), dim3(gx, slices4), dim3(kLongBlock), kLong4LdsBytes, stream, p);
+      hipLaunchKernelGGL((step_long4_kernel<IdxT, OPT>), dim3(gx, slices4), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
     }
     else if (long4)
-      hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, true>), dim3(1024, slices), dim3(kBlock), 0, stream, p);
+      hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, true>), dim3(1024, slices), dim3(kBlock), 0, lstream, p);
     else
-      hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, false>), dim3(1024, slices), dim3(kBlock), 0, stream, p);
+      hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, false>), dim3(1024, slices), dim3(kBlock), 0, lstream, p);
   }
+  // (a float4-per-lane variant, two runs per wave instruction, was measured too: no gain for SGD, 10-15 % slower for the
+  // stateful optimizers through register pressure — 8 bytes per lane stay)
+  const bool cached = p.a.cache_slot_of != nullptr;
+  if (vec2 && !cached)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 2, float, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  else if (vec2)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 2, float, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  else if (!cached)
+    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1, float, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  else
+    hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1, float, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // HALF / BF16 tables with gradients of the same dtype: SGD only (see wm_optimizer_args::value_dtype)
 template <typename IdxT, typename T>
-int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream)
+int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream, hipStream_t lstream)
 {
   constexpr int kOpt   = WHOLEMEMORY_OPT_SGD;
   constexpr int kS     = kSlice4;  // columns per long-run slice
@@ -738,6 +808,16 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream)
   const bool rows16    = p.a.dim % 8 == 0 && p.a.grad_stride % 8 == 0 && sstr % 8 == 0 && gaddr % 16 == 0 &&
                       p.a.dim <= 65535 * kS;
   if (!rows16) p.long_list = nullptr;  // no LDS-DMA path for this shape: the wave-per-run kernel folds every run itself
+  if (p.long_list != nullptr) {
+    static const bool lds_ok =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, kOpt, T>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLong4LdsBytes)) == hipSuccess;
+    if (!lds_ok) return -2;
+    launch_mark_long_runs<IdxT>(p, stream, lstream);
+    const int slices = static_cast<int>((p.a.dim + kS - 1) / kS);
+    const int gx     = std::max(1, 256 / slices);
+    hipLaunchKernelGGL((step_long4_kernel<IdxT, kOpt, T>), dim3(gx, slices), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
+  }
   const bool cached = p.a.cache_slot_of != nullptr;
   if (vec4 && !cached)
     hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 4, T, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
@@ -747,32 +827,23 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream)
     hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 1, T, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
   else
     hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 1, T, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
-  if (p.long_list != nullptr) {
-    static const bool lds_ok =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, kOpt, T>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLong4LdsBytes)) == hipSuccess;
-    if (!lds_ok) return -2;
-    const int slices = static_cast<int>((p.a.dim + kS - 1) / kS);
-    const int gx     = std::max(1, 256 / slices);
-    hipLaunchKernelGGL((step_long4_kernel<IdxT, kOpt, T>), dim3(gx, slices), dim3(kLongBlock), kLong4LdsBytes, stream, p);
-  }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <typename IdxT>
-int launch_step(const opt_params& p, int blocks, hipStream_t stream)
+int launch_step(const opt_params& p, int blocks, hipStream_t stream, hipStream_t lstream)
 {
   if (p.a.value_dtype == WHOLEMEMORY_DT_HALF || p.a.value_dtype == WHOLEMEMORY_DT_BF16) {
     if (p.a.type != WHOLEMEMORY_OPT_SGD) return -1;
-    return p.a.value_dtype == WHOLEMEMORY_DT_HALF ? launch_step_sgd16<IdxT, half_t>(p, blocks, stream)
-                                                  : launch_step_sgd16<IdxT, bf16_t>(p, blocks, stream);
+    return p.a.value_dtype == WHOLEMEMORY_DT_HALF ? launch_step_sgd16<IdxT, half_t>(p, blocks, stream, lstream)
+                                                  : launch_step_sgd16<IdxT, bf16_t>(p, blocks, stream, lstream);
   }
   if (p.a.value_dtype != WHOLEMEMORY_DT_FLOAT && p.a.value_dtype != WHOLEMEMORY_DT_UNKNOWN) return -1;
   switch (p.a.type) {
-    case WHOLEMEMORY_OPT_SGD: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_SGD>(p, blocks, stream);
-    case WHOLEMEMORY_OPT_LAZY_ADAM: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_LAZY_ADAM>(p, blocks, stream);
-    case WHOLEMEMORY_OPT_ADAGRAD: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_ADAGRAD>(p, blocks, stream);
-    case WHOLEMEMORY_OPT_RMSPROP: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_RMSPROP>(p, blocks, stream);
+    case WHOLEMEMORY_OPT_SGD: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_SGD>(p, blocks, stream, lstream);
+    case WHOLEMEMORY_OPT_LAZY_ADAM: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_LAZY_ADAM>(p, blocks, stream, lstream);
+    case WHOLEMEMORY_OPT_ADAGRAD: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_ADAGRAD>(p, blocks, stream, lstream);
+    case WHOLEMEMORY_OPT_RMSPROP: return launch_step_opt<IdxT, WHOLEMEMORY_OPT_RMSPROP>(p, blocks, stream, lstream);
     default: return -1;
   }
 }
@@ -833,16 +904,22 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
     // [int32 counter | pad to 16 B | entries]; at most count / (kLongRun + 1) long runs can exist
     p.long_count = static_cast<int32_t*>(a->long_run_ws);
     p.long_list  = reinterpret_cast<long_run_entry*>(static_cast<char*>(a->long_run_ws) + 16);
-    if (hipMemsetAsync(p.long_count, 0, 16, stream) != hipSuccess) return -2;
   }
+  // the long-run side goes to its own stream (WM_STEP_SERIAL=1: everything on the caller's stream, for measurements)
+  hipStream_t lstream = stream;
+  static const bool serial = getenv("WM_STEP_SERIAL") != nullptr;
+  if (p.long_list != nullptr && hipMemsetAsync(p.long_count, 0, 16, stream) != hipSuccess) return -2;
+  if (p.long_list != nullptr && !serial && long_lane::get().fork(stream)) lstream = long_lane::get().stream;
   int64_t waves = a->count;
   int max_blocks = 256 * 8;
   if (const char* e = getenv("WM_STEP_BLOCKS")) max_blocks = std::max(1, atoi(e));
   int blocks = static_cast<int>(std::min<int64_t>((waves + 3) / 4, max_blocks));
   if (blocks < 1) blocks = 1;
-  if (a->index_dtype == WHOLEMEMORY_DT_INT) return launch_step<int32_t>(p, blocks, stream);
-  if (a->index_dtype == WHOLEMEMORY_DT_INT64) return launch_step<int64_t>(p, blocks, stream);
-  return -1;
+  int rc = -1;
+  if (a->index_dtype == WHOLEMEMORY_DT_INT) rc = launch_step<int32_t>(p, blocks, stream, lstream);
+  if (a->index_dtype == WHOLEMEMORY_DT_INT64) rc = launch_step<int64_t>(p, blocks, stream, lstream);
+  if (lstream != stream && !long_lane::get().join(stream)) return -2;  // the caller's stream continues after both sides
+  return rc;
 }
 
 template <typename IdxT>
