@@ -509,50 +509,55 @@ __global__ __launch_bounds__(kBlock) void step_long_kernel(opt_params p)
   }
 }
 
-// step_long_kernel restructured for rows of whole float4s. Two facts pace a long run (measured on the Zipf(1.05)
-// batch whose hottest id has ~490 k duplicates, 8.8 ms in the kernel above):
-//   (1) one CU pulls at most ~10-13 B/cycle (~25-30 GB/s) out of HBM, whatever it keeps in flight (a 128-column,
-//       whole-row variant of this kernel with a 3-tile LDS-DMA ring ran at 23 GB/s per workgroup and was SLOWER,
-//       11 ms): the fetch of one run has to be spread over CUs, so a workgroup takes a column slice — 64 columns, one
-//       workgroup per (run, slice);
+// step_long_kernel restructured for rows of whole 16-byte pieces. What paces a long run (measured on the Zipf(1.05) batch
+// whose hottest id has 527 k duplicates, 8.8 ms in the kernel above; in-kernel cycle counters, experiments/*):
+//   (1) one CU pulls only ~25-40 GB/s out of HBM whatever it keeps in flight (a 128-column, whole-row variant with a
+//       3-tile LDS-DMA ring ran at 23 GB/s per workgroup and was SLOWER): the fetch of one run has to be spread over
+//       CUs, so a workgroup takes a column slice of 128 bytes per row, one workgroup per (run, slice);
 //   (2) the kernel above keeps ONE tile in flight and pays two dependent HBM latencies per tile (order[] entries, then
-//       rows): 7 GB/s per workgroup, a quarter of (1).
-// So: tiles travel global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction = 256 / S rows of the
-// slice) into a ring of kRing tile buffers — no staging registers, and because the compiler does not track LDS-DMA
-// results the waits are hand-counted `s_waitcnt vmcnt(N)` + raw `s_barrier`, so kRing - 1 tiles really stay in flight
-// while one is folded (a register ring does not survive hipcc's s_waitcnt placement: it drains at every loop trip).
-// Loads return in issue order (vmcnt), so order[] reads interleaved with row reads would drain the ring: row addresses
-// come out of LDS, where the order[] entries are kept a chunk of 2048 rows at a time in two alternating buffers — the
-// folding wave fetches chunk c + 1 into registers while chunk c is folded and drops it into the free buffer, so the tile
-// ring runs through a whole run without draining (with one buffer refilled between chunks a 527 k-row run lost ~8 us
-// per 4096 rows, 1.1 of 4.5 ms, to the refill and the restart of the ring). One wave folds a tile, unpredicated for
-// full tiles; in-situ counters on that run: fold 11.5 cycles per row (6 for the LDS reads, 6 for the dependent add — a
-// single wave overlaps neither with the other, experiments/fold_microbench.hip), fetch of the 256-byte slices at
-// ~38 GB/s per CU, i.e. both sides now take about the same 2.5-3.5 ms. Summation order per element is unchanged
-// (receive order, first row copied): results stay bit-identical.
+//       rows): 7 GB/s per workgroup;
+//   (3) a wave pays ~6 cycles per row for its LDS read and ~6 for the dependent add and overlaps neither with the other,
+//       however the reads are scheduled (experiments/fold_microbench.hip) — per ROW, whatever the width of the slice.
+// So: tiles travel global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction = 8 rows of the slice)
+// into a ring of tile buffers — no staging registers, and because the compiler does not track LDS-DMA results the waits
+// are hand-counted `s_waitcnt vmcnt(N)` + raw `s_barrier`, so the whole ring really stays in flight (a register ring
+// does not survive hipcc's s_waitcnt placement: it drains at every loop trip). Loads return in issue order (vmcnt), so
+// order[] reads interleaved with row reads would drain the ring: row addresses come out of LDS, where the order[]
+// entries are kept a chunk of 2048 rows at a time in two alternating buffers — wave 0 fetches chunk c + 1 into
+// registers while chunk c is folded and drops it into the free buffer, so the ring runs through a whole run without
+// draining (refilling one buffer between chunks cost ~8 us per 4096 rows, 1.1 of 4.5 ms on the hottest run). Two waves
+// fold alternate tiles: while one adds the 128 rows it holds in registers to the running sums, the other reads its next
+// tile out of LDS; the sums change hands through LDS at the per-tile barrier. Summation order per element is unchanged
+// (receive order; starting from -0.0f is the same as copying the first row, and rows past the end of a run are read as
+// -0.0f, which adds nothing): results stay bit-identical. History on the Zipf batch, kernel alone: 8.8 ms (kernel
+// above) -> 4.5 (LDS-DMA ring, 256-byte slices) -> 3.5 (order[] double-buffered) -> 3.4 (two folding waves) -> 3.0
+// (128-byte slices, which only pay once the fold is off the critical path; 64-byte slices: no faster alone and they
+// take twice the CUs away from step_short_kernel running beside it).
 
 constexpr int kOrdChunk  = 2048;   // order[] entries per LDS buffer (two buffers)
-constexpr int kRing      = 4;
-constexpr int kSlice4    = 64;     // columns per workgroup = lanes of the folding wave. Narrower slices spread the fetch of a
-                                   // run over more CUs but the fold costs the same per ROW whatever its width, and more
-                                   // with rows that are not 256 B apart in LDS (no ds_read2st64): measured on the Zipf
-                                   // batch, fp32, 32 columns 4.0 ms, 64 columns 3.5 ms
-constexpr int kTileBytes = 32768;  // one LDS tile
-constexpr size_t kLong4LdsBytes = static_cast<size_t>(kRing) * kTileBytes + 2 * kOrdChunk * 4;
+constexpr int kRingBytes = 131072; // LDS given to the tile ring
+constexpr int kSlice4Bytes = 128;  // bytes of every row per workgroup: 32 fp32 / 64 16-bit columns. One CU pulls a limited
+                                   // number of bytes per second out of HBM whatever it keeps in flight, so a run is
+                                   // spread over dim * elt / 128 workgroups
+template <typename T>
+constexpr int slice4_cols() { return kSlice4Bytes / static_cast<int>(sizeof(T)); }
+constexpr int kTile4Rows = 128;    // rows per LDS tile = registers of a folding wave (32 KiB of fp32 slices, 16 KiB of 16-bit ones)
+constexpr size_t kLong4LdsBytes = static_cast<size_t>(kRingBytes) + 2 * kOrdChunk * 4 + 64 * 4;  // + the partial sums
 
 constexpr int kLongProducers = 4;                          // waves that only fetch
-constexpr int kLongBlock     = 64 * (kLongProducers + 1);  // + wave 0, which only folds
+constexpr int kLongFolders   = 2;                          // waves 0 and 1 fold alternate tiles
+constexpr int kLongBlock     = 64 * (kLongProducers + kLongFolders);
 
 template <typename IdxT, int OPT, typename T = float>
 __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
 {
   extern __shared__ __attribute__((aligned(16))) float lds4[];
-  constexpr int S          = kSlice4;                                   // columns per slice
-  constexpr int kRowBytes  = S * static_cast<int>(sizeof(T));           // 256 B (fp32) / 128 B (16-bit) of every row
-  constexpr int kTile4Rows = kTileBytes / kRowBytes;                    // rows per LDS tile
+  constexpr int S          = slice4_cols<T>();                          // columns per slice: 32 (fp32) / 64 (16-bit)
+  constexpr int kRowBytes  = kSlice4Bytes;                              // bytes of every row a workgroup handles
+  constexpr int kRing      = kRingBytes / (kTile4Rows * kRowBytes) > 8 ? 8 : kRingBytes / (kTile4Rows * kRowBytes);  // tiles in the ring
   constexpr int kE16       = 16 / static_cast<int>(sizeof(T));          // elements per 16-byte piece
   T* const tiles       = reinterpret_cast<T*>(lds4);                                        // [kRing][kTile4Rows][S]
-  int32_t* const ord_s = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(lds4) + kRing * kTileBytes);  // [2][kOrdChunk]
+  int32_t* const ord_s = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(lds4) + kRingBytes);  // [2][kOrdChunk]
   const wm_optimizer_args& a = p.a;
   const int n_long           = *p.long_count;
   const IdxT* ids            = static_cast<const IdxT*>(a.ids);
@@ -561,20 +566,23 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
   constexpr int kLpr         = kRowBytes / 16;                                // lanes per row (16-byte pieces)
   constexpr int kRpp         = 64 / kLpr;                                     // rows per wave instruction
   constexpr int kLoads       = kTile4Rows / (kRpp * kLongProducers);          // pieces per producer lane per tile (8)
-  static_assert(kLoads * (kRing - 2) < 64, "vmcnt field");
+  static_assert(kLoads * kRing < 64, "vmcnt field");
   const int lane             = threadIdx.x & 63;
-  // wave 0 folds, waves 1 .. kLongProducers fetch: the fetch side of a tile (8 x [ord_s read -> address -> M0 ->
-  // LDS-DMA issue] per wave) costs about as much wave time as folding it, and a wave doing both was the pacing item
+  // Waves 0 and 1 fold, waves 2 .. fetch. One wave pays ~6 cycles per row for the LDS read and ~6 for the dependent add
+  // and overlaps neither with the other (experiments/fold_microbench.hip), so two waves take turns: while the owner of
+  // tile t adds its 128 (256) rows out of REGISTERS to the running sums, the other one reads tile t + 1 from LDS into
+  // its registers; the sums change hands through 256 bytes of LDS at the barrier that ends every tile anyway.
   const int wave_id   = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const bool producer = wave_id > 0;
-  const int wv        = wave_id - 1;
+  const bool producer = wave_id >= kLongFolders;
+  const int wv        = wave_id - kLongFolders;
   const int c_safe    = min((lane % kLpr) * kE16, cols - kE16);  // lanes past a narrow slice re-read its last piece
   const int r_lane    = lane / kLpr;
-  const bool folder   = threadIdx.x < cols;  // one column per lane of wave 0
+  const bool folder   = lane < cols;  // one column per lane of a folding wave
+  float* const acc_s  = reinterpret_cast<float*>(ord_s + 2 * kOrdChunk);  // [64] running sums between the two folders
 
   constexpr int kTpc   = kOrdChunk / kTile4Rows;  // tiles per chunk of order[] entries
   constexpr int kPre   = kOrdChunk / 64;          // entries per lane of wave 0 when it carries a whole chunk in registers
-  static_assert((kOrdChunk & (kOrdChunk - 1)) == 0 && kOrdChunk % kTile4Rows == 0 && kTpc > kRing, "a chunk is a whole number of tiles, more than the ring holds");
+  static_assert((kOrdChunk & (kOrdChunk - 1)) == 0 && kOrdChunk % kTile4Rows == 0 && kTpc > kRing + 1 && kTpc % 2 == 0, "a chunk is a whole number of tiles, more than the ring holds");
 
   for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
     const long_run_entry ent = p.long_list[li];
@@ -585,7 +593,6 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
     const int32_t run_rows   = s1 - s0;
     const int n_tiles        = (run_rows + kTile4Rows - 1) / kTile4Rows;
     const int n_chunks       = (run_rows + kOrdChunk - 1) / kOrdChunk;
-    float acc                = 0.f;
     // order[] entries reach the producers through two LDS buffers of one chunk each (chunk c in buffer c % 2), so the
     // tile ring never drains inside a run: chunk 0 is staged by everybody, every later chunk is fetched by wave 0 into
     // registers a whole chunk ahead (plain loads — wave 0 has no LDS-DMA of its own to keep count of) and dropped into
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
 #pragma unroll
       for (int k = 0; k < kPre; k++) ord_s[(c & 1) * kOrdChunk + k * 64 + lane] = pre[k];
     };
-    if (!producer && n_chunks > 1) prefetch_chunk(1);
+    if (wave_id == 0 && n_chunks > 1) prefetch_chunk(1);
     __syncthreads();
     // tile t -> ring slot t % kRing: kLoads LDS-DMA pieces per producer lane; producer w, piece i lands as the kRpp
     // adjacent tile rows starting at kRpp (w + kLongProducers i) (wave-uniform LDS base + lane * 16 B). Rows are
@@ -623,58 +630,88 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
         __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(slot + kRpp * (wv + kLongProducers * i) * S), 16, 0, 0);
       }
     };
+    // the rows of one tile, in the registers of the wave that owns it
+    float v[kTile4Rows];
+    // Rows past the end of the run become -0.0f: x + (-0.0f) == x bit for bit for every x, so the owner adds all
+    // kTile4Rows registers without predicates (and a register array cannot be indexed by a loop counter anyway).
+    auto read_tile = [&](int t) {
+      const T* src = tiles + (t % kRing) * (kTile4Rows * S) + lane;
+#pragma clang loop unroll(full)
+      for (int k = 0; k < kTile4Rows; k++) v[k] = load_wide<T>(src[k * S]);
+      const int32_t rows = run_rows - t * kTile4Rows;
+      if (rows < kTile4Rows) {
+#pragma clang loop unroll(full)
+        for (int k = 0; k < kTile4Rows; k++) v[k] = k < rows ? v[k] : -0.0f;
+      }
+    };
+    // Schedule. Before barrier t every slot is in use: tile t sits in its owner's registers (its slot is free), tile
+    // t + 1 has landed, tiles t + 2 .. t + kRing - 1 are in flight. After barrier t the producers refill the slot of
+    // tile t with tile t + kRing, the owner of tile t (wave t % 2) takes the sums from LDS, adds its rows and puts the
+    // sums back, the other folder reads tile t + 1. A lane past the slice (lane >= cols) folds rubbish nobody reads.
+    // (two separate loops with the same number of barriers: in one loop the registers of a tile would stay reserved in
+    // the producers' code too and hipcc spills to scratch — vector memory traffic that would also wreck the vmcnt count)
+    float acc = 0.f;
     if (producer) {
 #pragma unroll
-      for (int j = 0; j < kRing - 1; j++) issue(j);
-    }
-    for (int tt = 0; tt < n_tiles; tt++) {
-      // producers: tiles tt .. tt + kRing - 2 are in flight (kLoads pieces each, oldest first): tile tt has landed
-      // once at most kLoads * (kRing - 2) pieces remain; the barrier extends that to every producer's pieces and
-      // tells them that wave 0 is done with tile tt - 1, whose slot the next tile reuses
-      if (producer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads * (kRing - 2)) : "memory");
+      for (int j = 0; j < kRing; j++) issue(j);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads * (kRing - 1)) : "memory");  // tile 0 has landed
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (producer) {
-        issue(tt + kRing - 1);
-      } else {
-        // first tile of chunk c: buffer (c + 1) % 2 was last read for the tiles of chunk c - 1, all issued before the
-        // barrier just passed (kTpc > kRing); its new content is first read kTpc - kRing + 1 barriers from now
-        if (tt % kTpc == 0) {
-          const int c = tt / kTpc;
-          if (c + 1 < n_chunks) {
-            drop_chunk(c + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in LDS before this wave reaches the next barrier
-            if (c + 2 < n_chunks) prefetch_chunk(c + 2);
+      for (int tt = 0; tt < n_tiles; tt++) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads * (kRing - 2)) : "memory");  // tile tt + 1 has landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(tt + kRing);
+      }
+    } else {
+      // one barrier per tile for everybody; a folding wave alternates between adding its own tile and reading its next
+      auto tile_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // sums / order entries written, tile in registers
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      };
+      auto add_tile = [&](int t) {
+        // the first occurrence is copied, not added to 0 — which is what starting from -0.0f does: -0.0f + x == x
+        acc = t > 0 ? acc_s[lane] : -0.0f;
+#pragma clang loop unroll(full)
+        for (int k = 0; k < kTile4Rows; k++) acc += v[k];
+        if (t + 1 < n_tiles) acc_s[lane] = acc;
+      };
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (wave_id == 0) {  // even tiles
+        read_tile(0);
+        for (int tt = 0; tt < n_tiles; tt += 2) {
+          tile_barrier();
+          // first tile of chunk c: buffer (c + 1) % 2 was last read for the tiles of chunk c - 1, all issued long before
+          // the barrier just passed (kTpc > kRing + 1); its new content is first read kTpc - kRing barriers from now
+          if (tt % kTpc == 0) {
+            const int c = tt / kTpc;
+            if (c + 1 < n_chunks) {
+              drop_chunk(c + 1);
+              if (c + 2 < n_chunks) prefetch_chunk(c + 2);
+            }
+          }
+          add_tile(tt);
+          if (tt + 1 < n_tiles) {
+            tile_barrier();
+            if (tt + 2 < n_tiles) read_tile(tt + 2);
           }
         }
-        if (folder) {
-          const int32_t rows = min(kTile4Rows, run_rows - tt * kTile4Rows);
-          const T* src       = tiles + (tt % kRing) * (kTile4Rows * S) + threadIdx.x;
-          if (rows == kTile4Rows && tt != 0) {
-            // the hot loop, no predicates. One wave pays ~6 cycles per row for its LDS reads (ds_read2st64_b32 when the
-            // rows are 256 B apart) and ~6 for each dependent add, and the two do not overlap inside one wave however
-            // the reads are scheduled (experiments/fold_microbench.hip): 64 rows are read back to back, then folded
-#pragma unroll 1
-            for (int32_t r = 0; r < kTile4Rows; r += 64) {
-              float v[64];
-#pragma unroll
-              for (int k = 0; k < 64; k++) v[k] = load_wide<T>(src[(r + k) * S]);
-#pragma unroll
-              for (int k = 0; k < 64; k++) acc += v[k];
-            }
-          } else {
-            int32_t r = 0;
-            if (tt == 0) {
-              acc = load_wide<T>(src[0]);  // first occurrence is copied, not added to 0
-              r   = 1;
-            }
-            for (; r < rows; r++) acc += load_wide<T>(src[r * S]);
+      } else {  // odd tiles
+        for (int tt = 0; tt < n_tiles; tt += 2) {
+          tile_barrier();
+          if (tt + 1 < n_tiles) {
+            read_tile(tt + 1);
+            tile_barrier();
+            add_tile(tt + 1);
           }
         }
       }
     }
     if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // clamped tail tiles must not land in the next run
-    if (!producer && folder) apply_optimizer<OPT, T>(a, local, col0 + threadIdx.x, acc, ent.beta1t, ent.beta2t);
+    if (wave_id == ((n_tiles - 1) & 1) && folder)
+      apply_optimizer<OPT, T>(a, local, col0 + lane, acc, ent.beta1t, ent.beta2t);
   }
 }
 
@@ -762,7 +799,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
     const int slices = static_cast<int>((p.a.dim + kSliceCols - 1) / kSliceCols);
     const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4;
     const bool rows4 = p.a.dim % 4 == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4 &&
-                       p.a.dim <= 65535 * kSlice4;
+                       p.a.dim <= 65535 * slice4_cols<float>();
     static const bool old_long = getenv("WM_STEP_LONG_OLD") != nullptr;
     if (rows4 && !old_long) {
       static const bool lds_ok =
@@ -771,7 +808,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
       if (!lds_ok) return -2;
       // 144 KiB of LDS = one workgroup per CU: launch one resident wave of workgroups (256 CUs) and let each walk the
       // run list — with more workgroups than CUs the hottest run may only START after several rounds of others
-      const int slices4 = static_cast<int>((p.a.dim + kSlice4 - 1) / kSlice4);
+      const int slices4 = static_cast<int>((p.a.dim + slice4_cols<float>() - 1) / slice4_cols<float>());
       int gx            = std::max(1, 256 / slices4);
       if (const char* e = getenv("WM_LONG_GRID")) gx = std::max(1, atoi(e));
       hipLaunchKernelGGL((step_long4_kernel<IdxT, OPT>), dim3(gx, slices4), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
@@ -800,7 +837,7 @@ template <typename IdxT, typename T>
 int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream, hipStream_t lstream)
 {
   constexpr int kOpt   = WHOLEMEMORY_OPT_SGD;
-  constexpr int kS     = kSlice4;  // columns per long-run slice
+  constexpr int kS     = slice4_cols<T>();  // columns per long-run slice
   const uint64_t gaddr = reinterpret_cast<uint64_t>(p.a.grads) | reinterpret_cast<uint64_t>(p.a.self_grads);
   const int64_t sstr   = p.a.self_grads == nullptr ? 0 : p.a.self_grad_stride;
   const bool vec4      = p.a.dim % 4 == 0 && p.a.grad_stride % 4 == 0 && sstr % 4 == 0 && p.a.table_stride % 4 == 0 &&
