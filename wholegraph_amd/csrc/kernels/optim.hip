@@ -30,6 +30,8 @@
 
 #include "../backend.hpp"
 #include "device_common.cuh"
+
+#include <mutex>
 #include <wholememory/embedding.h>
 
 namespace wm {
@@ -744,6 +746,7 @@ __global__ void mark_long_runs_kernel(opt_params p)
 // Side stream + fork/join events for the long-run kernels, created once per process. fork(): the side stream waits for
 // everything the caller's stream has queued so far; join(): the caller's stream waits for the side stream.
 struct long_lane {
+  std::mutex mu;  // one fork .. join sequence at a time: the events are shared
   hipStream_t stream = nullptr;
   hipEvent_t forked = nullptr, marked = nullptr, joined = nullptr;
   bool ok = false;
@@ -945,6 +948,8 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   // the long-run side goes to its own stream (WM_STEP_SERIAL=1: everything on the caller's stream, for measurements)
   hipStream_t lstream = stream;
   static const bool serial = getenv("WM_STEP_SERIAL") != nullptr;
+  std::unique_lock<std::mutex> lane_lock;
+  if (p.long_list != nullptr && !serial) lane_lock = std::unique_lock<std::mutex>(long_lane::get().mu);
   if (p.long_list != nullptr && hipMemsetAsync(p.long_count, 0, 16, stream) != hipSuccess) return -2;
   if (p.long_list != nullptr && !serial && long_lane::get().fork(stream)) lstream = long_lane::get().stream;
   int64_t waves = a->count;
