@@ -1,7 +1,7 @@
 # do step_long4_kernel and step_short_kernel overlap? start/end timestamps of the last gradient-apply call
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tr
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $GRAFT_REPO_ROOT/bench.py --op grad_apply --dist zipf --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $GRAFT_REPO_ROOT/bench.py --op grad_apply --dist zipf --optimizer ${OPT:-sgd} --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 f=$(find /tmp/tr -name "*kernel_trace.csv" | head -1)
 python3 - $f <<'PY'
 import csv, sys

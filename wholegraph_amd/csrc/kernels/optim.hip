@@ -149,7 +149,13 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, void* unique_
 //                       order per element is still exactly the receive order, so results stay bit-identical; a
 //                       500 k-duplicate hot row (Zipf s = 1.05) costs milliseconds instead of ~0.5 s of dependent
 //                       global loads.
-constexpr int kLongRun   = 32;
+// Runs of up to kLongRun rows are folded by the wave that owns them in step_short_kernel (4 rows prefetched per
+// dependent round: ~60 us for 256 rows, and a Zipf batch has only one or two such runs per wave). The long-run kernel
+// pays ~6 us per run before its first row is folded and keeps 255 VGPRs x 6 waves busy on a CU while it walks its list —
+// with the threshold at 32 it was given 9600 runs of the Zipf(1.05) batch, held every CU for over a millisecond and
+// halved the speed of step_short_kernel beside it; at 256 it gets 1300 (whole call, SGD / LazyAdam / fp16 x 256:
+// 32 -> 4.45 / 6.7 / 5.2 ms, 256 -> 3.85 / 6.1 / 4.2 ms, 1024 -> 3.85 / 6.1 / 4.3 ms, 4096 -> 4.2 / 6.2 / 4.2 ms).
+constexpr int kLongRun   = 256;
 constexpr int kSliceCols = 32;    // 128 B of every row per long-run workgroup
 constexpr int kTileRows  = 256;   // rows per LDS tile (32 KiB), double buffered
 
