@@ -384,9 +384,16 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
       oa.cache_state_row_elems = e->cache->args.row_bytes2 / static_cast<int64_t>(sizeof(float));
     }
   }
-  dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa,
-                 static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived,
-                 self_direct ? &self_ref : nullptr);
+  // Everything this rank was given is its own and nothing was dropped (one rank, no negative ids): bucketing is stable, so
+  // the receive order IS the caller's order and the caller's gradient tensor IS the receive buffer — no remapping pass
+  const bool whole_input_is_self = self_direct && x.self_count == iarr.size && n_recv == iarr.size;
+  if (whole_input_is_self)
+    dedup_and_step(recv_ids, iarr.dtype, n_recv, self_ref.grads, self_ref.stride, &oa,
+                   static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived, nullptr);
+  else
+    dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa,
+                   static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived,
+                   self_direct ? &self_ref : nullptr);
   // temporaries go back to the caller's allocator on return; like the reference's distributed ops
   // the stream is drained first so nothing in flight still reads them
   WM_BK(bk->stream_sync(stream));
