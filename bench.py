@@ -43,6 +43,9 @@ def parse():
                    help="table dtype (side measurements; the contract metric is f32)")
     p.add_argument("--cache-ratio", type=float, default=0.0,
                    help="side measurement: give the embedding a device row cache of this ratio (HOST tables)")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                   help="torch.distributed backend at N > 1: nccl = RCCL over xGMI (the measured configuration); gloo = "
+                        "host collectives, which also lets several ranks share one GPU (bring-up of this script only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-check", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -141,14 +144,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         a.gpus = world
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     import wholegraph_amd.torch as wgth
     from wholegraph_amd import binding as wmb
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # under torch.distributed.run (any N)
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
-        torch.distributed.init_process_group(backend="nccl", init_method="env://")
+        torch.distributed.init_process_group(backend=a.backend, init_method="env://")
         wgth.init(rank, world, local_rank, world, "warn")
         comm = wgth.get_global_communicator()
     else:
@@ -215,7 +218,7 @@ def main():
     ev1.record()
     barrier()
     t1 = time.perf_counter()
-    dt = torch.tensor([t1 - t0], device="cuda", dtype=torch.float64)
+    dt = torch.tensor([t1 - t0], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
     if launched:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     wall = float(dt.item())
@@ -269,6 +272,8 @@ def main():
                                    round(pair_bytes / (wall / a.steps) / 1e9, 2) if pair_bytes else None,
                                "note": "rows all-to-all-v over RCCL grouped send/recv, pipelined in row chunks with the "
                                        "owner-side gather and the reorder-on-receive kernels"}
+            if a.backend != "nccl":
+                res["exchange"]["note"] = "BRING-UP RUN: collectives over torch.distributed/%s, not RCCL" % a.backend
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     wgth.destroy_embedding(emb)
