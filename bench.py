@@ -224,6 +224,35 @@ def main():
     wall = float(dt.item())
     dev_ms = ev0.elapsed_time(ev1) / a.steps  # HIP events on the stream the kernels were launched on
 
+    # N > 1: the step is link-bound (see `exchange`); the HBM roofline object then describes the dominant HBM kernel on its
+    # own — the owner-side row gather — timed on this rank's local shard outside the step loop, same ids folded into it
+    local_kernel_roofline = None
+    if world > 1 and a.op == "gather" and a.dtype == "f32" and rank == 0:
+        import ctypes as C
+        from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream
+        lidx = idx % rows_per_gpu
+        wt, wi, wo = wrap_torch_tensor(local), wrap_torch_tensor(lidx), wrap_torch_tensor(out)
+        call = lambda: wmb.check(wmb.lib().wholememory_gather(wt.handle, wi.handle, wo.handle, get_wholegraph_env_fns(),
+                                                              C.c_void_p(get_stream()), -1))
+        for _ in range(3):
+            call()
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        for _ in range(10):
+            call()
+        k1.record()
+        torch.cuda.synchronize()
+        kms = k0.elapsed_time(k1) / 10
+        kbytes = a.indices * (8 + 2 * a.dim * es)
+        local_kernel_roofline = {"bound": "hbm", "achieved": round(kbytes / (kms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                                 "unit": "GB/s", "frac": round(kbytes / (kms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                                 "kernel": "rows_copy16_fast_kernel<long, true, 2, false>", "kernel_ms": round(kms, 4),
+                                 "algorithmic_bytes_per_launch": kbytes,
+                                 "scope": "owner-side row gather on rank 0's local shard, timed outside the step loop; "
+                                          "the step itself is link-bound (see exchange)"}
+    if launched:
+        torch.distributed.barrier()
+
     if rank == 0:
         lookups = a.indices * world * a.steps / wall
         out_bytes = a.dim * es
@@ -262,6 +291,8 @@ def main():
                                "algorithmic_bytes_per_launch": a.indices * algo_bytes}
             if not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(a.dim, a.cpu_seconds)
+        if world > 1 and a.op == "gather" and a.dtype == "f32":
+            res["roofline"] = local_kernel_roofline
         if world > 1 and a.op == "gather" and mt == "distributed":
             # the step is bound by the point-to-point xGMI links: every rank pulls (W-1)/W of its rows from peers,
             # one link per peer. Uniform ids -> n/W rows + ids per ordered pair per step.
