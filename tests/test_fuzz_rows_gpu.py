@@ -1,0 +1,19 @@
+"""Randomised gather / scatter shapes against torch indexing on the GPU (experiments/fuzz_rows.py): dtype pairs with casts,
+dims 1..700, padded strides, column-offset views, strided outputs, int32 / int64 ids with negatives and duplicates, the
+three memory types — complements the fixed reference parameter sets of test_gather_scatter_gpu.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_row_shapes_match_torch(wm_lib, seed):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "experiments", "fuzz_rows.py"), "250", str(seed)],
+                       capture_output=True, timeout=900)
+    out = p.stdout.decode() + p.stderr.decode()
+    assert p.returncode == 0 and "cases 250, failures 0" in out, out[-3000:]
