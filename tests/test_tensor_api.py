@@ -160,3 +160,17 @@ def test_env_test_op(gpu_env):
         assert dev.is_cuda and not pinned.is_cuda and not host.is_cuda
         for t in (dev, pinned, host):
             assert torch.equal(t.cuda(), want)
+
+
+def test_wrapper_can_be_passed_as_a_temporary(wm_lib):
+    """`wrap_torch_tensor(t)` owns its C handle; passing the wrapper itself (not `.handle`) keeps a temporary alive for
+    the duration of the call."""
+    import torch
+    from wholegraph_amd import binding as wmb
+    from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor
+    t = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    desc = wm_lib.wholememory_tensor_get_tensor_description(wrap_torch_tensor(t))
+    assert bool(desc)
+    w = wrap_torch_tensor(t)
+    td = C.cast(wm_lib.wholememory_tensor_get_tensor_description(w), C.POINTER(wmb.TensorDescription)).contents
+    assert td.dim == 2 and list(td.sizes[:2]) == [3, 4] and list(td.strides[:2]) == [4, 1]

@@ -167,6 +167,12 @@ class WrappedLocalTensor(object):
         wmb.check(wmb.lib().wholememory_make_tensor_from_pointer(C.byref(self.handle), C.c_void_p(t.data_ptr()),
                                                                  C.byref(desc)))
 
+    @property
+    def _as_parameter_(self):
+        """ctypes passes the wrapper itself: `lib.wholememory_gather(table, wrap_torch_tensor(idx), ...)` keeps the temporary
+        alive for the call, which `wrap_torch_tensor(idx).handle` does not (the wrapper owns the C handle)."""
+        return self.handle
+
     def __del__(self):
         try:
             if self.handle:
