@@ -237,3 +237,38 @@ def test_rejects_mixed_number_classes(gpu_env):
         wm.gather(torch.zeros(4, dtype=torch.int64, device="cuda"), force_dtype=torch.int32)
     assert ei.value.code == 3
     wgth.destroy_wholememory_tensor(wm)
+
+
+def test_mapped_gather_and_scatter_are_graph_capturable(gpu_env):
+    """CHUNKED / CONTINUOUS gather and scatter enqueue kernels on the caller's stream and nothing else (no host sync, no
+    scratch allocation), so a launch-bound sequence of small lookups can be captured into a hipGraph and replayed."""
+    torch = _torch()
+    import wholegraph_amd.torch as wgth
+    rows, dim, n, k = 200003, 64, 2048, 8
+    emb = wgth.create_embedding(gpu_env, "chunked", "cuda", torch.float32, [rows, dim])
+    table = emb.get_embedding_tensor()
+    local, _ = table.get_local_tensor()
+    local.copy_((torch.arange(rows, device="cuda") & 0xFFFFFF).float().unsqueeze(1).expand(rows, dim))
+    idxs = [torch.randint(0, rows, (n,), device="cuda") for _ in range(k)]
+    outs = [torch.zeros((n, dim), device="cuda") for _ in range(k)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up outside the capture
+        for i in range(k):
+            emb.gather(idxs[i], out=outs[i])
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(k):
+            emb.gather(idxs[i], out=outs[i])
+        table.scatter(outs[0] + 1.0, idxs[0])          # rows idxs[0] become value + 1 (duplicates agree)
+        emb.gather(idxs[0], out=outs[1])
+    for o in outs:
+        o.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for i in range(2, k):
+        assert bool((outs[i] == (idxs[i] & 0xFFFFFF).float().unsqueeze(1)).all())
+    assert bool((outs[1] == (idxs[0] & 0xFFFFFF).float().unsqueeze(1) + 1.0).all())
+    wgth.destroy_embedding(emb)
