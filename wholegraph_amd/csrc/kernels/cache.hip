@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "../backend.hpp"
 
 namespace wm {
@@ -204,25 +206,35 @@ __global__ __launch_bounds__(kBlock) void cache_update_kernel(cache_dev c, raw_v
   }
 }
 
-// ids -> (slot or -1, id or -1): the two index lists of the split lookup
+// ids -> (slot or -1, id or -1): the two index lists of the split lookup. Grid-stride with at most 1024 workgroups and ONE
+// atomic per workgroup for the hit statistics: an atomicAdd per wave on the single counter serialised 15 k atomics per
+// 1 M ids and made this 20 us kernel take 190 us.
 template <typename IdxT>
-__global__ void cache_split_kernel(cache_dev c, const IdxT* ids, int64_t n, int64_t* cache_idx, IdxT* raw_idx,
-                                   unsigned long long* hits)
+__global__ __launch_bounds__(kBlock) void cache_split_kernel(cache_dev c, const IdxT* ids, int64_t n, int64_t* cache_idx,
+                                                             IdxT* raw_idx, unsigned long long* hits)
 {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  bool hit        = false;
-  if (i < n) {
-    const IdxT id   = ids[i];
-    const int64_t r = static_cast<int64_t>(id) - c.cover_start;
-    int32_t slot    = -1;
-    if (id >= 0 && r >= 0 && r < c.cover_rows) slot = c.slot_of[r];
-    hit          = slot >= 0;
-    cache_idx[i] = slot;
-    raw_idx[i]   = hit ? static_cast<IdxT>(-1) : id;
+  __shared__ unsigned int block_hits;
+  if (threadIdx.x == 0) block_hits = 0;
+  __syncthreads();
+  unsigned int wave_hits = 0;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kBlock; base < n; base += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t i = base + threadIdx.x;
+    bool hit        = false;
+    if (i < n) {
+      const IdxT id   = ids[i];
+      const int64_t r = static_cast<int64_t>(id) - c.cover_start;
+      int32_t slot    = -1;
+      if (id >= 0 && r >= 0 && r < c.cover_rows) slot = c.slot_of[r];
+      hit          = slot >= 0;
+      cache_idx[i] = slot;
+      raw_idx[i]   = hit ? static_cast<IdxT>(-1) : id;
+    }
+    wave_hits += static_cast<unsigned int>(__popcll(__ballot(hit)));
   }
   if (hits != nullptr) {
-    const unsigned long long m = __ballot(hit);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(hits, static_cast<unsigned long long>(__popcll(m)));
+    if ((threadIdx.x & 63) == 0 && wave_hits) atomicAdd(&block_hits, wave_hits);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_hits) atomicAdd(hits, static_cast<unsigned long long>(block_hits));
   }
 }
 
@@ -248,15 +260,29 @@ __global__ __launch_bounds__(kBlock) void cache_writeback_kernel(cache_dev c, ra
   }
 }
 
-__global__ void cache_info_kernel(cache_dev c, unsigned long long* out)
+// occupied / modified cache lines: grid-stride, one pair of atomics per workgroup
+__global__ __launch_bounds__(kBlock) void cache_info_kernel(cache_dev c, unsigned long long* out)
 {
-  const int64_t slot = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const bool occ     = slot < c.n_sets * 64 && c.row_of[slot] >= 0;
-  const bool dirt    = occ && c.dirty[slot];
-  const unsigned long long mo = __ballot(occ), md = __ballot(dirt);
+  __shared__ unsigned int block_occ, block_dirty;
+  if (threadIdx.x == 0) block_occ = block_dirty = 0;
+  __syncthreads();
+  unsigned int occ_n = 0, dirty_n = 0;
+  const int64_t slots = c.n_sets * 64;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kBlock; base < slots; base += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t slot = base + threadIdx.x;
+    const bool occ     = slot < slots && c.row_of[slot] >= 0;
+    const bool dirt    = occ && c.dirty[slot];
+    occ_n += static_cast<unsigned int>(__popcll(__ballot(occ)));
+    dirty_n += static_cast<unsigned int>(__popcll(__ballot(dirt)));
+  }
   if ((threadIdx.x & 63) == 0) {
-    if (mo) atomicAdd(out, static_cast<unsigned long long>(__popcll(mo)));
-    if (md) atomicAdd(out + 1, static_cast<unsigned long long>(__popcll(md)));
+    if (occ_n) atomicAdd(&block_occ, occ_n);
+    if (dirty_n) atomicAdd(&block_dirty, dirty_n);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (block_occ) atomicAdd(out, static_cast<unsigned long long>(block_occ));
+    if (block_dirty) atomicAdd(out + 1, static_cast<unsigned long long>(block_dirty));
   }
 }
 
@@ -290,7 +316,7 @@ int hip_cache_split(const wm_cache_args* c, const void* ids, wholememory_dtype_t
 {
   if (n == 0) return 0;
   const cache_dev d = make_dev(*c);
-  const int blocks  = static_cast<int>((n + kBlock - 1) / kBlock);
+  const int blocks  = static_cast<int>(std::min<int64_t>((n + kBlock - 1) / kBlock, 1024));
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (dt == WHOLEMEMORY_DT_INT)
     hipLaunchKernelGGL((cache_split_kernel<int32_t>), dim3(blocks), dim3(kBlock), 0, stream, d, static_cast<const int32_t*>(ids), n, cache_idx, static_cast<int32_t*>(raw_idx), hits_dev);
@@ -316,7 +342,7 @@ int hip_cache_info(const wm_cache_args* c, unsigned long long* out2_dev, void* s
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (hipMemsetAsync(out2_dev, 0, 16, stream) != hipSuccess) return -2;
   if (c->n_sets == 0) return 0;
-  const int blocks = static_cast<int>((c->n_sets * 64 + kBlock - 1) / kBlock);
+  const int blocks = static_cast<int>(std::min<int64_t>((c->n_sets * 64 + kBlock - 1) / kBlock, 2048));
   hipLaunchKernelGGL(cache_info_kernel, dim3(blocks), dim3(kBlock), 0, stream, make_dev(*c), out2_dev);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
