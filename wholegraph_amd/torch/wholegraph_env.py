@@ -2,7 +2,7 @@
 caching allocator), the current HIP stream, and torch.Tensor -> wholememory_tensor_t wrapping.
 
 Reference counterpart: ``python/pylibwholegraph/pylibwholegraph/torch/wholegraph_env.py:27-182`` (Python
-callback env fns; the optional C++ torch extension of the reference is not needed here).
+callback env fns) and ``torch_cpp_ext/torch_env_func_ptrs.cpp`` (native env fns: ``csrc/torch_env.cpp`` here).
 """
 import ctypes as C
 import threading
@@ -135,14 +135,43 @@ class _EnvTable(object):
         return self._slots.get(int(ctx))
 
 
+class _NativeEnvTable(_EnvTable):
+    """Scratch buffers straight from torch's HIP caching allocator in C++ (csrc/torch_env.cpp, libwg_torch_env.so — the
+    counterpart of the reference's torch C++ extension); only the variable-size OUTPUT buffers, which must become torch
+    tensors, still come through the Python callbacks of the base class."""
+
+    def __init__(self, lib):
+        super().__init__()
+        lib.wg_torch_env_init.restype = None
+        lib.wg_torch_env_init.argtypes = [C.POINTER(wmb.EnvFunc), wmb.MALLOC_FN, wmb.FREE_FN, C.c_void_p]
+        self._lib = lib
+        self.env = wmb.EnvFunc()
+        lib.wg_torch_env_init(C.byref(self.env), self._malloc, self._free, None)
+
+
+def _load_native_env():
+    import os
+    if os.environ.get("WG_NATIVE_ENV", "1") == "0" or device_memory_is_host():
+        return None
+    path = os.path.join(os.path.dirname(wmb.LIB_PATH), "libwg_torch_env.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        return C.CDLL(path)
+    except OSError:
+        return None
+
+
 _default_env = None
 
 
 def get_wholegraph_env_fns(use_default=True):
-    """ctypes pointer to a wholememory_env_func_t backed by torch allocations."""
+    """ctypes pointer to a wholememory_env_func_t backed by torch allocations: the native table when libwg_torch_env.so
+    was built (WG_NATIVE_ENV=0 forces the all-Python one), else Python callbacks around torch.empty."""
     global _default_env
     if _default_env is None or not use_default:
-        table = _EnvTable()
+        lib = _load_native_env()
+        table = _NativeEnvTable(lib) if lib is not None else _EnvTable()
         if use_default:
             _default_env = table
     else:
