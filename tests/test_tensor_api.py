@@ -174,3 +174,27 @@ def test_wrapper_can_be_passed_as_a_temporary(wm_lib):
     w = wrap_torch_tensor(t)
     td = C.cast(wm_lib.wholememory_tensor_get_tensor_description(w), C.POINTER(wmb.TensorDescription)).contents
     assert td.dim == 2 and list(td.sizes[:2]) == [3, 4] and list(td.strides[:2]) == [4, 1]
+
+
+@pytest.mark.gpu
+def test_native_env_functions_are_in_use(gpu_env):
+    """On a GPU box the default env table takes scratch memory natively from torch's caching allocator
+    (libwg_torch_env.so); WG_NATIVE_ENV=0 would select the all-Python table."""
+    import os
+    import torch
+    from wholegraph_amd.torch import wholegraph_env as we
+    we.get_wholegraph_env_fns()
+    assert os.path.exists(os.path.join(os.path.dirname(B.LIB_PATH), "libwg_torch_env.so"))
+    assert isinstance(we._default_env, we._NativeEnvTable)
+    env = we._default_env.env
+    # a scratch allocation through the table comes out of torch's allocator: reserved memory does not grow on reuse
+    ctx = C.c_void_p()
+    desc = B.make_tensor_desc([1 << 20], B.DT_FLOAT)
+    env.temporary_fns.create_memory_context_fn(C.byref(ctx), None)
+    p1 = env.temporary_fns.malloc_fn(C.byref(desc), B.MA_DEVICE, ctx, None)
+    assert p1
+    env.temporary_fns.free_fn(ctx, None)
+    reserved = torch.cuda.memory_reserved()
+    p2 = env.temporary_fns.malloc_fn(C.byref(desc), B.MA_DEVICE, ctx, None)
+    assert p2 and torch.cuda.memory_reserved() == reserved
+    env.temporary_fns.destroy_memory_context_fn(ctx, None)
