@@ -310,3 +310,50 @@ def test_save_load_roundtrip(gpu_env, tmp_path):
     assert np.array_equal(local.cpu().numpy(), data) and np.array_equal(m.cpu().numpy(), data * 2)
     wgth.destroy_wholememory_optimizer(opt)
     wgth.destroy_embedding(emb)
+
+
+@pytest.mark.parametrize("with_negatives", [False, True])
+def test_gradient_apply_ignores_negative_ids(gpu_env, with_negatives):
+    """Negative ids are dropped by the bucketing (bucket_ids_func.cu:73): a batch with such entries must leave the table
+    exactly as the same batch without them does. Without negatives a single rank takes the no-staging path (the caller's
+    ids and gradient rows used in place); with them it takes the general one — both against the same expectation."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    n_rows, dim, n = 50021, 64, 30000
+    rng = np.random.default_rng(9)
+    init = rng.standard_normal((n_rows, dim)).astype(np.float32)
+    ids = rng.integers(0, n_rows, n).astype(np.int64)
+    ids[:500] = ids[7]                                   # a long run too
+    grads = rng.standard_normal((n, dim)).astype(np.float32)
+
+    def run(batch_ids, batch_grads):
+        emb = wgth.create_embedding(gpu_env, "distributed", "cuda", torch.float32, [n_rows, dim])
+        local, _ = emb.get_embedding_tensor().get_local_tensor()
+        local.copy_(torch.from_numpy(init).cuda())
+        wgth.create_wholememory_optimizer(emb, "sgd", {"weight_decay": 0.01})
+        emb.add_gradients(torch.from_numpy(batch_ids).cuda(), torch.from_numpy(batch_grads).cuda())
+        emb.need_apply = True
+        emb.apply_gradients(0.05)
+        torch.cuda.synchronize()
+        out = local.cpu().numpy().copy()
+        wgth.destroy_embedding(emb)
+        return out
+
+    want = run(ids, grads)
+    if with_negatives:
+        pos = np.sort(rng.choice(n + 700, 700, replace=False))
+        # interleave 700 negative entries (with junk gradient rows) at random positions, order of the rest unchanged
+        keep = np.ones(n + 700, dtype=bool)
+        keep[pos] = False
+        mixed_ids = np.full(n + 700, -1, dtype=np.int64)
+        mixed_ids[keep] = ids
+        mixed_grads = np.full((n + 700, dim), 1e9, dtype=np.float32)
+        mixed_grads[keep] = grads
+        got = run(mixed_ids, mixed_grads)
+    else:
+        got = run(ids.copy(), grads.copy())
+    assert got.tobytes() == want.tobytes()
+    uniq, dg = oracle.dedup_grads(ids, grads)
+    ref = init.copy()
+    oracle.Optimizer("sgd", n_rows, dim, weight_decay=0.01).step(uniq, dg, ref, dim, 0, dim, 0.05)
+    assert want.tobytes() == ref.tobytes()

@@ -264,8 +264,12 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   const size_t ies    = wholememory_dtype_get_element_size(iarr.dtype);
   const char* idx_ptr = static_cast<const char*>(wholememory_tensor_get_data_pointer(indices));  // data ptr already offset
 
+  // this rank's own rows are not copied at all: the step kernels read them where the caller left them (the receive
+  // positions of the self segment are remapped to caller rows after the sort). WM_GRAD_SELF_COPY=1 restores the copy.
+  const char* self_copy_env = getenv("WM_GRAD_SELF_COPY");
+  const bool self_in_place  = bk->remap_self_order != nullptr && !(self_copy_env != nullptr && self_copy_env[0] == '1');
   id_exchange x(env);
-  bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x, true);
+  bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x, true, self_in_place);
   (void)ies;
   const int rank = e->comm->world_rank;
 
@@ -278,12 +282,14 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   const int64_t n_recv = full_recv_offsets[e->comm->world_size];
 
   temp_mem send_rows(env), recv_rows(env), recv_ids_mem(env);
-  auto* send_buf = static_cast<char*>(send_rows.device(dim * x.total_valid, vdt));
-  auto* recv_buf = static_cast<char*>(recv_rows.device(dim * n_recv, vdt));
+  // (x.identity: one rank, nothing dropped — the caller's ids and gradient rows are used where they are: no staging
+  // buffers at all, which at 10 M x 512 B rows is 10 GB not taken from the allocator)
+  auto* send_buf = static_cast<char*>(send_rows.device(x.identity ? 0 : dim * x.total_valid, vdt));
+  auto* recv_buf = static_cast<char*>(recv_rows.device(x.identity ? 0 : dim * n_recv, vdt));
   const size_t row_bytes = static_cast<size_t>(dim) * ves;
-  char* recv_ids = static_cast<char*>(recv_ids_mem.device(n_recv, iarr.dtype));
+  char* recv_ids = x.identity ? const_cast<char*>(idx_ptr) : static_cast<char*>(recv_ids_mem.device(n_recv, iarr.dtype));
   // ids: peers' segments were received compactly (self cut out) — place them around the self slot
-  for (int r = 0; r < e->comm->world_size; r++) {
+  for (int r = 0; r < e->comm->world_size && !x.identity; r++) {
     const char* src = r == rank ? static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset
                                 : static_cast<const char*>(x.recv_ids) + ies * x.recv_offsets[r];
     if (full_recv_counts[r] > 0)
@@ -307,11 +313,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     ga.max_blocks   = -1;
     WM_BK(bk->gather_rows(&ga, stream));
   };
-  // this rank's own rows are not copied at all: the step kernels read them where the caller left them (the receive
-  // positions of the self segment are remapped to caller rows after the sort). WM_GRAD_SELF_COPY=1 restores the copy.
-  const char* self_copy_env = getenv("WM_GRAD_SELF_COPY");
-  const bool self_direct    = x.self_count > 0 && bk->remap_self_order != nullptr &&
-                           !(self_copy_env != nullptr && self_copy_env[0] == '1');
+  const bool self_direct = x.self_count > 0 && self_in_place;
   self_rows_ref self_ref;
   if (self_direct) {
     self_ref.begin  = full_recv_offsets[rank];

@@ -57,7 +57,7 @@ void* temp_mem::alloc(int64_t elt_count, wholememory_dtype_t dtype, wholememory_
 // ------------------------------------------------------------------------------------------------
 void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
                              const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream,
-                             id_exchange* x, bool keep_self_local)
+                             id_exchange* x, bool keep_self_local, bool allow_identity)
 {
   const auto* bk = backend();
   const int W    = comm->world_size;
@@ -71,7 +71,7 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   // owners than ranks an id of owner o travels to rank o % W (first hop of the HIERARCHY gather)
   const int owners = static_cast<int>(entry_offsets.size()) - 1;
   WM_CHECK(owners >= W, "bucket_and_exchange_ids: fewer row ranges than ranks");
-  temp_mem dev_offsets(env), dev_counts(env), workspace(env), host_counts(env);
+  temp_mem dev_offsets(env), dev_counts(env), workspace(env), workspace2(env), host_counts(env);
   auto* d_off = static_cast<uint64_t*>(dev_offsets.device(owners + 1, WHOLEMEMORY_DT_INT64));
   auto* d_cnt = static_cast<int64_t*>(dev_counts.device(W, WHOLEMEMORY_DT_INT64));
   auto* h_cnt = static_cast<int64_t*>(host_counts.pinned(W + owners + 1, WHOLEMEMORY_DT_INT64));
@@ -80,6 +80,30 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   for (int i = 0; i <= owners; i++) h_off[i] = entry_offsets[i];
   WM_BK(bk->memcpy_async(d_off, h_off, sizeof(uint64_t) * (owners + 1), stream));
 
+  if (allow_identity && keep_self_local && W == 1 && owners == 1) {
+    // one rank: the only thing bucketing could do is drop negative ids — count first (histogram only), and when there is
+    // none leave the caller's array where it is
+    wm_bucket_args ca{};
+    ca.indices       = indices;
+    ca.index_dtype   = index_dtype;
+    ca.n             = n;
+    ca.entry_offsets = d_off;
+    ca.world_size    = 1;
+    ca.counts        = d_cnt;
+    ca.workspace     = workspace.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, 1)), WHOLEMEMORY_DT_INT8);
+    WM_BK(bk->bucket_ids(&ca, stream));
+    WM_BK(bk->memcpy_async(h_cnt, d_cnt, sizeof(int64_t), stream));
+    WM_BK(bk->stream_sync(stream));
+    if (h_cnt[0] == n) {
+      x->identity       = true;
+      x->bucketed_ids   = const_cast<void*>(indices);
+      x->raw_indices    = nullptr;
+      x->bucket_offsets = {0, n};
+      x->total_valid = x->self_count = n;
+      x->self_offset = x->total_send = x->total_recv = x->global_moved = 0;
+      return;
+    }
+  }
   x->bucketed_ids = x->bucketed_mem.device(n, index_dtype);
   x->raw_indices  = static_cast<int64_t*>(x->raw_mem.device(n, WHOLEMEMORY_DT_INT64));
 
@@ -93,7 +117,7 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   ba.counts        = d_cnt;
   ba.bucketed_ids  = x->bucketed_ids;
   ba.raw_indices   = x->raw_indices;
-  ba.workspace     = workspace.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, W)), WHOLEMEMORY_DT_INT8);
+  ba.workspace     = workspace2.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, W)), WHOLEMEMORY_DT_INT8);
   WM_BK(bk->bucket_ids(&ba, stream));
   WM_BK(bk->memcpy_async(h_cnt, d_cnt, sizeof(int64_t) * W, stream));
   WM_BK(bk->stream_sync(stream));

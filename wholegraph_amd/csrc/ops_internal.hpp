@@ -43,6 +43,9 @@ struct id_exchange {
   int64_t total_recv  = 0;                          // ids received from peers
   int64_t total_valid = 0;                          // non-negative ids of this rank (all owners)
   int64_t global_moved = 0;                         // ids that change rank, summed over ALL ranks (same on every rank)
+  // one rank and not a single negative id: nothing was moved or dropped — bucketed_ids IS the caller's array and
+  // raw_indices (null) stands for the identity. Only produced when the caller asked for it (allow_identity)
+  bool identity = false;
   int64_t self_count  = 0;                          // ids of this rank that it owns itself
   int64_t self_offset = 0;                          // their position in bucketed_ids / raw_indices
   void* bucketed_ids   = nullptr;                   // [n]   ids grouped by owner (index dtype)
@@ -53,7 +56,7 @@ struct id_exchange {
 
 void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
                              const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream,
-                             id_exchange* x, bool keep_self_local = false);
+                             id_exchange* x, bool keep_self_local = false, bool allow_identity = false);
 
 // all-to-all-v of fixed-size rows with explicit per-peer row offsets on both sides
 void exchange_segments(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts,
