@@ -17,3 +17,13 @@ def test_random_row_shapes_match_torch(wm_lib, seed):
                        capture_output=True, timeout=900)
     out = p.stdout.decode() + p.stderr.decode()
     assert p.returncode == 0 and "cases 250, failures 0" in out, out[-3000:]
+
+
+@pytest.mark.gpu
+def test_random_dedup_apply_cases_match_the_oracle(wm_lib):
+    """experiments/fuzz_optim.py: optimizer kinds x dims x strides x run-length mixes (in-wave folds, the LDS-DMA long-run
+    kernel across tile and order-chunk boundaries, its fallback), two steps each, bit-exact against the oracle."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "experiments", "fuzz_optim.py"), "120", "17"],
+                       capture_output=True, timeout=900)
+    out = p.stdout.decode() + p.stderr.decode()
+    assert p.returncode == 0 and "cases 120, failures 0" in out, out[-3000:]
