@@ -27,3 +27,13 @@ def test_random_dedup_apply_cases_match_the_oracle(wm_lib):
                        capture_output=True, timeout=900)
     out = p.stdout.decode() + p.stderr.decode()
     assert p.returncode == 0 and "cases 120, failures 0" in out, out[-3000:]
+
+
+@pytest.mark.gpu
+def test_random_op_sequences_keep_the_row_cache_transparent(wm_lib):
+    """experiments/fuzz_cache.py: gathers / training steps / write-backs / drops on a cached HOST embedding against an
+    uncached twin, outputs, tables and optimizer states equal bit for bit."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "experiments", "fuzz_cache.py"), "40", "5"],
+                       capture_output=True, timeout=900)
+    out = p.stdout.decode() + p.stderr.decode()
+    assert p.returncode == 0 and "sequences 40, failures 0" in out, out[-3000:]
