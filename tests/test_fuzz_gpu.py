@@ -37,3 +37,13 @@ def test_random_op_sequences_keep_the_row_cache_transparent(wm_lib):
                        capture_output=True, timeout=900)
     out = p.stdout.decode() + p.stderr.decode()
     assert p.returncode == 0 and "sequences 40, failures 0" in out, out[-3000:]
+
+
+@pytest.mark.gpu
+def test_random_graphs_sample_like_the_oracle(wm_lib):
+    """experiments/fuzz_sample.py: random CSR graphs / fan-outs / seeds / dtypes / placements — unweighted and weighted
+    one-hop sampling and append_unique bit for bit against the oracle."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "experiments", "fuzz_sample.py"), "150", "9"],
+                       capture_output=True, timeout=900)
+    out = p.stdout.decode() + p.stderr.decode()
+    assert p.returncode == 0 and "cases 150, failures 0" in out, out[-3000:]
