@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 MODE = sys.argv[4] if len(sys.argv) > 4 else "cpu"
 HIP_MODE = MODE.startswith("hip")   # real kernels on cuda:0, collectives still over gloo
 HIER_MODE = MODE.endswith("-hier")  # HIERARCHY tables on a pretended multi-node layout (WM_LOCAL_SIZE ranks per node)
+FUZZ_MODE = MODE.endswith("-fuzz")  # random shapes / partitions / dtypes (FUZZ_SEED, FUZZ_CASES), same on every rank
 if not HIP_MODE:
     os.environ["WHOLEGRAPH_AMD_TESTING"] = "1"
 
@@ -404,6 +405,31 @@ def hierarchy_scenarios(comm, rank, world):
     scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)
 
 
+def fuzz_scenarios(comm, rank, world):
+    """Random table shapes, dtype pairs, id dtypes and row partitions (every rank draws the same ones from FUZZ_SEED) through
+    the gather / scatter scenario; HIERARCHY tables too when a node layout is pretended (WM_LOCAL_SIZE)."""
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
+    types = ["distributed"] + (["hierarchy"] if "WM_LOCAL_SIZE" in os.environ else [])
+    pairs = [(np.float32, np.float32), (np.float16, np.float32), (np.float32, np.float16), (np.int64, np.int32),
+             (np.int32, np.int64), (np.float16, np.float16)]
+    for case in range(int(os.environ.get("FUZZ_CASES", "10"))):
+        n_rows = int(rng.integers(1, 5000))
+        dim = int(rng.choice([1, 3, 4, 8, 11, 32, 33, 64, 100]))
+        tdt, odt = pairs[rng.integers(len(pairs))]
+        idt = np.int32 if rng.random() < 0.5 else np.int64
+        mt = types[rng.integers(len(types))]
+        entries = None
+        if rng.random() < 0.5 and n_rows >= world:
+            cuts = np.sort(rng.choice(np.arange(1, n_rows), world - 1, replace=False)) if world > 1 else np.array([], int)
+            entries = [int(x) for x in np.diff(np.concatenate([[0], cuts, [n_rows]]))]
+        try:
+            scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, entries)
+        except BaseException:
+            print("FUZZ CASE %d: %s rows %d dim %d %s->%s %s entries %s" % (
+                case, mt, n_rows, dim, np.dtype(tdt).name, np.dtype(odt).name, np.dtype(idt).name, entries), flush=True)
+            raise
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
@@ -416,6 +442,13 @@ def main():
     wgth.init(rank, world, rank, world, os.environ.get("WM_TEST_LOG", "warn"))
     comm = wgth.get_global_communicator()
     assert comm.get_rank() == rank and comm.get_size() == world
+    if FUZZ_MODE:
+        fuzz_scenarios(comm, rank, world)
+        comm.barrier()
+        dist.barrier()
+        print("RANK %d OK" % rank)
+        wgth.finalize()
+        return
     if HIER_MODE:
         hierarchy_scenarios(comm, rank, world)
         comm.barrier()

@@ -71,3 +71,15 @@ def test_hierarchy_gather_over_gloo(wm_lib, world, local, chunks):
 @pytest.mark.parametrize("world,local", [(4, 2), (3, 3)])
 def test_hierarchy_gather_hip_kernels(wm_lib, world, local):
     run_world(world, "hip-hier", {"WM_LOCAL_SIZE": str(local)})
+
+
+@pytest.mark.parametrize("world,local,seed", [(2, 0, 1), (3, 0, 2), (4, 2, 3), (5, 0, 4), (6, 3, 5), (6, 2, 6)])
+def test_random_shapes_and_partitions_over_gloo(wm_lib, world, local, seed):
+    """Random table shapes / dtype pairs / id dtypes / custom row partitions through the multi-rank gather + scatter
+    scenario (DISTRIBUTED, and HIERARCHY on a pretended node layout), bit-exact vs the oracle's multi-rank simulation."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "test_backend"], stdout=subprocess.DEVNULL)
+    env = {"WHOLEGRAPH_AMD_TESTING": "1", "HIP_VISIBLE_DEVICES": "", "FUZZ_SEED": str(seed), "FUZZ_CASES": "12",
+           "WM_EXCHANGE_CHUNKS": str(1 + seed % 3)}
+    if local:
+        env["WM_LOCAL_SIZE"] = str(local)
+    run_world(world, "cpu-fuzz", env)
