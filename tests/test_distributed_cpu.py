@@ -83,3 +83,12 @@ def test_random_shapes_and_partitions_over_gloo(wm_lib, world, local, seed):
     if local:
         env["WM_LOCAL_SIZE"] = str(local)
     run_world(world, "cpu-fuzz", env)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,local,seed", [(3, 0, 11), (4, 2, 12)])
+def test_random_shapes_and_partitions_hip_kernels(wm_lib, world, local, seed):
+    env = {"FUZZ_SEED": str(seed), "FUZZ_CASES": "10"}
+    if local:
+        env["WM_LOCAL_SIZE"] = str(local)
+    run_world(world, "hip-fuzz", env)
