@@ -424,6 +424,12 @@ def fuzz_scenarios(comm, rank, world):
             entries = [int(x) for x in np.diff(np.concatenate([[0], cuts, [n_rows]]))]
         try:
             scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, entries)
+            if case % 3 == 0:   # a training flow too: random optimizer on a randomly partitioned 1201-row table
+                kind, params = [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}), ("adagrad", {}),
+                                ("rmsprop", {"alpha": 0.95})][rng.integers(4)]
+                cuts = np.sort(rng.choice(np.arange(1, 1201), world - 1, replace=False))
+                gent = [int(x) for x in np.diff(np.concatenate([[0], cuts, [1201]]))] if rng.random() < 0.5 else None
+                scenario_gradient_apply(comm, rank, world, kind, params, np.int64 if rng.random() < 0.5 else np.int32, gent, mt=mt)
         except BaseException:
             print("FUZZ CASE %d: %s rows %d dim %d %s->%s %s entries %s" % (
                 case, mt, n_rows, dim, np.dtype(tdt).name, np.dtype(odt).name, np.dtype(idt).name, entries), flush=True)
