@@ -10,11 +10,17 @@ random int64 ids (default 10 M) into an fp32 [n, 128] output, table resident in 
 `value` follows the reference bench convention (cpp/bench/wholememory_ops/gather_scatter_bench.cu:364):
 output bytes / time / 1e9, aggregated over all ranks; `mlookups_per_s` and the algorithmic
 (idx + row read + row write = 1032 B / lookup) rate are reported beside it.
-Launch: python bench.py [--gpus 1]   or   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+Launch: python bench.py [--gpus N]  (N > 1 without RANK in the environment: the script starts N ranks itself, one per
+visible GPU, like the reference bench forks one process per device, gather_scatter_bench.cu:257-284)
+   or   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+The timed region is EXACTLY --steps steps between two barriers; `stability` is a separate leg of per-step HIP-event times
+(min / median / p95 over >= 200 steps) run after it, so one noisy neighbour cannot hide in a 36 ms window.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,8 +34,10 @@ import torch
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--stability-steps", type=int, default=200,
+                   help="per-step HIP-event timing leg after the timed region (0 = skip)")
     p.add_argument("--rows", type=int, default=0, help="table rows per GPU (default: 100M at N=1, 125M at N>1)")
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--indices", type=int, default=10_000_000)
@@ -88,6 +96,24 @@ def usable_cores():
     return n
 
 
+def cpu_gather_rate(rows, dim, n, seconds, threads):
+    """passes of the oracle's OpenMP gather of n random int64 ids over a host rows x dim fp32 table for ~seconds"""
+    import oracle
+    oracle.set_num_threads(threads)
+    table = np.empty((rows, dim), dtype=np.float32)
+    table[:] = (np.arange(rows, dtype=np.int64) & 0xFFFFFF).astype(np.float32)[:, None]
+    tab = oracle.ShardedTable([table], np.array([0, rows], dtype=np.uint64), dim)
+    idx = np.random.default_rng(42).integers(0, rows, n, dtype=np.int64)
+    out = np.empty((n, dim), dtype=np.float32)
+    oracle.gather(tab, idx, out)  # warm
+    t0, passes = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        oracle.gather(tab, idx, out)
+        passes += 1
+    dt = time.perf_counter() - t0
+    return passes * n / dt, passes, dt
+
+
 def cpu_baseline(dim, seconds):
     """The oracle's gather (OpenMP over indices) on a host-resident table on this box's host cores:
     a bounded sample of the same workload shape (random 512 B rows, int64 ids)."""
@@ -129,11 +155,76 @@ def cpu_baseline(dim, seconds):
         passes += 1
     res["torch_index_select_GBps"] = round(passes * n * dim * 4 / (time.perf_counter() - t0) / 1e9, 3)
     res["torch_threads"] = torch.get_num_threads()
+    del table, tab, tt, to, out
+    # BASELINE config C1 at its full shape (10 M x 64 fp32 host table, 1 M random ids): the reference's own CPU-runnable
+    # case; the GPU number for the same shape (HOST-located table read over PCIe) is reported next to it
+    lk, passes, dt = cpu_gather_rate(10_000_000, 64, 1_000_000, min(5.0, seconds), threads)
+    res["c1_shape"] = {"value": round(lk * 64 * 4 / 1e9, 3), "unit": "GB/s", "mlookups_per_s": round(lk / 1e6, 2),
+                       "cores": threads, "kind": "port",
+                       "sample": "oracle gather, %d passes of 1000000 random int64 ids over a host 10000000x64 fp32 table "
+                                 "in %.1f s" % (passes, dt)}
     return res
+
+
+def gpu_c1_host(wgth, comm):
+    """config C1 on the GPU path: HOST-located 10 M x 64 fp32 WholeMemory table (pinned, read by the GPU over PCIe /
+    Infinity Fabric), 1 M random int64 ids -> device output. Side number for the cpu_baseline c1_shape line."""
+    rows, dim, n = 10_000_000, 64, 1_000_000
+    emb = wgth.create_embedding(comm, "chunked", "cpu", torch.float32, [rows, dim])
+    local, _ = emb.get_embedding_tensor().get_local_tensor(host_view=True)
+    local[:] = (torch.arange(rows, dtype=torch.int64) & 0xFFFFFF).to(torch.float32).unsqueeze(1)
+    idx = torch.from_numpy(np.random.default_rng(42).integers(0, rows, n, dtype=np.int64)).cuda()
+    out = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        emb.gather(idx, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, 0], (idx & 0xFFFFFF).to(torch.float32))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        emb.gather(idx, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    wgth.destroy_embedding(emb)
+    return {"ms_per_gather": round(ms, 4), "value": round(n * dim * 4 / (ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+            "mlookups_per_s": round(n / (ms * 1e-3) / 1e6, 1), "bound": "pcie",
+            "workload": "C1 HOST chunked 10000000x64 fp32 table in pinned host memory, 1000000 uniform int64 ids, output in HBM"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher: start N ranks (one per visible GPU over RCCL; with --backend gloo the
+    ranks may share a GPU) and pass rank 0's single JSON line through."""
+    n = a.gpus
+    have = torch.cuda.device_count()
+    if a.backend == "nccl" and have < n:
+        sys.stderr.write("bench.py: --gpus %d asked but only %d GPU(s) are visible; RCCL needs one device per rank "
+                         "(use --backend gloo to share a device for bring-up)\n" % (n, have))
+        sys.exit(2)
+    port = str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WM_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
 
 def main():
     a = parse()
+    if "RANK" not in os.environ and a.gpus > 1:
+        self_launch(a)
     # stdout carries exactly one line, the JSON record: native libraries (RCCL prints "Librccl path : ..." on load)
     # write to fd 1 directly, so fd 1 points at stderr until the record is printed
     sys.stdout.flush()
@@ -158,6 +249,9 @@ def main():
         wmb.check(wmb.lib().wholememory_init(0, wmb.LEVEL_WARN))
         comm = wgth.create_group_communicator(1)
     assert wmb.lib().wholememory_ext_backend_name() == b"hip-gfx950"
+    transport, transport_ranks = comm.transport()
+    if world > 1 and a.backend == "nccl":
+        assert (transport, transport_ranks) == ("rccl", world), "expected %d RCCL ranks, have %s" % (world, (transport, transport_ranks))
 
     rows_per_gpu = a.rows or (100_000_000 if world == 1 else 125_000_000)
     total_rows = rows_per_gpu * world
@@ -223,6 +317,23 @@ def main():
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     wall = float(dt.item())
     dev_ms = ev0.elapsed_time(ev1) / a.steps  # HIP events on the stream the kernels were launched on
+    rows_kernel = wmb.lib().wholememory_ext_last_rows_kernel().decode()   # what the HIP runtime calls the kernel just run
+
+    # per-step spread, outside the timed region: one HIP event pair per step
+    stability = None
+    if a.stability_steps > 0:   # every rank runs it: at N > 1 the step is a collective
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.stability_steps + 1)]
+        evs[0].record()
+        for i in range(a.stability_steps):
+            step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(a.stability_steps)])
+        stability = {"steps": a.stability_steps, "min_ms": round(float(per.min()), 4),
+                     "median_ms": round(float(np.median(per)), 4), "p95_ms": round(float(np.percentile(per, 95)), 4),
+                     "max_ms": round(float(per.max()), 4),
+                     "note": "per-step HIP-event times on rank 0, separate from the timed region"}
+        barrier()
 
     # N > 1: the step is link-bound (see `exchange`); the HBM roofline object then describes the dominant HBM kernel on its
     # own — the owner-side row gather — timed on this rank's local shard outside the step loop, same ids folded into it
@@ -246,7 +357,7 @@ def main():
         kbytes = a.indices * (8 + 2 * a.dim * es)
         local_kernel_roofline = {"bound": "hbm", "achieved": round(kbytes / (kms * 1e-3) / 1e9, 1), "peak": 8000.0,
                                  "unit": "GB/s", "frac": round(kbytes / (kms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
-                                 "kernel": "rows_copy16_fast_kernel<long, true, 2, false>", "kernel_ms": round(kms, 4),
+                                 "kernel": wmb.lib().wholememory_ext_last_rows_kernel().decode(), "kernel_ms": round(kms, 4),
                                  "algorithmic_bytes_per_launch": kbytes,
                                  "scope": "owner-side row gather on rank 0's local shard, timed outside the step loop; "
                                           "the step itself is link-bound (see exchange)"}
@@ -262,7 +373,8 @@ def main():
                 a.op, {"gather": "gathered output", "scatter": "scattered input", "grad_apply": "gradient"}[a.op]),
             "value": round(lookups * out_bytes / 1e9, 2),
             "unit": "GB/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": world, "rccl_ranks": transport_ranks if transport == "rccl" else 0, "transport": transport,
+            "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(wall / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
@@ -278,19 +390,27 @@ def main():
         if world == 1 and a.op == "gather" and a.dtype == "f32":
             # dominant kernel = rows_copy_kernel<long,16,true>: the whole step at N=1
             achieved = a.indices * algo_bytes / (dev_ms * 1e-3) / 1e9
-            traffic = None
+            # HBM traffic comes from PMC counters, which need their own rocprofv3 passes (scripts/collect_traffic.py runs this
+            # very command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`); the figure is per launch of the same
+            # kernel on the same workload, and the bench line says where it was measured
+            traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and a.indices == 10_000_000 and a.dim == 128 and a.dist == "uniform":
                 try:
-                    traffic = json.load(open(pmc)).get("gather_hbm_bytes_per_launch")
+                    rec = json.load(open(pmc))
+                    traffic = rec.get("gather_hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_traffic.json@%s (%s)" % (rec.get("commit", "r01"), rec.get("collected", "round 1"))
                 except Exception:
                     traffic = None
             res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                               "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                               "kernel": "rows_copy16_fast_kernel<long, true, 2, false>", "kernel_ms": round(dev_ms, 4),
+                               "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
+                               "kernel": rows_kernel, "kernel_ms": round(dev_ms, 4),
                                "algorithmic_bytes_per_launch": a.indices * algo_bytes}
+            if stability is not None:
+                res["roofline"]["frac_at_median_step"] = round(a.indices * algo_bytes / (stability["median_ms"] * 1e-3) / 8e12, 4)
             if not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(a.dim, a.cpu_seconds)
+                res["gpu_c1_host"] = gpu_c1_host(wgth, comm)
         if world > 1 and a.op == "gather" and a.dtype == "f32":
             res["roofline"] = local_kernel_roofline
         if world > 1 and a.op == "gather" and mt == "distributed":
@@ -305,6 +425,8 @@ def main():
                                        "owner-side gather and the reorder-on-receive kernels"}
             if a.backend != "nccl":
                 res["exchange"]["note"] = "BRING-UP RUN: collectives over torch.distributed/%s, not RCCL" % a.backend
+        if stability is not None:
+            res["stability"] = stability
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     wgth.destroy_embedding(emb)

@@ -47,6 +47,11 @@ typedef struct wm_ext_collectives_t wm_ext_collectives_t;
 enum wholememory_error_code_t wholememory_create_communicator_ext(
   wholememory_comm_t* comm, int rank, int size, const struct wm_ext_collectives_t* collectives);
 
+/* Which transport carries this communicator's collectives: name = "rccl" | "external" | "external (sub-group)" | "none"
+ * (a single-rank communicator needs none); ranks = what the transport itself reports (ncclCommCount for RCCL, -1 when
+ * it cannot tell, 0 for "none"). bench.py prints it so that an N-GPU line proves N RCCL ranks. */
+enum wholememory_error_code_t wholememory_ext_communicator_transport(wholememory_comm_t comm, const char** name, int* ranks);
+
 /* ---- (2) raw stages ------------------------------------------------------------------------ */
 /* Owner bucketing of ids (reference bucket_ids_func.cu:51-87 + the grouping effect of
  * exchange_ids_nccl_func.cu:42-92). entry_offsets: DEVICE uint64[world+1] row offsets. counts:
@@ -114,6 +119,10 @@ enum wholememory_error_code_t wholememory_ext_round_robin_map(const void* ids,
 
 /* name of the installed device backend ("hip-gfx950" in the product) */
 const char* wholememory_ext_backend_name();
+
+/* demangled name the HIP runtime holds (hipKernelNameRefByPtr) for the gather / scatter kernel instantiation the calling
+ * thread launched last; "" before the first launch */
+const char* wholememory_ext_last_rows_kernel();
 
 /* ---- (3) testing seam ---------------------------------------------------------------------- */
 /* Replaces the device backend. Refuses (WHOLEMEMORY_NOT_SUPPORTED) unless the environment has

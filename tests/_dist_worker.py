@@ -12,6 +12,10 @@ MODE = sys.argv[4] if len(sys.argv) > 4 else "cpu"
 HIP_MODE = MODE.startswith("hip")   # real kernels on cuda:0, collectives still over gloo
 HIER_MODE = MODE.endswith("-hier")  # HIERARCHY tables on a pretended multi-node layout (WM_LOCAL_SIZE ranks per node)
 FUZZ_MODE = MODE.endswith("-fuzz")  # random shapes / partitions / dtypes (FUZZ_SEED, FUZZ_CASES), same on every rank
+# "hip-rccl": one rank per GPU, torch.distributed backend nccl, the library's own RCCL communicator underneath (the product
+# configuration). On a one-GPU box it runs at world 1 with WM_FORCE_RCCL=1 + WM_EXCHANGE_SELF=1 (set by the test), which
+# sends the rank's own segment through rccl_provider like a peer's.
+RCCL_MODE = MODE == "hip-rccl"
 if not HIP_MODE:
     os.environ["WHOLEGRAPH_AMD_TESTING"] = "1"
 
@@ -436,18 +440,66 @@ def fuzz_scenarios(comm, rank, world):
             raise
 
 
+def rccl_scenarios(comm, rank, world):
+    """The distributed ops with the library's RCCL transport underneath (reference nccl_comms.cpp:82-86 barrier,
+    :383-437 host_alltoall / alltoallv, communicator.cpp:703-752 create): transport identity, barrier, split, then
+    DISTRIBUTED gather / scatter / gradient apply bit-exact against the oracle's multi-rank simulation."""
+    assert comm.transport() == ("rccl", world), comm.transport()
+    comm.barrier()
+    # split: colour = rank parity -> communicators of ceil/floor(world / 2) ranks, each with its own ncclComm
+    sub = wgth.split_communicator(comm, rank % 2, rank)
+    assert sub.get_size() == (world + 1 - rank % 2) // 2 and sub.get_rank() == rank // 2
+    if sub.get_size() > 1 or os.environ.get("WM_EXCHANGE_SELF") == "1":
+        assert sub.transport() == ("rccl", sub.get_size()), sub.transport()
+    sub.barrier()
+    if os.environ.get("WM_EXCHANGE_SELF") == "1" or sub.get_size() > 1:
+        scenario_gather_scatter(sub, sub.get_rank(), sub.get_size(), "distributed", 1003, 11, np.float32, np.float32,
+                                np.int64, None)
+    wgth.destroy_communicator(sub)
+    comm.barrier()
+    scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)
+    scenario_gather_scatter(comm, rank, world, "distributed", 2000, 32, np.float16, np.float32, np.int32, None)
+    scenario_gather_scatter(comm, rank, world, "distributed", 300001, 128, np.float32, np.float32, np.int64, None)
+    w8 = np.random.default_rng(42).uniform(90, 100, world)
+    ent = [int(x) for x in (w8 / w8.sum() * 997).astype(int)]
+    ent[0] += 997 - sum(ent)
+    scenario_gather_scatter(comm, rank, world, "distributed", 997, 8, np.int64, np.int32, np.int64, ent)
+    os.environ["WM_GATHER_DEDUP"] = "2"
+    scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)
+    del os.environ["WM_GATHER_DEDUP"]
+    scenario_gather_scatter(comm, rank, world, "distributed", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
+    for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}), ("adagrad", {}),
+                         ("rmsprop", {"alpha": 0.95})]:
+        scenario_gradient_apply(comm, rank, world, kind, params, np.int64 if kind != "adagrad" else np.int32, None)
+    scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0)
+    scenario_sampling(comm, rank, world, "distributed", np.int64)
+    scenario_cached_embedding(comm, rank, world, "distributed")
+    scenario_file_io(comm, rank, world, "/tmp/wgamd_test_rccl_%s" % os.environ["MASTER_PORT"])
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
-    if HIP_MODE:
+    if RCCL_MODE:
+        assert torch.cuda.device_count() >= world, "hip-rccl needs one GPU per rank"
+        torch.cuda.set_device(rank)
+    elif HIP_MODE:
         torch.cuda.set_device(0)   # every rank shares the one GPU of the test box
+    dist.init_process_group(backend="nccl" if RCCL_MODE else "gloo", init_method="env://", rank=rank, world_size=world)
+    if HIP_MODE:
         assert wmb.lib().wholememory_ext_backend_name() == b"hip-gfx950"
     else:
         install_test_backend()
     wgth.init(rank, world, rank, world, os.environ.get("WM_TEST_LOG", "warn"))
     comm = wgth.get_global_communicator()
     assert comm.get_rank() == rank and comm.get_size() == world
+    if RCCL_MODE:
+        rccl_scenarios(comm, rank, world)
+        comm.barrier()
+        dist.barrier()
+        print("RANK %d OK" % rank)
+        wgth.finalize()
+        return
     if FUZZ_MODE:
         fuzz_scenarios(comm, rank, world)
         comm.barrier()

@@ -33,8 +33,44 @@ def test_single_gpu_line(wm_lib):
     roof = r["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert roof["algorithmic_bytes_per_launch"] == 500000 * (8 + 512 + 512)
+    assert "rows_copy16_fast_kernel" in roof["kernel"]          # the name comes from the HIP runtime, not from bench.py
     cpu = r["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu
+    assert cpu["c1_shape"]["value"] > 0 and "10000000x64" in cpu["c1_shape"]["sample"]
+    assert r["gpu_c1_host"]["value"] > 0 and r["gpu_c1_host"]["bound"] == "pcie"
+    st = r["stability"]
+    assert st["steps"] == 200 and 0 < st["min_ms"] <= st["median_ms"] <= st["p95_ms"] <= st["max_ms"]
+    assert r["transport"] == "none" and r["rccl_ranks"] == 0
+
+
+def test_self_launch_without_a_launcher(wm_lib):
+    """`python bench.py --gpus 2` with no RANK in the environment starts the ranks itself (reference bench:
+    gather_scatter_bench.cu:257-284 forks one process per device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rows", "1000003",
+                        "--indices", "300000", "--steps", "3", "--warmup", "1", "--stability-steps", "5"],
+                       capture_output=True, timeout=900, env=dict(env, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    r = _one_json_line(p.stdout)
+    assert r["n_gpus"] == 2 and r["transport"] == "external" and r["rccl_ranks"] == 0 and r["stability"]["steps"] == 5
+
+
+def test_more_gpus_than_visible_fails_loudly(wm_lib):
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1"],
+                       capture_output=True, timeout=300)
+    assert p.returncode != 0 and b"visible" in p.stderr and p.stdout.strip() == b""
+
+
+def test_forced_rccl_single_rank_reports_its_transport(wm_lib):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "4000000", "--indices", "500000",
+                        "--memory-type", "distributed", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--stability-steps", "0"], capture_output=True, timeout=600,
+                       env=dict(os.environ, WM_FORCE_RCCL="1", WM_EXCHANGE_SELF="1", WM_RCCL_SELF_SENDRECV="1"))
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    r = _one_json_line(p.stdout)
+    assert r["transport"] == "rccl" and r["rccl_ranks"] == 1 and r["n_gpus"] == 1 and "stability" not in r
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -58,6 +58,15 @@ def test_distributed_paths_over_gloo(wm_lib, world, chunks):
     run_world(world, "cpu", {"WHOLEGRAPH_AMD_TESTING": "1", "HIP_VISIBLE_DEVICES": "", "WM_EXCHANGE_CHUNKS": chunks})
 
 
+@pytest.mark.parametrize("world,chunks", [(2, "1"), (3, "2")])
+def test_loopback_self_segment_over_gloo(wm_lib, world, chunks):
+    """WM_EXCHANGE_SELF=1: a rank's own segment goes through the transport like a peer's (the mode the one-GPU RCCL tests
+    rely on, tests/test_rccl_transport_gpu.py) — results must not change."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "test_backend"], stdout=subprocess.DEVNULL)
+    run_world(world, "cpu", {"WHOLEGRAPH_AMD_TESTING": "1", "HIP_VISIBLE_DEVICES": "", "WM_EXCHANGE_CHUNKS": chunks,
+                             "WM_EXCHANGE_SELF": "1"})
+
+
 @pytest.mark.parametrize("world,local,chunks", [(4, 2, "1"), (6, 3, "2"), (6, 2, "1"), (4, 1, "1"), (3, 3, "1")])
 def test_hierarchy_gather_over_gloo(wm_lib, world, local, chunks):
     """HIERARCHY tables on a pretended `world / local` nodes x `local` ranks layout: ids relayed inside the node, distinct

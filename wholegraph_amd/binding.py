@@ -244,6 +244,7 @@ PROTOTYPES = {
     "csr_add_self_loop": (_i, [_vp, _vp, _vp, _vp, _vp]),
     # wholegraph_amd_ext.h
     "wholememory_create_communicator_ext": (_i, [_P(_vp), _i, _i, _P(ExtCollectives)]),
+    "wholememory_ext_communicator_transport": (_i, [_vp, _P(C.c_char_p), _P(_i)]),
     "wholememory_ext_bucket_ids": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _vp, _P(EnvFunc), _vp]),
     "wholememory_ext_bucket_ids_folded": (_i, [_vp, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _P(EnvFunc), _vp]),
     "wholememory_ext_dedup_apply": (_i, [_vp, _i, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i, _P(_f), _f, _vp,
@@ -251,6 +252,7 @@ PROTOTYPES = {
     "wholememory_ext_round_robin_map": (_i, [_vp, _vp, _i, _i64, _i64, _i, _i, _vp]),
     "wholememory_ext_embedding_cache_info": (_i, [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)]),
     "wholememory_ext_backend_name": (C.c_char_p, []),
+    "wholememory_ext_last_rows_kernel": (C.c_char_p, []),
     "wm_testing_install_backend": (_i, [_vp]),
 }
 

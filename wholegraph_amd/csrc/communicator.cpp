@@ -68,6 +68,11 @@ class rccl_provider : public collective_provider {
     WM_HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     WM_HIP_TRY(hipMalloc(&dev_stage_, kStageBytes));
     WM_HIP_TRY(hipHostMalloc(&host_stage_, kStageBytes, hipHostMallocDefault));
+    // WM_RCCL_SELF_SENDRECV=1 (bring-up / tests): the self segment of an all-to-all-v also travels as an
+    // ncclSend/ncclRecv pair inside the group instead of a device-to-device copy, so the grouped point-to-point
+    // path runs on a box with a single GPU
+    const char* e  = getenv("WM_RCCL_SELF_SENDRECV");
+    self_sendrecv_ = e != nullptr && e[0] == '1';
   }
   ~rccl_provider() override
   {
@@ -77,6 +82,11 @@ class rccl_provider : public collective_provider {
     if (stream_) (void)hipStreamDestroy(stream_);
   }
   const char* name() const override { return "rccl"; }
+  int transport_ranks() const override
+  {
+    int n = -1;
+    return ncclCommCount(comm_, &n) == ncclSuccess ? n : -1;
+  }
 
   void barrier() override
   {  // reference nccl_comms.cpp:82-86: 1-int allreduce + sync
@@ -104,10 +114,10 @@ class rccl_provider : public collective_provider {
     const char* s      = static_cast<const char*>(send);
     char* r            = static_cast<char*>(recv);
     if (send_bytes[rank_] != recv_bytes[rank_]) throw comm_error("alltoallv: self send/recv size mismatch");
-    if (send_bytes[rank_] > 0)
+    if (send_bytes[rank_] > 0 && !self_sendrecv_)
       WM_HIP_TRY(hipMemcpyAsync(r + recv_disp[rank_], s + send_disp[rank_], send_bytes[rank_], hipMemcpyDeviceToDevice, stream));
     WM_NCCL_TRY(ncclGroupStart());
-    for (int step = 1; step < size_; step++) {  // skewed order: rank r talks to r+step / r-step
+    for (int step = self_sendrecv_ ? 0 : 1; step < size_; step++) {  // skewed order: rank r talks to r+step / r-step
       int to   = (rank_ + step) % size_;
       int from = (rank_ - step + size_) % size_;
       if (recv_bytes[from] > 0) WM_NCCL_TRY(ncclRecv(r + recv_disp[from], recv_bytes[from], ncclInt8, from, comm_, stream));
@@ -139,6 +149,7 @@ class rccl_provider : public collective_provider {
   hipStream_t stream_ = nullptr;
   void* dev_stage_    = nullptr;
   void* host_stage_   = nullptr;
+  bool self_sendrecv_ = false;
 };
 
 // Sub-group of an external-collectives communicator: every collective is carried by the ROOT provider with the member
@@ -232,6 +243,12 @@ class ext_provider : public collective_provider {
   wm_ext_collectives_t c_;
   int size_;
 };
+
+bool loopback_requested()
+{
+  const char* e = getenv("WM_EXCHANGE_SELF");
+  return e != nullptr && e[0] == '1';
+}
 
 int next_comm_id()
 {
@@ -391,6 +408,7 @@ wholememory_error_code_t wholememory_create_communicator(wholememory_comm_t* com
   c->world_size = size;
   c->local_size = size;
   c->comm_id    = wm::next_comm_id();
+  c->loopback   = wm::loopback_requested();
   // WM_FORCE_RCCL=1 builds the RCCL transport even for a single rank (bring-up / smoke testing of the RCCL
   // plumbing on a one-GPU box); normally a single-rank communicator needs no transport at all.
   const char* force = getenv("WM_FORCE_RCCL");
@@ -427,6 +445,7 @@ wholememory_error_code_t wholememory_create_communicator_ext(wholememory_comm_t*
   c->world_size = size;
   c->local_size = size;
   c->comm_id    = wm::next_comm_id();
+  c->loopback   = wm::loopback_requested();
   if (size > 1) {
     c->transport.reset(new wm::ext_provider(*collectives, rank, size));
     try {
@@ -449,7 +468,7 @@ wholememory_error_code_t wholememory_split_communicator(wholememory_comm_t* new_
   WM_API_BEGIN
   if (new_comm == nullptr || comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
   *new_comm = nullptr;
-  if (comm->world_size == 1) {
+  if (comm->world_size == 1 && comm->transport == nullptr) {
     if (color < 0) return WHOLEMEMORY_SUCCESS;
     auto* c    = new wholememory_comm_();
     c->comm_id = wm::next_comm_id();
@@ -464,8 +483,9 @@ wholememory_error_code_t wholememory_split_communicator(wholememory_comm_t* new_
   c->world_rank = nr;
   c->world_size = ns;
   c->comm_id    = wm::next_comm_id();
+  c->loopback   = comm->loopback;
   c->adopt_nodes(*comm, members);
-  if (ns > 1) c->transport = std::move(sub);
+  if (ns > 1 || comm->loopback) c->transport = std::move(sub);
   *new_comm = c;
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
@@ -549,6 +569,13 @@ wholememory_error_code_t wholememory_communicator_barrier(wholememory_comm_t com
   comm->barrier();
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
+}
+wholememory_error_code_t wholememory_ext_communicator_transport(wholememory_comm_t comm, const char** name, int* ranks)
+{
+  if (comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (name != nullptr) *name = comm->transport ? comm->transport->name() : "none";
+  if (ranks != nullptr) *ranks = comm->transport ? comm->transport->transport_ranks() : 0;
+  return WHOLEMEMORY_SUCCESS;
 }
 bool wholememory_is_intranode_communicator(wholememory_comm_t comm) { return comm != nullptr && comm->local_size == comm->world_size; }
 bool wholememory_is_intra_mnnvl_communicator(wholememory_comm_t) { return false; }

@@ -18,6 +18,8 @@ class collective_provider {
  public:
   virtual ~collective_provider() = default;
   virtual const char* name() const = 0;
+  // ranks the transport itself reports (ncclCommCount for RCCL); -1 when the provider cannot tell
+  virtual int transport_ranks() const { return -1; }
   virtual void barrier() = 0;
   // host buffers: recv[r*bytes..] = rank r's send
   virtual void allgather_host(const void* send, void* recv, size_t bytes) = 0;
@@ -47,6 +49,12 @@ struct wholememory_comm_ {
   int comm_id    = 0;
   wholememory_distributed_backend_t distributed_backend = WHOLEMEMORY_DB_NCCL;
   std::unique_ptr<wm::collective_provider> transport;  // null when world_size == 1
+  // WM_EXCHANGE_SELF=1 (bring-up / tests): the distributed ops send this rank's OWN segment through the transport like
+  // any peer's instead of serving it locally, and a single-rank communicator that has a transport (WM_FORCE_RCCL=1)
+  // runs the whole bucket -> counts -> all-to-all-v route. This is how the RCCL provider is exercised on a one-GPU box.
+  bool loopback = false;
+  // true when a one-rank communicator may skip bucketing and exchange altogether
+  bool single_rank_direct() const { return world_size == 1 && !(loopback && transport != nullptr); }
   std::mutex mu;                                       // guards handle create/destroy (reference communicator.hpp:226)
   int live_handles = 0;
   void* side_stream = nullptr;                         // lazily created: carries the chunked all-to-all-v

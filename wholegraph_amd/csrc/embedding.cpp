@@ -267,9 +267,11 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   // this rank's own rows are not copied at all: the step kernels read them where the caller left them (the receive
   // positions of the self segment are remapped to caller rows after the sort). WM_GRAD_SELF_COPY=1 restores the copy.
   const char* self_copy_env = getenv("WM_GRAD_SELF_COPY");
-  const bool self_in_place  = bk->remap_self_order != nullptr && !(self_copy_env != nullptr && self_copy_env[0] == '1');
+  const bool self_local     = !e->comm->loopback;  // loopback: the self segment is exchanged like a peer's
+  const bool self_in_place  = self_local && bk->remap_self_order != nullptr &&
+                             !(self_copy_env != nullptr && self_copy_env[0] == '1');
   id_exchange x(env);
-  bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x, true, self_in_place);
+  bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x, self_local, self_in_place);
   (void)ies;
   const int rank = e->comm->world_rank;
 
@@ -321,7 +323,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     self_ref.rows   = x.raw_indices + x.self_offset;
     self_ref.grads  = wholememory_tensor_get_data_pointer(grads);
     self_ref.stride = gmat.stride;
-  } else {
+  } else if (self_local) {
     launch_rows(x.self_offset, x.self_offset + x.self_count, recv_buf + full_recv_offsets[rank] * row_bytes);
   }
   // peers' rows: line-up (HBM) and all-to-all-v (xGMI, side stream) pipelined in C row-chunks; the id sort that
@@ -340,7 +342,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
       int64_t a, b;
       chunk_of(x.send_counts[p], c, &a, &b);
       sc[p] = b - a, so[p] = x.bucket_offsets[p] + a;
-      if (p != rank) launch_rows(so[p], so[p] + sc[p], send_buf + so[p] * row_bytes);
+      if (p != rank || !self_local) launch_rows(so[p], so[p] + sc[p], send_buf + so[p] * row_bytes);
       chunk_of(x.recv_counts[p], c, &a, &b);
       rc[p] = b - a, ro[p] = full_recv_offsets[p] + a;
     }

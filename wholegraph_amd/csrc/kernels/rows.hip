@@ -24,8 +24,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cxxabi.h>
+
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 
 #include "../backend.hpp"
 #include "device_common.cuh"
@@ -415,6 +418,16 @@ __global__ __launch_bounds__(kBlock) void rows_convert_kernel(rows_params p)
   }
 }
 
+// every launch goes through here so the library can tell which kernel instantiation served the last call of this thread
+// (wholememory_ext_last_rows_kernel: bench.py reports the name the HIP runtime holds for it, not a hard-coded string)
+thread_local const void* t_last_rows_kernel = nullptr;
+template <typename K>
+inline void launch_rows_kernel(K kernel, int blocks, hipStream_t stream, const rows_params& p)
+{
+  t_last_rows_kernel = reinterpret_cast<const void*>(kernel);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, stream, p);
+}
+
 inline int ilog2_ceil(int x)
 {
   int l = 0;
@@ -467,9 +480,9 @@ template <typename IdxT, bool GATHER>
 void launch_flat(const rows_params& p, int blocks, hipStream_t stream)
 {
   if (p.row_map != nullptr)
-    hipLaunchKernelGGL((rows_flat_kernel<IdxT, GATHER, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
+    launch_rows_kernel(rows_flat_kernel<IdxT, GATHER, true>, blocks, stream, p);
   else
-    hipLaunchKernelGGL((rows_flat_kernel<IdxT, GATHER, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
+    launch_rows_kernel(rows_flat_kernel<IdxT, GATHER, false>, blocks, stream, p);
 }
 
 template <typename IdxT, bool GATHER>
@@ -483,7 +496,7 @@ void launch_copy(const rows_params& p, int vb, int blocks, hipStream_t stream)
     const bool one_row = p.row_vecs > 32;  // > 512 B: a full wave per row
     const bool has_map = p.row_map != nullptr;
 #define WM_FAST(RPS, MAP) \
-  hipLaunchKernelGGL((rows_copy16_fast_kernel<IdxT, GATHER, RPS, MAP>), dim3(blocks), dim3(kBlock), 0, stream, p)
+  launch_rows_kernel(rows_copy16_fast_kernel<IdxT, GATHER, RPS, MAP>, blocks, stream, p)
     if (one_row) {
       if (has_map) WM_FAST(1, true); else WM_FAST(1, false);
     } else {
@@ -493,11 +506,11 @@ void launch_copy(const rows_params& p, int vb, int blocks, hipStream_t stream)
     return;
   }
   switch (vb) {
-    case 16: hipLaunchKernelGGL((rows_copy_kernel<IdxT, 16, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p); break;
-    case 8: hipLaunchKernelGGL((rows_copy_kernel<IdxT, 8, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p); break;
-    case 4: hipLaunchKernelGGL((rows_copy_kernel<IdxT, 4, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p); break;
-    case 2: hipLaunchKernelGGL((rows_copy_kernel<IdxT, 2, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p); break;
-    default: hipLaunchKernelGGL((rows_copy_kernel<IdxT, 1, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p); break;
+    case 16: launch_rows_kernel(rows_copy_kernel<IdxT, 16, GATHER>, blocks, stream, p); break;
+    case 8: launch_rows_kernel(rows_copy_kernel<IdxT, 8, GATHER>, blocks, stream, p); break;
+    case 4: launch_rows_kernel(rows_copy_kernel<IdxT, 4, GATHER>, blocks, stream, p); break;
+    case 2: launch_rows_kernel(rows_copy_kernel<IdxT, 2, GATHER>, blocks, stream, p); break;
+    default: launch_rows_kernel(rows_copy_kernel<IdxT, 1, GATHER>, blocks, stream, p); break;
   }
 }
 
@@ -506,13 +519,13 @@ void launch_convert_v(const rows_params& p, int v, int blocks, hipStream_t strea
 {
   switch (v) {
     case 4:
-      hipLaunchKernelGGL((rows_convert_kernel<TabT, PlainT, IdxT, 4, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p);
+      launch_rows_kernel(rows_convert_kernel<TabT, PlainT, IdxT, 4, GATHER>, blocks, stream, p);
       break;
     case 2:
-      hipLaunchKernelGGL((rows_convert_kernel<TabT, PlainT, IdxT, 2, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p);
+      launch_rows_kernel(rows_convert_kernel<TabT, PlainT, IdxT, 2, GATHER>, blocks, stream, p);
       break;
     default:
-      hipLaunchKernelGGL((rows_convert_kernel<TabT, PlainT, IdxT, 1, GATHER>), dim3(blocks), dim3(kBlock), 0, stream, p);
+      launch_rows_kernel(rows_convert_kernel<TabT, PlainT, IdxT, 1, GATHER>, blocks, stream, p);
       break;
   }
 }
@@ -649,3 +662,18 @@ int hip_gather_rows(const wm_rows_args* a, void* stream) { return rows_op<true>(
 int hip_scatter_rows(const wm_rows_args* a, void* stream) { return rows_op<false>(a, stream); }
 
 }  // namespace wm
+
+// name (demangled) the HIP runtime holds for the row kernel this thread launched last; "" before the first launch
+extern "C" const char* wholememory_ext_last_rows_kernel()
+{
+  thread_local std::string name;
+  name.clear();
+  if (wm::t_last_rows_kernel == nullptr) return name.c_str();
+  const char* mangled = hipKernelNameRefByPtr(wm::t_last_rows_kernel, nullptr);
+  if (mangled == nullptr) return name.c_str();
+  int status       = 0;
+  char* demangled  = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+  name             = status == 0 && demangled != nullptr ? demangled : mangled;
+  if (demangled != nullptr) free(demangled);
+  return name.c_str();
+}

@@ -223,9 +223,9 @@ bool mapped_via_exchange(wholememory_tensor_t t, wholememory_memory_type_t mt)
 // use what all ranks know alike: the world size, the environment and id_exchange::global_moved.
 int exchange_chunks(int world_size, int64_t global_moved)
 {
-  if (world_size <= 1) return 1;
   const char* e = getenv("WM_EXCHANGE_CHUNKS");
   if (e != nullptr && atoi(e) >= 1) return std::min(atoi(e), 16);
+  if (world_size <= 1) return 1;
   // below ~256 k rows in and out of the average rank the exchange is latency-bound and extra launches only add overhead
   return 2 * global_moved / world_size >= (1 << 18) ? 4 : 1;
 }
@@ -430,7 +430,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   auto entry_offsets       = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
   if (via != nullptr) comm = via->comm, entry_offsets = via->offsets;
   const char* indices      = static_cast<const char*>(d.indices_ptr);  // data pointer: offset already applied
-  if (comm->world_size == 1 && cache == nullptr) {
+  if (comm->single_rank_direct() && cache == nullptr) {
     // one rank owns every row: nothing to bucket or exchange, the gather kernel itself skips negative ids
     wm_rows_args a{};
     fill_rows_args(&a, local_shard_gref(handle), d.table, indices, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain,
@@ -440,8 +440,10 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
     return WHOLEMEMORY_SUCCESS;
   }
 
+  // loopback (WM_EXCHANGE_SELF=1): this rank's own segment travels through the transport like a peer's
+  const bool self_local = !comm->loopback;
   id_exchange x(env);
-  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x, true);
+  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x, self_local);
   const auto local_gref = local_shard_gref(handle);
   // owner-side row gather: through the cache when there is one
   auto local_gather = [&](const wm_rows_args& ga) {
@@ -453,14 +455,15 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   };
   if (cache != nullptr && adjust_cache) {
     const int64_t total_rows = static_cast<int64_t>(entry_offsets[comm->world_size]);
-    WHOLEMEMORY_RETURN_ON_FAIL(row_cache_update(cache, static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset,
-                                                d.indices.dtype, x.self_count, total_rows, env, stream));
+    if (self_local)
+      WHOLEMEMORY_RETURN_ON_FAIL(row_cache_update(cache, static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset,
+                                                  d.indices.dtype, x.self_count, total_rows, env, stream));
     WHOLEMEMORY_RETURN_ON_FAIL(row_cache_update(cache, x.recv_ids, d.indices.dtype, x.total_recv, total_rows, env, stream));
   }
 
   // (a) ids this rank owns itself: straight from the local shard into their final output rows
   //     (row_map = raw_indices) — no staging buffer, no copy, no reorder pass for them
-  if (x.self_count > 0) {
+  if (x.self_count > 0 && self_local) {
     wm_rows_args sa{};
     fill_rows_args(&sa, local_gref, d.table, static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset,
                    d.indices.dtype, x.self_count, d.plain_ptr, d.plain, gather_sms);
@@ -514,7 +517,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   };
   auto reorder_chunk = [&](int c) {
     for (int p = 0; p < W; p++) {
-      if (p == rank) continue;
+      if (p == rank && self_local) continue;
       int64_t a, b;
       chunk_of(x.send_counts[p], c, &a, &b);
       if (b <= a) continue;
@@ -735,7 +738,7 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
   const int64_t dim   = d.table.sizes[1];
   auto entry_offsets  = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
   const char* indices = static_cast<const char*>(d.indices_ptr);  // data pointer: offset already applied
-  if (comm->world_size == 1) {
+  if (comm->single_rank_direct()) {
     // one rank owns every row: a plain scatter (negative ids are skipped by the kernel), then the reference's sync
     wm_rows_args a{};
     fill_rows_args(&a, local_shard_gref(handle), d.table, indices, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain,
@@ -745,12 +748,13 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
     return WHOLEMEMORY_SUCCESS;
   }
 
+  const bool self_local = !comm->loopback;  // loopback: the self segment is exchanged like a peer's
   id_exchange x(env);
-  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x, true);
+  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x, self_local);
   const auto local_gref = local_shard_gref(handle);
 
   // (a) rows this rank owns itself: input row raw_indices[j] -> local table row, directly
-  if (x.self_count > 0) {
+  if (x.self_count > 0 && self_local) {
     wm_rows_args sa{};
     fill_rows_args(&sa, local_gref, d.table, static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset,
                    d.indices.dtype, x.self_count, d.plain_ptr, d.plain, scatter_sms);
@@ -776,7 +780,7 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
   };
   auto lineup_chunk = [&](int c) {
     for (int p = 0; p < W; p++) {
-      if (p == rank) continue;
+      if (p == rank && self_local) continue;
       int64_t a, b;
       chunk_of(x.send_counts[p], c, &a, &b);
       if (b <= a) continue;

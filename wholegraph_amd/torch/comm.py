@@ -88,6 +88,13 @@ class WholeMemoryCommunicator(object):
     def destroy(self):
         destroy_communicator(self)
 
+    def transport(self):
+        """(name, ranks) of the collective transport under this communicator: ("rccl", N) on MI355X boxes, ("external", -1)
+        over torch.distributed/gloo, ("none", 0) for a single rank. Extension (wholegraph_amd_ext.h)."""
+        name, ranks = C.c_char_p(), C.c_int()
+        wmb.check(wmb.lib().wholememory_ext_communicator_transport(self.wmb_comm, C.byref(name), C.byref(ranks)))
+        return name.value.decode(), ranks.value
+
     @property
     def distributed_backend(self):
         return wholememory_distributed_backend_type_to_str(
@@ -211,8 +218,12 @@ def create_group_communicator(group_size=-1, comm_stride=1):
     L = wmb.lib()
     comm = C.c_void_p()
     import os
-    if group_size == 1 and os.environ.get("WM_FORCE_RCCL") != "1":
+    if group_size == 1:
+        # a one-rank group needs no bootstrap traffic. WM_FORCE_RCCL=1 still gives it a real RCCL communicator of size 1
+        # (the library reads the switch): the unique id is then made right here instead of being broadcast.
         uid = wmb.UniqueId()
+        if os.environ.get("WM_FORCE_RCCL") == "1":
+            wmb.check(L.wholememory_create_unique_id(C.byref(uid)))
         wmb.check(L.wholememory_create_communicator(C.byref(comm), uid, 0, 1))
         return WholeMemoryCommunicator(comm)
     if not _use_rccl_transport():
