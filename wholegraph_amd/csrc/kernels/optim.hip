@@ -247,9 +247,9 @@ __device__ __forceinline__ opt_elem load_elem(const wm_optimizer_args& a, const 
   return x;
 }
 
-template <int OPT, typename T = float>
-__device__ __forceinline__ void update_elem(const wm_optimizer_args& a, T* row, float* st, int64_t d, opt_elem x,
-                                            float grad_value, float beta1t, float beta2t)
+// the statement sequences themselves, on values: x.e / x.s0 / x.s1 in, updated in place (compiled with -ffp-contract=off)
+template <int OPT>
+__device__ __forceinline__ void opt_math(const wm_optimizer_args& a, opt_elem& x, float grad_value, float beta1t, float beta2t)
 {
   float embedding_value = x.e;
   if (OPT == WHOLEMEMORY_OPT_SGD) {
@@ -261,33 +261,43 @@ __device__ __forceinline__ void update_elem(const wm_optimizer_args& a, T* row, 
     } else {
       grad_value = grad_value + a.weight_decay * embedding_value;
     }
-    float m              = x.s0;
-    float v              = x.s1;
-    m                    = a.beta1 * m + (1 - a.beta1) * grad_value;
-    v                    = a.beta2 * v + (1 - a.beta2) * grad_value * grad_value;
-    float mhat           = m / (1 - beta1t);
-    float vhat           = v / (1 - beta2t);
-    embedding_value      = embedding_value - a.lr * mhat / (sqrtf(vhat) + a.epsilon);
-    st[d]                = m;
-    st[a.table_stride + d] = v;
+    float m         = x.s0;
+    float v         = x.s1;
+    m               = a.beta1 * m + (1 - a.beta1) * grad_value;
+    v               = a.beta2 * v + (1 - a.beta2) * grad_value * grad_value;
+    float mhat      = m / (1 - beta1t);
+    float vhat      = v / (1 - beta2t);
+    embedding_value = embedding_value - a.lr * mhat / (sqrtf(vhat) + a.epsilon);
+    x.s0            = m;
+    x.s1            = v;
   } else if (OPT == WHOLEMEMORY_OPT_ADAGRAD) {
     grad_value      = grad_value + a.weight_decay * embedding_value;
     float state_sum = x.s0;
     state_sum       = state_sum + grad_value * grad_value;
     embedding_value = embedding_value - a.lr * grad_value / (sqrtf(state_sum) + a.epsilon);
-    st[d]           = state_sum;
+    x.s0            = state_sum;
   } else if (OPT == WHOLEMEMORY_OPT_RMSPROP) {
     grad_value      = grad_value + a.weight_decay * embedding_value;
     float v         = x.s0;
     v               = a.alpha * v + (1 - a.alpha) * grad_value * grad_value;
     embedding_value = embedding_value - a.lr * grad_value / (sqrtf(v) + a.epsilon);
-    st[d]           = v;
+    x.s0            = v;
   }
+  x.e = embedding_value;
+}
+
+template <int OPT, typename T = float>
+__device__ __forceinline__ void update_elem(const wm_optimizer_args& a, T* row, float* st, int64_t d, opt_elem x,
+                                            float grad_value, float beta1t, float beta2t)
+{
+  opt_math<OPT>(a, x, grad_value, beta1t, beta2t);
+  if (OPT != WHOLEMEMORY_OPT_SGD) st[d] = x.s0;
+  if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM) st[a.table_stride + d] = x.s1;
   // the updated row is not read again in this pass: non-temporal store (merged into one wide store per lane)
   if constexpr (std::is_same<T, float>::value)
-    __builtin_nontemporal_store(embedding_value, &row[d]);
+    __builtin_nontemporal_store(x.e, &row[d]);
   else  // 16-bit tables (SGD extension): one rounding from the fp32 result
-    row[d] = store_narrow<T>(embedding_value);
+    row[d] = store_narrow<T>(x.e);
 }
 
 template <int OPT, typename T = float>
@@ -436,6 +446,169 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
     m_cur = m_nxt;
     m_nxt = m_nn;
     r_cur = r_nxt;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// step_tile_kernel: the gather kernel's shape applied to the fused step (fp32 rows of whole 16-byte pieces).
+// A wave owns a TILE of 64 consecutive runs (= 64 ascending unique ids): ids / run_starts / order[run start] arrive as
+// coalesced vector loads (lane l holds run 64 t + l), each lane resolves ITS run's gradient-row and table-row (and
+// state-row) addresses once, and the tile is then streamed kU steps of RPS rows at a time with the bases broadcast by
+// v_readlane — per step one 16-byte load per lane from the gradient row and one from the table row (two state rows
+// for the stateful optimizers), kU steps in flight before the first dependent arithmetic, updated rows written back
+// non-temporally. step_short_kernel walks the same data with scalar loads per run (ids -> run_starts -> order ->
+// rows: three dependent latencies per K runs per wave); here the metadata of 64 runs costs one latency.
+// Duplicates (run length > 1; 5 % of the runs of a uniform 10 M-in-100 M batch) are folded in the step that holds their
+// first row: the later rows are added one by one in receive order, 4 prefetched at a time — the reference order, so
+// results stay bit-identical. Runs of more than kLongRun rows belong to the long-run kernel as before.
+template <int RPS>
+__device__ __forceinline__ uint32_t tile_bcast32(uint32_t v, int e0, int sub)
+{
+  if (RPS == 1) return __builtin_amdgcn_readlane(v, e0);
+  if (RPS == 2) {
+    const uint32_t lo = __builtin_amdgcn_readlane(v, e0);
+    const uint32_t hi = __builtin_amdgcn_readlane(v, e0 + 1);
+    return sub ? hi : lo;
+  }
+  return __shfl(v, e0 + sub, 64);
+}
+template <int RPS, typename P>
+__device__ __forceinline__ P* tile_bcast_ptr(P* p, int e0, int sub)
+{
+  const uint64_t v  = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = tile_bcast32<RPS>(static_cast<uint32_t>(v), e0, sub);
+  const uint32_t hi = tile_bcast32<RPS>(static_cast<uint32_t>(v >> 32), e0, sub);
+  return reinterpret_cast<P*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+#ifndef WM_TILE_KU_SGD
+#define WM_TILE_KU_SGD 4
+#endif
+#ifndef WM_TILE_KU_STATE
+#define WM_TILE_KU_STATE 2
+#endif
+template <typename IdxT, int OPT, int RPS, bool CACHED>
+__global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
+{
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  constexpr int kU           = OPT == WHOLEMEMORY_OPT_SGD ? WM_TILE_KU_SGD : WM_TILE_KU_STATE;
+  constexpr int kLpr         = 64 / RPS;
+  constexpr bool kState      = OPT != WHOLEMEMORY_OPT_SGD;
+  constexpr bool kAdam       = OPT == WHOLEMEMORY_OPT_LAZY_ADAM;
+  const wm_optimizer_args& a = p.a;
+  const int lane             = threadIdx.x & 63;
+  const int64_t wave         = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t n_waves      = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  const int64_t count        = p.n_unique ? *p.n_unique : a.count;
+  const int64_t tiles        = (count + 63) / 64;
+  const IdxT* ids            = static_cast<const IdxT*>(a.ids);
+  const int col              = lane & (kLpr - 1);
+  const int sub              = lane / kLpr;
+  const int row_vecs         = static_cast<int>(a.dim / 4);
+
+  for (int64_t tile = wave; tile < tiles; tile += n_waves) {
+    const int64_t u     = tile * 64 + lane;
+    const int64_t uc    = min(u, count - 1);  // clamped: the loads stay unconditional, dead lanes get run length 0
+    const int64_t local = static_cast<int64_t>(ids[uc]) - a.local_entry_offset;
+    const int32_t my_s0 = a.run_starts[uc];
+    int32_t my_len      = u < count ? a.run_starts[uc + 1] - my_s0 : 0;
+    if (p.long_list != nullptr && my_len > kLongRun) my_len = 0;  // the long-run kernel's (mark_long_runs_kernel lists it)
+    const float* my_grad = grad_row<float>(a, a.order[my_s0]);
+    float* my_row;
+    float* my_st = nullptr;
+    if (CACHED) {
+      const int32_t slot = cache_slot(a, local);
+      my_row             = table_row_at<float>(a, local, slot);
+      my_st              = state_row_at(a, local, slot);
+      if (my_len > 0 && slot >= 0) a.cache_dirty[slot] = 1;
+    } else {
+      my_row = static_cast<float*>(a.local_table) + local * a.table_stride;
+      if (kState) my_st = a.per_element_state + local * a.per_element_stride;
+    }
+    float my_b1 = 0.f, my_b2 = 0.f;
+    if (kAdam) {
+      my_b1 = a.per_row_state[local * 2 + 0] * a.beta1;
+      my_b2 = a.per_row_state[local * 2 + 1] * a.beta2;
+      if (my_len > 0) {  // ids of a tile are distinct; dead lanes (same address as the last live one) do not write
+        a.per_row_state[local * 2 + 0] = my_b1;
+        a.per_row_state[local * 2 + 1] = my_b2;
+      }
+    }
+    for (int cbase = 0; cbase < row_vecs; cbase += kLpr) {  // > 1 trip only when a row has more pieces than a wave step covers
+      const int c        = cbase + col;
+      const bool col_ok  = c < row_vecs;
+      const int64_t coff = static_cast<int64_t>(c) * 4;
+#pragma unroll 1
+      for (int s = 0; s < 64; s += RPS * kU) {
+        f4 acc[kU], ev[kU], s0v[kU], s1v[kU];
+        float* trow[kU];
+        float* srow[kU];
+        int32_t ln[kU], rs[kU];
+        float b1[kU], b2[kU];
+#pragma unroll
+        for (int k = 0; k < kU; k++) {
+          const int e0     = s + RPS * k;
+          const float* g   = tile_bcast_ptr<RPS>(my_grad, e0, sub);
+          trow[k]          = tile_bcast_ptr<RPS>(my_row, e0, sub);
+          if (kState) srow[k] = tile_bcast_ptr<RPS>(my_st, e0, sub);
+          ln[k]            = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_len), e0, sub));
+          rs[k]            = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_s0), e0, sub));
+          if (kAdam) {
+            b1[k] = __builtin_bit_cast(float, tile_bcast32<RPS>(__builtin_bit_cast(uint32_t, my_b1), e0, sub));
+            b2[k] = __builtin_bit_cast(float, tile_bcast32<RPS>(__builtin_bit_cast(uint32_t, my_b2), e0, sub));
+          }
+          if (!col_ok) ln[k] = 0;
+          if (ln[k] > 0) {
+            // first occurrence copied (DedupIndiceAndGradientsKernel); the table / state pieces are loaded alongside
+            acc[k] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g + coff));
+            ev[k]  = __builtin_nontemporal_load(reinterpret_cast<const f4*>(trow[k] + coff));
+            if (kState) s0v[k] = *reinterpret_cast<const f4*>(srow[k] + coff);
+            if (kAdam) s1v[k] = *reinterpret_cast<const f4*>(srow[k] + a.table_stride + coff);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kU; k++) {
+          // longest run of this step's RPS rows, wave-uniform (the rows of a step differ only by `sub`)
+          int32_t longest = 0;
+#pragma unroll
+          for (int r = 0; r < RPS; r++) longest = max(longest, static_cast<int32_t>(__builtin_amdgcn_readlane(my_len, s + RPS * k + r)));
+          // later occurrences added in receive order, 4 rows prefetched at a time (index clamped into the run)
+          for (int32_t j = 1; j < longest; j += 4) {
+            f4 gq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              if (j + q < ln[k]) {
+                const int32_t o = a.order[rs[k] + j + q];
+                gq[q]           = __builtin_nontemporal_load(reinterpret_cast<const f4*>(grad_row<float>(a, o) + coff));
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+              if (j + q < ln[k]) acc[k] += gq[q];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kU; k++) {
+          if (ln[k] <= 0) continue;
+          f4 eo, so0, so1;
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            opt_elem x;
+            x.e  = ev[k][v];
+            x.s0 = kState ? s0v[k][v] : 0.f;
+            x.s1 = kAdam ? s1v[k][v] : 0.f;
+            opt_math<OPT>(a, x, acc[k][v], kAdam ? b1[k] : 0.f, kAdam ? b2[k] : 0.f);
+            eo[v]  = x.e;
+            so0[v] = x.s0;
+            so1[v] = x.s1;
+          }
+          if (kState) *reinterpret_cast<f4*>(srow[k] + coff) = so0;
+          if (kAdam) *reinterpret_cast<f4*>(srow[k] + a.table_stride + coff) = so1;
+          __builtin_nontemporal_store(eo, reinterpret_cast<f4*>(trow[k] + coff));
+        }
+      }
+    }
   }
 }
 
@@ -830,6 +1003,36 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
   // (a float4-per-lane variant, two runs per wave instruction, was measured too: no gain for SGD, 10-15 % slower for the
   // stateful optimizers through register pressure — 8 bytes per lane stay)
   const bool cached = p.a.cache_slot_of != nullptr;
+  // rows of whole 16-byte pieces on every side: the tile kernel (WM_STEP_TILE=0 keeps the wave-per-run kernel)
+  static const bool tile_off = getenv("WM_STEP_TILE") != nullptr && getenv("WM_STEP_TILE")[0] == '0';
+  const bool st_ok = p.a.per_element_state == nullptr ||
+                     (p.a.per_element_stride % 4 == 0 && reinterpret_cast<uint64_t>(p.a.per_element_state) % 16 == 0 &&
+                      (p.a.cache_state_data == nullptr || (p.a.cache_state_row_elems % 4 == 0 &&
+                                                           reinterpret_cast<uint64_t>(p.a.cache_state_data) % 16 == 0)));
+  const bool tb_ok = p.a.table_stride % 4 == 0 && reinterpret_cast<uint64_t>(p.a.local_table) % 16 == 0 &&
+                     (!cached || (p.a.cache_row_elems % 4 == 0 && reinterpret_cast<uint64_t>(p.a.cache_data) % 16 == 0));
+  const bool tile_ok = !tile_off && p.a.dim % 4 == 0 && p.a.dim >= 32 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 &&
+                       self_ok4 && st_ok && tb_ok;
+  if (tile_ok) {
+    const int64_t tiles = (p.a.count + 63) / 64;
+    int tblocks         = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, 256 * 32));
+    if (const char* e = getenv("WM_STEP_BLOCKS")) tblocks = std::min(tblocks, std::max(1, atoi(e)));
+    tblocks             = std::max(tblocks, 1);
+    const int vecs      = static_cast<int>(p.a.dim / 4);
+#define WM_TILE(RPS)                                                                                                    \
+  do {                                                                                                                  \
+    if (cached)                                                                                                         \
+      hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, RPS, true>), dim3(tblocks), dim3(kBlock), 0, stream, p);          \
+    else                                                                                                                \
+      hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, RPS, false>), dim3(tblocks), dim3(kBlock), 0, stream, p);         \
+  } while (0)
+    if (vecs > 32) WM_TILE(1);
+    else if (vecs > 16) WM_TILE(2);
+    else if (vecs > 8) WM_TILE(4);
+    else WM_TILE(8);
+#undef WM_TILE
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   if (vec2 && !cached)
     hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 2, float, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
   else if (vec2)
