@@ -39,34 +39,131 @@ namespace {
 
 constexpr int kBlock = 256;
 
-__global__ void iota_i32_kernel(int32_t* p, int64_t n)
+// Run detection over the sorted keys, three small launches instead of head-flags + a device-wide scan + compaction
+// (10 M keys: 185 us -> ~65 us): a tile is kRunTile consecutive sorted keys;
+//   run_count_kernel   heads per tile (a head = first key, or a key that differs from its predecessor)
+//   run_scan_kernel    one workgroup: exclusive prefix of the tile counts (a few thousand numbers) + the total
+//   run_compact_kernel recomputes its tile's heads, ranks them with a block scan on top of the tile's prefix and writes
+//                      unique_ids[rank] (widened to the caller's index type) and run_starts[rank]; the last tile adds the
+//                      closing run_starts entry and the count.
+// No tile waits for another one (a chained look-back scan serialises on the prefix hand-over while thousands of tiles are
+// resident), and the keys are read twice out of L2 / Infinity Cache rather than flags and ranks written and re-read.
+constexpr int kRunItems = 8;
+constexpr int kRunTile  = kBlock * kRunItems;  // 2048 keys
+
+template <typename KeyT>
+__device__ __forceinline__ int tile_heads(const KeyT* sorted, int64_t n, int64_t base, bool head[kRunItems], KeyT key[kRunItems])
 {
-  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = static_cast<int32_t>(i);
+  // thread t owns keys base + t * kRunItems + [0, kRunItems): contiguous, so its heads are already in rank order
+  const int64_t first = base + static_cast<int64_t>(threadIdx.x) * kRunItems;
+  KeyT prev           = first > 0 && first <= n ? sorted[first - 1] : KeyT(0);
+  int heads           = 0;
+#pragma unroll
+  for (int i = 0; i < kRunItems; i++) {
+    const int64_t g = first + i;
+    key[i]          = g < n ? sorted[g] : KeyT(0);
+    head[i]         = g < n && (g == 0 || key[i] != prev);
+    prev            = key[i];
+    heads += head[i] ? 1 : 0;
+  }
+  return heads;
+}
+
+__device__ __forceinline__ int block_exclusive_sum(int v, int* total)
+{
+  __shared__ int wave_sums[kBlock / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wave_sums[wv] = incl;
+  __syncthreads();
+  int before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; w++) {
+    if (w < wv) before += wave_sums[w];
+    all += wave_sums[w];
+  }
+  __syncthreads();
+  *total = all;
+  return before + incl - v;
 }
 
 template <typename KeyT>
-__global__ void head_flags_kernel(const KeyT* sorted, int64_t n, int32_t* flags)
+__global__ __launch_bounds__(kBlock) void run_count_kernel(const KeyT* sorted, int64_t n, int32_t* tile_counts)
 {
-  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
+  bool head[kRunItems];
+  KeyT key[kRunItems];
+  const int heads = tile_heads(sorted, n, static_cast<int64_t>(blockIdx.x) * kRunTile, head, key);
+  int total;
+  (void)block_exclusive_sum(heads, &total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
 }
 
-template <typename KeyT>
-__global__ void compact_runs_kernel(const KeyT* sorted, const int32_t* flags, const int32_t* run_idx, int64_t n,
-                                    KeyT* unique_ids, int32_t* run_starts, int64_t* n_unique)
+__global__ __launch_bounds__(1024) void run_scan_kernel(int32_t* tile_counts, int n_tiles, int64_t* n_unique)
 {
-  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (flags[i]) {
-    unique_ids[run_idx[i]] = sorted[i];
-    run_starts[run_idx[i]] = static_cast<int32_t>(i);
+  // one workgroup walks the tile counts in chunks of 1024, carrying the running total
+  __shared__ int wave_sums[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int base = 0; base < n_tiles; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n_tiles ? tile_counts[i] : 0;
+    int incl    = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_sums[wv] = incl;
+    __syncthreads();
+    int before = carry_s;
+    for (int w = 0; w < wv; w++) before += wave_sums[w];
+    if (i < n_tiles) tile_counts[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = before + incl;
+    __syncthreads();
   }
-  if (i == n - 1) {
-    int32_t total     = run_idx[i] + flags[i];
-    run_starts[total] = static_cast<int32_t>(n);
-    *n_unique         = total;
+  if (threadIdx.x == 0) *n_unique = carry_s;
+}
+
+template <typename KeyT, typename OutT>
+__global__ __launch_bounds__(kBlock) void run_compact_kernel(const KeyT* sorted, int64_t n, const int32_t* tile_prefix,
+                                                             const int64_t* n_unique, OutT* unique_ids, int32_t* run_starts)
+{
+  // heads are ranked inside the tile, parked in LDS at their rank and written out as two coalesced streams (a thread's
+  // own heads are kRunItems apart in rank order: written directly they cost a scattered store per item — 82 us vs ~35)
+  __shared__ KeyT s_key[kRunTile];
+  __shared__ int32_t s_pos[kRunTile];
+  bool head[kRunItems];
+  KeyT key[kRunItems];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kRunTile;
+  const int heads    = tile_heads(sorted, n, base, head, key);
+  int total;
+  int rank = block_exclusive_sum(heads, &total);
+#pragma unroll
+  for (int i = 0; i < kRunItems; i++) {
+    if (head[i]) {
+      s_key[rank] = key[i];
+      s_pos[rank] = static_cast<int32_t>(base + static_cast<int64_t>(threadIdx.x) * kRunItems + i);
+      rank++;
+    }
   }
+  __syncthreads();
+  const int64_t out0 = tile_prefix[blockIdx.x];
+  for (int i = threadIdx.x; i < total; i += kBlock) {
+    // ids are stored in the caller's (signed) index type: the keys are its two's-complement bits, possibly narrowed to
+    // 32 bits when the caller bounded them (then they are non-negative and the widening is exact)
+    const KeyT k         = s_key[i];
+    unique_ids[out0 + i] = sizeof(KeyT) == sizeof(OutT) ? static_cast<OutT>(k) : static_cast<OutT>(static_cast<uint64_t>(k));
+    run_starts[out0 + i] = s_pos[i];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) run_starts[*n_unique] = static_cast<int32_t>(n);
 }
 
 inline unsigned significant_bits(int64_t upper_bound, unsigned full)
@@ -77,61 +174,94 @@ inline unsigned significant_bits(int64_t upper_bound, unsigned full)
   return b;
 }
 
-template <typename KeyT>
+// keys narrowed on the fly: ids the caller bounded below 2^32 are sorted as 32-bit keys (8 + 4 bytes per element and
+// pass instead of 8 + 8 ... the first pass reads the 64-bit ids through this iterator, no conversion pass)
+struct narrow_to_u32 {
+  __host__ __device__ uint32_t operator()(const uint64_t& v) const { return static_cast<uint32_t>(v); }
+};
+
+// rocPRIM's onesweep with 9 radix bits per pass and 1024 x 8 keys per workgroup: ids of a 100 M-row shard (27 bits) sort
+// in 3 passes instead of the tuned default's 4 x 8 bits (10 M (key, position) pairs: 398 -> 251 us;
+// experiments/sort_variants.hip has the sweep). 64-bit keys keep the library default.
+template <typename SortKeyT>
+struct sort_config {
+  using type = rocprim::default_config;
+};
+template <>
+struct sort_config<uint32_t> {
+  using type = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 12>, rocprim::kernel_config<1024, 8>, 9,
+                                        rocprim::block_radix_rank_algorithm::match>>;
+};
+
+template <typename SortKeyT>
 struct dedup_layout {
-  KeyT* sorted;
-  int32_t* iota;
-  int32_t* flags;
-  int32_t* run_idx;
+  SortKeyT* sorted;
+  int32_t* tile_counts;
   void* temp;
   size_t temp_bytes;
   size_t total;
 };
 
-template <typename KeyT>
-dedup_layout<KeyT> layout(void* ws, int64_t n)
+inline int run_tiles(int64_t n) { return static_cast<int>((n + kRunTile - 1) / kRunTile); }
+
+template <typename SortKeyT>
+dedup_layout<SortKeyT> layout(void* ws, int64_t n)
 {
   auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-  size_t sort_bytes = 0, scan_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, static_cast<const KeyT*>(nullptr), static_cast<KeyT*>(nullptr),
-                            static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
-                            static_cast<size_t>(n), 0, 8 * sizeof(KeyT), nullptr);
-  (void)rocprim::exclusive_scan(nullptr, scan_bytes, static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
-                          0, static_cast<size_t>(n), rocprim::plus<int32_t>(), nullptr);
-  dedup_layout<KeyT> l;
-  char* p      = static_cast<char*>(ws);
-  size_t o     = 0;
-  l.sorted     = reinterpret_cast<KeyT*>(p + o), o += align(sizeof(KeyT) * n);
-  l.iota       = reinterpret_cast<int32_t*>(p + o), o += align(4 * n);
-  l.flags      = reinterpret_cast<int32_t*>(p + o), o += align(4 * n);
-  l.run_idx    = reinterpret_cast<int32_t*>(p + o), o += align(4 * n);
-  l.temp       = p + o;
-  l.temp_bytes = std::max(sort_bytes, scan_bytes);
-  l.total      = o + align(l.temp_bytes) + 256;
+  size_t sort_bytes = 0;
+  (void)rocprim::radix_sort_pairs<typename sort_config<SortKeyT>::type>(
+    nullptr, sort_bytes, static_cast<const SortKeyT*>(nullptr), static_cast<SortKeyT*>(nullptr),
+    rocprim::counting_iterator<int32_t>(0), static_cast<int32_t*>(nullptr), static_cast<size_t>(n), 0, 8 * sizeof(SortKeyT),
+    nullptr);
+  dedup_layout<SortKeyT> l;
+  char* p       = static_cast<char*>(ws);
+  size_t o      = 0;
+  l.sorted      = reinterpret_cast<SortKeyT*>(p + o), o += align(sizeof(SortKeyT) * n);
+  l.tile_counts = reinterpret_cast<int32_t*>(p + o), o += align(4 * static_cast<size_t>(run_tiles(n) + 1));
+  l.temp        = p + o;
+  l.temp_bytes  = sort_bytes;
+  l.total       = o + align(l.temp_bytes) + 256;
   return l;
+}
+
+template <typename SortKeyT, typename OutT>
+int detect_runs(const SortKeyT* sorted, int32_t* tile_counts, int64_t n, OutT* unique_ids, int32_t* run_starts,
+                int64_t* n_unique_out, hipStream_t stream)
+{
+  const int tiles = run_tiles(n);
+  hipLaunchKernelGGL((run_count_kernel<SortKeyT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts);
+  hipLaunchKernelGGL(run_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, tiles, n_unique_out);
+  hipLaunchKernelGGL((run_compact_kernel<SortKeyT, OutT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts,
+                     n_unique_out, unique_ids, run_starts);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <typename KeyT>
 int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, void* unique_ids, int32_t* run_starts,
               int32_t* order, int64_t* n_unique_out, void* workspace, hipStream_t stream)
 {
-  using UKey = typename std::make_unsigned<KeyT>::type;
-  auto l     = layout<UKey>(workspace, n);
-  int blocks = static_cast<int>((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(iota_i32_kernel, dim3(blocks), dim3(kBlock), 0, stream, l.iota, n);
+  using UKey          = typename std::make_unsigned<KeyT>::type;
+  const unsigned bits = significant_bits(key_upper_bound, 8 * sizeof(KeyT));
+  // the payload 0, 1, 2 ... is generated by the sort's first pass (counting iterator): no iota array
+  rocprim::counting_iterator<int32_t> positions(0);
+  if (sizeof(KeyT) == 8 && key_upper_bound > 0 && bits <= 32) {
+    auto l    = layout<uint32_t>(workspace, n);
+    size_t tb = l.temp_bytes;
+    auto keys = rocprim::make_transform_iterator(static_cast<const uint64_t*>(ids), narrow_to_u32());
+    if (rocprim::radix_sort_pairs<sort_config<uint32_t>::type>(l.temp, tb, keys, l.sorted, positions, order,
+                                                               static_cast<size_t>(n), 0, bits, stream) != hipSuccess)
+      return -2;
+    return detect_runs<uint32_t, UKey>(l.sorted, l.tile_counts, n, static_cast<UKey*>(unique_ids), run_starts, n_unique_out,
+                                       stream);
+  }
+  auto l    = layout<UKey>(workspace, n);
   size_t tb = l.temp_bytes;
-  if (rocprim::radix_sort_pairs(l.temp, tb, static_cast<const UKey*>(ids), l.sorted, l.iota, order,
-                                static_cast<size_t>(n), 0, significant_bits(key_upper_bound, 8 * sizeof(KeyT)),
-                                stream) != hipSuccess)
+  if (rocprim::radix_sort_pairs<typename sort_config<UKey>::type>(l.temp, tb, static_cast<const UKey*>(ids), l.sorted, positions,
+                                                                  order, static_cast<size_t>(n), 0, bits, stream) != hipSuccess)
     return -2;
-  hipLaunchKernelGGL((head_flags_kernel<UKey>), dim3(blocks), dim3(kBlock), 0, stream, l.sorted, n, l.flags);
-  tb = l.temp_bytes;
-  if (rocprim::exclusive_scan(l.temp, tb, l.flags, l.run_idx, 0, static_cast<size_t>(n), rocprim::plus<int32_t>(),
-                              stream) != hipSuccess)
-    return -2;
-  hipLaunchKernelGGL((compact_runs_kernel<UKey>), dim3(blocks), dim3(kBlock), 0, stream, l.sorted, l.flags, l.run_idx,
-                     n, static_cast<UKey*>(unique_ids), run_starts, n_unique_out);
-  return hipGetLastError() == hipSuccess ? 0 : -2;
+  return detect_runs<UKey, UKey>(l.sorted, l.tile_counts, n, static_cast<UKey*>(unique_ids), run_starts, n_unique_out, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -488,11 +618,16 @@ __device__ __forceinline__ P* tile_bcast_ptr(P* p, int e0, int sub)
 #ifndef WM_TILE_KU_STATE
 #define WM_TILE_KU_STATE 2
 #endif
-template <typename IdxT, int OPT, int RPS, bool CACHED>
+// VB = bytes per lane, KU = steps in flight (0: the default for the optimizer). Swept on the 10 M-row SGD / LazyAdam call
+// (profiles/r02_tile_sweep.txt): 16 B x 4 steps (SGD) and 16 B x 2 (stateful) are the defaults; 8 B per lane (a 512-byte row
+// per wave, every per-row quantity wave-uniform) is 5 % slower, 8 steps in flight no faster, grids of 2048 / 4096
+// workgroups 5-8 % slower than 8192.
+template <typename IdxT, int OPT, int RPS, bool CACHED, int VB = 16, int KU = 0>
 __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
 {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  constexpr int kU           = OPT == WHOLEMEMORY_OPT_SGD ? WM_TILE_KU_SGD : WM_TILE_KU_STATE;
+  constexpr int kVE          = VB / 4;  // floats per lane
+  typedef float f4 __attribute__((ext_vector_type(kVE)));
+  constexpr int kU           = KU > 0 ? KU : (OPT == WHOLEMEMORY_OPT_SGD ? WM_TILE_KU_SGD : WM_TILE_KU_STATE);
   constexpr int kLpr         = 64 / RPS;
   constexpr bool kState      = OPT != WHOLEMEMORY_OPT_SGD;
   constexpr bool kAdam       = OPT == WHOLEMEMORY_OPT_LAZY_ADAM;
@@ -505,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
   const IdxT* ids            = static_cast<const IdxT*>(a.ids);
   const int col              = lane & (kLpr - 1);
   const int sub              = lane / kLpr;
-  const int row_vecs         = static_cast<int>(a.dim / 4);
+  const int row_vecs         = static_cast<int>(a.dim / kVE);
 
   for (int64_t tile = wave; tile < tiles; tile += n_waves) {
     const int64_t u     = tile * 64 + lane;
@@ -538,7 +673,7 @@ __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
     for (int cbase = 0; cbase < row_vecs; cbase += kLpr) {  // > 1 trip only when a row has more pieces than a wave step covers
       const int c        = cbase + col;
       const bool col_ok  = c < row_vecs;
-      const int64_t coff = static_cast<int64_t>(c) * 4;
+      const int64_t coff = static_cast<int64_t>(c) * kVE;
 #pragma unroll 1
       for (int s = 0; s < 64; s += RPS * kU) {
         f4 acc[kU], ev[kU], s0v[kU], s1v[kU];
@@ -593,7 +728,7 @@ __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
           if (ln[k] <= 0) continue;
           f4 eo, so0, so1;
 #pragma unroll
-          for (int v = 0; v < 4; v++) {
+          for (int v = 0; v < kVE; v++) {
             opt_elem x;
             x.e  = ev[k][v];
             x.s0 = kState ? s0v[k][v] : 0.f;
