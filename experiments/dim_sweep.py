@@ -1,5 +1,8 @@
 #!/usr/bin/env python
-"""Side measurement: gather / scatter algorithmic bandwidth across row shapes (1 GPU, chunked table ~ 8 GB)."""
+"""Side measurement: gather / scatter algorithmic bandwidth across row shapes (1 GPU, chunked table ~ 8 GB).
+  python experiments/dim_sweep.py [--csv=file] [--ab] [dims ...]
+--ab: every (shape, op) is measured with WM_ROWS_FLAT=0 and =1 as well as the default rule, interleaved over 5 rounds of 10
+launches, and the MIN over rounds is reported (a shared box drifts by 10-20 % between back-to-back runs of one setting)."""
 import os
 import sys
 import time
@@ -16,8 +19,20 @@ def main():
     comm = wgth.create_group_communicator(1)
     cases = [(torch.float32, d) for d in (8, 16, 32, 64, 100, 128, 200, 256, 300, 512, 602, 1024)] + \
             [(torch.float16, d) for d in (64, 128, 256, 768, 1024)]
-    if len(sys.argv) > 1:
-        cases = [(torch.float32, int(x)) for x in sys.argv[1:]]
+    csv_out, ab = None, False
+    args = []
+    for x in sys.argv[1:]:
+        if x.startswith("--csv="):
+            csv_out = open(x[6:], "w")
+            csv_out.write("op,dtype,dim,row_bytes,stride_elems,n_ids,setting,kernel,ms_min,ms_median,algorithmic_GB,frac_of_8TBps\n")
+        elif x == "--ab":
+            ab = True
+        else:
+            args.append(x)
+    if args:
+        cases = [(torch.float32, int(x)) for x in args]
+    settings = [("default", None), ("flat=0", "0"), ("flat=1", "1"), ("tile=64", "T64")] if ab else [("default", None)]
+    rounds = 5 if ab else 1
     for dt, dim in cases:
         es = 4 if dt == torch.float32 else 2
         rows = int(8e9 // (dim * es))
@@ -28,17 +43,37 @@ def main():
         out = torch.empty((n, dim), dtype=dt, device="cuda")
         for op in ("gather", "scatter"):
             fn = (lambda: emb.gather(idx, out=out)) if op == "gather" else (lambda: t.scatter(out, idx))
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                fn()
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 10 * 1e3
-            algo = n * (8 + 2 * dim * es) / ms / 1e6
-            print("%-7s %s dim %4d (%4d B rows, stride %d) n=%8d : %.3f ms  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
-                op, str(dt).split(".")[1], dim, dim * es, t.stride()[0] if hasattr(t, "stride") else -1, n, ms, algo, algo / 80.0))
+            times = {s: [] for s, _ in settings}
+            kernels = {}
+            for r in range(rounds):
+                for name, val in settings:
+                    os.environ.pop("WM_ROWS_FLAT", None)
+                    os.environ.pop("WM_ROWS_TILE", None)
+                    if val is not None and val.startswith("T"):
+                        os.environ["WM_ROWS_TILE"] = val[1:]
+                    elif val is not None:
+                        os.environ["WM_ROWS_FLAT"] = val
+                    for _ in range(3):
+                        fn()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        fn()
+                    torch.cuda.synchronize()
+                    times[name].append((time.perf_counter() - t0) / 10 * 1e3)
+                    kernels[name] = wmb.lib().wholememory_ext_last_rows_kernel().decode().split("::")[-1].split("(")[0]
+            os.environ.pop("WM_ROWS_FLAT", None)
+            os.environ.pop("WM_ROWS_TILE", None)
+            gb = n * (8 + 2 * dim * es) / 1e9
+            for name, _ in settings:
+                ts = sorted(times[name])
+                mn, md = ts[0], ts[len(ts) // 2]
+                if csv_out:
+                    csv_out.write("%s,%s,%d,%d,%d,%d,%s,\"%s\",%.4f,%.4f,%.4f,%.4f\n" % (
+                        op, str(dt).split(".")[1], dim, dim * es, t.stride()[0], n, name, kernels[name], mn, md, gb, gb / mn / 8.0))
+                    csv_out.flush()
+                print("%-7s %s dim %4d (%4d B rows, stride %d) n=%8d %-8s: min %.3f ms median %.3f  %.1f%% of 8 TB/s algorithmic  [%s]" % (
+                    op, str(dt).split(".")[1], dim, dim * es, t.stride()[0], n, name, mn, md, gb / mn / 8.0 * 100, kernels[name]))
         wgth.destroy_embedding(emb)
 
 

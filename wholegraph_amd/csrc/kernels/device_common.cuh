@@ -81,4 +81,31 @@ __device__ __forceinline__ ToT convert_elt(FromT v)
   return store_narrow<ToT>(static_cast<to_wide>(load_wide<FromT>(v)));
 }
 
+// Row pointers that travel between lanes (v_readlane / ds_bpermute) come back as integers, and hipcc then no longer knows
+// they point to global memory: it emits FLAT loads and stores, which count on lgkmcnt as well as vmcnt — every wait for a
+// ds_bpermute result (or a scalar load) then also drains the row loads in flight, one load per wave at a time. These
+// helpers state the address space: table, plain, gradient and state rows are always global memory (device, pinned host
+// or a peer's mapping), never LDS or scratch.
+#define WM_GLOBAL_AS __attribute__((address_space(1)))
+template <typename V>
+__device__ __forceinline__ V ld_global(const void* p)
+{
+  return *(const WM_GLOBAL_AS V*)p;
+}
+template <typename V>
+__device__ __forceinline__ V ld_global_nt(const void* p)
+{
+  return __builtin_nontemporal_load((const WM_GLOBAL_AS V*)p);
+}
+template <typename V>
+__device__ __forceinline__ void st_global(void* p, V v)
+{
+  *(WM_GLOBAL_AS V*)p = v;
+}
+template <typename V>
+__device__ __forceinline__ void st_global_nt(void* p, V v)
+{
+  __builtin_nontemporal_store(v, (WM_GLOBAL_AS V*)p);
+}
+
 }  // namespace wm

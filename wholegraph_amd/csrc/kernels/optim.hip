@@ -696,10 +696,10 @@ __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
           if (!col_ok) ln[k] = 0;
           if (ln[k] > 0) {
             // first occurrence copied (DedupIndiceAndGradientsKernel); the table / state pieces are loaded alongside
-            acc[k] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g + coff));
-            ev[k]  = __builtin_nontemporal_load(reinterpret_cast<const f4*>(trow[k] + coff));
-            if (kState) s0v[k] = *reinterpret_cast<const f4*>(srow[k] + coff);
-            if (kAdam) s1v[k] = *reinterpret_cast<const f4*>(srow[k] + a.table_stride + coff);
+            acc[k] = ld_global_nt<f4>(g + coff);
+            ev[k]  = ld_global_nt<f4>(trow[k] + coff);
+            if (kState) s0v[k] = ld_global<f4>(srow[k] + coff);
+            if (kAdam) s1v[k] = ld_global<f4>(srow[k] + a.table_stride + coff);
           }
         }
 #pragma unroll
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
             for (int q = 0; q < 4; q++) {
               if (j + q < ln[k]) {
                 const int32_t o = a.order[rs[k] + j + q];
-                gq[q]           = __builtin_nontemporal_load(reinterpret_cast<const f4*>(grad_row<float>(a, o) + coff));
+                gq[q]           = ld_global_nt<f4>(grad_row<float>(a, o) + coff);
               }
             }
 #pragma unroll
@@ -738,9 +738,9 @@ __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
             so0[v] = x.s0;
             so1[v] = x.s1;
           }
-          if (kState) *reinterpret_cast<f4*>(srow[k] + coff) = so0;
-          if (kAdam) *reinterpret_cast<f4*>(srow[k] + a.table_stride + coff) = so1;
-          __builtin_nontemporal_store(eo, reinterpret_cast<f4*>(trow[k] + coff));
+          if (kState) st_global<f4>(srow[k] + coff, so0);
+          if (kAdam) st_global<f4>(srow[k] + a.table_stride + coff, so1);
+          st_global_nt<f4>(trow[k] + coff, eo);
         }
       }
     }

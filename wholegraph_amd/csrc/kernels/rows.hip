@@ -88,6 +88,10 @@ struct rows_params {
   int flat_slots;
   int flat_tail;
   float flat_rcp;
+  // entries per wave tile (64 / 32 / 16 / 8; the fast and flat kernels): big rows get smaller tiles, so that a launch has
+  // many more tiles than the chip has wave slots (64 rows of 2 KiB are 128 KiB per wave and 10 M KiB-rows only ~30 k tiles:
+  // under four rounds of resident waves, and the last round runs half empty)
+  int tile_rows;
 };
 
 // byte address of the first moved element of table row `idx`
@@ -173,15 +177,15 @@ __global__ __launch_bounds__(kBlock) void rows_copy_kernel(rows_params p)
           const bool ok = col_ok && e < kWave && t != nullptr;
           char* src     = GATHER ? t : q;
           dst[u]        = ok ? (GATHER ? q : t) + coff : nullptr;
-          if (ok) data[u] = *reinterpret_cast<const vec_t*>(src + coff);
+          if (ok) data[u] = ld_global<vec_t>(src + coff);
         }
 #pragma unroll
         for (int u = 0; u < kU; u++) {
           if (dst[u] != nullptr) {
             if constexpr (GATHER)
-              __builtin_nontemporal_store(data[u], reinterpret_cast<vec_t*>(dst[u]));
+              st_global_nt<vec_t>(dst[u], data[u]);
             else
-              *reinterpret_cast<vec_t*>(dst[u]) = data[u];
+              st_global<vec_t>(dst[u], data[u]);
           }
         }
       }
@@ -221,63 +225,71 @@ __global__ __launch_bounds__(kBlock) void rows_copy16_fast_kernel(rows_params p)
   const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
   const int col         = lane & (kLpr - 1);
   const bool upper      = RPS == 2 && lane >= kLpr;
-  const int64_t tiles   = (p.n + kWave - 1) / kWave;
+  const int tile_rows   = p.tile_rows;
+  const int64_t tiles   = (p.n + tile_rows - 1) / tile_rows;
 
   for (int64_t tile = wave; tile < tiles; tile += n_waves) {
     char *my_tab, *my_plain;
-    load_tile_entry<IdxT>(p, tile * kWave + lane, my_tab, my_plain);
+    load_tile_entry<IdxT>(p, lane < tile_rows ? tile * tile_rows + lane : p.n, my_tab, my_plain);
     // without a row map the plain side is affine in the entry number: no broadcast needed
-    char* const plain_tile = p.plain + (tile * kWave + (upper ? 1 : 0)) * p.plain_stride_bytes;
-    for (int cbase = 0; cbase < p.row_vecs; cbase += kLpr) {
-      const int c        = cbase + col;
-      const bool col_ok  = c < p.row_vecs;
-      const int64_t coff = static_cast<int64_t>(c) * 16;
+    char* const plain_tile = p.plain + (tile * tile_rows + (upper ? 1 : 0)) * p.plain_stride_bytes;
+    // The tile is a sequence of (row, 1 KiB chunk) steps, row-major: a row of more than 1 KiB is read front to back by
+    // consecutive wave instructions (kU of them in flight), not chunk 0 of every row first and chunk 1 a pass later —
+    // the second half of a row then finds its DRAM page still open (scatter of 2 KiB rows 65.8 -> 69.8 % of HBM peak, 4 KiB rows 63.7 -> 70.5 %; gather unchanged).
+    const int chunks = RPS == 1 ? (p.row_vecs + kLpr - 1) / kLpr : 1;
+    const int total  = (tile_rows / RPS) * chunks;   // a multiple of kU: tile_rows / RPS is (tile_rows >= 8)
+    int e = 0, cb = 0;
 #pragma unroll 1
-      for (int s0 = 0; s0 < kWave; s0 += RPS * kU) {
-        u32x4 data[kU];
-        char* dst[kU];
+    for (int q0 = 0; q0 < total; q0 += kU) {
+      u32x4 data[kU];
+      char* dst[kU];
 #pragma unroll
-        for (int u = 0; u < kU; u++) {
-          const int e0 = s0 + RPS * u;
-          char* t      = readlane_ptr(my_tab, e0);
+      for (int u = 0; u < kU; u++) {
+        const int e0 = RPS * e;
+        char* t      = readlane_ptr(my_tab, e0);
+        if (RPS == 2) {
+          char* t1 = readlane_ptr(my_tab, e0 + 1);
+          t        = upper ? t1 : t;
+        }
+        char* q;
+        if (HAS_MAP) {
+          q = readlane_ptr(my_plain, e0);
           if (RPS == 2) {
-            char* t1 = readlane_ptr(my_tab, e0 + 1);
-            t        = upper ? t1 : t;
+            char* q1 = readlane_ptr(my_plain, e0 + 1);
+            q        = upper ? q1 : q;
           }
-          char* q;
-          if (HAS_MAP) {
-            q = readlane_ptr(my_plain, e0);
-            if (RPS == 2) {
-              char* q1 = readlane_ptr(my_plain, e0 + 1);
-              q        = upper ? q1 : q;
-            }
-          } else {
-            q = plain_tile + static_cast<int64_t>(e0) * p.plain_stride_bytes;
-          }
-          const bool ok   = col_ok && t != nullptr;  // entries past n and negative ids carry a null base
-          const char* src = (GATHER ? t : q) + coff;
-          dst[u]          = ok ? (GATHER ? q : t) + coff : nullptr;
+        } else {
+          q = plain_tile + static_cast<int64_t>(e0) * p.plain_stride_bytes;
+        }
+        const int c        = cb * kLpr + col;
+        const int64_t coff = static_cast<int64_t>(c) * 16;
+        const bool ok      = c < p.row_vecs && t != nullptr;  // entries past n and negative ids carry a null base
+        const char* src    = (GATHER ? t : q) + coff;
+        dst[u]             = ok ? (GATHER ? q : t) + coff : nullptr;
 #ifndef WM_SCATTER_NT_LOAD
 #define WM_SCATTER_NT_LOAD 1
 #endif
 #ifndef WM_SCATTER_NT_STORE
 #define WM_SCATTER_NT_STORE 1
 #endif
-          if (ok) {
-            if constexpr (GATHER || WM_SCATTER_NT_LOAD)
-              data[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
-            else
-              data[u] = *reinterpret_cast<const u32x4*>(src);
-          }
+        if (ok) {
+          if constexpr (GATHER || WM_SCATTER_NT_LOAD)
+            data[u] = ld_global_nt<u32x4>(src);
+          else
+            data[u] = ld_global<u32x4>(src);
         }
+        if (++cb == chunks) {  // wave-uniform: stays in SGPRs
+          cb = 0;
+          e++;
+        }
+      }
 #pragma unroll
-        for (int u = 0; u < kU; u++) {
-          if (dst[u] != nullptr) {
-            if constexpr (GATHER || WM_SCATTER_NT_STORE)
-              __builtin_nontemporal_store(data[u], reinterpret_cast<u32x4*>(dst[u]));
-            else
-              *reinterpret_cast<u32x4*>(dst[u]) = data[u];
-          }
+      for (int u = 0; u < kU; u++) {
+        if (dst[u] != nullptr) {
+          if constexpr (GATHER || WM_SCATTER_NT_STORE)
+            st_global_nt<u32x4>(dst[u], data[u]);
+          else
+            st_global<u32x4>(dst[u], data[u]);
         }
       }
     }
@@ -301,15 +313,16 @@ __global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
   const int lane        = threadIdx.x & (kWave - 1);
   const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
   const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
-  const int64_t tiles   = (p.n + kWave - 1) / kWave;
+  const int tile_rows   = p.tile_rows;
+  const int64_t tiles   = (p.n + tile_rows - 1) / tile_rows;
   const int S           = p.flat_slots;
-  const int n_slots     = kWave * S;
+  const int n_slots     = tile_rows * S;
   const bool ragged     = p.flat_tail != 16;
 
   for (int64_t tile = wave; tile < tiles; tile += n_waves) {
     char *my_tab, *my_plain;
-    load_tile_entry<IdxT>(p, tile * kWave + lane, my_tab, my_plain);
-    char* const plain_tile = p.plain + tile * kWave * p.plain_stride_bytes;
+    load_tile_entry<IdxT>(p, lane < tile_rows ? tile * tile_rows + lane : p.n, my_tab, my_plain);
+    char* const plain_tile = p.plain + tile * tile_rows * p.plain_stride_bytes;
 #pragma unroll 1
     for (int v0 = 0; v0 < n_slots; v0 += kWave * kU) {
       u32x4 data[kU];
@@ -337,13 +350,13 @@ __global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
         if (ok) {
           if (!part[u]) {
             if constexpr (GATHER)
-              data[u] = *reinterpret_cast<const u32x4*>(src);  // rows share cache lines with their neighbours: keep them
+              data[u] = ld_global<u32x4>(src);  // rows share cache lines with their neighbours: keep them
             else
-              data[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+              data[u] = ld_global_nt<u32x4>(src);
           } else {
 #pragma unroll
             for (int w = 0; w < 3; w++)
-              if (w * 4 < p.flat_tail) data[u][w] = reinterpret_cast<const uint32_t*>(src)[w];
+              if (w * 4 < p.flat_tail) data[u][w] = ld_global<uint32_t>(src + 4 * w);
           }
         }
       }
@@ -351,11 +364,11 @@ __global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
       for (int u = 0; u < kU; u++) {
         if (dst[u] == nullptr) continue;
         if (!part[u]) {
-          __builtin_nontemporal_store(data[u], reinterpret_cast<u32x4*>(dst[u]));
+          st_global_nt<u32x4>(dst[u], data[u]);
         } else {
 #pragma unroll
           for (int w = 0; w < 3; w++)
-            if (w * 4 < p.flat_tail) reinterpret_cast<uint32_t*>(dst[u])[w] = data[u][w];
+            if (w * 4 < p.flat_tail) st_global<uint32_t>(dst[u] + 4 * w, data[u][w]);
         }
       }
     }
@@ -369,6 +382,39 @@ template <typename T, int V>
 struct alignas(sizeof(T) * V) elt_vec {
   T v[V];
 };
+
+// struct-typed accesses through an address-space pointer fall back to FLAT (the copy goes through a generic reference):
+// move the bytes as a plain vector of the same size and reinterpret them in registers
+template <typename S>
+__device__ __forceinline__ S ld_global_pod(const void* p)
+{
+  constexpr size_t N = sizeof(S);
+  static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32, "element vector size");
+  S out;
+  if constexpr (N == 32) {
+    u32x4 r[2] = {ld_global<u32x4>(p), ld_global<u32x4>(static_cast<const char*>(p) + 16)};
+    __builtin_memcpy(&out, r, N);
+  } else {
+    typename vec_of<N>::type r = ld_global<typename vec_of<N>::type>(p);
+    __builtin_memcpy(&out, &r, N);
+  }
+  return out;
+}
+template <typename S>
+__device__ __forceinline__ void st_global_pod(void* p, const S& v)
+{
+  constexpr size_t N = sizeof(S);
+  if constexpr (N == 32) {
+    u32x4 r[2];
+    __builtin_memcpy(r, &v, N);
+    st_global<u32x4>(p, r[0]);
+    st_global<u32x4>(static_cast<char*>(p) + 16, r[1]);
+  } else {
+    typename vec_of<N>::type r;
+    __builtin_memcpy(&r, &v, N);
+    st_global<typename vec_of<N>::type>(p, r);
+  }
+}
 
 template <typename TabT, typename PlainT, typename IdxT, int V, bool GATHER>
 __global__ __launch_bounds__(kBlock) void rows_convert_kernel(rows_params p)
@@ -402,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void rows_convert_kernel(rows_params p)
           const bool ok = col_ok && e < kWave && t != nullptr;
           const char* src = GATHER ? t : q;
           dst[u]        = ok ? (GATHER ? q : t) + static_cast<int64_t>(c) * V * sizeof(ToT) : nullptr;
-          if (ok) data[u] = *reinterpret_cast<const elt_vec<FromT, V>*>(src + static_cast<int64_t>(c) * V * sizeof(FromT));
+          if (ok) data[u] = ld_global_pod<elt_vec<FromT, V>>(src + static_cast<int64_t>(c) * V * sizeof(FromT));
         }
 #pragma unroll
         for (int u = 0; u < kU; u++) {
@@ -410,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void rows_convert_kernel(rows_params p)
             elt_vec<ToT, V> o;
 #pragma unroll
             for (int k = 0; k < V; k++) o.v[k] = convert_elt<FromT, ToT>(data[u].v[k]);
-            *reinterpret_cast<elt_vec<ToT, V>*>(dst[u]) = o;
+            st_global_pod<elt_vec<ToT, V>>(dst[u], o);
           }
         }
       }
@@ -470,7 +516,12 @@ bool want_flat(bool gather, int vb, int64_t row_bytes)
   if (ov == 0) return false;
   if (ov == 1) return true;
   const bool pow2 = (row_bytes & (row_bytes - 1)) == 0;
-  if (vb == 16) return gather && row_bytes > 256 && (!pow2 || row_bytes == 1024);
+  // 16-byte-multiple rows (interleaved A/B, min of 5 rounds, profiles/r02_dim_sweep_ab*.csv): gather — flat wins for every
+  // row that is not a power of two (400 B: 63 vs 57 %, 800 B: 67.5 vs 62 %, 1200 B: 63 vs 52 %); the powers of two,
+  // 1 KiB included, go to the readlane kernel with its smaller tiles (1 KiB: 71.4 vs 69.6 %, 2 KiB: 71.7 vs 70.0 %).
+  // scatter — flat wins for 400 B (50.7 vs 44.9 %), 416, 448 B (68 vs 56 %) and from 1200 B up (67.7 vs 63.2 %), loses at
+  // 800 B (50.6 vs 54.5 %)
+  if (vb == 16) return row_bytes > 256 && !pow2 && (gather || row_bytes < 640 || row_bytes > 1024);
   // 4- / 8-byte-multiple rows: 16-byte accesses at 4-byte alignment beat 4- / 8-byte vectors from ~320 B up
   // (508 B: 37 -> 46 %, 516 B: 27 -> 54 %, 2408 B: 42 -> 59 %; 200 B: 44 -> 41 %, so small rows stay on the old path)
   return row_bytes >= 320;
@@ -611,10 +662,14 @@ int rows_op(const wm_rows_args* a, void* stream_v)
   p.plain              = static_cast<char*>(a->plain) + a->plain_storage_offset * pes;
   p.plain_stride_bytes = a->plain_stride * pes;
 
-  const int64_t tiles = (a->n + kWave - 1) / kWave;
-  int blocks          = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, default_max_blocks()));
-  if (a->max_blocks > 0) blocks = std::min(blocks, a->max_blocks);
-  if (blocks < 1) blocks = 1;
+  p.tile_rows = kWave;
+  auto grid_for = [&](int tile_rows) {
+    const int64_t tiles = (a->n + tile_rows - 1) / tile_rows;
+    int b               = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, default_max_blocks()));
+    if (a->max_blocks > 0) b = std::min(b, a->max_blocks);
+    return std::max(b, 1);
+  };
+  int blocks = grid_for(kWave);
 
   // widest power-of-two access every address on both sides is aligned to — the reference's
   // alignment pick (gather_scatter_func.cuh:215-251) plus the base pointers themselves
@@ -636,6 +691,13 @@ int rows_op(const wm_rows_args* a, void* stream_v)
       p.flat_slots = static_cast<int>((row_bytes + 15) / 16);
       p.flat_tail  = static_cast<int>(row_bytes - 16 * static_cast<int64_t>(p.flat_slots - 1));
       p.flat_rcp   = 1.0f / static_cast<float>(p.flat_slots);
+    }
+    if (p.flat_slots > 0 || (vb == 16 && p.row_vecs >= 32)) {  // the two kernels that take tile_rows
+      const char* te    = getenv("WM_ROWS_TILE");  // experiment switch
+      const int forced  = te != nullptr ? atoi(te) : 0;
+      p.tile_rows = row_bytes <= 768 ? 64 : row_bytes <= 1536 ? 32 : row_bytes <= 3072 ? 16 : 8;
+      if (forced == 8 || forced == 16 || forced == 32 || forced == 64) p.tile_rows = forced;
+      blocks = grid_for(p.tile_rows);
     }
     if (a->index_dtype == WHOLEMEMORY_DT_INT)
       launch_copy<int32_t, GATHER>(p, static_cast<int>(vb), blocks, stream);
