@@ -33,6 +33,12 @@ typedef void* (*wholememory_malloc_func_t)(struct wholememory_tensor_description
                                            enum wholememory_memory_allocation_type_t kind, void* slot, void* global);
 typedef void (*wholememory_free_func_t)(void* slot, void* global);
 
+/* Stream ordering contract of temporary_fns (the reference leaves it implicit): the ops call malloc_fn / free_fn from
+ * the host while kernels that use the memory may still be queued on the op's `stream`. An allocator must therefore
+ * either be stream-ordered on that stream (torch's caching allocator on the current stream is, and the ops are always
+ * called with the current stream by the torch layer) or free synchronously (hipFree / the built-in default env). Ops
+ * that also work on the communicator's side stream fence it with an event on `stream` before they return, and the
+ * raw-stage entry points of wholegraph_amd_ext.h synchronise `stream` before their scratch is released. */
 struct wholememory_temp_memory_func_t { /* reference env_func_ptrs.h:58-64 */
   wholememory_create_memory_context_func_t create_memory_context_fn;
   wholememory_destroy_memory_context_func_t destroy_memory_context_fn;

@@ -74,6 +74,8 @@ def lib():
         L.wmo_sort_ids.argtypes = [c.c_void_p, c.c_int, c.c_int64, c.c_void_p, c.c_void_p]
         L.wmo_round_robin_map.restype = None
         L.wmo_round_robin_map.argtypes = [c.c_void_p, c.c_int, c.c_int64, c.c_int64, c.c_int, c.c_int, c.c_void_p]
+        L.wmo_round_robin_map_ex.restype = None
+        L.wmo_round_robin_map_ex.argtypes = [c.c_void_p, c.c_int, c.c_int64, c.c_int64, c.c_int, c.c_int, c.c_int64, c.c_void_p]
         L.wmo_dedup_grads.restype = c.c_int64
         L.wmo_dedup_grads.argtypes = [c.c_void_p, c.c_int, c.c_int64, c.c_void_p, c.c_int64, c.c_int64,
                                       c.c_void_p, c.c_void_p]
@@ -238,10 +240,14 @@ def sort_ids(indices):
     return sorted_out, raw
 
 
-def round_robin_map(indices, entry_start, world, rr):
+def round_robin_map(indices, entry_start, world, rr, rank_rows=0):
+    """rank_rows == 0: the reference statement (map_indices_func.cu:34-43). rank_rows > 0: the owner's shard (product)."""
     indices = np.ascontiguousarray(indices)
     out = np.empty_like(indices)
-    lib().wmo_round_robin_map(_p(indices), np_to_dt(indices.dtype), indices.size, entry_start, world, rr, _p(out))
+    if rank_rows:
+        lib().wmo_round_robin_map_ex(_p(indices), np_to_dt(indices.dtype), indices.size, entry_start, world, rr, rank_rows, _p(out))
+    else:
+        lib().wmo_round_robin_map(_p(indices), np_to_dt(indices.dtype), indices.size, entry_start, world, rr, _p(out))
     return out
 
 

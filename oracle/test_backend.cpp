@@ -27,8 +27,8 @@ int wmo_scatter_mapped(const void* in, int in_dtype, int64_t in_stride, int64_t 
                        int64_t storage_offset);
 void wmo_bucket_counts(const void* indices, int idx_dtype, int64_t n, const uint64_t* entry_offsets, int world_size,
                        int64_t* counts);
-void wmo_round_robin_map(const void* indices, int idx_dtype, int64_t n, int64_t entry_start, int world_size,
-                         int round_robin_size, void* mapped);
+void wmo_round_robin_map_ex(const void* indices, int idx_dtype, int64_t n, int64_t entry_start, int world_size,
+                            int round_robin_size, int64_t rank_rows, void* mapped);
 void wmo_sgd_step(const void* ids, int idx_dtype, int64_t count, const float* grads, int64_t grad_stride,
                   float* local_table, int64_t table_stride, int64_t local_entry_offset, int64_t dim, float weight_decay,
                   float lr);
@@ -273,9 +273,10 @@ int t_remap_self(int32_t* order, int64_t n, int64_t self_begin, int64_t self_cou
   }
   return 0;
 }
-int t_rr(const void* ids, void* mapped, wholememory_dtype_t dt, int64_t n, int64_t entry_start, int world, int rr, void*)
+int t_rr(const void* ids, void* mapped, wholememory_dtype_t dt, int64_t n, int64_t entry_start, int world, int rr,
+         int64_t rank_rows, void*)
 {
-  wmo_round_robin_map(ids, dt, n, entry_start, world, rr, mapped);
+  wmo_round_robin_map_ex(ids, dt, n, entry_start, world, rr, rank_rows, mapped);
   return 0;
 }
 int t_fill(float* p, float v, int64_t n, void*)

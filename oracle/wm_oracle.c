@@ -424,6 +424,29 @@ void wmo_sort_ids(const void* indices, int idx_dtype, int64_t n, void* sorted_ou
  * that owns the index is computed but unused (:39) and `entry_start` is the CALLER's local first
  * row (:88-90):
  *   t = idx / rr; off = idx % rr; wm = entry_start + rr * (t / W) + off               */
+/* rank_rows > 0 (NOT the reference): the owner's first row replaces entry_start — owner = t % W holds rows
+ * [owner * rank_rows, (owner + 1) * rank_rows), which is where the round-robin file loader (file_io.cpp:145-190 of the
+ * product; reference file_io.cpp round_robin path) puts entry ((l / rr) * W + r) * rr + l % rr of rank r. The reference
+ * statement is right only for ids the caller owns; the product maps to the owner (deviations). */
+void wmo_round_robin_map_ex(const void* indices, int idx_dtype, int64_t n, int64_t entry_start, int world_size,
+                            int round_robin_size, int64_t rank_rows, void* mapped)
+{
+  for (int64_t i = 0; i < n; i++) {
+    int64_t idx = load_index(idx_dtype, indices, i);
+    int64_t wm  = idx;
+    if (idx >= 0) {
+      int64_t t    = idx / round_robin_size;
+      int64_t off  = idx % round_robin_size;
+      int64_t base = rank_rows > 0 ? (t % world_size) * rank_rows : entry_start;
+      wm           = base + (int64_t)round_robin_size * (t / world_size) + off;
+    }
+    if (idx_dtype == DT_INT)
+      ((int32_t*)mapped)[i] = (int32_t)wm;
+    else
+      ((int64_t*)mapped)[i] = wm;
+  }
+}
+
 void wmo_round_robin_map(const void* indices, int idx_dtype, int64_t n, int64_t entry_start, int world_size,
                          int round_robin_size, void* mapped)
 {

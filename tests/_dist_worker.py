@@ -334,6 +334,21 @@ def scenario_file_io(comm, rank, world, tmpdir):
         if e < n_rows:
             assert np.array_equal(got[l], full[e]), "round-robin row %d on rank %d" % (l, rank)
     comm.barrier()
+    # ... and a gather by STORAGE id returns the file's rows whoever owns them (the reference's remap only finds the rows
+    # the caller owns itself, map_indices_func.cu:34-43; the product maps to the owner's shard)
+    ids = np.random.default_rng(70 + rank).integers(0, n_rows, 300 + 11 * rank).astype(np.int64)
+    ids[::17] = -1
+    out = dev(torch.full((len(ids), dim), -3.0))
+    got_rows = emb.gather(dev(torch.from_numpy(ids)), out=out)
+    if HIP_MODE:
+        torch.cuda.synchronize()
+    exp_rows = np.full((len(ids), dim), -3.0, np.float32)
+    exp_rows[ids >= 0] = full[ids[ids >= 0].astype(np.int64)]
+    assert np.array_equal(host(got_rows).numpy(), exp_rows), "round-robin gather by storage id, rank %d" % rank
+    rank_rows = emb.shape[0] // world
+    assert np.array_equal(oracle.round_robin_map(ids[ids >= 0], 0, world, rr, rank_rows=rank_rows) % rank_rows,
+                          rr * ((ids[ids >= 0] // rr) // world) + ids[ids >= 0] % rr)
+    comm.barrier()
     wgth.destroy_embedding(emb)
 
 

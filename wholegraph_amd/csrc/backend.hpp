@@ -184,8 +184,12 @@ struct wm_device_backend {
   // order[i] in [self_begin, self_begin + self_count)  ->  -(self_rows[order[i] - self_begin] + 1)   (see self_grads)
   int (*remap_self_order)(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count, const int64_t* self_rows,
                           void* stream);
+  // storage id -> WholeMemory row of a round-robin-loaded table: t = id / rr, off = id % rr, owner = t % world.
+  // rank_rows > 0: row = owner * rank_rows + rr * (t / world) + off — the row file_io.cpp put that entry in (every rank
+  // holds rank_rows rows). rank_rows == 0: the reference's statement as it stands, entry_start + rr * (t / world) + off
+  // (map_indices_func.cu:34-43 computes the owner and never uses it), which is only right for ids the caller owns.
   int (*round_robin_map)(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n,
-                         int64_t entry_start, int world_size, int round_robin_size, void* stream);
+                         int64_t entry_start, int world_size, int round_robin_size, int64_t rank_rows, void* stream);
   int (*fill_float)(float* p, float value, int64_t count, void* stream);
   // ---- graph ops (kernels/graph.hip); nullptr in a backend that does not provide them ----
   // counts[i] = min(degree(center i), max_sample) for i < n, counts[n] = 0

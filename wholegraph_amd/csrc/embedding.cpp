@@ -414,8 +414,14 @@ wholememory_error_code_t remap_round_robin(wholememory_embedding_* e, wholememor
   WHOLEMEMORY_RETURN_ON_FAIL(wholememory_make_tensor_from_pointer(mapped, mp, &md));
   size_t entry_start = 0;
   WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_get_local_entry_start(&entry_start, e->allocated));
+  // Deviation from the reference, on purpose: map_indices_func.cu:34-43 adds the CALLER's first row whoever owns the
+  // entry (it computes the owner and drops it), so with more than one rank an id whose block lives on another rank hits
+  // the wrong row. Here the row is the one wholememory_load_from_file(round_robin_size) put the entry in: every rank
+  // holds the same number of rows (create_embedding pads to that), owner = (id / rr) % world. One rank: identical.
+  const int64_t rank_rows = wholememory_tensor_get_tensor_description(e->allocated)->sizes[0] / e->comm->world_size;
   int rc = backend()->round_robin_map(wholememory_tensor_get_data_pointer(indices), mp, idesc->dtype, idesc->sizes[0],
-                                      static_cast<int64_t>(entry_start), e->comm->world_size, e->round_robin_size, stream);
+                                      static_cast<int64_t>(entry_start), e->comm->world_size, e->round_robin_size,
+                                      rank_rows, stream);
   if (rc != 0) return WHOLEMEMORY_CUDA_ERROR;
   // reference map_indices_func.cu:56-63 synchronises after the remap
   return backend()->stream_sync(stream) == 0 ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_CUDA_ERROR;

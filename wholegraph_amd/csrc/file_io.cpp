@@ -22,6 +22,23 @@
 #include "communicator.hpp"
 #include "wm_common.hpp"
 
+namespace wm {
+// every rank reports its own outcome; all return the first failure (by rank order), or success. Collective.
+static wholememory_error_code_t agree_on_result(wholememory_comm_t comm, wholememory_error_code_t mine)
+{
+  int code = static_cast<int>(mine);
+  std::vector<int> all(static_cast<size_t>(comm->world_size), 0);
+  comm->allgather_host(&code, all.data(), sizeof(int));
+  for (int r = 0; r < comm->world_size; r++) {
+    if (all[r] != WHOLEMEMORY_SUCCESS) {
+      if (mine == WHOLEMEMORY_SUCCESS) WM_ERROR("file I/O failed on rank %d (error %d)", r, all[r]);
+      return static_cast<wholememory_error_code_t>(all[r]);
+    }
+  }
+  return WHOLEMEMORY_SUCCESS;
+}
+}  // namespace wm
+
 extern "C" {
 
 wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
@@ -34,6 +51,12 @@ wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
 {
   WM_API_BEGIN
   if (handle == nullptr || file_names == nullptr || file_count <= 0) return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_comm_t comm;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, handle));
+  // Everything a single rank can fail on (a missing file, a short read, no pinned memory) happens inside `load_local`;
+  // the ranks then AGREE on the outcome (one small all-gather, which is also the closing barrier of the reference,
+  // file_io.cpp:2047) — a rank that failed no longer leaves the healthy ones waiting in a barrier it never reaches.
+  auto load_local = [&]() -> wholememory_error_code_t {
   if (file_entry_size == 0 || file_entry_size > memory_entry_size) return WHOLEMEMORY_INVALID_INPUT;
   if (round_robin_size < 0) return WHOLEMEMORY_INVALID_INPUT;
   const auto* bk = wm::backend();
@@ -63,8 +86,6 @@ wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
              wholememory_get_total_size(handle) / memory_entry_size);
     return WHOLEMEMORY_INVALID_VALUE;  // reference file_io.cpp:1926-1932
   }
-  wholememory_comm_t comm;
-  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, handle));
   void* local_ptr;
   size_t local_size, local_offset;
   WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_local_memory(&local_ptr, &local_size, &local_offset, handle));
@@ -207,8 +228,9 @@ wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
   cleanup();
   if (failed_io) return WHOLEMEMORY_SYSTEM_ERROR;
   if (failed_dev) return WHOLEMEMORY_CUDA_ERROR;
-  comm->barrier();
   return WHOLEMEMORY_SUCCESS;
+  };  // load_local
+  return wm::agree_on_result(comm, load_local());
   WM_API_END
 }
 
@@ -220,7 +242,17 @@ wholememory_error_code_t wholememory_store_to_file(wholememory_handle_t handle,
 {
   WM_API_BEGIN
   if (handle == nullptr || local_file_name == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_comm_t comm;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, handle));
+  // reference file_io.cpp:2059-2075: peers may still be scattering into this shard — wait for everybody first
+  comm->barrier();
+  auto store_local = [&]() -> wholememory_error_code_t {
   if (file_entry_size == 0 || memory_offset + file_entry_size > memory_entry_stride) return WHOLEMEMORY_INVALID_INPUT;
+  if (wholememory_get_data_granularity(handle) % memory_entry_stride != 0) {
+    WM_ERROR("memory_entry_stride=%zu does not divide the handle granularity %zu", memory_entry_stride,
+             wholememory_get_data_granularity(handle));
+    return WHOLEMEMORY_INVALID_INPUT;  // reference file_io.cpp:2076-2082
+  }
   const auto* bk = wm::backend();
   void* local_ptr;
   size_t local_size, local_offset;
@@ -246,8 +278,10 @@ wholememory_error_code_t wholememory_store_to_file(wholememory_handle_t handle,
       }
     }
   }
-  fclose(fp);
+  if (fclose(fp) != 0) return WHOLEMEMORY_SYSTEM_ERROR;
   return WHOLEMEMORY_SUCCESS;
+  };  // store_local
+  return wm::agree_on_result(comm, store_local());
   WM_API_END
 }
 

@@ -21,7 +21,7 @@ int hip_run_inverse(const int32_t* run_starts, const int32_t* order, const void*
 int hip_remap_self_order(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count, const int64_t* self_rows,
                          void* stream);
 int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n, int64_t entry_start,
-                        int world_size, int round_robin_size, void* stream);
+                        int world_size, int round_robin_size, int64_t rank_rows, void* stream);
 int hip_fill_float(float* p, float value, int64_t count, void* stream);
 int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const int64_t* row_pairs, const void* centers,
                       wholememory_dtype_t id_dtype, int n, int max_sample, int* counts, void* stream);

@@ -1234,15 +1234,21 @@ int launch_step(const opt_params& p, int blocks, hipStream_t stream, hipStream_t
 
 template <typename IdxT>
 __global__ void round_robin_map_kernel(const IdxT* ids, IdxT* mapped, int64_t n, int64_t entry_start, int world,
-                                       int rr)
+                                       int rr, int64_t rank_rows)
 {
-  // reference functions/map_indices_func.cu:26-45, quirk kept: entry_start is the caller's first row
+  // reference functions/map_indices_func.cu:26-45. rank_rows == 0 is the reference statement (the caller's first row
+  // plus the position inside a shard); rank_rows > 0 puts the OWNER's first row there (see backend.hpp)
   int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int64_t idx = static_cast<int64_t>(ids[i]);
-  int64_t t   = idx / rr;
-  int64_t off = idx % rr;
-  mapped[i]   = static_cast<IdxT>(entry_start + static_cast<int64_t>(rr) * (t / world) + off);
+  if (idx < 0) {  // "skip me" ids stay what they are
+    mapped[i] = ids[i];
+    return;
+  }
+  int64_t t    = idx / rr;
+  int64_t off  = idx % rr;
+  int64_t base = rank_rows > 0 ? (t % world) * rank_rows : entry_start;
+  mapped[i]    = static_cast<IdxT>(base + static_cast<int64_t>(rr) * (t / world) + off);
 }
 
 __global__ void fill_float_kernel(float* p, float v, int64_t n)
@@ -1362,7 +1368,7 @@ int hip_remap_self_order(int32_t* order, int64_t n, int64_t self_begin, int64_t 
 }
 
 int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n, int64_t entry_start,
-                        int world_size, int round_robin_size, void* stream_v)
+                        int world_size, int round_robin_size, int64_t rank_rows, void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (n == 0) return 0;
@@ -1370,11 +1376,11 @@ int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index
   if (index_dtype == WHOLEMEMORY_DT_INT)
     hipLaunchKernelGGL((round_robin_map_kernel<int32_t>), dim3(blocks), dim3(kBlock), 0, stream,
                        static_cast<const int32_t*>(ids), static_cast<int32_t*>(mapped), n, entry_start, world_size,
-                       round_robin_size);
+                       round_robin_size, rank_rows);
   else if (index_dtype == WHOLEMEMORY_DT_INT64)
     hipLaunchKernelGGL((round_robin_map_kernel<int64_t>), dim3(blocks), dim3(kBlock), 0, stream,
                        static_cast<const int64_t*>(ids), static_cast<int64_t*>(mapped), n, entry_start, world_size,
-                       round_robin_size);
+                       round_robin_size, rank_rows);
   else
     return -1;
   return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -168,21 +168,41 @@ void map_host_shared(wholememory_handle_* h)
   h->comm->allgather_host(name, names.data(), 64);
   memcpy(name, names.data(), 64);
   h->shm_bytes = std::max<size_t>(h->total_size, 16);
+  // Every step a single rank can fail on is followed by an exchange of success flags instead of a throw before the next
+  // collective (a rank that threw used to leave the others in a barrier for good), and the name is unlinked on every
+  // path once rank 0 has created it.
+  auto all_ok = [&](bool mine) {
+    char flag = mine ? 1 : 0;
+    std::vector<char> flags(static_cast<size_t>(W), 0);
+    h->comm->allgather_host(&flag, flags.data(), 1);   // doubles as the barrier between the steps
+    for (char f : flags)
+      if (f == 0) return false;
+    return true;
+  };
   int fd       = -1;
+  bool created = false;
   if (rank == 0) {
-    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, static_cast<off_t>(h->shm_bytes)) != 0) throw logic_error("shm_open/ftruncate failed");
+    fd      = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    created = fd >= 0;
+    if (created && ftruncate(fd, static_cast<off_t>(h->shm_bytes)) != 0) {
+      close(fd);
+      fd = -1;
+    }
   }
-  h->comm->barrier();
-  if (rank != 0) {
-    fd = shm_open(name, O_RDWR, 0600);
-    if (fd < 0) throw logic_error("shm_open (attach) failed");
+  if (!all_ok(rank != 0 || fd >= 0)) {
+    if (created) shm_unlink(name);
+    if (fd >= 0) close(fd);
+    throw logic_error("shm_open / ftruncate of the shared host segment failed on rank 0");
   }
-  void* p = mmap(nullptr, h->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (p == MAP_FAILED) throw logic_error("mmap of the shared segment failed");
-  h->comm->barrier();
+  if (rank != 0) fd = shm_open(name, O_RDWR, 0600);
+  void* p = fd >= 0 ? mmap(nullptr, h->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+  if (fd >= 0) close(fd);
+  const bool mapped = all_ok(p != MAP_FAILED);   // everybody has attached (or given up): the name can go
   if (rank == 0) shm_unlink(name);
+  if (!mapped) {
+    if (p != MAP_FAILED) munmap(p, h->shm_bytes);
+    throw logic_error("attaching the shared host segment failed on at least one rank");
+  }
   h->shm_host_ptr = p;
   void* dev       = nullptr;
   WM_BK(bk->host_register(p, h->shm_bytes, &dev));

@@ -955,6 +955,9 @@ wholememory_error_code_t wholememory_ext_bucket_ids_folded(const void* indices,
   ba.workspace     = ws.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, world_size)), WHOLEMEMORY_DT_INT8);
   int rc           = bk->bucket_ids(&ba, stream);
   if (rc == -1) return WHOLEMEMORY_INVALID_INPUT;
+  // the workspace goes back to the caller's allocator when `ws` leaves scope: it must not be in use any more (an env
+  // allocator is only required to be stream-ordered on ITS OWN current stream, see env_func_ptrs.h)
+  if (rc == 0 && bk->stream_sync(stream) != 0) rc = -2;
   return rc == 0 ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_CUDA_ERROR;
   WM_API_END
 }
@@ -970,7 +973,7 @@ wholememory_error_code_t wholememory_ext_round_robin_map(const void* ids,
 {
   WM_API_BEGIN
   if (round_robin_size <= 0 || world_size <= 0) return WHOLEMEMORY_INVALID_INPUT;
-  int rc = wm::backend()->round_robin_map(ids, mapped, index_dtype, n, entry_start, world_size, round_robin_size, stream);
+  int rc = wm::backend()->round_robin_map(ids, mapped, index_dtype, n, entry_start, world_size, round_robin_size, 0, stream);
   if (rc == -1) return WHOLEMEMORY_INVALID_INPUT;
   return rc == 0 ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_CUDA_ERROR;
   WM_API_END
