@@ -44,8 +44,13 @@ def parse():
     p.add_argument("--dist", choices=["uniform", "zipf", "zipf_clustered"], default="uniform")
     p.add_argument("--memory-type", default="", help="override: continuous|chunked|distributed")
     p.add_argument("--location", default="cuda", help="cuda|cpu (HOST-located table, config C1)")
-    p.add_argument("--op", choices=["gather", "scatter", "grad_apply"], default="gather",
-                   help="side measurements; the contract metric is gather")
+    p.add_argument("--op", choices=["gather", "scatter", "grad_apply", "sample_gather"], default="gather",
+                   help="side measurements; the contract metric is gather. sample_gather = BASELINE config 5: 2-hop "
+                        "neighbour sample + append_unique + feature gather on an ogbn-papers100M-shaped synthetic graph")
+    p.add_argument("--nodes", type=int, default=111_059_956, help="sample_gather: graph nodes (papers100M: 111,059,956)")
+    p.add_argument("--avg-degree", type=int, default=29, help="sample_gather: mean out-degree (papers100M, both directions: 29)")
+    p.add_argument("--seeds", type=int, default=1024, help="sample_gather: seed nodes per rank per step")
+    p.add_argument("--fanouts", default="30,30", help="sample_gather: fan-out per hop, seeds outwards")
     p.add_argument("--optimizer", default="sgd")
     p.add_argument("--dtype", choices=["f32", "f16", "bf16"], default="f32",
                    help="table dtype (side measurements; the contract metric is f32)")
@@ -192,6 +197,102 @@ def gpu_c1_host(wgth, comm):
             "workload": "C1 HOST chunked 10000000x64 fp32 table in pinned host memory, 1000000 uniform int64 ids, output in HBM"}
 
 
+def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
+    """BASELINE config 5 on synthetic data of the ogbn-papers100M shape: CSR (int64 row_ptr, int32 col) and a [nodes, 128] fp32
+    feature table in WholeMemory (CHUNKED on one GPU, DISTRIBUTED over several); one step = unweighted 2-hop sample from
+    `--seeds` seed nodes (GraphStructure.multilayer_sample_without_replacement: one-hop sample + append_unique per hop) +
+    gather of the features of every node of the sampled sub-graph."""
+    mt = a.memory_type or ("chunked" if world == 1 else "distributed")
+    nodes, avg = a.nodes, a.avg_degree
+    fanouts = [int(x) for x in a.fanouts.split(",")]
+    gen = torch.Generator(device="cuda").manual_seed(1)             # the same degrees on every rank
+    row = torch.zeros(nodes + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(torch.randint(0, 2 * avg + 1, (nodes,), device="cuda", generator=gen), 0, out=row[1:])
+    edges = int(row[-1])
+    wrow = wgth.create_wholememory_tensor(comm, mt, "cuda", [nodes + 1], torch.int64, [1])
+    wcol = wgth.create_wholememory_tensor(comm, mt, "cuda", [edges], torch.int32, [1])
+    lrow, rstart = wrow.get_local_tensor()
+    lrow.copy_(row[rstart:rstart + lrow.shape[0]])
+    del row
+    lcol, _ = wcol.get_local_tensor()
+    gen2 = torch.Generator(device="cuda").manual_seed(100 + rank)
+    for s0 in range(0, lcol.shape[0], 1 << 28):
+        e0 = min(lcol.shape[0], s0 + (1 << 28))
+        lcol[s0:e0] = torch.randint(0, nodes, (e0 - s0,), device="cuda", generator=gen2, dtype=torch.int32)
+    feat = wgth.create_embedding(comm, mt, "cuda", torch.float32, [nodes, a.dim])
+    lfeat, fstart = feat.get_embedding_tensor().get_local_tensor()
+    fill_table(lfeat, fstart)
+    g = wgth.GraphStructure()
+    g.set_csr_graph(wrow, wcol)
+    seeds = torch.randint(0, nodes, (a.seeds,), device="cuda", generator=gen2, dtype=torch.int32)
+    stat = {}
+
+    def step():
+        tg, ei, rp, ci = g.multilayer_sample_without_replacement(seeds, fanouts)
+        x = feat.gather(tg[0])
+        stat["nodes"], stat["edges"] = tg[0].numel(), sum(int(c.numel()) for c in ci)
+        stat["frontiers"] = [int(t.numel()) for t in tg]
+        return x, tg[0]
+
+    for _ in range(max(a.warmup, 2)):
+        x, ids = step()
+    barrier()
+    if not a.no_check:
+        assert torch.equal(x[:, 0], (ids.long() & 0xFFFFFF).to(torch.float32)), "gathered features differ from the closed form"
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    wall = time.perf_counter() - t0
+    dt = torch.tensor([wall], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
+    if launched:
+        torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+    wall = float(dt.item())
+    per = []
+    for _ in range(a.stability_steps):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t1) * 1e3)
+    ms = wall / a.steps * 1e3
+    row_bytes = a.dim * 4
+    # algorithmic HBM bytes of one step: per sampled centre one (row_ptr[c], row_ptr[c+1]) pair + its sampled col entries and
+    # outputs; append_unique sorts (id, position) pairs of targets + neighbours (3 radix passes, 12 B in + out each);
+    # the feature gather moves id + row in + row out per sub-graph node
+    centres = sum(stat["frontiers"][1:])
+    algo = centres * (16 + 8) + stat["edges"] * (4 + 4 + 4 + 4) + (centres + stat["edges"]) * 12 * 2 * 3 + \
+        stat["nodes"] * (8 + 2 * row_bytes)
+    res = {
+        "metric": "sample_gather_GBps_out (feature bytes of the sampled sub-graph per second; BASELINE config 5)",
+        "value": round(stat["nodes"] * row_bytes * world / (ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "sampled_edges_per_s": round(stat["edges"] * world / (ms * 1e-3), 0),
+        "subgraph_nodes_per_step": stat["nodes"], "sampled_edges_per_step": stat["edges"], "frontier_sizes": stat["frontiers"],
+        "config": {"workload": "C5 %s graph %d nodes / %d edges (int32 col) + %dx%d fp32 features, %d-hop %s unweighted sample "
+                               "from %d seeds per rank + append_unique + feature gather" % (
+                                   mt, nodes, edges, nodes, a.dim, len(fanouts), fanouts, a.seeds),
+                   "memory_type": mt, "seeds_per_rank": a.seeds, "fanouts": fanouts},
+        "roofline": {"bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(algo / (ms * 1e-3) / 8e12, 4), "traffic": None,
+                     "algorithmic_bytes_per_step": algo,
+                     "limited_by": "dependent-load latency (row_ptr -> col -> features) and launch / host-sync latency: a step is "
+                                   "%d small launches with a host round trip per hop to size the outputs, far from the HBM "
+                                   "roofline by construction; larger seed batches move it up (see --seeds)" % (8 * len(fanouts) + 2)},
+    }
+    if per:
+        per = np.array(per)
+        res["stability"] = {"steps": len(per), "min_ms": round(float(per.min()), 4), "median_ms": round(float(np.median(per)), 4),
+                            "p95_ms": round(float(np.percentile(per, 95)), 4), "max_ms": round(float(per.max()), 4),
+                            "note": "per-step host times (synchronised), separate from the timed region"}
+    wgth.destroy_embedding(feat)
+    wgth.destroy_wholememory_tensor(wrow)
+    wgth.destroy_wholememory_tensor(wcol)
+    return res
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -252,6 +353,22 @@ def main():
     transport, transport_ranks = comm.transport()
     if world > 1 and a.backend == "nccl":
         assert (transport, transport_ranks) == ("rccl", world), "expected %d RCCL ranks, have %s" % (world, (transport, transport_ranks))
+
+    if a.op == "sample_gather":
+        def barrier0():
+            torch.cuda.synchronize()
+            if launched:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+        res = run_sample_gather(a, wgth, comm, world, rank, launched, barrier0)
+        res["rccl_ranks"], res["transport"] = (transport_ranks if transport == "rccl" else 0), transport
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(res) + "\n").encode())
+        if launched:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
 
     rows_per_gpu = a.rows or (100_000_000 if world == 1 else 125_000_000)
     total_rows = rows_per_gpu * world

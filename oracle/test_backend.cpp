@@ -190,7 +190,10 @@ int t_dedup(const void* ids, wholememory_dtype_t dt, int64_t n, int64_t, void* u
 {
   std::vector<int32_t> ord(n);
   for (int64_t i = 0; i < n; i++) ord[i] = static_cast<int32_t>(i);
-  std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return idx_at(ids, dt, x) < idx_at(ids, dt, y); });
+  // the kernels' order: the ids' two's-complement bits as UNSIGNED keys — negative ("skip me") ids after every valid id
+  std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
+    return static_cast<uint64_t>(idx_at(ids, dt, x)) < static_cast<uint64_t>(idx_at(ids, dt, y));
+  });
   int64_t nu = 0;
   for (int64_t i = 0; i < n; i++) {
     order[i] = ord[i];
@@ -304,12 +307,38 @@ int t_env_test(const void* in, void* out, wholememory_dtype_t dt, int64_t dim, i
   }
 }
 
+size_t t_dup_ws(int64_t) { return 64; }
+int t_dup_estimate(const void* ids, wholememory_dtype_t dt, int64_t n, void*, int64_t* permille, void*)
+{
+  // exact duplicate share of the whole batch (the product samples and estimates; only the decision it feeds must agree
+  // between ranks, and that is taken from exchanged values)
+  std::vector<int64_t> v(static_cast<size_t>(n));
+  for (int64_t i = 0; i < n; i++) v[i] = idx_at(ids, dt, i);
+  std::sort(v.begin(), v.end());
+  const int64_t distinct = static_cast<int64_t>(std::unique(v.begin(), v.end()) - v.begin());
+  *permille              = n > 0 ? (1000 * (n - distinct) + n / 2) / n : 0;
+  return 0;
+}
+int t_sorted_counts(const void* ids, wholememory_dtype_t dt, const int64_t* n_dev, int64_t, const uint64_t* off, int world,
+                    int64_t* counts, void*)
+{
+  for (int r = 0; r < world; r++) counts[r] = 0;
+  for (int64_t i = 0; i < *n_dev; i++) {
+    const int64_t id = idx_at(ids, dt, i);
+    if (id < 0) continue;
+    for (int r = 0; r < world; r++)
+      if (static_cast<uint64_t>(id) >= off[r] && static_cast<uint64_t>(id) < off[r + 1]) counts[r]++;
+  }
+  return 0;
+}
+
 const wm_device_backend kTestBackend = {
   "oracle-test-backend (CPU, tests only)",
   t_device_count, t_malloc, t_free, t_malloc, t_free, t_memcpy, t_memset, t_sync,
   t_stream_create, t_noop1, t_event_create, t_noop1, t_noop2, t_noop2,
   t_ipc_get, t_ipc_open, t_ipc_close, t_host_register, t_host_unregister,
   t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_long_ws, t_run_inverse, t_remap_self, t_rr, t_fill,
+  t_dup_ws, t_dup_estimate, t_sorted_counts,
   // graph ops: not provided by the CPU backend
   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
   t_env_test,

@@ -123,6 +123,43 @@ def scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, e
     wgth.destroy_wholememory_tensor(wm)
 
 
+def scenario_gather_skewed(comm, rank, world, idt, entries=None):
+    """A batch dominated by a few hot rows (Zipf): with WM_GATHER_DEDUP unset the ranks estimate the duplicate share, agree
+    through the counts exchange and take the de-duplicating route (distinct ids sorted, owner segments by binary search,
+    rows received in place, local expansion); results are those of the plain route."""
+    n_rows, dim = 3001, 24
+    wm = wgth.create_wholememory_tensor(comm, "distributed", "cuda", [n_rows, dim], torch.float32, [dim, 1], entries)
+    full = np.random.default_rng(12).standard_normal((n_rows, dim)).astype(np.float32)
+    tab = oracle.ShardedTable.from_full(full, world, entries)
+    local, start = wm.get_local_tensor(host_view=False)
+    if local.shape[0]:
+        local.copy_(dev(torch.from_numpy(full[start:start + local.shape[0]])))
+    if HIP_MODE:
+        torch.cuda.synchronize()
+    comm.barrier()
+    rank_idx = []
+    for r in range(world):
+        g = np.random.default_rng(300 + r)
+        n = 0 if (r == 1 and world > 2) else 4000 + 13 * r          # one rank may ask for nothing
+        k = g.zipf(1.2, n).astype(np.uint64)
+        ix = ((k * np.uint64(2654435761)) % np.uint64(n_rows)).astype(idt)
+        if n:
+            ix[::31] = -1
+        rank_idx.append(ix)
+    exp = oracle.distributed_gather(tab, rank_idx, np.float32, out_init=[np.full((len(ix), dim), 7, np.float32) for ix in rank_idx])
+    from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream
+    for _ in range(2):
+        out = dev(torch.full((len(rank_idx[rank]), dim), 7.0))
+        wi, wo = wrap_torch_tensor(dev(torch.from_numpy(rank_idx[rank]))), wrap_torch_tensor(out)
+        wmb.check(wmb.lib().wholememory_gather(wm.wmb_tensor, wi.handle, wo.handle, get_wholegraph_env_fns(),
+                                               C.c_void_p(get_stream()), -1))
+        if HIP_MODE:
+            torch.cuda.synchronize()
+        assert host(out).numpy().tobytes() == exp[rank].tobytes(), "skewed gather mismatch on rank %d" % rank
+    comm.barrier()
+    wgth.destroy_wholememory_tensor(wm)
+
+
 def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries, mt="distributed"):
     n_rows, dim, steps = 1201, 13, 3
     emb = wgth.create_embedding(comm, mt, "cuda", torch.float32, [n_rows, dim],
@@ -482,6 +519,8 @@ def rccl_scenarios(comm, rank, world):
     os.environ["WM_GATHER_DEDUP"] = "2"
     scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)
     del os.environ["WM_GATHER_DEDUP"]
+    scenario_gather_skewed(comm, rank, world, np.int64)     # automatic decision (duplicate estimate through the exchange)
+    scenario_gather_skewed(comm, rank, world, np.int32)
     scenario_gather_scatter(comm, rank, world, "distributed", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
     for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}), ("adagrad", {}),
                          ("rmsprop", {"alpha": 0.95})]:
@@ -540,10 +579,18 @@ def main():
     ent[0] += 997 - sum(ent)
     ent2 = [2 * e for e in ent]
     ent2[0] += 2003 - sum(ent2)
+    ent3 = [3 * e for e in ent]
+    ent3[0] += 3001 - sum(ent3)
     scenario_gather_scatter(comm, rank, world, "distributed", 997, 8, np.int64, np.int32, np.int64, ent)
     # (4) trailing ranks empty under the equal plan: N < W * ceil(N / W) only when W > N … use tiny N
     if world >= 3:
         scenario_gather_scatter(comm, rank, world, "distributed", 4, 4, np.float32, np.float32, np.int64, None)
+    # (4') skewed batches: the automatic de-duplication decision (and the same batch with the decision forced off)
+    scenario_gather_skewed(comm, rank, world, np.int64)
+    scenario_gather_skewed(comm, rank, world, np.int32, ent3 if world > 1 else None)
+    os.environ["WM_GATHER_DEDUP"] = "0"
+    scenario_gather_skewed(comm, rank, world, np.int64)
+    del os.environ["WM_GATHER_DEDUP"]
     # (4a) the same gathers with request de-duplication before the exchange (WM_GATHER_DEDUP=1)
     os.environ["WM_GATHER_DEDUP"] = "1"
     scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)

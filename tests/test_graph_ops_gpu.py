@@ -244,8 +244,9 @@ def test_add_csr_self_loop_parity(gpu_env, n_nodes, max_degree):
 
 
 def test_multilayer_sample(gpu_env):
-    """3-hop [30, 30, 30]-style sampling (BASELINE config 5 sampler) = chained one-hop + append_unique; checked
-    hop by hop against the oracle driven with the same seeds."""
+    """3-hop sampling = chained one-hop + append_unique with the samplers' default (random) seeds: structural properties only
+    (frontiers nest, ids are distinct, per-centre counts = min(degree, fan-out), every sampled edge exists). The same chain
+    with fixed seeds is compared with the oracle bit for bit in tests/test_c5_flow_gpu.py."""
     import torch
     import wholegraph_amd.torch as wgth
     row_ptr, col = _graph(np.int64)

@@ -167,7 +167,8 @@ struct wm_device_backend {
   int (*scatter_rows)(const wm_rows_args* a, void* stream);
   size_t (*bucket_workspace_bytes)(int64_t n, int world_size);
   int (*bucket_ids)(const wm_bucket_args* a, void* stream);
-  // sort received ids as SIGNED keys (stable), emit unique ids, run starts and the sorted order.
+  // stable sort of the ids by their two's-complement bits as UNSIGNED keys (valid ids ascending, negative ids after all
+  // of them), emit unique ids, run starts and the sorted order. key_upper_bound > 0: every id is in [0, bound).
   // n_unique_out is a device int64. workspace from sort_workspace_bytes(n).
   size_t (*dedup_workspace_bytes)(int64_t n, wholememory_dtype_t index_dtype);
   int (*dedup_ids)(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound,
@@ -191,6 +192,17 @@ struct wm_device_backend {
   int (*round_robin_map)(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n,
                          int64_t entry_start, int world_size, int round_robin_size, int64_t rank_rows, void* stream);
   int (*fill_float)(float* p, float value, int64_t count, void* stream);
+  // Duplicate estimate of a batch of lookup ids (the requester-side decision whether to de-duplicate before the exchange):
+  // every k-th id is hashed into a bitmap; *permille_dev = 1000 * (1 - distinct / sampled) of the SAMPLE, by linear
+  // counting. A heuristic: backends need not agree on the value. workspace from dup_estimate_workspace_bytes(n).
+  size_t (*dup_estimate_workspace_bytes)(int64_t n);
+  int (*dup_estimate)(const void* ids, wholememory_dtype_t index_dtype, int64_t n, void* workspace, int64_t* permille_dev,
+                      void* stream);
+  // per-owner counts of ids that are already SORTED (as unsigned keys, the order dedup_ids leaves them in; negative ids
+  // come last and are not counted): counts[r] = #{ids in [entry_offsets[r], entry_offsets[r + 1])}. The number of ids is
+  // read from *n_dev (<= n_upper).
+  int (*sorted_owner_counts)(const void* sorted_ids, wholememory_dtype_t index_dtype, const int64_t* n_dev, int64_t n_upper,
+                             const uint64_t* entry_offsets, int world_size, int64_t* counts, void* stream);
   // ---- graph ops (kernels/graph.hip); nullptr in a backend that does not provide them ----
   // counts[i] = min(degree(center i), max_sample) for i < n, counts[n] = 0
   // (row bounds from row_pairs when it is not nullptr, else through row_gref)

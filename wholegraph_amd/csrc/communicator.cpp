@@ -107,6 +107,12 @@ class rccl_provider : public collective_provider {
     memcpy(recv, static_cast<char*>(host_stage_) + bytes, bytes * size_);
   }
 
+  bool allgather_device(const void* send, void* recv, size_t bytes, void* stream_v) override
+  {
+    WM_NCCL_TRY(ncclAllGather(send, recv, bytes, ncclInt8, comm_, static_cast<hipStream_t>(stream_v)));
+    return true;
+  }
+
   void alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp, void* recv,
                         const size_t* recv_bytes, const size_t* recv_disp, void* stream_v) override
   {
@@ -349,21 +355,49 @@ void wholememory_comm_::allgather_host(const void* send, void* recv, size_t byte
   transport->allgather_host(send, recv, bytes);
 }
 
-void wholememory_comm_::alltoall_host_i64(const int64_t* send, int64_t* recv, int64_t* between_ranks)
+void wholememory_comm_::alltoall_host_i64(const int64_t* send, int64_t* recv, int64_t* between_ranks, int64_t* extra)
 {
   if (between_ranks) *between_ranks = 0;
   if (!transport) {
     recv[0] = send[0];
-    return;
+    return;  // extra[0] already holds this rank's value
   }
-  // every rank learns the whole W x W matrix in one collective and reads its column
-  std::vector<int64_t> all(static_cast<size_t>(world_size) * world_size);
-  transport->allgather_host(send, all.data(), sizeof(int64_t) * world_size);
-  for (int r = 0; r < world_size; r++) recv[r] = all[static_cast<size_t>(r) * world_size + world_rank];
+  // every rank learns the whole W x (W + 1) matrix in one collective and reads its column
+  const size_t W = static_cast<size_t>(world_size), L = W + 1;
+  std::vector<int64_t> mine(L), all(W * L);
+  for (size_t r = 0; r < W; r++) mine[r] = send[r];
+  mine[W] = extra != nullptr ? extra[0] : 0;
+  transport->allgather_host(mine.data(), all.data(), sizeof(int64_t) * L);
+  for (size_t r = 0; r < W; r++) {
+    recv[r] = all[r * L + static_cast<size_t>(world_rank)];
+    if (extra != nullptr) extra[r] = all[r * L + W];
+  }
   if (between_ranks)
-    for (int s = 0; s < world_size; s++)
-      for (int r = 0; r < world_size; r++)
-        if (s != r) *between_ranks += all[static_cast<size_t>(s) * world_size + r];
+    for (size_t s = 0; s < W; s++)
+      for (size_t r = 0; r < W; r++)
+        if (s != r) *between_ranks += all[s * L + r];
+}
+
+bool wholememory_comm_::alltoall_counts_device(const int64_t* dev_counts, int64_t* dev_matrix, int64_t* pinned_matrix,
+                                               void* stream, int64_t* send, int64_t* recv, int64_t* between_ranks,
+                                               int64_t* extra)
+{
+  if (!transport) return false;
+  const size_t W = static_cast<size_t>(world_size), L = W + 1;
+  if (!transport->allgather_device(dev_counts, dev_matrix, sizeof(int64_t) * L, stream)) return false;
+  if (wm::backend()->memcpy_async(pinned_matrix, dev_matrix, sizeof(int64_t) * W * L, stream) != 0 ||
+      wm::backend()->stream_sync(stream) != 0)
+    throw wm::hip_error("counts exchange: copy of the count matrix failed");
+  if (between_ranks) *between_ranks = 0;
+  for (size_t r = 0; r < W; r++) {
+    send[r] = pinned_matrix[static_cast<size_t>(world_rank) * L + r];
+    recv[r] = pinned_matrix[r * L + static_cast<size_t>(world_rank)];
+    if (extra != nullptr) extra[r] = pinned_matrix[r * L + W];
+    if (between_ranks)
+      for (size_t q = 0; q < W; q++)
+        if (q != r) *between_ranks += pinned_matrix[r * L + q];
+  }
+  return true;
 }
 
 void wholememory_comm_::alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp,

@@ -23,6 +23,9 @@ class collective_provider {
   virtual void barrier() = 0;
   // host buffers: recv[r*bytes..] = rank r's send
   virtual void allgather_host(const void* send, void* recv, size_t bytes) = 0;
+  // the same on DEVICE buffers, enqueued on `stream` (no host round trip); false = this provider cannot (the caller
+  // then goes through allgather_host)
+  virtual bool allgather_device(const void* /*send*/, void* /*recv*/, size_t /*bytes*/, void* /*stream*/) { return false; }
   // device buffers, byte counts/displacements indexed by peer rank; enqueued on `stream`
   virtual void alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp, void* recv,
                                 const size_t* recv_bytes, const size_t* recv_disp, void* stream) = 0;
@@ -66,7 +69,17 @@ struct wholememory_comm_ {
   // counts exchange: recv[r] = what rank r sends to me (reference host_alltoall, nccl_comms.cpp:383-407)
   // between_ranks (optional): sum of the off-diagonal of the whole matrix — the same number on every rank, which makes it
   // a safe input for decisions all ranks must take alike
-  void alltoall_host_i64(const int64_t* send, int64_t* recv, int64_t* between_ranks = nullptr);
+  // `extra` (optional, in: this rank's value, out: [world_size] every rank's value) rides along with the counts: one more
+  // int64 per rank in the same collective (the duplicate estimate behind the de-duplication decision)
+  void alltoall_host_i64(const int64_t* send, int64_t* recv, int64_t* between_ranks = nullptr, int64_t* extra = nullptr);
+  // The same exchange starting from counts that are still on the DEVICE, with ONE host synchronisation in total: the
+  // W x W matrix is all-gathered on `stream` by the transport, copied to `pinned_matrix` (W * W int64, pinned) and the
+  // stream is drained once. send / recv receive this rank's row / column. Returns false when the transport has no
+  // device all-gather (external providers): the caller then copies its counts to the host and uses alltoall_host_i64.
+  // dev_counts holds W + 1 values (the counts and one extra value), the matrices W * (W + 1); `extra` receives every
+  // rank's extra value ([world_size], may be nullptr)
+  bool alltoall_counts_device(const int64_t* dev_counts, int64_t* dev_matrix, int64_t* pinned_matrix, void* stream,
+                              int64_t* send, int64_t* recv, int64_t* between_ranks, int64_t* extra = nullptr);
   void alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp, void* recv,
                         const size_t* recv_bytes, const size_t* recv_disp, void* stream);
 };

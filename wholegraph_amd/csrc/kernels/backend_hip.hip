@@ -23,6 +23,11 @@ int hip_remap_self_order(int32_t* order, int64_t n, int64_t self_begin, int64_t 
 int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index_dtype, int64_t n, int64_t entry_start,
                         int world_size, int round_robin_size, int64_t rank_rows, void* stream);
 int hip_fill_float(float* p, float value, int64_t count, void* stream);
+size_t hip_dup_estimate_workspace_bytes(int64_t n);
+int hip_dup_estimate(const void* ids, wholememory_dtype_t index_dtype, int64_t n, void* workspace, int64_t* permille_dev,
+                     void* stream);
+int hip_sorted_owner_counts(const void* sorted_ids, wholememory_dtype_t index_dtype, const int64_t* n_dev, int64_t n_upper,
+                            const uint64_t* entry_offsets, int world_size, int64_t* counts, void* stream);
 int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const int64_t* row_pairs, const void* centers,
                       wholememory_dtype_t id_dtype, int n, int max_sample, int* counts, void* stream);
 int hip_sample_pair_ids(const void* centers, wholememory_dtype_t id_dtype, int n, int64_t* ids, void* stream);
@@ -149,6 +154,9 @@ const wm_device_backend kHipBackend = {
   hip_remap_self_order,
   hip_round_robin_map,
   hip_fill_float,
+  hip_dup_estimate_workspace_bytes,
+  hip_dup_estimate,
+  hip_sorted_owner_counts,
   hip_sample_counts,
   hip_sample_pair_ids,
   hip_scan_i32_ws_bytes,

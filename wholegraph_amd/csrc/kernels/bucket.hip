@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "../backend.hpp"
 
@@ -238,6 +239,123 @@ int run_bucket(const wm_bucket_args* a, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ---- duplicate estimate (linear counting over a sample) ---------------------------------------------------------
+// One BYTE per hash slot, set with a plain store: a hot id (Zipf: one id is 5 % of the batch) hits the same slot tens of
+// thousands of times, and atomics to one word serialise (the bitmap + atomicOr version took 0.48 ms on the skewed batch,
+// 25 us on the uniform one); racing plain stores of the same value just merge.
+constexpr int kDupSlots = 1 << 24;          // 16 MiB of flags: stays in the Infinity Cache; <= ~1 M sampled ids (6 % full)
+constexpr int64_t kDupSampleTarget = 1 << 19;
+
+__device__ __forceinline__ uint32_t mix64(uint64_t x)
+{  // murmur3 finaliser
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return static_cast<uint32_t>(x);
+}
+
+template <typename IdxT>
+__global__ void dup_sample_kernel(const IdxT* ids, int64_t n, int64_t step, int64_t sampled, uint8_t* flags)
+{
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= sampled) return;
+  const int64_t id = static_cast<int64_t>(ids[min(j * step, n - 1)]);
+  flags[mix64(static_cast<uint64_t>(id)) & (kDupSlots - 1)] = 1;
+}
+
+__global__ __launch_bounds__(1024) void dup_count_kernel(const uint32_t* flag_words, int64_t sampled, unsigned long long* set_slots,
+                                                         unsigned int* blocks_done, int64_t* permille)
+{
+  __shared__ int s_sum[16];
+  int local = 0;  // flags are 0 / 1 bytes: the population count of a word is the number of set slots in it
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < kDupSlots / 4; i += gridDim.x * 1024) local += __popc(flag_words[i]);
+  for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < 16; w++) total += s_sum[w];
+    atomicAdd(set_slots, static_cast<unsigned long long>(total));
+    __threadfence();
+    if (atomicAdd(blocks_done, 1u) == gridDim.x - 1) {  // last block: linear counting, distinct ~ -M ln(1 - set / M)
+      const double M        = static_cast<double>(kDupSlots);
+      const double set      = static_cast<double>(atomicAdd(set_slots, 0ull));
+      const double distinct = set >= M ? M : -M * log(1.0 - set / M);
+      double dup            = 1.0 - distinct / static_cast<double>(sampled);
+      dup                   = dup < 0.0 ? 0.0 : dup;
+      *permille             = static_cast<int64_t>(dup * 1000.0 + 0.5);
+    }
+  }
+}
+
+template <typename IdxT>
+__global__ void sorted_owner_counts_kernel(const IdxT* sorted, const int64_t* n_dev, const uint64_t* entry_offsets, int world,
+                                           int64_t* counts)
+{
+  // thread r: lower bounds of entry_offsets[r] and entry_offsets[r + 1] in the ids, compared as UNSIGNED keys (the order
+  // they were sorted in; a negative id is a huge key and stays outside every range)
+  using UT = typename std::make_unsigned<IdxT>::type;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= world) return;
+  const int64_t n = *n_dev;
+  auto lower      = [&](uint64_t key) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (static_cast<uint64_t>(static_cast<UT>(sorted[mid])) < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  counts[r] = lower(entry_offsets[r + 1]) - lower(entry_offsets[r]);
+}
+
+}  // namespace
+
+size_t hip_dup_estimate_workspace_bytes(int64_t) { return static_cast<size_t>(kDupSlots) + 64; }
+
+int hip_dup_estimate(const void* ids, wholememory_dtype_t index_dtype, int64_t n, void* workspace, int64_t* permille_dev,
+                     void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (index_dtype != WHOLEMEMORY_DT_INT && index_dtype != WHOLEMEMORY_DT_INT64) return -1;
+  if (n < 2) return hipMemsetAsync(permille_dev, 0, sizeof(int64_t), stream) == hipSuccess ? 0 : -2;
+  auto* flags       = static_cast<uint8_t*>(workspace);
+  auto* set_slots   = reinterpret_cast<unsigned long long*>(flags + kDupSlots);
+  auto* blocks_done = reinterpret_cast<unsigned int*>(set_slots + 1);
+  if (hipMemsetAsync(workspace, 0, static_cast<size_t>(kDupSlots) + 64, stream) != hipSuccess) return -2;
+  const int64_t step    = std::max<int64_t>(1, n / kDupSampleTarget);
+  const int64_t sampled = (n + step - 1) / step;
+  const int blocks      = static_cast<int>((sampled + 255) / 256);
+  if (index_dtype == WHOLEMEMORY_DT_INT)
+    hipLaunchKernelGGL((dup_sample_kernel<int32_t>), dim3(blocks), dim3(256), 0, stream, static_cast<const int32_t*>(ids), n, step,
+                       sampled, flags);
+  else
+    hipLaunchKernelGGL((dup_sample_kernel<int64_t>), dim3(blocks), dim3(256), 0, stream, static_cast<const int64_t*>(ids), n, step,
+                       sampled, flags);
+  hipLaunchKernelGGL(dup_count_kernel, dim3(64), dim3(1024), 0, stream, reinterpret_cast<const uint32_t*>(flags), sampled,
+                     set_slots, blocks_done, permille_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int hip_sorted_owner_counts(const void* sorted_ids, wholememory_dtype_t index_dtype, const int64_t* n_dev, int64_t,
+                            const uint64_t* entry_offsets, int world_size, int64_t* counts, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const int blocks   = (world_size + 63) / 64;
+  if (index_dtype == WHOLEMEMORY_DT_INT)
+    hipLaunchKernelGGL((sorted_owner_counts_kernel<int32_t>), dim3(blocks), dim3(64), 0, stream,
+                       static_cast<const int32_t*>(sorted_ids), n_dev, entry_offsets, world_size, counts);
+  else if (index_dtype == WHOLEMEMORY_DT_INT64)
+    hipLaunchKernelGGL((sorted_owner_counts_kernel<int64_t>), dim3(blocks), dim3(64), 0, stream,
+                       static_cast<const int64_t*>(sorted_ids), n_dev, entry_offsets, world_size, counts);
+  else
+    return -1;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+namespace {
 }  // namespace
 
 size_t hip_bucket_workspace_bytes(int64_t n, int world_size)

