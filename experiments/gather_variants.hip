@@ -1,5 +1,5 @@
 // Experiment harness (not product code): variants of the 512 B-row gather kernel, timed with HIP events.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 experiments/gather_variants.hip -o experiments/gather_variants
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -ffp-contract=off experiments/gather_variants.hip wholegraph_amd/csrc/tensor_description.cpp -o experiments/gather_variants
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,0 +1,57 @@
+#!/bin/bash
+# Round profiles for profiles/: run on the GPU box through `gpurun -- 'bash scripts/collect_profiles.sh r02'`.
+#  1 the contract bench line (default flags) + rocprofv3 --kernel-trace --stats of the same command
+#  2 HBM traffic of the gather kernel: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (kernel trace only), plus the same
+#    two passes over a streaming-copy kernel of known size for calibration -> profiles/pmc_traffic.json (scripts/collect_traffic.py)
+#  3 side ops: scatter, gradient apply (uniform / zipf, SGD and LazyAdam): bench lines + kernel stats; PMC of the step kernel
+#  4 C5 (sample_gather) kernel stats, the C++ bench tool
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd $R
+python bench.py > $OUT/${TAG}_n1_bench.json 2> $OUT/${TAG}_n1_bench.err
+cut -c1-400 $OUT/${TAG}_n1_bench.json
+stats() {  # stats <name> <bench args...>: bench line + kernel stats of the same command
+  local name=$1; shift
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$name && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python $R/bench.py "$@" > $OUT/${TAG}_${name}_bench_under_rocprof.json 2>/dev/null )
+  cp $(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
+  head -4 $OUT/${TAG}_${name}_kernel_stats.csv | cut -c1-160
+}
+stats n1_bench --no-cpu-baseline
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_$c && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --no-cpu-baseline --steps 10 --warmup 2 --stability-steps 0 > /dev/null 2>&1 )
+  cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $OUT/${TAG}_bench_${c}_counter_collection.csv
+  if [ -x $R/experiments/gather_variants ]; then
+    ( cd /tmp && rm -rf /tmp/cal_$c && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/cal_$c -- $R/experiments/gather_variants 100000000 10000000 3 pmc > /dev/null 2>&1 )
+    f=$(find /tmp/cal_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_calib_${c}_counter_collection.csv
+  fi
+done
+python scripts/collect_traffic.py $OUT $TAG && cat $OUT/pmc_traffic.json | head -30
+python bench.py --op scatter --no-cpu-baseline > $OUT/${TAG}_scatter_bench.json 2>/dev/null
+stats scatter --op scatter --no-cpu-baseline --steps 50 --stability-steps 0
+for d in uniform zipf; do for o in sgd adam; do
+  python bench.py --op grad_apply --dist $d --optimizer $o --no-cpu-baseline > $OUT/${TAG}_grad_apply_${o}_${d}_bench.json 2>/dev/null
+  cut -c1-200 $OUT/${TAG}_grad_apply_${o}_${d}_bench.json | head -1
+done; done
+stats grad_apply --op grad_apply --no-cpu-baseline --steps 30 --stability-steps 0
+stats grad_apply_zipf --op grad_apply --dist zipf --no-cpu-baseline --steps 30 --stability-steps 0
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmcg_$c && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcg_$c -- python $R/bench.py --op grad_apply --no-cpu-baseline --steps 5 --warmup 2 --stability-steps 0 > /dev/null 2>&1 )
+  python - $(find /tmp/pmcg_$c -name "*counter_collection.csv" | head -1) $c >> $OUT/${TAG}_grad_apply_pmc_per_kernel.txt <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"][:90]
+    agg[k][0] += 1
+    agg[k][1] += float(r["Counter_Value"])
+print("==", sys.argv[2], "(KiB per launch; FETCH_SIZE counts half of the bytes of 16 B/lane reads on gfx950)")
+for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
+    print("%-92s launches %4d  KiB/launch %14.1f" % (k, n, v / n))
+PY
+done
+cat $OUT/${TAG}_grad_apply_pmc_per_kernel.txt | head -24
+python bench.py --op sample_gather --steps 50 --stability-steps 50 > $OUT/${TAG}_sample_gather_bench.json 2>/dev/null
+stats sample_gather --op sample_gather --steps 50 --stability-steps 0
+[ -x tools/gather_scatter_bench ] && tools/gather_scatter_bench > $OUT/${TAG}_cpp_bench.txt 2>&1; tail -6 $OUT/${TAG}_cpp_bench.txt
+ls $OUT
