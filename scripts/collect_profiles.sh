@@ -53,5 +53,11 @@ done
 cat $OUT/${TAG}_grad_apply_pmc_per_kernel.txt | head -24
 python bench.py --op sample_gather --steps 50 --stability-steps 50 > $OUT/${TAG}_sample_gather_bench.json 2>/dev/null
 stats sample_gather --op sample_gather --steps 50 --stability-steps 0
-[ -x tools/gather_scatter_bench ] && tools/gather_scatter_bench > $OUT/${TAG}_cpp_bench.txt 2>&1; tail -6 $OUT/${TAG}_cpp_bench.txt
+if [ -x tools/gather_scatter_bench ]; then
+  for f in gather scatter; do
+    echo "\$ tools/gather_scatter_bench -t chunked -l device -e 51200000000 -g 5120000000 -d 128 -c 20 -f $f" >> $OUT/${TAG}_cpp_bench.txt
+    tools/gather_scatter_bench -t chunked -l device -e 51200000000 -g 5120000000 -d 128 -c 20 -f $f >> $OUT/${TAG}_cpp_bench.txt 2>&1
+  done
+  tail -8 $OUT/${TAG}_cpp_bench.txt
+fi
 ls $OUT

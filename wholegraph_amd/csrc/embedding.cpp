@@ -185,6 +185,59 @@ struct self_rows_ref {
   int64_t stride      = 0;
 };
 
+// sorted view of a batch of received ids (unique ids, run starts, sorted order): the scratch lives as long as the object
+struct dedup_result {
+  explicit dedup_result(wholememory_env_func_t* env) : unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env) {}
+  void run(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, void* stream)
+  {
+    const auto* bk = backend();
+    d_unique  = unique_ids.device(n, index_dtype);
+    d_starts  = static_cast<int32_t*>(run_starts.device(n + 1, WHOLEMEMORY_DT_INT));
+    d_order   = static_cast<int32_t*>(order.device(n, WHOLEMEMORY_DT_INT));
+    d_nunique = static_cast<int64_t*>(n_unique.device(1, WHOLEMEMORY_DT_INT64));
+    void* d_ws = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n, index_dtype)), WHOLEMEMORY_DT_INT8);
+    int rc = bk->dedup_ids(ids, index_dtype, n, key_upper_bound, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
+    if (rc == -1) throw logic_error("dedup_ids: unsupported index dtype or more than 2^31 received ids");
+    if (rc != 0) throw hip_error("dedup_ids failed");
+  }
+  temp_mem unique_ids, run_starts, order, n_unique, ws;
+  void* d_unique     = nullptr;
+  int32_t* d_starts  = nullptr;
+  int32_t* d_order   = nullptr;
+  int64_t* d_nunique = nullptr;
+};
+
+// the fused duplicate-sum + optimizer kernel over an already sorted batch
+void step_sorted(dedup_result& r, wholememory_dtype_t index_dtype, int64_t n_recv, const void* recv_grads, int64_t grad_stride,
+                 wm_optimizer_args* oa, wholememory_env_func_t* env, void* stream, int64_t* n_unique_host, void* rows_ready,
+                 const self_rows_ref* self)
+{
+  const auto* bk = backend();
+  temp_mem host_n(env), long_ws(env);
+  oa->ids         = r.d_unique;
+  oa->index_dtype = index_dtype;
+  oa->run_starts  = r.d_starts;
+  oa->order       = r.d_order;
+  oa->grads       = recv_grads;
+  oa->grad_stride = grad_stride;
+  if (self != nullptr && self->count > 0) {
+    WM_BK(bk->remap_self_order(r.d_order, n_recv, self->begin, self->count, self->rows, stream));
+    oa->self_grads       = self->grads;
+    oa->self_grad_stride = self->stride;
+  }
+  oa->count       = n_recv;  // upper bound; the kernel reads the true count from d_nunique
+  oa->long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n_recv)), WHOLEMEMORY_DT_INT8);
+  if (rows_ready != nullptr) WM_BK(bk->stream_wait_event(stream, rows_ready));
+  int rc = bk->optimizer_step(oa, r.d_nunique, stream);
+  if (rc != 0) throw hip_error("optimizer_step failed");
+  if (n_unique_host != nullptr) {
+    auto* h = static_cast<int64_t*>(host_n.pinned(1, WHOLEMEMORY_DT_INT64));
+    WM_BK(bk->memcpy_async(h, r.d_nunique, sizeof(int64_t), stream));
+    WM_BK(bk->stream_sync(stream));
+    *n_unique_host = *h;
+  }
+}
+
 void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64_t n_recv, const void* recv_grads,
                     int64_t grad_stride, wm_optimizer_args* oa, int64_t key_upper_bound, wholememory_env_func_t* env,
                     void* stream, int64_t* n_unique_host, void* rows_ready = nullptr, const self_rows_ref* self = nullptr)
@@ -195,37 +248,9 @@ void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64
     if (n_unique_host) *n_unique_host = 0;
     return;
   }
-  temp_mem unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env), host_n(env), long_ws(env);
-  void* d_unique  = unique_ids.device(n_recv, index_dtype);
-  auto* d_starts  = static_cast<int32_t*>(run_starts.device(n_recv + 1, WHOLEMEMORY_DT_INT));
-  auto* d_order   = static_cast<int32_t*>(order.device(n_recv, WHOLEMEMORY_DT_INT));
-  auto* d_nunique = static_cast<int64_t*>(n_unique.device(1, WHOLEMEMORY_DT_INT64));
-  void* d_ws      = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n_recv, index_dtype)), WHOLEMEMORY_DT_INT8);
-  int rc = bk->dedup_ids(recv_ids, index_dtype, n_recv, key_upper_bound, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
-  if (rc == -1) throw logic_error("dedup_ids: unsupported index dtype or more than 2^31 received ids");
-  if (rc != 0) throw hip_error("dedup_ids failed");
-  oa->ids         = d_unique;
-  oa->index_dtype = index_dtype;
-  oa->run_starts  = d_starts;
-  oa->order       = d_order;
-  oa->grads       = recv_grads;
-  oa->grad_stride = grad_stride;
-  if (self != nullptr && self->count > 0) {
-    WM_BK(bk->remap_self_order(d_order, n_recv, self->begin, self->count, self->rows, stream));
-    oa->self_grads       = self->grads;
-    oa->self_grad_stride = self->stride;
-  }
-  oa->count       = n_recv;  // upper bound; the kernel reads the true count from d_nunique
-  oa->long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n_recv)), WHOLEMEMORY_DT_INT8);
-  if (rows_ready != nullptr) WM_BK(bk->stream_wait_event(stream, rows_ready));
-  rc              = bk->optimizer_step(oa, d_nunique, stream);
-  if (rc != 0) throw hip_error("optimizer_step failed");
-  if (n_unique_host != nullptr) {
-    auto* h = static_cast<int64_t*>(host_n.pinned(1, WHOLEMEMORY_DT_INT64));
-    WM_BK(bk->memcpy_async(h, d_nunique, sizeof(int64_t), stream));
-    WM_BK(bk->stream_sync(stream));
-    *n_unique_host = *h;
-  }
+  dedup_result r(env);
+  r.run(recv_ids, index_dtype, n_recv, key_upper_bound, stream);
+  step_sorted(r, index_dtype, n_recv, recv_grads, grad_stride, oa, env, stream, n_unique_host, rows_ready, self);
 }
 
 // reference embedding.cpp:146-323
@@ -270,8 +295,48 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   const bool self_local     = !e->comm->loopback;  // loopback: the self segment is exchanged like a peer's
   const bool self_in_place  = self_local && bk->remap_self_order != nullptr &&
                              !(self_copy_env != nullptr && self_copy_env[0] == '1');
+  // One rank, nothing to exchange: the batch is the receive buffer as it stands — unless it holds negative ("skip me")
+  // ids, which only a pass over the ids can tell. That pass (a histogram) and the host's look at its result used to sit in
+  // front of everything else; now the sort of the ids is queued right behind the histogram, SPECULATING that nothing is
+  // dropped, and the host synchronises while the sort runs. A batch with negative ids throws the sorted view away and takes
+  // the general route below.
+  std::unique_ptr<dedup_result> early;
+  if (self_in_place && e->comm->single_rank_direct() && iarr.size > 0 && iarr.size < (INT64_C(1) << 31)) {
+    temp_mem d_off_mem(env), d_cnt_mem(env), h_mem(env), ws_mem(env);
+    auto* d_off = static_cast<uint64_t*>(d_off_mem.device(2, WHOLEMEMORY_DT_INT64));
+    auto* d_cnt = static_cast<int64_t*>(d_cnt_mem.device(2, WHOLEMEMORY_DT_INT64));
+    auto* h     = static_cast<int64_t*>(h_mem.pinned(4, WHOLEMEMORY_DT_INT64));
+    h[0] = static_cast<int64_t>(entry_offsets[0]), h[1] = static_cast<int64_t>(entry_offsets[1]);
+    WM_BK(bk->memcpy_async(d_off, h, sizeof(int64_t) * 2, stream));
+    wm_bucket_args ca{};
+    ca.indices       = idx_ptr;
+    ca.index_dtype   = iarr.dtype;
+    ca.n             = iarr.size;
+    ca.entry_offsets = d_off;
+    ca.world_size    = 1;
+    ca.counts        = d_cnt;
+    ca.workspace     = ws_mem.device(static_cast<int64_t>(bk->bucket_workspace_bytes(iarr.size, 1)), WHOLEMEMORY_DT_INT8);
+    WM_BK(bk->bucket_ids(&ca, stream));
+    WM_BK(bk->memcpy_async(h + 2, d_cnt, sizeof(int64_t), stream));
+    early.reset(new dedup_result(env));
+    early->run(idx_ptr, iarr.dtype, iarr.size, static_cast<int64_t>(entry_offsets[1]), stream);
+    WM_BK(bk->stream_sync(stream));
+    if (h[2] != iarr.size) early.reset();  // ids were dropped: not the identity after all
+  }
   id_exchange x(env);
-  bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x, self_local, self_in_place);
+  if (early) {
+    x.identity       = true;
+    x.bucketed_ids   = const_cast<char*>(idx_ptr);
+    x.raw_indices    = nullptr;
+    x.send_counts    = {0};
+    x.recv_counts    = {0};
+    x.send_offsets   = {0, 0};
+    x.recv_offsets   = {0, 0};
+    x.bucket_offsets = {0, iarr.size};
+    x.total_valid = x.self_count = iarr.size;
+  } else {
+    bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x, self_local, self_in_place);
+  }
   (void)ies;
   const int rank = e->comm->world_rank;
 
@@ -391,7 +456,9 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   // Everything this rank was given is its own and nothing was dropped (one rank, no negative ids): bucketing is stable, so
   // the receive order IS the caller's order and the caller's gradient tensor IS the receive buffer — no remapping pass
   const bool whole_input_is_self = self_direct && x.self_count == iarr.size && n_recv == iarr.size;
-  if (whole_input_is_self)
+  if (whole_input_is_self && early)
+    step_sorted(*early, iarr.dtype, n_recv, self_ref.grads, self_ref.stride, &oa, env, stream, nullptr, rows_arrived, nullptr);
+  else if (whole_input_is_self)
     dedup_and_step(recv_ids, iarr.dtype, n_recv, self_ref.grads, self_ref.stride, &oa,
                    static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived, nullptr);
   else
