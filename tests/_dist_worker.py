@@ -625,6 +625,13 @@ def main():
     os.environ["WG_LOAD_THREADS_PER_RANK"] = "3"
     scenario_file_io(comm, rank, world, "/tmp/wgamd_test_t_%s" % port)
     del os.environ["WG_LOAD_THREADS_PER_RANK"]
+    # ... and past the page cache (O_DIRECT through aligned bounce buffers; falls back where the file system refuses it)
+    os.environ["WG_LOAD_USE_DIRECTIO"] = "1"
+    scenario_file_io(comm, rank, world, "/var/tmp/wgamd_test_d_%s" % port)
+    os.environ["WG_LOAD_THREADS_PER_RANK"] = "2"
+    scenario_file_io(comm, rank, world, "/tmp/wgamd_test_dt_%s" % port)
+    del os.environ["WG_LOAD_THREADS_PER_RANK"]
+    del os.environ["WG_LOAD_USE_DIRECTIO"]
     # (5) gradient apply, all optimizers
     for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}),
                          ("adam", {"adam_w": 1.0, "weight_decay": 0.02}), ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]:

@@ -7,6 +7,7 @@
 // WG_LOAD_BUFFER_SIZE_MB as in the reference) through pinned double buffers; the O_DIRECT variant
 // (WG_LOAD_USE_DIRECTIO) is not built.
 #include <algorithm>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -126,18 +127,57 @@ wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
     }
     p = static_cast<char*>(v);
   }
+  // WG_LOAD_USE_DIRECTIO=1 (reference file_io.cpp:1975-1979): the files are opened with O_DIRECT and read past the page
+  // cache — for feature files larger than host memory. Direct reads need block-aligned offsets, lengths and buffers, and the
+  // rows wanted are none of that, so every read goes through a per-thread aligned bounce buffer: the enclosing aligned
+  // window is read and the wanted bytes are copied out. A file system that refuses O_DIRECT (tmpfs) falls back to
+  // buffered reads with a warning.
+  bool direct_io = false;
+  if (const char* e = getenv("WG_LOAD_USE_DIRECTIO")) direct_io = e[0] == '1' && e[1] == 0;
   for (int f = 0; f < file_count; f++) {
-    if ((fds[f] = open(file_names[f], O_RDONLY)) < 0) {
+    fds[f] = open(file_names[f], direct_io ? (O_RDONLY | O_DIRECT) : O_RDONLY);
+    if (fds[f] < 0 && direct_io) {
+      WM_WARN("O_DIRECT refused for %s (%s): buffered reads instead", file_names[f], strerror(errno));
+      for (int g = 0; g < f; g++) {
+        close(fds[g]);
+        fds[g] = open(file_names[g], O_RDONLY);
+      }
+      direct_io = false;
+      fds[f]    = open(file_names[f], O_RDONLY);
+    }
+    if (fds[f] < 0) {
       WM_ERROR("input_file[%d] %s cannot be opened for read.", f, file_names[f]);
       cleanup();
       return WHOLEMEMORY_INVALID_INPUT;
     }
   }
-  auto pread_all = [](int fd, char* dst, size_t bytes, off_t off) -> bool {
+  constexpr size_t kBlock  = 4096;          // alignment of direct reads
+  constexpr size_t kBounce = size_t(4) << 20;
+  auto pread_all = [direct_io](int fd, char* dst, size_t bytes, off_t off) -> bool {
+    if (!direct_io) {
+      while (bytes > 0) {
+        const ssize_t got = pread(fd, dst, bytes, off);
+        if (got <= 0) return false;
+        dst += got, off += got, bytes -= static_cast<size_t>(got);
+      }
+      return true;
+    }
+    struct bounce_buffer {
+      char* p = nullptr;
+      bounce_buffer() { if (posix_memalign(reinterpret_cast<void**>(&p), kBlock, kBounce) != 0) p = nullptr; }
+      ~bounce_buffer() { free(p); }
+    };
+    thread_local bounce_buffer bounce;
+    if (bounce.p == nullptr) return false;
     while (bytes > 0) {
-      const ssize_t got = pread(fd, dst, bytes, off);
-      if (got <= 0) return false;
-      dst += got, off += got, bytes -= static_cast<size_t>(got);
+      const off_t window   = off & ~static_cast<off_t>(kBlock - 1);
+      const size_t lead    = static_cast<size_t>(off - window);
+      const size_t want    = std::min<size_t>(size_t(4) << 20, (lead + bytes + kBlock - 1) / kBlock * kBlock);
+      const ssize_t got    = pread(fd, bounce.p, want, window);   // short only at the end of the file
+      if (got <= static_cast<ssize_t>(lead)) return false;
+      const size_t usable  = std::min(bytes, static_cast<size_t>(got) - lead);
+      memcpy(dst, bounce.p + lead, usable);
+      dst += usable, off += static_cast<off_t>(usable), bytes -= usable;
     }
     return true;
   };
