@@ -31,7 +31,7 @@ def main():
             args.append(x)
     if args:
         cases = [(torch.float32, int(x)) for x in args]
-    settings = [("default", None), ("flat=0", "0"), ("flat=1", "1"), ("tile=64", "T64")] if ab else [("default", None)]
+    settings = [("default", None), ("flat=0", "0"), ("flat=1", "1"), ("tile=64", "T64"), ("staged=0", "S0")] if ab else [("default", None)]
     rounds = 5 if ab else 1
     for dt, dim in cases:
         es = 4 if dt == torch.float32 else 2
@@ -49,7 +49,10 @@ def main():
                 for name, val in settings:
                     os.environ.pop("WM_ROWS_FLAT", None)
                     os.environ.pop("WM_ROWS_TILE", None)
-                    if val is not None and val.startswith("T"):
+                    os.environ.pop("WM_ROWS_STAGED", None)
+                    if val is not None and val.startswith("S"):
+                        os.environ["WM_ROWS_STAGED"] = val[1:]
+                    elif val is not None and val.startswith("T"):
                         os.environ["WM_ROWS_TILE"] = val[1:]
                     elif val is not None:
                         os.environ["WM_ROWS_FLAT"] = val
@@ -64,6 +67,7 @@ def main():
                     kernels[name] = wmb.lib().wholememory_ext_last_rows_kernel().decode().split("::")[-1].split("(")[0]
             os.environ.pop("WM_ROWS_FLAT", None)
             os.environ.pop("WM_ROWS_TILE", None)
+            os.environ.pop("WM_ROWS_STAGED", None)
             gb = n * (8 + 2 * dim * es) / 1e9
             for name, _ in settings:
                 ts = sorted(times[name])

@@ -92,6 +92,8 @@ struct rows_params {
   // many more tiles than the chip has wave slots (64 rows of 2 KiB are 128 KiB per wave and 10 M KiB-rows only ~30 k tiles:
   // under four rounds of resident waves, and the last round runs half empty)
   int tile_rows;
+  // LDS-staged gather (rows_staged_gather_kernel): rows per chunk (a power of two, chunk bytes a multiple of 16), 0 = not used
+  int stage_rows;
 };
 
 // byte address of the first moved element of table row `idx`
@@ -376,6 +378,92 @@ __global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-staged gather for a DENSE output whose rows are only 4- or 8-byte aligned (dim 129 -> 516 B, dim 602 -> 2408 B ...)
+// ------------------------------------------------------------------------------------------------
+// The table rows of such an embedding start on 16-byte boundaries (the stride is padded), the rows of the dense [n, dim]
+// output do not: every 16-byte store of the flat kernel straddles 64-byte sectors on the output side. But the output of R
+// consecutive entries is ONE contiguous piece of R * row_bytes bytes, 16-byte aligned as a whole when R * row_bytes is a
+// multiple of 16 — so the rows of a chunk are assembled in LDS at their dense offsets (aligned 16-byte global loads from
+// the table, dword LDS writes) and leave as aligned 16-byte non-temporal stores of the contiguous stream. Each wave has
+// its own LDS region: no workgroup barrier, only the wave's own LDS ordering. A chunk with a skipped entry (negative id, or
+// past the end of the batch) must not touch that entry's output row: such chunks take the per-row path (dword stores).
+constexpr int kStageIters = 5;  // 16-byte slots per lane per chunk: chunks of up to 5 KiB (5 x 64 x 16 B)
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void rows_staged_gather_kernel(rows_params p)
+{
+  extern __shared__ __attribute__((aligned(16))) char staged_lds[];
+  const int lane        = threadIdx.x & (kWave - 1);
+  const int wave_in_blk = threadIdx.x >> 6;
+  const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  const int64_t tiles   = (p.n + kWave - 1) / kWave;
+  const int R           = p.stage_rows;
+  const int S           = p.flat_slots;                       // 16-byte slots per row, the last one holds flat_tail bytes
+  const int row_bytes   = (S - 1) * 16 + p.flat_tail;
+  const int chunk_bytes = R * row_bytes;                      // multiple of 16
+  const int chunk_slots = R * S;
+  const int chunk_vecs  = chunk_bytes >> 4;
+  char* const lds       = staged_lds + wave_in_blk * ((chunk_bytes + 15) & ~15);
+  const int tail_words  = p.flat_tail >> 2;
+
+  for (int64_t tile = wave; tile < tiles; tile += n_waves) {
+    char *my_tab, *my_plain;
+    load_tile_entry<IdxT>(p, tile * kWave + lane, my_tab, my_plain);
+    const uint64_t present = __ballot(my_tab != nullptr);
+    for (int r0 = 0; r0 < kWave; r0 += R) {
+      const uint64_t chunk_mask = (R == 64 ? ~0ull : ((1ull << R) - 1)) << r0;
+      if ((present & chunk_mask) == 0) continue;              // nothing to move (tail of the last tile, all skipped)
+      char* const out = p.plain + (tile * kWave + r0) * static_cast<int64_t>(row_bytes);
+      if ((present & chunk_mask) == chunk_mask) {
+        // ---- table -> LDS: slot v of the chunk = row v / S, piece v % S; every load of the chunk is issued before the
+        // first LDS write (up to kStageIters x 1 KiB per wave in flight)
+        u32x4 d[kStageIters];
+        int lds_off[kStageIters], nw[kStageIters];
+#pragma unroll
+        for (int i = 0; i < kStageIters; i++) {
+          const int v = min(lane + i * kWave, chunk_slots - 1);   // clamped: the broadcast below needs every lane
+          const int r = static_cast<int>(static_cast<float>(v) * p.flat_rcp);
+          int row = r, col = v - r * S;
+          if (col < 0) row--, col += S;
+          if (col >= S) row++, col -= S;
+          // (ds_bpermute returns 0 for an inactive SOURCE lane: the broadcast must not sit inside the guard)
+          const char* t = shfl_ptr(my_tab, r0 + row);
+          nw[i]         = 0;
+          if (lane + i * kWave < chunk_slots) {
+            d[i]       = ld_global_nt<u32x4>(t + col * 16);   // the padded table row holds 16 bytes here even in the tail slot
+            lds_off[i] = row * row_bytes + col * 16;
+            nw[i]      = col == S - 1 ? tail_words : 4;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kStageIters; i++) {
+          uint32_t* dst = reinterpret_cast<uint32_t*>(lds + lds_off[i]);
+#pragma unroll
+          for (int w = 0; w < 4; w++)
+            if (w < nw[i]) dst[w] = d[i][w];
+        }
+        // the rows of the chunk sit in this wave's LDS region only; LDS operations of one wave complete in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- LDS -> the contiguous, 16-byte aligned output stream
+        for (int v = lane; v < chunk_vecs; v += kWave)
+          st_global_nt<u32x4>(out + v * 16, *reinterpret_cast<const u32x4*>(lds + v * 16));
+        __builtin_amdgcn_wave_barrier();                      // the next chunk overwrites the region
+      } else {
+        // ---- a skipped entry inside the chunk: row by row, dword stores at the rows' natural alignment
+        for (int r = 0; r < R; r++) {
+          const char* t = shfl_ptr(my_tab, r0 + r);
+          if (t == nullptr) continue;                         // wave-uniform
+          char* q = out + r * static_cast<int64_t>(row_bytes);
+          for (int w = lane; w < (row_bytes >> 2); w += kWave) st_global<uint32_t>(q + 4 * w, ld_global<uint32_t>(t + 4 * w));
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // converting path: V elements per lane, FromT -> ToT through the reference's conversion chain
 // ------------------------------------------------------------------------------------------------
 template <typename T, int V>
@@ -509,6 +597,13 @@ int flat_override()
   return e == nullptr ? -1 : atoi(e);
 }
 
+// WM_ROWS_STAGED=0 switches the LDS-staged gather off (A/B)
+bool staged_enabled()
+{
+  const char* e = getenv("WM_ROWS_STAGED");
+  return e == nullptr || e[0] != '0';
+}
+
 // flat-stream kernel or the pow-of-two lane mappings? (rule from experiments/dim_sweep.py, see rows_flat_kernel)
 bool want_flat(bool gather, int vb, int64_t row_bytes)
 {
@@ -539,6 +634,15 @@ void launch_flat(const rows_params& p, int blocks, hipStream_t stream)
 template <typename IdxT, bool GATHER>
 void launch_copy(const rows_params& p, int vb, int blocks, hipStream_t stream)
 {
+  if constexpr (GATHER) {
+    if (p.stage_rows > 0) {
+      const int row_bytes   = (p.flat_slots - 1) * 16 + p.flat_tail;
+      const size_t lds      = static_cast<size_t>(kBlock / kWave) * ((static_cast<size_t>(p.stage_rows) * row_bytes + 15) & ~size_t(15));
+      t_last_rows_kernel    = reinterpret_cast<const void*>(rows_staged_gather_kernel<IdxT>);
+      hipLaunchKernelGGL(rows_staged_gather_kernel<IdxT>, dim3(blocks), dim3(kBlock), lds, stream, p);
+      return;
+    }
+  }
   if (p.flat_slots > 0) {
     launch_flat<IdxT, GATHER>(p, blocks, stream);
     return;
@@ -692,7 +796,22 @@ int rows_op(const wm_rows_args* a, void* stream_v)
       p.flat_tail  = static_cast<int>(row_bytes - 16 * static_cast<int64_t>(p.flat_slots - 1));
       p.flat_rcp   = 1.0f / static_cast<float>(p.flat_slots);
     }
-    if (p.flat_slots > 0 || (vb == 16 && p.row_vecs >= 32)) {  // the two kernels that take tile_rows
+    // LDS-staged gather: dense output rows only 4 / 8-byte aligned, table rows on 16-byte boundaries with room for whole
+    // 16-byte loads (padded stride), no row map (the output of consecutive entries must be one contiguous piece)
+    if (GATHER && p.flat_slots > 0 && p.flat_tail != 16 && p.row_map == nullptr && p.plain_stride_bytes == row_bytes &&
+        (reinterpret_cast<uint64_t>(p.plain) & 15) == 0 && p.table_stride_bytes % 16 == 0 && p.table_offset_bytes % 16 == 0 &&
+        (tab_base & 15) == 0 && a->gref.stride % 16 == 0 && p.table_stride_bytes >= static_cast<int64_t>(p.flat_slots) * 16 &&
+        row_bytes <= 1024 && staged_enabled()) {   // measured: 516 B rows 52.2 -> 55.2 % of peak, 2408 B rows 60.9 -> 59.6 %
+      const int need = row_bytes % 8 == 0 ? 2 : 4;   // rows per 16-byte-aligned piece of the dense stream
+      int R          = 64;
+      while (R > need && static_cast<int64_t>(R) * row_bytes > 5120) R >>= 1;
+      if (static_cast<int64_t>(R) * row_bytes <= 5120) {   // kStageIters x 1 KiB per wave; bigger rows stay on the flat kernel
+        p.stage_rows = R;
+        p.tile_rows  = kWave;
+        blocks       = grid_for(kWave);
+      }
+    }
+    if (p.stage_rows == 0 && (p.flat_slots > 0 || (vb == 16 && p.row_vecs >= 32))) {  // the two kernels that take tile_rows
       const char* te    = getenv("WM_ROWS_TILE");  // experiment switch
       const int forced  = te != nullptr ? atoi(te) : 0;
       p.tile_rows = row_bytes <= 768 ? 64 : row_bytes <= 1536 ? 32 : row_bytes <= 3072 ? 16 : 8;
