@@ -92,3 +92,23 @@ def test_multi_rank_line_over_host_collectives(wm_lib, world):
     assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0 and "local shard" in r["roofline"]["scope"]
     # whole-job aggregate: all ranks' lookups over the slowest rank's time
     assert abs(r["mlookups_per_s"] - world * 300000 / (r["ms_per_step"] * 1e-3) / 1e6) / r["mlookups_per_s"] < 0.02
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sample_gather_line(wm_lib, world):
+    """BASELINE config 5 as a bench op (small graph): one JSON line with the contract keys and its own roofline object; at
+    world 2 the CSR and the features are DISTRIBUTED over two ranks sharing the GPU (collectives over gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--op", "sample_gather", "--nodes", "2000003", "--avg-degree", "12",
+           "--seeds", "512", "--fanouts", "10,5", "--steps", "3", "--warmup", "2", "--stability-steps", "4"]
+    if world > 1:
+        cmd += ["--gpus", str(world), "--backend", "gloo"]
+    p = subprocess.run(cmd, capture_output=True, timeout=900, env=dict(env, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    r = _one_json_line(p.stdout)
+    assert all(k in r for k in CONTRACT) and r["n_gpus"] == world and r["unit"] == "GB/s" and r["value"] > 0
+    assert r["config"]["fanouts"] == [10, 5] and r["frontier_sizes"][-1] == 512 and len(r["frontier_sizes"]) == 3
+    assert r["frontier_sizes"][0] == r["subgraph_nodes_per_step"] > 512 and r["sampled_edges_per_step"] > 0
+    roof = r["roofline"]
+    assert roof["bound"] == "hbm" and "latency" in roof["limited_by"] and 0 < roof["frac"] < 1
+    assert r["stability"]["steps"] == 4
