@@ -618,19 +618,62 @@ __device__ __forceinline__ P* tile_bcast_ptr(P* p, int e0, int sub)
 #ifndef WM_TILE_KU_STATE
 #define WM_TILE_KU_STATE 2
 #endif
-// VB = bytes per lane, KU = steps in flight (0: the default for the optimizer). Swept on the 10 M-row SGD / LazyAdam call
+// 16 bytes per lane, KU = steps in flight (0: the default for the optimizer). Swept on the 10 M-row SGD / LazyAdam call
 // (profiles/r02_tile_sweep.txt): 16 B x 4 steps (SGD) and 16 B x 2 (stateful) are the defaults; 8 B per lane (a 512-byte row
 // per wave, every per-row quantity wave-uniform) is 5 % slower, 8 steps in flight no faster, grids of 2048 / 4096
 // workgroups 5-8 % slower than 8192.
-template <typename IdxT, int OPT, int RPS, bool CACHED, int VB = 16, int KU = 0>
+// T = element type of the table AND of the gradient rows: float, or half / bf16 (SGD only: duplicates are summed in fp32
+// in receive order, the update is computed in fp32 from fp32(e) and rounded once — 8 elements per 16-byte piece).
+typedef uint32_t tile_raw4 __attribute__((ext_vector_type(4)));
+template <int N>
+struct tile_vals {
+  float v[N];
+};
+template <typename T>
+__device__ __forceinline__ tile_vals<16 / sizeof(T)> tile_unpack(tile_raw4 r)
+{
+  tile_vals<16 / sizeof(T)> out;
+  if constexpr (std::is_same<T, float>::value) {
+    out.v[0] = __builtin_bit_cast(float, static_cast<uint32_t>(r.x));
+    out.v[1] = __builtin_bit_cast(float, static_cast<uint32_t>(r.y));
+    out.v[2] = __builtin_bit_cast(float, static_cast<uint32_t>(r.z));
+    out.v[3] = __builtin_bit_cast(float, static_cast<uint32_t>(r.w));
+  } else {
+    T e[8];
+    __builtin_memcpy(e, &r, 16);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out.v[i] = load_wide<T>(e[i]);
+  }
+  return out;
+}
+template <typename T>
+__device__ __forceinline__ tile_raw4 tile_pack(const tile_vals<16 / sizeof(T)>& in)
+{
+  tile_raw4 r;
+  if constexpr (std::is_same<T, float>::value) {
+    r.x = __builtin_bit_cast(uint32_t, in.v[0]);
+    r.y = __builtin_bit_cast(uint32_t, in.v[1]);
+    r.z = __builtin_bit_cast(uint32_t, in.v[2]);
+    r.w = __builtin_bit_cast(uint32_t, in.v[3]);
+  } else {
+    T e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = store_narrow<T>(in.v[i]);
+    __builtin_memcpy(&r, e, 16);
+  }
+  return r;
+}
+
+template <typename IdxT, int OPT, int RPS, bool CACHED, typename T = float, int KU = 0>
 __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
 {
-  constexpr int kVE          = VB / 4;  // floats per lane
-  typedef float f4 __attribute__((ext_vector_type(kVE)));
-  constexpr int kU           = KU > 0 ? KU : (OPT == WHOLEMEMORY_OPT_SGD ? WM_TILE_KU_SGD : WM_TILE_KU_STATE);
+  constexpr int kVE          = 16 / static_cast<int>(sizeof(T));  // elements per lane
+  constexpr bool k16         = sizeof(T) == 2;
+  constexpr int kU           = KU > 0 ? KU : ((OPT == WHOLEMEMORY_OPT_SGD && !k16) ? WM_TILE_KU_SGD : WM_TILE_KU_STATE);
   constexpr int kLpr         = 64 / RPS;
   constexpr bool kState      = OPT != WHOLEMEMORY_OPT_SGD;
   constexpr bool kAdam       = OPT == WHOLEMEMORY_OPT_LAZY_ADAM;
+  static_assert(!k16 || OPT == WHOLEMEMORY_OPT_SGD, "16-bit tables are trained with SGD only");
   const wm_optimizer_args& a = p.a;
   const int lane             = threadIdx.x & 63;
   const int64_t wave         = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
@@ -649,16 +692,16 @@ __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
     const int32_t my_s0 = a.run_starts[uc];
     int32_t my_len      = u < count ? a.run_starts[uc + 1] - my_s0 : 0;
     if (p.long_list != nullptr && my_len > kLongRun) my_len = 0;  // the long-run kernel's (mark_long_runs_kernel lists it)
-    const float* my_grad = grad_row<float>(a, a.order[my_s0]);
-    float* my_row;
+    const T* my_grad = grad_row<T>(a, a.order[my_s0]);
+    T* my_row;
     float* my_st = nullptr;
     if (CACHED) {
       const int32_t slot = cache_slot(a, local);
-      my_row             = table_row_at<float>(a, local, slot);
+      my_row             = table_row_at<T>(a, local, slot);
       my_st              = state_row_at(a, local, slot);
       if (my_len > 0 && slot >= 0) a.cache_dirty[slot] = 1;
     } else {
-      my_row = static_cast<float*>(a.local_table) + local * a.table_stride;
+      my_row = static_cast<T*>(a.local_table) + local * a.table_stride;
       if (kState) my_st = a.per_element_state + local * a.per_element_stride;
     }
     float my_b1 = 0.f, my_b2 = 0.f;
@@ -676,19 +719,20 @@ __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
       const int64_t coff = static_cast<int64_t>(c) * kVE;
 #pragma unroll 1
       for (int s = 0; s < 64; s += RPS * kU) {
-        f4 acc[kU], ev[kU], s0v[kU], s1v[kU];
-        float* trow[kU];
+        tile_vals<kVE> acc[kU];
+        tile_raw4 ev[kU], s0v[kU], s1v[kU];
+        T* trow[kU];
         float* srow[kU];
         int32_t ln[kU], rs[kU];
         float b1[kU], b2[kU];
 #pragma unroll
         for (int k = 0; k < kU; k++) {
-          const int e0     = s + RPS * k;
-          const float* g   = tile_bcast_ptr<RPS>(my_grad, e0, sub);
-          trow[k]          = tile_bcast_ptr<RPS>(my_row, e0, sub);
+          const int e0 = s + RPS * k;
+          const T* g   = tile_bcast_ptr<RPS>(my_grad, e0, sub);
+          trow[k]      = tile_bcast_ptr<RPS>(my_row, e0, sub);
           if (kState) srow[k] = tile_bcast_ptr<RPS>(my_st, e0, sub);
-          ln[k]            = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_len), e0, sub));
-          rs[k]            = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_s0), e0, sub));
+          ln[k]        = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_len), e0, sub));
+          rs[k]        = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_s0), e0, sub));
           if (kAdam) {
             b1[k] = __builtin_bit_cast(float, tile_bcast32<RPS>(__builtin_bit_cast(uint32_t, my_b1), e0, sub));
             b2[k] = __builtin_bit_cast(float, tile_bcast32<RPS>(__builtin_bit_cast(uint32_t, my_b2), e0, sub));
@@ -696,10 +740,10 @@ __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
           if (!col_ok) ln[k] = 0;
           if (ln[k] > 0) {
             // first occurrence copied (DedupIndiceAndGradientsKernel); the table / state pieces are loaded alongside
-            acc[k] = ld_global_nt<f4>(g + coff);
-            ev[k]  = ld_global_nt<f4>(trow[k] + coff);
-            if (kState) s0v[k] = ld_global<f4>(srow[k] + coff);
-            if (kAdam) s1v[k] = ld_global<f4>(srow[k] + a.table_stride + coff);
+            acc[k] = tile_unpack<T>(ld_global_nt<tile_raw4>(g + coff));
+            ev[k] = ld_global_nt<tile_raw4>(trow[k] + coff);
+            if (kState) s0v[k] = ld_global<tile_raw4>(srow[k] + coff);
+            if (kAdam) s1v[k] = ld_global<tile_raw4>(srow[k] + a.table_stride + coff);
           }
         }
 #pragma unroll
@@ -710,37 +754,46 @@ __global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
           for (int r = 0; r < RPS; r++) longest = max(longest, static_cast<int32_t>(__builtin_amdgcn_readlane(my_len, s + RPS * k + r)));
           // later occurrences added in receive order, 4 rows prefetched at a time (index clamped into the run)
           for (int32_t j = 1; j < longest; j += 4) {
-            f4 gq[4];
+            tile_raw4 gq[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               if (j + q < ln[k]) {
                 const int32_t o = a.order[rs[k] + j + q];
-                gq[q]           = ld_global_nt<f4>(grad_row<float>(a, o) + coff);
+                gq[q]           = ld_global_nt<tile_raw4>(grad_row<T>(a, o) + coff);
               }
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-              if (j + q < ln[k]) acc[k] += gq[q];
+            for (int q = 0; q < 4; q++) {
+              if (j + q < ln[k]) {
+                const tile_vals<kVE> gv = tile_unpack<T>(gq[q]);
+#pragma unroll
+                for (int v = 0; v < kVE; v++) acc[k].v[v] += gv.v[v];
+              }
+            }
           }
         }
 #pragma unroll
         for (int k = 0; k < kU; k++) {
           if (ln[k] <= 0) continue;
-          f4 eo, so0, so1;
+          const tile_vals<kVE> e_in = tile_unpack<T>(ev[k]);
+          tile_vals<4> s0_in{}, s1_in{}, so0{}, so1{};
+          tile_vals<kVE> eo;
+          if (kState) s0_in = tile_unpack<float>(s0v[k]);
+          if (kAdam) s1_in = tile_unpack<float>(s1v[k]);
 #pragma unroll
           for (int v = 0; v < kVE; v++) {
             opt_elem x;
-            x.e  = ev[k][v];
-            x.s0 = kState ? s0v[k][v] : 0.f;
-            x.s1 = kAdam ? s1v[k][v] : 0.f;
-            opt_math<OPT>(a, x, acc[k][v], kAdam ? b1[k] : 0.f, kAdam ? b2[k] : 0.f);
-            eo[v]  = x.e;
-            so0[v] = x.s0;
-            so1[v] = x.s1;
+            x.e  = e_in.v[v];
+            x.s0 = kState ? s0_in.v[v & 3] : 0.f;
+            x.s1 = kAdam ? s1_in.v[v & 3] : 0.f;
+            opt_math<OPT>(a, x, acc[k].v[v], kAdam ? b1[k] : 0.f, kAdam ? b2[k] : 0.f);
+            eo.v[v] = x.e;
+            if (kState) so0.v[v & 3] = x.s0;
+            if (kAdam) so1.v[v & 3] = x.s1;
           }
-          if (kState) st_global<f4>(srow[k] + coff, so0);
-          if (kAdam) st_global<f4>(srow[k] + a.table_stride + coff, so1);
-          st_global_nt<f4>(trow[k] + coff, eo);
+          if (kState) st_global<tile_raw4>(srow[k] + coff, tile_pack<float>(so0));
+          if (kAdam) st_global<tile_raw4>(srow[k] + a.table_stride + coff, tile_pack<float>(so1));
+          st_global_nt<tile_raw4>(trow[k] + coff, tile_pack<T>(eo));
         }
       }
     }
@@ -1203,6 +1256,31 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream, hipStream_t 
     hipLaunchKernelGGL((step_long4_kernel<IdxT, kOpt, T>), dim3(gx, slices), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
   }
   const bool cached = p.a.cache_slot_of != nullptr;
+  // rows of whole 16-byte pieces (8 elements) on every side: the tile kernel, as for fp32 tables
+  static const bool tile_off = getenv("WM_STEP_TILE") != nullptr && getenv("WM_STEP_TILE")[0] == '0';
+  const bool tile_ok = !tile_off && rows16 && p.a.dim >= 64 && p.a.table_stride % 8 == 0 &&
+                       reinterpret_cast<uint64_t>(p.a.local_table) % 16 == 0 &&
+                       (!cached || (p.a.cache_row_elems % 8 == 0 && reinterpret_cast<uint64_t>(p.a.cache_data) % 16 == 0));
+  if (tile_ok) {
+    const int64_t tiles = (p.a.count + 63) / 64;
+    int tblocks         = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, 256 * 32));
+    if (const char* e = getenv("WM_STEP_BLOCKS")) tblocks = std::min(tblocks, std::max(1, atoi(e)));
+    tblocks             = std::max(tblocks, 1);
+    const int vecs      = static_cast<int>(p.a.dim / 8);
+#define WM_TILE16(RPS)                                                                                                       \
+  do {                                                                                                                       \
+    if (cached)                                                                                                              \
+      hipLaunchKernelGGL((step_tile_kernel<IdxT, kOpt, RPS, true, T>), dim3(tblocks), dim3(kBlock), 0, stream, p);           \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((step_tile_kernel<IdxT, kOpt, RPS, false, T>), dim3(tblocks), dim3(kBlock), 0, stream, p);          \
+  } while (0)
+    if (vecs > 32) WM_TILE16(1);
+    else if (vecs > 16) WM_TILE16(2);
+    else if (vecs > 8) WM_TILE16(4);
+    else WM_TILE16(8);
+#undef WM_TILE16
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   if (vec4 && !cached)
     hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 4, T, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
   else if (vec4)
