@@ -452,6 +452,31 @@ def main():
                      "note": "per-step HIP-event times on rank 0, separate from the timed region"}
         barrier()
 
+    # N > 1: BASELINE config C3 proper is the Zipf-skewed batch. A short side leg after the contract measurement: the same step
+    # with Zipf(1.05) ids (hot rows hashed over the owners), with the library's automatic request de-duplication and with it
+    # forced off — on real links this is the evidence for what the de-duplication saves
+    c3_zipf = None
+    if world > 1 and a.op == "gather" and a.dist == "uniform" and mt == "distributed":
+        zidx = torch.from_numpy(make_indices(a.indices, total_rows, "zipf", 4242 + rank)).cuda()
+        c3_zipf = {"index_distribution": "zipf(1.05), hashed", "steps": 20}
+        for label, env_val in (("dedup_auto", None), ("dedup_off", "0")):
+            if env_val is None:
+                os.environ.pop("WM_GATHER_DEDUP", None)
+            else:
+                os.environ["WM_GATHER_DEDUP"] = env_val
+            for _ in range(3):
+                emb.gather(zidx, out=out)
+            barrier()
+            tz = time.perf_counter()
+            for _ in range(20):
+                emb.gather(zidx, out=out)
+            barrier()
+            dz = torch.tensor([time.perf_counter() - tz], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(dz, op=torch.distributed.ReduceOp.MAX)
+            c3_zipf[label + "_ms_per_step"] = round(float(dz.item()) / 20 * 1e3, 4)
+        os.environ.pop("WM_GATHER_DEDUP", None)
+        c3_zipf["dedup_auto_value_GBps"] = round(a.indices * world * a.dim * es / (c3_zipf["dedup_auto_ms_per_step"] * 1e-3) / 1e9, 2)
+
     # N > 1: the step is link-bound (see `exchange`); the HBM roofline object then describes the dominant HBM kernel on its
     # own — the owner-side row gather — timed on this rank's local shard outside the step loop, same ids folded into it
     local_kernel_roofline = None
@@ -544,6 +569,8 @@ def main():
                 res["exchange"]["note"] = "BRING-UP RUN: collectives over torch.distributed/%s, not RCCL" % a.backend
         if stability is not None:
             res["stability"] = stability
+        if c3_zipf is not None:
+            res["c3_zipf"] = c3_zipf
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     wgth.destroy_embedding(emb)

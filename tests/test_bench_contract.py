@@ -90,6 +90,7 @@ def test_multi_rank_line_over_host_collectives(wm_lib, world):
     assert r["value"] > 0 and "cpu_baseline" not in r            # the host baseline is an N = 1 item
     assert r["exchange"]["bound"] == "xgmi" and "BRING-UP" in r["exchange"]["note"]
     assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0 and "local shard" in r["roofline"]["scope"]
+    assert r["c3_zipf"]["dedup_auto_ms_per_step"] > 0 and r["c3_zipf"]["dedup_off_ms_per_step"] > 0   # the Zipf side leg (C3)
     # whole-job aggregate: all ranks' lookups over the slowest rank's time
     assert abs(r["mlookups_per_s"] - world * 300000 / (r["ms_per_step"] * 1e-3) / 1e6) / r["mlookups_per_s"] < 0.02
 
