@@ -185,7 +185,7 @@ int t_bucket(const wm_bucket_args* a, void*)
 }
 
 size_t t_dedup_ws(int64_t, wholememory_dtype_t) { return 64; }
-int t_dedup(const void* ids, wholememory_dtype_t dt, int64_t n, int64_t, void* unique_ids, int32_t* run_starts,
+int t_dedup(const void* ids, wholememory_dtype_t dt, int64_t n, int64_t, int64_t, void* unique_ids, int32_t* run_starts,
             int32_t* order, int64_t* n_unique_out, void*, void*)
 {
   std::vector<int32_t> ord(n);

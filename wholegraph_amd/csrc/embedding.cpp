@@ -188,7 +188,8 @@ struct self_rows_ref {
 // sorted view of a batch of received ids (unique ids, run starts, sorted order): the scratch lives as long as the object
 struct dedup_result {
   explicit dedup_result(wholememory_env_func_t* env) : unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env) {}
-  void run(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, void* stream)
+  void run(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, void* stream,
+           int64_t key_lower_bound = 0)
   {
     const auto* bk = backend();
     d_unique  = unique_ids.device(n, index_dtype);
@@ -196,7 +197,7 @@ struct dedup_result {
     d_order   = static_cast<int32_t*>(order.device(n, WHOLEMEMORY_DT_INT));
     d_nunique = static_cast<int64_t*>(n_unique.device(1, WHOLEMEMORY_DT_INT64));
     void* d_ws = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n, index_dtype)), WHOLEMEMORY_DT_INT8);
-    int rc = bk->dedup_ids(ids, index_dtype, n, key_upper_bound, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
+    int rc = bk->dedup_ids(ids, index_dtype, n, key_upper_bound, key_lower_bound, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
     if (rc == -1) throw logic_error("dedup_ids: unsupported index dtype or more than 2^31 received ids");
     if (rc != 0) throw hip_error("dedup_ids failed");
   }
@@ -240,7 +241,8 @@ void step_sorted(dedup_result& r, wholememory_dtype_t index_dtype, int64_t n_rec
 
 void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64_t n_recv, const void* recv_grads,
                     int64_t grad_stride, wm_optimizer_args* oa, int64_t key_upper_bound, wholememory_env_func_t* env,
-                    void* stream, int64_t* n_unique_host, void* rows_ready = nullptr, const self_rows_ref* self = nullptr)
+                    void* stream, int64_t* n_unique_host, void* rows_ready = nullptr, const self_rows_ref* self = nullptr,
+                    int64_t key_lower_bound = 0)
 {
   const auto* bk = backend();
   if (n_recv == 0) {
@@ -249,7 +251,7 @@ void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64
     return;
   }
   dedup_result r(env);
-  r.run(recv_ids, index_dtype, n_recv, key_upper_bound, stream);
+  r.run(recv_ids, index_dtype, n_recv, key_upper_bound, stream, key_lower_bound);
   step_sorted(r, index_dtype, n_recv, recv_grads, grad_stride, oa, env, stream, n_unique_host, rows_ready, self);
 }
 
@@ -460,11 +462,11 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     step_sorted(*early, iarr.dtype, n_recv, self_ref.grads, self_ref.stride, &oa, env, stream, nullptr, rows_arrived, nullptr);
   else if (whole_input_is_self)
     dedup_and_step(recv_ids, iarr.dtype, n_recv, self_ref.grads, self_ref.stride, &oa,
-                   static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived, nullptr);
+                   static_cast<int64_t>(entry_offsets[rank + 1]), env, stream, nullptr, rows_arrived, nullptr,
+                   static_cast<int64_t>(entry_offsets[rank]));
   else
-    dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa,
-                   static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream, nullptr, rows_arrived,
-                   self_direct ? &self_ref : nullptr);
+    dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa, static_cast<int64_t>(entry_offsets[rank + 1]), env, stream,
+                   nullptr, rows_arrived, self_direct ? &self_ref : nullptr, static_cast<int64_t>(entry_offsets[rank]));
   // temporaries go back to the caller's allocator on return; like the reference's distributed ops
   // the stream is drained first so nothing in flight still reads them
   WM_BK(bk->stream_sync(stream));
@@ -854,7 +856,7 @@ wholememory_error_code_t wholememory_ext_dedup_apply(const void* recv_ids,
   oa.per_row_state      = per_row_state;
   int64_t nu            = 0;
   wm::dedup_and_step(recv_ids, index_dtype, n_recv, recv_grads, grad_stride, &oa, local_entry_offset + local_entry_count,
-                     p_env_fns, stream, &nu);
+                     p_env_fns, stream, &nu, nullptr, nullptr, local_entry_offset);
   if (n_unique_host) *n_unique_host = nu;
   return WHOLEMEMORY_SUCCESS;
   WM_API_END

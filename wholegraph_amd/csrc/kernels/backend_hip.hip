@@ -11,7 +11,7 @@ int hip_scatter_rows(const wm_rows_args* a, void* stream);
 size_t hip_bucket_workspace_bytes(int64_t n, int world_size);
 int hip_bucket_ids(const wm_bucket_args* a, void* stream);
 size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype);
-int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound,
+int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, int64_t key_lower_bound,
                   void* unique_ids, int32_t* run_starts, int32_t* order, int64_t* n_unique_out, void* workspace,
                   void* stream);
 int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(1024) void run_scan_kernel(int32_t* tile_counts, in
 
 template <typename KeyT, typename OutT>
 __global__ __launch_bounds__(kBlock) void run_compact_kernel(const KeyT* sorted, int64_t n, const int32_t* tile_prefix,
-                                                             const int64_t* n_unique, OutT* unique_ids, int32_t* run_starts)
+                                                             const int64_t* n_unique, OutT* unique_ids, int32_t* run_starts,
+                                                             OutT key_base)
 {
   // heads are ranked inside the tile, parked in LDS at their rank and written out as two coalesced streams (a thread's
   // own heads are kRunItems apart in rank order: written directly they cost a scattered store per item — 82 us vs ~35)
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(kBlock) void run_compact_kernel(const KeyT* sorted,
     // ids are stored in the caller's (signed) index type: the keys are its two's-complement bits, possibly narrowed to
     // 32 bits when the caller bounded them (then they are non-negative and the widening is exact)
     const KeyT k         = s_key[i];
-    unique_ids[out0 + i] = sizeof(KeyT) == sizeof(OutT) ? static_cast<OutT>(k) : static_cast<OutT>(static_cast<uint64_t>(k));
+    // (key_base: the keys were sorted relative to the first row of the owner's range, see run_dedup)
+    unique_ids[out0 + i] = (sizeof(KeyT) == sizeof(OutT) ? static_cast<OutT>(k) : static_cast<OutT>(static_cast<uint64_t>(k))) + key_base;
     run_starts[out0 + i] = s_pos[i];
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) run_starts[*n_unique] = static_cast<int32_t>(n);
@@ -174,10 +176,14 @@ inline unsigned significant_bits(int64_t upper_bound, unsigned full)
   return b;
 }
 
-// keys narrowed on the fly: ids the caller bounded below 2^32 are sorted as 32-bit keys (8 + 4 bytes per element and
-// pass instead of 8 + 8 ... the first pass reads the 64-bit ids through this iterator, no conversion pass)
+// keys narrowed on the fly: ids the caller bounded to a range of less than 2^32 rows are sorted as 32-bit keys RELATIVE to
+// the start of the range (8 + 4 bytes per element and pass instead of 8 + 8, and only the bits of the range's width: a
+// 125 M-row shard of a 1 B-row table sorts 27 bits in 3 passes, not 30 in 4) ... the first pass reads the ids through this
+// iterator, no conversion pass
+template <typename InT>
 struct narrow_to_u32 {
-  __host__ __device__ uint32_t operator()(const uint64_t& v) const { return static_cast<uint32_t>(v); }
+  InT base;
+  __host__ __device__ uint32_t operator()(const InT& v) const { return static_cast<uint32_t>(v - base); }
 };
 
 // rocPRIM's onesweep with 9 radix bits per pass and 1024 x 8 keys per workgroup: ids of a 100 M-row shard (27 bits) sort
@@ -228,33 +234,34 @@ dedup_layout<SortKeyT> layout(void* ws, int64_t n)
 
 template <typename SortKeyT, typename OutT>
 int detect_runs(const SortKeyT* sorted, int32_t* tile_counts, int64_t n, OutT* unique_ids, int32_t* run_starts,
-                int64_t* n_unique_out, hipStream_t stream)
+                int64_t* n_unique_out, hipStream_t stream, OutT key_base = 0)
 {
   const int tiles = run_tiles(n);
   hipLaunchKernelGGL((run_count_kernel<SortKeyT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts);
   hipLaunchKernelGGL(run_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, tiles, n_unique_out);
   hipLaunchKernelGGL((run_compact_kernel<SortKeyT, OutT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts,
-                     n_unique_out, unique_ids, run_starts);
+                     n_unique_out, unique_ids, run_starts, key_base);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <typename KeyT>
-int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, void* unique_ids, int32_t* run_starts,
-              int32_t* order, int64_t* n_unique_out, void* workspace, hipStream_t stream)
+int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_lower_bound, void* unique_ids,
+              int32_t* run_starts, int32_t* order, int64_t* n_unique_out, void* workspace, hipStream_t stream)
 {
-  using UKey          = typename std::make_unsigned<KeyT>::type;
-  const unsigned bits = significant_bits(key_upper_bound, 8 * sizeof(KeyT));
+  using UKey = typename std::make_unsigned<KeyT>::type;
+  if (key_upper_bound <= 0 || key_lower_bound < 0 || key_lower_bound >= key_upper_bound) key_lower_bound = 0;
+  const unsigned bits = significant_bits(key_upper_bound > 0 ? key_upper_bound - key_lower_bound : 0, 8 * sizeof(KeyT));
   // the payload 0, 1, 2 ... is generated by the sort's first pass (counting iterator): no iota array
   rocprim::counting_iterator<int32_t> positions(0);
-  if (sizeof(KeyT) == 8 && key_upper_bound > 0 && bits <= 32) {
+  if (key_upper_bound > 0 && bits <= 32 && (sizeof(KeyT) == 8 || key_lower_bound > 0)) {
     auto l    = layout<uint32_t>(workspace, n);
     size_t tb = l.temp_bytes;
-    auto keys = rocprim::make_transform_iterator(static_cast<const uint64_t*>(ids), narrow_to_u32());
+    auto keys = rocprim::make_transform_iterator(static_cast<const UKey*>(ids), narrow_to_u32<UKey>{static_cast<UKey>(key_lower_bound)});
     if (rocprim::radix_sort_pairs<sort_config<uint32_t>::type>(l.temp, tb, keys, l.sorted, positions, order,
                                                                static_cast<size_t>(n), 0, bits, stream) != hipSuccess)
       return -2;
     return detect_runs<uint32_t, UKey>(l.sorted, l.tile_counts, n, static_cast<UKey*>(unique_ids), run_starts, n_unique_out,
-                                       stream);
+                                       stream, static_cast<UKey>(key_lower_bound));
   }
   auto l    = layout<UKey>(workspace, n);
   size_t tb = l.temp_bytes;
@@ -1345,7 +1352,7 @@ size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype)
   return layout<uint64_t>(nullptr, n).total;
 }
 
-int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound,
+int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, int64_t key_lower_bound,
                   void* unique_ids, int32_t* run_starts, int32_t* order, int64_t* n_unique_out, void* workspace,
                   void* stream_v)
 {
@@ -1353,9 +1360,9 @@ int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, i
   if (n >= (1ll << 31)) return -1;  // reference casts the receive count to int (exchange_embeddings_nccl_func.cu:118)
   if (n == 0) return hipMemsetAsync(n_unique_out, 0, sizeof(int64_t), stream) == hipSuccess ? 0 : -2;
   if (index_dtype == WHOLEMEMORY_DT_INT)
-    return run_dedup<int32_t>(ids, n, key_upper_bound, unique_ids, run_starts, order, n_unique_out, workspace, stream);
+    return run_dedup<int32_t>(ids, n, key_upper_bound, key_lower_bound, unique_ids, run_starts, order, n_unique_out, workspace, stream);
   if (index_dtype == WHOLEMEMORY_DT_INT64)
-    return run_dedup<int64_t>(ids, n, key_upper_bound, unique_ids, run_starts, order, n_unique_out, workspace, stream);
+    return run_dedup<int64_t>(ids, n, key_upper_bound, key_lower_bound, unique_ids, run_starts, order, n_unique_out, workspace, stream);
   return -1;
 }
 

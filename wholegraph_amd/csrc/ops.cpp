@@ -458,7 +458,7 @@ wholememory_error_code_t gather_distributed_dedup(wholememory_handle_t handle, c
   auto* d_nunique = static_cast<int64_t*>(n_unique.device(1, WHOLEMEMORY_DT_INT64));
   void* d_ws = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n, d.indices.dtype)), WHOLEMEMORY_DT_INT8);
   // full-width keys: negative ("skip me") ids must stay distinct from every valid id; as unsigned keys they sort last
-  int rc = bk->dedup_ids(d.indices_ptr, d.indices.dtype, n, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
+  int rc = bk->dedup_ids(d.indices_ptr, d.indices.dtype, n, 0, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
   if (rc != 0) throw hip_error("dedup of the requested ids failed");  // not a return: the peers are committed to the exchange
 
   // (1) owner segments of the distinct ids + the ids exchange; the host learns the counts in the exchange's one sync
@@ -735,7 +735,7 @@ wholememory_error_code_t gather_hierarchy(wholememory_handle_t handle, const op_
     auto* d_order   = static_cast<int32_t*>(order.device(n_relay, WHOLEMEMORY_DT_INT));
     auto* d_nunique = static_cast<int64_t*>(n_unique.device(1, WHOLEMEMORY_DT_INT64));
     void* d_ws = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n_relay, d.indices.dtype)), WHOLEMEMORY_DT_INT8);
-    int rc = bk->dedup_ids(xa.recv_ids, d.indices.dtype, n_relay, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
+    int rc = bk->dedup_ids(xa.recv_ids, d.indices.dtype, n_relay, 0, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
     if (rc != 0) throw hip_error("dedup of relayed ids failed");  // not a return: the peers are already committed to hop B
     inv = static_cast<int64_t*>(inverse.device(n_relay, WHOLEMEMORY_DT_INT64));
     WM_BK(bk->run_inverse(d_starts, d_order, d_unique, d.indices.dtype, d_nunique, n_relay, inv, stream));
