@@ -21,36 +21,32 @@ from .utils import (
     str_to_wmb_wholememory_location,
 )
 
-global_communicators = {}
-local_node_communicator = None
-local_device_communicator = None
-local_mnnvl_communicator = None
+class _JobTopology(object):
+    """What this process knows about the job (ranks / ranks per node, told by init()) and the communicators already built
+    for the three standard scopes. A scope that coincides with another one (a single-node job: node == world; a single-GPU
+    job: device == node == world) shares that communicator instead of building a second one."""
 
-all_comm_world_rank = 0
-all_comm_world_size = 1
-all_comm_local_rank = 0
-all_comm_local_size = 1
+    def __init__(self):
+        self.world_rank, self.world_size, self.local_rank, self.local_size = 0, 1, 0, 1
+        self.world = {}        # distributed backend name -> communicator over every rank
+        self.node = None       # ranks of this node
+        self.device = None     # this rank alone
+        self.mnnvl = None
+
+    def scope_sizes(self):
+        return {"world": self.world_size, "node": self.local_size, "device": 1}
+
+
+_job = _JobTopology()
 
 
 def reset_communicators():
-    global all_comm_world_rank, all_comm_world_size, all_comm_local_rank, all_comm_local_size
-    global global_communicators, local_node_communicator, local_device_communicator, local_mnnvl_communicator
-    global_communicators = {}
-    local_node_communicator = None
-    local_device_communicator = None
-    local_mnnvl_communicator = None
-    all_comm_world_rank = 0
-    all_comm_world_size = 1
-    all_comm_local_rank = 0
-    all_comm_local_size = 1
+    global _job
+    _job = _JobTopology()
 
 
 def set_world_info(world_rank, world_size, local_rank, local_size):
-    global all_comm_world_rank, all_comm_world_size, all_comm_local_rank, all_comm_local_size
-    all_comm_world_rank = world_rank
-    all_comm_world_size = world_size
-    all_comm_local_rank = local_rank
-    all_comm_local_size = local_size
+    _job.world_rank, _job.world_size, _job.local_rank, _job.local_size = world_rank, world_size, local_rank, local_size
 
 
 class WholeMemoryCommunicator(object):
@@ -208,13 +204,13 @@ def create_group_communicator(group_size=-1, comm_stride=1):
     world_rank = dist.get_rank() if dist.is_initialized() else 0
     if group_size == -1:
         group_size = world_size
-    strided_group_size = group_size * comm_stride
-    assert world_size % strided_group_size == 0
-    strided_group_count = world_size // strided_group_size
-    strided_group_idx = world_rank // strided_group_size
-    idx_in_strided_group = world_rank % strided_group_size
-    inner_group_idx = idx_in_strided_group % comm_stride
-    idx_in_group = idx_in_strided_group // comm_stride
+    # The world is cut into blocks of group_size * comm_stride consecutive ranks; inside a block, the ranks congruent modulo
+    # comm_stride form one group (block b, lane l: ranks b * block + l + k * comm_stride, k = 0 .. group_size - 1).
+    block = group_size * comm_stride
+    assert world_size % block == 0, "group_size * comm_stride must divide the world size"
+    n_blocks = world_size // block
+    my_block, within_block = divmod(world_rank, block)
+    my_pos, my_lane = divmod(within_block, comm_stride)      # position inside my group, which of the block's groups
     L = wmb.lib()
     comm = C.c_void_p()
     import os
@@ -229,29 +225,29 @@ def create_group_communicator(group_size=-1, comm_stride=1):
     if not _use_rccl_transport():
         # host-framework collectives (gloo etc.): one torch process group per wholememory group
         my_group, my_ranks = None, None
-        for sg in range(strided_group_count):
-            for ig in range(comm_stride):
-                ranks = [sg * strided_group_size + ig + k * comm_stride for k in range(group_size)]
+        for b in range(n_blocks):
+            for lane in range(comm_stride):
+                ranks = [b * block + lane + k * comm_stride for k in range(group_size)]
                 g = dist.new_group(ranks=ranks) if world_size != group_size else None
-                if sg == strided_group_idx and ig == inner_group_idx:
+                if b == my_block and lane == my_lane:
                     my_group, my_ranks = g, ranks
         device_is_host = L.wholememory_ext_backend_name() != b"hip-gfx950"
-        coll = _TorchDistCollectives(my_group, idx_in_group, group_size, device_is_host)
-        wmb.check(L.wholememory_create_communicator_ext(C.byref(comm), idx_in_group, group_size, C.byref(coll.table)))
+        coll = _TorchDistCollectives(my_group, my_pos, group_size, device_is_host)
+        wmb.check(L.wholememory_create_communicator_ext(C.byref(comm), my_pos, group_size, C.byref(coll.table)))
         return WholeMemoryCommunicator(comm, keepalive=coll)
     my_uid = wmb.UniqueId()
-    for sg in range(strided_group_count):
-        for ig in range(comm_stride):
-            root = sg * strided_group_size + ig
+    for b in range(n_blocks):
+        for lane in range(comm_stride):
+            root = b * block + lane
             tmp = wmb.UniqueId()
             if world_rank == root:
                 wmb.check(L.wholememory_create_unique_id(C.byref(tmp)))
             uid_t = torch.frombuffer(bytearray(C.string_at(C.byref(tmp), wmb.UNIQUE_ID_BYTES)), dtype=torch.uint8).cuda()
             dist.broadcast(uid_t, root)
-            if sg == strided_group_idx and ig == inner_group_idx:
+            if b == my_block and lane == my_lane:
                 raw = bytes(uid_t.cpu().numpy().tobytes())
                 C.memmove(C.byref(my_uid), raw, wmb.UNIQUE_ID_BYTES)
-    wmb.check(L.wholememory_create_communicator(C.byref(comm), my_uid, idx_in_group, group_size))
+    wmb.check(L.wholememory_create_communicator(C.byref(comm), my_uid, my_pos, group_size))
     return WholeMemoryCommunicator(comm)
 
 
@@ -276,52 +272,56 @@ def comm_set_distributed_backend(wm_comm, distributed_backend):
 
 
 def get_global_communicator(distributed_backend="nccl"):
-    """Communicator spanning every rank of the job. reference comm.py:197-218."""
-    global global_communicators, local_node_communicator, local_device_communicator
-    if distributed_backend not in global_communicators:
-        global_communicator = create_group_communicator()
-        comm_set_distributed_backend(global_communicator, distributed_backend)
-        global_communicators[distributed_backend] = global_communicator
-        if distributed_backend == "nccl":
-            if local_node_communicator is None and all_comm_local_size == all_comm_world_size:
-                local_node_communicator = global_communicator
-            if local_device_communicator is None and all_comm_world_size == 1:
-                local_device_communicator = global_communicator
-    return global_communicators[distributed_backend]
+    """Communicator over every rank of the job (one per distributed backend name; reference comm.py:197-218)."""
+    comm = _job.world.get(distributed_backend)
+    if comm is None:
+        comm = create_group_communicator()
+        comm_set_distributed_backend(comm, distributed_backend)
+        _job.world[distributed_backend] = comm
+        if distributed_backend == "nccl":           # the node / device scopes only ever use this backend
+            sizes = _job.scope_sizes()
+            if _job.node is None and sizes["node"] == sizes["world"]:
+                _job.node = comm
+            if _job.device is None and sizes["world"] == 1:
+                _job.device = comm
+    return comm
 
 
 def get_local_node_communicator():
-    global global_communicators, local_node_communicator, local_device_communicator
-    if local_node_communicator is None:
-        local_node_communicator = create_group_communicator(all_comm_local_size)
-        if all_comm_local_size == all_comm_world_size:
-            assert "nccl" not in global_communicators
-            global_communicators["nccl"] = local_node_communicator
-        if all_comm_local_size == 1:
-            assert local_device_communicator is None
-            local_device_communicator = local_node_communicator
-    return local_node_communicator
+    """Communicator over the ranks of this node."""
+    if _job.node is None:
+        sizes = _job.scope_sizes()
+        _job.node = create_group_communicator(sizes["node"])
+        if sizes["node"] == sizes["world"]:
+            assert "nccl" not in _job.world
+            _job.world["nccl"] = _job.node
+        if sizes["node"] == 1:
+            assert _job.device is None
+            _job.device = _job.node
+    return _job.node
 
 
 def get_local_device_communicator():
-    global global_communicators, local_node_communicator, local_device_communicator
-    if local_device_communicator is None:
-        local_device_communicator = create_group_communicator(1)
-        if all_comm_local_size == 1:
-            assert local_node_communicator is None
-            local_node_communicator = local_device_communicator
-        if all_comm_world_size == 1:
-            assert "nccl" not in global_communicators
-            global_communicators["nccl"] = local_device_communicator
-    return local_device_communicator
+    """Communicator of this rank alone."""
+    if _job.device is None:
+        sizes = _job.scope_sizes()
+        _job.device = create_group_communicator(1)
+        if sizes["node"] == 1:
+            assert _job.node is None
+            _job.node = _job.device
+        if sizes["world"] == 1:
+            assert "nccl" not in _job.world
+            _job.world["nccl"] = _job.device
+    return _job.device
 
 
 def get_local_mnnvl_communicator():
-    global local_mnnvl_communicator
-    if local_mnnvl_communicator is None:
-        g = get_global_communicator()
-        is_in_clique, _, _, _, clique_id, _ = g.get_clique_info()
-        if not is_in_clique:
+    """Ranks of this rank's multi-node NVLink clique — there is no such domain on MI355X nodes: the clique query answers
+    "not in a clique" and this raises like the reference does on such a system."""
+    if _job.mnnvl is None:
+        world = get_global_communicator()
+        in_clique, _, _, _, clique_id, _ = world.get_clique_info()
+        if not in_clique:
             raise RuntimeError("the gpu does not belong to any mnnvl domain,can not create local_mnnvl_communicator")
-        local_mnnvl_communicator = split_communicator(g, clique_id)
-    return local_mnnvl_communicator
+        _job.mnnvl = split_communicator(world, clique_id)
+    return _job.mnnvl

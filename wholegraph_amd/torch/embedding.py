@@ -234,57 +234,61 @@ class WholeMemoryEmbedding(object):
             self.get_optimizer_state(state_name).from_file_prefix(file_prefix + "_" + state_name, part_count)
 
 
+def _reconcile_sharding(embedding_entry_partition, cache_policy, round_robin_size):
+    """The three ways to say where rows live exclude each other: a cache policy decides for itself, an explicit per-rank
+    partition wins over round-robin sharding. Returns (partition, round_robin_size) after dropping what is overridden, with
+    the reference's notices."""
+    if embedding_entry_partition is not None and cache_policy is not None:
+        print("embedding_entry_partition is ignored because cache_policy is specified")
+        embedding_entry_partition = None
+    if embedding_entry_partition is not None and round_robin_size:
+        print("round_robin_size is ignored because embedding_entry_partition is specified")
+        round_robin_size = 0
+    return embedding_entry_partition, round_robin_size
+
+
 def create_embedding(comm: WholeMemoryCommunicator, memory_type: str, memory_location: str, dtype: torch.dtype,
                      sizes: List[int], *, cache_policy: Union[WholeMemoryCachePolicy, None] = None,
                      embedding_entry_partition: Union[List[int], None] = None, random_init: bool = False,
                      gather_sms: int = -1, round_robin_size: int = 0):
-    """Collective. sizes must be 2-D. reference embedding.py:380-459."""
-    assert len(sizes) == 2
-    if embedding_entry_partition is not None and cache_policy is not None:
-        print("embedding_entry_partition is ignored because cache_policy is specified")
-        embedding_entry_partition = None
-    if embedding_entry_partition is not None and round_robin_size != 0:
-        print("round_robin_size is ignored because embedding_entry_partition is specified")
-        round_robin_size = 0
-    desc = wmb.make_tensor_desc(list(sizes), torch_dtype_to_wholememory_dtype(dtype), [sizes[1], 1], 0)
-    e = C.c_void_p()
+    """Collective over `comm`: a [rows, dim] embedding table (reference embedding.py:380-459, same arguments).
+    embedding_entry_partition: rows per rank (default: equal shares); round_robin_size: rows per round-robin block when the
+    table is filled from files in round-robin order; gather_sms: cap on the workgroups of the gather kernels (-1: default)."""
+    rows, dim = sizes                                            # exactly two dimensions
+    partition, round_robin_size = _reconcile_sharding(embedding_entry_partition, cache_policy, round_robin_size)
+    description = wmb.make_tensor_desc([rows, dim], torch_dtype_to_wholememory_dtype(dtype), [dim, 1], 0)
+    handle = C.c_void_p()
     wmb.check(wmb.lib().wholememory_create_embedding(
-        C.byref(e), C.byref(desc), comm.wmb_comm, str_to_wmb_wholememory_memory_type(memory_type),
-        str_to_wmb_wholememory_location(memory_location),
-        cache_policy.wmb_cache_policy if cache_policy is not None else None,
-        wmb.size_t_array(embedding_entry_partition), gather_sms, round_robin_size))
-    wm_embedding = WholeMemoryEmbedding(e, cache_policy)
-    if random_init is True:
-        local_tensor, _ = wm_embedding.get_embedding_tensor().get_local_tensor()
-        if local_tensor.numel() > 0:
-            torch.nn.init.xavier_uniform_(local_tensor)
+        C.byref(handle), C.byref(description), comm.wmb_comm, str_to_wmb_wholememory_memory_type(memory_type),
+        str_to_wmb_wholememory_location(memory_location), cache_policy.wmb_cache_policy if cache_policy else None,
+        wmb.size_t_array(partition), gather_sms, round_robin_size))
+    embedding = WholeMemoryEmbedding(handle, cache_policy)
+    if random_init:
+        shard, _ = embedding.get_embedding_tensor().get_local_tensor()
+        if shard.numel():
+            torch.nn.init.xavier_uniform_(shard)
     comm.barrier()
-    return wm_embedding
+    return embedding
 
 
 def create_embedding_from_filelist(comm, memory_type, memory_location, filelist, dtype, last_dim_size, *,
                                    cache_policy=None, embedding_entry_partition=None, gather_sms=-1,
                                    round_robin_size=0):
-    if isinstance(filelist, str):
-        filelist = [filelist]
-    assert last_dim_size > 0
-    if embedding_entry_partition is not None and round_robin_size != 0:
-        print("round_robin_size is ignored because embedding_entry_partition is specified")
-        round_robin_size = 0
-    element_size = torch.tensor([], dtype=dtype).element_size()
-    file_entry_size = element_size * last_dim_size
-    total_file_size = 0
-    for filename in filelist:
-        file_size = get_file_size(filename)
-        if file_size % file_entry_size != 0:
-            raise ValueError("File %s size is %d not mutlple of %d" % (filename, file_size, file_entry_size))
-        total_file_size += file_size
-    total_entry_count = total_file_size // file_entry_size
-    wm_embedding = create_embedding(comm, memory_type, memory_location, dtype, [total_entry_count, last_dim_size],
-                                    cache_policy=cache_policy, embedding_entry_partition=embedding_entry_partition,
-                                    gather_sms=gather_sms, round_robin_size=round_robin_size)
-    wm_embedding.get_embedding_tensor().from_filelist(filelist, round_robin_size)
-    return wm_embedding
+    """An embedding sized after, and filled from, raw row-major files of `last_dim_size`-wide rows (one file or a list)."""
+    files = [filelist] if isinstance(filelist, str) else list(filelist)
+    if last_dim_size <= 0:
+        raise ValueError("last_dim_size must be positive")
+    partition, round_robin_size = _reconcile_sharding(embedding_entry_partition, None, round_robin_size)
+    row_bytes = torch.empty(0, dtype=dtype).element_size() * last_dim_size
+    sizes = {name: get_file_size(name) for name in files}
+    ragged = [name for name, nbytes in sizes.items() if nbytes % row_bytes]
+    if ragged:
+        raise ValueError("File %s size is %d not mutlple of %d" % (ragged[0], sizes[ragged[0]], row_bytes))
+    embedding = create_embedding(comm, memory_type, memory_location, dtype, [sum(sizes.values()) // row_bytes, last_dim_size],
+                                 cache_policy=cache_policy, embedding_entry_partition=partition, gather_sms=gather_sms,
+                                 round_robin_size=round_robin_size)
+    embedding.get_embedding_tensor().from_filelist(files, round_robin_size)
+    return embedding
 
 
 def destroy_embedding(wm_embedding: WholeMemoryEmbedding):
@@ -308,18 +312,18 @@ class WholeMemoryEmbeddingModule(torch.nn.Module):
 
 
 def create_wholememory_optimizer(embeddings, optimizer_type: str, param_dict: dict):
-    wm_optimizer = WholeMemoryOptimizer(get_global_communicator())
-    wmb.check(wmb.lib().wholememory_create_embedding_optimizer(
-        C.byref(wm_optimizer.wmb_opt), str_to_wmb_wholememory_optimizer_type(optimizer_type)))
-    for k, v in (param_dict or {}).items():
-        val = C.c_float(float(v))
-        wmb.check(wmb.lib().wholememory_optimizer_set_parameter(wm_optimizer.wmb_opt, k.encode(), C.byref(val)))
-    if isinstance(embeddings, WholeMemoryEmbedding):
-        wm_optimizer.add_embedding(embeddings)
-    else:
-        for em in embeddings:
-            wm_optimizer.add_embedding(em)
-    return wm_optimizer
+    """One sparse optimizer ("sgd" | "adam" | "adagrad" | "rmsprop") for an embedding or a list of them; param_dict holds the
+    hyper-parameters by the reference's names (weight_decay, epsilon, beta1, beta2, alpha, adam_w)."""
+    optimizer = WholeMemoryOptimizer(get_global_communicator())
+    kind = str_to_wmb_wholememory_optimizer_type(optimizer_type)
+    wmb.check(wmb.lib().wholememory_create_embedding_optimizer(C.byref(optimizer.wmb_opt), kind))
+    for name, value in (param_dict or {}).items():
+        boxed = C.c_float(float(value))
+        wmb.check(wmb.lib().wholememory_optimizer_set_parameter(optimizer.wmb_opt, name.encode(), C.byref(boxed)))
+    targets = [embeddings] if isinstance(embeddings, WholeMemoryEmbedding) else list(embeddings)
+    for target in targets:
+        optimizer.add_embedding(target)
+    return optimizer
 
 
 def destroy_wholememory_optimizer(optimizer: WholeMemoryOptimizer):
