@@ -467,9 +467,13 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   else
     dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa, static_cast<int64_t>(entry_offsets[rank + 1]), env, stream,
                    nullptr, rows_arrived, self_direct ? &self_ref : nullptr, static_cast<int64_t>(entry_offsets[rank]));
-  // temporaries go back to the caller's allocator on return; like the reference's distributed ops
-  // the stream is drained first so nothing in flight still reads them
-  WM_BK(bk->stream_sync(stream));
+  // The reference returns with the optimizer kernels still queued (embedding.cpp:318-323: its scratch goes back to the env
+  // allocator, which is stream-ordered — include/wholememory/env_func_ptrs.h states that contract). The same here on ONE
+  // rank: no trailing synchronise, so a training loop's next step is prepared while this one runs (the end-of-call bubble
+  // was ~0.1 ms of a 3.2 ms step). With several ranks the stream is drained before returning: a peer may read this shard
+  // through its own mapping (CHUNKED / CONTINUOUS) right after the barrier that follows the step, and that barrier orders
+  // hosts, not this stream.
+  if (e->comm->world_size > 1 || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
   return WHOLEMEMORY_SUCCESS;
 }
 
