@@ -482,7 +482,9 @@ wholememory_error_code_t gather_distributed_dedup(wholememory_handle_t handle, c
   fill_rows_args(&ea, wholememory_create_continuous_global_reference(uniq_rows), du.plain, inv, WHOLEMEMORY_DT_INT64, n,
                  d.plain_ptr, d.plain, gather_sms);
   WM_BK(bk->gather_rows(&ea, stream));
-  WM_BK(bk->stream_sync(stream));  // scratch buffers return to the caller's allocator
+  // like the plain route, this one returns with its last kernels queued: the scratch goes back to the caller's
+  // stream-ordered allocator (env_func_ptrs.h), and the side stream of the pipelined exchange was fenced by its last event
+  if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
   return WHOLEMEMORY_SUCCESS;
 }
 
