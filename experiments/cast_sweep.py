@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Side measurement: gather / scatter WITH a dtype cast (table dtype != plain dtype), 8 GB table, 10 M ids.
+python experiments/cast_sweep.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import wholegraph_amd.torch as wgth
+from wholegraph_amd import binding as wmb
+wmb.check(wmb.lib().wholememory_init(0, wmb.LEVEL_WARN))
+comm = wgth.create_group_communicator(1)
+es = {torch.float32: 4, torch.float16: 2, torch.bfloat16: 2}
+for tdt, odt, dim in [(torch.float16, torch.float32, 128), (torch.float16, torch.float32, 256), (torch.float32, torch.float16, 128),
+                      (torch.bfloat16, torch.float32, 128), (torch.float16, torch.float16, 256), (torch.float16, torch.float32, 100)]:
+    rows = int(8e9 // (dim * es[tdt]))
+    n = 10_000_000
+    emb = wgth.create_embedding(comm, "chunked", "cuda", tdt, [rows, dim])
+    t = emb.get_embedding_tensor()
+    idx = torch.randint(0, rows, (n,), device="cuda")
+    out = torch.empty((n, dim), dtype=odt, device="cuda")
+    for op in ("gather", "scatter"):
+        fn = (lambda: emb.gather(idx, force_dtype=odt, out=out)) if op == "gather" else (lambda: t.scatter(out, idx))
+        best = 1e9
+        for r in range(3):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+        gb = n * (8 + dim * es[tdt] + dim * es[odt]) / 1e9
+        k = wmb.lib().wholememory_ext_last_rows_kernel().decode().split("::")[-1].split("(")[0]
+        print("%-7s %s -> %s dim %d: %.3f ms  %.1f%% of 8 TB/s algorithmic  [%s]" % (
+            op, str(tdt).split(".")[1], str(odt).split(".")[1], dim, best, gb / best / 8.0 * 100, k))
+    wgth.destroy_embedding(emb)

@@ -58,17 +58,17 @@ int main(int argc, char** argv)
   while ((N - 1) >> bits) bits++;
   run<rocprim::default_config>("default", d_ids, d_sorted, d_order, n, bits, temp, cap);
   run<rocprim::default_config>("default, 32 bits", d_ids, d_sorted, d_order, n, 32, temp, cap);
-  run<osw<1024, 12, 8>>("onesweep match <1024,12> 8 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
-  run<osw<1024, 8, 8>>("onesweep match <1024,8> 8 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
-  run<osw<1024, 16, 8>>("onesweep match <1024,16> 8 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
-  run<osw<512, 12, 8>>("onesweep match <512,12> 8 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
-  run<osw<512, 16, 8>>("onesweep match <512,16> 8 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
-  run<osw<1024, 12, 9>>("onesweep match <1024,12> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
   run<osw<1024, 8, 9>>("onesweep match <1024,8> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
-  run<osw<512, 12, 9>>("onesweep match <512,12> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
-  run<osw<512, 16, 9>>("onesweep match <512,16> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
+  run<osw<1024, 7, 9>>("onesweep match <1024,7> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
   run<osw<1024, 6, 9>>("onesweep match <1024,6> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
-  run<osw<1024, 12, 7>>("onesweep match <1024,12> 7 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
-  run<osw<1024, 16, 7>>("onesweep match <1024,16> 7 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
+  run<osw<1024, 10, 9>>("onesweep match <1024,10> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
+  run<osw<768, 8, 9>>("onesweep match <768,8> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
+  run<osw<512, 8, 9>>("onesweep match <512,8> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
+  run<osw<512, 10, 9>>("onesweep match <512,10> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
+  run<osw<256, 16, 9>>("onesweep match <256,16> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
+  run<osw<1024, 4, 9>>("onesweep match <1024,4> 9 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
+  run<osw<1024, 8, 10>>("onesweep match <1024,8> 10 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
+  run<osw<512, 8, 10>>("onesweep match <512,8> 10 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
+  run<osw<1024, 4, 10>>("onesweep match <1024,4> 10 bits/pass", d_ids, d_sorted, d_order, n, bits, temp, cap);
   return 0;
 }
