@@ -31,7 +31,7 @@ for tdt, odt, dim in [(torch.float16, torch.float32, 128), (torch.float16, torch
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
         gb = n * (8 + dim * es[tdt] + dim * es[odt]) / 1e9
-        k = wmb.lib().wholememory_ext_last_rows_kernel().decode().split("::")[-1].split("(")[0]
+        k = re.search(r"(rows_\w+<[^(]*>)\(", wmb.lib().wholememory_ext_last_rows_kernel().decode()).group(1)
         print("%-7s %s -> %s dim %d: %.3f ms  %.1f%% of 8 TB/s algorithmic  [%s]" % (
             op, str(tdt).split(".")[1], str(odt).split(".")[1], dim, best, gb / best / 8.0 * 100, k))
     wgth.destroy_embedding(emb)

@@ -4,6 +4,7 @@
 --ab: every (shape, op) is measured with WM_ROWS_FLAT=0 and =1 as well as the default rule, interleaved over 5 rounds of 10
 launches, and the MIN over rounds is reported (a shared box drifts by 10-20 % between back-to-back runs of one setting)."""
 import os
+import re
 import sys
 import time
 
@@ -64,7 +65,7 @@ def main():
                         fn()
                     torch.cuda.synchronize()
                     times[name].append((time.perf_counter() - t0) / 10 * 1e3)
-                    kernels[name] = wmb.lib().wholememory_ext_last_rows_kernel().decode().split("::")[-1].split("(")[0]
+                    kernels[name] = re.search(r"(rows_\w+<[^(]*>)\(", wmb.lib().wholememory_ext_last_rows_kernel().decode()).group(1)
             os.environ.pop("WM_ROWS_FLAT", None)
             os.environ.pop("WM_ROWS_TILE", None)
             os.environ.pop("WM_ROWS_STAGED", None)
