@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Side measurement: gather / scatter WITH a dtype cast (table dtype != plain dtype), 8 GB table, 10 M ids.
 python experiments/cast_sweep.py"""
-import os, sys, time
+import os, re, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
