@@ -185,18 +185,27 @@ int t_bucket(const wm_bucket_args* a, void*)
 }
 
 size_t t_dedup_ws(int64_t, wholememory_dtype_t) { return 64; }
-int t_dedup(const void* ids, wholememory_dtype_t dt, int64_t n, int64_t, int64_t, void* unique_ids, int32_t* run_starts,
+int t_dedup(const void* ids, wholememory_dtype_t dt, int64_t n, int64_t upper, int64_t lower, void* unique_ids, int32_t* run_starts,
             int32_t* order, int64_t* n_unique_out, void*, void*)
 {
   std::vector<int32_t> ord(n);
   for (int64_t i = 0; i < n; i++) ord[i] = static_cast<int32_t>(i);
-  // the kernels' order: the ids' two's-complement bits as UNSIGNED keys — negative ("skip me") ids after every valid id
+  if (upper <= 0 || lower < 0 || lower >= upper) lower = 0;
+  // a bounded range narrower than 2^32 - 1 rows: ids outside it are dropped from the runs (backend.hpp)
+  const bool drops = upper > 0 && upper - lower < INT64_C(0xFFFFFFFF);
+  auto outside     = [&](int64_t id) { return drops && (id < lower || id >= upper); };
+  // the kernels' order: the ids' two's-complement bits as UNSIGNED keys — negative ("skip me") ids after every valid id;
+  // dropped ids behind everything, in their original order
   std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
-    return static_cast<uint64_t>(idx_at(ids, dt, x)) < static_cast<uint64_t>(idx_at(ids, dt, y));
+    const int64_t a = idx_at(ids, dt, x), b = idx_at(ids, dt, y);
+    if (outside(a) || outside(b)) return !outside(a) && outside(b);
+    return static_cast<uint64_t>(a) < static_cast<uint64_t>(b);
   });
-  int64_t nu = 0;
+  int64_t nu = 0, kept = 0;
   for (int64_t i = 0; i < n; i++) {
     order[i] = ord[i];
+    if (outside(idx_at(ids, dt, ord[i]))) continue;
+    kept = i + 1;
     if (i == 0 || idx_at(ids, dt, ord[i]) != idx_at(ids, dt, ord[i - 1])) {
       if (dt == WHOLEMEMORY_DT_INT)
         static_cast<int32_t*>(unique_ids)[nu] = static_cast<int32_t>(idx_at(ids, dt, ord[i]));
@@ -206,7 +215,7 @@ int t_dedup(const void* ids, wholememory_dtype_t dt, int64_t n, int64_t, int64_t
       nu++;
     }
   }
-  run_starts[nu] = static_cast<int32_t>(n);
+  run_starts[nu] = static_cast<int32_t>(kept);
   *n_unique_out  = nu;
   return 0;
 }

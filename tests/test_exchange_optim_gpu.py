@@ -312,18 +312,21 @@ def test_save_load_roundtrip(gpu_env, tmp_path):
     wgth.destroy_embedding(emb)
 
 
-@pytest.mark.parametrize("with_negatives", [False, True])
-def test_gradient_apply_ignores_negative_ids(gpu_env, with_negatives):
+@pytest.mark.parametrize("idt", [np.int64, np.int32])
+@pytest.mark.parametrize("with_negatives", [False, True, "past_end", "only_junk"])
+def test_gradient_apply_ignores_negative_ids(gpu_env, with_negatives, idt):
     """Negative ids are dropped by the bucketing (bucket_ids_func.cu:73): a batch with such entries must leave the table
-    exactly as the same batch without them does. Without negatives a single rank takes the no-staging path (the caller's
-    ids and gradient rows used in place); with them it takes the general one — both against the same expectation."""
+    exactly as the same batch without them does. A single rank uses the caller's ids and gradient rows in place and drops
+    the ids that address no row inside the owner-side sort (they read as one marker key behind every row) — negative ones,
+    and ("past_end") ids beyond the table; "only_junk": a batch of nothing else leaves the table untouched."""
     import torch
     import wholegraph_amd.torch as wgth
     n_rows, dim, n = 50021, 64, 30000
     rng = np.random.default_rng(9)
     init = rng.standard_normal((n_rows, dim)).astype(np.float32)
-    ids = rng.integers(0, n_rows, n).astype(np.int64)
+    ids = rng.integers(0, n_rows, n).astype(idt)
     ids[:500] = ids[7]                                   # a long run too
+    ids[500:520] = n_rows - 1                            # the last row: next to the marker key
     grads = rng.standard_normal((n, dim)).astype(np.float32)
 
     def run(batch_ids, batch_grads):
@@ -339,13 +342,22 @@ def test_gradient_apply_ignores_negative_ids(gpu_env, with_negatives):
         wgth.destroy_embedding(emb)
         return out
 
+    if with_negatives == "only_junk":
+        junk = np.array([-1, -7, n_rows, n_rows + 3, np.iinfo(idt).max, np.iinfo(idt).min] * 50, dtype=idt)
+        got = run(junk, np.full((len(junk), dim), 1e9, dtype=np.float32))
+        assert got.tobytes() == init.tobytes()
+        return
     want = run(ids, grads)
     if with_negatives:
         pos = np.sort(rng.choice(n + 700, 700, replace=False))
-        # interleave 700 negative entries (with junk gradient rows) at random positions, order of the rest unchanged
+        # interleave 700 junk entries (with junk gradient rows) at random positions, order of the rest unchanged
         keep = np.ones(n + 700, dtype=bool)
         keep[pos] = False
-        mixed_ids = np.full(n + 700, -1, dtype=np.int64)
+        mixed_ids = np.full(n + 700, -1, dtype=idt)
+        if with_negatives == "past_end":
+            mixed_ids[pos[::3]] = n_rows
+            mixed_ids[pos[1::3]] = np.iinfo(idt).max
+            mixed_ids[pos[2::3]] = n_rows + 12345
         mixed_ids[keep] = ids
         mixed_grads = np.full((n + 700, dim), 1e9, dtype=np.float32)
         mixed_grads[keep] = grads
@@ -353,7 +365,7 @@ def test_gradient_apply_ignores_negative_ids(gpu_env, with_negatives):
     else:
         got = run(ids.copy(), grads.copy())
     assert got.tobytes() == want.tobytes()
-    uniq, dg = oracle.dedup_grads(ids, grads)
+    uniq, dg = oracle.dedup_grads(ids.astype(np.int64), grads)
     ref = init.copy()
     oracle.Optimizer("sgd", n_rows, dim, weight_decay=0.01).step(uniq, dg, ref, dim, 0, dim, 0.05)
     assert want.tobytes() == ref.tobytes()

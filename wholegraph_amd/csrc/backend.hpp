@@ -168,12 +168,15 @@ struct wm_device_backend {
   size_t (*bucket_workspace_bytes)(int64_t n, int world_size);
   int (*bucket_ids)(const wm_bucket_args* a, void* stream);
   // stable sort of the ids by their two's-complement bits as UNSIGNED keys (valid ids ascending, negative ids after all
-  // of them), emit unique ids, run starts and the sorted order. key_upper_bound > 0: every id is in [0, bound).
-  // n_unique_out is a device int64. workspace from sort_workspace_bytes(n).
+  // of them), emit unique ids, run starts and the sorted order. n_unique_out is a device int64. workspace from
+  // dedup_workspace_bytes(n).
   size_t (*dedup_workspace_bytes)(int64_t n, wholememory_dtype_t index_dtype);
-  // key_lower_bound (with key_upper_bound > 0): every id is in [lower, upper) — the owner's own row range; a backend may
-  // sort id - lower and so need fewer key bits (a 125 M-row shard of a 1 B-row table: 27 instead of 30 bits, 3 radix passes
-  // instead of 4). The outputs are the ids themselves either way.
+  // key_upper_bound > 0 (key_lower_bound defaults to 0): the ids of interest are those in [lower, upper) — the owner's own
+  // row range; a backend may sort id - lower and so need fewer key bits (a 125 M-row shard of a 1 B-row table: 27 instead
+  // of 30 bits, 3 radix passes instead of 4). The outputs are the ids themselves either way. Ids OUTSIDE the range
+  // (negative "skip me" ids, ids past the table) are left out of the runs when upper - lower < 2^32 - 1: they are not
+  // counted in n_unique_out, and their positions fill the tail of `order` behind the last run (run_starts[n_unique] = where
+  // that tail starts). For a wider range every id must lie inside it.
   int (*dedup_ids)(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, int64_t key_lower_bound,
                    void* unique_ids, int32_t* run_starts, int32_t* order, int64_t* n_unique_out, void* workspace,
                    void* stream);

@@ -297,33 +297,17 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   const bool self_local     = !e->comm->loopback;  // loopback: the self segment is exchanged like a peer's
   const bool self_in_place  = self_local && bk->remap_self_order != nullptr &&
                              !(self_copy_env != nullptr && self_copy_env[0] == '1');
-  // One rank, nothing to exchange: the batch is the receive buffer as it stands — unless it holds negative ("skip me")
-  // ids, which only a pass over the ids can tell. That pass (a histogram) and the host's look at its result used to sit in
-  // front of everything else; now the sort of the ids is queued right behind the histogram, SPECULATING that nothing is
-  // dropped, and the host synchronises while the sort runs. A batch with negative ids throws the sorted view away and takes
-  // the general route below.
+  // One rank, nothing to exchange: the batch IS the receive buffer, the caller's gradient tensor IS the row buffer. Ids that
+  // address no row (negative "skip me" ids, ids past the table) are dropped by the sort itself — they read as one marker key
+  // that sorts behind every row and whose run is not counted (backend.hpp: dedup_ids) — so no pass over the ids and no look
+  // at a count by the host stands in front of the sort (that was a histogram, two small copies and a host synchronise:
+  // ~45 us of a 3.2 ms call, and the host can now queue the next call while this one runs).
   std::unique_ptr<dedup_result> early;
-  if (self_in_place && e->comm->single_rank_direct() && iarr.size > 0 && iarr.size < (INT64_C(1) << 31)) {
-    temp_mem d_off_mem(env), d_cnt_mem(env), h_mem(env), ws_mem(env);
-    auto* d_off = static_cast<uint64_t*>(d_off_mem.device(2, WHOLEMEMORY_DT_INT64));
-    auto* d_cnt = static_cast<int64_t*>(d_cnt_mem.device(2, WHOLEMEMORY_DT_INT64));
-    auto* h     = static_cast<int64_t*>(h_mem.pinned(4, WHOLEMEMORY_DT_INT64));
-    h[0] = static_cast<int64_t>(entry_offsets[0]), h[1] = static_cast<int64_t>(entry_offsets[1]);
-    WM_BK(bk->memcpy_async(d_off, h, sizeof(int64_t) * 2, stream));
-    wm_bucket_args ca{};
-    ca.indices       = idx_ptr;
-    ca.index_dtype   = iarr.dtype;
-    ca.n             = iarr.size;
-    ca.entry_offsets = d_off;
-    ca.world_size    = 1;
-    ca.counts        = d_cnt;
-    ca.workspace     = ws_mem.device(static_cast<int64_t>(bk->bucket_workspace_bytes(iarr.size, 1)), WHOLEMEMORY_DT_INT8);
-    WM_BK(bk->bucket_ids(&ca, stream));
-    WM_BK(bk->memcpy_async(h + 2, d_cnt, sizeof(int64_t), stream));
+  if (self_in_place && e->comm->single_rank_direct() && iarr.size > 0 && iarr.size < (INT64_C(1) << 31) &&
+      entry_offsets[1] - entry_offsets[0] < UINT64_C(0xFFFFFFFF)) {
     early.reset(new dedup_result(env));
-    early->run(idx_ptr, iarr.dtype, iarr.size, static_cast<int64_t>(entry_offsets[1]), stream);
-    WM_BK(bk->stream_sync(stream));
-    if (h[2] != iarr.size) early.reset();  // ids were dropped: not the identity after all
+    early->run(idx_ptr, iarr.dtype, iarr.size, static_cast<int64_t>(entry_offsets[1]), stream,
+               static_cast<int64_t>(entry_offsets[0]));
   }
   id_exchange x(env);
   if (early) {
@@ -335,7 +319,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     x.send_offsets   = {0, 0};
     x.recv_offsets   = {0, 0};
     x.bucket_offsets = {0, iarr.size};
-    x.total_valid = x.self_count = iarr.size;
+    x.total_valid = x.self_count = iarr.size;   // upper bounds: the true number of runs stays on the device
   } else {
     bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x, self_local, self_in_place);
   }
@@ -455,7 +439,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
       oa.cache_state_row_elems = e->cache->args.row_bytes2 / static_cast<int64_t>(sizeof(float));
     }
   }
-  // Everything this rank was given is its own and nothing was dropped (one rank, no negative ids): bucketing is stable, so
+  // Everything this rank was given is its own (one rank; ids that address no row are dropped inside the sort, see above):
   // the receive order IS the caller's order and the caller's gradient tensor IS the receive buffer — no remapping pass
   const bool whole_input_is_self = self_direct && x.self_count == iarr.size && n_recv == iarr.size;
   if (whole_input_is_self && early)

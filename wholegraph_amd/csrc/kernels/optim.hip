@@ -26,6 +26,63 @@
 #include <cstdlib>
 #include <cstring>
 
+// rocPRIM's radix sort copies its inputs to scratch first whenever input and output "can alias", and answers "yes" for
+// every iterator that is not a plain pointer (detail/various.hpp) — 26 us per 10 M (key, position) pairs for the narrowing
+// key iterator and the counting payload used below. The exact answers for those two, declared before the sort's templates
+// are defined (the call there is a qualified name: only overloads visible at that point take part):
+#include <iterator>
+#include <rocprim/config.hpp>
+#include <rocprim/detail/various.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+namespace wm {
+// random-access iterator over ids[i] - base, narrowed to 32 bits (rocprim::transform_iterator keeps its pointer private).
+// An id outside [base, base + span) — negative ("skip me") or past the range — reads as the key `span`: all such ids sort
+// behind every real key, as ONE run that the run detection drops (see run_dedup).
+template <typename InT>
+struct narrow_key_iterator {
+  using value_type        = uint32_t;
+  using reference         = uint32_t;
+  using pointer           = const uint32_t*;
+  using difference_type   = std::ptrdiff_t;
+  using iterator_category = std::random_access_iterator_tag;
+  const InT* ptr;  // InT is the UNSIGNED index type: a negative id is a huge offset
+  InT base;
+  uint32_t span;
+  __host__ __device__ uint32_t key(InT v) const
+  {
+    const InT off = v - base;
+    return off < static_cast<InT>(span) ? static_cast<uint32_t>(off) : span;
+  }
+  __host__ __device__ uint32_t operator*() const { return key(*ptr); }
+  __host__ __device__ uint32_t operator[](difference_type i) const { return key(ptr[i]); }
+  __host__ __device__ narrow_key_iterator operator+(difference_type d) const { return {ptr + d, base, span}; }
+  __host__ __device__ narrow_key_iterator operator-(difference_type d) const { return {ptr - d, base, span}; }
+  __host__ __device__ difference_type operator-(const narrow_key_iterator& o) const { return ptr - o.ptr; }
+  __host__ __device__ narrow_key_iterator& operator+=(difference_type d) { ptr += d; return *this; }
+  __host__ __device__ narrow_key_iterator& operator-=(difference_type d) { ptr -= d; return *this; }
+  __host__ __device__ narrow_key_iterator& operator++() { ++ptr; return *this; }
+  __host__ __device__ narrow_key_iterator operator++(int) { narrow_key_iterator t = *this; ++ptr; return t; }
+  __host__ __device__ narrow_key_iterator& operator--() { --ptr; return *this; }
+  __host__ __device__ narrow_key_iterator operator--(int) { narrow_key_iterator t = *this; --ptr; return t; }
+  __host__ __device__ bool operator==(const narrow_key_iterator& o) const { return ptr == o.ptr; }
+  __host__ __device__ bool operator!=(const narrow_key_iterator& o) const { return ptr != o.ptr; }
+  __host__ __device__ bool operator<(const narrow_key_iterator& o) const { return ptr < o.ptr; }
+};
+}  // namespace wm
+BEGIN_ROCPRIM_NAMESPACE
+namespace detail {
+template <class InT, class Out>
+inline bool can_iterators_alias(::wm::narrow_key_iterator<InT> it, Out* out, const size_t size)
+{
+  return can_iterators_alias(it.ptr, out, size);  // the ids array against the output array
+}
+template <class I, class D, class Out>
+inline bool can_iterators_alias(counting_iterator<I, D>, Out*, const size_t)
+{
+  return false;  // generates its values, reads no memory
+}
+}  // namespace detail
+END_ROCPRIM_NAMESPACE
 #include <rocprim/rocprim.hpp>
 
 #include "../backend.hpp"
@@ -103,7 +160,10 @@ __global__ __launch_bounds__(kBlock) void run_count_kernel(const KeyT* sorted, i
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(1024) void run_scan_kernel(int32_t* tile_counts, int n_tiles, int64_t* n_unique)
+// `last_key` / `drop_key`: when the LAST sorted key equals drop_key (the out-of-range marker of narrow_key_iterator), its run —
+// the last one — does not count (last_key == nullptr: nothing is dropped)
+__global__ __launch_bounds__(1024) void run_scan_kernel(int32_t* tile_counts, int n_tiles, int64_t* n_unique,
+                                                        const uint32_t* last_key, uint32_t drop_key)
 {
   // one workgroup walks the tile counts in chunks of 1024, carrying the running total
   __shared__ int wave_sums[16];
@@ -129,13 +189,13 @@ __global__ __launch_bounds__(1024) void run_scan_kernel(int32_t* tile_counts, in
     if (threadIdx.x == 1023) carry_s = before + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *n_unique = carry_s;
+  if (threadIdx.x == 0) *n_unique = carry_s - (last_key != nullptr && *last_key == drop_key ? 1 : 0);
 }
 
 template <typename KeyT, typename OutT>
 __global__ __launch_bounds__(kBlock) void run_compact_kernel(const KeyT* sorted, int64_t n, const int32_t* tile_prefix,
                                                              const int64_t* n_unique, OutT* unique_ids, int32_t* run_starts,
-                                                             OutT key_base)
+                                                             OutT key_base, bool drop_last, KeyT drop_key)
 {
   // heads are ranked inside the tile, parked in LDS at their rank and written out as two coalesced streams (a thread's
   // own heads are kRunItems apart in rank order: written directly they cost a scattered store per item — 82 us vs ~35)
@@ -165,7 +225,10 @@ __global__ __launch_bounds__(kBlock) void run_compact_kernel(const KeyT* sorted,
     unique_ids[out0 + i] = (sizeof(KeyT) == sizeof(OutT) ? static_cast<OutT>(k) : static_cast<OutT>(static_cast<uint64_t>(k))) + key_base;
     run_starts[out0 + i] = s_pos[i];
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) run_starts[*n_unique] = static_cast<int32_t>(n);
+  // end marker — unless the out-of-range run was dropped: then its own start (written above, at index *n_unique) ends the
+  // last real run
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && !(drop_last && sorted[n - 1] == drop_key))
+    run_starts[*n_unique] = static_cast<int32_t>(n);
 }
 
 inline unsigned significant_bits(int64_t upper_bound, unsigned full)
@@ -179,12 +242,7 @@ inline unsigned significant_bits(int64_t upper_bound, unsigned full)
 // keys narrowed on the fly: ids the caller bounded to a range of less than 2^32 rows are sorted as 32-bit keys RELATIVE to
 // the start of the range (8 + 4 bytes per element and pass instead of 8 + 8, and only the bits of the range's width: a
 // 125 M-row shard of a 1 B-row table sorts 27 bits in 3 passes, not 30 in 4) ... the first pass reads the ids through this
-// iterator, no conversion pass
-template <typename InT>
-struct narrow_to_u32 {
-  InT base;
-  __host__ __device__ uint32_t operator()(const InT& v) const { return static_cast<uint32_t>(v - base); }
-};
+// iterator (narrow_key_iterator, top of the file), no conversion pass
 
 // rocPRIM's onesweep with 9 radix bits per pass and 1024 x 8 keys per workgroup: ids of a 100 M-row shard (27 bits) sort
 // in 3 passes instead of the tuned default's 4 x 8 bits (10 M (key, position) pairs: 398 -> 251 us;
@@ -234,13 +292,18 @@ dedup_layout<SortKeyT> layout(void* ws, int64_t n)
 
 template <typename SortKeyT, typename OutT>
 int detect_runs(const SortKeyT* sorted, int32_t* tile_counts, int64_t n, OutT* unique_ids, int32_t* run_starts,
-                int64_t* n_unique_out, hipStream_t stream, OutT key_base = 0)
+                int64_t* n_unique_out, hipStream_t stream, OutT key_base = 0, bool drop_last = false, SortKeyT drop_key = 0)
 {
   const int tiles = run_tiles(n);
+  const uint32_t* last_key = nullptr;
+  if constexpr (sizeof(SortKeyT) == 4) {
+    if (drop_last) last_key = reinterpret_cast<const uint32_t*>(sorted + (n - 1));
+  }
   hipLaunchKernelGGL((run_count_kernel<SortKeyT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts);
-  hipLaunchKernelGGL(run_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, tiles, n_unique_out);
+  hipLaunchKernelGGL(run_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, tiles, n_unique_out, last_key,
+                     static_cast<uint32_t>(drop_key));
   hipLaunchKernelGGL((run_compact_kernel<SortKeyT, OutT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts,
-                     n_unique_out, unique_ids, run_starts, key_base);
+                     n_unique_out, unique_ids, run_starts, key_base, last_key != nullptr, drop_key);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -250,19 +313,22 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
 {
   using UKey = typename std::make_unsigned<KeyT>::type;
   if (key_upper_bound <= 0 || key_lower_bound < 0 || key_lower_bound >= key_upper_bound) key_lower_bound = 0;
-  const unsigned bits = significant_bits(key_upper_bound > 0 ? key_upper_bound - key_lower_bound : 0, 8 * sizeof(KeyT));
   // the payload 0, 1, 2 ... is generated by the sort's first pass (counting iterator): no iota array
   rocprim::counting_iterator<int32_t> positions(0);
-  if (key_upper_bound > 0 && bits <= 32 && (sizeof(KeyT) == 8 || key_lower_bound > 0)) {
+  const int64_t span = key_upper_bound > 0 ? key_upper_bound - key_lower_bound : 0;
+  if (span > 0 && span < INT64_C(0xFFFFFFFF)) {
+    // a bounded range of fewer than 2^32 - 1 rows: 32-bit keys relative to its start, the value `span` marks ids outside it
+    const unsigned bits = significant_bits(span + 1, 32);
     auto l    = layout<uint32_t>(workspace, n);
     size_t tb = l.temp_bytes;
-    auto keys = rocprim::make_transform_iterator(static_cast<const UKey*>(ids), narrow_to_u32<UKey>{static_cast<UKey>(key_lower_bound)});
+    narrow_key_iterator<UKey> keys{static_cast<const UKey*>(ids), static_cast<UKey>(key_lower_bound), static_cast<uint32_t>(span)};
     if (rocprim::radix_sort_pairs<sort_config<uint32_t>::type>(l.temp, tb, keys, l.sorted, positions, order,
                                                                static_cast<size_t>(n), 0, bits, stream) != hipSuccess)
       return -2;
     return detect_runs<uint32_t, UKey>(l.sorted, l.tile_counts, n, static_cast<UKey*>(unique_ids), run_starts, n_unique_out,
-                                       stream, static_cast<UKey>(key_lower_bound));
+                                       stream, static_cast<UKey>(key_lower_bound), true, static_cast<uint32_t>(span));
   }
+  const unsigned bits = significant_bits(key_upper_bound > 0 ? key_upper_bound : 0, 8 * sizeof(KeyT));
   auto l    = layout<UKey>(workspace, n);
   size_t tb = l.temp_bytes;
   if (rocprim::radix_sort_pairs<typename sort_config<UKey>::type>(l.temp, tb, static_cast<const UKey*>(ids), l.sorted, positions,
