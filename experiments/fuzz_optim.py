@@ -36,12 +36,35 @@ for case in range(cases):
     ids = np.concatenate(parts)
     rng.shuffle(ids)
     ids = (ids + local_off).astype(idt)
+    # ids that address no row of this shard (negative, below it, past it) with junk gradient rows, in a third of the cases:
+    # the sort drops them (backend.hpp: dedup_ids), the oracle never sees them
+    junk_pos = None
+    if len(ids) and rng.random() < 0.33:
+        n_junk = int(rng.integers(1, 40))
+        info = np.iinfo(idt)
+        pool = [-1, -5, info.min, info.max, local_off + local_rows, local_off + local_rows + 7]
+        if local_off > 0:
+            pool += [local_off - 1, 0]
+        junk = np.array([pool[i] for i in rng.integers(0, len(pool), n_junk)], dtype=idt)
+        total = len(ids) + n_junk
+        junk_pos = np.sort(rng.choice(total, n_junk, replace=False))
+        keep = np.ones(total, dtype=bool)
+        keep[junk_pos] = False
+        mixed = np.empty(total, dtype=idt)
+        mixed[keep], mixed[junk_pos] = ids, junk
+        ids = mixed
     n = len(ids)
     grad_stride = dim + int(rng.choice([0, 0, 0, 4]))
     grads_buf = rng.standard_normal((max(n, 1), grad_stride)).astype(np.float32)
-    grads = np.ascontiguousarray(grads_buf[:n, :dim])
+    if junk_pos is not None:
+        grads_buf[junk_pos] = 1e30
+    good = np.ones(n, dtype=bool)
+    if junk_pos is not None:
+        good[junk_pos] = False
+    grads = np.ascontiguousarray(grads_buf[:n, :dim][good])
+    good_ids = ids[good]
     desc = "case %d: %s %s dim %d stride %d grad_stride %d rows %d n %d hot %s %s" % (
-        case, kind, params, dim, stride, grad_stride, local_rows, n, hot, np.dtype(idt).name)
+        case, kind, params, dim, stride, grad_stride, local_rows, n, hot, np.dtype(idt).name) + (" +junk" if junk_pos is not None else "")
     table = np.zeros((local_rows, stride), np.float32)
     table[:, :dim] = rng.standard_normal((local_rows, dim)).astype(np.float32)
     p = dict(weight_decay=0.0, epsilon=1e-8, beta1=0.9, beta2=0.999, alpha=0.99, adam_w=0.0)
@@ -68,7 +91,7 @@ for case in range(cases):
                 d_pe.data_ptr() if d_pe is not None else None, d_pr.data_ptr() if d_pr is not None else None, C.byref(nu),
                 get_wholegraph_env_fns(), C.c_void_p(get_stream())))
             torch.cuda.synchronize()
-            uniq, dg = oracle.dedup_grads(ids, grads) if n else (ids[:0], grads[:0])
+            uniq, dg = oracle.dedup_grads(good_ids, grads) if len(good_ids) else (good_ids[:0], grads[:0])
             ref_opt.step(uniq, dg, ref_table, stride, local_off, dim, 0.03)
             ok = ok and nu.value == len(uniq) and d_table.cpu().numpy().tobytes() == ref_table.tobytes()
         if kind != "sgd":
