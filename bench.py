@@ -234,17 +234,32 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
         stat["frontiers"] = [int(t.numel()) for t in tg]
         return x, tg[0]
 
+    torch.cuda.reset_peak_memory_stats()
+    resident = torch.cuda.memory_allocated()
     for _ in range(max(a.warmup, 2)):
         x, ids = step()
     barrier()
     if not a.no_check:
         assert torch.equal(x[:, 0], (ids.long() & 0xFFFFFF).to(torch.float32)), "gathered features differ from the closed form"
+    # nothing of the warm-up stays referenced: a live output (15 GB at 65536 seeds) in the middle of the caching allocator's
+    # blocks makes the next steps' buffers miss their cached blocks, and fresh hipMallocs land inside the timed region
+    del x, ids
+    step()   # one step in the timed loop's own pattern (outputs dropped at once): the allocator settles before the clock starts
+    # The sizes of a step's outputs and scratch buffers vary by ~0.1 % from step to step (random sampler seeds), and the
+    # caching allocator answers a request a few MB above every cached block with a fresh hipMalloc — ~370 ms for the 15 GB
+    # feature output of a 65536-seed step. One block with 5 % headroom over everything a step ever held at once is put into
+    # the cache here; `device_allocs_in_timed_region` in the line says how many fresh allocations still happened (0 expected).
+    transient = torch.cuda.max_memory_allocated() - resident
+    headroom = torch.empty(int(transient * 1.05) + (64 << 20), dtype=torch.uint8, device="cuda")
+    del headroom
     barrier()
+    allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     wall = time.perf_counter() - t0
+    stat["device_allocs_in_timed_region"] = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0
     dt = torch.tensor([wall], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
     if launched:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
@@ -271,6 +286,7 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "sampled_edges_per_s": round(stat["edges"] * world / (ms * 1e-3), 0),
         "subgraph_nodes_per_step": stat["nodes"], "sampled_edges_per_step": stat["edges"], "frontier_sizes": stat["frontiers"],
+        "device_allocs_in_timed_region": stat["device_allocs_in_timed_region"],   # fresh hipMallocs by the caching allocator: 0 in a steady state
         "config": {"workload": "C5 %s graph %d nodes / %d edges (int32 col) + %dx%d fp32 features, %d-hop %s unweighted sample "
                                "from %d seeds per rank + append_unique + feature gather" % (
                                    mt, nodes, edges, nodes, a.dim, len(fanouts), fanouts, a.seeds),
@@ -279,8 +295,9 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
                      "frac": round(algo / (ms * 1e-3) / 8e12, 4), "traffic": None,
                      "algorithmic_bytes_per_step": algo,
                      "limited_by": "dependent-load latency (row_ptr -> col -> features) and launch / host-sync latency: a step is "
-                                   "%d small launches with a host round trip per hop to size the outputs, far from the HBM "
-                                   "roofline by construction; larger seed batches move it up (see --seeds)" % (8 * len(fanouts) + 2)},
+                                   "~%d small launches / copies with two host round trips per hop to size the outputs "
+                                   "(rocprofv3 timeline: experiments/trace_c5.sh), far from the HBM "
+                                   "roofline by construction; larger seed batches move it up (see --seeds)" % (14 * len(fanouts) + 2)},
     }
     if per:
         per = np.array(per)

@@ -7,11 +7,15 @@ Parameter sets follow the reference's tests:
   cpp/tests/graph_ops/append_unique_tests.cu, csr_add_self_loop_tests.cu, python test_graph_append_unique.py
 Bit-exact: samples are a pure function of (seed, center position, max_sample_count, CSR row).
 """
+import os
+
 import numpy as np
 import pytest
 
 import oracle
 from test_graph_oracle import make_csr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -201,7 +205,8 @@ def test_weighted_sample_follows_the_weights(gpu_env):
 
 @pytest.mark.parametrize("np_dtype", [np.int32, np.int64])
 @pytest.mark.parametrize("nt,nn,universe", [(700, 9000, 5000), (1, 1, 10), (0, 5000, 300), (3000, 0, 10 ** 6),
-                                            (50000, 400000, 150000), (1000, 20000, 2 ** 31 - 1)])
+                                            (50000, 400000, 150000), (1000, 20000, 2 ** 31 - 1),
+                                            (100000, 2200000, 3000000)])   # the last one: > 2 M 32-bit keys = the sort route
 def test_append_unique_parity(gpu_env, np_dtype, nt, nn, universe):
     import torch
     import wholegraph_amd.torch.graph_ops as gops
@@ -220,6 +225,74 @@ def test_append_unique_parity(gpu_env, np_dtype, nt, nn, universe):
     assert np.array_equal(mapping.cpu().numpy(), o_map)
     only = gops.append_unique(torch.from_numpy(targets).cuda(), torch.from_numpy(neighbors).cuda())
     assert torch.equal(only, uniq)
+
+
+@pytest.mark.parametrize("np_dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("case", ["all_ones_id", "extremes", "hot_id", "duplicate_targets", "colliding_hashes"])
+def test_append_unique_table_edges(gpu_env, np_dtype, case):
+    """The hash-table append_unique at its edges: the id whose bits are all ones (the table's "empty" pattern, it has a slot
+    of its own), the extreme values of the dtype, one id offered by every neighbour position (the atomic-min hot spot),
+    duplicates among the targets (the first one wins, as in the oracle), and ids a multiple of a large power of two apart."""
+    import torch
+    import wholegraph_amd.torch.graph_ops as gops
+    rng = np.random.default_rng(5)
+    info = np.iinfo(np_dtype)
+    if case == "all_ones_id":
+        targets = np.array([7, -1, 3], dtype=np_dtype)
+        neighbors = np.concatenate([rng.integers(-3, 12, 5000), np.full(100, -1)]).astype(np_dtype)
+        rng.shuffle(neighbors)
+    elif case == "extremes":
+        targets = np.array([info.max, 0], dtype=np_dtype)
+        neighbors = rng.choice(np.array([info.min, info.max, info.min + 1, info.max - 1, -1, 0, 1], dtype=np_dtype), 4000)
+    elif case == "hot_id":
+        targets = np.arange(10, 20, dtype=np_dtype)
+        neighbors = np.full(300000, 123456, dtype=np_dtype)
+        neighbors[::1000] = 15
+        neighbors[7::5000] = 99
+    elif case == "duplicate_targets":
+        targets = np.array([5, 9, 5, 5, 2, 9], dtype=np_dtype)
+        neighbors = rng.integers(0, 12, 3000).astype(np_dtype)
+    else:
+        step = 1 << 20
+        targets = (np.arange(50) * step).astype(np_dtype)
+        neighbors = (rng.integers(0, 1500, 60000) * step).astype(np_dtype)
+    o_uniq, o_map = oracle.append_unique(targets, neighbors)
+    uniq, mapping = gops.append_unique(torch.from_numpy(targets).cuda(), torch.from_numpy(neighbors).cuda(), True)
+    assert np.array_equal(uniq.cpu().numpy(), o_uniq)
+    assert np.array_equal(mapping.cpu().numpy(), o_map)
+    assert np.array_equal(o_uniq[o_map], neighbors)
+
+
+@pytest.mark.parametrize("limit", ["0", "1000000000"])
+def test_append_unique_both_routes(limit):
+    """Both routes of append_unique (hash table / radix sort; the library picks by size and id width) forced over the same
+    inputs through WM_AU_TABLE_MAX, in a process of their own (the switch is read once): equal to the oracle either way."""
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch, oracle
+import wholegraph_amd.torch as wgth
+import wholegraph_amd.torch.graph_ops as gops
+from wholegraph_amd import binding as wmb
+wmb.check(wmb.lib().wholememory_init(0, wmb.LEVEL_ERROR))
+wgth.create_group_communicator(1)
+rng = np.random.default_rng(11)
+for dt in (np.int32, np.int64):
+    for nt, nn, universe in [(0, 0, 10), (5, 0, 10), (0, 7, 3), (700, 9000, 5000), (30000, 600000, 200000)]:
+        t = rng.permutation(universe)[:nt].astype(dt)
+        n = rng.integers(0, universe, nn).astype(dt)
+        if nn > 4:
+            n[:3] = -1
+        ou, om = oracle.append_unique(t, n)
+        u, m = gops.append_unique(torch.from_numpy(t).cuda(), torch.from_numpy(n).cuda(), True)
+        assert np.array_equal(u.cpu().numpy(), ou) and np.array_equal(m.cpu().numpy(), om), (dt, nt, nn)
+print("ROUTES_OK")
+""" % ROOT
+    env = dict(os.environ, WM_AU_TABLE_MAX=limit)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ROUTES_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
 def test_append_unique_reference_docstring_example(gpu_env):

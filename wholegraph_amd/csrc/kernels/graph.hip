@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -406,6 +407,150 @@ int dispatch_weighted(const weighted_params& w, bool id32, bool col32, hipStream
 }
 
 // ------------------------------------------------------------------------------------------------ append_unique
+// unique = targets (as they stand) ++ the neighbour ids that are not targets, each once, in the order of their FIRST
+// occurrence in the neighbour array; mapping[p] = position of neighbours[p] in that array.
+// Round 1 sorted (id, position) pairs; on a 950 k-key hop rocPRIM picks its merge sort for that size — a block sort and
+// 19 merge passes, ~30 launches per call and 250 us of the C5 step. Here: an open-addressing table in scratch
+// (2 slots per key, linear probing) whose slot holds the id and the SMALLEST position it occurs at (targets are positions
+// 0 .. nt-1, neighbours nt ..), built with one compare-and-swap + one atomic min per key. A neighbour is "new" when the
+// smallest position of its id is its own; an exclusive scan over those flags ranks the new ids in neighbour order. Six
+// launches before the host learns the count, two after. Every step is an order-independent reduction (min) or a scan, so
+// the result is deterministic and equals the oracle's bit for bit.
+template <typename KeyT>
+struct au_layout {
+  KeyT* slots;        // cap + 1 ids (all-ones = empty; slot `cap` is reserved for the id that IS all-ones)
+  uint32_t* min_pos;  // cap + 1 smallest positions (0xFFFFFFFF = none yet)
+  uint32_t* slot_of;  // nt + nn: where each key landed (phase 2 and the flag pass do not probe again)
+  int *first_flag, *new_rank;  // nn + 1 each
+  void* temp;
+  size_t temp_bytes, table_bytes, total;
+  uint32_t cap;
+};
+
+template <typename KeyT>
+au_layout<KeyT> au_plan(void* ws, int nt, int nn)
+{
+  const size_t n = static_cast<size_t>(nt) + nn;
+  auto al        = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  size_t scan_b  = 0;
+  (void)rocprim::exclusive_scan(nullptr, scan_b, static_cast<const int*>(nullptr), static_cast<int*>(nullptr), 0,
+                                static_cast<size_t>(nn) + 1, rocprim::plus<int>(), nullptr);
+  au_layout<KeyT> l;
+  size_t cap = 64;
+  while (cap < 2 * n) cap <<= 1;   // n < 2^31: cap <= 2^32 would not fit uint32 — n is an int sum the host keeps below 2^30
+  l.cap    = static_cast<uint32_t>(cap);
+  char* p  = static_cast<char*>(ws);
+  size_t o = 0;
+  // [slots | min_pos] are contiguous: one memset of 0xFF bytes empties both
+  l.slots = reinterpret_cast<KeyT*>(p + o), o += al(sizeof(KeyT) * (cap + 1));
+  l.min_pos = reinterpret_cast<uint32_t*>(p + o), o += al(4 * (cap + 1));
+  l.table_bytes = o;
+  l.slot_of = reinterpret_cast<uint32_t*>(p + o), o += al(4 * std::max<size_t>(n, 1));
+  l.first_flag = reinterpret_cast<int*>(p + o), o += al(4 * (static_cast<size_t>(nn) + 1));
+  l.new_rank = reinterpret_cast<int*>(p + o), o += al(4 * (static_cast<size_t>(nn) + 1));
+  l.temp       = p + o;
+  l.temp_bytes = scan_b;
+  l.total      = o + al(l.temp_bytes) + 256;
+  return l;
+}
+
+__device__ __forceinline__ uint32_t au_hash(uint64_t k)
+{
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 29;
+  return static_cast<uint32_t>(k);
+}
+
+__device__ __forceinline__ uint32_t au_cas(uint32_t* a, uint32_t expect, uint32_t v) { return atomicCAS(a, expect, v); }
+__device__ __forceinline__ uint64_t au_cas(uint64_t* a, uint64_t expect, uint64_t v)
+{
+  return atomicCAS(reinterpret_cast<unsigned long long*>(a), static_cast<unsigned long long>(expect), static_cast<unsigned long long>(v));
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, int nt, const KeyT* neighbors, int nn,
+                                                           KeyT* slots, uint32_t* min_pos, uint32_t* slot_of, uint32_t cap)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nt + nn) return;
+  constexpr KeyT kEmpty = ~static_cast<KeyT>(0);
+  const KeyT key        = i < nt ? targets[i] : neighbors[i - nt];
+  uint32_t s            = cap;  // the id that looks like "empty" has a slot of its own
+  if (key != kEmpty) {
+    s = au_hash(static_cast<uint64_t>(key)) & (cap - 1);
+    for (;;) {
+      KeyT cur = slots[s];
+      if (cur == kEmpty) cur = au_cas(&slots[s], kEmpty, key);   // returns what was there: empty = the slot is mine now
+      if (cur == kEmpty || cur == key) break;
+      s = (s + 1) & (cap - 1);
+    }
+  }
+  slot_of[i] = s;
+  // (a plain look first: a hot id is offered by thousands of positions, most of them larger than what is already there)
+  if (min_pos[s] > static_cast<uint32_t>(i)) atomicMin(&min_pos[s], static_cast<uint32_t>(i));
+}
+
+__global__ __launch_bounds__(kBlock) void au_flag_kernel(const uint32_t* min_pos, const uint32_t* slot_of, int nt, int nn,
+                                                         int* first_flag)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > nn) return;
+  // first occurrence of an id that no target holds (targets sit at positions < nt); entry nn closes the exclusive scan
+  first_flag[p] = p < nn && min_pos[slot_of[nt + p]] == static_cast<uint32_t>(nt + p) ? 1 : 0;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, const uint32_t* min_pos, const uint32_t* slot_of,
+                                                         const int* new_rank, int nt, int nn, KeyT* out_unique, int* mapping)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nn) return;
+  const uint32_t s = slot_of[nt + p];
+  const int m      = static_cast<int>(min_pos[s]);
+  const int uid    = m < nt ? m : nt + new_rank[m - nt];
+  if (m == nt + p) out_unique[uid] = slots[s];
+  if (mapping != nullptr) mapping[p] = uid;
+}
+
+template <typename KeyT>
+int au_phase1(const void* targets, int nt, const void* neighbors, int nn, void* ws, int* new_count_dev, hipStream_t stream)
+{
+  using UKey  = typename std::make_unsigned<KeyT>::type;
+  auto l      = au_plan<UKey>(ws, nt, nn);
+  const int n = nt + nn;
+  if (hipMemsetAsync(l.slots, 0xFF, l.table_bytes, stream) != hipSuccess) return -2;
+  if (n > 0)
+    hipLaunchKernelGGL((au_insert_kernel<UKey>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                       static_cast<const UKey*>(targets), nt, static_cast<const UKey*>(neighbors), nn, l.slots, l.min_pos,
+                       l.slot_of, l.cap);
+  hipLaunchKernelGGL(au_flag_kernel, dim3((nn + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.min_pos, l.slot_of, nt, nn,
+                     l.first_flag);
+  size_t tb = l.temp_bytes;
+  if (rocprim::exclusive_scan(l.temp, tb, l.first_flag, l.new_rank, 0, static_cast<size_t>(nn) + 1, rocprim::plus<int>(),
+                              stream) != hipSuccess)
+    return -2;
+  // new_rank[nn] = number of new unique neighbours
+  if (hipMemcpyAsync(new_count_dev, l.new_rank + nn, sizeof(int), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -2;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename KeyT>
+int au_phase2(const void* targets, int nt, int nn, void* ws, void* out_unique, int* mapping, hipStream_t stream)
+{
+  using UKey = typename std::make_unsigned<KeyT>::type;
+  auto l     = au_plan<UKey>(ws, nt, nn);
+  if (nt > 0 && hipMemcpyAsync(out_unique, targets, sizeof(KeyT) * nt, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -2;
+  if (nn > 0)
+    hipLaunchKernelGGL((au_emit_kernel<UKey>), dim3((nn + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.slots, l.min_pos,
+                       l.slot_of, l.new_rank, nt, nn, static_cast<UKey*>(out_unique), mapping);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// -- the sort route (round 1), kept for BIG inputs: a table for tens of millions of ids no longer sits in the caches and its
+// random atomics lose against the radix sort's streaming passes (1 M + 22.4 M ids: sort 2.44 ms, table 2.92 ms): stable
+// radix sort of (id, position) over targets ++ neighbours, run heads by max-scan, "first occurrence is a neighbour" flags,
+// exclusive scan -> unique index
 template <typename KeyT>
 __global__ void concat_keys_kernel(const KeyT* targets, int nt, const KeyT* neighbors, int nn, KeyT* keys, int* pos)
 {
@@ -454,7 +599,7 @@ struct max_op {
 };
 
 template <typename KeyT>
-struct au_layout {
+struct aus_layout {
   KeyT *keys, *sorted;
   int *pos, *sorted_pos, *head, *first_flag, *new_rank;
   void* temp;
@@ -462,7 +607,7 @@ struct au_layout {
 };
 
 template <typename KeyT>
-au_layout<KeyT> au_plan(void* ws, int nt, int nn)
+aus_layout<KeyT> aus_plan(void* ws, int nt, int nn)
 {
   const size_t n = static_cast<size_t>(nt) + nn;
   auto al        = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
@@ -474,7 +619,7 @@ au_layout<KeyT> au_plan(void* ws, int nt, int nn)
                                 nullptr);
   (void)rocprim::exclusive_scan(nullptr, scan2_b, static_cast<const int*>(nullptr), static_cast<int*>(nullptr), 0,
                                 static_cast<size_t>(nn) + 1, rocprim::plus<int>(), nullptr);
-  au_layout<KeyT> l;
+  aus_layout<KeyT> l;
   char* p  = static_cast<char*>(ws);
   size_t o = 0;
   l.keys = reinterpret_cast<KeyT*>(p + o), o += al(sizeof(KeyT) * n);
@@ -491,10 +636,10 @@ au_layout<KeyT> au_plan(void* ws, int nt, int nn)
 }
 
 template <typename KeyT>
-int au_phase1(const void* targets, int nt, const void* neighbors, int nn, void* ws, int* new_count_dev, hipStream_t stream)
+int aus_phase1(const void* targets, int nt, const void* neighbors, int nn, void* ws, int* new_count_dev, hipStream_t stream)
 {
   using UKey     = typename std::make_unsigned<KeyT>::type;
-  auto l         = au_plan<UKey>(ws, nt, nn);
+  auto l         = aus_plan<UKey>(ws, nt, nn);
   const int n    = nt + nn;
   const int blks = (n + kBlock - 1) / kBlock;
   hipLaunchKernelGGL((concat_keys_kernel<UKey>), dim3(blks), dim3(kBlock), 0, stream, static_cast<const UKey*>(targets), nt,
@@ -518,16 +663,31 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, void* 
 }
 
 template <typename KeyT>
-int au_phase2(const void* targets, int nt, int nn, void* ws, void* out_unique, int* mapping, hipStream_t stream)
+int aus_phase2(const void* targets, int nt, int nn, void* ws, void* out_unique, int* mapping, hipStream_t stream)
 {
   using UKey     = typename std::make_unsigned<KeyT>::type;
-  auto l         = au_plan<UKey>(ws, nt, nn);
+  auto l         = aus_plan<UKey>(ws, nt, nn);
   const int n    = nt + nn;
   const int blks = (n + kBlock - 1) / kBlock;
   if (nt > 0 && hipMemcpyAsync(out_unique, targets, sizeof(KeyT) * nt, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -2;
   hipLaunchKernelGGL((emit_unique_kernel<UKey>), dim3(blks), dim3(kBlock), 0, stream, l.sorted, l.head, l.sorted_pos,
                      l.new_rank, n, nt, static_cast<UKey*>(out_unique), mapping);
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+
+// which route (experiments/au_crossover.py, whole calls): 32-bit ids — the table wins up to ~2 M keys (950 k: 0.21 vs 0.31 ms)
+// and loses from 4 M on (0.68 vs 0.60 ms; 23 M: 2.84 vs 2.39 ms) once it no longer sits in the caches; 64-bit ids — the sort
+// moves twice the key bytes through twice the passes and the table wins or ties up to the largest size measured (23 M: 3.02 vs
+// 3.12 ms). WM_AU_TABLE_MAX overrides the key-count limit for both (measurements).
+inline bool au_use_table(int nt, int nn, wholememory_dtype_t dt)
+{
+  static const int64_t forced = [] {
+    const char* e = getenv("WM_AU_TABLE_MAX");
+    return e != nullptr ? static_cast<int64_t>(atoll(e)) : INT64_C(-1);
+  }();
+  const int64_t limit = forced >= 0 ? forced : (dt == WHOLEMEMORY_DT_INT ? INT64_C(2) << 20 : INT64_C(24) << 20);
+  return static_cast<int64_t>(nt) + nn <= limit;
 }
 
 __global__ void add_self_loop_kernel(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows)
@@ -670,20 +830,31 @@ int hip_sample_weighted(const wm_sample_args* a, void* stream_v)
 
 size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt)
 {
-  return dt == WHOLEMEMORY_DT_INT ? au_plan<uint32_t>(nullptr, nt, nn).total : au_plan<uint64_t>(nullptr, nt, nn).total;
+  if (au_use_table(nt, nn, dt)) return dt == WHOLEMEMORY_DT_INT ? au_plan<uint32_t>(nullptr, nt, nn).total : au_plan<uint64_t>(nullptr, nt, nn).total;
+  return dt == WHOLEMEMORY_DT_INT ? aus_plan<uint32_t>(nullptr, nt, nn).total : aus_plan<uint64_t>(nullptr, nt, nn).total;
 }
 int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, wholememory_dtype_t dt, void* ws,
                              int* new_count_dev, void* stream)
 {
-  if (dt == WHOLEMEMORY_DT_INT) return au_phase1<int32_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream));
-  if (dt == WHOLEMEMORY_DT_INT64) return au_phase1<int64_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream));
+  const bool table = au_use_table(nt, nn, dt);
+  if (dt == WHOLEMEMORY_DT_INT)
+    return table ? au_phase1<int32_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream))
+                 : aus_phase1<int32_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream));
+  if (dt == WHOLEMEMORY_DT_INT64)
+    return table ? au_phase1<int64_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream))
+                 : aus_phase1<int64_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream));
   return -1;
 }
 int hip_append_unique_phase2(const void* targets, int nt, int nn, wholememory_dtype_t dt, void* ws, void* out_unique,
                              int* mapping, void* stream)
 {
-  if (dt == WHOLEMEMORY_DT_INT) return au_phase2<int32_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream));
-  if (dt == WHOLEMEMORY_DT_INT64) return au_phase2<int64_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream));
+  const bool table = au_use_table(nt, nn, dt);
+  if (dt == WHOLEMEMORY_DT_INT)
+    return table ? au_phase2<int32_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream))
+                 : aus_phase2<int32_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream));
+  if (dt == WHOLEMEMORY_DT_INT64)
+    return table ? au_phase2<int64_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream))
+                 : aus_phase2<int64_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream));
   return -1;
 }
 int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream)
