@@ -447,6 +447,7 @@ def main():
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
+    allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(a.steps):
@@ -454,6 +455,7 @@ def main():
     ev1.record()
     barrier()
     t1 = time.perf_counter()
+    fresh_allocs = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0   # hipMallocs by the caching allocator: 0 in a steady state
     dt = torch.tensor([t1 - t0], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
     if launched:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
@@ -547,6 +549,7 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "mlookups_per_s": round(lookups / 1e6, 1),
             "algorithmic_GBps": round(lookups * algo_bytes / 1e9, 2),
+            "device_allocs_in_timed_region": fresh_allocs,
             "config": {"workload": ("C2 chunked 1-GPU %dx%d %s table, %d %s int64 ids" if world == 1 else
                                     "C3 distributed %dx%d %s table, %d %s int64 ids per rank, RCCL alltoallv")
                                    % (total_rows, a.dim, {"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[a.dtype],
