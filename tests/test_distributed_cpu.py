@@ -50,7 +50,7 @@ def test_multi_rank_on_one_gpu_hip_kernels(wm_lib, world, chunks):
     run_world(world, "hip", {"WM_EXCHANGE_CHUNKS": chunks})
 
 
-@pytest.mark.parametrize("world,chunks", [(2, "1"), (2, "3"), (3, "1"), (3, "3"), (8, "4")])
+@pytest.mark.parametrize("world,chunks", [(1, "1"), (2, "1"), (2, "3"), (3, "1"), (3, "3"), (8, "4")])
 def test_distributed_paths_over_gloo(wm_lib, world, chunks):
     # always through make: the test backend shares struct layouts with csrc/backend.hpp and must be rebuilt when that
     # header changes (a no-op when it is up to date)
