@@ -33,24 +33,33 @@ class WholeMemoryTensor(object):
     def _desc(self):
         return wmb.lib().wholememory_tensor_get_tensor_description(self.wmb_tensor).contents
 
+    def _layout(self):
+        """(dtype, shape, strides, storage_offset): fixed for the life of the tensor, read from the C side once"""
+        lay = getattr(self, "_cached_layout", None)
+        if lay is None:
+            d = self._desc()
+            n = d.dim
+            lay = (wholememory_dtype_to_torch_dtype(d.dtype), tuple(int(d.sizes[i]) for i in range(n)),
+                   tuple(int(d.strides[i]) for i in range(n)), int(d.storage_offset))
+            self._cached_layout = lay
+        return lay
+
     @property
     def dtype(self):
-        return wholememory_dtype_to_torch_dtype(self._desc().dtype)
+        return self._layout()[0]
 
     def dim(self):
-        return self._desc().dim
+        return len(self._layout()[1])
 
     @property
     def shape(self):
-        d = self._desc()
-        return tuple(int(d.sizes[i]) for i in range(d.dim))
+        return self._layout()[1]
 
     def stride(self):
-        d = self._desc()
-        return tuple(int(d.strides[i]) for i in range(d.dim))
+        return self._layout()[2]
 
     def storage_offset(self):
-        return int(self._desc().storage_offset)
+        return self._layout()[3]
 
     def _handle(self):
         return C.c_void_p(wmb.lib().wholememory_tensor_get_memory_handle(self.wmb_tensor))

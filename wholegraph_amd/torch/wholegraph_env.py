@@ -179,6 +179,9 @@ def get_wholegraph_env_fns(use_default=True):
     return C.pointer(table.env)
 
 
+_desc_cache = {}
+
+
 class WrappedLocalTensor(object):
     """A torch tensor wrapped as a (non-owning) wholememory_tensor_t for the duration of one call."""
 
@@ -191,8 +194,17 @@ class WrappedLocalTensor(object):
             return
         # shape/stride/dtype + data_ptr(), storage_offset 0 (reference wholegraph_env.py:173-182)
         # (an empty torch tensor may report stride 0: describe it as dense instead)
-        strides = list(t.stride()) if t.numel() > 0 else None
-        desc = wmb.make_tensor_desc(list(t.shape), torch_dtype_to_wholememory_dtype(t.dtype), strides, 0)
+        # The description only depends on (shape, strides, dtype): a training loop wraps the same few layouts over and over,
+        # so finished descriptions are kept (the library copies the struct, it is never written through)
+        shape = tuple(t.shape)
+        strides = tuple(t.stride()) if t.numel() > 0 else None
+        key = (shape, strides, t.dtype)
+        desc = _desc_cache.get(key)
+        if desc is None:
+            desc = wmb.make_tensor_desc(list(shape), torch_dtype_to_wholememory_dtype(t.dtype),
+                                        list(strides) if strides is not None else None, 0)
+            if len(_desc_cache) < 4096:
+                _desc_cache[key] = desc
         wmb.check(wmb.lib().wholememory_make_tensor_from_pointer(C.byref(self.handle), C.c_void_p(t.data_ptr()),
                                                                  C.byref(desc)))
 
