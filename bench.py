@@ -463,9 +463,19 @@ def main():
     dev_ms = ev0.elapsed_time(ev1) / a.steps  # HIP events on the stream the kernels were launched on
     rows_kernel = wmb.lib().wholememory_ext_last_rows_kernel().decode()   # what the HIP runtime calls the kernel just run
 
-    # per-step spread, outside the timed region: one HIP event pair per step
-    stability = None
-    if a.stability_steps > 0:   # every rank runs it: at N > 1 the step is a collective
+    # Side legs, outside the timed region. They must never cost the contract line its measurement: an exception in one of
+    # them is recorded in the line (`side_errors`) instead of ending the run — all ranks run the same code on the same shapes,
+    # so they fail or pass together.
+    side_errors = {}
+
+    def guarded(name, leg):
+        try:
+            return leg()
+        except Exception as ex:  # noqa
+            side_errors[name] = repr(ex)[:300]
+            return None
+
+    def stability_leg():   # per-step spread: one HIP event pair per step (every rank runs it: at N > 1 the step is a collective)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.stability_steps + 1)]
         evs[0].record()
         for i in range(a.stability_steps):
@@ -473,41 +483,42 @@ def main():
             evs[i + 1].record()
         torch.cuda.synchronize()
         per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(a.stability_steps)])
-        stability = {"steps": a.stability_steps, "min_ms": round(float(per.min()), 4),
-                     "median_ms": round(float(np.median(per)), 4), "p95_ms": round(float(np.percentile(per, 95)), 4),
-                     "max_ms": round(float(per.max()), 4),
-                     "note": "per-step HIP-event times on rank 0, separate from the timed region"}
         barrier()
+        return {"steps": a.stability_steps, "min_ms": round(float(per.min()), 4),
+                "median_ms": round(float(np.median(per)), 4), "p95_ms": round(float(np.percentile(per, 95)), 4),
+                "max_ms": round(float(per.max()), 4),
+                "note": "per-step HIP-event times on rank 0, separate from the timed region"}
 
-    # N > 1: BASELINE config C3 proper is the Zipf-skewed batch. A short side leg after the contract measurement: the same step
-    # with Zipf(1.05) ids (hot rows hashed over the owners), with the library's automatic request de-duplication and with it
-    # forced off — on real links this is the evidence for what the de-duplication saves
-    c3_zipf = None
-    if world > 1 and a.op == "gather" and a.dist == "uniform" and mt == "distributed":
+    def zipf_leg():
+        # N > 1: BASELINE config C3 proper is the Zipf-skewed batch: the same step with Zipf(1.05) ids (hot rows hashed over the
+        # owners), with the library's automatic request de-duplication and with it forced off — on real links this is the
+        # evidence for what the de-duplication saves
         zidx = torch.from_numpy(make_indices(a.indices, total_rows, "zipf", 4242 + rank)).cuda()
-        c3_zipf = {"index_distribution": "zipf(1.05), hashed", "steps": 20}
-        for label, env_val in (("dedup_auto", None), ("dedup_off", "0")):
-            if env_val is None:
-                os.environ.pop("WM_GATHER_DEDUP", None)
-            else:
-                os.environ["WM_GATHER_DEDUP"] = env_val
-            for _ in range(3):
-                emb.gather(zidx, out=out)
-            barrier()
-            tz = time.perf_counter()
-            for _ in range(20):
-                emb.gather(zidx, out=out)
-            barrier()
-            dz = torch.tensor([time.perf_counter() - tz], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
-            torch.distributed.all_reduce(dz, op=torch.distributed.ReduceOp.MAX)
-            c3_zipf[label + "_ms_per_step"] = round(float(dz.item()) / 20 * 1e3, 4)
-        os.environ.pop("WM_GATHER_DEDUP", None)
-        c3_zipf["dedup_auto_value_GBps"] = round(a.indices * world * a.dim * es / (c3_zipf["dedup_auto_ms_per_step"] * 1e-3) / 1e9, 2)
+        res = {"index_distribution": "zipf(1.05), hashed", "steps": 20}
+        try:
+            for label, env_val in (("dedup_auto", None), ("dedup_off", "0")):
+                if env_val is None:
+                    os.environ.pop("WM_GATHER_DEDUP", None)
+                else:
+                    os.environ["WM_GATHER_DEDUP"] = env_val
+                for _ in range(3):
+                    emb.gather(zidx, out=out)
+                barrier()
+                tz = time.perf_counter()
+                for _ in range(20):
+                    emb.gather(zidx, out=out)
+                barrier()
+                dz = torch.tensor([time.perf_counter() - tz], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
+                torch.distributed.all_reduce(dz, op=torch.distributed.ReduceOp.MAX)
+                res[label + "_ms_per_step"] = round(float(dz.item()) / 20 * 1e3, 4)
+        finally:
+            os.environ.pop("WM_GATHER_DEDUP", None)
+        res["dedup_auto_value_GBps"] = round(a.indices * world * a.dim * es / (res["dedup_auto_ms_per_step"] * 1e-3) / 1e9, 2)
+        return res
 
-    # N > 1: the step is link-bound (see `exchange`); the HBM roofline object then describes the dominant HBM kernel on its
-    # own — the owner-side row gather — timed on this rank's local shard outside the step loop, same ids folded into it
-    local_kernel_roofline = None
-    if world > 1 and a.op == "gather" and a.dtype == "f32" and rank == 0:
+    def local_kernel_leg():
+        # N > 1: the step is link-bound (see `exchange`); the HBM roofline object then describes the dominant HBM kernel on its
+        # own — the owner-side row gather — timed on this rank's local shard outside the step loop, same ids folded into it
         import ctypes as C
         from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream
         lidx = idx % rows_per_gpu
@@ -524,12 +535,20 @@ def main():
         torch.cuda.synchronize()
         kms = k0.elapsed_time(k1) / 10
         kbytes = a.indices * (8 + 2 * a.dim * es)
-        local_kernel_roofline = {"bound": "hbm", "achieved": round(kbytes / (kms * 1e-3) / 1e9, 1), "peak": 8000.0,
-                                 "unit": "GB/s", "frac": round(kbytes / (kms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
-                                 "kernel": wmb.lib().wholememory_ext_last_rows_kernel().decode(), "kernel_ms": round(kms, 4),
-                                 "algorithmic_bytes_per_launch": kbytes,
-                                 "scope": "owner-side row gather on rank 0's local shard, timed outside the step loop; "
-                                          "the step itself is link-bound (see exchange)"}
+        return {"bound": "hbm", "achieved": round(kbytes / (kms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(kbytes / (kms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                "kernel": wmb.lib().wholememory_ext_last_rows_kernel().decode(), "kernel_ms": round(kms, 4),
+                "algorithmic_bytes_per_launch": kbytes,
+                "scope": "owner-side row gather on rank 0's local shard, timed outside the step loop; "
+                         "the step itself is link-bound (see exchange)"}
+
+    stability = guarded("stability", stability_leg) if a.stability_steps > 0 else None
+    c3_zipf = None
+    if world > 1 and a.op == "gather" and a.dist == "uniform" and mt == "distributed":
+        c3_zipf = guarded("c3_zipf", zipf_leg)
+    local_kernel_roofline = None
+    if world > 1 and a.op == "gather" and a.dtype == "f32" and rank == 0:
+        local_kernel_roofline = guarded("local_kernel_roofline", local_kernel_leg)
     if launched:
         torch.distributed.barrier()
 
@@ -579,8 +598,8 @@ def main():
             if stability is not None:
                 res["roofline"]["frac_at_median_step"] = round(a.indices * algo_bytes / (stability["median_ms"] * 1e-3) / 8e12, 4)
             if not a.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(a.dim, a.cpu_seconds)
-                res["gpu_c1_host"] = gpu_c1_host(wgth, comm)
+                res["cpu_baseline"] = guarded("cpu_baseline", lambda: cpu_baseline(a.dim, a.cpu_seconds))
+                res["gpu_c1_host"] = guarded("gpu_c1_host", lambda: gpu_c1_host(wgth, comm))
         if world > 1 and a.op == "gather" and a.dtype == "f32":
             res["roofline"] = local_kernel_roofline
         if world > 1 and a.op == "gather" and mt == "distributed":
@@ -599,6 +618,9 @@ def main():
             res["stability"] = stability
         if c3_zipf is not None:
             res["c3_zipf"] = c3_zipf
+
+        if side_errors:
+            res["side_errors"] = side_errors
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     wgth.destroy_embedding(emb)
