@@ -295,7 +295,7 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
                      "frac": round(algo / (ms * 1e-3) / 8e12, 4), "traffic": None,
                      "algorithmic_bytes_per_step": algo,
                      "limited_by": "dependent-load latency (row_ptr -> col -> features) and launch / host-sync latency: a step is "
-                                   "~%d small launches / copies with two host round trips per hop to size the outputs "
+                                   "~%d small launches / copies with one host round trip per hop to size the outputs "
                                    "(rocprofv3 timeline: experiments/trace_c5.sh), far from the HBM "
                                    "roofline by construction; larger seed batches move it up (see --seeds)" % (14 * len(fanouts) + 2)},
     }

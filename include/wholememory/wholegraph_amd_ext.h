@@ -124,6 +124,25 @@ const char* wholememory_ext_backend_name();
  * thread launched last; "" before the first launch */
 const char* wholememory_ext_last_rows_kernel();
 
+/* One hop of multi-layer neighbour sampling as one call: unweighted sampling without replacement of every node of
+ * `center_nodes_tensor` followed by graph_append_unique(center nodes, sampled neighbours), with ONE host round trip to size
+ * the outputs instead of the two of the separate ops (reference: wholegraph_csr_unweighted_sample_without_replacement,
+ * include/wholememory/wholegraph_op.h, + graph_append_unique, graph_op.h, driven per hop by
+ * python/pylibwholegraph/pylibwholegraph/torch/graph_structure.py:140-196). Outputs, bit-identical to that sequence:
+ *   output_sample_offset_tensor  int32 [n_center + 1], caller-allocated (csr_row_ptr of the sampled block)
+ *   unique        (memory context)  center nodes ++ new neighbour ids in first-occurrence order
+ *   neighbor_pos  (memory context)  int32 [n_samples]: position of each sampled neighbour in `unique`
+ *   center_lid    (memory context)  int32 [n_samples]: position of its centre in center_nodes_tensor
+ * WHOLEMEMORY_NOT_SUPPORTED (nothing queued, nothing allocated) when the CSR is not mapped into this rank (DISTRIBUTED /
+ * HIERARCHY), when column ids and center ids differ in dtype, when max_sample_count <= 0 or the center array is empty:
+ * the caller then runs the two ops. */
+wholememory_error_code_t wholememory_ext_sample_append_unique(
+  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor,
+  wholememory_tensor_t center_nodes_tensor, int max_sample_count, unsigned long long random_seed,
+  wholememory_tensor_t output_sample_offset_tensor, void* output_unique_memory_context,
+  void* output_neighbor_pos_memory_context, void* output_center_localid_memory_context, wholememory_env_func_t* p_env_fns,
+  void* stream);
+
 /* ---- (3) testing seam ---------------------------------------------------------------------- */
 /* Replaces the device backend. Refuses (WHOLEMEMORY_NOT_SUPPORTED) unless the environment has
  * WHOLEGRAPH_AMD_TESTING=1. `backend` is a const wm_device_backend* (wholegraph_amd/csrc/backend.hpp);

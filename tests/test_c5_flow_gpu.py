@@ -76,3 +76,91 @@ def test_sample_append_unique_gather_chain(gpu_env, mt, id_dtype, fanouts):
     wgth.destroy_embedding(emb)
     wgth.destroy_wholememory_tensor(wrow)
     wgth.destroy_wholememory_tensor(wcol)
+
+
+def _two_ops(wops, gops, wrow, wcol, frontier, fanout, seed):
+    off, ids, lid = wops.unweighted_sample_without_replacement(wrow.wmb_tensor, wcol.wmb_tensor, frontier, fanout, seed, True, False)
+    uniq, pos = gops.append_unique(frontier, ids, need_neighbor_raw_to_unique=True)
+    return off, uniq, pos, lid
+
+
+@pytest.mark.parametrize("mt", ["chunked", "continuous"])
+@pytest.mark.parametrize("id_dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("fanout", [1, 30, 200])
+def test_fused_hop_equals_the_two_ops(gpu_env, mt, id_dtype, fanout):
+    """wholememory_ext_sample_append_unique (one call, one host round trip) against the sampler followed by append_unique:
+    the four outputs are equal element for element — frontiers with duplicates, zero-degree and heavy nodes included."""
+    import torch
+    import wholegraph_amd.torch.wholegraph_ops as wops
+    import wholegraph_amd.torch.graph_ops as gops
+    n_nodes = 9001
+    row_ptr, col = make_csr(n_nodes, 40, 7, id_dtype, heavy=[(3, 3000), (4, 0), (5, 700), (6, 31)])
+    wrow, wcol = _wm_array(gpu_env, mt, row_ptr), _wm_array(gpu_env, mt, col)
+    rng = np.random.default_rng(fanout)
+    for n_front in (1, 4, 777):
+        front = np.concatenate([[3, 4, 5, 6, 4], rng.integers(0, n_nodes, n_front)])[:max(n_front, 1)].astype(id_dtype)
+        frontier = torch.from_numpy(front).cuda()
+        fused = wops.sample_append_unique(wrow.wmb_tensor, wcol.wmb_tensor, frontier, fanout, 99 + n_front)
+        assert fused is not None
+        want = _two_ops(wops, gops, wrow, wcol, frontier, fanout, 99 + n_front)
+        for name, a, b in zip(("offsets", "unique", "neighbour positions", "centre ids"), fused, want):
+            assert a.dtype == b.dtype and torch.equal(a, b), "%s differ (frontier %d, fan-out %d)" % (name, n_front, fanout)
+        o_off, o_ids, o_lid, _ = oracle.sample_unweighted(row_ptr, col, front, fanout, 99 + n_front, need_egid=False)
+        o_uniq, o_map = oracle.append_unique(front, o_ids)
+        assert np.array_equal(fused[1].cpu().numpy(), o_uniq) and np.array_equal(fused[2].cpu().numpy(), o_map)
+    # nothing to sample at all: a frontier of zero-degree nodes
+    lonely = torch.from_numpy(np.array([4, 4, 4], dtype=id_dtype)).cuda()
+    off, uniq, pos, lid = wops.sample_append_unique(wrow.wmb_tensor, wcol.wmb_tensor, lonely, fanout, 5)
+    assert off.tolist() == [0, 0, 0, 0] and uniq.tolist() == [4, 4, 4] and pos.numel() == 0 and lid.numel() == 0
+
+
+def test_fused_hop_declines_what_it_does_not_cover(gpu_env):
+    """None (WHOLEMEMORY_NOT_SUPPORTED, nothing queued) for a DISTRIBUTED CSR, for column ids of another dtype than the
+    frontier's, for an empty frontier and for max_sample_count <= 0: GraphStructure then runs the two ops."""
+    import torch
+    import wholegraph_amd.torch.wholegraph_ops as wops
+    row_ptr, col = make_csr(500, 9, 3, np.int32)
+    wrow, wcol = _wm_array(gpu_env, "chunked", row_ptr), _wm_array(gpu_env, "chunked", col)
+    f32 = torch.arange(10, dtype=torch.int32, device="cuda")
+    assert wops.sample_append_unique(wrow.wmb_tensor, wcol.wmb_tensor, f32.long(), 5, 1) is None      # int64 frontier, int32 columns
+    assert wops.sample_append_unique(wrow.wmb_tensor, wcol.wmb_tensor, f32[:0], 5, 1) is None
+    assert wops.sample_append_unique(wrow.wmb_tensor, wcol.wmb_tensor, f32, 0, 1) is None
+    assert wops.sample_append_unique(wrow.wmb_tensor, wcol.wmb_tensor, f32, 5, 1) is not None
+    drow, dcol = _wm_array(gpu_env, "distributed", row_ptr), _wm_array(gpu_env, "distributed", col)
+    assert wops.sample_append_unique(drow.wmb_tensor, dcol.wmb_tensor, f32, 5, 1) is None
+
+
+def test_fused_hop_big_frontier_route():
+    """A frontier whose upper bound exceeds what the table route of append_unique serves (forced here with
+    WM_AU_TABLE_MAX=0): the fused op learns the sample count first and takes the sort route — same outputs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch, oracle
+from test_graph_oracle import make_csr
+import wholegraph_amd.torch as wgth
+import wholegraph_amd.torch.wholegraph_ops as wops
+from wholegraph_amd import binding as wmb
+wmb.check(wmb.lib().wholememory_init(0, wmb.LEVEL_ERROR))
+comm = wgth.create_group_communicator(1)
+for dt in (np.int32, np.int64):
+    row_ptr, col = make_csr(4000, 30, 11, dt, heavy=[(3, 900), (4, 0)])
+    ws = []
+    for arr in (row_ptr, col):
+        t = wgth.create_wholememory_tensor(comm, "chunked", "cuda", [arr.shape[0]], torch.from_numpy(arr).dtype, [1])
+        t.get_local_tensor()[0].copy_(torch.from_numpy(arr)); ws.append(t)
+    front = np.random.default_rng(1).integers(0, 4000, 600).astype(dt)
+    off, uniq, pos, lid = wops.sample_append_unique(ws[0].wmb_tensor, ws[1].wmb_tensor, torch.from_numpy(front).cuda(), 12, 77)
+    o_off, o_ids, o_lid, _ = oracle.sample_unweighted(row_ptr, col, front, 12, 77, need_egid=False)
+    o_uniq, o_map = oracle.append_unique(front, o_ids)
+    assert np.array_equal(off.cpu().numpy(), o_off) and np.array_equal(uniq.cpu().numpy(), o_uniq)
+    assert np.array_equal(pos.cpu().numpy(), o_map) and np.array_equal(lid.cpu().numpy(), o_lid)
+print("BIG_ROUTE_OK")
+""" % (root, os.path.join(root, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, WM_AU_TABLE_MAX="0"), capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0 and "BIG_ROUTE_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libwholegraph.so")
 
 # ---- enums (values are ABI; include/wholememory/*.h) -------------------------------------------
 WHOLEMEMORY_SUCCESS = 0
+NOT_SUPPORTED = 9
 ERROR_NAMES = {
     0: "WHOLEMEMORY_SUCCESS", 1: "WHOLEMEMORY_UNKNOW_ERROR", 2: "WHOLEMEMORY_NOT_IMPLEMENTED",
     3: "WHOLEMEMORY_LOGIC_ERROR", 4: "WHOLEMEMORY_CUDA_ERROR", 5: "WHOLEMEMORY_COMMUNICATION_ERROR",
@@ -253,6 +254,8 @@ PROTOTYPES = {
     "wholememory_ext_embedding_cache_info": (_i, [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)]),
     "wholememory_ext_backend_name": (C.c_char_p, []),
     "wholememory_ext_last_rows_kernel": (C.c_char_p, []),
+    "wholememory_ext_sample_append_unique": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_ulonglong, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "wm_testing_install_backend": (_i, [_vp]),
 }
 

@@ -222,11 +222,16 @@ struct wm_device_backend {
   int (*sample_weighted)(const wm_sample_args* a, void* stream);  // max_sample_count in [1, 8192]
   // append_unique in two phases around the host learning the output size: phase 1 leaves the number of neighbour ids
   // that are not targets in *new_count_dev, phase 2 writes the unique array and the raw->unique mapping
+  // n_neighbor_dev (optional): the neighbour array holds n_neighbor entries of ROOM, the number in use is read on the
+  // device (the fused sample + append_unique op learns both counts with one host round trip). A backend route that
+  // cannot work from a device count returns -3 before queueing anything; the caller then passes the exact count.
+  // phase 2 takes the same n_neighbor as phase 1 (the scratch layout depends on it) and the number of entries in use.
   size_t (*append_unique_workspace_bytes)(int n_target, int n_neighbor, wholememory_dtype_t dtype);
   int (*append_unique_phase1)(const void* targets, int n_target, const void* neighbors, int n_neighbor,
-                              wholememory_dtype_t dtype, void* workspace, int* new_count_dev, void* stream);
-  int (*append_unique_phase2)(const void* targets, int n_target, int n_neighbor, wholememory_dtype_t dtype, void* workspace,
-                              void* out_unique, int* mapping, void* stream);
+                              const int* n_neighbor_dev, wholememory_dtype_t dtype, void* workspace, int* new_count_dev,
+                              void* stream);
+  int (*append_unique_phase2)(const void* targets, int n_target, int n_neighbor, int n_neighbor_used,
+                              wholememory_dtype_t dtype, void* workspace, void* out_unique, int* mapping, void* stream);
   int (*csr_add_self_loop)(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
   // out[i, c] = T(float(i)) + in[c] (wholememory_env_test_op)
   int (*env_test_fill)(const void* in, void* out, wholememory_dtype_t dtype, int64_t dim, int64_t entries, int64_t stride,

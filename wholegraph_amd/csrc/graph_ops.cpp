@@ -230,7 +230,11 @@ wholememory_error_code_t sample_without_replacement(
   } else if (total > 0) {
     WM_BK(weighted ? bk->sample_weighted(&a, stream) : bk->sample_unweighted(&a, stream));
   }
-  WM_BK(bk->stream_sync(stream));  // the reference returns with the samples complete (:385,:404)
+  // The reference returns with the samples complete (:385,:404). Here the outputs come from the env allocator, which is
+  // ordered on `stream` (include/wholememory/env_func_ptrs.h), and so is every consumer: the call returns with the kernels
+  // queued — one host round trip per call (the count) instead of two. The DISTRIBUTED route keeps the drain: its gathers are
+  // collectives and peers read this rank's buffers.
+  if (via_gather || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
   return WHOLEMEMORY_SUCCESS;
 }
 
@@ -375,14 +379,123 @@ wholememory_error_code_t graph_append_unique(wholememory_tensor_t target_nodes_t
   temp_mem ws_mem(p_env_fns), count_mem(p_env_fns);
   void* ws       = ws_mem.device(static_cast<int64_t>(bk->append_unique_workspace_bytes(nt, nn, target_desc.dtype)), WHOLEMEMORY_DT_INT8);
   int* count_dev = static_cast<int*>(count_mem.device(1, WHOLEMEMORY_DT_INT));
-  WM_BK(bk->append_unique_phase1(targets, nt, neighbors, nn, target_desc.dtype, ws, count_dev, stream));
+  WM_BK(bk->append_unique_phase1(targets, nt, neighbors, nn, nullptr, target_desc.dtype, ws, count_dev, stream));
   int new_count = 0;
   WM_BK(bk->memcpy_async(&new_count, count_dev, sizeof(int), stream));
   WM_BK(bk->stream_sync(stream));
   void* out = output_alloc(p_env_fns, output_unique_node_memory_context, static_cast<int64_t>(nt) + new_count, target_desc.dtype);
   if (out == nullptr) return WHOLEMEMORY_OUT_OF_MEMORY;
-  WM_BK(bk->append_unique_phase2(targets, nt, nn, target_desc.dtype, ws, out, mapping, stream));
-  WM_BK(bk->stream_sync(stream));
+  WM_BK(bk->append_unique_phase2(targets, nt, nn, nn, target_desc.dtype, ws, out, mapping, stream));
+  if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));  // stream-ordered outputs and scratch, as above
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+// One hop of multi-layer sampling as ONE call (extension; the reference runs the sampler and append_unique as two ops with a
+// host round trip each to size their outputs — wholegraph_ops/unweighted_sample_without_replacement + graph_ops/append_unique,
+// driven by python/.../torch/graph_structure.py:140-196). Here the sampled ids go to scratch sized for the upper bound
+// n_center * max_sample_count, append_unique reads the number in use on the device, and the host learns both counts —
+// samples and new unique ids — with a single synchronise. Outputs are bit-identical to the two-op sequence:
+//   output_sample_offset_tensor  int32 [n_center + 1]   (caller-allocated, as in the sampler)
+//   unique                       frontier ++ new neighbour ids in first-occurrence order   (append_unique's output)
+//   neighbor_pos                 int32 [n_samples]: position of every sampled neighbour in `unique`
+//   center_lid                   int32 [n_samples]: position of its centre in the frontier
+// Mapped CSR (CONTINUOUS / CHUNKED / plain) with column ids of the frontier's dtype only; anything else answers
+// WHOLEMEMORY_NOT_SUPPORTED before touching the stream and the caller takes the two-op route.
+wholememory_error_code_t wholememory_ext_sample_append_unique(
+  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor,
+  wholememory_tensor_t center_nodes_tensor, int max_sample_count, unsigned long long random_seed,
+  wholememory_tensor_t output_sample_offset_tensor, void* output_unique_memory_context,
+  void* output_neighbor_pos_memory_context, void* output_center_localid_memory_context, wholememory_env_func_t* p_env_fns,
+  void* stream)
+{
+  WM_API_BEGIN
+  const auto* bk = graph_backend();
+  if (bk == nullptr) return WHOLEMEMORY_NOT_SUPPORTED;
+  if (p_env_fns == nullptr || output_unique_memory_context == nullptr || output_neighbor_pos_memory_context == nullptr ||
+      output_center_localid_memory_context == nullptr)
+    return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_error_code_t err = WHOLEMEMORY_SUCCESS;
+  wholememory_array_description_t row_desc, col_desc, center_desc, offset_desc;
+  if (!array_of(wm_csr_row_ptr_tensor, "wm_csr_row_ptr_tensor", &row_desc, &err)) return err;
+  if (!array_of(wm_csr_col_ptr_tensor, "wm_csr_col_ptr_tensor", &col_desc, &err)) return err;
+  if (!array_of(center_nodes_tensor, "center_nodes_tensor", &center_desc, &err)) return err;
+  if (!array_of(output_sample_offset_tensor, "output_sample_offset_tensor", &offset_desc, &err)) return err;
+  const auto row_mt = memory_type_of(wm_csr_row_ptr_tensor), col_mt = memory_type_of(wm_csr_col_ptr_tensor);
+  const bool mapped = row_mt != WHOLEMEMORY_MT_HIERARCHY && col_mt != WHOLEMEMORY_MT_HIERARCHY &&
+                      row_mt != WHOLEMEMORY_MT_DISTRIBUTED && col_mt != WHOLEMEMORY_MT_DISTRIBUTED;
+  const int64_t n = center_desc.size;
+  const int64_t room = n * static_cast<int64_t>(std::max(max_sample_count, 0));
+  if (!mapped || max_sample_count <= 0 || row_desc.dtype != WHOLEMEMORY_DT_INT64 || offset_desc.dtype != WHOLEMEMORY_DT_INT ||
+      !is_index_dtype(center_desc.dtype) || col_desc.dtype != center_desc.dtype || offset_desc.size < n + 1 || n == 0 ||
+      n + room >= (INT64_C(1) << 31) - 1)
+    return WHOLEMEMORY_NOT_SUPPORTED;
+  wm_sample_args a{};
+  WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_row_ptr_tensor, &a.row_gref));
+  WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_col_ptr_tensor, &a.col_gref));
+  a.row_storage_offset = row_desc.storage_offset;
+  a.col_storage_offset = col_desc.storage_offset;
+  a.col_dtype          = col_desc.dtype;
+  a.centers            = wholememory_tensor_get_data_pointer(center_nodes_tensor);
+  a.center_dtype       = center_desc.dtype;
+  a.n_center           = static_cast<int>(n);
+  a.max_sample_count   = max_sample_count;
+  a.random_seed        = random_seed;
+  int* offsets         = static_cast<int*>(wholememory_tensor_get_data_pointer(output_sample_offset_tensor));
+  a.sample_offsets     = offsets;
+
+  const int nt = static_cast<int>(n), nn_room = static_cast<int>(room);
+  temp_mem counts_mem(p_env_fns), scan_mem(p_env_fns), ids_mem(p_env_fns), lid_mem(p_env_fns), ws_mem(p_env_fns),
+    count_mem(p_env_fns), host_mem(p_env_fns);
+  int* counts          = static_cast<int*>(counts_mem.device(n + 1, WHOLEMEMORY_DT_INT));
+  const size_t scan_ws = bk->scan_i32_workspace_bytes(n + 1);
+  void* scan_ws_ptr    = scan_mem.device(static_cast<int64_t>(scan_ws), WHOLEMEMORY_DT_INT8);
+  void* ids            = ids_mem.device(room, col_desc.dtype);
+  int* lid             = static_cast<int*>(lid_mem.device(room, WHOLEMEMORY_DT_INT));
+  void* ws = ws_mem.device(static_cast<int64_t>(bk->append_unique_workspace_bytes(nt, nn_room, center_desc.dtype)), WHOLEMEMORY_DT_INT8);
+  int* count_dev = static_cast<int*>(count_mem.device(1, WHOLEMEMORY_DT_INT));
+  int* host      = static_cast<int*>(host_mem.pinned(2, WHOLEMEMORY_DT_INT));
+
+  WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, a.n_center, max_sample_count,
+                          counts, stream));
+  WM_BK(bk->exclusive_scan_i32(counts, offsets, n + 1, scan_ws_ptr, scan_ws, stream));
+  a.out_ids        = ids;
+  a.out_center_lid = lid;
+  WM_BK(bk->sample_unweighted(&a, stream));   // writes exactly offsets[n] entries of the scratch arrays
+  int rc = bk->append_unique_phase1(a.centers, nt, ids, nn_room, offsets + n, center_desc.dtype, ws, count_dev, stream);
+  int total = 0, n_new = 0;
+  if (rc == -3) {
+    // a frontier too big for the route that works from a device-side count: learn the sample count first
+    WM_BK(bk->memcpy_async(host, offsets + n, sizeof(int), stream));
+    WM_BK(bk->stream_sync(stream));
+    total = host[0];
+    temp_mem ws2_mem(p_env_fns);
+    void* ws2 = ws2_mem.device(static_cast<int64_t>(bk->append_unique_workspace_bytes(nt, total, center_desc.dtype)), WHOLEMEMORY_DT_INT8);
+    WM_BK(bk->append_unique_phase1(a.centers, nt, ids, total, nullptr, center_desc.dtype, ws2, count_dev, stream));
+    WM_BK(bk->memcpy_async(host + 1, count_dev, sizeof(int), stream));
+    WM_BK(bk->stream_sync(stream));
+    n_new = host[1];
+    void* uniq = output_alloc(p_env_fns, output_unique_memory_context, static_cast<int64_t>(nt) + n_new, center_desc.dtype);
+    int* pos   = static_cast<int*>(output_alloc(p_env_fns, output_neighbor_pos_memory_context, total, WHOLEMEMORY_DT_INT));
+    int* olid  = static_cast<int*>(output_alloc(p_env_fns, output_center_localid_memory_context, total, WHOLEMEMORY_DT_INT));
+    if (uniq == nullptr || (total > 0 && (pos == nullptr || olid == nullptr))) return WHOLEMEMORY_OUT_OF_MEMORY;
+    WM_BK(bk->append_unique_phase2(a.centers, nt, total, total, center_desc.dtype, ws2, uniq, pos, stream));
+    if (total > 0) WM_BK(bk->memcpy_async(olid, lid, sizeof(int) * static_cast<size_t>(total), stream));
+    WM_BK(bk->stream_sync(stream));   // ws2 goes out of scope here
+    return WHOLEMEMORY_SUCCESS;
+  }
+  if (rc != 0) return rc == -1 ? WHOLEMEMORY_LOGIC_ERROR : WHOLEMEMORY_CUDA_ERROR;
+  WM_BK(bk->memcpy_async(host, offsets + n, sizeof(int), stream));
+  WM_BK(bk->memcpy_async(host + 1, count_dev, sizeof(int), stream));
+  WM_BK(bk->stream_sync(stream));             // the only host round trip of the hop
+  total = host[0], n_new = host[1];
+  void* uniq = output_alloc(p_env_fns, output_unique_memory_context, static_cast<int64_t>(nt) + n_new, center_desc.dtype);
+  int* pos   = static_cast<int*>(output_alloc(p_env_fns, output_neighbor_pos_memory_context, total, WHOLEMEMORY_DT_INT));
+  int* olid  = static_cast<int*>(output_alloc(p_env_fns, output_center_localid_memory_context, total, WHOLEMEMORY_DT_INT));
+  if (uniq == nullptr || (total > 0 && (pos == nullptr || olid == nullptr))) return WHOLEMEMORY_OUT_OF_MEMORY;
+  WM_BK(bk->append_unique_phase2(a.centers, nt, nn_room, total, center_desc.dtype, ws, uniq, pos, stream));
+  if (total > 0) WM_BK(bk->memcpy_async(olid, lid, sizeof(int) * static_cast<size_t>(total), stream));
+  if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));   // outputs and scratch are ordered on `stream`
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
 }

@@ -470,9 +470,11 @@ __device__ __forceinline__ uint64_t au_cas(uint64_t* a, uint64_t expect, uint64_
 
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, int nt, const KeyT* neighbors, int nn,
-                                                           KeyT* slots, uint32_t* min_pos, uint32_t* slot_of, uint32_t cap)
+                                                           const int* nn_dev, KeyT* slots, uint32_t* min_pos,
+                                                           uint32_t* slot_of, uint32_t cap)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nn_dev != nullptr) nn = min(nn, *nn_dev);   // room for nn neighbours, *nn_dev of them in use
   if (i >= nt + nn) return;
   constexpr KeyT kEmpty = ~static_cast<KeyT>(0);
   const KeyT key        = i < nt ? targets[i] : neighbors[i - nt];
@@ -492,12 +494,14 @@ __global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, 
 }
 
 __global__ __launch_bounds__(kBlock) void au_flag_kernel(const uint32_t* min_pos, const uint32_t* slot_of, int nt, int nn,
-                                                         int* first_flag)
+                                                         const int* nn_dev, int* first_flag)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > nn) return;
-  // first occurrence of an id that no target holds (targets sit at positions < nt); entry nn closes the exclusive scan
-  first_flag[p] = p < nn && min_pos[slot_of[nt + p]] == static_cast<uint32_t>(nt + p) ? 1 : 0;
+  const int used = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+  // first occurrence of an id that no target holds (targets sit at positions < nt); the entries past the ones in use are
+  // zero, so the exclusive scan's last entry (index nn) is the number of new ids whatever `used` is
+  first_flag[p] = p < used && min_pos[slot_of[nt + p]] == static_cast<uint32_t>(nt + p) ? 1 : 0;
 }
 
 template <typename KeyT>
@@ -514,7 +518,8 @@ __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, cons
 }
 
 template <typename KeyT>
-int au_phase1(const void* targets, int nt, const void* neighbors, int nn, void* ws, int* new_count_dev, hipStream_t stream)
+int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const int* nn_dev, void* ws, int* new_count_dev,
+              hipStream_t stream)
 {
   using UKey  = typename std::make_unsigned<KeyT>::type;
   auto l      = au_plan<UKey>(ws, nt, nn);
@@ -522,10 +527,10 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, void* 
   if (hipMemsetAsync(l.slots, 0xFF, l.table_bytes, stream) != hipSuccess) return -2;
   if (n > 0)
     hipLaunchKernelGGL((au_insert_kernel<UKey>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-                       static_cast<const UKey*>(targets), nt, static_cast<const UKey*>(neighbors), nn, l.slots, l.min_pos,
-                       l.slot_of, l.cap);
+                       static_cast<const UKey*>(targets), nt, static_cast<const UKey*>(neighbors), nn, nn_dev, l.slots,
+                       l.min_pos, l.slot_of, l.cap);
   hipLaunchKernelGGL(au_flag_kernel, dim3((nn + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.min_pos, l.slot_of, nt, nn,
-                     l.first_flag);
+                     nn_dev, l.first_flag);
   size_t tb = l.temp_bytes;
   if (rocprim::exclusive_scan(l.temp, tb, l.first_flag, l.new_rank, 0, static_cast<size_t>(nn) + 1, rocprim::plus<int>(),
                               stream) != hipSuccess)
@@ -536,14 +541,14 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, void* 
 }
 
 template <typename KeyT>
-int au_phase2(const void* targets, int nt, int nn, void* ws, void* out_unique, int* mapping, hipStream_t stream)
+int au_phase2(const void* targets, int nt, int nn, int nn_used, void* ws, void* out_unique, int* mapping, hipStream_t stream)
 {
   using UKey = typename std::make_unsigned<KeyT>::type;
-  auto l     = au_plan<UKey>(ws, nt, nn);
+  auto l     = au_plan<UKey>(ws, nt, nn);   // the layout phase 1 used
   if (nt > 0 && hipMemcpyAsync(out_unique, targets, sizeof(KeyT) * nt, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -2;
-  if (nn > 0)
-    hipLaunchKernelGGL((au_emit_kernel<UKey>), dim3((nn + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.slots, l.min_pos,
-                       l.slot_of, l.new_rank, nt, nn, static_cast<UKey*>(out_unique), mapping);
+  if (nn_used > 0)
+    hipLaunchKernelGGL((au_emit_kernel<UKey>), dim3((nn_used + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.slots, l.min_pos,
+                       l.slot_of, l.new_rank, nt, nn_used, static_cast<UKey*>(out_unique), mapping);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -833,28 +838,32 @@ size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt)
   if (au_use_table(nt, nn, dt)) return dt == WHOLEMEMORY_DT_INT ? au_plan<uint32_t>(nullptr, nt, nn).total : au_plan<uint64_t>(nullptr, nt, nn).total;
   return dt == WHOLEMEMORY_DT_INT ? aus_plan<uint32_t>(nullptr, nt, nn).total : aus_plan<uint64_t>(nullptr, nt, nn).total;
 }
-int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, wholememory_dtype_t dt, void* ws,
-                             int* new_count_dev, void* stream)
+int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, const int* nn_dev,
+                             wholememory_dtype_t dt, void* ws, int* new_count_dev, void* stream_v)
 {
-  const bool table = au_use_table(nt, nn, dt);
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const bool table   = au_use_table(nt, nn, dt);
+  if (!table && nn_dev != nullptr) return -3;   // the sort route needs the exact count on the host
   if (dt == WHOLEMEMORY_DT_INT)
-    return table ? au_phase1<int32_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream))
-                 : aus_phase1<int32_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream));
+    return table ? au_phase1<int32_t>(targets, nt, neighbors, nn, nn_dev, ws, new_count_dev, stream)
+                 : aus_phase1<int32_t>(targets, nt, neighbors, nn, ws, new_count_dev, stream);
   if (dt == WHOLEMEMORY_DT_INT64)
-    return table ? au_phase1<int64_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream))
-                 : aus_phase1<int64_t>(targets, nt, neighbors, nn, ws, new_count_dev, static_cast<hipStream_t>(stream));
+    return table ? au_phase1<int64_t>(targets, nt, neighbors, nn, nn_dev, ws, new_count_dev, stream)
+                 : aus_phase1<int64_t>(targets, nt, neighbors, nn, ws, new_count_dev, stream);
   return -1;
 }
-int hip_append_unique_phase2(const void* targets, int nt, int nn, wholememory_dtype_t dt, void* ws, void* out_unique,
-                             int* mapping, void* stream)
+int hip_append_unique_phase2(const void* targets, int nt, int nn, int nn_used, wholememory_dtype_t dt, void* ws,
+                             void* out_unique, int* mapping, void* stream_v)
 {
-  const bool table = au_use_table(nt, nn, dt);
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const bool table   = au_use_table(nt, nn, dt);
+  if (!table && nn_used != nn) return -3;
   if (dt == WHOLEMEMORY_DT_INT)
-    return table ? au_phase2<int32_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream))
-                 : aus_phase2<int32_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream));
+    return table ? au_phase2<int32_t>(targets, nt, nn, nn_used, ws, out_unique, mapping, stream)
+                 : aus_phase2<int32_t>(targets, nt, nn, ws, out_unique, mapping, stream);
   if (dt == WHOLEMEMORY_DT_INT64)
-    return table ? au_phase2<int64_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream))
-                 : aus_phase2<int64_t>(targets, nt, nn, ws, out_unique, mapping, static_cast<hipStream_t>(stream));
+    return table ? au_phase2<int64_t>(targets, nt, nn, nn_used, ws, out_unique, mapping, stream)
+                 : aus_phase2<int64_t>(targets, nt, nn, ws, out_unique, mapping, stream);
   return -1;
 }
 int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream)

@@ -4,9 +4,10 @@ Public surface = ``pylibwholegraph.torch.graph_structure.GraphStructure`` (refer
 ``python/pylibwholegraph/pylibwholegraph/torch/graph_structure.py:21-228``: same method names, arguments and return
 layouts, so cuGraph-DGL / PyG call sites keep working). The bodies are this package's own: the CSR pair is validated once
 in a helper, attributes live in one registry keyed by kind, and the multi-hop sampler is a loop over a per-hop record
-instead of four parallel lists. One extension: ``multilayer_sample_without_replacement(..., random_seeds=[...])`` fixes the
+instead of four parallel lists. Extensions: ``multilayer_sample_without_replacement(..., random_seeds=[...])`` fixes the
 per-hop sampler seeds (the reference draws them from the global RNG), which is what lets tests/test_c5_flow_gpu.py replay
-the whole chain on the CPU oracle.
+the whole chain on the CPU oracle; and an unweighted hop on a CSR mapped into this rank runs as ONE library call
+(``wholegraph_ops.sample_append_unique``: sampler + append_unique with a single host round trip, same outputs).
 """
 from collections import namedtuple
 from typing import List, Optional, Sequence, Union
@@ -110,8 +111,17 @@ class GraphStructure(object):
         frontier = node_ids
         for depth, fanout in enumerate(max_neighbors):          # depth 0 = next to the seeds = layer hops - 1
             seed = None if random_seeds is None else random_seeds[depth]
-            offsets, neighbours, centre_lid = self._one_hop(frontier, fanout, weight_name, seed, True, False)
-            widened, neighbour_pos = graph_ops.append_unique(frontier, neighbours, need_neighbor_raw_to_unique=True)
+            fused = None
+            if weight_name is None:
+                # sampler + append_unique as one library call with one host round trip (extension); None = not applicable
+                # to this graph (CSR not mapped into this rank, id dtypes differ ...): the two ops below then
+                fused = wholegraph_ops.sample_append_unique(self.csr_row_ptr.wmb_tensor, self.csr_col_ind.wmb_tensor,
+                                                            frontier, fanout, seed)
+            if fused is not None:
+                offsets, widened, neighbour_pos, centre_lid = fused
+            else:
+                offsets, neighbours, centre_lid = self._one_hop(frontier, fanout, weight_name, seed, True, False)
+                widened, neighbour_pos = graph_ops.append_unique(frontier, neighbours, need_neighbor_raw_to_unique=True)
             layers[hops - 1 - depth] = _Hop(widened, torch.stack([neighbour_pos, centre_lid]), offsets, neighbour_pos)
             frontier = widened
         return ([hop.targets for hop in layers] + [node_ids], [hop.edge_index for hop in layers],

@@ -54,6 +54,29 @@ def unweighted_sample_without_replacement(wm_csr_row_ptr_tensor, wm_csr_col_ptr_
     return _sample_outputs(offset, dest, lid, egid, need_center_local_output, need_edge_output)
 
 
+def sample_append_unique(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, center_nodes_tensor: torch.Tensor, max_sample_count: int,
+                         random_seed: Union[int, None] = None):
+    """Extension (include/wholememory/wholegraph_amd_ext.h): one hop = unweighted sampling + append_unique(center nodes,
+    sampled neighbours) in ONE call with one host round trip. Returns (sample_offset int32 [n + 1], unique nodes, position of
+    every sampled neighbour in `unique` int32, center local id int32) — or None when the library declines (CSR not mapped
+    into this rank, dtypes differ, empty frontier, max_sample_count <= 0): run the two ops then."""
+    row, col = _handle(wm_csr_row_ptr_tensor), _handle(wm_csr_col_ptr_tensor)
+    assert center_nodes_tensor.dim() == 1
+    if random_seed is None:
+        random_seed = random.getrandbits(64)
+    offset = torch.empty(center_nodes_tensor.shape[0] + 1, device=op_device(), dtype=torch.int)
+    uniq, pos, lid = TorchMemoryContext(), TorchMemoryContext(), TorchMemoryContext()
+    wc, wo = wrap_torch_tensor(center_nodes_tensor), wrap_torch_tensor(offset)
+    rc = wmb.lib().wholememory_ext_sample_append_unique(
+        row, col, wc.handle, int(max_sample_count), C.c_ulonglong(random_seed & 0xFFFFFFFFFFFFFFFF), wo.handle,
+        C.c_void_p(uniq.get_c_context()), C.c_void_p(pos.get_c_context()), C.c_void_p(lid.get_c_context()),
+        get_wholegraph_env_fns(), C.c_void_p(get_stream()))
+    if rc == wmb.NOT_SUPPORTED:
+        return None
+    wmb.check(rc)
+    return offset, uniq.get_tensor(), pos.get_tensor(), lid.get_tensor()
+
+
 def weighted_sample_without_replacement(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, wm_csr_weight_ptr_tensor,
                                         center_nodes_tensor: torch.Tensor, max_sample_count: int,
                                         random_seed: Union[int, None] = None, need_center_local_output: bool = False,
