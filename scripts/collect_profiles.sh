@@ -14,7 +14,7 @@ python bench.py > $OUT/${TAG}_n1_bench.json 2> $OUT/${TAG}_n1_bench.err
 cut -c1-400 $OUT/${TAG}_n1_bench.json
 stats() {  # stats <name> <bench args...>: bench line + kernel stats of the same command
   local name=$1; shift
-  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$name && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python $R/bench.py "$@" > $OUT/${TAG}_${name}_bench_under_rocprof.json 2>/dev/null )
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$name && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python $R/bench.py "$@" > $OUT/${TAG}_${name}_under_rocprof.json 2>/dev/null )
   cp $(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
   head -4 $OUT/${TAG}_${name}_kernel_stats.csv | cut -c1-160
 }
