@@ -737,8 +737,9 @@ __device__ __forceinline__ tile_raw4 tile_pack(const tile_vals<16 / sizeof(T)>& 
   return r;
 }
 
-template <typename IdxT, int OPT, int RPS, bool CACHED, typename T = float, int KU = 0>
-__global__ __launch_bounds__(kBlock) void step_tile_kernel(opt_params p)
+template <typename IdxT, int OPT, int RPS, bool CACHED, typename T = float, int KU = 0, int OCC = 0>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC > 0 ? OCC : 1, OCC > 0 ? OCC : 8)))
+void step_tile_kernel(opt_params p)
 {
   constexpr int kVE          = 16 / static_cast<int>(sizeof(T));  // elements per lane
   constexpr bool k16         = sizeof(T) == 2;
@@ -1280,6 +1281,18 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
     if (const char* e = getenv("WM_STEP_BLOCKS")) tblocks = std::min(tblocks, std::max(1, atoi(e)));
     tblocks             = std::max(tblocks, 1);
     const int vecs      = static_cast<int>(p.a.dim / 4);
+    // SGD on 512-byte fp32 rows (two runs per wave instruction), uncached: the same kernel compiled for 7 waves / SIMD — a
+    // 72-register budget, 10 values spilled to scratch — instead of the 5 its natural 84 registers allow: whole call 3.05 ->
+    // 2.99 ms per 10 M rows (experiments/occ_ab.py, interleaved in one process). The other row widths lose with it (dim 32:
+    // +7 %, 64: +2 %, 256: +0.5-1 %; 6 waves lose everywhere) and keep their natural budget. WM_TILE_OCC=5 switches it off.
+    if constexpr (OPT == WHOLEMEMORY_OPT_SGD) {
+      const char* occ_env = getenv("WM_TILE_OCC");
+      const bool natural  = occ_env != nullptr && atoi(occ_env) == 5;
+      if (!cached && !natural && vecs > 16 && vecs <= 32) {
+        hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, 2, false, float, 0, 7>), dim3(tblocks), dim3(kBlock), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+      }
+    }
 #define WM_TILE(RPS)                                                                                                    \
   do {                                                                                                                  \
     if (cached)                                                                                                         \
