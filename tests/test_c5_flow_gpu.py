@@ -14,12 +14,13 @@ from test_graph_oracle import make_csr
 pytestmark = pytest.mark.gpu
 
 
-def _wm_array(comm, mt, arr):
+def _wm_array(comm, mt, arr, loc="cuda"):
     import torch
     import wholegraph_amd.torch as wgth
-    t = wgth.create_wholememory_tensor(comm, mt, "cuda", [arr.shape[0]], torch.from_numpy(arr).dtype, [1])
-    local, _ = t.get_local_tensor()
+    t = wgth.create_wholememory_tensor(comm, mt, loc, [arr.shape[0]], torch.from_numpy(arr).dtype, [1])
+    local, _ = t.get_local_tensor(host_view=(loc == "cpu"))
     local.copy_(torch.from_numpy(arr))
+    torch.cuda.synchronize()
     return t
 
 
@@ -112,6 +113,20 @@ def test_fused_hop_equals_the_two_ops(gpu_env, mt, id_dtype, fanout):
     lonely = torch.from_numpy(np.array([4, 4, 4], dtype=id_dtype)).cuda()
     off, uniq, pos, lid = wops.sample_append_unique(wrow.wmb_tensor, wcol.wmb_tensor, lonely, fanout, 5)
     assert off.tolist() == [0, 0, 0, 0] and uniq.tolist() == [4, 4, 4] and pos.numel() == 0 and lid.numel() == 0
+
+
+def test_fused_hop_on_a_host_located_graph(gpu_env):
+    """the CSR in pinned host memory (memory_location "cpu"), read by the kernels over PCIe: the fused hop still applies"""
+    import torch
+    import wholegraph_amd.torch.wholegraph_ops as wops
+    import wholegraph_amd.torch.graph_ops as gops
+    row_ptr, col = make_csr(3001, 25, 5, np.int64, heavy=[(3, 900), (4, 0)])
+    wrow, wcol = _wm_array(gpu_env, "chunked", row_ptr, "cpu"), _wm_array(gpu_env, "chunked", col, "cpu")
+    frontier = torch.from_numpy(np.random.default_rng(3).integers(0, 3001, 400).astype(np.int64)).cuda()
+    fused = wops.sample_append_unique(wrow.wmb_tensor, wcol.wmb_tensor, frontier, 10, 123)
+    assert fused is not None
+    for a, b in zip(fused, _two_ops(wops, gops, wrow, wcol, frontier, 10, 123)):
+        assert torch.equal(a, b)
 
 
 def test_fused_hop_declines_what_it_does_not_cover(gpu_env):
