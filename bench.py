@@ -428,7 +428,12 @@ def main():
     # plain single allocation would have given.
     output_placement = None
     if a.op == "gather" and world == 1 and a.out_candidates > 1:
-        cands = [out] + [torch.empty((a.indices, a.dim), dtype=tdt, device="cuda") for _ in range(a.out_candidates - 1)]
+        cands = [out]
+        try:
+            for _ in range(a.out_candidates - 1):
+                cands.append(torch.empty((a.indices, a.dim), dtype=tdt, device="cuda"))
+        except torch.cuda.OutOfMemoryError:   # a table that leaves no room for more candidates: choose among those that fit
+            pass
         probe_ms = []
         for c in cands:
             for _ in range(2):
