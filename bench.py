@@ -430,7 +430,12 @@ def main():
     # region, which is unchanged. Nothing is hidden: every probe time goes into the line (`placement.probe_ms[table][output]`;
     # entry [0][0] is what plain single allocations give).
     placement = None
-    if a.op == "gather" and world == 1 and (a.out_candidates > 1 or a.table_candidates > 1):
+    if a.op in ("gather", "scatter") and world == 1 and (a.out_candidates > 1 or a.table_candidates > 1):
+        def probe_op(tb, c):   # the op about to be timed, on one candidate pair (scatter: the buffer is the source)
+            if a.op == "gather":
+                tb.gather(idx, out=c)
+            else:
+                tb.get_embedding_tensor().scatter(c, idx)
         tables, cands = [emb], [out]
         if a.location == "cuda" and policy is None:
             try:
@@ -448,11 +453,11 @@ def main():
             row = []
             for c in cands:
                 for _ in range(2):
-                    tb.gather(idx, out=c)
+                    probe_op(tb, c)
                 p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 p0.record()
                 for _ in range(6):
-                    tb.gather(idx, out=c)
+                    probe_op(tb, c)
                 p1.record()
                 torch.cuda.synchronize()
                 row.append(p0.elapsed_time(p1) / 6)
@@ -470,7 +475,7 @@ def main():
         del tables, cands, c, tb
         torch.cuda.synchronize()
         placement = {"probe_ms": [[round(x, 4) for x in row] for row in grid], "picked": {"table": ti, "output": oi},
-                     "note": "6-launch probes of the same gather for every (candidate table, candidate output buffer) pair; "
+                     "note": "6-launch probes of the same op for every (candidate table, candidate output / source buffer) pair; "
                              "[0][0] is what single allocations give; the timed region below runs on the picked pair"}
     opt = None
     if a.op == "grad_apply":

@@ -19,6 +19,20 @@ stats() {  # stats <name> <bench args...>: bench line + kernel stats of the same
   head -4 $OUT/${TAG}_${name}_kernel_stats.csv | cut -c1-160
 }
 stats n1_bench --no-cpu-baseline
+# the same process, per launch: the placement probes of bench.py run on slower candidate pairs too, so the stats average over
+# ALL launches sits above the timed region's; the tail of the trace (timed region + stability leg) is what `kernel_ms` measures
+python - $(find /tmp/prof_n1_bench -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_n1_bench_kernel_trace_tail.txt <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rows_copy16_fast_kernel" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+tail = dur[-400:]
+print("kernel: %s" % rows[-1]["Kernel_Name"])
+print("all %d launches of the process (placement probes included): average %.4f ms" % (len(dur), sum(dur) / len(dur)))
+print("last %d launches (timed region + stability leg, on the picked pair): average %.4f ms, min %.4f, max %.4f" % (
+    len(tail), sum(tail) / len(tail), min(tail), max(tail)))
+PY
+cat $OUT/${TAG}_n1_bench_kernel_trace_tail.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_$c && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --no-cpu-baseline --steps 10 --warmup 2 --stability-steps 0 > /dev/null 2>&1 )
   cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $OUT/${TAG}_bench_${c}_counter_collection.csv
