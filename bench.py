@@ -15,7 +15,8 @@ visible GPU, like the reference bench forks one process per device, gather_scatt
    or   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
 The timed region is EXACTLY --steps steps between two barriers; `stability` is a separate leg of per-step HIP-event times
 (min / median / p95 over >= 200 steps) run after it, so one noisy neighbour cannot hide in a 36 ms window.
-Table and output buffer: allocated once before the timed region, as in the reference bench — chosen among `--table-candidates`
+Table and output buffer (gather; source buffer for scatter / SGD gradient apply): allocated once before the timed region, as in
+the reference bench — chosen among `--table-candidates`
 (default 3) x `--out-candidates` (default 6) allocations, every pair probed with 6 launches, the fastest pair kept (the memory
 system serves different physical placements of the two buffers at different levels: DESIGN.md section 3.1). Every probe is in
 the line (`placement.probe_ms`; entry [0][0] = what single allocations give); `--table-candidates 1 --out-candidates 1` takes
@@ -430,12 +431,17 @@ def main():
     # region, which is unchanged. Nothing is hidden: every probe time goes into the line (`placement.probe_ms[table][output]`;
     # entry [0][0] is what plain single allocations give).
     placement = None
-    if a.op in ("gather", "scatter") and world == 1 and (a.out_candidates > 1 or a.table_candidates > 1):
-        def probe_op(tb, c):   # the op about to be timed, on one candidate pair (scatter: the buffer is the source)
+    sgd_apply = a.op == "grad_apply" and a.optimizer == "sgd" and a.dtype == "f32"   # (stateful optimizers: 2-3 x the table per candidate)
+    if (a.op in ("gather", "scatter") or sgd_apply) and world == 1 and (a.out_candidates > 1 or a.table_candidates > 1):
+        def probe_op(tb, c):   # the op about to be timed, on one candidate pair (scatter / gradient apply: the buffer is the source)
             if a.op == "gather":
                 tb.gather(idx, out=c)
-            else:
+            elif a.op == "scatter":
                 tb.get_embedding_tensor().scatter(c, idx)
+            else:
+                tb.add_gradients(idx, c)
+                tb.need_apply = True
+                tb.apply_gradients(0.01)
         tables, cands = [emb], [out]
         if a.location == "cuda" and policy is None:
             try:
@@ -448,6 +454,9 @@ def main():
                 cands.append(torch.empty((a.indices, a.dim), dtype=tdt, device="cuda"))
         except torch.cuda.OutOfMemoryError:
             pass
+        if sgd_apply:
+            for tb in tables:
+                wgth.create_wholememory_optimizer(tb, a.optimizer, {})
         grid = []
         for tb in tables:
             row = []
@@ -479,7 +488,8 @@ def main():
                              "[0][0] is what single allocations give; the timed region below runs on the picked pair"}
     opt = None
     if a.op == "grad_apply":
-        opt = wgth.create_wholememory_optimizer(emb, a.optimizer, {})
+        if not (sgd_apply and placement is not None):   # (the placement probes gave every candidate its optimizer)
+            opt = wgth.create_wholememory_optimizer(emb, a.optimizer, {})
         out.normal_()
 
     def step():
