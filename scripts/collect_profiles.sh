@@ -69,8 +69,8 @@ python bench.py --op sample_gather --steps 50 --stability-steps 50 > $OUT/${TAG}
 stats sample_gather --op sample_gather --steps 50 --stability-steps 0
 if [ -x tools/gather_scatter_bench ]; then
   for f in gather scatter; do
-    echo "\$ tools/gather_scatter_bench -t chunked -l device -e 51200000000 -g 5120000000 -d 128 -c 20 -f $f" >> $OUT/${TAG}_cpp_bench.txt
-    tools/gather_scatter_bench -t chunked -l device -e 51200000000 -g 5120000000 -d 128 -c 20 -f $f >> $OUT/${TAG}_cpp_bench.txt 2>&1
+    echo "\$ tools/gather_scatter_bench -t chunked -l device -e 51200000000 -g 5120000000 -d 128 -c 20 -p 6 -f $f" >> $OUT/${TAG}_cpp_bench.txt
+    tools/gather_scatter_bench -t chunked -l device -e 51200000000 -g 5120000000 -d 128 -c 20 -p 6 -f $f >> $OUT/${TAG}_cpp_bench.txt 2>&1
   done
   tail -8 $OUT/${TAG}_cpp_bench.txt
 fi

@@ -11,6 +11,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -37,6 +38,7 @@ struct options {
   int loops            = 20;
   bool scatter         = false;
   int gpus             = 1;
+  int candidates       = 1;  // -p, gather / scatter row buffers to choose from (the level follows placement)
 };
 
 struct shared_page {
@@ -144,12 +146,53 @@ int run_rank(const options& o, int rank, shared_page* sh)
     return o.scatter ? wholememory_scatter(rows_t, idx_t, table, env, nullptr, -1)
                      : wholememory_gather(table, idx_t, rows_t, env, nullptr, -1);
   };
-  for (int i = 0; i < 3; i++) WM_OK(call());
-  HIP_OK(hipDeviceSynchronize());
-  WM_OK(wholememory_communicator_barrier(comm));
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
+  // -p K: the row buffer is chosen among K allocations, each probed with a few calls of the op about to be timed (the level
+  // the memory system serves depends on where the buffer sits relative to the table: DESIGN.md section 3.1); every probe is
+  // printed, the first one is what a single allocation gives
+  std::vector<float*> spare;
+  if (o.candidates > 1) {
+    float* best_buf = d_rows;
+    float best_ms   = 0;
+    for (int k = 0; k < o.candidates; k++) {
+      float* buf = d_rows;
+      if (k > 0) {
+        if (hipMalloc(&buf, sizeof(float) * n * o.dim) != hipSuccess) break;
+        HIP_OK(hipMemcpy(buf, d_rows, sizeof(float) * n * o.dim, hipMemcpyDeviceToDevice));
+        spare.push_back(buf);
+      }
+      wholememory_tensor_t cand_t = nullptr;
+      WM_OK(wholememory_make_tensor_from_pointer(&cand_t, buf, &ot));
+      auto probe = [&]() {
+        return o.scatter ? wholememory_scatter(cand_t, idx_t, table, env, nullptr, -1)
+                         : wholememory_gather(table, idx_t, cand_t, env, nullptr, -1);
+      };
+      for (int i = 0; i < 2; i++) WM_OK(probe());
+      HIP_OK(hipEventRecord(e0, nullptr));
+      for (int i = 0; i < 6; i++) WM_OK(probe());
+      HIP_OK(hipEventRecord(e1, nullptr));
+      HIP_OK(hipEventSynchronize(e1));
+      float pms = 0;
+      HIP_OK(hipEventElapsedTime(&pms, e0, e1));
+      pms /= 6;
+      if (rank == 0) printf("  candidate row buffer %d: %.4f ms per call\n", k, pms);
+      if (k == 0 || pms < best_ms) best_ms = pms, best_buf = buf;
+      WM_OK(wholememory_destroy_tensor(cand_t));
+    }
+    if (best_buf != d_rows) {   // the timed calls use the chosen buffer
+      WM_OK(wholememory_destroy_tensor(rows_t));
+      WM_OK(wholememory_make_tensor_from_pointer(&rows_t, best_buf, &ot));
+      for (auto& b : spare)
+        if (b == best_buf) std::swap(b, d_rows);
+    }
+    for (auto b : spare) (void)hipFree(b);
+    spare.clear();
+  }
+  for (int i = 0; i < 3; i++) WM_OK(call());
+  HIP_OK(hipDeviceSynchronize());
+  WM_OK(wholememory_communicator_barrier(comm));
   HIP_OK(hipEventRecord(e0, nullptr));
   for (int i = 0; i < o.loops; i++) WM_OK(call());
   HIP_OK(hipEventRecord(e1, nullptr));
@@ -195,6 +238,7 @@ const char* kUsage =
   "  -g, --gather_size           bytes gathered / scattered per rank per call     (default 64 MiB)\n"
   "  -d, --embedding_dim         fp32 elements per row                            (default 128)\n"
   "  -c, --loop_count            timed calls                                      (default 20)\n"
+  "  -p, --placement_candidates  row buffers to choose the fastest from           (default 1: the first allocation)\n"
   "  -f, --test_type             gather | scatter                                 (default gather)\n"
   "  -n, --num_gpu               processes = GPUs of this node                    (default 1)\n";
 
@@ -222,6 +266,8 @@ bool parse(int argc, char** argv, options* o)
       o->dim = atoll(value());
     } else if (a == "-c" || a == "--loop_count") {
       o->loops = atoi(value());
+    } else if (a == "-p" || a == "--placement_candidates") {
+      o->candidates = std::max(1, atoi(value()));
     } else if (a == "-f" || a == "--test_type") {
       std::string v = value();
       if (v != "gather" && v != "scatter") return false;
