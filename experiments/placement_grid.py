@@ -20,6 +20,8 @@ def timed(fn, reps=12):
     return (time.perf_counter() - t0) / reps * 1e3
 embs = [wgth.create_embedding(comm, "chunked", "cuda", torch.float32, [rows, dim]) for _ in range(T)]
 outs = [torch.empty((n, dim), device="cuda") for _ in range(O)]
+print("table addresses: " + " ".join("0x%x" % e.get_embedding_tensor().get_local_tensor()[0].data_ptr() for e in embs))
+print("output addresses: " + " ".join("0x%x" % o.data_ptr() for o in outs))
 print("gather ms, rows = tables, columns = output buffers")
 for ti, e in enumerate(embs):
     print("  table %d: " % ti + "  ".join("%.3f" % timed(lambda: e.gather(idx, out=o)) for o in outs), flush=True)
