@@ -15,6 +15,10 @@ struct vmm_buf {
 
 static int g_exportable = 0;
 extern "C" void vmm_set_exportable(int on) { g_exportable = on; }
+// stride k > 1: k x as many chunks are created, every k-th one is mapped, the others are released afterwards — the mapped chunks
+// then cannot be physical neighbours of each other
+static int g_stride = 1;
+extern "C" void vmm_set_stride(int k) { g_stride = k < 1 ? 1 : k; }
 
 extern "C" void* vmm_alloc(size_t bytes, size_t chunk_bytes, int shuffle_seed, void** base_out)
 {
@@ -32,8 +36,16 @@ extern "C" void* vmm_alloc(size_t bytes, size_t chunk_bytes, int shuffle_seed, v
   auto* b            = new vmm_buf{nullptr, n * chunk, chunk, {}};
   if (hipMemAddressReserve(&b->base, b->bytes, 0, nullptr, 0) != hipSuccess) return nullptr;
   b->handles.resize(n);
-  for (size_t i = 0; i < n; i++)
+  std::vector<hipMemGenericAllocationHandle_t> spacers;
+  for (size_t i = 0; i < n; i++) {
     if (hipMemCreate(&b->handles[i], chunk, &prop, 0) != hipSuccess) return nullptr;
+    for (int k = 1; k < g_stride; k++) {
+      hipMemGenericAllocationHandle_t sp;
+      if (hipMemCreate(&sp, chunk, &prop, 0) != hipSuccess) return nullptr;
+      spacers.push_back(sp);
+    }
+  }
+  for (auto sp : spacers) (void)hipMemRelease(sp);
   std::vector<size_t> order(n);
   for (size_t i = 0; i < n; i++) order[i] = i;
   if (shuffle_seed != 0) {
@@ -54,9 +66,10 @@ extern "C" void vmm_free(void* handle)
 {
   auto* b = static_cast<vmm_buf*>(handle);
   if (b == nullptr) return;
-  (void)hipMemUnmap(b->base, b->bytes);
+  for (size_t i = 0; i < b->handles.size(); i++) (void)hipMemUnmap(static_cast<char*>(b->base) + i * b->chunk, b->chunk);   // one per mapping
   for (auto h : b->handles) (void)hipMemRelease(h);
   (void)hipMemAddressFree(b->base, b->bytes);
+  (void)hipDeviceSynchronize();   // teardown is not finished when hipMemAddressFree returns (experiments/vmm_cycle.hip)
   delete b;
 }
 

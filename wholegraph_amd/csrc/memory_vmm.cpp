@@ -201,7 +201,13 @@ void vmm_continuous_destroy(wholememory_comm_t comm, vmm_mapping* m) noexcept
     if (m->handles[r] != nullptr) (void)hipMemRelease(m->handles[r]);
   }
   (void)hipMemAddressFree(m->base, m->total_alloc);
+  // The next reservation is often handed the same virtual range, and without this second synchronise kernels on the NEW
+  // mapping have been seen to lose writes (a torch-free reproducer cycling reserve / create / map / fill / check / unmap /
+  // release / free: 25 of 120 cycles with 1-3 M wrong words, 0 with the synchronise — the teardown is not finished when
+  // hipMemAddressFree returns)
+  (void)hipDeviceSynchronize();
   m->base = nullptr;
 }
 
 }  // namespace wm
+
