@@ -198,4 +198,3 @@ def test_native_env_functions_are_in_use(gpu_env):
     p2 = env.temporary_fns.malloc_fn(C.byref(desc), B.MA_DEVICE, ctx, None)
     assert p2 and torch.cuda.memory_reserved() == reserved
     env.temporary_fns.destroy_memory_context_fn(ctx, None)
-

@@ -240,4 +240,3 @@ def create_wholememory_tensor_from_filelist(comm, memory_type, memory_location, 
 def destroy_wholememory_tensor(wm_tensor):
     wmb.check(wmb.lib().wholememory_destroy_tensor(wm_tensor.wmb_tensor))
     wm_tensor.wmb_tensor = None
-
