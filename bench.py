@@ -15,12 +15,10 @@ visible GPU, like the reference bench forks one process per device, gather_scatt
    or   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
 The timed region is EXACTLY --steps steps between two barriers; `stability` is a separate leg of per-step HIP-event times
 (min / median / p95 over >= 200 steps) run after it, so one noisy neighbour cannot hide in a 36 ms window.
-Table and output buffer (gather; source buffer for scatter / SGD gradient apply): allocated once before the timed region, as in
-the reference bench — chosen among `--table-candidates`
-(default 3) x `--out-candidates` (default 6) allocations, every pair probed with 6 launches, the fastest pair kept (the memory
-system serves different physical placements of the two buffers at different levels: DESIGN.md section 3.1). Every probe is in
-the line (`placement.probe_ms`; entry [0][0] = what single allocations give); `--table-candidates 1 --out-candidates 1` takes
-the first allocations as they come.
+Table and output buffer (gather; source buffer for scatter / SGD gradient apply): plain single allocations, made once before the
+timed region as in the reference bench. (`--table-candidates T --out-candidates O` is round 2's side experiment: T x O candidate
+pairs probed, the fastest kept, every probe in the line as `placement.probe_ms`. Round 3 launches the row kernels in order —
+DESIGN.md section 3.1 — which removed the dependence on the buffers' physical placement, and the default is 1 x 1.)
 """
 import argparse
 import json
@@ -65,11 +63,12 @@ def parse():
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="torch.distributed backend at N > 1: nccl = RCCL over xGMI (the measured configuration); gloo = "
                         "host collectives, which also lets several ranks share one GPU (bring-up of this script only)")
-    p.add_argument("--out-candidates", type=int, default=6,
-                   help="gather at N=1: allocate this many output buffers (and --table-candidates tables), probe every pair with "
-                        "a few launches and keep the fastest (the gather level follows the physical placement of the two "
-                        "buffers, DESIGN.md section 3.1); 1 = take the first allocation as it comes. Every probe is in the line.")
-    p.add_argument("--table-candidates", type=int, default=3, help="see --out-candidates")
+    p.add_argument("--out-candidates", type=int, default=1,
+                   help="side experiment (round 2): allocate this many output buffers (and --table-candidates tables), probe every "
+                        "pair with a few launches and keep the fastest. Default 1 = plain single allocations, what every caller "
+                        "gets: since round 3 the row kernels are launched in order (DESIGN.md section 3.1) and no longer depend on "
+                        "the physical placement of the buffers. Every probe is in the line.")
+    p.add_argument("--table-candidates", type=int, default=1, help="see --out-candidates")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-check", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -423,13 +422,11 @@ def main():
     # the output buffer is allocated once, as in the reference bench (gather_scatter_bench.cu:322-343):
     # a fresh 5 GB hipMalloc inside the timed region would cost ~140 ms and is not part of the op
     out = torch.empty((a.indices, a.dim), dtype=tdt, device="cuda")
-    # Where the allocator puts the two long-lived buffers of this workload — the table and the output — decides the level the
-    # gather runs at (profiles/r02_placement_study.txt: with 3 tables x 5 output buffers alive at once
-    # the pairs gather at 1.70 ... 1.95 ms, each pair at its own stable level; torch's own index_select shows the same levels).
-    # Long-lived buffers are therefore worth choosing: a few candidate tables (unfilled) and output buffers are allocated,
-    # every pair is probed with a handful of launches, the fastest pair is kept and the rest is freed — all before the timed
-    # region, which is unchanged. Nothing is hidden: every probe time goes into the line (`placement.probe_ms[table][output]`;
-    # entry [0][0] is what plain single allocations give).
+    # Round 2 side experiment, off by default (--table-candidates / --out-candidates > 1): with the persistent launch shape of
+    # rounds 1-2 the gather level followed the physical placement of the (table, output) pair (profiles/r02_placement_study.txt),
+    # so a few candidate tables (unfilled) and output buffers could be allocated, every pair probed and the fastest kept — all
+    # before the timed region, every probe in the line (`placement.probe_ms[table][output]`). The in-order launch shape of round 3
+    # made the level independent of the placement (profiles/r03_placement_*), and the contract line runs on plain allocations.
     placement = None
     sgd_apply = a.op == "grad_apply" and a.optimizer == "sgd" and a.dtype == "f32"   # (stateful optimizers: 2-3 x the table per candidate)
     if (a.op in ("gather", "scatter") or sgd_apply) and world == 1 and (a.out_candidates > 1 or a.table_candidates > 1):
@@ -644,7 +641,8 @@ def main():
             "mlookups_per_s": round(lookups / 1e6, 1),
             "algorithmic_GBps": round(lookups * algo_bytes / 1e9, 2),
             "device_allocs_in_timed_region": fresh_allocs,
-            "placement": placement,
+            "placement": placement,   # None: plain single allocations (the default)
+            "launch_shape": "persistent (WM_ROWS_INORDER=0)" if os.environ.get("WM_ROWS_INORDER", "1") == "0" else "in-order",
             "config": {"workload": ("C2 chunked 1-GPU %dx%d %s table, %d %s int64 ids" if world == 1 else
                                     "C3 distributed %dx%d %s table, %d %s int64 ids per rank, RCCL alltoallv")
                                    % (total_rows, a.dim, {"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[a.dtype],
@@ -704,6 +702,10 @@ def main():
                                "bytes_per_ordered_pair_per_step": pair_bytes,
                                "achieved_GBps_per_link_direction":
                                    round(pair_bytes / (wall / a.steps) / 1e9, 2) if pair_bytes else None,
+                               # what the links alone allow: every ordered pair moves its bytes over its own link direction
+                               "predicted_link_bound_ms_per_step": round(pair_bytes / 76.8e9 * 1e3, 4) if pair_bytes else None,
+                               "predicted_link_bound_value_GBps":
+                                   round(a.indices * world * out_bytes / (pair_bytes / 76.8e9) / 1e9, 1) if pair_bytes else None,
                                "note": "rows all-to-all-v over RCCL grouped send/recv, pipelined in row chunks with the "
                                        "owner-side gather and the reorder-on-receive kernels"}
             if a.backend != "nccl":

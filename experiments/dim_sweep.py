@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Side measurement: gather / scatter algorithmic bandwidth across row shapes (1 GPU, chunked table ~ 8 GB).
   python experiments/dim_sweep.py [--csv=file] [--ab] [dims ...]
---ab: every (shape, op) is measured with WM_ROWS_FLAT=0 and =1 as well as the default rule, interleaved over 5 rounds of 10
+--ab: every (shape, op) is measured under several kernel / launch-shape switches (WM_ROWS_INORDER, WM_ROWS_BLOCK, WM_ROWS_FLAT,
+WM_ROWS_STAGED; DIM_SWEEP_SETTINGS=default,inorder=0 keeps a subset) as well as the default rule, interleaved over 5 rounds of 10
 launches, and the MIN over rounds is reported (a shared box drifts by 10-20 % between back-to-back runs of one setting)."""
 import os
 import re
@@ -32,7 +33,13 @@ def main():
             args.append(x)
     if args:
         cases = [(torch.float32, int(x)) for x in args]
-    settings = [("default", None), ("flat=0", "0"), ("flat=1", "1"), ("tile=64", "T64"), ("staged=0", "S0")] if ab else [("default", None)]
+    knobs = ("WM_ROWS_FLAT", "WM_ROWS_TILE", "WM_ROWS_STAGED", "WM_ROWS_INORDER", "WM_ROWS_BLOCK")
+    settings = [("default", {}), ("inorder=0", {"WM_ROWS_INORDER": "0"}), ("block=64", {"WM_ROWS_BLOCK": "64"}),
+                ("flat=0", {"WM_ROWS_FLAT": "0"}), ("flat=1", {"WM_ROWS_FLAT": "1"}),
+                ("staged=0", {"WM_ROWS_STAGED": "0"})] if ab else [("default", {})]
+    if ab and os.environ.get("DIM_SWEEP_SETTINGS"):   # e.g. "default,inorder=0"
+        keep = os.environ["DIM_SWEEP_SETTINGS"].split(",")
+        settings = [x for x in settings if x[0] in keep]
     rounds = 5 if ab else 1
     for dt, dim in cases:
         es = 4 if dt == torch.float32 else 2
@@ -48,15 +55,9 @@ def main():
             kernels = {}
             for r in range(rounds):
                 for name, val in settings:
-                    os.environ.pop("WM_ROWS_FLAT", None)
-                    os.environ.pop("WM_ROWS_TILE", None)
-                    os.environ.pop("WM_ROWS_STAGED", None)
-                    if val is not None and val.startswith("S"):
-                        os.environ["WM_ROWS_STAGED"] = val[1:]
-                    elif val is not None and val.startswith("T"):
-                        os.environ["WM_ROWS_TILE"] = val[1:]
-                    elif val is not None:
-                        os.environ["WM_ROWS_FLAT"] = val
+                    for k in knobs:
+                        os.environ.pop(k, None)
+                    os.environ.update(val)
                     for _ in range(3):
                         fn()
                     torch.cuda.synchronize()
@@ -66,9 +67,8 @@ def main():
                     torch.cuda.synchronize()
                     times[name].append((time.perf_counter() - t0) / 10 * 1e3)
                     kernels[name] = re.search(r"(rows_\w+<[^(]*>)\(", wmb.lib().wholememory_ext_last_rows_kernel().decode()).group(1)
-            os.environ.pop("WM_ROWS_FLAT", None)
-            os.environ.pop("WM_ROWS_TILE", None)
-            os.environ.pop("WM_ROWS_STAGED", None)
+            for k in knobs:
+                os.environ.pop(k, None)
             gb = n * (8 + 2 * dim * es) / 1e9
             for name, _ in settings:
                 ts = sorted(times[name])

@@ -143,6 +143,14 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
   void* output_neighbor_pos_memory_context, void* output_center_localid_memory_context, wholememory_env_func_t* p_env_fns,
   void* stream);
 
+/* Completion semantics of the ops whose reference versions drain the stream before returning (neighbour sampling,
+ * graph_append_unique and the fused hop above). Default 0 = the reference's: outputs complete and scratch idle at return,
+ * safe with any env functions. 1 = the ops return with their last kernels queued on `stream` (one host round trip fewer
+ * per call); only legal when every allocator behind p_env_fns is stream-ordered on that stream and every consumer of the
+ * outputs is ordered on it — wholegraph_amd.torch declares it for torch's caching allocator. Process-wide;
+ * WM_ASYNC_OPS=0/1 in the environment overrides the call. */
+enum wholememory_error_code_t wholememory_ext_set_async_completion(int on);
+
 /* ---- (3) testing seam ---------------------------------------------------------------------- */
 /* Replaces the device backend. Refuses (WHOLEMEMORY_NOT_SUPPORTED) unless the environment has
  * WHOLEGRAPH_AMD_TESTING=1. `backend` is a const wm_device_backend* (wholegraph_amd/csrc/backend.hpp);

@@ -270,10 +270,12 @@ int t_step(const wm_optimizer_args* a, const int64_t* n_unique_dev, void*)
 
 size_t t_long_ws(int64_t) { return 64; }
 int t_run_inverse(const int32_t* run_starts, const int32_t* order, const void* unique_ids, wholememory_dtype_t dt,
-                  const int64_t* n_unique, int64_t n, int64_t* inverse, void*)
+                  const int64_t* n_unique, int64_t n, int64_t id_limit, int64_t* inverse, void*)
 {
-  for (int64_t u = 0; u < *n_unique; u++)
-    for (int32_t j = run_starts[u]; j < run_starts[u + 1]; j++) inverse[order[j]] = idx_at(unique_ids, dt, u) < 0 ? -1 : u;
+  for (int64_t u = 0; u < *n_unique; u++) {
+    const int64_t id = idx_at(unique_ids, dt, u);
+    for (int32_t j = run_starts[u]; j < run_starts[u + 1]; j++) inverse[order[j]] = (id < 0 || (id_limit > 0 && id >= id_limit)) ? -1 : u;
+  }
   (void)n;
   return 0;
 }

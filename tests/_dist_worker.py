@@ -160,10 +160,15 @@ def scenario_gather_skewed(comm, rank, world, idt, entries=None):
     wgth.destroy_wholememory_tensor(wm)
 
 
-def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries, mt="distributed"):
+def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries, mt="distributed", loc="cuda"):
+    """Training steps on a table of any memory type (reference embedding_base::gather_gradient_apply, embedding.cpp:146-323,
+    runs over every type): after each step the owner's shard is compared with the oracle, and EVERY rank reads the whole
+    table back — for CHUNKED / CONTINUOUS through its own mappings of the peers' shards (right behind the optimizer's
+    barrier: the owners must have drained their streams), for DISTRIBUTED through the collective gather."""
     n_rows, dim, steps = 1201, 13, 3
-    emb = wgth.create_embedding(comm, mt, "cuda", torch.float32, [n_rows, dim],
+    emb = wgth.create_embedding(comm, mt, loc, torch.float32, [n_rows, dim],
                                 embedding_entry_partition=entries)
+    hv = loc == "cpu"
     stride = emb.get_embedding_tensor().stride()[0]
     assert stride == 16
     init = np.random.default_rng(5).standard_normal((n_rows, dim)).astype(np.float32)
@@ -171,10 +176,14 @@ def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries, mt="d
     padded[:, :dim] = init
     tab = oracle.ShardedTable.from_full(padded, world, entries)
     tab.dim = dim
-    local, start = emb.get_embedding_tensor().get_local_tensor()
+    local, start = emb.get_embedding_tensor().get_local_tensor(host_view=hv)
     cnt = int(tab.entry_offsets[rank + 1] - tab.entry_offsets[rank])
     assert tuple(local.shape) == (cnt, dim) and local.stride(0) == stride
-    local.copy_(dev(torch.from_numpy(init[start:start + cnt])))
+    local.copy_(torch.from_numpy(init[start:start + cnt]) if hv else dev(torch.from_numpy(init[start:start + cnt])))
+    if HIP_MODE:
+        torch.cuda.synchronize()
+    comm.barrier()
+    all_ids = dev(torch.arange(n_rows, dtype=torch.int64))
     opt = wgth.create_wholememory_optimizer(emb, kind, params)
     assert emb.get_optimizer_state_names() == {"sgd": [], "adam": ["m", "v", "beta12t"], "adagrad": ["state_sum"],
                                                "rmsprop": ["v"]}[kind]
@@ -198,9 +207,33 @@ def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries, mt="d
         oracle.gradient_apply(tab, ref_opts, rank_idx, rank_grads, 0.05)
         if HIP_MODE:
             torch.cuda.synchronize()
-        got = host(local).numpy()
+        got = (local if hv else host(local)).numpy()
+        if os.environ.get("WM_TEST_DIAG") and kind in ("rmsprop", "adagrad"):
+            st, _ = emb.get_optimizer_state("v" if kind == "rmsprop" else "state_sum").get_local_tensor()
+            st_got, st_want = host(st).numpy(), ref_opts[rank].per_element[:cnt, :dim]
+            if st_got.tobytes() != st_want.tobytes():
+                sb = np.nonzero((st_got != st_want).any(axis=1))[0]
+                print("DIAG-STATE rank %d step %d %s %s: %d bad state rows (first %s -> global %s), got %s want %s" % (
+                    rank, step, kind, mt, len(sb), sb[:8], sb[:8] + start, st_got[sb[0]][:3], st_want[sb[0]][:3]), flush=True)
+        if got.tobytes() != tab.shards[rank][:cnt, :dim].tobytes() and os.environ.get("WM_TEST_DIAG"):
+            want = tab.shards[rank][:cnt, :dim]
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            touched = np.unique(np.concatenate([ix[ix >= 0] for ix in rank_idx]).astype(np.int64))
+            print("DIAG rank %d step %d %s %s/%s: %d bad rows of %d (first %s), global ids %s; touched this step: %s; max |diff| %g" % (
+                rank, step, kind, mt, loc, len(bad), cnt, bad[:8], (bad[:8] + start), np.isin(bad + start, touched)[:8],
+                np.abs(got[bad].astype(np.float64) - want[bad]).max()), flush=True)
+            for b in bad[:3]:
+                print("   row %d got %s want %s" % (b + start, got[b][:4], want[b][:4]), flush=True)
         assert got.tobytes() == tab.shards[rank][:cnt, :dim].tobytes(), \
-            "gradient apply (%s) mismatch on rank %d step %d" % (kind, rank, step)
+            "gradient apply (%s, %s/%s) mismatch on rank %d step %d" % (kind, mt, loc, rank, step)
+        # the whole table as THIS rank sees it right after the step (opt.step ended with the communicator's barrier)
+        seen = emb.gather(all_ids)
+        if HIP_MODE:
+            torch.cuda.synchronize()
+        whole = np.concatenate([tab.shards[r][:int(tab.entry_offsets[r + 1] - tab.entry_offsets[r]), :dim] for r in range(world)])
+        assert host(seen).numpy().tobytes() == whole.tobytes(), \
+            "table read back after the step (%s, %s/%s) differs on rank %d step %d" % (kind, mt, loc, rank, step)
+        comm.barrier()   # nobody starts the next step while a peer still reads
     if kind == "adam":
         m, _ = emb.get_optimizer_state("m").get_local_tensor()
         assert host(m).numpy().tobytes() == ref_opts[rank].per_element[:cnt, :dim].tobytes()
@@ -211,12 +244,12 @@ def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries, mt="d
     wgth.destroy_embedding(emb)
 
 
-def scenario_sgd16(comm, rank, world, tdt, dim, lr, wd):
+def scenario_sgd16(comm, rank, world, tdt, dim, lr, wd, mt="distributed"):
     """HALF / BF16 table trained with SGD over several ranks (HIP mode): gradient rows travel in the table dtype, the
     owner sums duplicates in fp32 in rank-major receive order and rounds once. Oracle = the fp32 multi-rank oracle
     wrapped in exact widenings and that one rounding."""
     n_rows, steps = 1501, 2
-    emb = wgth.create_embedding(comm, "distributed", "cuda", tdt, [n_rows, dim])
+    emb = wgth.create_embedding(comm, mt, "cuda", tdt, [n_rows, dim])
     stride = emb.get_embedding_tensor().stride()[0]
     init16 = torch.from_numpy(np.random.default_rng(8).standard_normal((n_rows, dim)).astype(np.float32)).to(tdt)
     padded = np.zeros((n_rows, stride), dtype=np.float32)
@@ -247,7 +280,15 @@ def scenario_sgd16(comm, rank, world, tdt, dim, lr, wd):
         torch.cuda.synchronize()
         want = torch.from_numpy(tab.shards[rank][:cnt, :dim].copy()).to(tdt)
         assert torch.equal(host(local).view(torch.int16), want.view(torch.int16)), \
-            "16-bit SGD mismatch on rank %d step %d" % (rank, step)
+            "16-bit SGD (%s) mismatch on rank %d step %d" % (mt, rank, step)
+        if mt != "distributed":   # every rank reads the whole table through its mappings right behind the step's barrier
+            seen = emb.gather(dev(torch.arange(n_rows, dtype=torch.int64)))
+            torch.cuda.synchronize()
+            whole = torch.from_numpy(np.concatenate(
+                [tab.shards[r][:int(tab.entry_offsets[r + 1] - tab.entry_offsets[r]), :dim] for r in range(world)])).to(tdt)
+            assert torch.equal(host(seen).view(torch.int16), whole.view(torch.int16)), \
+                "16-bit table read back (%s) differs on rank %d step %d" % (mt, rank, step)
+            comm.barrier()
     comm.barrier()
     wgth.destroy_wholememory_optimizer(opt)
     wgth.destroy_embedding(emb)
@@ -530,6 +571,12 @@ def rccl_scenarios(comm, rank, world):
                          ("rmsprop", {"alpha": 0.95})]:
         scenario_gradient_apply(comm, rank, world, kind, params, np.int64 if kind != "adagrad" else np.int32, None)
     scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0)
+    # C4 as BASELINE names it: training on mapped tables (several GPUs: hipIpc / HIP-VMM mappings between the ranks)
+    for mt5 in ("continuous", "chunked"):
+        for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}), ("adagrad", {}),
+                             ("rmsprop", {"alpha": 0.95})]:
+            scenario_gradient_apply(comm, rank, world, kind, params, np.int64, None, mt=mt5)
+        scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0, mt=mt5)
     scenario_sampling(comm, rank, world, "distributed", np.int64)
     scenario_cached_embedding(comm, rank, world, "distributed")
     scenario_file_io(comm, rank, world, "/tmp/wgamd_test_rccl_%s" % os.environ["MASTER_PORT"])
@@ -567,6 +614,25 @@ def main():
         return
     if HIER_MODE:
         hierarchy_scenarios(comm, rank, world)
+        comm.barrier()
+        dist.barrier()
+        print("RANK %d OK" % rank)
+        wgth.finalize()
+        return
+    if os.environ.get("WM_TEST_ONLY") == "mapped_training":   # debugging aid: only the mapped-table training block, repeated
+        gw = np.random.default_rng(7).uniform(60, 100, world)
+        gent = [int(x) for x in (gw / gw.sum() * 1201).astype(int)]
+        gent[-1] += 1201 - sum(gent)
+        for rep in range(int(os.environ.get("WM_TEST_REPS", "3"))):
+            for mt5 in ("continuous", "chunked"):
+                for kind, params in [("rmsprop", {"alpha": 0.95}), ("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}), ("adagrad", {})]:
+                    for ent5, idt5 in ((gent, np.int64), (None, np.int32), (gent, np.int32), (None, np.int64)):
+                        try:
+                            scenario_gradient_apply(comm, rank, world, kind, params, idt5, ent5, mt=mt5)
+                            print("ok   rep %d %s %s %s %s" % (rep, mt5, kind, "custom" if ent5 else "equal", np.dtype(idt5).name), flush=True)
+                        except AssertionError as ex:
+                            print("FAIL rep %d %s %s %s %s: %s" % (rep, mt5, kind, "custom" if ent5 else "equal", np.dtype(idt5).name, ex), flush=True)
+                            os._exit(3)
         comm.barrier()
         dist.barrier()
         print("RANK %d OK" % rank)
@@ -640,6 +706,25 @@ def main():
     for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}),
                          ("adam", {"adam_w": 1.0, "weight_decay": 0.02}), ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]:
         scenario_gradient_apply(comm, rank, world, kind, params, np.int64 if kind != "adagrad" else np.int32, None)
+    # (5') BASELINE config C4 as named — training on MAPPED tables shared by several ranks (reference embedding.cpp:146-323 over
+    #      memory_handle.cpp:633-1054): every optimizer, equal and custom partitions, skip-me ids (step 1 of the scenario).
+    #      HOST-located mapped tables (one shm segment) run on the CPU backend too; device CHUNKED (hipIpc) and CONTINUOUS
+    #      (HIP VMM) need the HIP backend.
+    gw = np.random.default_rng(7).uniform(60, 100, world)
+    gent = [int(x) for x in (gw / gw.sum() * 1201).astype(int)]
+    gent[-1] += 1201 - sum(gent)
+    mapped = [("chunked", "cpu"), ("continuous", "cpu")]
+    if HIP_MODE:
+        mapped = [("chunked", "cuda"), ("continuous", "cuda")] + mapped
+    for k, (mt5, loc5) in enumerate(mapped):
+        for j, (kind, params) in enumerate([("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}),
+                                            ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]):
+            scenario_gradient_apply(comm, rank, world, kind, params, np.int32 if (j + k) % 2 else np.int64,
+                                    gent if (j + k) % 2 == 0 else None, mt=mt5, loc=loc5)
+    if HIP_MODE:
+        scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0, mt="continuous")
+        scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0, mt="chunked")
+        scenario_sgd16(comm, rank, world, torch.bfloat16, 40, 0.05, 0.01, mt="continuous")
     if HIP_MODE:
         # (7) device row caches: HOST tables served and trained through per-rank caches
         scenario_cached_embedding(comm, rank, world, "distributed")

@@ -55,6 +55,27 @@ def test_self_launch_without_a_launcher(wm_lib):
     assert r["n_gpus"] == 2 and r["transport"] == "external" and r["rccl_ranks"] == 0 and r["stability"]["steps"] == 5
 
 
+def test_eight_ranks_exchange_object(wm_lib):
+    """The N = 8 plumbing of bench.py before the first SCALE run: 8 ranks (sharing the one GPU, host collectives), toy
+    sizes, the line's `exchange` object with the bytes every ordered pair moves per step and the link-bound prediction."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--rows", "250007",
+                        "--indices", "80000", "--steps", "2", "--warmup", "1", "--stability-steps", "0"],
+                       capture_output=True, timeout=900, env=dict(env, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    r = _one_json_line(p.stdout)
+    assert all(k in r for k in CONTRACT) and r["n_gpus"] == 8 and r["scaling"] == "weak"
+    assert "C3 distributed 2000056x128" in r["config"]["workload"] and r["config"]["rows_per_gpu"] == 250007
+    ex = r["exchange"]
+    assert ex["bound"] == "xgmi" and ex["link_peak_GBps_per_direction"] == 76.8
+    assert ex["bytes_per_ordered_pair_per_step"] == 80000 / 8 * (512 + 8)        # rows + ids of one peer's share
+    assert abs(ex["predicted_link_bound_ms_per_step"] - 80000 / 8 * 520 / 76.8e9 * 1e3) < 1e-3
+    assert ex["predicted_link_bound_value_GBps"] > 0 and "BRING-UP" in ex["note"]
+    assert r["roofline"]["bound"] == "hbm" and "owner-side row gather" in r["roofline"]["scope"]
+    assert r["c3_zipf"]["dedup_auto_ms_per_step"] > 0 and r["c3_zipf"]["dedup_off_ms_per_step"] > 0
+    assert "side_errors" not in r, r.get("side_errors")
+
+
 def test_more_gpus_than_visible_fails_loudly(wm_lib):
     import torch
     n = torch.cuda.device_count() + 1

@@ -169,14 +169,23 @@ int run_rank(const options& o, int rank, shared_page* sh)
         return o.scatter ? wholememory_scatter(cand_t, idx_t, table, env, nullptr, -1)
                          : wholememory_gather(table, idx_t, cand_t, env, nullptr, -1);
       };
-      for (int i = 0; i < 2; i++) WM_OK(probe());
-      HIP_OK(hipEventRecord(e0, nullptr));
-      for (int i = 0; i < 6; i++) WM_OK(probe());
-      HIP_OK(hipEventRecord(e1, nullptr));
-      HIP_OK(hipEventSynchronize(e1));
       float pms = 0;
-      HIP_OK(hipEventElapsedTime(&pms, e0, e1));
-      pms /= 6;
+      // WM_BENCH_AB=<variable>: every candidate is also probed with <variable>=0 (e.g. WM_ROWS_INORDER: the persistent launch
+      // shape of rounds 1-2 beside the in-order one, on the very same buffers of one process)
+      const char* ab_var = getenv("WM_BENCH_AB");
+      for (int pass = ab_var != nullptr ? 0 : 1; pass < 2; pass++) {
+        if (ab_var != nullptr) {
+          if (pass == 0) setenv(ab_var, "0", 1); else unsetenv(ab_var);
+        }
+        for (int i = 0; i < 2; i++) WM_OK(probe());
+        HIP_OK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < 6; i++) WM_OK(probe());
+        HIP_OK(hipEventRecord(e1, nullptr));
+        HIP_OK(hipEventSynchronize(e1));
+        HIP_OK(hipEventElapsedTime(&pms, e0, e1));
+        pms /= 6;
+        if (rank == 0 && pass == 0) printf("  candidate row buffer %d with %s=0: %.4f ms per call\n", k, ab_var, pms);
+      }
       if (rank == 0) printf("  candidate row buffer %d: %.4f ms per call\n", k, pms);
       if (k == 0 || pms < best_ms) best_ms = pms, best_buf = buf;
       WM_OK(wholememory_destroy_tensor(cand_t));

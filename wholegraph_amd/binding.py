@@ -256,6 +256,7 @@ PROTOTYPES = {
     "wholememory_ext_last_rows_kernel": (C.c_char_p, []),
     "wholememory_ext_sample_append_unique": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_ulonglong, C.c_void_p,
                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wholememory_ext_set_async_completion": (_i, [_i]),
     "wm_testing_install_backend": (_i, [_vp]),
 }
 

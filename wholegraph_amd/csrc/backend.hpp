@@ -52,6 +52,10 @@ struct wm_bucket_args {
   // owners (owner_count+1 entries) and an id of owner o goes to bucket o % world_size — first hop of the HIERARCHY
   // gather, where the buckets are the ranks of this node and the owners the ranks of every node
   int owner_count;
+  // 1: `workspace` still holds the scanned block offsets an earlier counts-only call (bucketed_ids == nullptr) over the very
+  // same ids / offsets left there, and `counts` is not needed again: only the grouping pass runs. A backend may ignore it
+  // and recompute everything (the results are the same).
+  int reuse_scan;
 };
 
 struct wm_optimizer_args {
@@ -185,9 +189,9 @@ struct wm_device_backend {
   int (*optimizer_step)(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);
   size_t (*long_run_workspace_bytes)(int64_t n_recv);
   // inverse of a dedup: inverse[order[j]] = index of the run that sorted position j belongs to, or -1 when that run's
-  // id is negative (n_unique_dev: device scalar written by dedup_ids)
+  // id is negative or, with id_limit > 0, not below id_limit (n_unique_dev: device scalar written by dedup_ids)
   int (*run_inverse)(const int32_t* run_starts, const int32_t* order, const void* unique_ids, wholememory_dtype_t index_dtype,
-                     const int64_t* n_unique_dev, int64_t n, int64_t* inverse, void* stream);
+                     const int64_t* n_unique_dev, int64_t n, int64_t id_limit, int64_t* inverse, void* stream);
   // order[i] in [self_begin, self_begin + self_count)  ->  -(self_rows[order[i] - self_begin] + 1)   (see self_grads)
   int (*remap_self_order)(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count, const int64_t* self_rows,
                           void* stream);

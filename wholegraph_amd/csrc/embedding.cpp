@@ -135,8 +135,12 @@ wholememory_error_code_t create_states(wholememory_embedding_* e)
     }
     // zero the local shard of the packed states (reference zero_local_state_tensor)
     auto* ld = wholememory_tensor_get_tensor_description(e->state_local);
-    WM_BK(bk->memset_async(wholememory_tensor_get_data_pointer(e->state_local), 0,
-                           static_cast<size_t>(ld->sizes[0]) * ld->strides[0] * sizeof(float), nullptr));
+    if (getenv("WM_STATE_ZERO_MEMSET") != nullptr)
+      WM_BK(bk->memset_async(wholememory_tensor_get_data_pointer(e->state_local), 0,
+                             static_cast<size_t>(ld->sizes[0]) * ld->strides[0] * sizeof(float), nullptr));
+    else
+      WM_BK(bk->fill_float(static_cast<float*>(wholememory_tensor_get_data_pointer(e->state_local)), 0.0f,
+                           ld->sizes[0] * ld->strides[0], nullptr));
     WM_BK(bk->stream_sync(nullptr));
     // a read-write device cache also holds the states of its resident rows (reference: cachable optimizer states)
     if (e->cache != nullptr && e->cache->writable) WHOLEMEMORY_RETURN_ON_FAIL(wm::row_cache_attach_states(e->cache, e->state_local));
@@ -475,7 +479,14 @@ wholememory_error_code_t remap_round_robin(wholememory_embedding_* e, wholememor
   // entry (it computes the owner and drops it), so with more than one rank an id whose block lives on another rank hits
   // the wrong row. Here the row is the one wholememory_load_from_file(round_robin_size) put the entry in: every rank
   // holds the same number of rows (create_embedding pads to that), owner = (id / rr) % world. One rank: identical.
-  const int64_t rank_rows = wholememory_tensor_get_tensor_description(e->allocated)->sizes[0] / e->comm->world_size;
+  // WM_RR_REFERENCE=1 restores the reference's caller-relative statement (rank_rows = 0 below) for call sites that were
+  // written against it: ids are then only right for entries the CALLER owns ("round-robin remap").
+  static const bool reference_statement = [] {
+    const char* v = getenv("WM_RR_REFERENCE");
+    return v != nullptr && v[0] == '1';
+  }();
+  const int64_t rank_rows =
+    reference_statement ? 0 : wholememory_tensor_get_tensor_description(e->allocated)->sizes[0] / e->comm->world_size;
   int rc = backend()->round_robin_map(wholememory_tensor_get_data_pointer(indices), mp, idesc->dtype, idesc->sizes[0],
                                       static_cast<int64_t>(entry_start), e->comm->world_size, e->round_robin_size,
                                       rank_rows, stream);

@@ -230,11 +230,12 @@ wholememory_error_code_t sample_without_replacement(
   } else if (total > 0) {
     WM_BK(weighted ? bk->sample_weighted(&a, stream) : bk->sample_unweighted(&a, stream));
   }
-  // The reference returns with the samples complete (:385,:404). Here the outputs come from the env allocator, which is
-  // ordered on `stream` (include/wholememory/env_func_ptrs.h), and so is every consumer: the call returns with the kernels
-  // queued — one host round trip per call (the count) instead of two. The DISTRIBUTED route keeps the drain: its gathers are
+  // The reference returns with the samples complete (:385,:404), and so does this by default. A host framework whose env
+  // allocator is ordered on `stream`, like every consumer of the outputs, may declare that
+  // (wholememory_ext_set_async_completion): the call then returns with the kernels queued — one host round trip per call
+  // (the count) instead of two. The DISTRIBUTED route keeps the drain: its gathers are
   // collectives and peers read this rank's buffers.
-  if (via_gather || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+  if (via_gather || !async_completion_enabled() || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
   return WHOLEMEMORY_SUCCESS;
 }
 
@@ -386,7 +387,7 @@ wholememory_error_code_t graph_append_unique(wholememory_tensor_t target_nodes_t
   void* out = output_alloc(p_env_fns, output_unique_node_memory_context, static_cast<int64_t>(nt) + new_count, target_desc.dtype);
   if (out == nullptr) return WHOLEMEMORY_OUT_OF_MEMORY;
   WM_BK(bk->append_unique_phase2(targets, nt, nn, nn, target_desc.dtype, ws, out, mapping, stream));
-  if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));  // stream-ordered outputs and scratch, as above
+  if (!async_completion_enabled() || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));  // (reference append_unique_func.cuh:351)
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
 }
@@ -495,7 +496,7 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
   if (uniq == nullptr || (total > 0 && (pos == nullptr || olid == nullptr))) return WHOLEMEMORY_OUT_OF_MEMORY;
   WM_BK(bk->append_unique_phase2(a.centers, nt, nn_room, total, center_desc.dtype, ws, uniq, pos, stream));
   if (total > 0) WM_BK(bk->memcpy_async(olid, lid, sizeof(int) * static_cast<size_t>(total), stream));
-  if (debug_sync_enabled()) WM_BK(bk->stream_sync(stream));   // outputs and scratch are ordered on `stream`
+  if (!async_completion_enabled() || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));   // else: outputs and scratch are ordered on `stream`
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
 }

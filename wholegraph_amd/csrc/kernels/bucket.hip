@@ -227,10 +227,12 @@ int run_bucket(const wm_bucket_args* a, hipStream_t stream)
   int64_t* block_counts = static_cast<int64_t*>(a->workspace);
   const IdxT* ids       = static_cast<const IdxT*>(a->indices);
   const int owners      = a->owner_count > 0 ? a->owner_count : a->world_size;
-  hipLaunchKernelGGL((bucket_hist_kernel<IdxT>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n, a->entry_offsets,
-                     a->world_size, owners, g.chunk, block_counts);
-  hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, block_counts, g.blocks, a->world_size,
-                     a->counts);
+  if (!(a->reuse_scan && a->bucketed_ids != nullptr)) {  // (reuse: the counts-only call over the same ids left the scan behind)
+    hipLaunchKernelGGL((bucket_hist_kernel<IdxT>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n, a->entry_offsets,
+                       a->world_size, owners, g.chunk, block_counts);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, block_counts, g.blocks, a->world_size,
+                       a->counts);
+  }
   if (a->bucketed_ids != nullptr && a->raw_indices != nullptr) {
     hipLaunchKernelGGL((bucket_scatter_kernel<IdxT>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n,
                        a->entry_offsets, a->world_size, owners, g.chunk, block_counts,

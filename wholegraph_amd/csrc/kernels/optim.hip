@@ -1480,7 +1480,7 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
 
 template <typename IdxT>
 __global__ void run_inverse_kernel(const int32_t* run_starts, const int32_t* order, const IdxT* unique_ids,
-                                   const int64_t* n_unique, int64_t n, int64_t* inverse)
+                                   const int64_t* n_unique, int64_t n, int64_t id_limit, int64_t* inverse)
 {
   // the run of sorted position j: last u with run_starts[u] <= j. The 256 positions of a workgroup are consecutive, so
   // their runs lie between the run of the first and the run of the last one: two full-range searches per workgroup, then
@@ -1500,20 +1500,21 @@ __global__ void run_inverse_kernel(const int32_t* run_starts, const int32_t* ord
   __syncthreads();
   if (j >= n) return;
   const int64_t u   = search(j, s_lo, s_hi);
-  inverse[order[j]] = unique_ids[u] < 0 ? -1 : u;
+  const int64_t id  = static_cast<int64_t>(unique_ids[u]);
+  inverse[order[j]] = (id < 0 || (id_limit > 0 && id >= id_limit)) ? -1 : u;
 }
 
 int hip_run_inverse(const int32_t* run_starts, const int32_t* order, const void* unique_ids, wholememory_dtype_t index_dtype,
-                    const int64_t* n_unique_dev, int64_t n, int64_t* inverse, void* stream)
+                    const int64_t* n_unique_dev, int64_t n, int64_t id_limit, int64_t* inverse, void* stream)
 {
   if (n == 0) return 0;
   const int blocks = static_cast<int>((n + kBlock - 1) / kBlock);
   if (index_dtype == WHOLEMEMORY_DT_INT)
     hipLaunchKernelGGL((run_inverse_kernel<int32_t>), dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       run_starts, order, static_cast<const int32_t*>(unique_ids), n_unique_dev, n, inverse);
+                       run_starts, order, static_cast<const int32_t*>(unique_ids), n_unique_dev, n, id_limit, inverse);
   else if (index_dtype == WHOLEMEMORY_DT_INT64)
     hipLaunchKernelGGL((run_inverse_kernel<int64_t>), dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       run_starts, order, static_cast<const int64_t*>(unique_ids), n_unique_dev, n, inverse);
+                       run_starts, order, static_cast<const int64_t*>(unique_ids), n_unique_dev, n, id_limit, inverse);
   else
     return -1;
   return hipGetLastError() == hipSuccess ? 0 : -2;

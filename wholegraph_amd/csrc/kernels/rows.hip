@@ -36,7 +36,7 @@
 namespace wm {
 namespace {
 
-constexpr int kBlock  = 256;
+constexpr int kBlock  = 256;   // threads per workgroup of the persistent (capped-grid) launches; upper bound for all
 constexpr int kWave   = 64;
 
 template <int BYTES>
@@ -94,6 +94,8 @@ struct rows_params {
   int tile_rows;
   // LDS-staged gather (rows_staged_gather_kernel): rows per chunk (a power of two, chunk bytes a multiple of 16), 0 = not used
   int stage_rows;
+  // host side only: threads per workgroup of this launch (a multiple of 64, <= kBlock; the kernels read blockDim)
+  int launch_threads;
 };
 
 // byte address of the first moved element of table row `idx`
@@ -153,8 +155,8 @@ __global__ __launch_bounds__(kBlock) void rows_copy_kernel(rows_params p)
   using vec_t         = typename vec_of<VB>::type;
   constexpr int kU    = 4;
   const int lane      = threadIdx.x & (kWave - 1);
-  const int64_t wave  = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
-  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  const int64_t wave  = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
   const int lpr       = 1 << p.lpr_log2;
   const int rps       = kWave >> p.lpr_log2;  // rows per step
   const int sub       = lane >> p.lpr_log2;   // which row of the step this lane serves
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(kBlock) void rows_copy16_fast_kernel(rows_params p)
   constexpr int kU      = WM_FAST_KU;
   constexpr int kLpr    = kWave / RPS;
   const int lane        = threadIdx.x & (kWave - 1);
-  const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
-  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
   const int col         = lane & (kLpr - 1);
   const bool upper      = RPS == 2 && lane >= kLpr;
   const int tile_rows   = p.tile_rows;
@@ -313,8 +315,8 @@ __global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
 {
   constexpr int kU      = 4;
   const int lane        = threadIdx.x & (kWave - 1);
-  const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
-  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
   const int tile_rows   = p.tile_rows;
   const int64_t tiles   = (p.n + tile_rows - 1) / tile_rows;
   const int S           = p.flat_slots;
@@ -394,9 +396,10 @@ __global__ __launch_bounds__(kBlock) void rows_staged_gather_kernel(rows_params 
   extern __shared__ __attribute__((aligned(16))) char staged_lds[];
   const int lane        = threadIdx.x & (kWave - 1);
   const int wave_in_blk = threadIdx.x >> 6;
-  const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
-  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
-  const int64_t tiles   = (p.n + kWave - 1) / kWave;
+  const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  const int tile_rows   = p.tile_rows;                        // 64 (persistent launches) or one chunk of R rows (in-order launches)
+  const int64_t tiles   = (p.n + tile_rows - 1) / tile_rows;
   const int R           = p.stage_rows;
   const int S           = p.flat_slots;                       // 16-byte slots per row, the last one holds flat_tail bytes
   const int row_bytes   = (S - 1) * 16 + p.flat_tail;
@@ -408,12 +411,12 @@ __global__ __launch_bounds__(kBlock) void rows_staged_gather_kernel(rows_params 
 
   for (int64_t tile = wave; tile < tiles; tile += n_waves) {
     char *my_tab, *my_plain;
-    load_tile_entry<IdxT>(p, tile * kWave + lane, my_tab, my_plain);
+    load_tile_entry<IdxT>(p, lane < tile_rows ? tile * tile_rows + lane : p.n, my_tab, my_plain);
     const uint64_t present = __ballot(my_tab != nullptr);
-    for (int r0 = 0; r0 < kWave; r0 += R) {
+    for (int r0 = 0; r0 < tile_rows; r0 += R) {
       const uint64_t chunk_mask = (R == 64 ? ~0ull : ((1ull << R) - 1)) << r0;
       if ((present & chunk_mask) == 0) continue;              // nothing to move (tail of the last tile, all skipped)
-      char* const out = p.plain + (tile * kWave + r0) * static_cast<int64_t>(row_bytes);
+      char* const out = p.plain + (tile * tile_rows + r0) * static_cast<int64_t>(row_bytes);
       if ((present & chunk_mask) == chunk_mask) {
         // ---- table -> LDS: slot v of the chunk = row v / S, piece v % S; every load of the chunk is issued before the
         // first LDS write (up to kStageIters x 1 KiB per wave in flight)
@@ -510,8 +513,8 @@ __global__ __launch_bounds__(kBlock) void rows_convert_kernel(rows_params p)
   using FromT         = typename std::conditional<GATHER, TabT, PlainT>::type;
   using ToT           = typename std::conditional<GATHER, PlainT, TabT>::type;
   const int lane      = threadIdx.x & (kWave - 1);
-  const int wave      = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-  const int n_waves   = (gridDim.x * kBlock) >> 6;
+  const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
   const int lpr       = 1 << p.lpr_log2;
   const int rps       = kWave >> p.lpr_log2;
   const int sub       = lane >> p.lpr_log2;
@@ -559,7 +562,7 @@ template <typename K>
 inline void launch_rows_kernel(K kernel, int blocks, hipStream_t stream, const rows_params& p)
 {
   t_last_rows_kernel = reinterpret_cast<const void*>(kernel);
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, stream, p);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(p.launch_threads), 0, stream, p);
 }
 
 inline int ilog2_ceil(int x)
@@ -588,6 +591,21 @@ int default_max_blocks()
       cus = 256;
   }
   return cus * 32;  // measured: 8192 workgroups (32 per CU) beat 2048 by ~2% on the 10 M-id gather
+}
+
+// WM_ROWS_INORDER=0: the persistent grid-stride launches of rounds 1-2 (A/B)
+bool inorder_enabled()
+{
+  const char* e = getenv("WM_ROWS_INORDER");
+  return e == nullptr || e[0] != '0';
+}
+// threads per workgroup of the in-order launches (WM_ROWS_BLOCK=64 / 128 / 256; measured: 64 and 256 within 1 %, 512 and
+// 1024 5-12 % slower — the finer the unit the dispatcher hands out, the tighter the window)
+int inorder_block_threads()
+{
+  const char* e = getenv("WM_ROWS_BLOCK");
+  const int v   = e != nullptr ? atoi(e) : 0;
+  return (v == 64 || v == 128 || v == 256) ? v : 256;
 }
 
 // 0 = never, 1 = always when legal, -1 (default) = by the measured rule in want_flat()
@@ -637,9 +655,9 @@ void launch_copy(const rows_params& p, int vb, int blocks, hipStream_t stream)
   if constexpr (GATHER) {
     if (p.stage_rows > 0) {
       const int row_bytes   = (p.flat_slots - 1) * 16 + p.flat_tail;
-      const size_t lds      = static_cast<size_t>(kBlock / kWave) * ((static_cast<size_t>(p.stage_rows) * row_bytes + 15) & ~size_t(15));
+      const size_t lds      = static_cast<size_t>(p.launch_threads / kWave) * ((static_cast<size_t>(p.stage_rows) * row_bytes + 15) & ~size_t(15));
       t_last_rows_kernel    = reinterpret_cast<const void*>(rows_staged_gather_kernel<IdxT>);
-      hipLaunchKernelGGL(rows_staged_gather_kernel<IdxT>, dim3(blocks), dim3(kBlock), lds, stream, p);
+      hipLaunchKernelGGL(rows_staged_gather_kernel<IdxT>, dim3(blocks), dim3(p.launch_threads), lds, stream, p);
       return;
     }
   }
@@ -766,10 +784,23 @@ int rows_op(const wm_rows_args* a, void* stream_v)
   p.plain              = static_cast<char*>(a->plain) + a->plain_storage_offset * pes;
   p.plain_stride_bytes = a->plain_stride * pes;
 
-  p.tile_rows = kWave;
+  // Launch shape (round 3). IN ORDER (the default): one tile per wave and as many workgroups as that takes — the hardware
+  // dispatcher hands workgroups out in order, so the tiles in flight are one compact window that advances through the
+  // streamed side (the gather's output, the scatter's input), and a tile is ~4 KiB moved as ONE batch (all loads, then all
+  // stores). PERSISTENT (when the caller caps the grid: gather_sms / scatter_sms, or WM_ROWS_INORDER=0): round 1-2's
+  // grid-stride loop over tiles of up to 64 rows. Measured on the 10 M x 512 B gather (experiments/placement_pmc.hip,
+  // profiles/r03_placement_*): the persistent shape runs at 1.70 ... 1.95 ms depending on the PHYSICAL PLACEMENT of the
+  // output buffer (its 8192 resident waves each own a 32 KiB tile and the 8192 workgroups sweep the output four times, so
+  // the 64-byte write requests of one DRAM page arrive spread over microseconds; a physically contiguous buffer: always
+  // slow), the in-order shape at 1.64-1.73 ms on every buffer of every process, the contiguous one included.
+  const bool inorder = a->max_blocks <= 0 && inorder_enabled();
+  p.launch_threads   = inorder ? inorder_block_threads() : kBlock;
+  p.tile_rows        = kWave;
   auto grid_for = [&](int tile_rows) {
     const int64_t tiles = (a->n + tile_rows - 1) / tile_rows;
-    int b               = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, default_max_blocks()));
+    const int wpb       = p.launch_threads / kWave;
+    if (inorder) return static_cast<int>(std::min<int64_t>((tiles + wpb - 1) / wpb, INT64_C(0x7fffffff)));
+    int b = static_cast<int>(std::min<int64_t>((tiles + wpb - 1) / wpb, default_max_blocks()));
     if (a->max_blocks > 0) b = std::min(b, a->max_blocks);
     return std::max(b, 1);
   };
@@ -807,15 +838,26 @@ int rows_op(const wm_rows_args* a, void* stream_v)
       while (R > need && static_cast<int64_t>(R) * row_bytes > 5120) R >>= 1;
       if (static_cast<int64_t>(R) * row_bytes <= 5120) {   // kStageIters x 1 KiB per wave; bigger rows stay on the flat kernel
         p.stage_rows = R;
-        p.tile_rows  = kWave;
-        blocks       = grid_for(kWave);
+        p.tile_rows  = inorder ? R : kWave;   // in order: one chunk (<= 5 KiB) per wave
+        blocks       = grid_for(p.tile_rows);
       }
     }
     if (p.stage_rows == 0 && (p.flat_slots > 0 || (vb == 16 && p.row_vecs >= 32))) {  // the two kernels that take tile_rows
       const char* te    = getenv("WM_ROWS_TILE");  // experiment switch
       const int forced  = te != nullptr ? atoi(te) : 0;
       p.tile_rows = row_bytes <= 768 ? 64 : row_bytes <= 1536 ? 32 : row_bytes <= 3072 ? 16 : 8;
-      if (forced == 8 || forced == 16 || forced == 32 || forced == 64) p.tile_rows = forced;
+      if (inorder) {
+        if (p.flat_slots > 0) {   // flat stream: a batch is 4 x 64 slots of 16 bytes; the rows that fill one batch, or two when
+          const int S     = p.flat_slots;   // one would stay under 80 % full (2408 B rows = 151 slots: 1 row 59 %, 3 rows 88 % of two)
+          const int r1    = std::max(1, 256 / S), r2 = std::max(1, 512 / S);
+          const double f1 = r1 * S / 256.0, f2 = r2 * S / 512.0;
+          p.tile_rows     = std::min(kWave, (S > 256 || f1 >= 0.8 || f2 <= f1) ? r1 : r2);
+        } else {                  // readlane kernel: (tile_rows / RPS) x chunks steps, a multiple of its 4-step batch
+          const int chunks = p.row_vecs > 32 ? (p.row_vecs + kWave - 1) / kWave : 1;
+          p.tile_rows      = p.row_vecs == 32 ? 8 : chunks == 1 ? 4 : chunks == 2 ? 2 : chunks % 4 == 0 ? 1 : 4;
+        }
+      }
+      if ((forced == 8 || forced == 16 || forced == 32 || forced == 64) && (p.flat_slots > 0 || forced % 8 == 0)) p.tile_rows = forced;
       blocks = grid_for(p.tile_rows);
     }
     if (a->index_dtype == WHOLEMEMORY_DT_INT)

@@ -10,6 +10,7 @@
 #include <sys/un.h>
 #include <unistd.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -200,11 +201,19 @@ void vmm_continuous_destroy(wholememory_comm_t comm, vmm_mapping* m) noexcept
     (void)hipMemUnmap(static_cast<char*>(m->base) + m->alloc_offsets[r], m->alloc_sizes[r]);
     if (m->handles[r] != nullptr) (void)hipMemRelease(m->handles[r]);
   }
-  (void)hipMemAddressFree(m->base, m->total_alloc);
-  // The next reservation is often handed the same virtual range, and without this second synchronise kernels on the NEW
-  // mapping have been seen to lose writes (a torch-free reproducer cycling reserve / create / map / fill / check / unmap /
-  // release / free: 25 of 120 cycles with 1-3 M wrong words, 0 with the synchronise — the teardown is not finished when
-  // hipMemAddressFree returns)
+  // The virtual range is NOT handed back (WM_VMM_FREE_VA=1 restores hipMemAddressFree). On this ROCm a range that is
+  // freed is usually handed out again by the next reservation, and translations of the OLD mapping survive in the GPU's
+  // TLBs: kernels on the new mapping then read and write 4 KiB pages of the released physical memory. Round 2 saw it as
+  // lost writes in one process (experiments/vmm_cycle.hip) and papered over it with a second synchronise; round 3's
+  // multi-process training tests on CONTINUOUS tables (tests/_dist_worker.py: scenario_gradient_apply) still hit it — the
+  // wrong rows always filled whole 4 KiB pages (rows 576-639 of a 64-byte-row table ...), the values were the previous
+  // table's. A range that is never reserved again cannot be hit by a stale translation: what leaks is address space only
+  // (the physical pages are released above), 2^47 bytes of it are there, a table takes its padded size.
+  static const bool free_va = [] {
+    const char* e = getenv("WM_VMM_FREE_VA");
+    return e != nullptr && e[0] == '1';
+  }();
+  if (free_va) (void)hipMemAddressFree(m->base, m->total_alloc);
   (void)hipDeviceSynchronize();
   m->base = nullptr;
 }

@@ -73,7 +73,11 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   const int owners = static_cast<int>(entry_offsets.size()) - 1;
   WM_CHECK(owners >= W, "bucket_and_exchange_ids: fewer row ranges than ranks");
   temp_mem dev_offsets(env), dev_counts(env), workspace(env), workspace2(env), host_counts(env), est_ws(env);
-  auto* d_off = static_cast<uint64_t*>(dev_offsets.device(owners + 1, WHOLEMEMORY_DT_INT64));
+  // defer_ids: the device copy of the offsets and the bucketing workspace (which keeps the scanned block counts of the
+  // counts-only pass) outlive this call inside `x`, so that finish_id_exchange() neither uploads the offsets a second time
+  // (its pinned staging buffer used to be released with the copy still queued) nor repeats the histogram pass
+  const bool keep_for_finish = defer_ids && sorted == nullptr;
+  auto* d_off = static_cast<uint64_t*>((keep_for_finish ? x->aux_offsets : dev_offsets).device(owners + 1, WHOLEMEMORY_DT_INT64));
   auto* d_cnt = static_cast<int64_t*>(dev_counts.device(W + 1, WHOLEMEMORY_DT_INT64));  // [W] = the duplicate estimate
   auto* h_cnt = static_cast<int64_t*>(host_counts.pinned(W + 1 + owners + 1, WHOLEMEMORY_DT_INT64));
   // stage the offsets through pinned memory so the H2D copy is truly asynchronous
@@ -108,7 +112,15 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   // the duplicate estimate of this rank's ids travels with the counts (slot W), so that every rank takes the same
   // de-duplication decision from the same W numbers
   // (a rank whose batch cannot be de-duplicated — 2^31 ids or more — publishes -1, which vetoes the decision for everybody)
-  const bool estimate = estimate_duplicates && bk->dup_estimate != nullptr && n > 0 && n < (INT64_C(1) << 31);
+  // Small batches are latency-bound and a de-duplicated exchange could not pay for its sort: they skip the estimate (a
+  // 16 MiB flag array to clear and count) and publish 0 — a vote for "as they are", not a veto; the other ranks' estimates
+  // still decide. WM_GATHER_DEDUP_MIN_IDS moves the limit.
+  static const int64_t estimate_min_ids = [] {
+    const char* e = getenv("WM_GATHER_DEDUP_MIN_IDS");
+    return e != nullptr && atoll(e) >= 0 ? static_cast<int64_t>(atoll(e)) : (INT64_C(1) << 18);
+  }();
+  const bool estimate = estimate_duplicates && bk->dup_estimate != nullptr && n >= std::max<int64_t>(estimate_min_ids, 2) &&
+                        n < (INT64_C(1) << 31);
   if (estimate) {
     void* ws = est_ws.device(static_cast<int64_t>(bk->dup_estimate_workspace_bytes(n)), WHOLEMEMORY_DT_INT8);
     WM_BK(bk->dup_estimate(indices, index_dtype, n, ws, d_cnt + W, stream));
@@ -138,7 +150,7 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
     ba.counts        = d_cnt;
     ba.bucketed_ids  = x->bucketed_ids;
     ba.raw_indices   = x->raw_indices;
-    ba.workspace     = workspace2.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, W)), WHOLEMEMORY_DT_INT8);
+    ba.workspace     = (keep_for_finish ? x->aux_ws : workspace2).device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, W)), WHOLEMEMORY_DT_INT8);
     WM_BK(bk->bucket_ids(&ba, stream));
   }
   // counts: with RCCL the W x W matrix is all-gathered on the caller's stream straight from the device counters and the
@@ -198,10 +210,10 @@ void finish_id_exchange(wholememory_comm_t comm, const void* indices, wholememor
   const size_t ies = wholememory_dtype_get_element_size(index_dtype);
   const int owners = static_cast<int>(entry_offsets.size()) - 1;
   (void)env;
-  auto* d_off = static_cast<uint64_t*>(x->aux_offsets.device(owners + 1, WHOLEMEMORY_DT_INT64));
-  auto* h_off = static_cast<uint64_t*>(x->aux_offsets_host.pinned(owners + 1, WHOLEMEMORY_DT_INT64));
-  for (int i = 0; i <= owners; i++) h_off[i] = entry_offsets[i];
-  WM_BK(bk->memcpy_async(d_off, h_off, sizeof(uint64_t) * (owners + 1), stream));
+  (void)owners;
+  // the offsets on the device and the scanned block counts of the counts-only pass are still in `x`
+  auto* d_off = static_cast<uint64_t*>(x->aux_offsets.get());
+  WM_CHECK(d_off != nullptr && x->aux_ws.get() != nullptr, "finish_id_exchange without a deferred bucket_and_exchange_ids");
   x->bucketed_ids = x->bucketed_mem.device(n, index_dtype);
   x->raw_indices  = static_cast<int64_t*>(x->raw_mem.device(n, WHOLEMEMORY_DT_INT64));
   wm_bucket_args ba{};
@@ -214,7 +226,8 @@ void finish_id_exchange(wholememory_comm_t comm, const void* indices, wholememor
   ba.counts        = static_cast<int64_t*>(x->aux_counts.device(W + 1, WHOLEMEMORY_DT_INT64));
   ba.bucketed_ids  = x->bucketed_ids;
   ba.raw_indices   = x->raw_indices;
-  ba.workspace     = x->aux_ws.device(static_cast<int64_t>(bk->bucket_workspace_bytes(n, W)), WHOLEMEMORY_DT_INT8);
+  ba.workspace     = x->aux_ws.get();
+  ba.reuse_scan    = 1;
   WM_BK(bk->bucket_ids(&ba, stream));
   x->recv_ids = x->recv_mem.device(x->total_recv, index_dtype);
   exchange_segments(comm, x->bucketed_ids, x->send_counts, x->bucket_offsets, x->recv_ids, x->recv_counts,
@@ -440,7 +453,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
 //    segments are found by W pairs of binary searches, and the rows are received straight into their place of the dense
 //    [distinct, dim] buffer — no reorder-on-receive pass either;
 //  * WHETHER to do it is decided per call from the batch itself: every rank estimates the duplicate share of a sample of its
-//    ids (linear counting over a 4 MiB bitmap, ~20 us) in the bucketing pass it runs anyway, the estimates ride along with
+//    ids (linear counting over 16 MiB of byte flags, ~25 us; batches under 2^18 ids skip it and vote 0) next to the bucketing pass it runs anyway, the estimates ride along with
 //    the counts exchange, and all ranks apply the same rule to the same W numbers (mean >= WM_GATHER_DEDUP_PERMILLE, default
 //    100 = 10 % duplicates in the sample) — so the collectives stay matched. Uniform batches pay only for the estimate.
 //    WM_GATHER_DEDUP=0 / 1 forces the choice (2: also on a single rank, to measure).
@@ -477,7 +490,10 @@ wholememory_error_code_t gather_distributed_dedup(wholememory_handle_t handle, c
   WHOLEMEMORY_RETURN_ON_FAIL(gather_distributed_rows(handle, du, env, stream, gather_sms, nullptr, false, nullptr, &x));
   // (3) expand: out[i] = uniq_rows[run of i]; positions of negative ids get -1 and stay untouched
   auto* inv = static_cast<int64_t*>(inverse.device(n, WHOLEMEMORY_DT_INT64));
-  WM_BK(bk->run_inverse(d_starts, d_order, d_unique, d.indices.dtype, d_nunique, n, inv, stream));
+  // (an id past the last row belongs to no owner segment and was not fetched: its output row stays untouched, like a
+  // negative id's — the plain route reads past the last owner's shard for such ids, undefined in the reference too)
+  WM_BK(bk->run_inverse(d_starts, d_order, d_unique, d.indices.dtype, d_nunique, n, static_cast<int64_t>(entry_offsets.back()),
+                        inv, stream));
   wm_rows_args ea{};
   fill_rows_args(&ea, wholememory_create_continuous_global_reference(uniq_rows), du.plain, inv, WHOLEMEMORY_DT_INT64, n,
                  d.plain_ptr, d.plain, gather_sms);
@@ -740,7 +756,7 @@ wholememory_error_code_t gather_hierarchy(wholememory_handle_t handle, const op_
     int rc = bk->dedup_ids(xa.recv_ids, d.indices.dtype, n_relay, 0, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
     if (rc != 0) throw hip_error("dedup of relayed ids failed");  // not a return: the peers are already committed to hop B
     inv = static_cast<int64_t*>(inverse.device(n_relay, WHOLEMEMORY_DT_INT64));
-    WM_BK(bk->run_inverse(d_starts, d_order, d_unique, d.indices.dtype, d_nunique, n_relay, inv, stream));
+    WM_BK(bk->run_inverse(d_starts, d_order, d_unique, d.indices.dtype, d_nunique, n_relay, 0, inv, stream));
     auto* h_n = static_cast<int64_t*>(host_n.pinned(1, WHOLEMEMORY_DT_INT64));
     WM_BK(bk->memcpy_async(h_n, d_nunique, sizeof(int64_t), stream));
     WM_BK(bk->stream_sync(stream));

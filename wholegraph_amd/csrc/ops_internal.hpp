@@ -36,7 +36,7 @@ class temp_mem {
 // functions/exchange_ids_nccl_func.cu:157-226).
 struct id_exchange {
   explicit id_exchange(wholememory_env_func_t* env)
-    : bucketed_mem(env), raw_mem(env), recv_mem(env), aux_offsets(env), aux_offsets_host(env), aux_counts(env), aux_ws(env)
+    : bucketed_mem(env), raw_mem(env), recv_mem(env), aux_offsets(env), aux_counts(env), aux_ws(env)
   {
   }
   std::vector<int64_t> send_counts, recv_counts;    // per peer, as they travel (self = 0 when kept local)
@@ -62,7 +62,9 @@ struct id_exchange {
   int64_t* raw_indices = nullptr;                   // [n]   original position of each grouped id
   void* recv_ids       = nullptr;                   // [total_recv] ids received, peer-major
   temp_mem bucketed_mem, raw_mem, recv_mem;
-  temp_mem aux_offsets, aux_offsets_host, aux_counts, aux_ws;  // scratch of finish_id_exchange: lives as long as the exchange
+  // a deferred exchange (bucket_and_exchange_ids(..., defer_ids) then finish_id_exchange): row offsets on the device and the
+  // bucketing workspace with the scanned block counts, kept from the first half for the second; aux_counts: its counts dummy
+  temp_mem aux_offsets, aux_counts, aux_ws;
 };
 
 // ids that are already sorted (as unsigned keys) and distinct, their number still on the device: what dedup_ids leaves

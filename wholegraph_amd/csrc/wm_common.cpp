@@ -4,6 +4,8 @@
 #include <ctime>
 #include <unistd.h>
 
+#include <wholememory/wholegraph_amd_ext.h>
+
 namespace wm {
 
 LogLevel& log_level_ref()
@@ -50,4 +52,24 @@ bool debug_sync_enabled()
   return v == 1;
 }
 
+namespace {
+int g_async_completion = 0;   // what the host framework declared (wholememory_ext_set_async_completion); off = reference semantics
+}
+void set_async_completion(bool on) { g_async_completion = on ? 1 : 0; }
+bool async_completion_enabled()
+{
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("WM_ASYNC_OPS");
+    forced        = (e == nullptr || e[0] == '\0') ? -1 : (e[0] != '0' ? 1 : 0);
+  }
+  return forced >= 0 ? forced == 1 : g_async_completion == 1;
+}
+
 }  // namespace wm
+
+extern "C" wholememory_error_code_t wholememory_ext_set_async_completion(int on)
+{
+  wm::set_async_completion(on != 0);
+  return WHOLEMEMORY_SUCCESS;
+}

@@ -48,6 +48,15 @@ inline T round_up(T a, T b)
 // WM_DEBUG_SYNC=1 makes ops synchronise + check after every stage (reference cuda_macros.cpp:30).
 bool debug_sync_enabled();
 
+// Completion semantics of the ops whose reference versions synchronise the stream before they return (neighbour sampling,
+// append_unique: unweighted_sample_without_replacement_func.cuh:474, append_unique_func.cuh:351). Off (the default): the
+// same here — outputs are complete and scratch is idle when the call returns, whatever env functions the caller
+// supplied. On: such ops return with their last kernels queued; legal only when every allocator behind p_env_fns is
+// stream-ordered on the op's stream and every consumer of the outputs is ordered on it too — the torch layer declares
+// that (wholememory_ext_set_async_completion(1)); WM_ASYNC_OPS=0/1 overrides either way.
+void set_async_completion(bool on);
+bool async_completion_enabled();
+
 }  // namespace wm
 
 #define WM_LOG(lvl, ...)                                                              \

@@ -114,6 +114,9 @@ class EmbeddingLookupFn(torch.autograd.Function):
     def forward(ctx, indice, dummy_input, wm_embedding, is_training=False, force_dtype=None):
         rows = wm_embedding.gather(indice, is_training=is_training, force_dtype=force_dtype)
         ctx.target = wm_embedding if (is_training and wm_embedding.need_grad()) else None
+        # the gradient handed back for dummy_input must look like the tensor the caller passed (its own anchor, maybe of
+        # another shape or on another device), not like the embedding's
+        ctx.dummy_like = (tuple(dummy_input.shape), dummy_input.dtype, dummy_input.device)
         if ctx.target is not None:
             ctx.save_for_backward(indice)
         return rows
@@ -121,10 +124,13 @@ class EmbeddingLookupFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_outputs):
         target, ctx.target = ctx.target, None
+        if target is None:   # a forward outside training (or without optimizer) recorded nothing: no gradient for anybody
+            return None, None, None, None, None
         (indice,) = ctx.saved_tensors
         target.add_gradients(indice, grad_outputs)
         # one entry per forward input; only dummy_input is differentiable and its gradient carries no information
-        return None, torch.zeros_like(target.dummy_input), None, None, None
+        shape, dtype, device = ctx.dummy_like
+        return None, torch.zeros(shape, dtype=dtype, device=device), None, None, None
 
 
 class WholeMemoryEmbedding(object):
@@ -280,11 +286,11 @@ def create_embedding_from_filelist(comm, memory_type, memory_location, filelist,
         raise ValueError("last_dim_size must be positive")
     partition, round_robin_size = _reconcile_sharding(embedding_entry_partition, None, round_robin_size)
     row_bytes = torch.empty(0, dtype=dtype).element_size() * last_dim_size
-    sizes = {name: get_file_size(name) for name in files}
-    ragged = [name for name, nbytes in sizes.items() if nbytes % row_bytes]
-    if ragged:
-        raise ValueError("File %s size is %d not mutlple of %d" % (ragged[0], sizes[ragged[0]], row_bytes))
-    embedding = create_embedding(comm, memory_type, memory_location, dtype, [sum(sizes.values()) // row_bytes, last_dim_size],
+    sizes = [get_file_size(name) for name in files]   # per list entry: a file named twice is loaded twice
+    for name, nbytes in zip(files, sizes):
+        if nbytes % row_bytes:
+            raise ValueError("File %s size is %d not mutlple of %d" % (name, nbytes, row_bytes))
+    embedding = create_embedding(comm, memory_type, memory_location, dtype, [sum(sizes) // row_bytes, last_dim_size],
                                  cache_policy=cache_policy, embedding_entry_partition=partition, gather_sms=gather_sms,
                                  round_robin_size=round_robin_size)
     embedding.get_embedding_tensor().from_filelist(files, round_robin_size)

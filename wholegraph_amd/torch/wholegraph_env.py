@@ -174,6 +174,10 @@ def get_wholegraph_env_fns(use_default=True):
         table = _NativeEnvTable(lib) if lib is not None else _EnvTable()
         if use_default:
             _default_env = table
+        # both tables hand out memory of torch's caching allocator on the current stream, which is also the stream every
+        # op of this layer is called with: stream-ordered scratch and outputs, so the sampling ops may return with their
+        # last kernels queued (the library's default keeps the reference's drain for other env functions)
+        wmb.check(wmb.lib().wholememory_ext_set_async_completion(1))
     else:
         table = _default_env
     return C.pointer(table.env)
