@@ -23,7 +23,7 @@ stats n1_bench --no-cpu-baseline
 # ALL launches sits above the timed region's; the tail of the trace (timed region + stability leg) is what `kernel_ms` measures
 python - $(find /tmp/prof_n1_bench -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_n1_bench_kernel_trace_tail.txt <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rows_copy16_fast_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rows_batch_kernel" in r["Kernel_Name"] or "rows_copy16_fast_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 tail = dur[-400:]

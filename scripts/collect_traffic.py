@@ -20,8 +20,8 @@ def per_launch(path, needle):
 
 def main():
     d, tag = sys.argv[1], sys.argv[2]
-    fetch, nf, kname = per_launch(os.path.join(d, "%s_bench_FETCH_SIZE_counter_collection.csv" % tag), "rows_copy16_fast_kernel")
-    write, nw, _ = per_launch(os.path.join(d, "%s_bench_WRITE_SIZE_counter_collection.csv" % tag), "rows_copy16_fast_kernel")
+    fetch, nf, kname = per_launch(os.path.join(d, "%s_bench_FETCH_SIZE_counter_collection.csv" % tag), "rows_batch_kernel")
+    write, nw, _ = per_launch(os.path.join(d, "%s_bench_WRITE_SIZE_counter_collection.csv" % tag), "rows_batch_kernel")
     cal = {"fetch_correction": 2.0, "write_correction": 1.0, "note": "calibration kernel not run: the guide's gfx950 factor is used"}
     cf = os.path.join(d, "%s_calib_FETCH_SIZE_counter_collection.csv" % tag)
     cw = os.path.join(d, "%s_calib_WRITE_SIZE_counter_collection.csv" % tag)

@@ -106,8 +106,11 @@ def test_c1_host_table_gather(gpu_env):
     wgth.destroy_embedding(emb)
 
 
-@pytest.mark.parametrize("dtype_name,rows,dim", [("float32", 100_000_000, 128), ("float16", 50_000_000, 256)])
-def test_c4_scatter_add_with_heavy_duplicates(gpu_env, dtype_name, rows, dim):
+@pytest.mark.parametrize("dtype_name,rows,dim,memory_type", [("float32", 100_000_000, 128, "distributed"),
+                                                             ("float16", 50_000_000, 256, "distributed"),
+                                                             ("float16", 50_000_000, 256, "continuous"),   # C4 as BASELINE names it
+                                                             ("float32", 100_000_000, 128, "continuous")])
+def test_c4_scatter_add_with_heavy_duplicates(gpu_env, dtype_name, rows, dim, memory_type):
     """Gradient apply as scatter-add (SGD, lr = -1, wd = 0) of 10 M Zipf(1.05) ids — about half of them duplicates, the
     hottest row hit ~10^5 times. Gradients are small integers, so every partial sum is an exactly representable integer
     whatever the summation order: table'[r] = table[r] + sum of the gradient rows addressed to r, bit for bit, checked
@@ -117,7 +120,7 @@ def test_c4_scatter_add_with_heavy_duplicates(gpu_env, dtype_name, rows, dim):
     dt = getattr(torch, dtype_name)
     _need_hbm(torch, 80)
     n = 10_000_000
-    emb = wgth.create_embedding(gpu_env, "distributed", "cuda", dt, [rows, dim])
+    emb = wgth.create_embedding(gpu_env, memory_type, "cuda", dt, [rows, dim])
     local, start = emb.get_embedding_tensor().get_local_tensor()
     local.zero_()
     opt = wgth.create_wholememory_optimizer(emb, "sgd", {"weight_decay": 0.0})

@@ -373,6 +373,9 @@ struct opt_params {
   const int64_t* n_unique;  // device scalar (or nullptr -> a.count)
   long_run_entry* long_list;
   int32_t* long_count;
+  // step_tile_kernel: runs per wave tile. 64 with the persistent grid of round 2; one batch (RPS x kU runs) when the tiles
+  // are handed out in order, one per wave (round 3, see launch_step_opt)
+  int tile_runs;
 };
 
 // optimizer statement sequences of the reference kernels (embedding_optimizer_func.cu:212-223, 392-415,
@@ -753,18 +756,19 @@ void step_tile_kernel(opt_params p)
   const int64_t wave         = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
   const int64_t n_waves      = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
   const int64_t count        = p.n_unique ? *p.n_unique : a.count;
-  const int64_t tiles        = (count + 63) / 64;
+  const int tile_runs        = p.tile_runs;   // a multiple of RPS * kU, <= 64
+  const int64_t tiles        = (count + tile_runs - 1) / tile_runs;
   const IdxT* ids            = static_cast<const IdxT*>(a.ids);
   const int col              = lane & (kLpr - 1);
   const int sub              = lane / kLpr;
   const int row_vecs         = static_cast<int>(a.dim / kVE);
 
   for (int64_t tile = wave; tile < tiles; tile += n_waves) {
-    const int64_t u     = tile * 64 + lane;
+    const int64_t u     = tile * tile_runs + min(lane, tile_runs - 1);
     const int64_t uc    = min(u, count - 1);  // clamped: the loads stay unconditional, dead lanes get run length 0
     const int64_t local = static_cast<int64_t>(ids[uc]) - a.local_entry_offset;
     const int32_t my_s0 = a.run_starts[uc];
-    int32_t my_len      = u < count ? a.run_starts[uc + 1] - my_s0 : 0;
+    int32_t my_len      = (u < count && lane < tile_runs) ? a.run_starts[uc + 1] - my_s0 : 0;
     if (p.long_list != nullptr && my_len > kLongRun) my_len = 0;  // the long-run kernel's (mark_long_runs_kernel lists it)
     const T* my_grad = grad_row<T>(a, a.order[my_s0]);
     T* my_row;
@@ -792,7 +796,7 @@ void step_tile_kernel(opt_params p)
       const bool col_ok  = c < row_vecs;
       const int64_t coff = static_cast<int64_t>(c) * kVE;
 #pragma unroll 1
-      for (int s = 0; s < 64; s += RPS * kU) {
+      for (int s = 0; s < tile_runs; s += RPS * kU) {
         tile_vals<kVE> acc[kU];
         tile_raw4 ev[kU], s0v[kU], s1v[kU];
         T* trow[kU];
@@ -1230,6 +1234,31 @@ void launch_mark_long_runs(const opt_params& p, hipStream_t stream, hipStream_t 
   }
 }
 
+// Launch shape of step_tile_kernel. Default: round 2's persistent grid of 8192 workgroups over tiles of 64 runs.
+// WM_TILE_INORDER=1: the in-order shape of the row kernels (rows.hip: rows_op) — one tile of ONE batch of runs per wave
+// (RPS x kU runs: 8 for SGD on 512-byte rows), as many workgroups as the upper bound of the run count takes (the true count is
+// on the device: waves past it leave at once). Measured on whole 10 M-row calls, interleaved in one process
+// (experiments/grad_inorder_ab.py, profiles/r03_grad_inorder_ab.txt): SGD uniform 3.281 vs 3.268 ms, Zipf 3.12-3.23 vs 3.09-3.10,
+// LazyAdam 6.295 vs 6.305, fp16 x 256 3.143 vs 3.189, 256-byte rows 1.856 vs 1.877 — a wash: this kernel has no dense streamed
+// side whose DRAM pages an ordered window could keep open (gradient rows arrive through order[], table rows are 1 in 10 of a
+// sorted sweep), so the default stays. WM_TILE_RUNS forces the tile (a multiple of the batch).
+inline void tile_launch_shape(int64_t count_bound, int vecs, int ku, int* tile_runs, int* tblocks)
+{
+  const int rps      = vecs > 32 ? 1 : vecs > 16 ? 2 : vecs > 8 ? 4 : 8;
+  const int batch    = rps * ku;
+  const char* io_env = getenv("WM_TILE_INORDER");
+  const bool inorder = io_env != nullptr && io_env[0] == '1';
+  *tile_runs         = inorder ? std::min(64, batch) : 64;
+  if (const char* e = getenv("WM_TILE_RUNS")) {
+    const int v = atoi(e);
+    if (v >= batch && v <= 64 && v % batch == 0) *tile_runs = v;
+  }
+  const int64_t tiles = (count_bound + *tile_runs - 1) / *tile_runs;
+  int b = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, inorder ? INT64_C(0x7fffffff) : INT64_C(256 * 32)));
+  if (const char* e = getenv("WM_STEP_BLOCKS")) b = std::min(b, std::max(1, atoi(e)));
+  *tblocks = std::max(b, 1);
+}
+
 template <typename IdxT, int OPT>
 int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStream_t lstream)
 {
@@ -1276,11 +1305,10 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
   const bool tile_ok = !tile_off && p.a.dim % 4 == 0 && p.a.dim >= 32 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 &&
                        self_ok4 && st_ok && tb_ok;
   if (tile_ok) {
-    const int64_t tiles = (p.a.count + 63) / 64;
-    int tblocks         = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, 256 * 32));
-    if (const char* e = getenv("WM_STEP_BLOCKS")) tblocks = std::min(tblocks, std::max(1, atoi(e)));
-    tblocks             = std::max(tblocks, 1);
-    const int vecs      = static_cast<int>(p.a.dim / 4);
+    const int vecs = static_cast<int>(p.a.dim / 4);
+    opt_params tp = p;
+    int tblocks   = 1;
+    tile_launch_shape(p.a.count, vecs, OPT == WHOLEMEMORY_OPT_SGD ? WM_TILE_KU_SGD : WM_TILE_KU_STATE, &tp.tile_runs, &tblocks);
     // SGD on 512-byte fp32 rows (two runs per wave instruction), uncached: the same kernel compiled for 7 waves / SIMD — a
     // 72-register budget, 10 values spilled to scratch — instead of the 5 its natural 84 registers allow: whole call 3.05 ->
     // 2.99 ms per 10 M rows (experiments/occ_ab.py, interleaved in one process). The other row widths lose with it (dim 32:
@@ -1289,16 +1317,16 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
       const char* occ_env = getenv("WM_TILE_OCC");
       const bool natural  = occ_env != nullptr && atoi(occ_env) == 5;
       if (!cached && !natural && vecs > 16 && vecs <= 32) {
-        hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, 2, false, float, 0, 7>), dim3(tblocks), dim3(kBlock), 0, stream, p);
+        hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, 2, false, float, 0, 7>), dim3(tblocks), dim3(kBlock), 0, stream, tp);
         return hipGetLastError() == hipSuccess ? 0 : -2;
       }
     }
 #define WM_TILE(RPS)                                                                                                    \
   do {                                                                                                                  \
     if (cached)                                                                                                         \
-      hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, RPS, true>), dim3(tblocks), dim3(kBlock), 0, stream, p);          \
+      hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, RPS, true>), dim3(tblocks), dim3(kBlock), 0, stream, tp);          \
     else                                                                                                                \
-      hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, RPS, false>), dim3(tblocks), dim3(kBlock), 0, stream, p);         \
+      hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, RPS, false>), dim3(tblocks), dim3(kBlock), 0, stream, tp);         \
   } while (0)
     if (vecs > 32) WM_TILE(1);
     else if (vecs > 16) WM_TILE(2);
@@ -1348,11 +1376,9 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream, hipStream_t 
                        reinterpret_cast<uint64_t>(p.a.local_table) % 16 == 0 &&
                        (!cached || (p.a.cache_row_elems % 8 == 0 && reinterpret_cast<uint64_t>(p.a.cache_data) % 16 == 0));
   if (tile_ok) {
-    const int64_t tiles = (p.a.count + 63) / 64;
-    int tblocks         = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, 256 * 32));
-    if (const char* e = getenv("WM_STEP_BLOCKS")) tblocks = std::min(tblocks, std::max(1, atoi(e)));
-    tblocks             = std::max(tblocks, 1);
-    const int vecs      = static_cast<int>(p.a.dim / 8);
+    const int vecs = static_cast<int>(p.a.dim / 8);
+    int tblocks    = 1;
+    tile_launch_shape(p.a.count, vecs, WM_TILE_KU_STATE, &p.tile_runs, &tblocks);
 #define WM_TILE16(RPS)                                                                                                       \
   do {                                                                                                                       \
     if (cached)                                                                                                              \

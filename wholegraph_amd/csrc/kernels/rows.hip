@@ -96,6 +96,8 @@ struct rows_params {
   int stage_rows;
   // host side only: threads per workgroup of this launch (a multiple of 64, <= kBlock; the kernels read blockDim)
   int launch_threads;
+  // host side only: 32 / 64 / 128 / 256 = this launch takes rows_batch_kernel<..., that many 16-byte pieces per row>
+  int batch_vecs;
 };
 
 // byte address of the first moved element of table row `idx`
@@ -299,6 +301,58 @@ __global__ __launch_bounds__(kBlock) void rows_copy16_fast_kernel(rows_params p)
     }
   }
 }
+
+// The in-order shape of the hot geometry, fully specialised: rows of 512 B, 1, 2 or 4 KiB (ROW_VECS 16-byte pieces), one
+// tile of 4 KiB per wave moved as ONE batch — four 1 KiB wave instructions of loads, then four of stores, no loop, no
+// column test — and the wave is done; the dispatcher hands the next tile to whichever wave slot frees up first, in order.
+// (experiments/placement_pmc.hip: rows_inorder<8, 256> is this kernel for 512 B rows; against the generic fast kernel run
+// with 8-row tiles it is worth another 2-3 % on the 10 M-row gather.)
+template <typename IdxT, bool GATHER, int ROW_VECS, bool HAS_MAP>
+__global__ __launch_bounds__(kBlock) void rows_batch_kernel(rows_params p)
+{
+  constexpr int kSteps  = 4;                                        // 4 x 1 KiB
+  constexpr int RPS     = ROW_VECS == 32 ? 2 : 1;                   // rows per wave instruction
+  constexpr int kChunks = ROW_VECS <= 64 ? 1 : ROW_VECS / 64;       // wave instructions per row
+  constexpr int kRows   = 256 / ROW_VECS;                           // rows per tile: 8, 4, 2, 1
+  const int lane        = threadIdx.x & (kWave - 1);
+  const int64_t tile    = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  if (tile * kRows >= p.n) return;
+  char *my_tab, *my_plain;
+  load_tile_entry<IdxT>(p, lane < kRows ? tile * kRows + lane : p.n, my_tab, my_plain);
+  const int col    = RPS == 2 ? (lane & 31) : lane;
+  const bool upper = RPS == 2 && lane >= 32;
+  char* const plain_tile = p.plain + (tile * kRows + (upper ? 1 : 0)) * p.plain_stride_bytes;
+  u32x4 data[kSteps];
+  char* dst[kSteps];
+#pragma unroll
+  for (int u = 0; u < kSteps; u++) {
+    const int e0 = RPS == 2 ? 2 * u : u / kChunks;                  // first row of this step (compile-time)
+    const int cb = RPS == 2 ? 0 : u % kChunks;
+    char* t      = readlane_ptr(my_tab, e0);
+    if (RPS == 2) {
+      char* t1 = readlane_ptr(my_tab, e0 + 1);
+      t        = upper ? t1 : t;
+    }
+    char* q;
+    if (HAS_MAP) {
+      q = readlane_ptr(my_plain, e0);
+      if (RPS == 2) {
+        char* q1 = readlane_ptr(my_plain, e0 + 1);
+        q        = upper ? q1 : q;
+      }
+    } else {
+      q = plain_tile + static_cast<int64_t>(e0) * p.plain_stride_bytes;
+    }
+    const int64_t coff = static_cast<int64_t>(cb * 64 + col) * 16;
+    const char* src    = (GATHER ? t : q) + coff;
+    dst[u]             = t != nullptr ? (GATHER ? q : t) + coff : nullptr;  // entries past n and negative ids carry a null base
+    if (t != nullptr) data[u] = ld_global_nt<u32x4>(src);
+  }
+#pragma unroll
+  for (int u = 0; u < kSteps; u++)
+    if (dst[u] != nullptr) st_global_nt<u32x4>(dst[u], data[u]);
+}
+
 
 // Rows whose size is not a power of two (400 B, 1200 B, 2408 B ... : dims 100 / 300 / 602 of common GNN datasets), and
 // 1 KiB rows. The pow-of-two lane mapping above leaves lanes idle and walks a big row in several passes; here the tile is
@@ -593,11 +647,12 @@ int default_max_blocks()
   return cus * 32;  // measured: 8192 workgroups (32 per CU) beat 2048 by ~2% on the 10 M-id gather
 }
 
-// WM_ROWS_INORDER=0: the persistent grid-stride launches of rounds 1-2 (A/B)
-bool inorder_enabled()
+// WM_ROWS_INORDER=0: the persistent grid-stride launches of rounds 1-2 everywhere; 1: in-order launches everywhere;
+// unset (-1): the measured rule in rows_op
+int inorder_setting()
 {
   const char* e = getenv("WM_ROWS_INORDER");
-  return e == nullptr || e[0] != '0';
+  return (e == nullptr || e[0] == '\0') ? -1 : (e[0] == '0' ? 0 : 1);
 }
 // threads per workgroup of the in-order launches (WM_ROWS_BLOCK=64 / 128 / 256; measured: 64 and 256 within 1 %, 512 and
 // 1024 5-12 % slower — the finer the unit the dispatcher hands out, the tighter the window)
@@ -663,6 +718,22 @@ void launch_copy(const rows_params& p, int vb, int blocks, hipStream_t stream)
   }
   if (p.flat_slots > 0) {
     launch_flat<IdxT, GATHER>(p, blocks, stream);
+    return;
+  }
+  if (vb == 16 && p.batch_vecs > 0) {  // in-order launch of 512 B / 1 / 2 / 4 KiB rows: the single-batch kernel
+    const bool has_map = p.row_map != nullptr;
+#define WM_BATCH(RV)                                                                                   \
+  do {                                                                                                 \
+    if (has_map) launch_rows_kernel(rows_batch_kernel<IdxT, GATHER, RV, true>, blocks, stream, p);     \
+    else launch_rows_kernel(rows_batch_kernel<IdxT, GATHER, RV, false>, blocks, stream, p);            \
+  } while (0)
+    switch (p.batch_vecs) {
+      case 32: WM_BATCH(32); break;
+      case 64: WM_BATCH(64); break;
+      case 128: WM_BATCH(128); break;
+      default: WM_BATCH(256); break;
+    }
+#undef WM_BATCH
     return;
   }
   if (vb == 16 && p.row_vecs >= 32) {  // rows of >= 512 B: readlane fast path
@@ -793,9 +864,14 @@ int rows_op(const wm_rows_args* a, void* stream_v)
   // output buffer (its 8192 resident waves each own a 32 KiB tile and the 8192 workgroups sweep the output four times, so
   // the 64-byte write requests of one DRAM page arrive spread over microseconds; a physically contiguous buffer: always
   // slow), the in-order shape at 1.64-1.73 ms on every buffer of every process, the contiguous one included.
-  const bool inorder = a->max_blocks <= 0 && inorder_enabled();
-  p.launch_threads   = inorder ? inorder_block_threads() : kBlock;
-  p.tile_rows        = kWave;
+  // WM_ROWS_INORDER: 0 = never, 1 = every kernel, unset = the measured rule: every kernel except the two whose per-tile set-up
+  // is too heavy for 4 KiB tiles — the flat-stream SCATTER (profiles/r03_dim_sweep_inorder_ab.csv: 1200 B rows 62 vs 70 % of
+  // peak, 516 B 46 vs 51 %, 2408 B 57 vs 60 %; the flat gather gains: 800 B 69 vs 65 %, 2408 B 66 vs 61 %) and the
+  // LDS-staged gather (516 B: 61 vs 65 %). Those two keep the persistent launch.
+  const int inorder_mode = inorder_setting();
+  bool inorder           = a->max_blocks <= 0 && inorder_mode != 0;
+  p.launch_threads       = inorder ? inorder_block_threads() : kBlock;
+  p.tile_rows            = kWave;
   auto grid_for = [&](int tile_rows) {
     const int64_t tiles = (a->n + tile_rows - 1) / tile_rows;
     const int wpb       = p.launch_threads / kWave;
@@ -826,6 +902,10 @@ int rows_op(const wm_rows_args* a, void* stream_v)
       p.flat_slots = static_cast<int>((row_bytes + 15) / 16);
       p.flat_tail  = static_cast<int>(row_bytes - 16 * static_cast<int64_t>(p.flat_slots - 1));
       p.flat_rcp   = 1.0f / static_cast<float>(p.flat_slots);
+      if (!GATHER && inorder_mode < 0 && inorder) {   // flat-stream scatter: persistent unless forced
+        inorder          = false;
+        p.launch_threads = kBlock;
+      }
     }
     // LDS-staged gather: dense output rows only 4 / 8-byte aligned, table rows on 16-byte boundaries with room for whole
     // 16-byte loads (padded stride), no row map (the output of consecutive entries must be one contiguous piece)
@@ -838,8 +918,12 @@ int rows_op(const wm_rows_args* a, void* stream_v)
       while (R > need && static_cast<int64_t>(R) * row_bytes > 5120) R >>= 1;
       if (static_cast<int64_t>(R) * row_bytes <= 5120) {   // kStageIters x 1 KiB per wave; bigger rows stay on the flat kernel
         p.stage_rows = R;
-        p.tile_rows  = inorder ? R : kWave;   // in order: one chunk (<= 5 KiB) per wave
-        blocks       = grid_for(p.tile_rows);
+        if (inorder_mode < 0 && inorder) {   // staged gather: persistent unless forced
+          inorder          = false;
+          p.launch_threads = kBlock;
+        }
+        p.tile_rows = inorder ? R : kWave;   // in order: one chunk (<= 5 KiB) per wave
+        blocks      = grid_for(p.tile_rows);
       }
     }
     if (p.stage_rows == 0 && (p.flat_slots > 0 || (vb == 16 && p.row_vecs >= 32))) {  // the two kernels that take tile_rows
@@ -855,6 +939,15 @@ int rows_op(const wm_rows_args* a, void* stream_v)
         } else {                  // readlane kernel: (tile_rows / RPS) x chunks steps, a multiple of its 4-step batch
           const int chunks = p.row_vecs > 32 ? (p.row_vecs + kWave - 1) / kWave : 1;
           p.tile_rows      = p.row_vecs == 32 ? 8 : chunks == 1 ? 4 : chunks == 2 ? 2 : chunks % 4 == 0 ? 1 : 4;
+          // 512 B / 1 / 2 / 4 KiB rows: exactly one 4 KiB batch per tile -> the specialised kernel (WM_ROWS_BATCH=0: A/B)
+          const char* be = getenv("WM_ROWS_BATCH");
+          if ((p.row_vecs == 32 || p.row_vecs == 64 || p.row_vecs == 128 || p.row_vecs == 256) && forced == 0 &&
+              !(be != nullptr && be[0] == '0')) {
+            p.batch_vecs = p.row_vecs;
+            // one wave per workgroup for this kernel: the finest unit the dispatcher can hand out (measured against 256
+            // threads on 512 B - 4 KiB rows: gather +0.2 ... +1.4 %, scatter +0.5 ... +1 %; the flat kernel loses 2-3 % with it)
+            if (getenv("WM_ROWS_BLOCK") == nullptr) p.launch_threads = kWave;
+          }
         }
       }
       if ((forced == 8 || forced == 16 || forced == 32 || forced == 64) && (p.flat_slots > 0 || forced % 8 == 0)) p.tile_rows = forced;
