@@ -268,7 +268,7 @@ int t_step(const wm_optimizer_args* a, const int64_t* n_unique_dev, void*)
   return 0;
 }
 
-size_t t_long_ws(int64_t) { return 64; }
+size_t t_long_ws(int64_t, int64_t) { return 64; }
 int t_run_inverse(const int32_t* run_starts, const int32_t* order, const void* unique_ids, wholememory_dtype_t dt,
                   const int64_t* n_unique, int64_t n, int64_t id_limit, int64_t* inverse, void*)
 {

@@ -249,6 +249,7 @@ def scenario_sgd16(comm, rank, world, tdt, dim, lr, wd, mt="distributed"):
     owner sums duplicates in fp32 in rank-major receive order and rounds once. Oracle = the fp32 multi-rank oracle
     wrapped in exact widenings and that one rounding."""
     n_rows, steps = 1501, 2
+    os.environ["WM_GRAD_FOLD"] = "ordered"   # the bits of the receive-order sum (the 16-bit default is the tree fold, round 3)
     emb = wgth.create_embedding(comm, mt, "cuda", tdt, [n_rows, dim])
     stride = emb.get_embedding_tensor().stride()[0]
     init16 = torch.from_numpy(np.random.default_rng(8).standard_normal((n_rows, dim)).astype(np.float32)).to(tdt)
@@ -290,6 +291,7 @@ def scenario_sgd16(comm, rank, world, tdt, dim, lr, wd, mt="distributed"):
                 "16-bit table read back (%s) differs on rank %d step %d" % (mt, rank, step)
             comm.barrier()
     comm.barrier()
+    del os.environ["WM_GRAD_FOLD"]
     wgth.destroy_wholememory_optimizer(opt)
     wgth.destroy_embedding(emb)
 

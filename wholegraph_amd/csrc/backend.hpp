@@ -92,8 +92,15 @@ struct wm_optimizer_args {
   float* per_row_state;        // adam: [rows, 2] (beta1^t, beta2^t); else nullptr
   float weight_decay, epsilon, beta1, beta2, alpha, lr;
   int adam_w;
-  void* long_run_ws;           // device scratch of long_run_workspace_bytes(n_recv) or nullptr (then every run is
+  void* long_run_ws;           // device scratch of long_run_workspace_bytes(n_recv, dim) or nullptr (then every run is
                                // folded by one wave)
+  // Order of the fp32 sum of a run's duplicate gradient rows. 0 = the reference's (receive order, one chain per element:
+  // exchange_embeddings_nccl_func.cu:76-103) — bit-identical results, the default for fp32 tables. 1 = "tree": runs of more
+  // than a few dozen rows are cut into segments of rows that are summed side by side and combined afterwards — a fixed
+  // order too (results are deterministic), but not the reference's: equal within rounding (and exact whenever the partial
+  // sums are exactly representable). -1 = the backend's default for the value dtype (ordered for fp32, tree for the 16-bit
+  // extension, WM_GRAD_FOLD=ordered|tree overrides).
+  int fold_mode;
 };
 
 // neighbour sampling on a CSR graph whose arrays are mapped (flat or chunked) in this process
@@ -187,7 +194,7 @@ struct wm_device_backend {
   // fused duplicate-sum + optimizer update. a->count bounds the launch; when n_unique_dev != nullptr the true
   // number of unique ids is read from that device scalar (no host sync to learn it).
   int (*optimizer_step)(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);
-  size_t (*long_run_workspace_bytes)(int64_t n_recv);
+  size_t (*long_run_workspace_bytes)(int64_t n_recv, int64_t dim);
   // inverse of a dedup: inverse[order[j]] = index of the run that sorted position j belongs to, or -1 when that run's
   // id is negative or, with id_limit > 0, not below id_limit (n_unique_dev: device scalar written by dedup_ids)
   int (*run_inverse)(const int32_t* run_starts, const int32_t* order, const void* unique_ids, wholememory_dtype_t index_dtype,

@@ -175,6 +175,7 @@ void fill_optimizer_args(wm_optimizer_args* a, const wholememory_embedding_optim
   a->alpha        = o->alpha;
   a->adam_w       = o->adam_w > 0.5f ? 1 : 0;
   a->lr           = lr;
+  a->fold_mode    = -1;   // the backend's default for the table dtype (ordered for fp32), WM_GRAD_FOLD overrides
 }
 
 // owner side: sort received ids, then the fused duplicate-sum + optimizer kernel
@@ -231,7 +232,7 @@ void step_sorted(dedup_result& r, wholememory_dtype_t index_dtype, int64_t n_rec
     oa->self_grad_stride = self->stride;
   }
   oa->count       = n_recv;  // upper bound; the kernel reads the true count from d_nunique
-  oa->long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n_recv)), WHOLEMEMORY_DT_INT8);
+  oa->long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n_recv, oa->dim)), WHOLEMEMORY_DT_INT8);
   if (rows_ready != nullptr) WM_BK(bk->stream_wait_event(stream, rows_ready));
   int rc = bk->optimizer_step(oa, r.d_nunique, stream);
   if (rc != 0) throw hip_error("optimizer_step failed");

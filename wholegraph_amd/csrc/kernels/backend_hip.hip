@@ -15,7 +15,7 @@ int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, i
                   void* unique_ids, int32_t* run_starts, int32_t* order, int64_t* n_unique_out, void* workspace,
                   void* stream);
 int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_dev, void* stream);
-size_t hip_long_run_ws_bytes(int64_t n_recv);
+size_t hip_long_run_ws_bytes(int64_t n_recv, int64_t dim);
 int hip_run_inverse(const int32_t* run_starts, const int32_t* order, const void* unique_ids, wholememory_dtype_t index_dtype,
                     const int64_t* n_unique_dev, int64_t n, int64_t id_limit, int64_t* inverse, void* stream);
 int hip_remap_self_order(int32_t* order, int64_t n, int64_t self_begin, int64_t self_count, const int64_t* self_rows,

@@ -376,6 +376,10 @@ struct opt_params {
   // step_tile_kernel: runs per wave tile. 64 with the persistent grid of round 2; one batch (RPS x kU runs) when the tiles
   // are handed out in order, one per wave (round 3, see launch_step_opt)
   int tile_runs;
+  // runs of more rows than this are not folded by step_tile_kernel / step_short_kernel but listed for the long-run side
+  // (kLongRun with the ordered fold, tree_threshold() with the tree fold)
+  int long_threshold;
+  int fold_tree;   // 1: the long-run side is the tree fold (tree_fold_kernel), 0: the ordered fold (step_long4_kernel)
 };
 
 // optimizer statement sequences of the reference kernels (embedding_optimizer_func.cu:212-223, 392-415,
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void step_short_kernel(opt_params p)
       live[k] = u0 + k < count;
       // runs of more than kLongRun rows belong to the long-run kernel (listed by mark_long_runs_kernel, which also
       // advances their LazyAdam beta powers): nothing of them is touched here
-      if (p.long_list != nullptr && m_cur.s1[k] - m_cur.s0[k] > kLongRun) live[k] = false;
+      if (p.long_list != nullptr && m_cur.s1[k] - m_cur.s0[k] > p.long_threshold) live[k] = false;
       if (OPT == WHOLEMEMORY_OPT_LAZY_ADAM && live[k] && lane == 0) {
         // every lane has read the old values (same wave, program order) before this store
         a.per_row_state[m_cur.local[k] * 2 + 0] = r_cur.beta1t[k];
@@ -769,7 +773,7 @@ void step_tile_kernel(opt_params p)
     const int64_t local = static_cast<int64_t>(ids[uc]) - a.local_entry_offset;
     const int32_t my_s0 = a.run_starts[uc];
     int32_t my_len      = (u < count && lane < tile_runs) ? a.run_starts[uc + 1] - my_s0 : 0;
-    if (p.long_list != nullptr && my_len > kLongRun) my_len = 0;  // the long-run kernel's (mark_long_runs_kernel lists it)
+    if (p.long_list != nullptr && my_len > p.long_threshold) my_len = 0;  // the long-run side's (mark_long_runs_kernel / tree_mark_kernel lists it)
     const T* my_grad = grad_row<T>(a, a.order[my_s0]);
     T* my_row;
     float* my_st = nullptr;
@@ -1234,6 +1238,281 @@ void launch_mark_long_runs(const opt_params& p, hipStream_t stream, hipStream_t 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// "Tree" fold of long duplicate runs (wm_optimizer_args::fold_mode = 1; WM_GRAD_FOLD=tree) — round 3.
+// The ordered fold above is one fp32 chain per element and run: the 527 k duplicates of the hottest row of a Zipf(1.05)
+// batch are 527 k dependent adds, ~8 cycles each, whatever feeds them (2.2-2.9 ms beside a 2.6 ms step_tile_kernel). When the
+// caller does not need the reference's association order, a run is cut by ROWS instead: segments of kTreeSeg rows, one
+// workgroup each, whose 256 threads sum kTreeSeg / row-slots rows apiece in registers (4 row loads in flight per thread) and
+// meet in LDS; runs of one segment apply the optimizer right there, longer ones park one fp32 partial row per segment and a
+// second small kernel adds the partials of a run in segment order and applies the optimizer. Every sum has a fixed order, so
+// results are deterministic — and exact whenever every partial sum is exactly representable (integer-valued gradients) —
+// but they are not the reference's bits: |tree - ordered| is bounded by the usual forward error of fp32 summation,
+// (number of terms) x 2^-24 x sum |g_i|, and the tree's own error is the smaller of the two (shorter chains).
+// Because the fold is bandwidth-bound, not latency-bound, the threshold between "the tile kernel folds it in its lanes" and
+// "listed for the long-run side" drops from 256 rows to kTreeMin.
+constexpr int kTreeSeg     = 512;   // rows per segment, at least
+constexpr int kTreeMaxSegs = 256;   // segments per run, at most (a longer run gets longer segments): bounds the combine chain
+constexpr int kTreeMin     = 128;   // runs of more rows than this are listed (WM_GRAD_FOLD_MIN; swept 16 ... 256 on the Zipf batch:
+                                    // 2.58 / 2.34 / 2.23 / 2.19 / 2.25 ms per call at 16 / 32 / 64 / 128 / 256)
+
+struct tree_run {
+  int32_t run;       // index into the unique ids
+  float beta1t, beta2t;
+  int32_t pbase;     // first partial row of the run, or -1 for a run of one segment
+  int32_t seg_rows;  // rows per segment
+  int32_t nseg;
+  int32_t pad[2];
+};
+struct tree_seg {
+  int32_t run_slot;  // index into the listed runs
+  int32_t seg;       // segment number inside the run
+};
+struct tree_ws_view {
+  int32_t* counters;       // [0] listed runs, [1] segments, [2] partial rows, [3] runs of several segments
+  tree_run* runs;
+  int32_t* multi;          // slots of the runs of several segments (what tree_combine_kernel walks)
+  tree_seg* segs;
+  float* partials;         // [partial rows][dim rounded up to 4]
+  int64_t max_runs, max_segs, max_partials;
+};
+__host__ __device__ inline int64_t tree_dim_pad(int64_t dim) { return (dim + 3) / 4 * 4; }
+inline void tree_bounds(int64_t n_recv, int threshold, int64_t* max_runs, int64_t* max_segs, int64_t* max_partials)
+{
+  *max_runs     = n_recv / (threshold + 1) + 2;
+  *max_partials = 2 * (n_recv / kTreeSeg) + 2;            // only runs of >= 2 segments park partials
+  *max_segs     = *max_runs + n_recv / kTreeSeg + 2;
+}
+inline size_t tree_ws_bytes(int64_t n_recv, int64_t dim, int threshold)
+{
+  int64_t r, s, q;
+  tree_bounds(n_recv, threshold, &r, &s, &q);
+  return 64 + static_cast<size_t>(r) * (sizeof(tree_run) + sizeof(int32_t)) + static_cast<size_t>(s) * sizeof(tree_seg) + 128 +
+         static_cast<size_t>(q) * static_cast<size_t>(tree_dim_pad(dim)) * sizeof(float);
+}
+inline tree_ws_view tree_ws_carve(void* ws, int64_t n_recv, int threshold)
+{
+  tree_ws_view v;
+  tree_bounds(n_recv, threshold, &v.max_runs, &v.max_segs, &v.max_partials);
+  char* p    = static_cast<char*>(ws);
+  v.counters = reinterpret_cast<int32_t*>(p);
+  p += 64;
+  v.runs = reinterpret_cast<tree_run*>(p);
+  p += static_cast<size_t>(v.max_runs) * sizeof(tree_run);
+  v.multi = reinterpret_cast<int32_t*>(p);
+  p += (static_cast<size_t>(v.max_runs) * sizeof(int32_t) + 15) & ~size_t(15);
+  v.segs = reinterpret_cast<tree_seg*>(p);
+  p += static_cast<size_t>(v.max_segs) * sizeof(tree_seg);
+  p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 63) & ~uintptr_t(63));
+  v.partials = reinterpret_cast<float*>(p);
+  return v;
+}
+
+// lists the runs of more than `threshold` rows with their segments. One lane per run finds and registers it (the beta powers of
+// LazyAdam are advanced here as in mark_long_runs_kernel); the segment entries of every listed run of a wave are then written
+// by the 64 lanes together — the hottest run of a Zipf batch has hundreds, and one lane writing them alone was 0.25 ms of
+// the call's critical path.
+template <typename IdxT>
+__global__ __launch_bounds__(256) void tree_mark_kernel(opt_params p, tree_ws_view w, int threshold)
+{
+  const wm_optimizer_args& a = p.a;
+  const int64_t count        = p.n_unique ? *p.n_unique : a.count;
+  const IdxT* ids            = static_cast<const IdxT*>(a.ids);
+  const int64_t u            = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int lane             = threadIdx.x & 63;
+  int32_t len                = 0;
+  if (u < count) len = a.run_starts[u + 1] - a.run_starts[u];
+  int slot = -1, sbase = 0, nseg = 0, seg_rows = 0;
+  float beta1t = 0.f, beta2t = 0.f;
+  const bool listed = len > threshold;
+  if (listed) {
+    if (a.type == WHOLEMEMORY_OPT_LAZY_ADAM) {
+      const int64_t local            = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
+      beta1t                         = a.per_row_state[local * 2 + 0] * a.beta1;
+      beta2t                         = a.per_row_state[local * 2 + 1] * a.beta2;
+      a.per_row_state[local * 2 + 0] = beta1t;
+      a.per_row_state[local * 2 + 1] = beta2t;
+    }
+    nseg     = min((len + kTreeSeg - 1) / kTreeSeg, kTreeMaxSegs);
+    seg_rows = (len + nseg - 1) / nseg;
+    nseg     = (len + seg_rows - 1) / seg_rows;   // no empty segment at the end
+  }
+  // one atomic per counter and WAVE (a Zipf batch lists ~10^5 runs; one atomic each on four addresses serialised)
+  const uint64_t lmask = __ballot(listed);
+  if (lmask != 0) {   // wave-uniform
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const bool is_multi  = nseg > 1;
+    const uint64_t mmask = __ballot(is_multi);
+    // inclusive wave scans of nseg (all listed) and of nseg over the multi-segment runs
+    int incl_all = nseg, incl_multi = is_multi ? nseg : 0;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int va = __shfl_up(incl_all, d, 64), vm = __shfl_up(incl_multi, d, 64);
+      if (lane >= d) incl_all += va, incl_multi += vm;
+    }
+    const int tot_all = __shfl(incl_all, 63, 64), tot_multi = __shfl(incl_multi, 63, 64);
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    if (lane == 0) {
+      b0 = atomicAdd(&w.counters[0], __popcll(lmask));
+      b1 = atomicAdd(&w.counters[1], tot_all);
+      if (mmask != 0) {
+        b2 = atomicAdd(&w.counters[2], tot_multi);
+        b3 = atomicAdd(&w.counters[3], __popcll(mmask));
+      }
+    }
+    b0 = __shfl(b0, 0, 64), b1 = __shfl(b1, 0, 64), b2 = __shfl(b2, 0, 64), b3 = __shfl(b3, 0, 64);
+    if (listed) {
+      slot            = b0 + __popcll(lmask & below);
+      sbase           = b1 + incl_all - nseg;
+      const int pbase = is_multi ? b2 + incl_multi - nseg : -1;
+      w.runs[slot]    = tree_run{static_cast<int32_t>(u), beta1t, beta2t, pbase, seg_rows, nseg, {0, 0}};
+      if (is_multi) w.multi[b3 + __popcll(mmask & below)] = slot;
+    }
+  }
+  uint64_t pending = __ballot(slot >= 0);
+  while (pending) {   // wave-uniform
+    const int src   = __ffsll(static_cast<long long>(pending)) - 1;
+    const int r_sl  = __shfl(slot, src, 64);
+    const int r_sb  = __shfl(sbase, src, 64);
+    const int r_ns  = __shfl(nseg, src, 64);
+    for (int g = lane; g < r_ns; g += 64) w.segs[r_sb + g] = tree_seg{r_sl, g};
+    pending &= pending - 1;
+  }
+}
+
+// one segment per workgroup trip: thread t = (row slot t / LPR, 16-byte piece t % LPR); rows of a slot are added in order,
+// four loads in flight, the row slots meet in LDS in slot order
+template <typename IdxT, int OPT, typename T>
+__global__ __launch_bounds__(kBlock) void tree_fold_kernel(opt_params p, tree_ws_view w)
+{
+  constexpr int kVE = 16 / static_cast<int>(sizeof(T));
+  __shared__ float red[kBlock * kVE];
+  const wm_optimizer_args& a = p.a;
+  const IdxT* ids            = static_cast<const IdxT*>(a.ids);
+  const int n_seg            = w.counters[1];
+  const int pieces           = static_cast<int>(a.dim / kVE);          // 16-byte pieces per row (the launcher checks dim % kVE == 0)
+  int lpr                    = 1;
+  while (lpr < pieces && lpr < kBlock) lpr <<= 1;                       // pieces handled per pass, a power of two <= 256
+  const int slots            = kBlock / lpr;                            // row slots
+  const int c                = threadIdx.x & (lpr - 1);
+  const int rs               = threadIdx.x / lpr;
+  const int64_t dpad         = tree_dim_pad(a.dim);
+  for (int si = blockIdx.x; si < n_seg; si += gridDim.x) {
+    const tree_seg sg   = w.segs[si];
+    const tree_run ent  = w.runs[sg.run_slot];
+    const int64_t u     = ent.run;
+    const int32_t s0    = a.run_starts[u] + sg.seg * ent.seg_rows;
+    const int32_t rows  = min(ent.seg_rows, a.run_starts[u + 1] - s0);
+    const int64_t local = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
+    for (int pbase = 0; pbase < pieces; pbase += lpr) {
+      const int piece = pbase + c;
+      const bool live = piece < pieces;
+      float acc[kVE];
+#pragma unroll
+      for (int v = 0; v < kVE; v++) acc[v] = 0.f;
+      if (live) {
+        for (int r = rs; r < rows; r += 4 * slots) {
+          tile_raw4 g[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int rr = r + q * slots;
+            if (rr < rows) g[q] = ld_global_nt<tile_raw4>(grad_row<T>(a, a.order[s0 + rr]) + static_cast<int64_t>(piece) * kVE);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (r + q * slots < rows) {
+              const tile_vals<kVE> gv = tile_unpack<T>(g[q]);
+#pragma unroll
+              for (int v = 0; v < kVE; v++) acc[v] += gv.v[v];
+            }
+          }
+        }
+      }
+      __syncthreads();   // (the previous pass / segment has read red[])
+#pragma unroll
+      for (int v = 0; v < kVE; v++) red[threadIdx.x * kVE + v] = acc[v];
+      __syncthreads();
+      if (rs == 0 && live) {
+        float tot[kVE];
+#pragma unroll
+        for (int v = 0; v < kVE; v++) tot[v] = red[c * kVE + v];
+        for (int s = 1; s < slots; s++) {
+#pragma unroll
+          for (int v = 0; v < kVE; v++) tot[v] += red[(s * lpr + c) * kVE + v];
+        }
+        if (ent.pbase < 0) {   // the whole run: apply the optimizer here
+#pragma unroll
+          for (int v = 0; v < kVE; v++)
+            apply_optimizer<OPT, T>(a, local, static_cast<int64_t>(piece) * kVE + v, tot[v], ent.beta1t, ent.beta2t);
+        } else {
+          float* dst = w.partials + (static_cast<int64_t>(ent.pbase) + sg.seg) * dpad + static_cast<int64_t>(piece) * kVE;
+#pragma unroll
+          for (int v = 0; v < kVE; v++) dst[v] = tot[v];
+        }
+      }
+    }
+  }
+}
+
+// runs of several segments: the partial rows are added in segment order (8 loads in flight per thread), then the optimizer
+// statement. One workgroup per run, one column per thread.
+template <typename IdxT, int OPT, typename T>
+__global__ __launch_bounds__(kBlock) void tree_combine_kernel(opt_params p, tree_ws_view w)
+{
+  const wm_optimizer_args& a = p.a;
+  const IdxT* ids            = static_cast<const IdxT*>(a.ids);
+  const int n_multi          = w.counters[3];
+  const int64_t dpad         = tree_dim_pad(a.dim);
+  for (int mi = blockIdx.x; mi < n_multi; mi += gridDim.x) {
+    const tree_run ent = w.runs[w.multi[mi]];
+    const int64_t local = static_cast<int64_t>(ids[ent.run]) - a.local_entry_offset;
+    for (int64_t d = threadIdx.x; d < a.dim; d += kBlock) {
+      const float* src = w.partials + static_cast<int64_t>(ent.pbase) * dpad + d;
+      float acc        = src[0];
+      for (int g = 1; g < ent.nseg; g += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = g + q < ent.nseg ? src[static_cast<int64_t>(g + q) * dpad] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (g + q < ent.nseg) acc += v[q];
+      }
+      apply_optimizer<OPT, T>(a, local, d, acc, ent.beta1t, ent.beta2t);
+    }
+  }
+}
+
+inline int tree_threshold()
+{
+  const char* e = getenv("WM_GRAD_FOLD_MIN");
+  const int v   = e != nullptr ? atoi(e) : 0;
+  return v >= 4 && v <= kLongRun ? v : kTreeMin;
+}
+// ordered (0) or tree (1): WM_GRAD_FOLD overrides, then the caller's fold_mode, then the default of the value dtype
+inline int resolve_fold_mode(const wm_optimizer_args& a)
+{
+  const char* e = getenv("WM_GRAD_FOLD");
+  if (e != nullptr && (e[0] == 't' || e[0] == 'T')) return 1;
+  if (e != nullptr && (e[0] == 'o' || e[0] == 'O')) return 0;
+  if (a.fold_mode >= 0) return a.fold_mode;
+  return (a.value_dtype == WHOLEMEMORY_DT_HALF || a.value_dtype == WHOLEMEMORY_DT_BF16) ? 1 : 0;
+}
+
+template <typename IdxT, int OPT, typename T>
+void launch_tree(const opt_params& p, hipStream_t stream, hipStream_t lstream)
+{
+  const tree_ws_view w = tree_ws_carve(p.a.long_run_ws, p.a.count, p.long_threshold);
+  const int mblocks    = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, INT64_C(1) << 22));
+  hipLaunchKernelGGL((tree_mark_kernel<IdxT>), dim3(std::max(mblocks, 1)), dim3(256), 0, lstream, p, w, p.long_threshold);
+  if (lstream != stream) {
+    (void)hipEventRecord(long_lane::get().marked, lstream);
+    (void)hipStreamWaitEvent(stream, long_lane::get().marked, 0);
+  }
+  int fgrid = 2048;
+  if (const char* e = getenv("WM_TREE_GRID")) fgrid = std::max(1, atoi(e));
+  hipLaunchKernelGGL((tree_fold_kernel<IdxT, OPT, T>), dim3(fgrid), dim3(kBlock), 0, lstream, p, w);
+  hipLaunchKernelGGL((tree_combine_kernel<IdxT, OPT, T>), dim3(256), dim3(kBlock), 0, lstream, p, w);
+}
+
 // Launch shape of step_tile_kernel. Default: round 2's persistent grid of 8192 workgroups over tiles of 64 runs.
 // WM_TILE_INORDER=1: the in-order shape of the row kernels (rows.hip: rows_op) — one tile of ONE batch of runs per wave
 // (RPS x kU runs: 8 for SGD on 512-byte rows), as many workgroups as the upper bound of the run count takes (the true count is
@@ -1267,7 +1546,9 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
   const bool self_ok4  = p.a.self_grads == nullptr || p.a.self_grad_stride % 4 == 0;
   const bool vec2      = p.a.dim % 2 == 0 && p.a.grad_stride % 2 == 0 && gaddr % 8 == 0 && self_ok2;
   // the long runs first, on their own stream: they are listed, then folded while step_short_kernel does the rest
-  if (p.long_list != nullptr) {
+  if (p.long_list != nullptr && p.fold_tree) {
+    launch_tree<IdxT, OPT, float>(p, stream, lstream);
+  } else if (p.long_list != nullptr) {
     launch_mark_long_runs<IdxT>(p, stream, lstream);
     const int slices = static_cast<int>((p.a.dim + kSliceCols - 1) / kSliceCols);
     const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4;
@@ -1359,7 +1640,9 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream, hipStream_t 
   const bool rows16    = p.a.dim % 8 == 0 && p.a.grad_stride % 8 == 0 && sstr % 8 == 0 && gaddr % 16 == 0 &&
                       p.a.dim <= 65535 * kS;
   if (!rows16) p.long_list = nullptr;  // no LDS-DMA path for this shape: the wave-per-run kernel folds every run itself
-  if (p.long_list != nullptr) {
+  if (p.long_list != nullptr && p.fold_tree) {
+    launch_tree<IdxT, kOpt, T>(p, stream, lstream);
+  } else if (p.long_list != nullptr) {
     static const bool lds_ok =
       hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, kOpt, T>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLong4LdsBytes)) == hipSuccess;
@@ -1471,7 +1754,11 @@ int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, i
   return -1;
 }
 
-size_t hip_long_run_ws_bytes(int64_t n_recv) { return 16 + sizeof(long_run_entry) * static_cast<size_t>(n_recv / (kLongRun + 1) + 2); }
+size_t hip_long_run_ws_bytes(int64_t n_recv, int64_t dim)
+{   // the larger of the two layouts (the fold order is only resolved at the step: it may depend on the value dtype)
+  return std::max(16 + sizeof(long_run_entry) * static_cast<size_t>(n_recv / (kLongRun + 1) + 2),
+                  tree_ws_bytes(n_recv, dim, std::min(tree_threshold(), kTreeMin)));
+}
 
 // a->count is an UPPER BOUND for the launch geometry; the true run count is read on the device from
 // a->run_starts' companion scalar when `n_unique_dev` is non-null (ids == unique ids from hip_dedup_ids).
@@ -1480,17 +1767,29 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (a->count == 0) return 0;
   opt_params p{*a, n_unique_dev, nullptr, nullptr};
+  p.long_threshold = kLongRun;
   if (a->long_run_ws != nullptr && a->dim <= 65535 * kSliceCols) {
     // [int32 counter | pad to 16 B | entries]; at most count / (kLongRun + 1) long runs can exist
     p.long_count = static_cast<int32_t*>(a->long_run_ws);
     p.long_list  = reinterpret_cast<long_run_entry*>(static_cast<char*>(a->long_run_ws) + 16);
+    // tree fold: 16-byte pieces of the gradient rows on every side (else the ordered kernels take the call as before)
+    const bool f32     = a->value_dtype != WHOLEMEMORY_DT_HALF && a->value_dtype != WHOLEMEMORY_DT_BF16;
+    const int ve       = f32 ? 4 : 8;
+    const uint64_t ga  = reinterpret_cast<uint64_t>(a->grads) | reinterpret_cast<uint64_t>(a->self_grads);
+    const bool pieces  = a->dim % ve == 0 && a->grad_stride % ve == 0 && ga % 16 == 0 &&
+                        (a->self_grads == nullptr || a->self_grad_stride % ve == 0);
+    if (resolve_fold_mode(*a) == 1 && pieces && a->count < (INT64_C(1) << 31)) {
+      p.fold_tree      = 1;
+      p.long_threshold = tree_threshold();
+      p.long_list      = reinterpret_cast<long_run_entry*>(static_cast<char*>(a->long_run_ws) + 64);   // (non-null marker; the tree kernels carve the workspace themselves)
+    }
   }
   // the long-run side goes to its own stream (WM_STEP_SERIAL=1: everything on the caller's stream, for measurements)
   hipStream_t lstream = stream;
   static const bool serial = getenv("WM_STEP_SERIAL") != nullptr;
   std::unique_lock<std::mutex> lane_lock;
   if (p.long_list != nullptr && !serial) lane_lock = std::unique_lock<std::mutex>(long_lane::get().mu);
-  if (p.long_list != nullptr && hipMemsetAsync(p.long_count, 0, 16, stream) != hipSuccess) return -2;
+  if (p.long_list != nullptr && hipMemsetAsync(p.long_count, 0, p.fold_tree ? 64 : 16, stream) != hipSuccess) return -2;
   if (p.long_list != nullptr && !serial && long_lane::get().fork(stream)) lstream = long_lane::get().stream;
   int64_t waves = a->count;
   int max_blocks = 256 * 8;
