@@ -238,11 +238,17 @@ struct wm_device_backend {
   // cannot work from a device count returns -3 before queueing anything; the caller then passes the exact count.
   // phase 2 takes the same n_neighbor as phase 1 (the scratch layout depends on it) and the number of entries in use.
   size_t (*append_unique_workspace_bytes)(int n_target, int n_neighbor, wholememory_dtype_t dtype);
+  // publish_host (optional, PINNED host memory the device can write, 2 ints): the phase's last kernel leaves
+  // {neighbours in use, new unique ids} there, so that the caller learns both with a stream synchronise and no copy
+  // command (a D2H / D2D copy of 4 bytes is its own ~13 us entry in the GPU's queue)
   int (*append_unique_phase1)(const void* targets, int n_target, const void* neighbors, int n_neighbor,
                               const int* n_neighbor_dev, wholememory_dtype_t dtype, void* workspace, int* new_count_dev,
-                              void* stream);
+                              int* publish_host, void* stream);
+  // copy_src / copy_dst (optional): n_neighbor_used ints moved by the emitting kernel on the side (the fused hop's centre
+  // local ids, from their upper-bound scratch to the exactly sized output)
   int (*append_unique_phase2)(const void* targets, int n_target, int n_neighbor, int n_neighbor_used,
-                              wholememory_dtype_t dtype, void* workspace, void* out_unique, int* mapping, void* stream);
+                              wholememory_dtype_t dtype, void* workspace, void* out_unique, int* mapping,
+                              const int* copy_src, int* copy_dst, void* stream);
   int (*csr_add_self_loop)(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
   // out[i, c] = T(float(i)) + in[c] (wholememory_env_test_op)
   int (*env_test_fill)(const void* in, void* out, wholememory_dtype_t dtype, int64_t dim, int64_t entries, int64_t stride,

@@ -377,16 +377,15 @@ wholememory_error_code_t graph_append_unique(wholememory_tensor_t target_nodes_t
     (void)output_alloc(p_env_fns, output_unique_node_memory_context, 0, target_desc.dtype);
     return WHOLEMEMORY_SUCCESS;
   }
-  temp_mem ws_mem(p_env_fns), count_mem(p_env_fns);
-  void* ws       = ws_mem.device(static_cast<int64_t>(bk->append_unique_workspace_bytes(nt, nn, target_desc.dtype)), WHOLEMEMORY_DT_INT8);
-  int* count_dev = static_cast<int*>(count_mem.device(1, WHOLEMEMORY_DT_INT));
-  WM_BK(bk->append_unique_phase1(targets, nt, neighbors, nn, nullptr, target_desc.dtype, ws, count_dev, stream));
-  int new_count = 0;
-  WM_BK(bk->memcpy_async(&new_count, count_dev, sizeof(int), stream));
+  temp_mem ws_mem(p_env_fns), host_mem(p_env_fns);
+  void* ws  = ws_mem.device(static_cast<int64_t>(bk->append_unique_workspace_bytes(nt, nn, target_desc.dtype)), WHOLEMEMORY_DT_INT8);
+  int* host = static_cast<int*>(host_mem.pinned(2, WHOLEMEMORY_DT_INT));   // written by the phase's last kernel
+  WM_BK(bk->append_unique_phase1(targets, nt, neighbors, nn, nullptr, target_desc.dtype, ws, nullptr, host, stream));
   WM_BK(bk->stream_sync(stream));
+  const int new_count = host[1];
   void* out = output_alloc(p_env_fns, output_unique_node_memory_context, static_cast<int64_t>(nt) + new_count, target_desc.dtype);
   if (out == nullptr) return WHOLEMEMORY_OUT_OF_MEMORY;
-  WM_BK(bk->append_unique_phase2(targets, nt, nn, nn, target_desc.dtype, ws, out, mapping, stream));
+  WM_BK(bk->append_unique_phase2(targets, nt, nn, nn, target_desc.dtype, ws, out, mapping, nullptr, nullptr, stream));
   if (!async_completion_enabled() || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));  // (reference append_unique_func.cuh:351)
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
@@ -447,15 +446,15 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
 
   const int nt = static_cast<int>(n), nn_room = static_cast<int>(room);
   temp_mem counts_mem(p_env_fns), scan_mem(p_env_fns), ids_mem(p_env_fns), lid_mem(p_env_fns), ws_mem(p_env_fns),
-    count_mem(p_env_fns), host_mem(p_env_fns);
+    host_mem(p_env_fns);
   int* counts          = static_cast<int*>(counts_mem.device(n + 1, WHOLEMEMORY_DT_INT));
   const size_t scan_ws = bk->scan_i32_workspace_bytes(n + 1);
   void* scan_ws_ptr    = scan_mem.device(static_cast<int64_t>(scan_ws), WHOLEMEMORY_DT_INT8);
   void* ids            = ids_mem.device(room, col_desc.dtype);
   int* lid             = static_cast<int*>(lid_mem.device(room, WHOLEMEMORY_DT_INT));
   void* ws = ws_mem.device(static_cast<int64_t>(bk->append_unique_workspace_bytes(nt, nn_room, center_desc.dtype)), WHOLEMEMORY_DT_INT8);
-  int* count_dev = static_cast<int*>(count_mem.device(1, WHOLEMEMORY_DT_INT));
-  int* host      = static_cast<int*>(host_mem.pinned(2, WHOLEMEMORY_DT_INT));
+  // {samples, new unique ids}: left in pinned memory by the last kernel before the host looks (no copy commands)
+  int* host = static_cast<int*>(host_mem.pinned(2, WHOLEMEMORY_DT_INT));
 
   WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, a.n_center, max_sample_count,
                           counts, stream));
@@ -463,7 +462,7 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
   a.out_ids        = ids;
   a.out_center_lid = lid;
   WM_BK(bk->sample_unweighted(&a, stream));   // writes exactly offsets[n] entries of the scratch arrays
-  int rc = bk->append_unique_phase1(a.centers, nt, ids, nn_room, offsets + n, center_desc.dtype, ws, count_dev, stream);
+  int rc = bk->append_unique_phase1(a.centers, nt, ids, nn_room, offsets + n, center_desc.dtype, ws, nullptr, host, stream);
   int total = 0, n_new = 0;
   if (rc == -3) {
     // a frontier too big for the route that works from a device-side count: learn the sample count first
@@ -472,30 +471,25 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
     total = host[0];
     temp_mem ws2_mem(p_env_fns);
     void* ws2 = ws2_mem.device(static_cast<int64_t>(bk->append_unique_workspace_bytes(nt, total, center_desc.dtype)), WHOLEMEMORY_DT_INT8);
-    WM_BK(bk->append_unique_phase1(a.centers, nt, ids, total, nullptr, center_desc.dtype, ws2, count_dev, stream));
-    WM_BK(bk->memcpy_async(host + 1, count_dev, sizeof(int), stream));
+    WM_BK(bk->append_unique_phase1(a.centers, nt, ids, total, nullptr, center_desc.dtype, ws2, nullptr, host, stream));
     WM_BK(bk->stream_sync(stream));
     n_new = host[1];
     void* uniq = output_alloc(p_env_fns, output_unique_memory_context, static_cast<int64_t>(nt) + n_new, center_desc.dtype);
     int* pos   = static_cast<int*>(output_alloc(p_env_fns, output_neighbor_pos_memory_context, total, WHOLEMEMORY_DT_INT));
     int* olid  = static_cast<int*>(output_alloc(p_env_fns, output_center_localid_memory_context, total, WHOLEMEMORY_DT_INT));
     if (uniq == nullptr || (total > 0 && (pos == nullptr || olid == nullptr))) return WHOLEMEMORY_OUT_OF_MEMORY;
-    WM_BK(bk->append_unique_phase2(a.centers, nt, total, total, center_desc.dtype, ws2, uniq, pos, stream));
-    if (total > 0) WM_BK(bk->memcpy_async(olid, lid, sizeof(int) * static_cast<size_t>(total), stream));
+    WM_BK(bk->append_unique_phase2(a.centers, nt, total, total, center_desc.dtype, ws2, uniq, pos, lid, olid, stream));
     WM_BK(bk->stream_sync(stream));   // ws2 goes out of scope here
     return WHOLEMEMORY_SUCCESS;
   }
   if (rc != 0) return rc == -1 ? WHOLEMEMORY_LOGIC_ERROR : WHOLEMEMORY_CUDA_ERROR;
-  WM_BK(bk->memcpy_async(host, offsets + n, sizeof(int), stream));
-  WM_BK(bk->memcpy_async(host + 1, count_dev, sizeof(int), stream));
   WM_BK(bk->stream_sync(stream));             // the only host round trip of the hop
   total = host[0], n_new = host[1];
   void* uniq = output_alloc(p_env_fns, output_unique_memory_context, static_cast<int64_t>(nt) + n_new, center_desc.dtype);
   int* pos   = static_cast<int*>(output_alloc(p_env_fns, output_neighbor_pos_memory_context, total, WHOLEMEMORY_DT_INT));
   int* olid  = static_cast<int*>(output_alloc(p_env_fns, output_center_localid_memory_context, total, WHOLEMEMORY_DT_INT));
   if (uniq == nullptr || (total > 0 && (pos == nullptr || olid == nullptr))) return WHOLEMEMORY_OUT_OF_MEMORY;
-  WM_BK(bk->append_unique_phase2(a.centers, nt, nn_room, total, center_desc.dtype, ws, uniq, pos, stream));
-  if (total > 0) WM_BK(bk->memcpy_async(olid, lid, sizeof(int) * static_cast<size_t>(total), stream));
+  WM_BK(bk->append_unique_phase2(a.centers, nt, nn_room, total, center_desc.dtype, ws, uniq, pos, lid, olid, stream));
   if (!async_completion_enabled() || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));   // else: outputs and scratch are ordered on `stream`
   return WHOLEMEMORY_SUCCESS;
   WM_API_END

@@ -37,9 +37,9 @@ int hip_sample_unweighted(const wm_sample_args* a, void* stream);
 int hip_sample_weighted(const wm_sample_args* a, void* stream);
 size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt);
 int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, const int* nn_dev,
-                             wholememory_dtype_t dt, void* ws, int* new_count_dev, void* stream);
+                             wholememory_dtype_t dt, void* ws, int* new_count_dev, int* publish_host, void* stream);
 int hip_append_unique_phase2(const void* targets, int nt, int nn, int nn_used, wholememory_dtype_t dt, void* ws,
-                             void* out_unique, int* mapping, void* stream);
+                             void* out_unique, int* mapping, const int* copy_src, int* copy_dst, void* stream);
 int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
 
 int hip_env_test_fill(const void* in, void* out, wholememory_dtype_t dt, int64_t dim, int64_t entries, int64_t stride, void* stream);

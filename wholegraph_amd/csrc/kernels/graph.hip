@@ -504,12 +504,28 @@ __global__ __launch_bounds__(kBlock) void au_flag_kernel(const uint32_t* min_pos
   first_flag[p] = p < used && min_pos[slot_of[nt + p]] == static_cast<uint32_t>(nt + p) ? 1 : 0;
 }
 
+// one new-count word written where the caller wants it (device and / or pinned host memory): replaces 4-byte copy commands
+__global__ void au_publish_kernel(const int* new_rank_end, const int* nn_dev, int nn, int* new_count_dev, int* publish_host)
+{
+  const int c = *new_rank_end;
+  if (new_count_dev != nullptr) *new_count_dev = c;
+  if (publish_host != nullptr) {
+    publish_host[0] = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+    publish_host[1] = c;
+  }
+}
+
+// (the grid covers max(nt, nn): the same launch copies the targets to the head of the output and, for the fused hop, the
+// centre local ids from their scratch to the exactly sized output — both were copy commands of their own)
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, const uint32_t* min_pos, const uint32_t* slot_of,
-                                                         const int* new_rank, int nt, int nn, KeyT* out_unique, int* mapping)
+                                                         const int* new_rank, int nt, int nn, KeyT* out_unique, int* mapping,
+                                                         const KeyT* targets, const int* copy_src, int* copy_dst)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < nt) out_unique[p] = targets[p];
   if (p >= nn) return;
+  if (copy_dst != nullptr) copy_dst[p] = copy_src[p];
   const uint32_t s = slot_of[nt + p];
   const int m      = static_cast<int>(min_pos[s]);
   const int uid    = m < nt ? m : nt + new_rank[m - nt];
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, cons
 
 template <typename KeyT>
 int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const int* nn_dev, void* ws, int* new_count_dev,
-              hipStream_t stream)
+              int* publish_host, hipStream_t stream)
 {
   using UKey  = typename std::make_unsigned<KeyT>::type;
   auto l      = au_plan<UKey>(ws, nt, nn);
@@ -536,19 +552,21 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
                               stream) != hipSuccess)
     return -2;
   // new_rank[nn] = number of new unique neighbours
-  if (hipMemcpyAsync(new_count_dev, l.new_rank + nn, sizeof(int), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -2;
+  hipLaunchKernelGGL(au_publish_kernel, dim3(1), dim3(1), 0, stream, l.new_rank + nn, nn_dev, nn, new_count_dev, publish_host);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <typename KeyT>
-int au_phase2(const void* targets, int nt, int nn, int nn_used, void* ws, void* out_unique, int* mapping, hipStream_t stream)
+int au_phase2(const void* targets, int nt, int nn, int nn_used, void* ws, void* out_unique, int* mapping, const int* copy_src,
+              int* copy_dst, hipStream_t stream)
 {
-  using UKey = typename std::make_unsigned<KeyT>::type;
-  auto l     = au_plan<UKey>(ws, nt, nn);   // the layout phase 1 used
-  if (nt > 0 && hipMemcpyAsync(out_unique, targets, sizeof(KeyT) * nt, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -2;
-  if (nn_used > 0)
-    hipLaunchKernelGGL((au_emit_kernel<UKey>), dim3((nn_used + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.slots, l.min_pos,
-                       l.slot_of, l.new_rank, nt, nn_used, static_cast<UKey*>(out_unique), mapping);
+  using UKey  = typename std::make_unsigned<KeyT>::type;
+  auto l      = au_plan<UKey>(ws, nt, nn);   // the layout phase 1 used
+  const int g = std::max(nt, nn_used);
+  if (g > 0)
+    hipLaunchKernelGGL((au_emit_kernel<UKey>), dim3((g + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.slots, l.min_pos,
+                       l.slot_of, l.new_rank, nt, nn_used, static_cast<UKey*>(out_unique), mapping,
+                       static_cast<const UKey*>(targets), copy_src, copy_dst);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -641,7 +659,8 @@ aus_layout<KeyT> aus_plan(void* ws, int nt, int nn)
 }
 
 template <typename KeyT>
-int aus_phase1(const void* targets, int nt, const void* neighbors, int nn, void* ws, int* new_count_dev, hipStream_t stream)
+int aus_phase1(const void* targets, int nt, const void* neighbors, int nn, void* ws, int* new_count_dev, int* publish_host,
+               hipStream_t stream)
 {
   using UKey     = typename std::make_unsigned<KeyT>::type;
   auto l         = aus_plan<UKey>(ws, nt, nn);
@@ -663,13 +682,18 @@ int aus_phase1(const void* targets, int nt, const void* neighbors, int nn, void*
                               stream) != hipSuccess)
     return -2;
   // new_rank[nn] = number of new unique neighbours
-  if (hipMemcpyAsync(new_count_dev, l.new_rank + nn, sizeof(int), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -2;
+  hipLaunchKernelGGL(au_publish_kernel, dim3(1), dim3(1), 0, stream, l.new_rank + nn, static_cast<const int*>(nullptr), nn,
+                     new_count_dev, publish_host);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <typename KeyT>
-int aus_phase2(const void* targets, int nt, int nn, void* ws, void* out_unique, int* mapping, hipStream_t stream)
+int aus_phase2(const void* targets, int nt, int nn, void* ws, void* out_unique, int* mapping, const int* copy_src, int* copy_dst,
+               hipStream_t stream)
 {
+  if (copy_dst != nullptr && nn > 0 &&
+      hipMemcpyAsync(copy_dst, copy_src, sizeof(int) * static_cast<size_t>(nn), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+    return -2;
   using UKey     = typename std::make_unsigned<KeyT>::type;
   auto l         = aus_plan<UKey>(ws, nt, nn);
   const int n    = nt + nn;
@@ -839,31 +863,31 @@ size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt)
   return dt == WHOLEMEMORY_DT_INT ? aus_plan<uint32_t>(nullptr, nt, nn).total : aus_plan<uint64_t>(nullptr, nt, nn).total;
 }
 int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, const int* nn_dev,
-                             wholememory_dtype_t dt, void* ws, int* new_count_dev, void* stream_v)
+                             wholememory_dtype_t dt, void* ws, int* new_count_dev, int* publish_host, void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const bool table   = au_use_table(nt, nn, dt);
   if (!table && nn_dev != nullptr) return -3;   // the sort route needs the exact count on the host
   if (dt == WHOLEMEMORY_DT_INT)
-    return table ? au_phase1<int32_t>(targets, nt, neighbors, nn, nn_dev, ws, new_count_dev, stream)
-                 : aus_phase1<int32_t>(targets, nt, neighbors, nn, ws, new_count_dev, stream);
+    return table ? au_phase1<int32_t>(targets, nt, neighbors, nn, nn_dev, ws, new_count_dev, publish_host, stream)
+                 : aus_phase1<int32_t>(targets, nt, neighbors, nn, ws, new_count_dev, publish_host, stream);
   if (dt == WHOLEMEMORY_DT_INT64)
-    return table ? au_phase1<int64_t>(targets, nt, neighbors, nn, nn_dev, ws, new_count_dev, stream)
-                 : aus_phase1<int64_t>(targets, nt, neighbors, nn, ws, new_count_dev, stream);
+    return table ? au_phase1<int64_t>(targets, nt, neighbors, nn, nn_dev, ws, new_count_dev, publish_host, stream)
+                 : aus_phase1<int64_t>(targets, nt, neighbors, nn, ws, new_count_dev, publish_host, stream);
   return -1;
 }
 int hip_append_unique_phase2(const void* targets, int nt, int nn, int nn_used, wholememory_dtype_t dt, void* ws,
-                             void* out_unique, int* mapping, void* stream_v)
+                             void* out_unique, int* mapping, const int* copy_src, int* copy_dst, void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const bool table   = au_use_table(nt, nn, dt);
   if (!table && nn_used != nn) return -3;
   if (dt == WHOLEMEMORY_DT_INT)
-    return table ? au_phase2<int32_t>(targets, nt, nn, nn_used, ws, out_unique, mapping, stream)
-                 : aus_phase2<int32_t>(targets, nt, nn, ws, out_unique, mapping, stream);
+    return table ? au_phase2<int32_t>(targets, nt, nn, nn_used, ws, out_unique, mapping, copy_src, copy_dst, stream)
+                 : aus_phase2<int32_t>(targets, nt, nn, ws, out_unique, mapping, copy_src, copy_dst, stream);
   if (dt == WHOLEMEMORY_DT_INT64)
-    return table ? au_phase2<int64_t>(targets, nt, nn, nn_used, ws, out_unique, mapping, stream)
-                 : aus_phase2<int64_t>(targets, nt, nn, ws, out_unique, mapping, stream);
+    return table ? au_phase2<int64_t>(targets, nt, nn, nn_used, ws, out_unique, mapping, copy_src, copy_dst, stream)
+                 : aus_phase2<int64_t>(targets, nt, nn, ws, out_unique, mapping, copy_src, copy_dst, stream);
   return -1;
 }
 int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream)
