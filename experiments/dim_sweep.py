@@ -33,8 +33,8 @@ def main():
             args.append(x)
     if args:
         cases = [(torch.float32, int(x)) for x in args]
-    knobs = ("WM_ROWS_FLAT", "WM_ROWS_TILE", "WM_ROWS_STAGED", "WM_ROWS_INORDER", "WM_ROWS_BLOCK", "WM_ROWS_BATCH")
-    settings = [("default", {}), ("inorder=0", {"WM_ROWS_INORDER": "0"}), ("block=64", {"WM_ROWS_BLOCK": "64"}), ("batch=0", {"WM_ROWS_BATCH": "0"}), ("inorder=1", {"WM_ROWS_INORDER": "1"}),
+    knobs = ("WM_ROWS_FLAT", "WM_ROWS_TILE", "WM_ROWS_STAGED", "WM_ROWS_INORDER", "WM_ROWS_BLOCK", "WM_ROWS_BATCH", "WM_ROWS_PIECES", "WM_ROWS_LDS")
+    settings = [("default", {}), ("inorder=0", {"WM_ROWS_INORDER": "0"}), ("block=64", {"WM_ROWS_BLOCK": "64"}), ("batch=0", {"WM_ROWS_BATCH": "0"}), ("pieces=1", {"WM_ROWS_PIECES": "1"}), ("lds=6.6k", {"WM_ROWS_LDS": "6800"}), ("lds=10k", {"WM_ROWS_LDS": "10240"}), ("lds=20k", {"WM_ROWS_LDS": "20480"}), ("pieces+nostage", {"WM_ROWS_PIECES": "1", "WM_ROWS_STAGED": "0"}), ("inorder=1", {"WM_ROWS_INORDER": "1"}),
                 ("flat=0", {"WM_ROWS_FLAT": "0"}), ("flat=1", {"WM_ROWS_FLAT": "1"}),
                 ("staged=0", {"WM_ROWS_STAGED": "0"})] if ab else [("default", {})]
     if ab and os.environ.get("DIM_SWEEP_SETTINGS"):   # e.g. "default,inorder=0"

@@ -98,6 +98,8 @@ struct rows_params {
   int launch_threads;
   // host side only: 32 / 64 / 128 / 256 = this launch takes rows_batch_kernel<..., that many 16-byte pieces per row>
   int batch_vecs;
+  // 1 = rows_pieces_kernel: flat_slots counts the WHOLE 16-byte pieces only and flat_tail (0 / 4 / 8 / 12) the bytes after them
+  int pieces;
 };
 
 // byte address of the first moved element of table row `idx`
@@ -307,8 +309,11 @@ __global__ __launch_bounds__(kBlock) void rows_copy16_fast_kernel(rows_params p)
 // column test — and the wave is done; the dispatcher hands the next tile to whichever wave slot frees up first, in order.
 // (experiments/placement_pmc.hip: rows_inorder<8, 256> is this kernel for 512 B rows; against the generic fast kernel run
 // with 8-row tiles it is worth another 2-3 % on the 10 M-row gather.)
+// At most 6 waves per SIMD: with 24 instead of 32 waves per CU the window of tiles in flight is a quarter narrower and the
+// kernel a little faster on every shape (interleaved in one process, profiles/r03_dim_sweep_occupancy.csv: gather 74.8 -> 75.5 %
+// of peak at 512 B, 74.4 -> 75.8 % at 1 KiB, 74.5 -> 75.8 % at 4 KiB; 16 waves per CU: 71-76 %, 8: 45-57 %).
 template <typename IdxT, bool GATHER, int ROW_VECS, bool HAS_MAP>
-__global__ __launch_bounds__(kBlock) void rows_batch_kernel(rows_params p)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 6))) void rows_batch_kernel(rows_params p)
 {
   constexpr int kSteps  = 4;                                        // 4 x 1 KiB
   constexpr int RPS     = ROW_VECS == 32 ? 2 : 1;                   // rows per wave instruction
@@ -430,6 +435,67 @@ __global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
         }
       }
     }
+  }
+}
+
+// The in-order shape for rows that are NOT 512 B / 1 / 2 / 4 KiB: a row = `full` whole 16-byte pieces + a tail of 0 / 4 / 8 /
+// 12 bytes. One tile per wave: R rows whose R x full pieces fill up to kPiecesBatches batches of 4 x 64 lanes (piece v of
+// the tile = row v / full, piece v % full; all loads of a batch, then all its stores); the tails are one more, dword-wide
+// step with lane l serving row l. Against rows_flat_kernel (which carries the tail inside its slot loop as a per-lane
+// special case and needs 100-104 VGPRs = 4 waves per SIMD) this one has no per-slot branches and fits 8 waves.
+// Addresses on the dense side may be only 4-byte aligned (516 B rows): 16-byte accesses at such addresses are legal on
+// gfx950 global memory.
+template <typename IdxT, bool GATHER, bool HAS_MAP>
+__global__ __launch_bounds__(kBlock) void rows_pieces_kernel(rows_params p)
+{
+  constexpr int kSteps = 4;
+  const int lane       = threadIdx.x & (kWave - 1);
+  const int64_t tile   = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int R          = p.tile_rows;
+  if (tile * R >= p.n) return;
+  const int full    = p.flat_slots;   // whole 16-byte pieces per row (here: WITHOUT the tail)
+  const int n_slots = R * full;
+  char *my_tab, *my_plain;
+  load_tile_entry<IdxT>(p, lane < R ? tile * R + lane : p.n, my_tab, my_plain);
+  char* const plain_tile = p.plain + tile * R * p.plain_stride_bytes;
+#pragma unroll 1
+  for (int v0 = 0; v0 < n_slots; v0 += kWave * kSteps) {
+    u32x4 data[kSteps];
+    char* dst[kSteps];
+#pragma unroll
+    for (int u = 0; u < kSteps; u++) {
+      const int v = v0 + u * kWave + lane;
+      int row     = static_cast<int>(static_cast<float>(v) * p.flat_rcp);  // v / full, fixed up below
+      int col     = v - row * full;
+      if (col < 0) row--, col += full;
+      if (col >= full) row++, col -= full;
+      char* t         = shfl_ptr(my_tab, row & (kWave - 1));
+      char* q         = HAS_MAP ? shfl_ptr(my_plain, row & (kWave - 1)) : plain_tile + row * p.plain_stride_bytes;
+      const bool ok   = v < n_slots && t != nullptr;  // entries past n and negative ids carry a null base
+      const char* src = (GATHER ? t : q) + col * 16;
+      dst[u]          = ok ? (GATHER ? q : t) + col * 16 : nullptr;
+      if (ok) {
+        if constexpr (GATHER)
+          data[u] = ld_global<u32x4>(src);   // table rows that do not fill their last line share it with the next piece
+        else
+          data[u] = ld_global_nt<u32x4>(src);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSteps; u++)
+      if (dst[u] != nullptr) st_global_nt<u32x4>(dst[u], data[u]);
+  }
+  if (p.flat_tail > 0 && my_tab != nullptr) {   // lane l < R: the tail dwords of its own row
+    char* q         = HAS_MAP ? my_plain : plain_tile + lane * p.plain_stride_bytes;
+    const char* src = (GATHER ? my_tab : q) + full * 16;
+    char* d         = (GATHER ? q : my_tab) + full * 16;
+    uint32_t w[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      if (4 * k < p.flat_tail) w[k] = ld_global<uint32_t>(src + 4 * k);
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      if (4 * k < p.flat_tail) st_global<uint32_t>(d + 4 * k, w[k]);
   }
 }
 
@@ -616,7 +682,10 @@ template <typename K>
 inline void launch_rows_kernel(K kernel, int blocks, hipStream_t stream, const rows_params& p)
 {
   t_last_rows_kernel = reinterpret_cast<const void*>(kernel);
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(p.launch_threads), 0, stream, p);
+  // WM_ROWS_LDS=bytes (experiments): dynamic LDS nobody uses, to cap the workgroups resident per CU
+  const char* le   = getenv("WM_ROWS_LDS");
+  const size_t lds = le != nullptr ? static_cast<size_t>(atoi(le)) : 0;
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(p.launch_threads), lds, stream, p);
 }
 
 inline int ilog2_ceil(int x)
@@ -663,6 +732,19 @@ int inorder_block_threads()
   return (v == 64 || v == 128 || v == 256) ? v : 256;
 }
 
+// rows_pieces_kernel for the shapes the flat-stream kernel serves? WM_ROWS_PIECES=0 never, 1 always, unset: the measured rule
+bool pieces_wanted(bool gather, int64_t row_bytes)
+{
+  const char* e = getenv("WM_ROWS_PIECES");
+  if (e != nullptr && e[0] != '\0') return e[0] != '0';
+  // Measured (profiles/r03_dim_sweep_pieces.csv, interleaved with the flat kernel in one process): gathers lose 6-12 points
+  // on every shape (400 B ... 4120 B); scatters win at 1032 B (+4), 1544 B (+1) and 2408 B (+6) and lose at 400 B (-2), 516 B
+  // (-1), 1200 B (-1.5) and 4120 B (-3.5). No rule worth shipping came out of that: the kernel stays opt-in.
+  (void)gather;
+  (void)row_bytes;
+  return false;
+}
+
 // 0 = never, 1 = always when legal, -1 (default) = by the measured rule in want_flat()
 int flat_override()
 {
@@ -698,6 +780,13 @@ bool want_flat(bool gather, int vb, int64_t row_bytes)
 template <typename IdxT, bool GATHER>
 void launch_flat(const rows_params& p, int blocks, hipStream_t stream)
 {
+  if (p.pieces) {
+    if (p.row_map != nullptr)
+      launch_rows_kernel(rows_pieces_kernel<IdxT, GATHER, true>, blocks, stream, p);
+    else
+      launch_rows_kernel(rows_pieces_kernel<IdxT, GATHER, false>, blocks, stream, p);
+    return;
+  }
   if (p.row_map != nullptr)
     launch_rows_kernel(rows_flat_kernel<IdxT, GATHER, true>, blocks, stream, p);
   else
@@ -925,6 +1014,16 @@ int rows_op(const wm_rows_args* a, void* stream_v)
         p.tile_rows = inorder ? R : kWave;   // in order: one chunk (<= 5 KiB) per wave
         blocks      = grid_for(p.tile_rows);
       }
+    }
+    // rows_pieces_kernel instead of the flat-stream kernel (in-order launches only; WM_ROWS_PIECES=0 / 1 forces)
+    if (p.stage_rows == 0 && p.flat_slots > 0 && a->max_blocks <= 0 && inorder_mode != 0 && row_bytes >= 16 &&
+        pieces_wanted(GATHER, row_bytes)) {
+      p.pieces         = 1;
+      p.flat_slots     = static_cast<int>(row_bytes / 16);
+      p.flat_tail      = static_cast<int>(row_bytes % 16);
+      p.flat_rcp       = 1.0f / static_cast<float>(p.flat_slots);
+      inorder          = true;
+      p.launch_threads = inorder_block_threads();
     }
     if (p.stage_rows == 0 && (p.flat_slots > 0 || (vb == 16 && p.row_vecs >= 32))) {  // the two kernels that take tile_rows
       const char* te    = getenv("WM_ROWS_TILE");  // experiment switch
