@@ -227,6 +227,11 @@ struct wm_device_backend {
                        const void* centers, wholememory_dtype_t center_dtype, int n, int max_sample, int* counts, void* stream);
   // ids[2i] = center i, ids[2i + 1] = center i + 1
   int (*sample_pair_ids)(const void* centers, wholememory_dtype_t center_dtype, int n, int64_t* ids, void* stream);
+  // sample_counts + exclusive scan in one pass (mapped CSR only): offsets[0 .. n]; workspace of scan_i32_workspace_bytes(n + 1).
+  // Optional: nullptr = run the two steps
+  int (*sample_offsets)(const wholememory_gref_t* row_gref, int64_t row_storage_offset, const void* centers,
+                        wholememory_dtype_t center_dtype, int n_center, int max_sample_count, int* offsets, void* workspace,
+                        size_t workspace_bytes, void* stream);
   size_t (*scan_i32_workspace_bytes)(int64_t n);
   int (*exclusive_scan_i32)(const int* in, int* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
   int (*sample_unweighted)(const wm_sample_args* a, void* stream);

@@ -456,9 +456,16 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
   // {samples, new unique ids}: left in pinned memory by the last kernel before the host looks (no copy commands)
   int* host = static_cast<int*>(host_mem.pinned(2, WHOLEMEMORY_DT_INT));
 
-  WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, a.n_center, max_sample_count,
-                          counts, stream));
-  WM_BK(bk->exclusive_scan_i32(counts, offsets, n + 1, scan_ws_ptr, scan_ws, stream));
+  // (sample_offsets — the counts computed inside the scan's input iterator — exists and is bit-identical, but the look-back
+  // scan with random row_ptr loads per element is slower than count kernel + plain scan: 8-19 us against 4 + 6; WM_SAMPLE_FUSED_SCAN=1)
+  if (bk->sample_offsets != nullptr && getenv("WM_SAMPLE_FUSED_SCAN") != nullptr) {
+    WM_BK(bk->sample_offsets(&a.row_gref, a.row_storage_offset, a.centers, a.center_dtype, a.n_center, max_sample_count, offsets,
+                             scan_ws_ptr, scan_ws, stream));
+  } else {
+    WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, a.n_center, max_sample_count,
+                            counts, stream));
+    WM_BK(bk->exclusive_scan_i32(counts, offsets, n + 1, scan_ws_ptr, scan_ws, stream));
+  }
   a.out_ids        = ids;
   a.out_center_lid = lid;
   WM_BK(bk->sample_unweighted(&a, stream));   // writes exactly offsets[n] entries of the scratch arrays

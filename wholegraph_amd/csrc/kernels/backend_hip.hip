@@ -33,6 +33,8 @@ int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const
 int hip_sample_pair_ids(const void* centers, wholememory_dtype_t id_dtype, int n, int64_t* ids, void* stream);
 size_t hip_scan_i32_ws_bytes(int64_t n);
 int hip_exclusive_scan_i32(const int* in, int* out, int64_t n, void* ws, size_t ws_bytes, void* stream);
+int hip_sample_offsets(const wholememory_gref_t* row_gref, int64_t row_off, const void* centers, wholememory_dtype_t id_dtype,
+                       int n, int max_sample, int* offsets, void* ws, size_t ws_bytes, void* stream);
 int hip_sample_unweighted(const wm_sample_args* a, void* stream);
 int hip_sample_weighted(const wm_sample_args* a, void* stream);
 size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt);
@@ -159,6 +161,7 @@ const wm_device_backend kHipBackend = {
   hip_sorted_owner_counts,
   hip_sample_counts,
   hip_sample_pair_ids,
+  hip_sample_offsets,
   hip_scan_i32_ws_bytes,
   hip_exclusive_scan_i32,
   hip_sample_unweighted,

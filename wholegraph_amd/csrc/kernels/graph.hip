@@ -222,6 +222,66 @@ __global__ __launch_bounds__(kBlock) void sample_sparse_kernel(sample_params p)
   }
 }
 
+// The same recurrence for max_sample <= 64 (the fan-outs GNN samplers use: 5 ... 30) with NOTHING in LDS: lane i holds draw
+// r[i], sampled position a[i] and entry i of the sparse image of Q (position, value) in registers; a lookup is one ballot
+// and one v_readlane, an update one predicated move. The LDS version pays two LDS round trips, a fence and a wave barrier
+// per step of the sequential recurrence (~70 us for the 24 k centres of a papers100M-shaped second hop).
+template <typename IdT, typename ColT>
+__global__ __launch_bounds__(kBlock) void sample_small_kernel(sample_params p)
+{
+  const int M      = p.max_sample;   // 1 ... 64
+  const int lane   = threadIdx.x & 63;
+  const int center = blockIdx.x * kWavesPerBlk + (threadIdx.x >> 6);
+  if (center >= p.n_center) return;
+  ColT* out = static_cast<ColT*>(p.out_ids);
+  int64_t s, e;
+  row_bounds<IdT>(p, center, &s, &e);
+  const int N = static_cast<int>(e - s);
+  if (N <= 0) return;
+  const int off = p.offsets[center];
+  if (N <= M) {  // every neighbour
+    for (int i = lane; i < N; i += 64) {
+      if (out) out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
+      if (p.out_lid) p.out_lid[off + i] = center;
+      if (p.out_egid) p.out_egid[off + i] = s + i;
+    }
+    return;
+  }
+  // draw i belongs to virtual thread j = i % T (stream center * T + j), its (i / T)-th draw — as in sample_sparse_kernel
+  const sample_geometry g = sample_geometry_for(M);
+  int my_r = 0;
+  if (lane < M) {
+    const int j = lane % g.threads, k = lane / g.threads;
+    pcg32 rng(p.seed, 0, static_cast<uint64_t>(center) * g.threads + j);
+    int32_t v = 0;
+    for (int q = 0; q <= k; q++) v = rng.next_i32();
+    my_r = v % (N - lane);
+  }
+  int q_pos = -1, q_val = 0, my_a = 0;   // entry `lane` of the sparse list; lanes >= cnt hold no entry
+  int cnt = 0;                           // wave-uniform
+  for (int i = 0; i < M; i++) {
+    const int x = __builtin_amdgcn_readlane(my_r, i);
+    const int y = N - 1 - i;
+    const uint64_t mx = __ballot(lane < cnt && q_pos == x);
+    const uint64_t my = __ballot(lane < cnt && q_pos == y);
+    const int ix      = mx ? __ffsll(static_cast<long long>(mx)) - 1 : -1;
+    const int vx      = mx ? __builtin_amdgcn_readlane(q_val, ix) : x;
+    const int vy      = my ? __builtin_amdgcn_readlane(q_val, __ffsll(static_cast<long long>(my)) - 1) : y;
+    if (lane == i) my_a = vx;
+    if (ix >= 0) {
+      if (lane == ix) q_val = vy;
+    } else {
+      if (lane == cnt) q_pos = x, q_val = vy;
+      cnt++;
+    }
+  }
+  if (lane < M) {
+    if (out) out[off + lane] = gref_load<ColT>(p.col_ptr, p.col_off + s + my_a);
+    if (p.out_lid) p.out_lid[off + lane] = center;
+    if (p.out_egid) p.out_egid[off + lane] = s + my_a;
+  }
+}
+
 // M > 1024 (reference large_sample_kernel :62-130): reservoir of M slots; candidate idx >= M replaces slot
 // rand % (idx + 1) when that is < M, the LARGEST idx wins a slot. 32 virtual threads per center node (streams
 // center*32 + t), thread t visits idx = M + t, M + t + 32, ... with consecutive draws. One wave per center node,
@@ -274,6 +334,9 @@ int launch_sample(const sample_params& p, hipStream_t stream)
   if (p.n_center == 0) return 0;
   if (p.max_sample > kMaxSparse) {
     hipLaunchKernelGGL((sample_large_kernel<IdT, ColT>), dim3(p.n_center), dim3(64), 0, stream, p);
+  } else if (p.max_sample >= 1 && p.max_sample <= 64 && getenv("WM_SAMPLE_LDS") == nullptr) {
+    const int blocks = (p.n_center + kWavesPerBlk - 1) / kWavesPerBlk;
+    hipLaunchKernelGGL((sample_small_kernel<IdT, ColT>), dim3(blocks), dim3(kBlock), 0, stream, p);
   } else {
     const int M       = std::max(p.max_sample, 1);
     const size_t lds  = static_cast<size_t>(kWavesPerBlk) * 4 * M * sizeof(int);
@@ -478,6 +541,28 @@ __global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, 
   if (i >= nt + nn) return;
   constexpr KeyT kEmpty = ~static_cast<KeyT>(0);
   const KeyT key        = i < nt ? targets[i] : neighbors[i - nt];
+  if constexpr (sizeof(KeyT) == 4) {
+    // 32-bit ids: (id << 32 | smallest position) in ONE 64-bit word per slot — the [slots | min_pos] region read as uint64 —
+    // so a new id costs one compare-and-swap and a repeated one usually nothing (its position is larger than what is there)
+    // instead of a compare-and-swap plus an atomic min on a second array
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(slots);
+    const unsigned long long mine = (static_cast<unsigned long long>(key) << 32) | static_cast<uint32_t>(i);
+    uint32_t s = au_hash(static_cast<uint64_t>(key)) & (cap - 1);
+    for (;;) {
+      unsigned long long cur = table[s];
+      if (cur == ~0ull) {
+        cur = atomicCAS(&table[s], ~0ull, mine);
+        if (cur == ~0ull) break;                       // the slot is mine
+      }
+      if (static_cast<uint32_t>(cur >> 32) == key) {   // equal ids: the words compare by position
+        if (cur > mine) atomicMin(&table[s], mine);
+        break;
+      }
+      s = (s + 1) & (cap - 1);
+    }
+    slot_of[i] = s;
+    return;
+  }
   uint32_t s            = cap;  // the id that looks like "empty" has a slot of its own
   if (key != kEmpty) {
     s = au_hash(static_cast<uint64_t>(key)) & (cap - 1);
@@ -494,14 +579,15 @@ __global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, 
 }
 
 __global__ __launch_bounds__(kBlock) void au_flag_kernel(const uint32_t* min_pos, const uint32_t* slot_of, int nt, int nn,
-                                                         const int* nn_dev, int* first_flag)
+                                                         const int* nn_dev, int* first_flag, int stride)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > nn) return;
   const int used = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
   // first occurrence of an id that no target holds (targets sit at positions < nt); the entries past the ones in use are
   // zero, so the exclusive scan's last entry (index nn) is the number of new ids whatever `used` is
-  first_flag[p] = p < used && min_pos[slot_of[nt + p]] == static_cast<uint32_t>(nt + p) ? 1 : 0;
+  // (stride 2: 32-bit ids keep (id, position) words, min_pos then points at their low halves)
+  first_flag[p] = p < used && min_pos[static_cast<size_t>(slot_of[nt + p]) * stride] == static_cast<uint32_t>(nt + p) ? 1 : 0;
 }
 
 // one new-count word written where the caller wants it (device and / or pinned host memory): replaces 4-byte copy commands
@@ -517,6 +603,18 @@ __global__ void au_publish_kernel(const int* new_rank_end, const int* nn_dev, in
 
 // (the grid covers max(nt, nn): the same launch copies the targets to the head of the output and, for the fused hop, the
 // centre local ids from their scratch to the exactly sized output — both were copy commands of their own)
+struct au_flag_fn {   // au_flag_kernel as a function of the neighbour position (input iterator of the ranking scan)
+  const uint32_t* min_pos;
+  const uint32_t* slot_of;
+  int nt, nn;
+  const int* nn_dev;
+  __device__ int operator()(int p) const
+  {
+    const int used = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+    return p < used && min_pos[slot_of[nt + p]] == static_cast<uint32_t>(nt + p) ? 1 : 0;
+  }
+};
+
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, const uint32_t* min_pos, const uint32_t* slot_of,
                                                          const int* new_rank, int nt, int nn, KeyT* out_unique, int* mapping,
@@ -527,9 +625,18 @@ __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, cons
   if (p >= nn) return;
   if (copy_dst != nullptr) copy_dst[p] = copy_src[p];
   const uint32_t s = slot_of[nt + p];
-  const int m      = static_cast<int>(min_pos[s]);
-  const int uid    = m < nt ? m : nt + new_rank[m - nt];
-  if (m == nt + p) out_unique[uid] = slots[s];
+  int m;
+  KeyT key;
+  if constexpr (sizeof(KeyT) == 4) {
+    const unsigned long long w = reinterpret_cast<const unsigned long long*>(slots)[s];
+    m   = static_cast<int>(static_cast<uint32_t>(w));
+    key = static_cast<KeyT>(w >> 32);
+  } else {
+    m   = static_cast<int>(min_pos[s]);
+    key = slots[s];
+  }
+  const int uid = m < nt ? m : nt + new_rank[m - nt];
+  if (m == nt + p) out_unique[uid] = key;
   if (mapping != nullptr) mapping[p] = uid;
 }
 
@@ -545,8 +652,12 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
     hipLaunchKernelGGL((au_insert_kernel<UKey>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                        static_cast<const UKey*>(targets), nt, static_cast<const UKey*>(neighbors), nn, nn_dev, l.slots,
                        l.min_pos, l.slot_of, l.cap);
-  hipLaunchKernelGGL(au_flag_kernel, dim3((nn + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.min_pos, l.slot_of, nt, nn,
-                     nn_dev, l.first_flag);
+  // (computing the flags inside the scan's input iterator instead — au_flag_fn — was measured: the look-back scan with two
+  // dependent random loads per element takes 19.9 us against 6.8 + 5.9 us for flag kernel + plain scan)
+  // 32-bit ids: the positions are the low halves of the (id, position) words that start where `slots` starts
+  const uint32_t* positions = sizeof(UKey) == 4 ? reinterpret_cast<const uint32_t*>(l.slots) : l.min_pos;
+  hipLaunchKernelGGL(au_flag_kernel, dim3((nn + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, positions, l.slot_of, nt, nn,
+                     nn_dev, l.first_flag, sizeof(UKey) == 4 ? 2 : 1);
   size_t tb = l.temp_bytes;
   if (rocprim::exclusive_scan(l.temp, tb, l.first_flag, l.new_rank, 0, static_cast<size_t>(nn) + 1, rocprim::plus<int>(),
                               stream) != hipSuccess)
@@ -794,6 +905,46 @@ int hip_sample_pair_ids(const void* centers, wholememory_dtype_t id_dtype, int n
   else
     return -1;
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// offsets[i] = sum of min(degree(center j), max_sample) over j < i, i = 0 .. n: the per-centre counts are computed inside the
+// scan's input iterator (no count kernel, no count array)
+template <typename IdT>
+struct degree_fn {
+  gref_view row_ptr;
+  int64_t row_off;
+  const IdT* centers;
+  int n, max_sample;
+  __device__ int operator()(int i) const
+  {
+    if (i >= n) return 0;  // the scan runs over n + 1 entries (reference :334-338)
+    const int64_t nid = static_cast<int64_t>(centers[i]);
+    const int64_t s   = gref_load<int64_t>(row_ptr, row_off + nid);
+    const int64_t e   = gref_load<int64_t>(row_ptr, row_off + nid + 1);
+    int deg           = static_cast<int>(e - s);
+    if (max_sample > 0) deg = min(deg, max_sample);
+    return deg;
+  }
+};
+int hip_sample_offsets(const wholememory_gref_t* row_gref, int64_t row_off, const void* centers, wholememory_dtype_t id_dtype,
+                       int n, int max_sample, int* offsets, void* ws, size_t ws_bytes, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const gref_view rv = make_view(*row_gref);
+  size_t b           = ws_bytes;
+  hipError_t rc;
+  if (id_dtype == WHOLEMEMORY_DT_INT) {
+    degree_fn<int32_t> fn{rv, row_off, static_cast<const int32_t*>(centers), n, max_sample};
+    rc = rocprim::exclusive_scan(ws, b, rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn), offsets, 0,
+                                 static_cast<size_t>(n) + 1, rocprim::plus<int>(), stream);
+  } else if (id_dtype == WHOLEMEMORY_DT_INT64) {
+    degree_fn<int64_t> fn{rv, row_off, static_cast<const int64_t*>(centers), n, max_sample};
+    rc = rocprim::exclusive_scan(ws, b, rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn), offsets, 0,
+                                 static_cast<size_t>(n) + 1, rocprim::plus<int>(), stream);
+  } else {
+    return -1;
+  }
+  return rc == hipSuccess ? 0 : -2;
 }
 
 size_t hip_scan_i32_ws_bytes(int64_t n)
