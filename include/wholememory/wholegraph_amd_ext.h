@@ -143,6 +143,26 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
   void* output_neighbor_pos_memory_context, void* output_center_localid_memory_context, wholememory_env_func_t* p_env_fns,
   void* stream);
 
+/* Every hop of a multi-layer unweighted sample (hop = neighbour sample + graph_append_unique, as in
+ * wholememory_ext_sample_append_unique) in ONE call with NO host round trip inside. The caller sizes every array for its upper
+ * bound: hop h (h = 0 next to the seeds) has at most cap_c[h] centres and cap_s[h] = cap_c[h] * max_sample_counts[h] samples,
+ * cap_c[0] = number of seeds, cap_c[h + 1] = cap_c[h] + cap_s[h]:
+ *   sample_offsets[h]  int32 [cap_c[h] + 1]        unique[h]       id dtype [cap_c[h] + cap_s[h]]
+ *   neighbor_pos[h]    int32 [cap_s[h]]            center_lid[h]   int32 [cap_s[h]]
+ * all DEVICE memory; counts_host: PINNED host memory the device can write, 2 * hops ints — the last kernel of hop h leaves
+ * {samples, new unique ids} of that hop in counts_host[2h], counts_host[2h + 1]. After ONE stream synchronise the caller
+ * trims: with n_c[0] = seeds and n_c[h + 1] = n_c[h] + new[h], hop h's csr_row_ptr is sample_offsets[h][0 .. n_c[h]], its
+ * widened frontier unique[h][0 .. n_c[h + 1]), neighbor_pos / center_lid the first samples[h] entries. Bit-identical to `hops`
+ * calls of wholememory_ext_sample_append_unique with the same seeds. WHOLEMEMORY_NOT_SUPPORTED (nothing queued) when the CSR is
+ * not mapped into this rank, the id dtypes differ, there is no seed, a fan-out is <= 0 or a hop's upper bounds exceed what
+ * graph_append_unique's hash-table route takes (the caller then runs hop by hop). Reference call sequence:
+ * python/pylibwholegraph/pylibwholegraph/torch/graph_structure.py:140-196. */
+enum wholememory_error_code_t wholememory_ext_multilayer_sample(
+  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor, wholememory_tensor_t seed_nodes_tensor,
+  int hops, const int* max_sample_counts, const unsigned long long* random_seeds, void* const* sample_offsets,
+  void* const* unique, int* const* neighbor_pos, int* const* center_lid, int* counts_host,
+  struct wholememory_env_func_t* p_env_fns, void* stream);
+
 /* Completion semantics of the ops whose reference versions drain the stream before returning (neighbour sampling,
  * graph_append_unique and the fused hop above). Default 0 = the reference's: outputs complete and scratch idle at return,
  * safe with any env functions. 1 = the ops return with their last kernels queued on `stream` (one host round trip fewer

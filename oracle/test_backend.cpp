@@ -351,7 +351,7 @@ const wm_device_backend kTestBackend = {
   t_gather, t_scatter, t_bucket_ws, t_bucket, t_dedup_ws, t_dedup, t_step, t_long_ws, t_run_inverse, t_remap_self, t_rr, t_fill,
   t_dup_ws, t_dup_estimate, t_sorted_counts,
   // graph ops: not provided by the CPU backend
-  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
   t_env_test,
 };
 

@@ -179,3 +179,45 @@ print("BIG_ROUTE_OK")
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, WM_AU_TABLE_MAX="0"), capture_output=True, text=True,
                        timeout=600)
     assert p.returncode == 0 and "BIG_ROUTE_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mt,loc", [("chunked", "cuda"), ("continuous", "cuda"), ("chunked", "cpu")])
+@pytest.mark.parametrize("id_dtype,fanouts", [(np.int32, [30, 30]), (np.int64, [15, 10, 5]), (np.int32, [1]), (np.int64, [200, 3])])
+def test_chain_with_one_host_round_trip_equals_hop_by_hop(gpu_env, monkeypatch, mt, loc, id_dtype, fanouts):
+    """wholememory_ext_multilayer_sample (upper-bound-sized buffers, counts kept on the device between hops, ONE stream
+    synchronise for the whole chain) against the hop-by-hop route (WM_MULTILAYER_CHAIN=0: one fused call and one host round
+    trip per hop) with the same per-hop seeds: every returned tensor equal, bit for bit."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    n_nodes = 30011
+    row_ptr, col = make_csr(n_nodes, 60, 7, id_dtype, heavy=[(3, 5000), (4, 0), (5, 1500), (6, 31), (7, 201)])
+    wrow, wcol = _wm_array(gpu_env, mt, row_ptr, loc), _wm_array(gpu_env, mt, col, loc)
+    g = wgth.GraphStructure()
+    g.set_csr_graph(wrow, wcol)
+    seeds = torch.from_numpy(np.concatenate([[3, 4, 5, 6, 7, 7], np.random.default_rng(9).permutation(n_nodes)[:700]]).astype(id_dtype)).cuda()
+    hop_seeds = [77 + 5 * i for i in range(len(fanouts))]
+    monkeypatch.setenv("WM_MULTILAYER_CHAIN", "0")
+    ref = g.multilayer_sample_without_replacement(seeds, fanouts, random_seeds=hop_seeds)
+    monkeypatch.setenv("WM_MULTILAYER_CHAIN", "1")
+    got = g.multilayer_sample_without_replacement(seeds, fanouts, random_seeds=hop_seeds)
+    torch.cuda.synchronize()
+    for name, a_list, b_list in zip(("target_gids", "edge_indice", "csr_row_ptr", "csr_col_ind"), got, ref):
+        assert len(a_list) == len(b_list)
+        for layer, (a, b) in enumerate(zip(a_list, b_list)):
+            assert a.dtype == b.dtype and tuple(a.shape) == tuple(b.shape), "%s[%d]: %s vs %s" % (name, layer, a.shape, b.shape)
+            assert torch.equal(a, b), "%s[%d] differs" % (name, layer)
+    # the chain really ran as one call: its outputs are views of upper-bound buffers
+    assert got[0][0].untyped_storage().nbytes() >= ref[0][0].untyped_storage().nbytes()
+
+
+def test_chain_declines_upper_bounds_beyond_the_table_route(gpu_env):
+    """65536 seeds x [30, 30]: the second hop's upper bound (2 M centres + 61 M samples) is past what append_unique's hash
+    table takes from device-side counts: the library answers NOT_SUPPORTED before queueing anything and the caller goes hop by hop."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    from wholegraph_amd.torch import wholegraph_ops
+    row_ptr, col = make_csr(5003, 20, 3, np.int32)
+    wrow, wcol = _wm_array(gpu_env, "chunked", row_ptr), _wm_array(gpu_env, "chunked", col)
+    seeds = torch.randint(0, 5003, (65536,), dtype=torch.int32, device="cuda")
+    assert wholegraph_ops.multilayer_sample(wrow.wmb_tensor, wcol.wmb_tensor, seeds, [30, 30], [1, 2]) is None
+    assert wholegraph_ops.multilayer_sample(wrow.wmb_tensor, wcol.wmb_tensor, seeds[:0], [5], [1]) is None

@@ -123,6 +123,17 @@ struct wm_sample_args {
   wholememory_gref_t weight_gref;
   int64_t weight_storage_offset;
   wholememory_dtype_t weight_dtype;
+  // optional (device): the number of centres in use when `centers` / `sample_offsets` are sized for an upper bound n_center
+  // (the frontier of the previous hop of a bounded multi-hop call); nullptr = n_center
+  const int* n_center_dev;
+};
+
+// device-side sizes of an append_unique over upper-bound-sized arrays (the hops of wholememory_ext_multilayer_sample: nothing
+// leaves the device between hops). nullptr instead of the struct = every size is the host's.
+struct wm_au_bounds {
+  const int* n_target_dev;    // targets in use (<= n_target)
+  const int* n_neighbor_dev;  // neighbours in use (<= n_neighbor)
+  int* n_unique_dev;          // out: targets in use + new ids = what the output holds (the next hop's centre count)
 };
 
 // device row cache of an embedding (kernels/cache.hip): direct map row -> slot, 64-slot LFU sets
@@ -223,8 +234,10 @@ struct wm_device_backend {
   // ---- graph ops (kernels/graph.hip); nullptr in a backend that does not provide them ----
   // counts[i] = min(degree(center i), max_sample) for i < n, counts[n] = 0
   // (row bounds from row_pairs when it is not nullptr, else through row_gref)
+  // n_dev (optional, device): centres in use of the n the arrays are sized for; counts past them are 0
   int (*sample_counts)(const wholememory_gref_t* row_gref, int64_t row_storage_offset, const int64_t* row_pairs,
-                       const void* centers, wholememory_dtype_t center_dtype, int n, int max_sample, int* counts, void* stream);
+                       const void* centers, wholememory_dtype_t center_dtype, int n, const int* n_dev, int max_sample,
+                       int* counts, void* stream);
   // ids[2i] = center i, ids[2i + 1] = center i + 1
   int (*sample_pair_ids)(const void* centers, wholememory_dtype_t center_dtype, int n, int64_t* ids, void* stream);
   // sample_counts + exclusive scan in one pass (mapped CSR only): offsets[0 .. n]; workspace of scan_i32_workspace_bytes(n + 1).
@@ -248,13 +261,16 @@ struct wm_device_backend {
   // command (a D2H / D2D copy of 4 bytes is its own ~13 us entry in the GPU's queue)
   int (*append_unique_phase1)(const void* targets, int n_target, const void* neighbors, int n_neighbor,
                               const int* n_neighbor_dev, wholememory_dtype_t dtype, void* workspace, int* new_count_dev,
-                              int* publish_host, void* stream);
+                              int* publish_host, const wm_au_bounds* bounds, void* stream);
   // copy_src / copy_dst (optional): n_neighbor_used ints moved by the emitting kernel on the side (the fused hop's centre
   // local ids, from their upper-bound scratch to the exactly sized output)
   int (*append_unique_phase2)(const void* targets, int n_target, int n_neighbor, int n_neighbor_used,
                               wholememory_dtype_t dtype, void* workspace, void* out_unique, int* mapping,
-                              const int* copy_src, int* copy_dst, void* stream);
+                              const int* copy_src, int* copy_dst, const wm_au_bounds* bounds, void* stream);
   int (*csr_add_self_loop)(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
+  // can append_unique over arrays with room for n_target + n_neighbor ids run from device-side counts (wm_au_bounds)?
+  // (the hash-table route can, the sort route needs the counts on the host)
+  bool (*append_unique_takes_bounds)(int n_target, int n_neighbor, wholememory_dtype_t dtype);
   // out[i, c] = T(float(i)) + in[c] (wholememory_env_test_op)
   int (*env_test_fill)(const void* in, void* out, wholememory_dtype_t dtype, int64_t dim, int64_t entries, int64_t stride,
                        void* stream);

@@ -207,7 +207,7 @@ wholememory_error_code_t sample_without_replacement(
     a.row_pairs = pairs;
   }
   WM_BK(bk->sample_counts(via_gather ? nullptr : &a.row_gref, a.row_storage_offset, a.row_pairs, a.centers, a.center_dtype,
-                          a.n_center, max_sample_count, counts, stream));
+                          a.n_center, nullptr, max_sample_count, counts, stream));
   WM_BK(bk->exclusive_scan_i32(counts, offsets, n + 1, scan_ws_ptr, scan_ws, stream));
   int total = 0;
   WM_BK(bk->memcpy_async(&total, offsets + n, sizeof(int), stream));
@@ -380,12 +380,12 @@ wholememory_error_code_t graph_append_unique(wholememory_tensor_t target_nodes_t
   temp_mem ws_mem(p_env_fns), host_mem(p_env_fns);
   void* ws  = ws_mem.device(static_cast<int64_t>(bk->append_unique_workspace_bytes(nt, nn, target_desc.dtype)), WHOLEMEMORY_DT_INT8);
   int* host = static_cast<int*>(host_mem.pinned(2, WHOLEMEMORY_DT_INT));   // written by the phase's last kernel
-  WM_BK(bk->append_unique_phase1(targets, nt, neighbors, nn, nullptr, target_desc.dtype, ws, nullptr, host, stream));
+  WM_BK(bk->append_unique_phase1(targets, nt, neighbors, nn, nullptr, target_desc.dtype, ws, nullptr, host, nullptr, stream));
   WM_BK(bk->stream_sync(stream));
   const int new_count = host[1];
   void* out = output_alloc(p_env_fns, output_unique_node_memory_context, static_cast<int64_t>(nt) + new_count, target_desc.dtype);
   if (out == nullptr) return WHOLEMEMORY_OUT_OF_MEMORY;
-  WM_BK(bk->append_unique_phase2(targets, nt, nn, nn, target_desc.dtype, ws, out, mapping, nullptr, nullptr, stream));
+  WM_BK(bk->append_unique_phase2(targets, nt, nn, nn, target_desc.dtype, ws, out, mapping, nullptr, nullptr, nullptr, stream));
   if (!async_completion_enabled() || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));  // (reference append_unique_func.cuh:351)
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
@@ -462,14 +462,14 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
     WM_BK(bk->sample_offsets(&a.row_gref, a.row_storage_offset, a.centers, a.center_dtype, a.n_center, max_sample_count, offsets,
                              scan_ws_ptr, scan_ws, stream));
   } else {
-    WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, a.n_center, max_sample_count,
+    WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, a.n_center, nullptr, max_sample_count,
                             counts, stream));
     WM_BK(bk->exclusive_scan_i32(counts, offsets, n + 1, scan_ws_ptr, scan_ws, stream));
   }
   a.out_ids        = ids;
   a.out_center_lid = lid;
   WM_BK(bk->sample_unweighted(&a, stream));   // writes exactly offsets[n] entries of the scratch arrays
-  int rc = bk->append_unique_phase1(a.centers, nt, ids, nn_room, offsets + n, center_desc.dtype, ws, nullptr, host, stream);
+  int rc = bk->append_unique_phase1(a.centers, nt, ids, nn_room, offsets + n, center_desc.dtype, ws, nullptr, host, nullptr, stream);
   int total = 0, n_new = 0;
   if (rc == -3) {
     // a frontier too big for the route that works from a device-side count: learn the sample count first
@@ -478,14 +478,14 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
     total = host[0];
     temp_mem ws2_mem(p_env_fns);
     void* ws2 = ws2_mem.device(static_cast<int64_t>(bk->append_unique_workspace_bytes(nt, total, center_desc.dtype)), WHOLEMEMORY_DT_INT8);
-    WM_BK(bk->append_unique_phase1(a.centers, nt, ids, total, nullptr, center_desc.dtype, ws2, nullptr, host, stream));
+    WM_BK(bk->append_unique_phase1(a.centers, nt, ids, total, nullptr, center_desc.dtype, ws2, nullptr, host, nullptr, stream));
     WM_BK(bk->stream_sync(stream));
     n_new = host[1];
     void* uniq = output_alloc(p_env_fns, output_unique_memory_context, static_cast<int64_t>(nt) + n_new, center_desc.dtype);
     int* pos   = static_cast<int*>(output_alloc(p_env_fns, output_neighbor_pos_memory_context, total, WHOLEMEMORY_DT_INT));
     int* olid  = static_cast<int*>(output_alloc(p_env_fns, output_center_localid_memory_context, total, WHOLEMEMORY_DT_INT));
     if (uniq == nullptr || (total > 0 && (pos == nullptr || olid == nullptr))) return WHOLEMEMORY_OUT_OF_MEMORY;
-    WM_BK(bk->append_unique_phase2(a.centers, nt, total, total, center_desc.dtype, ws2, uniq, pos, lid, olid, stream));
+    WM_BK(bk->append_unique_phase2(a.centers, nt, total, total, center_desc.dtype, ws2, uniq, pos, lid, olid, nullptr, stream));
     WM_BK(bk->stream_sync(stream));   // ws2 goes out of scope here
     return WHOLEMEMORY_SUCCESS;
   }
@@ -496,8 +496,103 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
   int* pos   = static_cast<int*>(output_alloc(p_env_fns, output_neighbor_pos_memory_context, total, WHOLEMEMORY_DT_INT));
   int* olid  = static_cast<int*>(output_alloc(p_env_fns, output_center_localid_memory_context, total, WHOLEMEMORY_DT_INT));
   if (uniq == nullptr || (total > 0 && (pos == nullptr || olid == nullptr))) return WHOLEMEMORY_OUT_OF_MEMORY;
-  WM_BK(bk->append_unique_phase2(a.centers, nt, nn_room, total, center_desc.dtype, ws, uniq, pos, lid, olid, stream));
+  WM_BK(bk->append_unique_phase2(a.centers, nt, nn_room, total, center_desc.dtype, ws, uniq, pos, lid, olid, nullptr, stream));
   if (!async_completion_enabled() || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));   // else: outputs and scratch are ordered on `stream`
+  return WHOLEMEMORY_SUCCESS;
+  WM_API_END
+}
+
+// The whole chain of hops of GraphStructure.multilayer_sample_without_replacement as ONE call with NO host round trip inside
+// (extension; the reference pays two per hop, the fused hop above one): every array is sized by the CALLER for its upper
+// bound — hop h has at most cap_c[h] centres (cap_c[0] = seeds, cap_c[h + 1] = cap_c[h] + cap_s[h]) and cap_s[h] = cap_c[h] x
+// fan-out samples — the counts stay on the device from hop to hop (wm_sample_args::n_center_dev, wm_au_bounds), and the last
+// kernel of every hop leaves {samples, new unique ids} in counts_host[2h], counts_host[2h + 1] (pinned memory). The caller
+// synchronises the stream ONCE, reads the counts and trims:
+//   sample_offsets[h]  int32 [cap_c[h] + 1]          first n_c[h] + 1 entries are the hop's csr_row_ptr
+//   unique[h]          ids   [cap_c[h] + cap_s[h]]    first n_c[h] + new[h] entries = centres ++ new neighbours = hop h + 1's centres
+//   neighbor_pos[h]    int32 [cap_s[h]]               first samples[h] entries
+//   center_lid[h]      int32 [cap_s[h]]               first samples[h] entries
+// with n_c[0] = seeds, n_c[h + 1] = n_c[h] + new[h]. Outputs equal those of `hops` fused-hop calls bit for bit (same kernels,
+// same per-hop seeds). WHOLEMEMORY_NOT_SUPPORTED (nothing queued): CSR not mapped into this rank, dtypes differ, an empty seed
+// array, a fan-out <= 0, or a hop whose upper bounds are too big for the hash-table route of append_unique.
+wholememory_error_code_t wholememory_ext_multilayer_sample(
+  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor, wholememory_tensor_t seed_nodes_tensor,
+  int hops, const int* max_sample_counts, const unsigned long long* random_seeds, void* const* sample_offsets, void* const* unique,
+  int* const* neighbor_pos, int* const* center_lid, int* counts_host, wholememory_env_func_t* p_env_fns, void* stream)
+{
+  WM_API_BEGIN
+  const auto* bk = graph_backend();
+  if (bk == nullptr || bk->append_unique_takes_bounds == nullptr) return WHOLEMEMORY_NOT_SUPPORTED;
+  if (p_env_fns == nullptr || hops <= 0 || hops > 16 || max_sample_counts == nullptr || random_seeds == nullptr ||
+      sample_offsets == nullptr || unique == nullptr || neighbor_pos == nullptr || center_lid == nullptr || counts_host == nullptr)
+    return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_error_code_t err = WHOLEMEMORY_SUCCESS;
+  wholememory_array_description_t row_desc, col_desc, seed_desc;
+  if (!array_of(wm_csr_row_ptr_tensor, "wm_csr_row_ptr_tensor", &row_desc, &err)) return err;
+  if (!array_of(wm_csr_col_ptr_tensor, "wm_csr_col_ptr_tensor", &col_desc, &err)) return err;
+  if (!array_of(seed_nodes_tensor, "seed_nodes_tensor", &seed_desc, &err)) return err;
+  const auto row_mt = memory_type_of(wm_csr_row_ptr_tensor), col_mt = memory_type_of(wm_csr_col_ptr_tensor);
+  const bool mapped = row_mt != WHOLEMEMORY_MT_HIERARCHY && col_mt != WHOLEMEMORY_MT_HIERARCHY &&
+                      row_mt != WHOLEMEMORY_MT_DISTRIBUTED && col_mt != WHOLEMEMORY_MT_DISTRIBUTED;
+  if (!mapped || row_desc.dtype != WHOLEMEMORY_DT_INT64 || !is_index_dtype(seed_desc.dtype) || col_desc.dtype != seed_desc.dtype ||
+      seed_desc.size == 0)
+    return WHOLEMEMORY_NOT_SUPPORTED;
+  std::vector<int64_t> cap_c(hops + 1), cap_s(hops);
+  cap_c[0] = seed_desc.size;
+  for (int h = 0; h < hops; h++) {
+    if (max_sample_counts[h] <= 0) return WHOLEMEMORY_NOT_SUPPORTED;
+    cap_s[h]     = cap_c[h] * max_sample_counts[h];
+    cap_c[h + 1] = cap_c[h] + cap_s[h];
+    if (cap_c[h + 1] >= (INT64_C(1) << 31) - 1 ||
+        !bk->append_unique_takes_bounds(static_cast<int>(cap_c[h]), static_cast<int>(cap_s[h]), seed_desc.dtype))
+      return WHOLEMEMORY_NOT_SUPPORTED;
+  }
+  wm_sample_args a{};
+  WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_row_ptr_tensor, &a.row_gref));
+  WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_col_ptr_tensor, &a.col_gref));
+  a.row_storage_offset = row_desc.storage_offset;
+  a.col_storage_offset = col_desc.storage_offset;
+  a.col_dtype          = col_desc.dtype;
+  a.center_dtype       = seed_desc.dtype;
+
+  // scratch of all hops at once (the kernels are queued back to back; nothing may be reused before the last one has run)
+  temp_mem n_dev_mem(p_env_fns);
+  int* n_dev = static_cast<int*>(n_dev_mem.device(hops, WHOLEMEMORY_DT_INT));   // centres of hop h + 1 = unique ids after hop h
+  std::vector<std::unique_ptr<temp_mem>> keep;
+  auto scratch = [&](int64_t count, wholememory_dtype_t dt) {
+    keep.emplace_back(new temp_mem(p_env_fns));
+    return keep.back()->device(count, dt);
+  };
+  for (int h = 0; h < hops; h++) {
+    const int nc = static_cast<int>(cap_c[h]), ns = static_cast<int>(cap_s[h]);
+    const int* centres_in_use = h == 0 ? nullptr : n_dev + (h - 1);
+    a.centers          = h == 0 ? wholememory_tensor_get_data_pointer(seed_nodes_tensor) : unique[h - 1];
+    a.n_center         = nc;
+    a.n_center_dev     = centres_in_use;
+    a.max_sample_count = max_sample_counts[h];
+    a.random_seed      = random_seeds[h];
+    int* offsets       = static_cast<int*>(sample_offsets[h]);
+    a.sample_offsets   = offsets;
+    int* counts        = static_cast<int*>(scratch(nc + 1, WHOLEMEMORY_DT_INT));
+    const size_t scan_ws = bk->scan_i32_workspace_bytes(nc + 1);
+    void* scan_ws_ptr  = scratch(static_cast<int64_t>(scan_ws), WHOLEMEMORY_DT_INT8);
+    void* ids          = scratch(ns, col_desc.dtype);
+    void* ws = scratch(static_cast<int64_t>(bk->append_unique_workspace_bytes(nc, ns, seed_desc.dtype)), WHOLEMEMORY_DT_INT8);
+    WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, nc, centres_in_use,
+                            a.max_sample_count, counts, stream));
+    WM_BK(bk->exclusive_scan_i32(counts, offsets, nc + 1, scan_ws_ptr, scan_ws, stream));   // offsets[nc] = samples of the hop
+    a.out_ids        = ids;
+    a.out_center_lid = center_lid[h];
+    WM_BK(bk->sample_unweighted(&a, stream));
+    wm_au_bounds b{centres_in_use, offsets + nc, n_dev + h};
+    int rc = bk->append_unique_phase1(a.centers, nc, ids, ns, offsets + nc, seed_desc.dtype, ws, nullptr, counts_host + 2 * h, &b, stream);
+    if (rc != 0) return rc == -1 ? WHOLEMEMORY_LOGIC_ERROR : WHOLEMEMORY_CUDA_ERROR;
+    WM_BK(bk->append_unique_phase2(a.centers, nc, ns, ns, seed_desc.dtype, ws, unique[h], neighbor_pos[h], nullptr, nullptr, &b, stream));
+  }
+  // by default the call returns complete, like every op of the reference; a host framework that declared stream-ordered
+  // allocators (wholememory_ext_set_async_completion) gets it back with everything queued and synchronises when it reads
+  // counts_host
+  if (!async_completion_enabled() || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
 }

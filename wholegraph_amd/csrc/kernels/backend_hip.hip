@@ -29,7 +29,7 @@ int hip_dup_estimate(const void* ids, wholememory_dtype_t index_dtype, int64_t n
 int hip_sorted_owner_counts(const void* sorted_ids, wholememory_dtype_t index_dtype, const int64_t* n_dev, int64_t n_upper,
                             const uint64_t* entry_offsets, int world_size, int64_t* counts, void* stream);
 int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const int64_t* row_pairs, const void* centers,
-                      wholememory_dtype_t id_dtype, int n, int max_sample, int* counts, void* stream);
+                      wholememory_dtype_t id_dtype, int n, const int* n_dev, int max_sample, int* counts, void* stream);
 int hip_sample_pair_ids(const void* centers, wholememory_dtype_t id_dtype, int n, int64_t* ids, void* stream);
 size_t hip_scan_i32_ws_bytes(int64_t n);
 int hip_exclusive_scan_i32(const int* in, int* out, int64_t n, void* ws, size_t ws_bytes, void* stream);
@@ -39,10 +39,13 @@ int hip_sample_unweighted(const wm_sample_args* a, void* stream);
 int hip_sample_weighted(const wm_sample_args* a, void* stream);
 size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt);
 int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, const int* nn_dev,
-                             wholememory_dtype_t dt, void* ws, int* new_count_dev, int* publish_host, void* stream);
+                             wholememory_dtype_t dt, void* ws, int* new_count_dev, int* publish_host, const wm_au_bounds* bounds,
+                             void* stream);
 int hip_append_unique_phase2(const void* targets, int nt, int nn, int nn_used, wholememory_dtype_t dt, void* ws,
-                             void* out_unique, int* mapping, const int* copy_src, int* copy_dst, void* stream);
+                             void* out_unique, int* mapping, const int* copy_src, int* copy_dst, const wm_au_bounds* bounds,
+                             void* stream);
 int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream);
+bool hip_append_unique_takes_bounds(int nt, int nn, wholememory_dtype_t dt);
 
 int hip_env_test_fill(const void* in, void* out, wholememory_dtype_t dt, int64_t dim, int64_t entries, int64_t stride, void* stream);
 int hip_cache_update(const wm_cache_args* c, const void* unique_rows, wholememory_dtype_t dt, const int32_t* run_starts,
@@ -170,6 +173,7 @@ const wm_device_backend kHipBackend = {
   hip_append_unique_phase1,
   hip_append_unique_phase2,
   hip_csr_add_self_loop,
+  hip_append_unique_takes_bounds,
   hip_env_test_fill,
   hip_cache_update,
   hip_cache_split,

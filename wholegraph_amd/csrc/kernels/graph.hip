@@ -91,12 +91,13 @@ __global__ void pair_ids_kernel(const IdT* centers, int n, int64_t* ids)
 
 template <typename IdT>
 __global__ void sample_count_kernel(gref_view row_ptr, int64_t row_off, const int64_t* pairs, const IdT* centers, int n,
-                                    int max_sample, int* counts)
+                                    const int* n_dev, int max_sample, int* counts)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
-  if (i == n) {
-    counts[n] = 0;  // the scan runs over n + 1 entries (reference :334-338)
+  const int used = n_dev != nullptr ? min(n, *n_dev) : n;   // arrays sized for n, `used` centres in them
+  if (i >= used) {
+    counts[i] = 0;  // the scan runs over n + 1 entries (reference :334-338)
     return;
   }
   int64_t s, e;
@@ -126,7 +127,12 @@ struct sample_params {
   void* out_ids;       // ColT, or nullptr
   int* out_lid;        // optional
   int64_t* out_egid;   // optional
+  const int* n_center_dev;  // optional: centres in use (<= n_center)
 };
+__device__ __forceinline__ int centers_in_use(const sample_params& p)
+{
+  return p.n_center_dev != nullptr ? min(p.n_center, *p.n_center_dev) : p.n_center;
+}
 
 template <typename IdT>
 __device__ __forceinline__ void row_bounds(const sample_params& p, int center, int64_t* s, int64_t* e)
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void sample_sparse_kernel(sample_params p)
   int* qpos         = a_s + M;
   int* qval         = qpos + M;
   const int center  = blockIdx.x * kWavesPerBlk + wave_in;
-  if (center >= p.n_center) return;
+  if (center >= centers_in_use(p)) return;
   ColT* out          = static_cast<ColT*>(p.out_ids);
   int64_t s, e;
   row_bounds<IdT>(p, center, &s, &e);
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void sample_small_kernel(sample_params p)
   const int M      = p.max_sample;   // 1 ... 64
   const int lane   = threadIdx.x & 63;
   const int center = blockIdx.x * kWavesPerBlk + (threadIdx.x >> 6);
-  if (center >= p.n_center) return;
+  if (center >= centers_in_use(p)) return;
   ColT* out = static_cast<ColT*>(p.out_ids);
   int64_t s, e;
   row_bounds<IdT>(p, center, &s, &e);
@@ -290,6 +296,7 @@ template <typename IdT, typename ColT>
 __global__ __launch_bounds__(64) void sample_large_kernel(sample_params p)
 {
   const int center = blockIdx.x;
+  if (center >= centers_in_use(p)) return;   // (block-uniform)
   const int lane   = threadIdx.x;
   const int M      = p.max_sample;
   ColT* out          = static_cast<ColT*>(p.out_ids);
@@ -534,19 +541,27 @@ __device__ __forceinline__ uint64_t au_cas(uint64_t* a, uint64_t expect, uint64_
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, int nt, const KeyT* neighbors, int nn,
                                                            const int* nn_dev, KeyT* slots, uint32_t* min_pos,
-                                                           uint32_t* slot_of, uint32_t cap)
+                                                           uint32_t* slot_of, uint32_t cap, const int* nt_dev)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (nn_dev != nullptr) nn = min(nn, *nn_dev);   // room for nn neighbours, *nn_dev of them in use
+  // the arrays hold room for nt targets and nn neighbours; nt_use / nn_use of them are in use (device-side counts of a
+  // bounded call, else all). Thread i serves array entry i of targets ++ neighbours; the POSITION of a key — what
+  // "first occurrence" is decided on — counts the entries in use: targets 0 .. nt_use - 1, neighbours nt_use ...
+  const int i      = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nt_use = nt_dev != nullptr ? min(nt, *nt_dev) : nt;
+  const int nn_use = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
   if (i >= nt + nn) return;
+  const bool is_target = i < nt;
+  const int entry      = is_target ? i : i - nt;
+  if (entry >= (is_target ? nt_use : nn_use)) return;
+  const int pos         = is_target ? entry : nt_use + entry;
   constexpr KeyT kEmpty = ~static_cast<KeyT>(0);
-  const KeyT key        = i < nt ? targets[i] : neighbors[i - nt];
+  const KeyT key        = is_target ? targets[entry] : neighbors[entry];
   if constexpr (sizeof(KeyT) == 4) {
     // 32-bit ids: (id << 32 | smallest position) in ONE 64-bit word per slot — the [slots | min_pos] region read as uint64 —
     // so a new id costs one compare-and-swap and a repeated one usually nothing (its position is larger than what is there)
     // instead of a compare-and-swap plus an atomic min on a second array
     unsigned long long* table = reinterpret_cast<unsigned long long*>(slots);
-    const unsigned long long mine = (static_cast<unsigned long long>(key) << 32) | static_cast<uint32_t>(i);
+    const unsigned long long mine = (static_cast<unsigned long long>(key) << 32) | static_cast<uint32_t>(pos);
     uint32_t s = au_hash(static_cast<uint64_t>(key)) & (cap - 1);
     for (;;) {
       unsigned long long cur = table[s];
@@ -575,23 +590,25 @@ __global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, 
   }
   slot_of[i] = s;
   // (a plain look first: a hot id is offered by thousands of positions, most of them larger than what is already there)
-  if (min_pos[s] > static_cast<uint32_t>(i)) atomicMin(&min_pos[s], static_cast<uint32_t>(i));
+  if (min_pos[s] > static_cast<uint32_t>(pos)) atomicMin(&min_pos[s], static_cast<uint32_t>(pos));
 }
 
 __global__ __launch_bounds__(kBlock) void au_flag_kernel(const uint32_t* min_pos, const uint32_t* slot_of, int nt, int nn,
-                                                         const int* nn_dev, int* first_flag, int stride)
+                                                         const int* nn_dev, int* first_flag, int stride, const int* nt_dev)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > nn) return;
-  const int used = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+  const int used   = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+  const int nt_use = nt_dev != nullptr ? min(nt, *nt_dev) : nt;
   // first occurrence of an id that no target holds (targets sit at positions < nt); the entries past the ones in use are
   // zero, so the exclusive scan's last entry (index nn) is the number of new ids whatever `used` is
   // (stride 2: 32-bit ids keep (id, position) words, min_pos then points at their low halves)
-  first_flag[p] = p < used && min_pos[static_cast<size_t>(slot_of[nt + p]) * stride] == static_cast<uint32_t>(nt + p) ? 1 : 0;
+  first_flag[p] = p < used && min_pos[static_cast<size_t>(slot_of[nt + p]) * stride] == static_cast<uint32_t>(nt_use + p) ? 1 : 0;
 }
 
 // one new-count word written where the caller wants it (device and / or pinned host memory): replaces 4-byte copy commands
-__global__ void au_publish_kernel(const int* new_rank_end, const int* nn_dev, int nn, int* new_count_dev, int* publish_host)
+__global__ void au_publish_kernel(const int* new_rank_end, const int* nn_dev, int nn, int* new_count_dev, int* publish_host,
+                                  const int* nt_dev, int nt, int* n_unique_dev)
 {
   const int c = *new_rank_end;
   if (new_count_dev != nullptr) *new_count_dev = c;
@@ -599,6 +616,7 @@ __global__ void au_publish_kernel(const int* new_rank_end, const int* nn_dev, in
     publish_host[0] = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
     publish_host[1] = c;
   }
+  if (n_unique_dev != nullptr) *n_unique_dev = (nt_dev != nullptr ? min(nt, *nt_dev) : nt) + c;
 }
 
 // (the grid covers max(nt, nn): the same launch copies the targets to the head of the output and, for the fused hop, the
@@ -618,11 +636,14 @@ struct au_flag_fn {   // au_flag_kernel as a function of the neighbour position 
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, const uint32_t* min_pos, const uint32_t* slot_of,
                                                          const int* new_rank, int nt, int nn, KeyT* out_unique, int* mapping,
-                                                         const KeyT* targets, const int* copy_src, int* copy_dst)
+                                                         const KeyT* targets, const int* copy_src, int* copy_dst,
+                                                         const int* nt_dev, const int* nn_dev)
 {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < nt) out_unique[p] = targets[p];
-  if (p >= nn) return;
+  const int p      = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nt_use = nt_dev != nullptr ? min(nt, *nt_dev) : nt;
+  const int nn_use = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+  if (p < nt_use) out_unique[p] = targets[p];
+  if (p >= nn_use) return;
   if (copy_dst != nullptr) copy_dst[p] = copy_src[p];
   const uint32_t s = slot_of[nt + p];
   int m;
@@ -635,15 +656,17 @@ __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, cons
     m   = static_cast<int>(min_pos[s]);
     key = slots[s];
   }
-  const int uid = m < nt ? m : nt + new_rank[m - nt];
-  if (m == nt + p) out_unique[uid] = key;
+  const int uid = m < nt_use ? m : nt_use + new_rank[m - nt_use];
+  if (m == nt_use + p) out_unique[uid] = key;
   if (mapping != nullptr) mapping[p] = uid;
 }
 
 template <typename KeyT>
 int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const int* nn_dev, void* ws, int* new_count_dev,
-              int* publish_host, hipStream_t stream)
+              int* publish_host, const wm_au_bounds* bounds, hipStream_t stream)
 {
+  const int* nt_dev = bounds != nullptr ? bounds->n_target_dev : nullptr;
+  if (bounds != nullptr && bounds->n_neighbor_dev != nullptr) nn_dev = bounds->n_neighbor_dev;
   using UKey  = typename std::make_unsigned<KeyT>::type;
   auto l      = au_plan<UKey>(ws, nt, nn);
   const int n = nt + nn;
@@ -651,33 +674,36 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
   if (n > 0)
     hipLaunchKernelGGL((au_insert_kernel<UKey>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                        static_cast<const UKey*>(targets), nt, static_cast<const UKey*>(neighbors), nn, nn_dev, l.slots,
-                       l.min_pos, l.slot_of, l.cap);
+                       l.min_pos, l.slot_of, l.cap, nt_dev);
   // (computing the flags inside the scan's input iterator instead — au_flag_fn — was measured: the look-back scan with two
   // dependent random loads per element takes 19.9 us against 6.8 + 5.9 us for flag kernel + plain scan)
   // 32-bit ids: the positions are the low halves of the (id, position) words that start where `slots` starts
   const uint32_t* positions = sizeof(UKey) == 4 ? reinterpret_cast<const uint32_t*>(l.slots) : l.min_pos;
   hipLaunchKernelGGL(au_flag_kernel, dim3((nn + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, positions, l.slot_of, nt, nn,
-                     nn_dev, l.first_flag, sizeof(UKey) == 4 ? 2 : 1);
+                     nn_dev, l.first_flag, sizeof(UKey) == 4 ? 2 : 1, nt_dev);
   size_t tb = l.temp_bytes;
   if (rocprim::exclusive_scan(l.temp, tb, l.first_flag, l.new_rank, 0, static_cast<size_t>(nn) + 1, rocprim::plus<int>(),
                               stream) != hipSuccess)
     return -2;
   // new_rank[nn] = number of new unique neighbours
-  hipLaunchKernelGGL(au_publish_kernel, dim3(1), dim3(1), 0, stream, l.new_rank + nn, nn_dev, nn, new_count_dev, publish_host);
+  hipLaunchKernelGGL(au_publish_kernel, dim3(1), dim3(1), 0, stream, l.new_rank + nn, nn_dev, nn, new_count_dev, publish_host,
+                     nt_dev, nt, bounds != nullptr ? bounds->n_unique_dev : static_cast<int*>(nullptr));
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <typename KeyT>
 int au_phase2(const void* targets, int nt, int nn, int nn_used, void* ws, void* out_unique, int* mapping, const int* copy_src,
-              int* copy_dst, hipStream_t stream)
+              int* copy_dst, const wm_au_bounds* bounds, hipStream_t stream)
 {
+  const int* nt_dev = bounds != nullptr ? bounds->n_target_dev : nullptr;
+  const int* nn_dev = bounds != nullptr ? bounds->n_neighbor_dev : nullptr;
   using UKey  = typename std::make_unsigned<KeyT>::type;
   auto l      = au_plan<UKey>(ws, nt, nn);   // the layout phase 1 used
   const int g = std::max(nt, nn_used);
   if (g > 0)
     hipLaunchKernelGGL((au_emit_kernel<UKey>), dim3((g + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.slots, l.min_pos,
                        l.slot_of, l.new_rank, nt, nn_used, static_cast<UKey*>(out_unique), mapping,
-                       static_cast<const UKey*>(targets), copy_src, copy_dst);
+                       static_cast<const UKey*>(targets), copy_src, copy_dst, nt_dev, nn_dev);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -794,7 +820,7 @@ int aus_phase1(const void* targets, int nt, const void* neighbors, int nn, void*
     return -2;
   // new_rank[nn] = number of new unique neighbours
   hipLaunchKernelGGL(au_publish_kernel, dim3(1), dim3(1), 0, stream, l.new_rank + nn, static_cast<const int*>(nullptr), nn,
-                     new_count_dev, publish_host);
+                     new_count_dev, publish_host, static_cast<const int*>(nullptr), nt, static_cast<int*>(nullptr));
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -876,7 +902,7 @@ int hip_env_test_fill(const void* in, void* out, wholememory_dtype_t dt, int64_t
 
 // ---- launchers exported to backend_hip ----
 int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const int64_t* row_pairs, const void* centers,
-                      wholememory_dtype_t id_dtype, int n, int max_sample, int* counts, void* stream_v)
+                      wholememory_dtype_t id_dtype, int n, const int* n_dev, int max_sample, int* counts, void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   gref_view rv{};
@@ -884,10 +910,10 @@ int hip_sample_counts(const wholememory_gref_t* row_gref, int64_t row_off, const
   const int blocks = (n + 1 + 127) / 128;
   if (id_dtype == WHOLEMEMORY_DT_INT)
     hipLaunchKernelGGL((sample_count_kernel<int32_t>), dim3(blocks), dim3(128), 0, stream, rv, row_off, row_pairs,
-                       static_cast<const int32_t*>(centers), n, max_sample, counts);
+                       static_cast<const int32_t*>(centers), n, n_dev, max_sample, counts);
   else if (id_dtype == WHOLEMEMORY_DT_INT64)
     hipLaunchKernelGGL((sample_count_kernel<int64_t>), dim3(blocks), dim3(128), 0, stream, rv, row_off, row_pairs,
-                       static_cast<const int64_t*>(centers), n, max_sample, counts);
+                       static_cast<const int64_t*>(centers), n, n_dev, max_sample, counts);
   else
     return -1;
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -968,6 +994,7 @@ int hip_sample_unweighted(const wm_sample_args* a, void* stream_v)
   p.centers = a->centers, p.n_center = a->n_center, p.max_sample = a->max_sample_count;
   p.seed = a->random_seed, p.offsets = a->sample_offsets;
   p.out_ids = a->out_ids, p.out_lid = a->out_center_lid, p.out_egid = a->out_edge_gid;
+  p.n_center_dev = a->n_center_dev;
   if (a->row_pairs != nullptr) {
     // positions only: row bounds come from the fetched pairs, the caller gathers the columns by edge id afterwards
     if (a->out_ids != nullptr || a->out_edge_gid == nullptr) return -1;
@@ -1014,32 +1041,38 @@ size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt)
   return dt == WHOLEMEMORY_DT_INT ? aus_plan<uint32_t>(nullptr, nt, nn).total : aus_plan<uint64_t>(nullptr, nt, nn).total;
 }
 int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, const int* nn_dev,
-                             wholememory_dtype_t dt, void* ws, int* new_count_dev, int* publish_host, void* stream_v)
+                             wholememory_dtype_t dt, void* ws, int* new_count_dev, int* publish_host, const wm_au_bounds* bounds,
+                             void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const bool table   = au_use_table(nt, nn, dt);
-  if (!table && nn_dev != nullptr) return -3;   // the sort route needs the exact count on the host
+  if (!table && (nn_dev != nullptr || bounds != nullptr)) return -3;   // the sort route needs the exact counts on the host
   if (dt == WHOLEMEMORY_DT_INT)
-    return table ? au_phase1<int32_t>(targets, nt, neighbors, nn, nn_dev, ws, new_count_dev, publish_host, stream)
+    return table ? au_phase1<int32_t>(targets, nt, neighbors, nn, nn_dev, ws, new_count_dev, publish_host, bounds, stream)
                  : aus_phase1<int32_t>(targets, nt, neighbors, nn, ws, new_count_dev, publish_host, stream);
   if (dt == WHOLEMEMORY_DT_INT64)
-    return table ? au_phase1<int64_t>(targets, nt, neighbors, nn, nn_dev, ws, new_count_dev, publish_host, stream)
+    return table ? au_phase1<int64_t>(targets, nt, neighbors, nn, nn_dev, ws, new_count_dev, publish_host, bounds, stream)
                  : aus_phase1<int64_t>(targets, nt, neighbors, nn, ws, new_count_dev, publish_host, stream);
   return -1;
 }
 int hip_append_unique_phase2(const void* targets, int nt, int nn, int nn_used, wholememory_dtype_t dt, void* ws,
-                             void* out_unique, int* mapping, const int* copy_src, int* copy_dst, void* stream_v)
+                             void* out_unique, int* mapping, const int* copy_src, int* copy_dst, const wm_au_bounds* bounds,
+                             void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const bool table   = au_use_table(nt, nn, dt);
-  if (!table && nn_used != nn) return -3;
+  if (!table && (nn_used != nn || bounds != nullptr)) return -3;
   if (dt == WHOLEMEMORY_DT_INT)
-    return table ? au_phase2<int32_t>(targets, nt, nn, nn_used, ws, out_unique, mapping, copy_src, copy_dst, stream)
+    return table ? au_phase2<int32_t>(targets, nt, nn, nn_used, ws, out_unique, mapping, copy_src, copy_dst, bounds, stream)
                  : aus_phase2<int32_t>(targets, nt, nn, ws, out_unique, mapping, copy_src, copy_dst, stream);
   if (dt == WHOLEMEMORY_DT_INT64)
-    return table ? au_phase2<int64_t>(targets, nt, nn, nn_used, ws, out_unique, mapping, copy_src, copy_dst, stream)
+    return table ? au_phase2<int64_t>(targets, nt, nn, nn_used, ws, out_unique, mapping, copy_src, copy_dst, bounds, stream)
                  : aus_phase2<int64_t>(targets, nt, nn, ws, out_unique, mapping, copy_src, copy_dst, stream);
   return -1;
+}
+bool hip_append_unique_takes_bounds(int nt, int nn, wholememory_dtype_t dt)
+{
+  return (dt == WHOLEMEMORY_DT_INT || dt == WHOLEMEMORY_DT_INT64) && au_use_table(nt, nn, dt);
 }
 int hip_csr_add_self_loop(const int* row_ptr, const int* col, int* out_row, int* out_col, int n_rows, void* stream)
 {

@@ -6,9 +6,12 @@ layouts, so cuGraph-DGL / PyG call sites keep working). The bodies are this pack
 in a helper, attributes live in one registry keyed by kind, and the multi-hop sampler is a loop over a per-hop record
 instead of four parallel lists. Extensions: ``multilayer_sample_without_replacement(..., random_seeds=[...])`` fixes the
 per-hop sampler seeds (the reference draws them from the global RNG), which is what lets tests/test_c5_flow_gpu.py replay
-the whole chain on the CPU oracle; and an unweighted hop on a CSR mapped into this rank runs as ONE library call
-(``wholegraph_ops.sample_append_unique``: sampler + append_unique with a single host round trip, same outputs).
+the whole chain on the CPU oracle; an unweighted multi-hop sample on a CSR mapped into this rank runs as ONE library call
+with ONE host round trip for all hops (``wholegraph_ops.multilayer_sample``: upper-bound-sized buffers, counts kept on the
+device, views trimmed at the end; ``WM_MULTILAYER_CHAIN=0`` switches it off), and where that does not apply a hop still runs as
+one call (``wholegraph_ops.sample_append_unique``: sampler + append_unique with a single host round trip, same outputs).
 """
+import os
 from collections import namedtuple
 from typing import List, Optional, Sequence, Union
 
@@ -108,6 +111,16 @@ class GraphStructure(object):
         if random_seeds is not None:
             assert len(random_seeds) == hops, "one seed per hop"
         layers = [None] * hops
+        if weight_name is None and hops > 0 and os.environ.get("WM_MULTILAYER_CHAIN", "1") != "0":
+            # the whole chain as one library call with a single host round trip (extension); None = not applicable to this
+            # graph or these sizes: hop by hop below then
+            chain = wholegraph_ops.multilayer_sample(self.csr_row_ptr.wmb_tensor, self.csr_col_ind.wmb_tensor, node_ids,
+                                                     max_neighbors, random_seeds)
+            if chain is not None:
+                for depth, (offsets, widened, neighbour_pos, centre_lid, edge_index) in enumerate(chain):
+                    layers[hops - 1 - depth] = _Hop(widened, edge_index, offsets, neighbour_pos)
+                return ([hop.targets for hop in layers] + [node_ids], [hop.edge_index for hop in layers],
+                        [hop.row_ptr for hop in layers], [hop.col_ind for hop in layers])
         frontier = node_ids
         for depth, fanout in enumerate(max_neighbors):          # depth 0 = next to the seeds = layer hops - 1
             seed = None if random_seeds is None else random_seeds[depth]

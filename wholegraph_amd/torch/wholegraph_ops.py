@@ -77,6 +77,59 @@ def sample_append_unique(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, center_no
     return offset, uniq.get_tensor(), pos.get_tensor(), lid.get_tensor()
 
 
+_pinned_counts = {}
+
+
+def multilayer_sample(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_tensor: torch.Tensor, max_sample_counts,
+                      random_seeds=None):
+    """Extension (wholememory_ext_multilayer_sample): every hop of an unweighted multi-layer sample in ONE library call with no
+    host round trip inside — buffers sized for their upper bounds, counts kept on the device between hops, ONE stream
+    synchronise here at the end. Returns a list with one (sample_offset, unique, neighbor_pos, center_lid) tuple per hop, hop 0
+    next to the seeds, each tensor a trimmed view of its upper-bound buffer and equal to what `sample_append_unique` returns hop
+    by hop with the same seeds — or None when the library declines (CSR not mapped into this rank, dtypes differ, empty seeds,
+    upper bounds beyond append_unique's hash-table route): run hop by hop then."""
+    row, col = _handle(wm_csr_row_ptr_tensor), _handle(wm_csr_col_ptr_tensor)
+    assert seed_nodes_tensor.dim() == 1
+    hops = len(max_sample_counts)
+    n0 = seed_nodes_tensor.shape[0]
+    if hops == 0 or n0 == 0 or any(int(m) <= 0 for m in max_sample_counts):
+        return None
+    if random_seeds is None:
+        random_seeds = [random.getrandbits(64) for _ in range(hops)]
+    cap_c, cap_s = [n0], []
+    for m in max_sample_counts:
+        cap_s.append(cap_c[-1] * int(m))
+        cap_c.append(cap_c[-1] + cap_s[-1])
+    if cap_c[-1] >= (1 << 31) - 1:
+        return None
+    dev, idt = op_device(), seed_nodes_tensor.dtype
+    offsets = [torch.empty(cap_c[h] + 1, device=dev, dtype=torch.int) for h in range(hops)]
+    uniques = [torch.empty(cap_c[h + 1], device=dev, dtype=idt) for h in range(hops)]
+    edges = [torch.empty((2, max(cap_s[h], 1)), device=dev, dtype=torch.int) for h in range(hops)]   # row 0 positions, row 1 centre ids
+    counts = _pinned_counts.get(hops)
+    if counts is None:
+        counts = _pinned_counts[hops] = torch.zeros(2 * hops, dtype=torch.int32).pin_memory()
+    fan = (C.c_int * hops)(*[int(m) for m in max_sample_counts])
+    rng = (C.c_ulonglong * hops)(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in random_seeds])
+    ptrs = lambda ts: (C.c_void_p * hops)(*[t.data_ptr() for t in ts])
+    ws = wrap_torch_tensor(seed_nodes_tensor)
+    rc = wmb.lib().wholememory_ext_multilayer_sample(
+        row, col, ws.handle, hops, fan, rng, ptrs(offsets), ptrs(uniques), ptrs([e[0] for e in edges]),
+        ptrs([e[1] for e in edges]), C.c_void_p(counts.data_ptr()), get_wholegraph_env_fns(), C.c_void_p(get_stream()))
+    if rc == wmb.NOT_SUPPORTED:
+        return None
+    wmb.check(rc)
+    torch.cuda.current_stream().synchronize()        # the one host round trip of the whole chain
+    got = counts.tolist()
+    out, n_c = [], n0
+    for h in range(hops):
+        n_samples, n_new = got[2 * h], got[2 * h + 1]
+        out.append((offsets[h][:n_c + 1], uniques[h][:n_c + n_new], edges[h][0, :n_samples], edges[h][1, :n_samples],
+                    edges[h][:, :n_samples]))
+        n_c += n_new
+    return out
+
+
 def weighted_sample_without_replacement(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, wm_csr_weight_ptr_tensor,
                                         center_nodes_tensor: torch.Tensor, max_sample_count: int,
                                         random_seed: Union[int, None] = None, need_center_local_output: bool = False,
