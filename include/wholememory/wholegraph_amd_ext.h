@@ -155,7 +155,9 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
  * widened frontier unique[h][0 .. n_c[h + 1]), neighbor_pos / center_lid the first samples[h] entries. Bit-identical to `hops`
  * calls of wholememory_ext_sample_append_unique with the same seeds. WHOLEMEMORY_NOT_SUPPORTED (nothing queued) when the CSR is
  * not mapped into this rank, the id dtypes differ, there is no seed, a fan-out is <= 0 or a hop's upper bounds exceed what
- * graph_append_unique's hash-table route takes (the caller then runs hop by hop). Reference call sequence:
+ * graph_append_unique's hash-table route takes (the caller then runs hop by hop). With sample_offsets == NULL the call is a QUERY:
+ * it answers SUCCESS / NOT_SUPPORTED for these tensors, hops and fan-outs and touches nothing else — ask before allocating the
+ * upper-bound buffers. Reference call sequence:
  * python/pylibwholegraph/pylibwholegraph/torch/graph_structure.py:140-196. */
 enum wholememory_error_code_t wholememory_ext_multilayer_sample(
   wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor, wholememory_tensor_t seed_nodes_tensor,

@@ -211,13 +211,17 @@ def test_chain_with_one_host_round_trip_equals_hop_by_hop(gpu_env, monkeypatch, 
 
 
 def test_chain_declines_upper_bounds_beyond_the_table_route(gpu_env):
-    """65536 seeds x [30, 30]: the second hop's upper bound (2 M centres + 61 M samples) is past what append_unique's hash
-    table takes from device-side counts: the library answers NOT_SUPPORTED before queueing anything and the caller goes hop by hop."""
+    """65536 seeds x [30, 30, 30]: the third hop's upper bound (63 M centres + 1.9 G samples) is past what append_unique's hash
+    table takes from device-side counts: the library answers NOT_SUPPORTED to the query, before any buffer is allocated or
+    anything queued, and the caller goes hop by hop. 65536 x [30, 30] (63 M keys at most) is taken."""
     import torch
     import wholegraph_amd.torch as wgth
     from wholegraph_amd.torch import wholegraph_ops
     row_ptr, col = make_csr(5003, 20, 3, np.int32)
     wrow, wcol = _wm_array(gpu_env, "chunked", row_ptr), _wm_array(gpu_env, "chunked", col)
     seeds = torch.randint(0, 5003, (65536,), dtype=torch.int32, device="cuda")
-    assert wholegraph_ops.multilayer_sample(wrow.wmb_tensor, wcol.wmb_tensor, seeds, [30, 30], [1, 2]) is None
+    free0 = torch.cuda.mem_get_info()[0]
+    assert wholegraph_ops.multilayer_sample(wrow.wmb_tensor, wcol.wmb_tensor, seeds, [30, 30, 30], [1, 2, 3]) is None
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20), "a declined chain must not have allocated its buffers"
     assert wholegraph_ops.multilayer_sample(wrow.wmb_tensor, wcol.wmb_tensor, seeds[:0], [5], [1]) is None
+    assert wholegraph_ops.multilayer_sample(wrow.wmb_tensor, wcol.wmb_tensor, seeds[:4096], [30, 30], [1, 2]) is not None

@@ -523,8 +523,12 @@ wholememory_error_code_t wholememory_ext_multilayer_sample(
   WM_API_BEGIN
   const auto* bk = graph_backend();
   if (bk == nullptr || bk->append_unique_takes_bounds == nullptr) return WHOLEMEMORY_NOT_SUPPORTED;
-  if (p_env_fns == nullptr || hops <= 0 || hops > 16 || max_sample_counts == nullptr || random_seeds == nullptr ||
-      sample_offsets == nullptr || unique == nullptr || neighbor_pos == nullptr || center_lid == nullptr || counts_host == nullptr)
+  // sample_offsets == nullptr: a QUERY — would this chain be taken? (SUCCESS / NOT_SUPPORTED, nothing queued, no buffer needed:
+  // the caller asks before it allocates the upper-bound buffers)
+  const bool query = sample_offsets == nullptr;
+  if (hops <= 0 || hops > 16 || max_sample_counts == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (!query && (p_env_fns == nullptr || random_seeds == nullptr || unique == nullptr || neighbor_pos == nullptr ||
+                 center_lid == nullptr || counts_host == nullptr))
     return WHOLEMEMORY_INVALID_INPUT;
   wholememory_error_code_t err = WHOLEMEMORY_SUCCESS;
   wholememory_array_description_t row_desc, col_desc, seed_desc;
@@ -547,6 +551,7 @@ wholememory_error_code_t wholememory_ext_multilayer_sample(
         !bk->append_unique_takes_bounds(static_cast<int>(cap_c[h]), static_cast<int>(cap_s[h]), seed_desc.dtype))
       return WHOLEMEMORY_NOT_SUPPORTED;
   }
+  if (query) return WHOLEMEMORY_SUCCESS;
   wm_sample_args a{};
   WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_row_ptr_tensor, &a.row_gref));
   WHOLEMEMORY_RETURN_ON_FAIL(tensor_mapped_gref(wm_csr_col_ptr_tensor, &a.col_gref));

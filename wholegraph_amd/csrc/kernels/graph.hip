@@ -842,17 +842,19 @@ int aus_phase2(const void* targets, int nt, int nn, void* ws, void* out_unique, 
 }
 
 
-// which route (experiments/au_crossover.py, whole calls): 32-bit ids — the table wins up to ~2 M keys (950 k: 0.21 vs 0.31 ms)
-// and loses from 4 M on (0.68 vs 0.60 ms; 23 M: 2.84 vs 2.39 ms) once it no longer sits in the caches; 64-bit ids — the sort
-// moves twice the key bytes through twice the passes and the table wins or ties up to the largest size measured (23 M: 3.02 vs
-// 3.12 ms). WM_AU_TABLE_MAX overrides the key-count limit for both (measurements).
+// which route (experiments/au_crossover.py, whole calls). 64-bit ids: the sort moves twice the key bytes through twice the
+// passes and the table wins or ties up to the largest size measured (23 M: 3.02 vs 3.12 ms): the table serves up to 24 M keys.
+// 32-bit ids, round 2 (id and smallest position in two arrays, two atomics per new id): the table won up to ~2 M keys only.
+// Round 3 (one 64-bit word per slot, one atomic per new id): it wins at every size measured — 950 k keys 0.139 vs 0.260 ms,
+// 4.2 M 0.42 vs 0.54, 16.8 M 1.52 vs 2.05, 23.4 M 2.01 vs 2.46 ms, and the 65 536-seed C5 step (a 37 M-key second hop) 10.15
+// vs 11.0 ms — so it serves up to 128 M keys (a 2 GiB table). WM_AU_TABLE_MAX overrides the limit for both widths.
 inline bool au_use_table(int nt, int nn, wholememory_dtype_t dt)
 {
   static const int64_t forced = [] {
     const char* e = getenv("WM_AU_TABLE_MAX");
     return e != nullptr ? static_cast<int64_t>(atoll(e)) : INT64_C(-1);
   }();
-  const int64_t limit = forced >= 0 ? forced : (dt == WHOLEMEMORY_DT_INT ? INT64_C(2) << 20 : INT64_C(24) << 20);
+  const int64_t limit = forced >= 0 ? forced : (dt == WHOLEMEMORY_DT_INT ? INT64_C(128) << 20 : INT64_C(24) << 20);
   return static_cast<int64_t>(nt) + nn <= limit;
 }
 

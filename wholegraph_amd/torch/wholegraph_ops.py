@@ -102,6 +102,12 @@ def multilayer_sample(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_t
         cap_c.append(cap_c[-1] + cap_s[-1])
     if cap_c[-1] >= (1 << 31) - 1:
         return None
+    fan = (C.c_int * hops)(*[int(m) for m in max_sample_counts])
+    ws = wrap_torch_tensor(seed_nodes_tensor)
+    # ask first (no buffers yet: the upper bounds of a declined chain can be tens of GB)
+    if wmb.lib().wholememory_ext_multilayer_sample(row, col, ws.handle, hops, fan, None, None, None, None, None, None, None,
+                                                   None) == wmb.NOT_SUPPORTED:
+        return None
     dev, idt = op_device(), seed_nodes_tensor.dtype
     offsets = [torch.empty(cap_c[h] + 1, device=dev, dtype=torch.int) for h in range(hops)]
     uniques = [torch.empty(cap_c[h + 1], device=dev, dtype=idt) for h in range(hops)]
@@ -109,10 +115,8 @@ def multilayer_sample(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_t
     counts = _pinned_counts.get(hops)
     if counts is None:
         counts = _pinned_counts[hops] = torch.zeros(2 * hops, dtype=torch.int32).pin_memory()
-    fan = (C.c_int * hops)(*[int(m) for m in max_sample_counts])
     rng = (C.c_ulonglong * hops)(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in random_seeds])
     ptrs = lambda ts: (C.c_void_p * hops)(*[t.data_ptr() for t in ts])
-    ws = wrap_torch_tensor(seed_nodes_tensor)
     rc = wmb.lib().wholememory_ext_multilayer_sample(
         row, col, ws.handle, hops, fan, rng, ptrs(offsets), ptrs(uniques), ptrs([e[0] for e in edges]),
         ptrs([e[1] for e in edges]), C.c_void_p(counts.data_ptr()), get_wholegraph_env_fns(), C.c_void_p(get_stream()))
