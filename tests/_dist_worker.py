@@ -296,6 +296,48 @@ def scenario_sgd16(comm, rank, world, tdt, dim, lr, wd, mt="distributed"):
     wgth.destroy_embedding(emb)
 
 
+def scenario_tree_fold(comm, rank, world, mt, kind, params):
+    """WM_GRAD_FOLD=tree over several ranks (HIP mode): duplicates of a hot id arrive from every rank (a run of several
+    segments at its owner, self rows read in place beside received ones); gradients are integer-valued, so the tree's sums are
+    exact and table + states must equal the ordered multi-rank oracle bit for bit."""
+    n_rows, dim, steps = 2003, 64, 2
+    os.environ["WM_GRAD_FOLD"] = "tree"
+    emb = wgth.create_embedding(comm, mt, "cuda", torch.float32, [n_rows, dim])
+    stride = emb.get_embedding_tensor().stride()[0]
+    init = np.random.default_rng(31).standard_normal((n_rows, dim)).astype(np.float32)
+    padded = np.zeros((n_rows, stride), dtype=np.float32)
+    padded[:, :dim] = init
+    tab = oracle.ShardedTable.from_full(padded, world, None)
+    tab.dim = dim
+    local, start = emb.get_embedding_tensor().get_local_tensor()
+    cnt = int(tab.entry_offsets[rank + 1] - tab.entry_offsets[rank])
+    local.copy_(dev(torch.from_numpy(init[start:start + cnt])))
+    torch.cuda.synchronize()
+    comm.barrier()
+    opt = wgth.create_wholememory_optimizer(emb, kind, params)
+    ref_opts = [oracle.Optimizer(kind, int(tab.entry_offsets[r + 1] - tab.entry_offsets[r]), stride, **params) for r in range(world)]
+    for step in range(steps):
+        rank_idx, rank_grads = [], []
+        for r in range(world):
+            g = np.random.default_rng(900 * step + r)
+            ix = g.integers(0, n_rows, 5000 + 17 * r).astype(np.int64)
+            ix[::2] = 5 + step              # ~2500 duplicates per rank of one id
+            ix[1::10] = n_rows - 3          # ~500 per rank of another (one segment at world 1, several at world 3)
+            rank_idx.append(ix)
+            rank_grads.append(g.integers(-2, 3, (len(ix), dim)).astype(np.float32))
+        emb.add_gradients(dev(torch.from_numpy(rank_idx[rank])), dev(torch.from_numpy(rank_grads[rank])))
+        emb.need_apply = True
+        opt.step(0.05)
+        oracle.gradient_apply(tab, ref_opts, rank_idx, rank_grads, 0.05)
+        torch.cuda.synchronize()
+        assert host(local).numpy().tobytes() == tab.shards[rank][:cnt, :dim].tobytes(), \
+            "tree fold (%s, %s) mismatch on rank %d step %d" % (kind, mt, rank, step)
+    comm.barrier()
+    del os.environ["WM_GRAD_FOLD"]
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)
+
+
 def scenario_cached_embedding(comm, rank, world, mt):
     """HOST embedding with a read-write device cache on every rank (HIP mode): owners serve lookups cache-first through
     the exchange, train through the cache, write back. Bit-exact vs the uncached multi-rank oracle."""
@@ -579,6 +621,7 @@ def rccl_scenarios(comm, rank, world):
                              ("rmsprop", {"alpha": 0.95})]:
             scenario_gradient_apply(comm, rank, world, kind, params, np.int64, None, mt=mt5)
         scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0, mt=mt5)
+    scenario_tree_fold(comm, rank, world, "distributed", "rmsprop", {"alpha": 0.95})
     scenario_sampling(comm, rank, world, "distributed", np.int64)
     scenario_cached_embedding(comm, rank, world, "distributed")
     scenario_file_io(comm, rank, world, "/tmp/wgamd_test_rccl_%s" % os.environ["MASTER_PORT"])
@@ -724,6 +767,8 @@ def main():
             scenario_gradient_apply(comm, rank, world, kind, params, np.int32 if (j + k) % 2 else np.int64,
                                     gent if (j + k) % 2 == 0 else None, mt=mt5, loc=loc5)
     if HIP_MODE:
+        scenario_tree_fold(comm, rank, world, "distributed", "sgd", {"weight_decay": 0.0})
+        scenario_tree_fold(comm, rank, world, "continuous", "adam", {"weight_decay": 0.01})
         scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0, mt="continuous")
         scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0, mt="chunked")
         scenario_sgd16(comm, rank, world, torch.bfloat16, 40, 0.05, 0.01, mt="continuous")

@@ -513,3 +513,47 @@ def test_tree_fold_is_the_default_of_the_16bit_extension_and_deterministic(gpu_e
     np.add.at(want, ids, grads.astype(np.float64))
     assert np.array_equal(results[0], results[1])
     assert np.array_equal(results[0].astype(np.float64), want.astype(np.float16).astype(np.float64))
+
+
+@pytest.mark.parametrize("kind,code,params", [("adam", 2, {"weight_decay": 0.01}), ("adam", 2, {"weight_decay": 0.02, "adam_w": 1.0}),
+                                              ("rmsprop", 3, {"alpha": 0.9}), ("adagrad", 4, {"weight_decay": 0.01})])
+@pytest.mark.parametrize("dim,idt", [(128, np.int64), (36, np.int32)])
+def test_tree_fold_stateful_optimizers_exact_on_integer_gradients(gpu_env, monkeypatch, kind, code, params, dim, idt):
+    """The tree fold in front of the stateful optimizers: with integer-valued gradients the folded sums are exact, so table
+    AND optimizer states must equal the ordered oracle bit for bit over several steps (long runs of one and of several
+    segments, LazyAdam's per-row beta powers advanced once per listed run)."""
+    import torch
+    from wholegraph_amd import binding as wmb
+    monkeypatch.setenv("WM_GRAD_FOLD", "tree")
+    rng = np.random.default_rng(dim + code)
+    local_rows, local_off, n_recv = 3001, 777, 60_000
+    stride = int(oracle.align_embedding_dim(dim, 4))
+    table = np.zeros((local_rows, stride), np.float32)
+    table[:, :dim] = rng.standard_normal((local_rows, dim)).astype(np.float32)
+    ids = (local_off + _run_mix(rng, n_recv, local_rows, hot=[9000, 2500])).astype(idt)
+    p = dict(weight_decay=0.0, epsilon=1e-8, beta1=0.9, beta2=0.999, alpha=0.99, adam_w=0.0)
+    p.update(params)
+    ref_opt = oracle.Optimizer(kind, local_rows, stride, **params)
+    d_table = torch.from_numpy(table.copy()).cuda()
+    d_pr = torch.ones((local_rows, 2), device="cuda") if kind == "adam" else None
+    d_pe = torch.zeros((local_rows, (2 if kind == "adam" else 1) * stride), device="cuda")
+    arr = (C.c_float * 6)(p["weight_decay"], p["epsilon"], p["beta1"], p["beta2"], p["alpha"], p["adam_w"])
+    env, stream = _env()
+    ref_table = table.copy()
+    d_ids = torch.from_numpy(ids).cuda()
+    for step in range(3):
+        grads = rng.integers(-2, 3, (n_recv, dim)).astype(np.float32)
+        d_grads = torch.from_numpy(grads).cuda()
+        nu = C.c_int64(-1)
+        wmb.check(wmb.lib().wholememory_ext_dedup_apply(
+            d_ids.data_ptr(), wmb.DT_INT if idt == np.int32 else wmb.DT_INT64, n_recv, d_grads.data_ptr(), dim, dim,
+            d_table.data_ptr(), stride, local_off, local_rows, code, arr, 0.03, d_pe.data_ptr(),
+            d_pr.data_ptr() if d_pr is not None else None, C.byref(nu), env, stream))
+        torch.cuda.synchronize()
+        uniq, dg = oracle.dedup_grads(ids, grads)
+        assert nu.value == len(uniq)
+        ref_opt.step(uniq, dg, ref_table, stride, local_off, dim, 0.03)
+        assert d_table.cpu().numpy().tobytes() == ref_table.tobytes(), "%s step %d: table differs" % (kind, step)
+    assert d_pe.cpu().numpy().tobytes() == ref_opt.per_element.tobytes()
+    if kind == "adam":
+        assert d_pr.cpu().numpy().tobytes() == ref_opt.per_row.tobytes()
