@@ -6,20 +6,23 @@
 //   scatter: table[idx[i], c]     = cast(plain[row_map(i), c])
 //
 // MI355X design (NOT the reference's warp-per-row + smem staging):
-//  * a wave owns a TILE of 64 consecutive entries: one coalesced 512 B (int64) index load, each
-//    lane resolves ITS entry's owner rank / byte address once (the reference re-derives the rank
-//    with a 64-bit divide per element access, device_reference.cuh:47);
-//  * the tile is then streamed in "steps": LPR = lanes per row (power of two covering
-//    row_bytes / vector bytes, <= 64), 64/LPR rows per step, each lane moving one 16-byte vector
-//    (global_load_dwordx4 / global_store_dwordx4). A 512 B fp32 row is 32 lanes x 16 B, so a step
-//    moves two whole rows as one 1 KiB wave transaction; row base addresses travel between lanes
-//    with v_readlane (fast path) or ds_bpermute (generic path): no LDS allocation, no barriers;
-//  * several steps of loads are issued before the first store, so each wave keeps 4-8 KiB of
-//    random HBM reads in flight (Little's law: ~10 MB chip-wide are needed to cover ~2 us of
-//    loaded HBM latency at 5-6 TB/s; 4 KiB x 32 waves x 256 CUs = 32 MiB);
-//  * the streamed side (gather output / scatter input) is touched exactly once, so gather stores
-//    are non-temporal to keep L2 / Infinity Cache for table rows (which DO repeat under skew);
-//  * grid = min(tiles/4, 8 x 256 CUs) workgroups of 4 waves, grid-stride over tiles.
+//  * a wave owns a TILE of consecutive entries: one coalesced index load, each lane resolves ITS
+//    entry's owner rank / byte address once (the reference re-derives the rank with a 64-bit divide
+//    per element access, device_reference.cuh:47);
+//  * the tile is moved in wave "steps" of 16 bytes per lane (global_load_dwordx4 /
+//    global_store_dwordx4): a 512 B fp32 row is 32 lanes x 16 B, so a step moves two whole rows as
+//    one 1 KiB wave transaction; row base addresses travel between lanes with v_readlane (fast /
+//    batch kernels) or ds_bpermute (generic and flat kernels): no LDS allocation, no barriers;
+//  * all loads of a batch (4 steps = 4 KiB per wave) are issued before its first store (Little's
+//    law: ~10 MB chip-wide are needed to cover ~2 us of loaded HBM latency at 5-6 TB/s);
+//  * the streamed side (gather output / scatter input) is touched exactly once: non-temporal on
+//    both sides, which keeps L2 / Infinity Cache for table rows (which DO repeat under skew);
+//  * launch shape (round 3, see rows_op): IN ORDER — one ~4 KiB tile per wave and as many workgroups
+//    as that takes, handed out in order by the dispatcher, so that the tiles in flight are one
+//    compact window advancing through the streamed side. Rounds 1-2 ran a persistent grid
+//    (min(tiles/4, 32 x CUs) workgroups, grid-stride over 64-row tiles), whose scattered write front
+//    made the kernel's speed depend on the physical placement of the buffers; that shape remains
+//    for callers that cap the grid (gather_sms / scatter_sms) and for two kernels that need it.
 // The path is HBM-bound byte movement: there is no contraction here and MFMA is not used.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
