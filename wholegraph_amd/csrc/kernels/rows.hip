@@ -168,16 +168,17 @@ __global__ __launch_bounds__(kBlock) void rows_copy_kernel(rows_params p)
   const int rps       = kWave >> p.lpr_log2;  // rows per step
   const int sub       = lane >> p.lpr_log2;   // which row of the step this lane serves
   const int col       = lane & (lpr - 1);
-  const int64_t tiles = (p.n + kWave - 1) / kWave;
+  const int tile_rows = p.tile_rows;   // 64, or fewer (a multiple of rps * kU) for in-order launches of big rows
+  const int64_t tiles = (p.n + tile_rows - 1) / tile_rows;
 
   for (int64_t tile = wave; tile < tiles; tile += n_waves) {
     char *my_tab, *my_plain;
-    load_tile_entry<IdxT>(p, tile * kWave + lane, my_tab, my_plain);
+    load_tile_entry<IdxT>(p, lane < tile_rows ? tile * tile_rows + lane : p.n, my_tab, my_plain);
     for (int cbase = 0; cbase < p.row_vecs; cbase += lpr) {  // >1 trip only when a row needs > 64 vectors
       const int c        = cbase + col;
       const bool col_ok  = c < p.row_vecs;
       const int64_t coff = static_cast<int64_t>(c) * VB;
-      for (int s0 = 0; s0 < kWave; s0 += rps * kU) {
+      for (int s0 = 0; s0 < tile_rows; s0 += rps * kU) {
         vec_t data[kU];
         char* dst[kU];
 #pragma unroll
@@ -642,16 +643,17 @@ __global__ __launch_bounds__(kBlock) void rows_convert_kernel(rows_params p)
   const int rps       = kWave >> p.lpr_log2;
   const int sub       = lane >> p.lpr_log2;
   const int col       = lane & (lpr - 1);
-  const int64_t tiles = (p.n + kWave - 1) / kWave;
+  const int tile_rows = p.tile_rows;   // 64, or fewer (a multiple of rps * kU) for in-order launches of big rows
+  const int64_t tiles = (p.n + tile_rows - 1) / tile_rows;
   constexpr int kU    = 4;
 
   for (int64_t tile = wave; tile < tiles; tile += n_waves) {
     char *my_tab, *my_plain;
-    load_tile_entry<IdxT>(p, tile * kWave + lane, my_tab, my_plain);
+    load_tile_entry<IdxT>(p, lane < tile_rows ? tile * tile_rows + lane : p.n, my_tab, my_plain);
     for (int cbase = 0; cbase < p.row_vecs; cbase += lpr) {
       const int c       = cbase + col;
       const bool col_ok = c < p.row_vecs;
-      for (int s0 = 0; s0 < kWave; s0 += rps * kU) {
+      for (int s0 = 0; s0 < tile_rows; s0 += rps * kU) {
         elt_vec<FromT, V> data[kU];
         char* dst[kU];
 #pragma unroll
@@ -746,6 +748,18 @@ bool pieces_wanted(bool gather, int64_t row_bytes)
   (void)gather;
   (void)row_bytes;
   return false;
+}
+
+// rows per wave tile of rows_copy_kernel / rows_convert_kernel when they are launched in order: about 4 KiB of the (wider) row
+// side, a power of two between one batch of the kernel (rps x 4 rows) and 64. WM_ROWS_SMALL_TILE=0 keeps 64-row tiles (A/B).
+int small_tile_rows(int lpr_log2, int64_t row_bytes)
+{
+  const char* e = getenv("WM_ROWS_SMALL_TILE");
+  if (e != nullptr && e[0] == '0') return kWave;
+  const int batch = (kWave >> lpr_log2) * 4;
+  int t           = kWave;
+  while (t > batch && static_cast<int64_t>(t) * row_bytes > 4096) t >>= 1;
+  return std::max(t, std::min(batch, kWave));
 }
 
 // 0 = never, 1 = always when legal, -1 (default) = by the measured rule in want_flat()
@@ -1055,6 +1069,10 @@ int rows_op(const wm_rows_args* a, void* stream_v)
       if ((forced == 8 || forced == 16 || forced == 32 || forced == 64) && (p.flat_slots > 0 || forced % 8 == 0)) p.tile_rows = forced;
       blocks = grid_for(p.tile_rows);
     }
+    if (inorder && p.stage_rows == 0 && p.flat_slots == 0 && !(vb == 16 && p.row_vecs >= 32)) {   // rows_copy_kernel
+      p.tile_rows = small_tile_rows(p.lpr_log2, row_bytes);
+      blocks      = grid_for(p.tile_rows);
+    }
     if (a->index_dtype == WHOLEMEMORY_DT_INT)
       launch_copy<int32_t, GATHER>(p, static_cast<int>(vb), blocks, stream);
     else
@@ -1068,6 +1086,10 @@ int rows_op(const wm_rows_args* a, void* stream_v)
     while (v > 1 && ((tab_base % (v * tes)) != 0 || (reinterpret_cast<uint64_t>(p.plain) % (v * pes)) != 0)) v >>= 1;
     p.row_vecs = static_cast<int>(a->dim / v);
     p.lpr_log2 = std::min(6, ilog2_ceil(p.row_vecs));
+    if (inorder) {   // rows_convert_kernel: ~4 KiB of the wider side per wave
+      p.tile_rows = small_tile_rows(p.lpr_log2, a->dim * std::max(tes, pes));
+      blocks      = grid_for(p.tile_rows);
+    }
     if (!launch_convert<GATHER>(p, a->table_dtype, a->plain_dtype, a->index_dtype, static_cast<int>(v), blocks, stream))
       return -1;
   }
