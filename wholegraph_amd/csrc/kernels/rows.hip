@@ -22,7 +22,10 @@
 //    compact window advancing through the streamed side. Rounds 1-2 ran a persistent grid
 //    (min(tiles/4, 32 x CUs) workgroups, grid-stride over 64-row tiles), whose scattered write front
 //    made the kernel's speed depend on the physical placement of the buffers; that shape remains
-//    for callers that cap the grid (gather_sms / scatter_sms) and for two kernels that need it.
+//    for callers that cap the grid (gather_sms / scatter_sms) and for the flat-stream scatter;
+//  * rows that are not powers of two: the flat-stream kernel (slots of 16 bytes over a tile's rows), and where the dense
+//    side is contiguous the LDS-staged kernels (rows_staged_gather_kernel / rows_staged_scatter_kernel): the dense side of
+//    a chunk of rows moves as one aligned 16-byte stream through the wave's own LDS region.
 // The path is HBM-bound byte movement: there is no contraction here and MFMA is not used.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -513,8 +516,9 @@ __global__ __launch_bounds__(kBlock) void rows_pieces_kernel(rows_params p)
 // the table, dword LDS writes) and leave as aligned 16-byte non-temporal stores of the contiguous stream. Each wave has
 // its own LDS region: no workgroup barrier, only the wave's own LDS ordering. A chunk with a skipped entry (negative id, or
 // past the end of the batch) must not touch that entry's output row: such chunks take the per-row path (dword stores).
-constexpr int kStageIters = 5;  // 16-byte slots per lane per chunk: chunks of up to 5 KiB (5 x 64 x 16 B)
-template <typename IdxT>
+// kStageIters = 16-byte slots per lane per chunk: chunks of up to 5 KiB (5 x 64 x 16 B), or 10 KiB for the rows whose
+// smallest aligned group (2 or 4 rows) does not fit 5 KiB
+template <typename IdxT, int kStageIters>
 __global__ __launch_bounds__(kBlock) void rows_staged_gather_kernel(rows_params p)
 {
   extern __shared__ __attribute__((aligned(16))) char staged_lds[];
@@ -584,6 +588,90 @@ __global__ __launch_bounds__(kBlock) void rows_staged_gather_kernel(rows_params 
           if (t == nullptr) continue;                         // wave-uniform
           char* q = out + r * static_cast<int64_t>(row_bytes);
           for (int w = lane; w < (row_bytes >> 2); w += kWave) st_global<uint32_t>(q + 4 * w, ld_global<uint32_t>(t + 4 * w));
+        }
+      }
+    }
+  }
+}
+
+// The mirror for SCATTER (round 3): the dense INPUT rows are the misaligned side. A chunk of R consecutive input rows is one
+// contiguous, 16-byte aligned piece: it enters LDS with aligned 16-byte non-temporal loads, and every table row is then
+// written as whole aligned 16-byte pieces (+ its dword tail) assembled from dword LDS reads at the row's dense offset.
+// Entries with a negative id are simply not written (the dense side is only read); a chunk that reaches past the end of
+// the batch takes the per-row path so that nothing is read behind the input.
+template <typename IdxT, int kStageIters>
+__global__ __launch_bounds__(kBlock) void rows_staged_scatter_kernel(rows_params p)
+{
+  extern __shared__ __attribute__((aligned(16))) char staged_lds[];
+  const int lane        = threadIdx.x & (kWave - 1);
+  const int wave_in_blk = threadIdx.x >> 6;
+  const int64_t wave    = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  const int tile_rows   = p.tile_rows;
+  const int64_t tiles   = (p.n + tile_rows - 1) / tile_rows;
+  const int R           = p.stage_rows;
+  const int S           = p.flat_slots;
+  const int row_bytes   = (S - 1) * 16 + p.flat_tail;
+  const int chunk_bytes = R * row_bytes;
+  const int chunk_slots = R * S;
+  const int chunk_vecs  = chunk_bytes >> 4;
+  char* const lds       = staged_lds + wave_in_blk * ((chunk_bytes + 15) & ~15);
+  const int tail_words  = p.flat_tail >> 2;
+
+  for (int64_t tile = wave; tile < tiles; tile += n_waves) {
+    char *my_tab, *my_plain;
+    load_tile_entry<IdxT>(p, lane < tile_rows ? tile * tile_rows + lane : p.n, my_tab, my_plain);
+    const uint64_t present = __ballot(my_tab != nullptr);
+    for (int r0 = 0; r0 < tile_rows; r0 += R) {
+      const uint64_t chunk_mask = (R == 64 ? ~0ull : ((1ull << R) - 1)) << r0;
+      if ((present & chunk_mask) == 0) continue;
+      const int64_t e0     = tile * tile_rows + r0;
+      const char* const in = p.plain + e0 * static_cast<int64_t>(row_bytes);
+      if (e0 + R <= p.n) {
+        // ---- dense input -> LDS, aligned 16-byte pieces of the contiguous stream
+        u32x4 d[kStageIters];
+#pragma unroll
+        for (int i = 0; i < kStageIters; i++) {
+          const int v = lane + i * kWave;
+          if (v < chunk_vecs) d[i] = ld_global_nt<u32x4>(in + v * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < kStageIters; i++) {
+          const int v = lane + i * kWave;
+          if (v < chunk_vecs) *reinterpret_cast<u32x4*>(lds + v * 16) = d[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- LDS -> table rows: slot v of the chunk = row v / S, piece v % S
+#pragma unroll
+        for (int i = 0; i < kStageIters; i++) {
+          const int v = min(lane + i * kWave, chunk_slots - 1);   // clamped: the broadcast below needs every lane
+          const int r = static_cast<int>(static_cast<float>(v) * p.flat_rcp);
+          int row = r, col = v - r * S;
+          if (col < 0) row--, col += S;
+          if (col >= S) row++, col -= S;
+          char* t = shfl_ptr(my_tab, r0 + row);
+          if (lane + i * kWave < chunk_slots && t != nullptr) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(lds + row * row_bytes + col * 16);
+            if (col < S - 1 || tail_words == 4) {
+              u32x4 x;
+              x[0] = src[0], x[1] = src[1], x[2] = src[2], x[3] = src[3];
+              st_global_nt<u32x4>(t + col * 16, x);
+            } else {
+#pragma unroll
+              for (int w = 0; w < 3; w++)
+                if (w < tail_words) st_global<uint32_t>(t + col * 16 + 4 * w, src[w]);
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();                      // the next chunk overwrites the region
+      } else {
+        for (int r = 0; r < R && e0 + r < p.n; r++) {
+          char* t = shfl_ptr(my_tab, r0 + r);
+          if (t == nullptr) continue;                         // wave-uniform
+          const char* q = in + r * static_cast<int64_t>(row_bytes);
+          for (int w = lane; w < (row_bytes >> 2); w += kWave) st_global<uint32_t>(t + 4 * w, ld_global<uint32_t>(q + 4 * w));
         }
       }
     }
@@ -769,6 +857,29 @@ int flat_override()
   return e == nullptr ? -1 : atoi(e);
 }
 
+// WM_ROWS_STAGED_SCATTER=0 switches the LDS-staged scatter off (A/B: the flat-stream kernel then)
+bool staged_scatter_enabled()
+{
+  const char* e = getenv("WM_ROWS_STAGED_SCATTER");
+  return e == nullptr || e[0] != '0';
+}
+// longest row the staged kernels take (WM_ROWS_STAGED_MAXROW overrides, A/B)
+int64_t staged_max_row(bool gather)
+{
+  const char* e = getenv("WM_ROWS_STAGED_MAXROW");
+  if (e != nullptr && atoll(e) > 0) return atoll(e);
+  (void)gather;
+  return 5120;
+}
+// rows of whole 16-byte pieces (no tail) that the flat-stream kernel would take: through the staged kernel too? Measured
+// (profiles/r03_dim_sweep_staged_aligned.csv): scatter +1.3 ... +4.3 points on every shape from 400 B to 4000 B, gather mixed
+// (+4.7 at 400 B and 1600 B, -6.3 at 4000 B) -> yes for the scatter, no for the gather. WM_ROWS_STAGED_ALIGNED=0 / 1 forces.
+bool staged_aligned_rows(bool gather)
+{
+  const char* e = getenv("WM_ROWS_STAGED_ALIGNED");
+  if (e != nullptr && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return !gather;
+}
 // WM_ROWS_STAGED=0 switches the LDS-staged gather off (A/B)
 bool staged_enabled()
 {
@@ -813,14 +924,26 @@ void launch_flat(const rows_params& p, int blocks, hipStream_t stream)
 template <typename IdxT, bool GATHER>
 void launch_copy(const rows_params& p, int vb, int blocks, hipStream_t stream)
 {
-  if constexpr (GATHER) {
-    if (p.stage_rows > 0) {
-      const int row_bytes   = (p.flat_slots - 1) * 16 + p.flat_tail;
-      const size_t lds      = static_cast<size_t>(p.launch_threads / kWave) * ((static_cast<size_t>(p.stage_rows) * row_bytes + 15) & ~size_t(15));
-      t_last_rows_kernel    = reinterpret_cast<const void*>(rows_staged_gather_kernel<IdxT>);
-      hipLaunchKernelGGL(rows_staged_gather_kernel<IdxT>, dim3(blocks), dim3(p.launch_threads), lds, stream, p);
-      return;
-    }
+  if (p.stage_rows > 0) {
+    const int row_bytes   = (p.flat_slots - 1) * 16 + p.flat_tail;
+    const size_t lds      = static_cast<size_t>(p.launch_threads / kWave) * ((static_cast<size_t>(p.stage_rows) * row_bytes + 15) & ~size_t(15));
+    const bool big = static_cast<size_t>(p.stage_rows) * row_bytes > 5120;   // chunks of up to 10 KiB
+#define WM_STAGED(KERNEL)                                                                                   \
+  do {                                                                                                      \
+    if (big) {                                                                                              \
+      t_last_rows_kernel = reinterpret_cast<const void*>(KERNEL<IdxT, 10>);                                 \
+      hipLaunchKernelGGL((KERNEL<IdxT, 10>), dim3(blocks), dim3(p.launch_threads), lds, stream, p);         \
+    } else {                                                                                                \
+      t_last_rows_kernel = reinterpret_cast<const void*>(KERNEL<IdxT, 5>);                                  \
+      hipLaunchKernelGGL((KERNEL<IdxT, 5>), dim3(blocks), dim3(p.launch_threads), lds, stream, p);          \
+    }                                                                                                       \
+  } while (0)
+    if constexpr (GATHER)
+      WM_STAGED(rows_staged_gather_kernel);
+    else
+      WM_STAGED(rows_staged_scatter_kernel);
+#undef WM_STAGED
+    return;
   }
   if (p.flat_slots > 0) {
     launch_flat<IdxT, GATHER>(p, blocks, stream);
@@ -970,10 +1093,11 @@ int rows_op(const wm_rows_args* a, void* stream_v)
   // output buffer (its 8192 resident waves each own a 32 KiB tile and the 8192 workgroups sweep the output four times, so
   // the 64-byte write requests of one DRAM page arrive spread over microseconds; a physically contiguous buffer: always
   // slow), the in-order shape at 1.64-1.73 ms on every buffer of every process, the contiguous one included.
-  // WM_ROWS_INORDER: 0 = never, 1 = every kernel, unset = the measured rule: every kernel except the two whose per-tile set-up
-  // is too heavy for 4 KiB tiles — the flat-stream SCATTER (profiles/r03_dim_sweep_inorder_ab.csv: 1200 B rows 62 vs 70 % of
-  // peak, 516 B 46 vs 51 %, 2408 B 57 vs 60 %; the flat gather gains: 800 B 69 vs 65 %, 2408 B 66 vs 61 %) and the
-  // LDS-staged gather (516 B: 61 vs 65 %). Those two keep the persistent launch.
+  // WM_ROWS_INORDER: 0 = never, 1 = every kernel, unset = the measured rule: every kernel except the flat-stream SCATTER, whose
+  // per-tile set-up is too heavy for 4 KiB tiles (profiles/r03_dim_sweep_inorder_ab.csv: 1200 B rows 62 vs 70 % of peak,
+  // 516 B 46 vs 51 %, 2408 B 57 vs 60 %; the flat gather gains: 800 B 69 vs 65 %, 2408 B 66 vs 61 %) — it keeps the persistent
+  // launch where it is still used. The LDS-staged kernels run in order, one chunk per wave (measured twice on different
+  // boxes, profiles/r03_dim_sweep_staged_scatter.csv: gather +6 ... +10 points, scatter +2 ... +3.5 over the persistent grid).
   const int inorder_mode = inorder_setting();
   bool inorder           = a->max_blocks <= 0 && inorder_mode != 0;
   p.launch_threads       = inorder ? inorder_block_threads() : kBlock;
@@ -1013,22 +1137,32 @@ int rows_op(const wm_rows_args* a, void* stream_v)
         p.launch_threads = kBlock;
       }
     }
-    // LDS-staged gather: dense output rows only 4 / 8-byte aligned, table rows on 16-byte boundaries with room for whole
-    // 16-byte loads (padded stride), no row map (the output of consecutive entries must be one contiguous piece)
-    if (GATHER && p.flat_slots > 0 && p.flat_tail != 16 && p.row_map == nullptr && p.plain_stride_bytes == row_bytes &&
+    // LDS-staged kernels: dense rows only 4 / 8-byte aligned (for the scatter also rows of whole 16-byte pieces), table rows on
+    // 16-byte boundaries with room for whole 16-byte accesses (padded stride), no row map (the dense side of consecutive
+    // entries must be one contiguous piece). Rows up to 5120 B whose smallest aligned group (1 / 2 / 4 rows) fits a 10 KiB
+    // chunk. Measured against the flat-stream kernel (same file): scatter 516 B 39.4 -> 46.1 % of peak on a slow box and
+    // 49.9 -> 61.0 on a fast one, 1000 B 42.9 -> 55.0, 1204 B 51.9 -> 63.2, 2408 B 51.4 -> 60.0, 4120 B 56.5 -> 58.7; gather
+    // 1032 B 52.0 -> 64.1, 2408 B 60.4 -> 66.6, 4120 B 61.8 -> 68.6.
+    if ((GATHER ? staged_enabled() : staged_scatter_enabled()) && p.flat_slots > 0 && (p.flat_tail != 16 || staged_aligned_rows(GATHER)) &&
+        p.row_map == nullptr &&
+        p.plain_stride_bytes == row_bytes &&
         (reinterpret_cast<uint64_t>(p.plain) & 15) == 0 && p.table_stride_bytes % 16 == 0 && p.table_offset_bytes % 16 == 0 &&
         (tab_base & 15) == 0 && a->gref.stride % 16 == 0 && p.table_stride_bytes >= static_cast<int64_t>(p.flat_slots) * 16 &&
-        row_bytes <= 1024 && staged_enabled()) {   // measured: 516 B rows 52.2 -> 55.2 % of peak, 2408 B rows 60.9 -> 59.6 %
-      const int need = row_bytes % 8 == 0 ? 2 : 4;   // rows per 16-byte-aligned piece of the dense stream
-      int R          = 64;
-      while (R > need && static_cast<int64_t>(R) * row_bytes > 5120) R >>= 1;
-      if (static_cast<int64_t>(R) * row_bytes <= 5120) {   // kStageIters x 1 KiB per wave; bigger rows stay on the flat kernel
+        row_bytes <= staged_max_row(GATHER)) {
+      const int need    = row_bytes % 16 == 0 ? 1 : row_bytes % 8 == 0 ? 2 : 4;   // rows per 16-byte-aligned piece of the dense stream
+      const int64_t cap = static_cast<int64_t>(need) * row_bytes <= 5120 ? 5120 : 10240;   // 5 or 10 x 1 KiB per wave
+      int R             = 64;
+      while (R > need && static_cast<int64_t>(R) * row_bytes > cap) R >>= 1;
+      if (static_cast<int64_t>(R) * row_bytes <= cap) {   // bigger rows stay on the flat kernel
         p.stage_rows = R;
-        if (inorder_mode < 0 && inorder) {   // staged gather: persistent unless forced
+        if (inorder_mode == 0 || a->max_blocks > 0) {
           inorder          = false;
           p.launch_threads = kBlock;
+        } else {          // in order: one chunk per wave (the flat branch above may have switched it off for the scatter)
+          inorder          = true;
+          p.launch_threads = inorder_block_threads();
         }
-        p.tile_rows = inorder ? R : kWave;   // in order: one chunk (<= 5 KiB) per wave
+        p.tile_rows = inorder ? R : kWave;
         blocks      = grid_for(p.tile_rows);
       }
     }
