@@ -33,11 +33,11 @@ def main():
             args.append(x)
     if args:
         cases = [(torch.float32, int(x)) for x in args]
-    knobs = ("WM_ROWS_FLAT", "WM_ROWS_TILE", "WM_ROWS_STAGED", "WM_ROWS_INORDER", "WM_ROWS_BLOCK", "WM_ROWS_BATCH", "WM_ROWS_PIECES", "WM_ROWS_LDS", "WM_ROWS_STAGED_SCATTER", "WM_ROWS_STAGED_MAXROW", "WM_ROWS_STAGED_ALIGNED")
+    knobs = ("WM_ROWS_FLAT", "WM_ROWS_TILE", "WM_ROWS_STAGED", "WM_ROWS_INORDER", "WM_ROWS_BLOCK", "WM_ROWS_BATCH", "WM_ROWS_PIECES", "WM_ROWS_LDS", "WM_ROWS_STAGED_SCATTER", "WM_ROWS_STAGED_MAXROW", "WM_ROWS_STAGED_ALIGNED", "WM_ROWS_STAGED_MINROW")
     settings = [("default", {}), ("inorder=0", {"WM_ROWS_INORDER": "0"}), ("block=64", {"WM_ROWS_BLOCK": "64"}), ("batch=0", {"WM_ROWS_BATCH": "0"}), ("pieces=1", {"WM_ROWS_PIECES": "1"}), ("lds=6.6k", {"WM_ROWS_LDS": "6800"}), ("lds=10k", {"WM_ROWS_LDS": "10240"}), ("lds=20k", {"WM_ROWS_LDS": "20480"}), ("pieces+nostage", {"WM_ROWS_PIECES": "1", "WM_ROWS_STAGED": "0"}), ("inorder=1", {"WM_ROWS_INORDER": "1"}),
                 ("flat=0", {"WM_ROWS_FLAT": "0"}), ("flat=1", {"WM_ROWS_FLAT": "1"}),
                 ("staged=0", {"WM_ROWS_STAGED": "0"}), ("sscatter=0", {"WM_ROWS_STAGED_SCATTER": "0"}),
-                ("maxrow=5120", {"WM_ROWS_STAGED_MAXROW": "5120"}), ("maxrow=1024", {"WM_ROWS_STAGED_MAXROW": "1024"}), ("aligned=1", {"WM_ROWS_STAGED_ALIGNED": "1"}), ("maxrow=5120+inorder=0", {"WM_ROWS_STAGED_MAXROW": "5120", "WM_ROWS_INORDER": "0"})] if ab else [("default", {})]
+                ("maxrow=5120", {"WM_ROWS_STAGED_MAXROW": "5120"}), ("maxrow=1024", {"WM_ROWS_STAGED_MAXROW": "1024"}), ("aligned=1", {"WM_ROWS_STAGED_ALIGNED": "1"}), ("minrow=16", {"WM_ROWS_STAGED_MINROW": "16"}), ("minrow=1M", {"WM_ROWS_STAGED_MINROW": "1000000"}), ("maxrow=5120+inorder=0", {"WM_ROWS_STAGED_MAXROW": "5120", "WM_ROWS_INORDER": "0"})] if ab else [("default", {})]
     if ab and os.environ.get("DIM_SWEEP_SETTINGS"):   # e.g. "default,inorder=0"
         keep = os.environ["DIM_SWEEP_SETTINGS"].split(",")
         settings = [x for x in settings if x[0] in keep]

@@ -871,14 +871,27 @@ int64_t staged_max_row(bool gather)
   (void)gather;
   return 5120;
 }
+// shortest row the staged kernels are tried on (WM_ROWS_STAGED_MINROW overrides, A/B). Measured against rows_copy_kernel
+// (profiles/r03_dim_sweep_flat_forced.csv): gather of ragged rows 132 B 29.8 -> 49.5 % of peak, 164 B 34.3 -> 56.5, 200 B
+// 46.8 -> 57.0, 260 B 29.5 -> 58.9, and r03_dim_sweep_staged_small_rows.csv: 36 B 23.4 -> 29.5, 52 B 34.0 -> 45.1, 68 B 28.6 ->
+// 40.2, 100 B 33.8 -> 47.6, 120 B 60.9 -> 70.1; scatter 164 B +3.2, 200 B +4.1, 260 B +8.2 points, 132 B and below equal
+// or -1; rows of whole 16-byte pieces, scatter: 144 B +0.8, 176 B +2.2, 208 B +3.4, 240 B +5.2, 80 B equal.
+int64_t staged_min_row(bool gather, bool aligned)
+{
+  const char* e = getenv("WM_ROWS_STAGED_MINROW");
+  if (e != nullptr && atoll(e) > 0) return atoll(e);
+  return gather ? 16 : aligned ? 144 : 160;
+}
 // rows of whole 16-byte pieces (no tail) that the flat-stream kernel would take: through the staged kernel too? Measured
 // (profiles/r03_dim_sweep_staged_aligned.csv): scatter +1.3 ... +4.3 points on every shape from 400 B to 4000 B, gather mixed
-// (+4.7 at 400 B and 1600 B, -6.3 at 4000 B) -> yes for the scatter, no for the gather. WM_ROWS_STAGED_ALIGNED=0 / 1 forces.
-bool staged_aligned_rows(bool gather)
+// (+4.7 at 400 B and 1600 B, -0.9 at 544 B and 1200 B, -6.3 at 4000 B; under 512 B always ahead: 48 B +1.8, 112 B +3.5, 176 B
+// +5.7, 240 B +5.5, 304 B +3.1, r03_dim_sweep_staged_aligned_small.csv) -> yes for the scatter, under 512 B for the gather.
+// WM_ROWS_STAGED_ALIGNED=0 / 1 forces.
+bool staged_aligned_rows(bool gather, int64_t row_bytes)
 {
   const char* e = getenv("WM_ROWS_STAGED_ALIGNED");
   if (e != nullptr && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-  return !gather;
+  return !gather || row_bytes < 512;
 }
 // WM_ROWS_STAGED=0 switches the LDS-staged gather off (A/B)
 bool staged_enabled()
@@ -1128,14 +1141,15 @@ int rows_op(const wm_rows_args* a, void* stream_v)
     p.lpr_log2              = std::min(6, ilog2_ceil(p.row_vecs));
     // flat-stream kernel: needs every address 4-byte aligned (then 16-byte accesses are legal at any such address)
     const bool dword_ok = vb >= 4 && row_bytes < (INT64_C(1) << 24);
-    if (dword_ok && want_flat(GATHER, static_cast<int>(vb), row_bytes)) {
+    const bool flat     = dword_ok && want_flat(GATHER, static_cast<int>(vb), row_bytes);
+    // the staged kernels share the flat kernel's slot geometry; they are also tried on rows the flat kernel does not take
+    // (rows of whole 16-byte pieces above 256 B: where the flat rule says no, the readlane kernel is at least as good)
+    const bool stage_try = dword_ok && row_bytes >= staged_min_row(GATHER, row_bytes % 16 == 0) && (row_bytes & (row_bytes - 1)) != 0 &&
+                           (row_bytes % 16 != 0 || row_bytes <= 256);
+    if (flat || stage_try) {
       p.flat_slots = static_cast<int>((row_bytes + 15) / 16);
       p.flat_tail  = static_cast<int>(row_bytes - 16 * static_cast<int64_t>(p.flat_slots - 1));
       p.flat_rcp   = 1.0f / static_cast<float>(p.flat_slots);
-      if (!GATHER && inorder_mode < 0 && inorder) {   // flat-stream scatter: persistent unless forced
-        inorder          = false;
-        p.launch_threads = kBlock;
-      }
     }
     // LDS-staged kernels: dense rows only 4 / 8-byte aligned (for the scatter also rows of whole 16-byte pieces), table rows on
     // 16-byte boundaries with room for whole 16-byte accesses (padded stride), no row map (the dense side of consecutive
@@ -1143,7 +1157,7 @@ int rows_op(const wm_rows_args* a, void* stream_v)
     // chunk. Measured against the flat-stream kernel (same file): scatter 516 B 39.4 -> 46.1 % of peak on a slow box and
     // 49.9 -> 61.0 on a fast one, 1000 B 42.9 -> 55.0, 1204 B 51.9 -> 63.2, 2408 B 51.4 -> 60.0, 4120 B 56.5 -> 58.7; gather
     // 1032 B 52.0 -> 64.1, 2408 B 60.4 -> 66.6, 4120 B 61.8 -> 68.6.
-    if ((GATHER ? staged_enabled() : staged_scatter_enabled()) && p.flat_slots > 0 && (p.flat_tail != 16 || staged_aligned_rows(GATHER)) &&
+    if ((GATHER ? staged_enabled() : staged_scatter_enabled()) && p.flat_slots > 0 && (p.flat_tail != 16 || staged_aligned_rows(GATHER, row_bytes)) && (flat || stage_try) &&
         p.row_map == nullptr &&
         p.plain_stride_bytes == row_bytes &&
         (reinterpret_cast<uint64_t>(p.plain) & 15) == 0 && p.table_stride_bytes % 16 == 0 && p.table_offset_bytes % 16 == 0 &&
@@ -1164,6 +1178,14 @@ int rows_op(const wm_rows_args* a, void* stream_v)
         }
         p.tile_rows = inorder ? R : kWave;
         blocks      = grid_for(p.tile_rows);
+      }
+    }
+    if (p.stage_rows == 0 && p.flat_slots > 0) {
+      if (!flat) {
+        p.flat_slots = 0, p.flat_tail = 0;            // not staged after all: the generic kernels
+      } else if (!GATHER && inorder_mode < 0 && inorder) {   // flat-stream scatter: persistent unless forced
+        inorder          = false;
+        p.launch_threads = kBlock;
       }
     }
     // rows_pieces_kernel instead of the flat-stream kernel (in-order launches only; WM_ROWS_PIECES=0 / 1 forces)
