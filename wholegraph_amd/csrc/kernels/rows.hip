@@ -876,11 +876,14 @@ int64_t staged_max_row(bool gather)
 // 46.8 -> 57.0, 260 B 29.5 -> 58.9, and r03_dim_sweep_staged_small_rows.csv: 36 B 23.4 -> 29.5, 52 B 34.0 -> 45.1, 68 B 28.6 ->
 // 40.2, 100 B 33.8 -> 47.6, 120 B 60.9 -> 70.1; scatter 164 B +3.2, 200 B +4.1, 260 B +8.2 points, 132 B and below equal
 // or -1; rows of whole 16-byte pieces, scatter: 144 B +0.8, 176 B +2.2, 208 B +3.4, 240 B +5.2, 80 B equal.
-int64_t staged_min_row(bool gather, bool aligned)
+bool staged_row_wanted(bool gather, int64_t row_bytes)
 {
   const char* e = getenv("WM_ROWS_STAGED_MINROW");
-  if (e != nullptr && atoll(e) > 0) return atoll(e);
-  return gather ? 16 : aligned ? 144 : 160;
+  if (e != nullptr && atoll(e) > 0) return row_bytes >= atoll(e);
+  if (gather) return row_bytes >= 16;
+  // (scatter of 64 / 128 / 256 B rows: +1 / +1.2 / +6.6 although 96 B and 112 B lose 1-2: r03_dim_sweep_pow2_small.csv)
+  if ((row_bytes & (row_bytes - 1)) == 0 && row_bytes >= 64) return true;
+  return row_bytes >= (row_bytes % 16 == 0 ? 144 : 160);
 }
 // rows of whole 16-byte pieces (no tail) that the flat-stream kernel would take: through the staged kernel too? Measured
 // (profiles/r03_dim_sweep_staged_aligned.csv): scatter +1.3 ... +4.3 points on every shape from 400 B to 4000 B, gather mixed
@@ -1144,8 +1147,9 @@ int rows_op(const wm_rows_args* a, void* stream_v)
     const bool flat     = dword_ok && want_flat(GATHER, static_cast<int>(vb), row_bytes);
     // the staged kernels share the flat kernel's slot geometry; they are also tried on rows the flat kernel does not take
     // (rows of whole 16-byte pieces above 256 B: where the flat rule says no, the readlane kernel is at least as good)
-    const bool stage_try = dword_ok && row_bytes >= staged_min_row(GATHER, row_bytes % 16 == 0) && (row_bytes & (row_bytes - 1)) != 0 &&
-                           (row_bytes % 16 != 0 || row_bytes <= 256);
+    // and the powers of two from 512 B up have the single-batch kernel: r03_dim_sweep_pow2_staged.csv — 64 / 128 / 256 B rows
+    // gain +2.3 / +4.5 / +1.7 (gather) and +3.5 / +1.7 / +4.8 (scatter), 512 B - 4 KiB lose 0 ... 2.3)
+    const bool stage_try = dword_ok && staged_row_wanted(GATHER, row_bytes) && (row_bytes % 16 != 0 || row_bytes <= 256);
     if (flat || stage_try) {
       p.flat_slots = static_cast<int>((row_bytes + 15) / 16);
       p.flat_tail  = static_cast<int>(row_bytes - 16 * static_cast<int64_t>(p.flat_slots - 1));
