@@ -173,6 +173,13 @@ enum wholememory_error_code_t wholememory_ext_multilayer_sample(
  * WM_ASYNC_OPS=0/1 in the environment overrides the call. */
 enum wholememory_error_code_t wholememory_ext_set_async_completion(int on);
 
+/* Placement probe: milliseconds per GiB of pseudo-random 512-byte rows of [ptr, ptr + bytes) touched by a fixed kernel
+ * (kind 0 = zeros written: destroys the contents, 1 = read, 2 = read and written back), averaged over `reps` launches after a
+ * warm-up; blocks until done. The level the memory system serves random row accesses at depends on where a large allocation
+ * sits in HBM and stays with it for its lifetime; WM_MALLOC_PROBE=K makes wholememory_malloc pick the
+ * best of K candidate allocations with this probe (off by default: the candidates are alive together). */
+enum wholememory_error_code_t wholememory_ext_probe_memory(void* ptr, size_t bytes, int kind, int reps, float* ms_per_gib);
+
 /* ---- (3) testing seam ---------------------------------------------------------------------- */
 /* Replaces the device backend. Refuses (WHOLEMEMORY_NOT_SUPPORTED) unless the environment has
  * WHOLEGRAPH_AMD_TESTING=1. `backend` is a const wm_device_backend* (wholegraph_amd/csrc/backend.hpp);

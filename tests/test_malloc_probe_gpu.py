@@ -1,0 +1,67 @@
+"""Placement probe (csrc/kernels/probe.hip) and WM_MALLOC_PROBE=K (csrc/memory_handle.cpp:alloc_local): the best of K
+candidate allocations is kept for a device shard; the table it backs must behave like any other (gather / scatter parity
+with the closed form of the reference's own tests, wholememory_gather_tests.cu:288-528), and the probe itself must report a
+positive time for every kind without touching memory outside [ptr, ptr + bytes)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import wholegraph_amd.torch as wgth
+from wholegraph_amd import binding as wmb
+wmb.check(wmb.lib().wholememory_init(0, wmb.LEVEL_WARN))
+comm = wgth.create_group_communicator(1)
+rows, dim = 65536, 64                       # 16 MiB shard: above the lowered threshold
+emb = wgth.create_embedding(comm, "chunked", "cuda", torch.float32, [rows, dim])
+t = emb.get_embedding_tensor()
+g = torch.Generator(device="cuda").manual_seed(7)
+idx = torch.randperm(rows, device="cuda", generator=g)[:20000]
+src = (idx.to(torch.float32)[:, None] + torch.arange(dim, device="cuda", dtype=torch.float32)[None, :]).contiguous()
+t.scatter(src, idx)
+out = emb.gather(idx)
+assert torch.equal(out, src), "gather after scatter differs"
+untouched = torch.ones(rows, dtype=torch.bool, device="cuda"); untouched[idx] = False
+loc, first = t.get_local_tensor()
+print("OK", int(first))
+""" % ROOT
+
+
+def test_malloc_probe_keeps_a_working_table(wm_lib):
+    env = dict(os.environ, WM_MALLOC_PROBE="3", WM_MALLOC_PROBE_MIN_BYTES=str(1 << 20), WM_MALLOC_PROBE_VERBOSE="1")
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK 0" in r.stdout
+    lines = [l for l in r.stderr.splitlines() if "malloc probe: candidate" in l]
+    assert len(lines) == 3, r.stderr            # three candidates were allocated and timed
+    for l in lines:
+        assert float(l.split(":")[-1].split()[0]) > 0
+
+
+def test_probe_kinds_and_bounds(wm_lib):
+    from wholegraph_amd import binding as wmb
+    L = wmb.lib()
+    n = 8 << 20
+    guard = 4096
+    buf = torch.full((n + 2 * guard,), 7, dtype=torch.uint8, device="cuda")
+    ptr = buf.data_ptr() + guard
+    for kind in (1, 2):                          # the non-destructive kinds leave every byte as it was
+        ms = ctypes.c_float(0)
+        wmb.check(L.wholememory_ext_probe_memory(ctypes.c_void_p(ptr), ctypes.c_size_t(n), kind, 2, ctypes.byref(ms)))
+        assert ms.value > 0
+        assert bool((buf == 7).all())
+    ms = ctypes.c_float(0)
+    wmb.check(L.wholememory_ext_probe_memory(ctypes.c_void_p(ptr), ctypes.c_size_t(n), 0, 2, ctypes.byref(ms)))
+    assert ms.value > 0
+    assert bool((buf[:guard] == 7).all()) and bool((buf[-guard:] == 7).all())   # kind 0 writes zeros inside the range only
+    assert int((buf[guard:-guard] == 0).sum()) > 0
+    with pytest.raises(Exception):
+        wmb.check(L.wholememory_ext_probe_memory(ctypes.c_void_p(ptr), ctypes.c_size_t(n), 9, 1, ctypes.byref(ms)))

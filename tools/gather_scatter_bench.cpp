@@ -101,7 +101,32 @@ int run_rank(const options& o, int rank, shared_page* sh)
   wholememory_tensor_description_t tdesc;
   wholememory_copy_matrix_desc_to_tensor(&tdesc, &mdesc);
   wholememory_tensor_t table = nullptr, local = nullptr;
+  // experiments (profiles/r03_scatter_by_vram_offset.txt): WM_BENCH_BLOCKER_GB=a,b,... device allocations made BEFORE the table,
+  // so that the table lands further up in VRAM; WM_BENCH_BLOCKER_FREE=1 releases them again right after the table exists
+  std::vector<void*> blockers;
+  if (const char* be = getenv("WM_BENCH_BLOCKER_GB")) {
+    std::string spec(be);
+    size_t pos = 0;
+    while (pos < spec.size()) {
+      size_t comma    = spec.find(',', pos);
+      if (comma == std::string::npos) comma = spec.size();
+      const double gb = atof(spec.substr(pos, comma - pos).c_str());
+      void* b         = nullptr;
+      if (gb > 0 && hipMalloc(&b, static_cast<size_t>(gb * 1e9)) == hipSuccess) {
+        (void)hipMemset(b, 0, static_cast<size_t>(gb * 1e9));
+        blockers.push_back(b);
+      }
+      pos = comma + 1;
+    }
+    HIP_OK(hipDeviceSynchronize());
+  }
   WM_OK(wholememory_create_tensor(&table, &tdesc, comm, o.type, o.location));
+  if (const char* bf = getenv("WM_BENCH_BLOCKER_FREE")) {
+    if (bf[0] == '1') {
+      for (void* b : blockers) (void)hipFree(b);
+      blockers.clear();
+    }
+  }
   WM_OK(wholememory_tensor_map_local_tensor(table, &local));
   std::vector<size_t> offs(o.gpus + 1);
   WM_OK(wholememory_tensor_get_entry_offsets(offs.data(), table));

@@ -288,6 +288,10 @@ struct wm_device_backend {
                      void* raw_idx, unsigned long long* hits_dev, void* stream);
   int (*cache_writeback)(const wm_cache_args* c, int drop, void* stream);
   int (*cache_info)(const wm_cache_args* c, unsigned long long* occupied_dirty_dev, void* stream);
+  // placement probe (kernels/probe.hip): milliseconds per GiB of pseudo-random 512-byte rows of [ptr, ptr + bytes) touched,
+  // averaged over `reps` launches. kind 0 = write zeros (fresh allocations only), 1 = read, 2 = read and write back.
+  // Synchronises `stream`. nullptr in a backend that does not provide it.
+  int (*probe_memory)(void* ptr, size_t bytes, int kind, int reps, float* ms_per_gib, void* stream);
 };
 
 }  // extern "C"

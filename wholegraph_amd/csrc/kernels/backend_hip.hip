@@ -55,6 +55,7 @@ int hip_cache_split(const wm_cache_args* c, const void* ids, wholememory_dtype_t
                     unsigned long long* hits_dev, void* stream);
 int hip_cache_writeback(const wm_cache_args* c, int drop, void* stream);
 int hip_cache_info(const wm_cache_args* c, unsigned long long* out2_dev, void* stream);
+int hip_probe_memory(void* ptr, size_t bytes, int kind, int reps, float* ms_per_gib, void* stream);
 
 namespace {
 
@@ -179,6 +180,7 @@ const wm_device_backend kHipBackend = {
   hip_cache_split,
   hip_cache_writeback,
   hip_cache_info,
+  hip_probe_memory,
 };
 
 }  // namespace

@@ -126,10 +126,49 @@ void alloc_local(wholememory_handle_* h)
   const int rank  = h->comm->world_rank;
   h->local_alloc  = std::max<size_t>(h->part_sizes[rank], 16);
   h->local_is_pinned = h->location == WHOLEMEMORY_ML_HOST;
-  if (h->local_is_pinned)
+  if (h->local_is_pinned) {
     WM_BK(bk->malloc_pinned(&h->local_ptr, h->local_alloc));
-  else
-    WM_BK(bk->malloc_device(&h->local_ptr, h->local_alloc));
+    return;
+  }
+  // WM_MALLOC_PROBE=K (default 1 = off): for device shards of at least WM_MALLOC_PROBE_MIN_BYTES (default 1 GiB) up to K
+  // candidate allocations are made, each is timed with the placement probe (kernels/probe.hip: pseudo-random 512-byte row
+  // writes — the level the memory system serves them at depends on where the allocation sits in HBM, by up to 20 %, and
+  // stays with the allocation for its lifetime), the fastest is kept and the others are released. Candidates are alive
+  // together: K x the shard size must be free at this moment (a candidate that cannot be allocated ends the search).
+  // Every rank decides for its own shard; no collective is involved.
+  static const int k_candidates = [] {
+    const char* e = getenv("WM_MALLOC_PROBE");
+    const int k   = e != nullptr ? atoi(e) : 1;
+    return std::min(std::max(k, 1), 8);
+  }();
+  static const size_t min_bytes = [] {
+    const char* e = getenv("WM_MALLOC_PROBE_MIN_BYTES");
+    return e != nullptr && atoll(e) > 0 ? static_cast<size_t>(atoll(e)) : (static_cast<size_t>(1) << 30);
+  }();
+  WM_BK(bk->malloc_device(&h->local_ptr, h->local_alloc));
+  if (k_candidates <= 1 || bk->probe_memory == nullptr || h->local_alloc < min_bytes) return;
+  static const bool verbose = getenv("WM_MALLOC_PROBE_VERBOSE") != nullptr;
+  float best_ms = 0;
+  if (bk->probe_memory(h->local_ptr, h->local_alloc, 0, 3, &best_ms, nullptr) != 0) return;
+  if (verbose) fprintf(stderr, "[wholegraph_amd] malloc probe: candidate 0 at %p: %.4f ms per GiB\n", h->local_ptr, best_ms);
+  std::vector<void*> losers;
+  for (int k = 1; k < k_candidates; k++) {
+    void* cand = nullptr;
+    if (bk->malloc_device(&cand, h->local_alloc) != 0 || cand == nullptr) break;
+    float ms = 0;
+    const int prc = bk->probe_memory(cand, h->local_alloc, 0, 3, &ms, nullptr);
+    if (verbose) fprintf(stderr, "[wholegraph_amd] malloc probe: candidate %d at %p: %.4f ms per GiB\n", k, cand, ms);
+    if (prc == 0 && ms < best_ms) {
+      losers.push_back(h->local_ptr);
+      h->local_ptr = cand;
+      best_ms      = ms;
+    } else {
+      losers.push_back(cand);
+    }
+  }
+  for (void* l : losers) (void)bk->free_device(l);
+  WM_INFO("wholememory_malloc: kept the best of %d probed device allocations of %zu bytes (%.4f ms per GiB of random rows)",
+              static_cast<int>(losers.size()) + 1, h->local_alloc, best_ms);
 }
 
 void map_chunked_device(wholememory_handle_* h)
@@ -510,3 +549,12 @@ wholememory_gref_t wholememory_create_continuous_global_reference(void* ptr)
 }
 
 }  // extern "C"
+
+// placement probe on caller memory (experiments, tests; the same probe WM_MALLOC_PROBE uses inside wholememory_malloc)
+extern "C" wholememory_error_code_t wholememory_ext_probe_memory(void* ptr, size_t bytes, int kind, int reps, float* ms_per_gib)
+{
+  const auto* bk = wm::backend();
+  if (bk->probe_memory == nullptr) return WHOLEMEMORY_NOT_SUPPORTED;
+  const int rc = bk->probe_memory(ptr, bytes, kind, reps, ms_per_gib, nullptr);
+  return rc == 0 ? WHOLEMEMORY_SUCCESS : (rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR);
+}
