@@ -483,6 +483,27 @@ def main():
         placement = {"probe_ms": [[round(x, 4) for x in row] for row in grid], "picked": {"table": ti, "output": oi},
                      "note": "6-launch probes of the same op for every (candidate table, candidate output / source buffer) pair; "
                              "[0][0] is what single allocations give; the timed region below runs on the picked pair"}
+    # where the table landed in HBM: the fixed placement probe on this rank's shard, outside the timed
+    # region and non-destructive (kind 1 = random 512-byte rows read, kind 2 = read and written back), ms per GiB of rows
+    table_probe = None
+    if a.location == "cuda" and policy is None:
+        try:
+            import ctypes
+            shard, _ = emb.get_embedding_tensor().get_local_tensor()
+            vals = []
+            for kind in (1, 2):
+                ms = ctypes.c_float(0)
+                wmb.check(wmb.lib().wholememory_ext_probe_memory(ctypes.c_void_p(shard.data_ptr()),
+                                                                 ctypes.c_size_t(shard.numel() * shard.element_size()), kind, 3,
+                                                                 ctypes.byref(ms)))
+                vals.append(round(ms.value, 4))
+            table_probe = {"read_ms_per_GiB": vals[0], "read_write_back_ms_per_GiB": vals[1],
+                           "malloc_candidates": int(os.environ.get("WM_MALLOC_PROBE", "1")),
+                           "note": "random-row probe of the table's allocation; a write-side value near 0.36 is a well placed "
+                                   "table, 0.41-0.43 a badly placed one (scatter / gradient apply up to 20 % slower)"}
+            del shard
+        except Exception as e:   # a probe that fails must not take the bench line with it
+            table_probe = {"error": str(e)[:200]}
     opt = None
     if a.op == "grad_apply":
         if not (sgd_apply and placement is not None):   # (the placement probes gave every candidate its optimizer)
@@ -642,6 +663,7 @@ def main():
             "algorithmic_GBps": round(lookups * algo_bytes / 1e9, 2),
             "device_allocs_in_timed_region": fresh_allocs,
             "placement": placement,   # None: plain single allocations (the default)
+            "table_probe": table_probe,
             "launch_shape": "persistent (WM_ROWS_INORDER=0)" if os.environ.get("WM_ROWS_INORDER", "1") == "0" else "in-order",
             "config": {"workload": ("C2 chunked 1-GPU %dx%d %s table, %d %s int64 ids" if world == 1 else
                                     "C3 distributed %dx%d %s table, %d %s int64 ids per rank, RCCL alltoallv")
