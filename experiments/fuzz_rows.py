@@ -2,7 +2,7 @@
 """Randomised shapes for gather / scatter against torch indexing on the GPU (torch is the checker here: exact copies and
 the same round-to-nearest casts): dtype pairs, dims 1..700, padded strides, column offsets (sub-tensor views), output
 strides, int32 / int64 ids with negatives and duplicates, chunked / continuous / distributed (one rank).
-usage: fuzz_rows.py [cases] [seed]"""
+usage: fuzz_rows.py [cases] [seed]      (FUZZ_WIDE=1: most cases draw any dim in 1..1400 or a few wider ones, up to 2561)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,6 +18,7 @@ wmb.check(wmb.lib().wholememory_init(0, wmb.LEVEL_ERROR))
 comm = wgth.create_group_communicator(1)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+WIDE = os.environ.get("FUZZ_WIDE") == "1"
 FLOATS = [torch.float32, torch.float16, torch.float64, torch.bfloat16]
 INTS = [torch.int8, torch.int16, torch.int32, torch.int64]
 bad = 0
@@ -27,6 +28,8 @@ for case in range(cases):
     if torch.bfloat16 in (tdt, odt) and tdt != odt:
         tdt = odt = torch.bfloat16 if rng.random() < 0.5 else torch.float32   # bf16 is not registered for casts (as in the reference)
     dim = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 31, 32, 33, 64, 100, 127, 128, 129, 200, 256, 300, 513, 602, 700]))
+    if WIDE and rng.random() < 0.7:   # any width up to rows of 5.6 KiB (both chunk sizes of the LDS-staged kernels and past them)
+        dim = int(rng.integers(1, 1400)) if rng.random() < 0.8 else int(rng.choice([1024, 1030, 1280, 1281, 1279, 2048, 2560, 2561]))
     stride = dim + int(rng.choice([0, 0, 1, 3, 4, 13]))
     col0 = int(rng.integers(0, stride - dim + 1))
     n_rows = int(rng.integers(1, 30000))

@@ -14,7 +14,7 @@ if len(sys.argv) > 2 and sys.argv[2]:
     except Exception as e:
         print('no copy trace', e)
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-g = [i for i, r in enumerate(rows) if 'rows_copy16_fast_kernel<int' in r['Kernel_Name']]
+g = [i for i, r in enumerate(rows) if 'rows_copy16_fast_kernel<int' in r['Kernel_Name'] or 'rows_batch_kernel<int' in r['Kernel_Name']]
 a, b = g[-3], g[-2]
 sel = rows[a:b + 1]
 t0 = int(sel[0]['End_Timestamp'])
