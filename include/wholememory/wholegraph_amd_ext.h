@@ -180,6 +180,11 @@ enum wholememory_error_code_t wholememory_ext_set_async_completion(int on);
  * best of K candidate allocations with this probe (off by default: the candidates are alive together). */
 enum wholememory_error_code_t wholememory_ext_probe_memory(void* ptr, size_t bytes, int kind, int reps, float* ms_per_gib);
 
+/* Number of wholememory_gather calls of this process that took the sorted-ids route of HOST-located tables (rows of at most
+ * 512 bytes, batches of at least WM_HOST_SORTED_MIN ids: wholememory_op.h / gather_op.cpp:116-120 of the reference).
+ * A counter for tests and benchmarks. */
+int64_t wholememory_ext_host_sorted_gathers(void);
+
 /* ---- (3) testing seam ---------------------------------------------------------------------- */
 /* Replaces the device backend. Refuses (WHOLEMEMORY_NOT_SUPPORTED) unless the environment has
  * WHOLEGRAPH_AMD_TESTING=1. `backend` is a const wm_device_backend* (wholegraph_amd/csrc/backend.hpp);

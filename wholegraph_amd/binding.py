@@ -258,6 +258,7 @@ PROTOTYPES = {
                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "wholememory_ext_set_async_completion": (_i, [_i]),
     "wholememory_ext_probe_memory": (_i, [_vp, C.c_size_t, _i, _i, _P(_f)]),
+    "wholememory_ext_host_sorted_gathers": (_i64, []),
     "wholememory_ext_multilayer_sample": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wm_testing_install_backend": (_i, [_vp]),
 }

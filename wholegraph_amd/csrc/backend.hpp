@@ -292,6 +292,15 @@ struct wm_device_backend {
   // averaged over `reps` launches. kind 0 = write zeros (fresh allocations only), 1 = read, 2 = read and write back.
   // Synchronises `stream`. nullptr in a backend that does not provide it.
   int (*probe_memory)(void* ptr, size_t bytes, int kind, int reps, float* ms_per_gib, void* stream);
+  // Ids put in ascending row order for LOCALITY (the sorted-ids gather of HOST tables, gather_op.cpp:116-120 /
+  // sort_indices_func.cu:41-91): sorted_ids[i] = ids[raw[i]] with the ids ascending as unsigned numbers over the bits
+  // [low_bit, bits of key_upper_bound) — negative ("skip me") ids keep their value and come last; raw[] is int64 like every row
+  // map. Any permutation would be correct for the gather that follows; only pairs must stay together. Returns -3 (nothing
+  // queued) when the keys do not fit the 32-bit sort (key_upper_bound <= 0 or >= 2^32 - 1). Workspace from
+  // sort_ids_workspace_bytes(n). nullptr in a backend that does not provide it.
+  size_t (*sort_ids_workspace_bytes)(int64_t n);
+  int (*sort_ids)(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, int low_bit,
+                  void* sorted_ids, int64_t* raw, void* workspace, void* stream);
 };
 
 }  // extern "C"

@@ -56,6 +56,9 @@ int hip_cache_split(const wm_cache_args* c, const void* ids, wholememory_dtype_t
 int hip_cache_writeback(const wm_cache_args* c, int drop, void* stream);
 int hip_cache_info(const wm_cache_args* c, unsigned long long* out2_dev, void* stream);
 int hip_probe_memory(void* ptr, size_t bytes, int kind, int reps, float* ms_per_gib, void* stream);
+size_t hip_sort_ids_workspace_bytes(int64_t n);
+int hip_sort_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, int low_bit,
+                 void* sorted_ids, int64_t* raw, void* workspace, void* stream);
 
 namespace {
 
@@ -181,6 +184,8 @@ const wm_device_backend kHipBackend = {
   hip_cache_writeback,
   hip_cache_info,
   hip_probe_memory,
+  hip_sort_ids_workspace_bytes,
+  hip_sort_ids,
 };
 
 }  // namespace

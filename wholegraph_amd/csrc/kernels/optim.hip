@@ -1754,6 +1754,75 @@ int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, i
   return -1;
 }
 
+// ---- ids in ascending row order for locality (HOST-table gather, backend.hpp: sort_ids) ----
+namespace {
+template <typename KeyT>
+__global__ void expand_sorted_ids_kernel(const KeyT* ids, const int32_t* order, int64_t n, KeyT* sorted_ids, int64_t* raw)
+{
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t o = order[i];
+  sorted_ids[i]   = ids[o];   // the id as the caller wrote it (a negative one stays negative: the gather skips it)
+  raw[i]          = o;
+}
+
+struct sort_ids_layout {
+  uint32_t* keys;
+  int32_t* order;
+  void* temp;
+  size_t temp_bytes, total;
+};
+sort_ids_layout sort_ids_carve(void* ws, int64_t n)
+{
+  auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  size_t sort_bytes = 0;
+  (void)rocprim::radix_sort_pairs<sort_config<uint32_t>::type>(
+    nullptr, sort_bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+    rocprim::counting_iterator<int32_t>(0), static_cast<int32_t*>(nullptr), static_cast<size_t>(n), 0, 32, nullptr);
+  sort_ids_layout l;
+  char* p  = static_cast<char*>(ws);
+  size_t o = 0;
+  l.keys   = reinterpret_cast<uint32_t*>(p + o), o += align(4 * static_cast<size_t>(n));
+  l.order  = reinterpret_cast<int32_t*>(p + o), o += align(4 * static_cast<size_t>(n));
+  l.temp   = p + o;
+  l.temp_bytes = sort_bytes;
+  l.total  = o + align(sort_bytes) + 256;
+  return l;
+}
+
+template <typename KeyT>
+int run_sort_ids(const void* ids, int64_t n, int64_t key_upper_bound, int low_bit, void* sorted_ids, int64_t* raw, void* ws,
+                 hipStream_t stream)
+{
+  using UKey = typename std::make_unsigned<KeyT>::type;
+  auto l     = sort_ids_carve(ws, n);
+  size_t tb  = l.temp_bytes;
+  // ids outside [0, key_upper_bound) — negative ones above all — read as the key `key_upper_bound` and land behind every row
+  narrow_key_iterator<UKey> keys{static_cast<const UKey*>(ids), static_cast<UKey>(0), static_cast<uint32_t>(key_upper_bound)};
+  const unsigned bits = significant_bits(key_upper_bound + 1, 32);
+  const unsigned lo   = static_cast<unsigned>(std::max(0, std::min<int>(low_bit, static_cast<int>(bits) - 1)));
+  if (rocprim::radix_sort_pairs<sort_config<uint32_t>::type>(l.temp, tb, keys, l.keys, rocprim::counting_iterator<int32_t>(0),
+                                                             l.order, static_cast<size_t>(n), lo, bits, stream) != hipSuccess)
+    return -2;
+  hipLaunchKernelGGL((expand_sorted_ids_kernel<KeyT>), dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     stream, static_cast<const KeyT*>(ids), l.order, n, static_cast<KeyT*>(sorted_ids), raw);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+}  // namespace
+
+size_t hip_sort_ids_workspace_bytes(int64_t n) { return n <= 0 ? 256 : sort_ids_carve(nullptr, n).total; }
+
+int hip_sort_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, int low_bit,
+                 void* sorted_ids, int64_t* raw, void* workspace, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (n <= 0) return 0;
+  if (key_upper_bound <= 0 || key_upper_bound >= INT64_C(0xFFFFFFFF) || n >= (INT64_C(1) << 31)) return -3;
+  if (index_dtype == WHOLEMEMORY_DT_INT) return run_sort_ids<int32_t>(ids, n, key_upper_bound, low_bit, sorted_ids, raw, workspace, stream);
+  if (index_dtype == WHOLEMEMORY_DT_INT64) return run_sort_ids<int64_t>(ids, n, key_upper_bound, low_bit, sorted_ids, raw, workspace, stream);
+  return -1;
+}
+
 size_t hip_long_run_ws_bytes(int64_t n_recv, int64_t dim)
 {   // the larger of the two layouts (the fold order is only resolved at the step: it may depend on the value dtype)
   return std::max(16 + sizeof(long_run_entry) * static_cast<size_t>(n_recv / (kLongRun + 1) + 2),

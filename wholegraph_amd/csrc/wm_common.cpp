@@ -66,6 +66,21 @@ bool async_completion_enabled()
   return forced >= 0 ? forced == 1 : g_async_completion == 1;
 }
 
+// (read at every call: two getenv per HOST gather are noise beside a PCIe-bound kernel, and tests switch them per case)
+int64_t host_sorted_gather_min()
+{
+  const char* off = getenv("WM_HOST_SORTED_GATHER");
+  if (off != nullptr && off[0] == '0') return 0;
+  const char* e = getenv("WM_HOST_SORTED_MIN");
+  return e != nullptr && atoll(e) > 0 ? static_cast<int64_t>(atoll(e)) : static_cast<int64_t>(1) << 19;
+}
+
+int host_sorted_gather_low_bit()
+{
+  const char* e = getenv("WM_HOST_SORTED_LOW_BIT");
+  return e != nullptr && atoi(e) > 0 ? atoi(e) : 0;
+}
+
 }  // namespace wm
 
 extern "C" wholememory_error_code_t wholememory_ext_set_async_completion(int on)

@@ -56,6 +56,10 @@ bool debug_sync_enabled();
 // that (wholememory_ext_set_async_completion(1)); WM_ASYNC_OPS=0/1 overrides either way.
 void set_async_completion(bool on);
 bool async_completion_enabled();
+// sorted-ids gather of HOST tables (ops.cpp: wholememory_gather): smallest batch that takes it (0: route off,
+// WM_HOST_SORTED_GATHER=0 / WM_HOST_SORTED_MIN) and the lowest id bit the sort looks at (WM_HOST_SORTED_LOW_BIT)
+int64_t host_sorted_gather_min();
+int host_sorted_gather_low_bit();
 
 }  // namespace wm
 
