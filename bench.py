@@ -195,15 +195,20 @@ def gpu_c1_host(wgth, comm):
     torch.cuda.synchronize()
     assert torch.equal(out[:, 0], (idx & 0xFFFFFF).to(torch.float32))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    from wholegraph_amd import binding as _wmb
+    sorted_before = _wmb.lib().wholememory_ext_host_sorted_gathers()
     e0.record()
     for _ in range(20):
         emb.gather(idx, out=out)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
+    took_sorted = _wmb.lib().wholememory_ext_host_sorted_gathers() - sorted_before
     wgth.destroy_embedding(emb)
     return {"ms_per_gather": round(ms, 4), "value": round(n * dim * 4 / (ms * 1e-3) / 1e9, 2), "unit": "GB/s",
             "mlookups_per_s": round(n / (ms * 1e-3) / 1e6, 1), "bound": "pcie",
+            "route": "ids sorted by row first (reference gather_op.cpp:116-120), sort inside the timed calls" if took_sorted == 20
+                     else "ids as they come",
             "workload": "C1 HOST chunked 10000000x64 fp32 table in pinned host memory, 1000000 uniform int64 ids, output in HBM"}
 
 
