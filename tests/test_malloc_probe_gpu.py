@@ -1,5 +1,6 @@
-"""Placement probe (csrc/kernels/probe.hip) and WM_MALLOC_PROBE=K (csrc/memory_handle.cpp:alloc_local): the best of K
-candidate allocations is kept for a device shard; the table it backs must behave like any other (gather / scatter parity
+"""Placement probe (csrc/kernels/probe.hip) and the candidate choice in wholememory_malloc (csrc/memory_handle.cpp:alloc_local;
+automatic by default, WM_MALLOC_PROBE=K forces K candidates, =1 switches it off): the best of the probed candidate allocations
+is kept for a device shard; the table it backs must behave like any other (gather / scatter parity
 with the closed form of the reference's own tests, wholememory_gather_tests.cu:288-528), and the probe itself must report a
 positive time for every kind without touching memory outside [ptr, ptr + bytes)."""
 import ctypes
@@ -44,6 +45,26 @@ def test_malloc_probe_keeps_a_working_table(wm_lib):
     assert len(lines) == 3, r.stderr            # three candidates were allocated and timed
     for l in lines:
         assert float(l.split(":")[-1].split()[0]) > 0
+
+
+@pytest.mark.parametrize("good,expected", [("1e-9", 3), ("1000", 1)])
+def test_automatic_probe_stops_at_a_well_placed_candidate(wm_lib, good, expected):
+    """WM_MALLOC_PROBE unset = automatic: up to 3 candidates while half of the free memory holds them, none beyond the first
+    one that probes at or under WM_MALLOC_PROBE_GOOD."""
+    env = dict(os.environ, WM_MALLOC_PROBE_MIN_BYTES=str(1 << 20), WM_MALLOC_PROBE_VERBOSE="1", WM_MALLOC_PROBE_GOOD=good)
+    env.pop("WM_MALLOC_PROBE", None)
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK 0" in r.stdout
+    lines = [l for l in r.stderr.splitlines() if "malloc probe: candidate" in l]
+    assert len(lines) == expected, r.stderr
+
+
+def test_probe_switched_off(wm_lib):
+    env = dict(os.environ, WM_MALLOC_PROBE="1", WM_MALLOC_PROBE_MIN_BYTES=str(1 << 20), WM_MALLOC_PROBE_VERBOSE="1")
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK 0" in r.stdout, r.stdout + r.stderr
+    assert "malloc probe: candidate" not in r.stderr
 
 
 def test_probe_kinds_and_bounds(wm_lib):

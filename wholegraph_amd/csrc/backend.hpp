@@ -301,6 +301,8 @@ struct wm_device_backend {
   size_t (*sort_ids_workspace_bytes)(int64_t n);
   int (*sort_ids)(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, int low_bit,
                   void* sorted_ids, int64_t* raw, void* workspace, void* stream);
+  // free / total bytes of the current device's memory right now. nullptr in a backend that does not provide it.
+  int (*mem_info)(size_t* free_bytes, size_t* total_bytes);
 };
 
 }  // extern "C"

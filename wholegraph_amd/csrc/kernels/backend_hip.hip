@@ -129,6 +129,7 @@ int h_host_register(void* host_ptr, size_t bytes, void** dev_ptr)
   return rc(hipHostGetDevicePointer(dev_ptr, host_ptr, 0));
 }
 int h_host_unregister(void* host_ptr) { return rc(hipHostUnregister(host_ptr)); }
+int h_mem_info(size_t* free_bytes, size_t* total_bytes) { return rc(hipMemGetInfo(free_bytes, total_bytes)); }
 
 const wm_device_backend kHipBackend = {
   "hip-gfx950",
@@ -186,6 +187,7 @@ const wm_device_backend kHipBackend = {
   hip_probe_memory,
   hip_sort_ids_workspace_bytes,
   hip_sort_ids,
+  h_mem_info,
 };
 
 }  // namespace

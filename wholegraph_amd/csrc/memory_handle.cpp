@@ -130,27 +130,44 @@ void alloc_local(wholememory_handle_* h)
     WM_BK(bk->malloc_pinned(&h->local_ptr, h->local_alloc));
     return;
   }
-  // WM_MALLOC_PROBE=K (default 1 = off): for device shards of at least WM_MALLOC_PROBE_MIN_BYTES (default 1 GiB) up to K
-  // candidate allocations are made, each is timed with the placement probe (kernels/probe.hip: pseudo-random 512-byte row
-  // writes — the level the memory system serves them at depends on where the allocation sits in HBM, by up to 20 %, and
-  // stays with the allocation for its lifetime), the fastest is kept and the others are released. Candidates are alive
-  // together: K x the shard size must be free at this moment (a candidate that cannot be allocated ends the search).
-  // Every rank decides for its own shard; no collective is involved.
-  static const int k_candidates = [] {
+  // Placement probe. The level the memory system serves random row WRITES at (scatter, gradient
+  // apply) depends on where a big allocation sits in HBM — by up to 20 %, for the allocation's lifetime — so a device shard of
+  // at least WM_MALLOC_PROBE_MIN_BYTES (default 1 GiB) is chosen among up to K candidate allocations: each is timed with the
+  // probe (kernels/probe.hip: pseudo-random 512-byte row writes, a few ms), the fastest is kept, the others are released.
+  // The candidates have to be alive together (an allocation that is freed comes back at the same place).
+  //   WM_MALLOC_PROBE unset  automatic: up to 3 candidates, as many as fit in HALF of the memory that is free after the first
+  //                          one, and none at all when the first one already probes as well placed (WM_MALLOC_PROBE_GOOD,
+  //                          default 0.166 ms per GiB: well placed tables probe at 0.160-0.165, badly placed ones at 0.17-0.21)
+  //   WM_MALLOC_PROBE=1      off: the first allocation is the shard
+  //   WM_MALLOC_PROBE=K      exactly K candidates (2 ... 8), whatever the first one looks like
+  // A candidate that cannot be allocated ends the search. Every rank decides for its own shard; no collective is involved.
+  static const int k_setting = [] {
     const char* e = getenv("WM_MALLOC_PROBE");
-    const int k   = e != nullptr ? atoi(e) : 1;
-    return std::min(std::max(k, 1), 8);
+    if (e == nullptr || e[0] == '\0') return -1;
+    return std::min(std::max(atoi(e), 1), 8);
   }();
   static const size_t min_bytes = [] {
     const char* e = getenv("WM_MALLOC_PROBE_MIN_BYTES");
     return e != nullptr && atoll(e) > 0 ? static_cast<size_t>(atoll(e)) : (static_cast<size_t>(1) << 30);
   }();
+  static const float good_ms = [] {
+    const char* e = getenv("WM_MALLOC_PROBE_GOOD");
+    return e != nullptr && atof(e) > 0 ? static_cast<float>(atof(e)) : 0.166f;
+  }();
   WM_BK(bk->malloc_device(&h->local_ptr, h->local_alloc));
-  if (k_candidates <= 1 || bk->probe_memory == nullptr || h->local_alloc < min_bytes) return;
+  if (k_setting == 1 || bk->probe_memory == nullptr || h->local_alloc < min_bytes) return;
   static const bool verbose = getenv("WM_MALLOC_PROBE_VERBOSE") != nullptr;
+  int k_candidates = k_setting;
+  if (k_setting < 0) {
+    size_t free_b = 0, total_b = 0;
+    if (bk->mem_info == nullptr || bk->mem_info(&free_b, &total_b) != 0) return;
+    k_candidates = 1 + static_cast<int>(std::min<size_t>(2, free_b / 2 / h->local_alloc));
+    if (k_candidates <= 1) return;
+  }
   float best_ms = 0;
   if (bk->probe_memory(h->local_ptr, h->local_alloc, 0, 3, &best_ms, nullptr) != 0) return;
   if (verbose) fprintf(stderr, "[wholegraph_amd] malloc probe: candidate 0 at %p: %.4f ms per GiB\n", h->local_ptr, best_ms);
+  if (k_setting < 0 && best_ms <= good_ms) return;   // well placed as it is
   std::vector<void*> losers;
   for (int k = 1; k < k_candidates; k++) {
     void* cand = nullptr;
@@ -165,6 +182,7 @@ void alloc_local(wholememory_handle_* h)
     } else {
       losers.push_back(cand);
     }
+    if (k_setting < 0 && best_ms <= good_ms) break;
   }
   for (void* l : losers) (void)bk->free_device(l);
   WM_INFO("wholememory_malloc: kept the best of %d probed device allocations of %zu bytes (%.4f ms per GiB of random rows)",
