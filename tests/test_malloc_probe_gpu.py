@@ -21,16 +21,16 @@ import wholegraph_amd.torch as wgth
 from wholegraph_amd import binding as wmb
 wmb.check(wmb.lib().wholememory_init(0, wmb.LEVEL_WARN))
 comm = wgth.create_group_communicator(1)
-rows, dim = 65536, 64                       # 16 MiB shard: above the lowered threshold
+import os
+rows, dim = int(os.environ.get("PROBE_TEST_ROWS", "65536")), 64      # default: 16 MiB shard, above the lowered threshold
 emb = wgth.create_embedding(comm, "chunked", "cuda", torch.float32, [rows, dim])
 t = emb.get_embedding_tensor()
 g = torch.Generator(device="cuda").manual_seed(7)
-idx = torch.randperm(rows, device="cuda", generator=g)[:20000]
+idx = torch.randperm(20000, device="cuda", generator=g) * (rows // 20000)      # distinct rows spread over the shard
 src = (idx.to(torch.float32)[:, None] + torch.arange(dim, device="cuda", dtype=torch.float32)[None, :]).contiguous()
 t.scatter(src, idx)
 out = emb.gather(idx)
 assert torch.equal(out, src), "gather after scatter differs"
-untouched = torch.ones(rows, dtype=torch.bool, device="cuda"); untouched[idx] = False
 loc, first = t.get_local_tensor()
 print("OK", int(first))
 """ % ROOT
@@ -58,6 +58,21 @@ def test_automatic_probe_stops_at_a_well_placed_candidate(wm_lib, good, expected
     assert "OK 0" in r.stdout
     lines = [l for l in r.stderr.splitlines() if "malloc probe: candidate" in l]
     assert len(lines) == expected, r.stderr
+
+
+def test_candidates_that_do_not_fit_end_the_search_quietly(wm_lib):
+    """WM_MALLOC_PROBE=8 on a 70 GB shard: the fifth candidate cannot be allocated on a 288 GB device — the search ends there,
+    the best of the ones that fitted is kept, and the failed hipMalloc leaves no error behind for the ops that follow."""
+    free_b, _ = torch.cuda.mem_get_info()
+    rows = 70 * (1 << 30) // (64 * 4)
+    if free_b < 3 * rows * 256:
+        pytest.skip("needs most of an empty device")
+    env = dict(os.environ, WM_MALLOC_PROBE="8", WM_MALLOC_PROBE_VERBOSE="1", PROBE_TEST_ROWS=str(rows))
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK 0" in r.stdout
+    lines = [l for l in r.stderr.splitlines() if "malloc probe: candidate" in l]
+    assert 2 <= len(lines) < 8, r.stderr
 
 
 def test_probe_switched_off(wm_lib):

@@ -70,9 +70,21 @@ int h_device_count()
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
-int h_malloc_device(void** p, size_t bytes) { return rc(hipMalloc(p, bytes)); }
+// a failed allocation must not leave its error behind for the next, unrelated hipGetLastError() check (a candidate shard of the
+// placement probe that does not fit simply ends the search, memory_handle.cpp:alloc_local)
+int h_malloc_device(void** p, size_t bytes)
+{
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) (void)hipGetLastError();
+  return rc(e);
+}
 int h_free_device(void* p) { return rc(hipFree(p)); }
-int h_malloc_pinned(void** p, size_t bytes) { return rc(hipHostMalloc(p, bytes, hipHostMallocDefault)); }
+int h_malloc_pinned(void** p, size_t bytes)
+{
+  const hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) (void)hipGetLastError();
+  return rc(e);
+}
 int h_free_pinned(void* p) { return rc(hipHostFree(p)); }
 int h_memcpy_async(void* dst, const void* src, size_t bytes, void* stream)
 {
