@@ -242,20 +242,9 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
     seeds = torch.randint(0, nodes, (a.seeds,), device="cuda", generator=gen2, dtype=torch.int32)
     stat = {}
 
-    # WM_BENCH_C5_FUSED=0: the reference's flow as it stands (sampling call, then feat.gather(target_gids[0])); default: the
-    # gather_features_from extension — the feature rows are fetched inside the sampling call from the count it left on the
-    # device, so the step has one host round trip instead of two (falls back by itself where the fused call does not apply)
-    fused = os.environ.get("WM_BENCH_C5_FUSED", "1") != "0"
-
     def step():
-        if fused:
-            tg, ei, rp, ci, x = g.multilayer_sample_without_replacement(seeds, fanouts, gather_features_from=feat)
-            stat["feature_gather"] = ("inside the sampling call (count read on the device)"
-                                      if x.untyped_storage().nbytes() > x.numel() * x.element_size() else "separate call")
-        else:
-            tg, ei, rp, ci = g.multilayer_sample_without_replacement(seeds, fanouts)
-            x = feat.gather(tg[0])
-            stat["feature_gather"] = "separate call"
+        tg, ei, rp, ci = g.multilayer_sample_without_replacement(seeds, fanouts)
+        x = feat.gather(tg[0])
         stat["nodes"], stat["edges"] = tg[0].numel(), sum(int(c.numel()) for c in ci)
         stat["frontiers"] = [int(t.numel()) for t in tg]
         return x, tg[0]
@@ -313,7 +302,6 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
         "sampled_edges_per_s": round(stat["edges"] * world / (ms * 1e-3), 0),
         "subgraph_nodes_per_step": stat["nodes"], "sampled_edges_per_step": stat["edges"], "frontier_sizes": stat["frontiers"],
         "device_allocs_in_timed_region": stat["device_allocs_in_timed_region"],   # fresh hipMallocs by the caching allocator: 0 in a steady state
-        "feature_gather": stat.get("feature_gather"),
         "config": {"workload": "C5 %s graph %d nodes / %d edges (int32 col) + %dx%d fp32 features, %d-hop %s unweighted sample "
                                "from %d seeds per rank + append_unique + feature gather" % (
                                    mt, nodes, edges, nodes, a.dim, len(fanouts), fanouts, a.seeds),
@@ -322,7 +310,7 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
                      "frac": round(algo / (ms * 1e-3) / 8e12, 4), "traffic": None,
                      "algorithmic_bytes_per_step": algo,
                      "limited_by": "dependent-load latency (row_ptr -> col -> features) and launch / host-sync latency: a step is "
-                                   "~%d small launches with one host round trip per step to size the outputs "
+                                   "~%d small launches / copies with one host round trip per hop to size the outputs "
                                    "(rocprofv3 timeline: experiments/trace_c5.sh), far from the HBM "
                                    "roofline by construction; larger seed batches move it up (see --seeds)" % (14 * len(fanouts) + 2)},
     }

@@ -165,24 +165,6 @@ enum wholememory_error_code_t wholememory_ext_multilayer_sample(
   void* const* unique, int* const* neighbor_pos, int* const* center_lid, int* counts_host,
   struct wholememory_env_func_t* p_env_fns, void* stream);
 
-/* The chain above followed, in the same call and with no host round trip in between, by the gather of the feature rows of the
- * last hop's unique ids (every node of the sampled sub-graph): feature_output is a device [cap_c[hops], dim] tensor, its first
- * n_c[hops] rows are written (the count is read by the gather kernel on the device). feature_tensor: a mapped (CHUNKED /
- * CONTINUOUS / plain device) 2-D table indexed by node id; WHOLEMEMORY_NOT_SUPPORTED to the query otherwise. */
-enum wholememory_error_code_t wholememory_ext_multilayer_sample_gather(
-  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor, wholememory_tensor_t seed_nodes_tensor,
-  int hops, const int* max_sample_counts, const unsigned long long* random_seeds, void* const* sample_offsets,
-  void* const* unique, int* const* neighbor_pos, int* const* center_lid, int* counts_host,
-  wholememory_tensor_t feature_tensor, wholememory_tensor_t feature_output, struct wholememory_env_func_t* p_env_fns,
-  void* stream);
-
-/* wholememory_gather whose number of ids is known on the device only: indices_tensor has room for its size, the first
- * min(size, *n_valid_dev) ids are in use (n_valid_dev: device int), output rows past them stay untouched. Mapped tables only
- * (WHOLEMEMORY_NOT_SUPPORTED for tables behind the exchange: DISTRIBUTED / HIERARCHY); asynchronous on `stream`, no scratch. */
-enum wholememory_error_code_t wholememory_ext_gather_counted(wholememory_tensor_t wholememory_tensor,
-                                                             wholememory_tensor_t indices_tensor, const int* n_valid_dev,
-                                                             wholememory_tensor_t output_tensor, void* stream);
-
 /* Completion semantics of the ops whose reference versions drain the stream before returning (neighbour sampling,
  * graph_append_unique and the fused hop above). Default 0 = the reference's: outputs complete and scratch idle at return,
  * safe with any env functions. 1 = the ops return with their last kernels queued on `stream` (one host round trip fewer

@@ -126,9 +126,8 @@ int t_gather(const wm_rows_args* a, void*)
   if (a->n == 0 || a->dim == 0) return 0;
   shard_view v;
   if (!make_view(a, &v)) return -1;
-  const int64_t n = a->n_dev != nullptr ? std::min<int64_t>(a->n, *a->n_dev) : a->n;   // (host memory on this backend)
   int rc = wmo_gather(v.ptrs.data(), v.offs.data(), v.world, a->table_dtype, a->dim, a->table_stride,
-                      a->table_storage_offset, a->indices, a->index_dtype, n, a->row_map, a->plain, a->plain_dtype,
+                      a->table_storage_offset, a->indices, a->index_dtype, a->n, a->row_map, a->plain, a->plain_dtype,
                       a->plain_stride, a->plain_storage_offset);
   return rc == 0 ? 0 : -1;
 }

@@ -225,101 +225,3 @@ def test_chain_declines_upper_bounds_beyond_the_table_route(gpu_env):
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20), "a declined chain must not have allocated its buffers"
     assert wholegraph_ops.multilayer_sample(wrow.wmb_tensor, wcol.wmb_tensor, seeds[:0], [5], [1]) is None
     assert wholegraph_ops.multilayer_sample(wrow.wmb_tensor, wcol.wmb_tensor, seeds[:4096], [30, 30], [1, 2]) is not None
-
-
-@pytest.mark.parametrize("mt", ["chunked", "continuous", "none"])
-@pytest.mark.parametrize("dim,tdt,odt", [(128, "float32", "float32"), (100, "float32", "float32"), (64, "float16", "float32"),
-                                         (7, "int64", "int64"), (256, "float32", "float32")])
-@pytest.mark.parametrize("idt", ["int32", "int64"])
-def test_counted_gather_reads_its_size_on_the_device(gpu_env, wm_lib, mt, dim, tdt, odt, idt):
-    """wholememory_ext_gather_counted: the ids array has ROOM for n ids, the number in use is a device int — the first
-    min(n, *n_dev) output rows equal the plain gather's, the others (and rows of negative ids) stay as they were."""
-    import ctypes as C
-    import torch
-    import wholegraph_amd.torch as wgth
-    from wholegraph_amd import binding as wmb
-    from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor, get_stream
-    rows, room = 40_003, 5_000
-    tt, ot, it = getattr(torch, tdt), getattr(torch, odt), getattr(torch, idt)
-    rng = np.random.default_rng(3)
-    table = (torch.from_numpy(rng.standard_normal((rows, dim)).astype(np.float32) * 50).to(tt) if tt.is_floating_point
-             else torch.from_numpy(rng.integers(-2 ** 40, 2 ** 40, (rows, dim))))
-    if mt == "none":      # a plain device tensor wrapped as a wholememory tensor (no handle)
-        dev_table = table.cuda()
-        holder = wrap_torch_tensor(dev_table)
-        handle = holder.handle
-    else:
-        wm = wgth.create_wholememory_tensor(gpu_env, mt, "cuda", [rows, dim], tt, [dim, 1])
-        wm.get_local_tensor()[0].copy_(table)
-        handle = wm.wmb_tensor
-    idx_np = rng.integers(0, rows, room)
-    idx_np[::13] = -1
-    idx = torch.from_numpy(idx_np).to(it).cuda()
-    for used in (0, 1, 8, 9, 3217, room, room + 50):
-        n_dev = torch.tensor([used], dtype=torch.int32, device="cuda")
-        out = torch.full((room, dim), 7, dtype=ot, device="cuda")
-        wi, wo = wrap_torch_tensor(idx), wrap_torch_tensor(out)
-        wmb.check(wm_lib.wholememory_ext_gather_counted(handle, wi.handle, C.c_void_p(n_dev.data_ptr()), wo.handle,
-                                                        C.c_void_p(get_stream())))
-        torch.cuda.synchronize()
-        live = min(used, room)
-        want = torch.full((room, dim), 7, dtype=ot)
-        ok = torch.from_numpy(idx_np[:live] >= 0)
-        want[:live][ok] = table[torch.from_numpy(idx_np[:live][idx_np[:live] >= 0])].to(ot)
-        assert out.cpu().view(torch.uint8).numpy().tobytes() == want.view(torch.uint8).numpy().tobytes(), (used, mt, dim)
-    if mt != "none":
-        wgth.destroy_wholememory_tensor(wm)
-
-
-def test_counted_gather_declines_tables_behind_the_exchange(gpu_env, wm_lib):
-    import ctypes as C
-    import torch
-    import wholegraph_amd.torch as wgth
-    from wholegraph_amd import binding as wmb
-    from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor, get_stream
-    wm = wgth.create_wholememory_tensor(gpu_env, "distributed", "cuda", [1000, 8], torch.float32, [8, 1])
-    idx = torch.zeros(10, dtype=torch.int64, device="cuda")
-    out = torch.zeros((10, 8), device="cuda")
-    n_dev = torch.tensor([5], dtype=torch.int32, device="cuda")
-    wi, wo = wrap_torch_tensor(idx), wrap_torch_tensor(out)
-    rc = wm_lib.wholememory_ext_gather_counted(wm.wmb_tensor, wi.handle, C.c_void_p(n_dev.data_ptr()), wo.handle, C.c_void_p(get_stream()))
-    assert rc == wmb.NOT_SUPPORTED
-    wgth.destroy_wholememory_tensor(wm)
-
-
-@pytest.mark.parametrize("feat_mt,fused", [("chunked", True), ("continuous", True), ("distributed", False)])
-@pytest.mark.parametrize("id_dtype,fanouts,fdt", [(np.int32, [30, 30], None), (np.int64, [15, 10, 5], "float16"), (np.int32, [200, 3], None)])
-def test_chain_with_the_feature_gather_inside(gpu_env, feat_mt, fused, id_dtype, fanouts, fdt):
-    """multilayer_sample_without_replacement(..., gather_features_from=table): the fifth element equals
-    table.gather(target_gids[0]) bit for bit and the four lists equal those of the call without it; with a mapped table the
-    features come out of the sampling call itself (a view of the upper-bound buffer), with a DISTRIBUTED one by the ordinary
-    gather. Also through a WholeMemoryEmbedding."""
-    import torch
-    import wholegraph_amd.torch as wgth
-    n_nodes, dim = 20011, 128
-    row_ptr, col = make_csr(n_nodes, 40, 5, id_dtype, heavy=[(3, 3000), (4, 0), (5, 700)])
-    wrow, wcol = _wm_array(gpu_env, "chunked", row_ptr), _wm_array(gpu_env, "chunked", col)
-    g = wgth.GraphStructure()
-    g.set_csr_graph(wrow, wcol)
-    emb = wgth.create_embedding(gpu_env, feat_mt, "cuda", torch.float32, [n_nodes, dim])
-    table = emb.get_embedding_tensor()
-    all_ids = torch.arange(n_nodes, dtype=torch.int64, device="cuda")
-    table.scatter(torch.randn((n_nodes, dim), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)), all_ids)
-    seeds = torch.from_numpy(np.concatenate([[3, 4, 5, 5], np.random.default_rng(2).permutation(n_nodes)[:500]]).astype(id_dtype)).cuda()
-    hop_seeds = [11 + 3 * i for i in range(len(fanouts))]
-    force = None if fdt is None else getattr(torch, fdt)
-    ref = g.multilayer_sample_without_replacement(seeds, fanouts, random_seeds=hop_seeds)
-    want = table.gather(ref[0][0], force_dtype=force)
-    for source in (table, emb):
-        got = g.multilayer_sample_without_replacement(seeds, fanouts, random_seeds=hop_seeds, gather_features_from=source,
-                                                      feature_dtype=force)
-        torch.cuda.synchronize()
-        assert len(got) == 5
-        for a_list, b_list in zip(got[:4], ref):
-            assert len(a_list) == len(b_list) and all(torch.equal(a, b) for a, b in zip(a_list, b_list))
-        feats = got[4]
-        assert feats.dtype == want.dtype and tuple(feats.shape) == tuple(want.shape)
-        assert torch.equal(feats, want)
-        inside = feats.untyped_storage().nbytes() > feats.numel() * feats.element_size()
-        assert inside == fused
-    wgth.destroy_embedding(emb)

@@ -35,10 +35,6 @@ struct wm_rows_args {
   int64_t plain_stride;               // elements
   int64_t plain_storage_offset;       // elements
   int max_blocks;                     // "gather_sms"/"scatter_sms": -1 = default
-  // optional (gather only), device: the number of entries of `indices` in use is min(n, *n_dev), read by the kernel — n is
-  // then the ROOM of the arrays (the grid is sized for it) and entries past the count are skipped like negative ids. Lets a
-  // producer that leaves its output size on the device (the sampling chain) be followed by the gather with no host round trip.
-  const int* n_dev;
 };
 
 // per-rank bucketing of ids (see kernels/bucket.hip)

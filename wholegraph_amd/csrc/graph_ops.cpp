@@ -515,12 +515,10 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
 // with n_c[0] = seeds, n_c[h + 1] = n_c[h] + new[h]. Outputs equal those of `hops` fused-hop calls bit for bit (same kernels,
 // same per-hop seeds). WHOLEMEMORY_NOT_SUPPORTED (nothing queued): CSR not mapped into this rank, dtypes differ, an empty seed
 // array, a fan-out <= 0, or a hop whose upper bounds are too big for the hash-table route of append_unique.
-// (feature_tensor / feature_output: the _gather variant below; nullptr = the chain alone)
-static wholememory_error_code_t multilayer_chain(
+wholememory_error_code_t wholememory_ext_multilayer_sample(
   wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor, wholememory_tensor_t seed_nodes_tensor,
   int hops, const int* max_sample_counts, const unsigned long long* random_seeds, void* const* sample_offsets, void* const* unique,
-  int* const* neighbor_pos, int* const* center_lid, int* counts_host, wholememory_tensor_t feature_tensor,
-  wholememory_tensor_t feature_output, wholememory_env_func_t* p_env_fns, void* stream)
+  int* const* neighbor_pos, int* const* center_lid, int* counts_host, wholememory_env_func_t* p_env_fns, void* stream)
 {
   WM_API_BEGIN
   const auto* bk = graph_backend();
@@ -552,15 +550,6 @@ static wholememory_error_code_t multilayer_chain(
     if (cap_c[h + 1] >= (INT64_C(1) << 31) - 1 ||
         !bk->append_unique_takes_bounds(static_cast<int>(cap_c[h]), static_cast<int>(cap_s[h]), seed_desc.dtype))
       return WHOLEMEMORY_NOT_SUPPORTED;
-  }
-  if (feature_tensor != nullptr) {   // the features of the last hop's unique ids, gathered from a device-side count
-    if (query) {
-      // (no output buffer exists yet: ask with the table as its own stand-in for the shape / dtype rules)
-      const auto frc = gather_counted(feature_tensor, nullptr, seed_desc.dtype, 0, nullptr, feature_tensor, stream, true);
-      if (frc != WHOLEMEMORY_SUCCESS) return frc == WHOLEMEMORY_NOT_SUPPORTED ? frc : WHOLEMEMORY_INVALID_INPUT;
-    } else if (feature_output == nullptr) {
-      return WHOLEMEMORY_INVALID_INPUT;
-    }
   }
   if (query) return WHOLEMEMORY_SUCCESS;
   wm_sample_args a{};
@@ -605,43 +594,12 @@ static wholememory_error_code_t multilayer_chain(
     if (rc != 0) return rc == -1 ? WHOLEMEMORY_LOGIC_ERROR : WHOLEMEMORY_CUDA_ERROR;
     WM_BK(bk->append_unique_phase2(a.centers, nc, ns, ns, seed_desc.dtype, ws, unique[h], neighbor_pos[h], nullptr, nullptr, &b, stream));
   }
-  if (feature_tensor != nullptr) {
-    // unique[hops - 1] holds room for cap_c[hops] ids, n_dev[hops - 1] of them in use: the gather reads the count on the device
-    WHOLEMEMORY_RETURN_ON_FAIL(gather_counted(feature_tensor, unique[hops - 1], seed_desc.dtype, cap_c[hops], n_dev + (hops - 1),
-                                              feature_output, stream));
-  }
   // by default the call returns complete, like every op of the reference; a host framework that declared stream-ordered
   // allocators (wholememory_ext_set_async_completion) gets it back with everything queued and synchronises when it reads
   // counts_host
   if (!async_completion_enabled() || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
   return WHOLEMEMORY_SUCCESS;
   WM_API_END
-}
-
-wholememory_error_code_t wholememory_ext_multilayer_sample(
-  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor, wholememory_tensor_t seed_nodes_tensor,
-  int hops, const int* max_sample_counts, const unsigned long long* random_seeds, void* const* sample_offsets, void* const* unique,
-  int* const* neighbor_pos, int* const* center_lid, int* counts_host, wholememory_env_func_t* p_env_fns, void* stream)
-{
-  return multilayer_chain(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_tensor, hops, max_sample_counts, random_seeds,
-                          sample_offsets, unique, neighbor_pos, center_lid, counts_host, nullptr, nullptr, p_env_fns, stream);
-}
-
-// The chain above followed, in the same call and with no host round trip between them, by the gather of the feature rows of
-// the LAST hop's unique ids (GraphStructure's target_gids[0]: every node of the sampled sub-graph): feature_output has room for
-// cap_c[hops] rows, the first n_c[hops] are written — the gather kernel reads that count on the device (wm_rows_args::n_dev).
-// feature_tensor must be a mapped (CHUNKED / CONTINUOUS, or plain device) 2-D table indexed by node id; anything else answers
-// WHOLEMEMORY_NOT_SUPPORTED to the query (sample_offsets == nullptr) with nothing queued.
-wholememory_error_code_t wholememory_ext_multilayer_sample_gather(
-  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor, wholememory_tensor_t seed_nodes_tensor,
-  int hops, const int* max_sample_counts, const unsigned long long* random_seeds, void* const* sample_offsets, void* const* unique,
-  int* const* neighbor_pos, int* const* center_lid, int* counts_host, wholememory_tensor_t feature_tensor,
-  wholememory_tensor_t feature_output, wholememory_env_func_t* p_env_fns, void* stream)
-{
-  if (feature_tensor == nullptr) return WHOLEMEMORY_INVALID_INPUT;
-  return multilayer_chain(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_tensor, hops, max_sample_counts, random_seeds,
-                          sample_offsets, unique, neighbor_pos, center_lid, counts_host, feature_tensor, feature_output, p_env_fns,
-                          stream);
 }
 
 wholememory_error_code_t csr_add_self_loop(wholememory_tensor_t csr_row_ptr_tensor, wholememory_tensor_t csr_col_ptr_tensor,

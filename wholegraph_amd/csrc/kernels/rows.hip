@@ -83,7 +83,6 @@ struct rows_params {
   // index side
   const void* indices;
   const int64_t* row_map;
-  const int* n_dev;   // optional (gather): entries in use = min(n, *n_dev), see wm_rows_args::n_dev
   int64_t n;
   // plain side (already offset by storage_offset)
   char* plain;
@@ -140,10 +139,6 @@ __device__ __forceinline__ void load_tile_entry(const rows_params& p, int64_t en
 #endif
     int64_t idx = WM_IDX_NT ? static_cast<int64_t>(__builtin_nontemporal_load(static_cast<const IdxT*>(p.indices) + entry))
                             : static_cast<int64_t>(static_cast<const IdxT*>(p.indices)[entry]);
-    // a device-side count (wm_rows_args::n_dev): the arrays have room for p.n entries, so the id is read whatever the count
-    // says and the two loads are in flight together — testing the count first puts a whole memory latency in front of every
-    // one-tile wave (measured: the 560 k-row feature gather of a C5 step 100 -> 125 us)
-    if (p.n_dev != nullptr && entry >= static_cast<int64_t>(*p.n_dev)) idx = -1;
     if (idx >= 0) {
       tab         = resolve_row(p, idx);
       int64_t row = p.row_map ? p.row_map[entry] : entry;  // row map is always int64 (raw_indices)
@@ -1101,8 +1096,6 @@ int rows_op(const wm_rows_args* a, void* stream_v)
   p.table_offset_bytes = a->table_storage_offset * tes;
   p.indices            = a->indices;
   p.row_map            = static_cast<const int64_t*>(a->row_map);
-  p.n_dev              = a->n_dev;
-  if (!GATHER && a->n_dev != nullptr) return -1;   // (the scatter kernels test p.n in places of their own)
   p.n                  = a->n;
   p.plain              = static_cast<char*>(a->plain) + a->plain_storage_offset * pes;
   p.plain_stride_bytes = a->plain_stride * pes;

@@ -996,70 +996,11 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
 
 namespace wm {
 std::atomic<int64_t> g_host_sorted_gathers{0};
-
-wholememory_error_code_t gather_counted(wholememory_tensor_t table, const void* indices, wholememory_dtype_t index_dtype,
-                                        int64_t n_room, const int* n_dev, wholememory_tensor_t output, void* stream, bool query)
-{
-  if (table == nullptr || output == nullptr) return WHOLEMEMORY_INVALID_INPUT;
-  const bool has_handle = wholememory_tensor_has_handle(table);
-  if (has_handle) {
-    const auto mt = wholememory_get_memory_type(wholememory_tensor_get_memory_handle(table));
-    if ((mt != WHOLEMEMORY_MT_CHUNKED && mt != WHOLEMEMORY_MT_CONTINUOUS) || mapped_via_exchange(table, mt))
-      return WHOLEMEMORY_NOT_SUPPORTED;
-  }
-  auto td = *wholememory_tensor_get_tensor_description(table);
-  auto od = *wholememory_tensor_get_tensor_description(output);
-  if (td.dim != 2 || od.dim != 2 || (index_dtype != WHOLEMEMORY_DT_INT && index_dtype != WHOLEMEMORY_DT_INT64))
-    return WHOLEMEMORY_INVALID_INPUT;
-  op_descs d;
-  if (!wholememory_convert_tensor_desc_to_matrix(&d.table, &td) || !wholememory_convert_tensor_desc_to_matrix(&d.plain, &od))
-    return WHOLEMEMORY_INVALID_INPUT;
-  if (d.plain.sizes[0] < n_room || d.plain.sizes[1] != d.table.sizes[1]) {
-    WM_ERROR("counted gather: output is [%ld, %ld], needs room for %ld rows of %ld columns", static_cast<long>(d.plain.sizes[0]),
-             static_cast<long>(d.plain.sizes[1]), static_cast<long>(n_room), static_cast<long>(d.table.sizes[1]));
-    return WHOLEMEMORY_INVALID_INPUT;
-  }
-  if (wholememory_dtype_is_floating_number(d.table.dtype) != wholememory_dtype_is_floating_number(d.plain.dtype))
-    return WHOLEMEMORY_LOGIC_ERROR;   // as wholememory_gather (gather_func.cu:79-81)
-  if (query || n_room == 0) return WHOLEMEMORY_SUCCESS;
-  if (indices == nullptr || n_dev == nullptr) return WHOLEMEMORY_INVALID_INPUT;
-  wholememory_gref_t gref;
-  WHOLEMEMORY_RETURN_ON_FAIL(mapped_gref(table, &gref));
-  wm_rows_args a{};
-  // WM_COUNTED_BLOCKS=k (experiment switch): the persistent grid of k workgroups instead of one tile per wave — no workgroup is
-  // launched for the unused room then
-  static const int counted_blocks = [] {
-    const char* e = getenv("WM_COUNTED_BLOCKS");
-    return e != nullptr && atoi(e) > 0 ? atoi(e) : -1;
-  }();
-  fill_rows_args(&a, gref, d.table, indices, index_dtype, n_room, wholememory_tensor_get_data_pointer(output), d.plain, counted_blocks);
-  a.n_dev = n_dev;
-  const int rc = backend()->gather_rows(&a, stream);
-  if (rc == -1) return WHOLEMEMORY_INVALID_INPUT;
-  return rc == 0 ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_CUDA_ERROR;
-}
 }
 
 extern "C" {
 
 int64_t wholememory_ext_host_sorted_gathers(void) { return wm::g_host_sorted_gathers.load(std::memory_order_relaxed); }
-
-wholememory_error_code_t wholememory_ext_gather_counted(wholememory_tensor_t wholememory_tensor,
-                                                        wholememory_tensor_t indices_tensor,
-                                                        const int* n_valid_dev,
-                                                        wholememory_tensor_t output_tensor,
-                                                        void* stream)
-{
-  WM_API_BEGIN
-  if (indices_tensor == nullptr) return WHOLEMEMORY_INVALID_INPUT;
-  const auto* id = wholememory_tensor_get_tensor_description(indices_tensor);
-  if (id->dim != 1) return WHOLEMEMORY_INVALID_INPUT;
-  wholememory_error_code_t rc = wm::gather_counted(wholememory_tensor, wholememory_tensor_get_data_pointer(indices_tensor), id->dtype,
-                                                   id->sizes[0], n_valid_dev, output_tensor, stream);
-  if (rc == WHOLEMEMORY_SUCCESS && wm::debug_sync_enabled() && wm::backend()->stream_sync(stream) != 0) return WHOLEMEMORY_CUDA_ERROR;
-  return rc;
-  WM_API_END
-}
 
 wholememory_error_code_t wholememory_gather(wholememory_tensor_t wholememory_tensor,
                                             wholememory_tensor_t indices_tensor,

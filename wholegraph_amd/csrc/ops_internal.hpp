@@ -112,13 +112,6 @@ wholememory_gref_t local_shard_gref(wholememory_handle_t handle);
 // gref a kernel should use for a tensor mapped in this process (CONTINUOUS / CHUNKED handle or a plain pointer)
 wholememory_error_code_t tensor_mapped_gref(wholememory_tensor_t t, wholememory_gref_t* gref);
 
-// Gather whose number of ids is known on the DEVICE only: `indices` has room for n_room ids, the first min(n_room, *n_dev)
-// are in use, output rows past them stay untouched. Mapped tables only (a table behind the exchange needs the counts on the
-// host): WHOLEMEMORY_NOT_SUPPORTED otherwise, nothing queued. query = true only answers that question.
-wholememory_error_code_t gather_counted(wholememory_tensor_t table, const void* indices, wholememory_dtype_t index_dtype,
-                                        int64_t n_room, const int* n_dev, wholememory_tensor_t output, void* stream,
-                                        bool query = false);
-
 struct row_cache;
 // gather of an embedding with a device row cache (embedding_cache.hpp)
 wholememory_error_code_t gather_cached(wholememory_tensor_t table, wholememory_tensor_t indices_tensor,

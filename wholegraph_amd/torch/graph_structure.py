@@ -101,50 +101,26 @@ class GraphStructure(object):
     # ------------------------------------------------------------------------------------------ several hops
     def multilayer_sample_without_replacement(self, node_ids: torch.Tensor, max_neighbors: List[int],
                                               weight_name: Union[str, None] = None, *,
-                                              random_seeds: Optional[Sequence[int]] = None,
-                                              gather_features_from=None, feature_dtype=None):
+                                              random_seeds: Optional[Sequence[int]] = None):
         """Sample len(max_neighbors) hops outwards from node_ids (max_neighbors[0] is the fan-out of the hop next to the
         seeds). Returns four lists indexed by layer, OUTERMOST layer first, as the reference does:
           target_gids  (hops + 1 entries; the last one is node_ids, entry i holds entry i + 1 followed by its new neighbours)
           edge_indice  [2, n_edges]: row 0 = position of the neighbour in target_gids[i], row 1 = position of its centre
-          csr_row_ptr / csr_col_ind of the sampled block (col_ind = row 0 of edge_indice)
-        gather_features_from (extension; a WholeMemoryTensor / WholeMemoryEmbedding of node features): a fifth element is
-        returned, the feature rows of target_gids[0] — equal to gather_features_from.gather(target_gids[0]) — fetched inside
-        the sampling call when the whole chain runs as one library call (mapped CSR and mapped feature table), without a
-        second host round trip; by the ordinary gather otherwise."""
+          csr_row_ptr / csr_col_ind of the sampled block (col_ind = row 0 of edge_indice)"""
         hops = len(max_neighbors)
-        feat_src = fused_src = gather_features_from
-        if feat_src is not None and hasattr(feat_src, "get_embedding_tensor"):
-            # an embedding: inference lookup; its table is read directly by the fused call unless a row cache sits in front
-            fused_src = feat_src.get_embedding_tensor() if getattr(feat_src, "wmb_cache_policy", None) is None else None
-
-        def with_features(result):
-            if feat_src is None:
-                return result
-            return result + (feat_src.gather(result[0][0], force_dtype=feature_dtype),)
-
         if random_seeds is not None:
             assert len(random_seeds) == hops, "one seed per hop"
         layers = [None] * hops
         if weight_name is None and hops > 0 and os.environ.get("WM_MULTILAYER_CHAIN", "1") != "0":
             # the whole chain as one library call with a single host round trip (extension); None = not applicable to this
             # graph or these sizes: hop by hop below then
-            chain, features = None, None
-            if fused_src is not None:   # chain + feature gather in one call; None = one of the two is not applicable
-                both = wholegraph_ops.multilayer_sample(self.csr_row_ptr.wmb_tensor, self.csr_col_ind.wmb_tensor, node_ids,
-                                                        max_neighbors, random_seeds, feature_tensor=fused_src,
-                                                        feature_dtype=feature_dtype)
-                if both is not None:
-                    chain, features = both
-            if chain is None:
-                chain = wholegraph_ops.multilayer_sample(self.csr_row_ptr.wmb_tensor, self.csr_col_ind.wmb_tensor, node_ids,
-                                                         max_neighbors, random_seeds)
+            chain = wholegraph_ops.multilayer_sample(self.csr_row_ptr.wmb_tensor, self.csr_col_ind.wmb_tensor, node_ids,
+                                                     max_neighbors, random_seeds)
             if chain is not None:
                 for depth, (offsets, widened, neighbour_pos, centre_lid, edge_index) in enumerate(chain):
                     layers[hops - 1 - depth] = _Hop(widened, edge_index, offsets, neighbour_pos)
-                result = ([hop.targets for hop in layers] + [node_ids], [hop.edge_index for hop in layers],
-                          [hop.row_ptr for hop in layers], [hop.col_ind for hop in layers])
-                return result + (features,) if features is not None else with_features(result)
+                return ([hop.targets for hop in layers] + [node_ids], [hop.edge_index for hop in layers],
+                        [hop.row_ptr for hop in layers], [hop.col_ind for hop in layers])
         frontier = node_ids
         for depth, fanout in enumerate(max_neighbors):          # depth 0 = next to the seeds = layer hops - 1
             seed = None if random_seeds is None else random_seeds[depth]
@@ -161,5 +137,5 @@ class GraphStructure(object):
                 widened, neighbour_pos = graph_ops.append_unique(frontier, neighbours, need_neighbor_raw_to_unique=True)
             layers[hops - 1 - depth] = _Hop(widened, torch.stack([neighbour_pos, centre_lid]), offsets, neighbour_pos)
             frontier = widened
-        return with_features(([hop.targets for hop in layers] + [node_ids], [hop.edge_index for hop in layers],
-                              [hop.row_ptr for hop in layers], [hop.col_ind for hop in layers]))
+        return ([hop.targets for hop in layers] + [node_ids], [hop.edge_index for hop in layers],
+                [hop.row_ptr for hop in layers], [hop.col_ind for hop in layers])

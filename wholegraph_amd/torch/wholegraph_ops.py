@@ -81,19 +81,14 @@ _pinned_counts = {}
 
 
 def multilayer_sample(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_tensor: torch.Tensor, max_sample_counts,
-                      random_seeds=None, feature_tensor=None, feature_dtype=None):
+                      random_seeds=None):
     """Extension (wholememory_ext_multilayer_sample): every hop of an unweighted multi-layer sample in ONE library call with no
     host round trip inside — buffers sized for their upper bounds, counts kept on the device between hops, ONE stream
     synchronise here at the end. Returns a list with one (sample_offset, unique, neighbor_pos, center_lid) tuple per hop, hop 0
     next to the seeds, each tensor a trimmed view of its upper-bound buffer and equal to what `sample_append_unique` returns hop
     by hop with the same seeds — or None when the library declines (CSR not mapped into this rank, dtypes differ, empty seeds,
-    upper bounds beyond append_unique's hash-table route): run hop by hop then.
-    feature_tensor (a wholememory tensor handle, [nodes, dim], mapped into this rank): wholememory_ext_multilayer_sample_gather —
-    the feature rows of the last hop's unique ids are gathered in the SAME call, from the count the chain left on the device, so
-    the step still has one host round trip; returns (hops, features) then, features = [unique ids of the last hop, dim] of
-    feature_dtype (default: the table's). None as well when the table is not mapped (DISTRIBUTED / HIERARCHY)."""
+    upper bounds beyond append_unique's hash-table route): run hop by hop then."""
     row, col = _handle(wm_csr_row_ptr_tensor), _handle(wm_csr_col_ptr_tensor)
-    feat = _handle(feature_tensor) if feature_tensor is not None else None
     assert seed_nodes_tensor.dim() == 1
     hops = len(max_sample_counts)
     n0 = seed_nodes_tensor.shape[0]
@@ -110,15 +105,9 @@ def multilayer_sample(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_t
     fan = (C.c_int * hops)(*[int(m) for m in max_sample_counts])
     ws = wrap_torch_tensor(seed_nodes_tensor)
     # ask first (no buffers yet: the upper bounds of a declined chain can be tens of GB)
-    if feat is None:
-        answer = wmb.lib().wholememory_ext_multilayer_sample(row, col, ws.handle, hops, fan, None, None, None, None, None, None,
-                                                             None, None)
-    else:
-        answer = wmb.lib().wholememory_ext_multilayer_sample_gather(row, col, ws.handle, hops, fan, None, None, None, None, None,
-                                                                    None, feat, None, None, None)
-    if answer == wmb.NOT_SUPPORTED:
+    if wmb.lib().wholememory_ext_multilayer_sample(row, col, ws.handle, hops, fan, None, None, None, None, None, None, None,
+                                                   None) == wmb.NOT_SUPPORTED:
         return None
-    wmb.check(answer)
     dev, idt = op_device(), seed_nodes_tensor.dtype
     offsets = [torch.empty(cap_c[h] + 1, device=dev, dtype=torch.int) for h in range(hops)]
     uniques = [torch.empty(cap_c[h + 1], device=dev, dtype=idt) for h in range(hops)]
@@ -128,19 +117,9 @@ def multilayer_sample(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_t
         counts = _pinned_counts[hops] = torch.zeros(2 * hops, dtype=torch.int32).pin_memory()
     rng = (C.c_ulonglong * hops)(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in random_seeds])
     ptrs = lambda ts: (C.c_void_p * hops)(*[t.data_ptr() for t in ts])
-    features = wf = None
-    if feat is None:
-        rc = wmb.lib().wholememory_ext_multilayer_sample(
-            row, col, ws.handle, hops, fan, rng, ptrs(offsets), ptrs(uniques), ptrs([e[0] for e in edges]),
-            ptrs([e[1] for e in edges]), C.c_void_p(counts.data_ptr()), get_wholegraph_env_fns(), C.c_void_p(get_stream()))
-    else:
-        dim = int(feature_tensor.shape[1])
-        features = torch.empty((cap_c[hops], dim), device=dev, dtype=feature_dtype if feature_dtype is not None else feature_tensor.dtype)
-        wf = wrap_torch_tensor(features)
-        rc = wmb.lib().wholememory_ext_multilayer_sample_gather(
-            row, col, ws.handle, hops, fan, rng, ptrs(offsets), ptrs(uniques), ptrs([e[0] for e in edges]),
-            ptrs([e[1] for e in edges]), C.c_void_p(counts.data_ptr()), feat, wf.handle, get_wholegraph_env_fns(),
-            C.c_void_p(get_stream()))
+    rc = wmb.lib().wholememory_ext_multilayer_sample(
+        row, col, ws.handle, hops, fan, rng, ptrs(offsets), ptrs(uniques), ptrs([e[0] for e in edges]),
+        ptrs([e[1] for e in edges]), C.c_void_p(counts.data_ptr()), get_wholegraph_env_fns(), C.c_void_p(get_stream()))
     if rc == wmb.NOT_SUPPORTED:
         return None
     wmb.check(rc)
@@ -152,8 +131,6 @@ def multilayer_sample(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_t
         out.append((offsets[h][:n_c + 1], uniques[h][:n_c + n_new], edges[h][0, :n_samples], edges[h][1, :n_samples],
                     edges[h][:, :n_samples]))
         n_c += n_new
-    if feat is not None:
-        return out, features[:n_c]
     return out
 
 
