@@ -21,6 +21,7 @@ pairs probed, the fastest kept, every probe in the line as `placement.probe_ms`.
 DESIGN.md section 3.1 — which removed the dependence on the buffers' physical placement, and the default is 1 x 1.)
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -268,12 +269,19 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
     headroom = torch.empty(int(transient * 1.05) + (64 << 20), dtype=torch.uint8, device="cuda")
     del headroom
     barrier()
+    # a full collection of the interpreter's garbage collector walks every object torch's import left behind (~34 ms here,
+    # experiments/c5_step_windows.py: one window of 25 steps at 1.66 ms per step, flat 0.29 ms with the collector off); a step
+    # allocates enough Python containers to trigger one every few hundred steps. The objects alive now are moved out of the
+    # collector's reach for the timed region; the young generations keep being collected.
+    gc.collect()
+    gc.freeze()
     allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     wall = time.perf_counter() - t0
+    gc.unfreeze()
     stat["device_allocs_in_timed_region"] = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0
     dt = torch.tensor([wall], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
     if launched:
@@ -545,6 +553,8 @@ def main():
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
+    gc.collect()
+    gc.freeze()    # (see run_sample_gather: no full collection of the interpreter's long-lived objects inside the timed region)
     allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     ev0.record()
@@ -553,6 +563,7 @@ def main():
     ev1.record()
     barrier()
     t1 = time.perf_counter()
+    gc.unfreeze()
     fresh_allocs = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0   # hipMallocs by the caching allocator: 0 in a steady state
     dt = torch.tensor([t1 - t0], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
     if launched:

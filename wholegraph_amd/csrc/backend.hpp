@@ -134,6 +134,10 @@ struct wm_au_bounds {
   const int* n_target_dev;    // targets in use (<= n_target)
   const int* n_neighbor_dev;  // neighbours in use (<= n_neighbor)
   int* n_unique_dev;          // out: targets in use + new ids = what the output holds (the next hop's centre count)
+  // optional (pinned host memory, 2 ints): when set, {neighbours in use, new unique ids} and n_unique_dev are written by
+  // phase 2's emitting kernel instead of a kernel of their own at the end of phase 1 (the caller runs both phases back to
+  // back without looking at the counts in between, and passes no publish_host to phase 1): one tiny launch fewer per hop
+  int* publish_host_late;
 };
 
 // device row cache of an embedding (kernels/cache.hip): direct map row -> slot, 64-slot LFU sets

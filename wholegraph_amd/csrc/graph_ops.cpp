@@ -589,8 +589,9 @@ wholememory_error_code_t wholememory_ext_multilayer_sample(
     a.out_ids        = ids;
     a.out_center_lid = center_lid[h];
     WM_BK(bk->sample_unweighted(&a, stream));
-    wm_au_bounds b{centres_in_use, offsets + nc, n_dev + h};
-    int rc = bk->append_unique_phase1(a.centers, nc, ids, ns, offsets + nc, seed_desc.dtype, ws, nullptr, counts_host + 2 * h, &b, stream);
+    // (the hop's counts are published by phase 2's emitting kernel: one tiny launch fewer per hop)
+    wm_au_bounds b{centres_in_use, offsets + nc, n_dev + h, counts_host + 2 * h};
+    int rc = bk->append_unique_phase1(a.centers, nc, ids, ns, offsets + nc, seed_desc.dtype, ws, nullptr, nullptr, &b, stream);
     if (rc != 0) return rc == -1 ? WHOLEMEMORY_LOGIC_ERROR : WHOLEMEMORY_CUDA_ERROR;
     WM_BK(bk->append_unique_phase2(a.centers, nc, ns, ns, seed_desc.dtype, ws, unique[h], neighbor_pos[h], nullptr, nullptr, &b, stream));
   }

@@ -637,11 +637,18 @@ template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, const uint32_t* min_pos, const uint32_t* slot_of,
                                                          const int* new_rank, int nt, int nn, KeyT* out_unique, int* mapping,
                                                          const KeyT* targets, const int* copy_src, int* copy_dst,
-                                                         const int* nt_dev, const int* nn_dev)
+                                                         const int* nt_dev, const int* nn_dev, int* publish_late, int* n_unique_late,
+                                                         int nn_room)
 {
   const int p      = blockIdx.x * blockDim.x + threadIdx.x;
   const int nt_use = nt_dev != nullptr ? min(nt, *nt_dev) : nt;
   const int nn_use = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+  if (p == 0 && publish_late != nullptr) {   // what au_publish_kernel writes, here (wm_au_bounds::publish_host_late)
+    const int c     = new_rank[nn_room];     // the scan ran over the ROOM of the neighbour array: its last entry is the total
+    publish_late[0] = nn_use;
+    publish_late[1] = c;
+    if (n_unique_late != nullptr) *n_unique_late = nt_use + c;
+  }
   if (p < nt_use) out_unique[p] = targets[p];
   if (p >= nn_use) return;
   if (copy_dst != nullptr) copy_dst[p] = copy_src[p];
@@ -686,6 +693,8 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
                               stream) != hipSuccess)
     return -2;
   // new_rank[nn] = number of new unique neighbours
+  if (bounds != nullptr && bounds->publish_host_late != nullptr && new_count_dev == nullptr && publish_host == nullptr && nt + nn > 0)
+    return hipGetLastError() == hipSuccess ? 0 : -2;   // phase 2's kernel publishes (its grid is never empty then)
   hipLaunchKernelGGL(au_publish_kernel, dim3(1), dim3(1), 0, stream, l.new_rank + nn, nn_dev, nn, new_count_dev, publish_host,
                      nt_dev, nt, bounds != nullptr ? bounds->n_unique_dev : static_cast<int*>(nullptr));
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -700,10 +709,12 @@ int au_phase2(const void* targets, int nt, int nn, int nn_used, void* ws, void* 
   using UKey  = typename std::make_unsigned<KeyT>::type;
   auto l      = au_plan<UKey>(ws, nt, nn);   // the layout phase 1 used
   const int g = std::max(nt, nn_used);
+  int* late   = bounds != nullptr ? bounds->publish_host_late : nullptr;
   if (g > 0)
     hipLaunchKernelGGL((au_emit_kernel<UKey>), dim3((g + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.slots, l.min_pos,
                        l.slot_of, l.new_rank, nt, nn_used, static_cast<UKey*>(out_unique), mapping,
-                       static_cast<const UKey*>(targets), copy_src, copy_dst, nt_dev, nn_dev);
+                       static_cast<const UKey*>(targets), copy_src, copy_dst, nt_dev, nn_dev, late,
+                       late != nullptr ? bounds->n_unique_dev : static_cast<int*>(nullptr), nn);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
