@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 O=gpurun_out/r03_fuzz_campaign.txt
 : > $O
 run() { echo "== $*" >> $O; timeout 1500 "$@" 2>&1 | tail -12 >> $O; }
-FUZZ_WIDE=1 run python experiments/fuzz_rows.py 2500 301
+FUZZ_WIDE=1 run python experiments/fuzz_rows.py 2500 ${FUZZ_SEED_BASE:-301}
 run python experiments/fuzz_rows.py 1500 302
 WM_ROWS_INORDER=0 FUZZ_WIDE=1 run python experiments/fuzz_rows.py 800 303
 run python experiments/fuzz_optim.py 800 304
