@@ -511,7 +511,7 @@ def main():
                                                                  ctypes.byref(ms)))
                 vals.append(round(ms.value, 4))
             table_probe = {"read_ms_per_GiB": vals[0], "read_write_back_ms_per_GiB": vals[1],
-                           "malloc_candidates": os.environ.get("WM_MALLOC_PROBE", "auto (up to 3, stops at a well placed one)"),
+                           "malloc_candidates": os.environ.get("WM_MALLOC_PROBE", "auto (up to 6 within half of the free memory, stops at a well placed one)"),
                            "note": "random-row probe of the table's allocation; a write-side value near 0.36 is a well placed "
                                    "table, 0.41-0.43 a badly placed one (scatter / gradient apply up to 20 % slower)"}
             del shard

@@ -47,9 +47,9 @@ def test_malloc_probe_keeps_a_working_table(wm_lib):
         assert float(l.split(":")[-1].split()[0]) > 0
 
 
-@pytest.mark.parametrize("good,expected", [("1e-9", 3), ("1000", 1)])
+@pytest.mark.parametrize("good,expected", [("1e-9", 6), ("1000", 1)])
 def test_automatic_probe_stops_at_a_well_placed_candidate(wm_lib, good, expected):
-    """WM_MALLOC_PROBE unset = automatic: up to 3 candidates while half of the free memory holds them, none beyond the first
+    """WM_MALLOC_PROBE unset = automatic: up to 6 candidates while half of the free memory holds them, none beyond the first
     one that probes at or under WM_MALLOC_PROBE_GOOD."""
     env = dict(os.environ, WM_MALLOC_PROBE_MIN_BYTES=str(1 << 20), WM_MALLOC_PROBE_VERBOSE="1", WM_MALLOC_PROBE_GOOD=good)
     env.pop("WM_MALLOC_PROBE", None)

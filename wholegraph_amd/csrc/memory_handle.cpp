@@ -135,8 +135,10 @@ void alloc_local(wholememory_handle_* h)
   // at least WM_MALLOC_PROBE_MIN_BYTES (default 1 GiB) is chosen among up to K candidate allocations: each is timed with the
   // probe (kernels/probe.hip: pseudo-random 512-byte row writes, a few ms), the fastest is kept, the others are released.
   // The candidates have to be alive together (an allocation that is freed comes back at the same place).
-  //   WM_MALLOC_PROBE unset  automatic: up to 3 candidates, as many as fit in HALF of the memory that is free after the first
-  //                          one, and none at all when the first one already probes as well placed (WM_MALLOC_PROBE_GOOD,
+  //   WM_MALLOC_PROBE unset  automatic: up to 6 candidates, as many as fit in HALF of the memory that is free after the first
+  //                          one (a 51 GB table on an empty 288 GB device: 3; an 8 GB table: 6 — the first 24-40 GB a fresh
+  //                          process allocates tend to be the badly placed ones, profiles/r03_autoprobe_small_tables.txt),
+  //                          and none at all when the first one already probes as well placed (WM_MALLOC_PROBE_GOOD,
   //                          default 0.166 ms per GiB: well placed tables probe at 0.160-0.165, badly placed ones at 0.17-0.21)
   //   WM_MALLOC_PROBE=1      off: the first allocation is the shard
   //   WM_MALLOC_PROBE=K      exactly K candidates (2 ... 8), whatever the first one looks like
@@ -161,7 +163,7 @@ void alloc_local(wholememory_handle_* h)
   if (k_setting < 0) {
     size_t free_b = 0, total_b = 0;
     if (bk->mem_info == nullptr || bk->mem_info(&free_b, &total_b) != 0) return;
-    k_candidates = 1 + static_cast<int>(std::min<size_t>(2, free_b / 2 / h->local_alloc));
+    k_candidates = 1 + static_cast<int>(std::min<size_t>(5, free_b / 2 / h->local_alloc));
     if (k_candidates <= 1) return;
   }
   float best_ms = 0;
