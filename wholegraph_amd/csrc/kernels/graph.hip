@@ -263,24 +263,29 @@ __global__ __launch_bounds__(kBlock) void sample_small_kernel(sample_params p)
     for (int q = 0; q <= k; q++) v = rng.next_i32();
     my_r = v % (N - lane);
   }
-  int q_pos = -1, q_val = 0, my_a = 0;   // entry `lane` of the sparse list; lanes >= cnt hold no entry
-  int cnt = 0;                           // wave-uniform
-  for (int i = 0; i < M; i++) {
-    const int x = __builtin_amdgcn_readlane(my_r, i);
-    const int y = N - 1 - i;
-    const uint64_t mx = __ballot(lane < cnt && q_pos == x);
-    const uint64_t my = __ballot(lane < cnt && q_pos == y);
-    const int ix      = mx ? __ffsll(static_cast<long long>(mx)) - 1 : -1;
-    const int vx      = mx ? __builtin_amdgcn_readlane(q_val, ix) : x;
-    const int vy      = my ? __builtin_amdgcn_readlane(q_val, __ffsll(static_cast<long long>(my)) - 1) : y;
-    if (lane == i) my_a = vx;
-    if (ix >= 0) {
-      if (lane == ix) q_val = vy;
-    } else {
-      if (lane == cnt) q_pos = x, q_val = vy;
-      cnt++;
-    }
+  // The recurrence  for i = 0 .. M-1:  x = r[i], y = N-1-i;  a[i] = Q[x];  Q[x] = Q[y]   (Q = identity at the start)
+  // is sequential as written — one lookup of the sparse image of Q per step, ~22 dependent vector / scalar instructions each
+  // (round 3: the kernel is issue-bound, profiles/r03_sample_pmc.txt) — but its result has a closed form the lanes can
+  // evaluate side by side. Step k ASSIGNS key x_k the value v_k = Q_k[y_k] (Q_k = the state before step k), so
+  //     Q_i[p] = v_k for the LARGEST k < i with x_k == p, else p,
+  //     a[i]   = Q_i[x_i],        v_k = Q_k[y_k] = v_m for the largest m < k with x_m == y_k, else y_k.
+  // Lane i finds its two predecessors px = max{k < i : x_k == x_i} and py = max{k < i : x_k == y_i} in one pass over k (x_k
+  // broadcast by v_readlane); the v-chain k -> py(k) -> py(py(k)) ... ends in a step that moved an untouched position, whose
+  // value is that position: v_k = y_root(k), the root found by pointer jumping (6 doublings cover 64 steps). Same integers
+  // as the sequential loop, a third of the instructions.
+  const int my_x = my_r, my_y = N - 1 - lane;
+  int px = -1, py = -1;
+  for (int k = 0; k < M; k++) {
+    const int xk      = __builtin_amdgcn_readlane(my_x, k);
+    const bool before = k < lane;
+    if (before && xk == my_x) px = k;
+    if (before && xk == my_y) py = k;
   }
+  int root = py < 0 ? lane : py;
+#pragma unroll
+  for (int it = 0; it < 6; it++) root = __shfl(root, root, 64);
+  const int root_of_px = __shfl(root, px < 0 ? lane : px, 64);
+  const int my_a       = px < 0 ? my_x : N - 1 - root_of_px;
   if (lane < M) {
     if (out) out[off + lane] = gref_load<ColT>(p.col_ptr, p.col_off + s + my_a);
     if (p.out_lid) p.out_lid[off + lane] = center;
