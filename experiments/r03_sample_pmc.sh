@@ -10,8 +10,9 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_INSTS_VMEM_R
 import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    if "sample_small_kernel" in r["Kernel_Name"] or "au_insert_kernel" in r["Kernel_Name"]:
-        agg[r["Kernel_Name"].split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for name in ("sample_small_kernel", "au_insert_kernel"):
+        if name in r["Kernel_Name"]:
+            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
     for c, v in cs.items():
         v.sort()

@@ -232,64 +232,70 @@ __global__ __launch_bounds__(kBlock) void sample_sparse_kernel(sample_params p)
 // r[i], sampled position a[i] and entry i of the sparse image of Q (position, value) in registers; a lookup is one ballot
 // and one v_readlane, an update one predicated move. The LDS version pays two LDS round trips, a fence and a wave barrier
 // per step of the sequential recurrence (~70 us for the 24 k centres of a papers100M-shaped second hop).
-template <typename IdT, typename ColT>
+// G = lanes per centre: 64 (one centre per wave, max_sample <= 64) or 32 (TWO centres per wave, max_sample <= 32 — the fan-outs
+// GNN samplers use). Round 3 counters (profiles/r03_sample_pmc.txt): with one centre per wave a wave lives ~2 300 cycles and the
+// 31.7 k waves of a papers100M-shaped second hop are handed out at ~1.3 waves per ns — the kernel waits for the dispatcher,
+// the machine is 15 % occupied; two centres per wave halve the launches.
+template <typename IdT, typename ColT, int G>
 __global__ __launch_bounds__(kBlock) void sample_small_kernel(sample_params p)
 {
-  const int M      = p.max_sample;   // 1 ... 64
+  constexpr int kPerWave = 64 / G;
+  const int M      = p.max_sample;   // 1 ... G
   const int lane   = threadIdx.x & 63;
-  const int center = blockIdx.x * kWavesPerBlk + (threadIdx.x >> 6);
-  if (center >= centers_in_use(p)) return;
-  ColT* out = static_cast<ColT*>(p.out_ids);
-  int64_t s, e;
-  row_bounds<IdT>(p, center, &s, &e);
-  const int N = static_cast<int>(e - s);
-  if (N <= 0) return;
-  const int off = p.offsets[center];
-  if (N <= M) {  // every neighbour
-    for (int i = lane; i < N; i += 64) {
-      if (out) out[off + i] = gref_load<ColT>(p.col_ptr, p.col_off + s + i);
-      if (p.out_lid) p.out_lid[off + i] = center;
-      if (p.out_egid) p.out_egid[off + i] = s + i;
-    }
-    return;
-  }
+  const int gl     = lane & (G - 1);          // lane within its centre's group
+  const int gbase  = lane & ~(G - 1);         // first lane of the group
+  const int wave   = blockIdx.x * kWavesPerBlk + (threadIdx.x >> 6);
+  const int center = wave * kPerWave + lane / G;
+  // every lane of a group reads its centre's bounds itself (one address per group); a group past the end, an isolated node
+  // or a node with N <= M neighbours just sits out the parts it does not need — no early return, the groups of a wave
+  // share the shuffles below
+  const bool live = center < centers_in_use(p);
+  int64_t s = 0, e = 0;
+  if (live) row_bounds<IdT>(p, center, &s, &e);
+  const int N     = static_cast<int>(e - s);
+  const int off   = live && N > 0 ? p.offsets[center] : 0;
+  ColT* out       = static_cast<ColT*>(p.out_ids);
+  const bool all  = live && N > 0 && N <= M;      // every neighbour
+  const bool draw = live && N > M;                // M distinct positions out of N
+  if (!__any(live && N > 0)) return;
   // draw i belongs to virtual thread j = i % T (stream center * T + j), its (i / T)-th draw — as in sample_sparse_kernel
   const sample_geometry g = sample_geometry_for(M);
   int my_r = 0;
-  if (lane < M) {
-    const int j = lane % g.threads, k = lane / g.threads;
+  if (draw && gl < M) {
+    const int j = gl % g.threads, k = gl / g.threads;
     pcg32 rng(p.seed, 0, static_cast<uint64_t>(center) * g.threads + j);
     int32_t v = 0;
     for (int q = 0; q <= k; q++) v = rng.next_i32();
-    my_r = v % (N - lane);
+    my_r = v % (N - gl);
   }
   // The recurrence  for i = 0 .. M-1:  x = r[i], y = N-1-i;  a[i] = Q[x];  Q[x] = Q[y]   (Q = identity at the start)
   // is sequential as written — one lookup of the sparse image of Q per step, ~22 dependent vector / scalar instructions each
-  // (round 3: the kernel is issue-bound, profiles/r03_sample_pmc.txt) — but its result has a closed form the lanes can
-  // evaluate side by side. Step k ASSIGNS key x_k the value v_k = Q_k[y_k] (Q_k = the state before step k), so
+  // — but its result has a closed form the lanes can evaluate side by side. Step k ASSIGNS key x_k the value
+  // v_k = Q_k[y_k] (Q_k = the state before step k), so
   //     Q_i[p] = v_k for the LARGEST k < i with x_k == p, else p,
   //     a[i]   = Q_i[x_i],        v_k = Q_k[y_k] = v_m for the largest m < k with x_m == y_k, else y_k.
   // Lane i finds its two predecessors px = max{k < i : x_k == x_i} and py = max{k < i : x_k == y_i} in one pass over k (x_k
-  // broadcast by v_readlane); the v-chain k -> py(k) -> py(py(k)) ... ends in a step that moved an untouched position, whose
-  // value is that position: v_k = y_root(k), the root found by pointer jumping (6 doublings cover 64 steps). Same integers
-  // as the sequential loop, a third of the instructions.
-  const int my_x = my_r, my_y = N - 1 - lane;
+  // broadcast inside the group); the v-chain k -> py(k) -> py(py(k)) ... ends in a step that moved an untouched position,
+  // whose value is that position: v_k = y_root(k), the root found by pointer jumping (log2 G doublings cover G steps).
+  // Same integers as the sequential loop, a third of the instructions.
+  const int my_x = my_r, my_y = N - 1 - gl;
   int px = -1, py = -1;
   for (int k = 0; k < M; k++) {
-    const int xk      = __builtin_amdgcn_readlane(my_x, k);
-    const bool before = k < lane;
+    const int xk      = G == 64 ? __builtin_amdgcn_readlane(my_x, k) : __shfl(my_x, gbase + k, 64);
+    const bool before = k < gl;
     if (before && xk == my_x) px = k;
     if (before && xk == my_y) py = k;
   }
-  int root = py < 0 ? lane : py;
+  int root = py < 0 ? gl : py;                       // (group-relative step numbers)
 #pragma unroll
-  for (int it = 0; it < 6; it++) root = __shfl(root, root, 64);
-  const int root_of_px = __shfl(root, px < 0 ? lane : px, 64);
+  for (int it = 0; it < (G == 64 ? 6 : 5); it++) root = __shfl(root, gbase + root, 64);
+  const int root_of_px = __shfl(root, gbase + (px < 0 ? gl : px), 64);
   const int my_a       = px < 0 ? my_x : N - 1 - root_of_px;
-  if (lane < M) {
-    if (out) out[off + lane] = gref_load<ColT>(p.col_ptr, p.col_off + s + my_a);
-    if (p.out_lid) p.out_lid[off + lane] = center;
-    if (p.out_egid) p.out_egid[off + lane] = s + my_a;
+  const int pos        = all ? gl : my_a;            // neighbour position this lane emits
+  if ((all && gl < N) || (draw && gl < M)) {
+    if (out) out[off + gl] = gref_load<ColT>(p.col_ptr, p.col_off + s + pos);
+    if (p.out_lid) p.out_lid[off + gl] = center;
+    if (p.out_egid) p.out_egid[off + gl] = s + pos;
   }
 }
 
@@ -346,9 +352,12 @@ int launch_sample(const sample_params& p, hipStream_t stream)
   if (p.n_center == 0) return 0;
   if (p.max_sample > kMaxSparse) {
     hipLaunchKernelGGL((sample_large_kernel<IdT, ColT>), dim3(p.n_center), dim3(64), 0, stream, p);
+  } else if (p.max_sample >= 1 && p.max_sample <= 32 && getenv("WM_SAMPLE_LDS") == nullptr && getenv("WM_SAMPLE_ONE_PER_WAVE") == nullptr) {
+    const int per_block = 2 * kWavesPerBlk;   // two centres per wave
+    hipLaunchKernelGGL((sample_small_kernel<IdT, ColT, 32>), dim3((p.n_center + per_block - 1) / per_block), dim3(kBlock), 0, stream, p);
   } else if (p.max_sample >= 1 && p.max_sample <= 64 && getenv("WM_SAMPLE_LDS") == nullptr) {
     const int blocks = (p.n_center + kWavesPerBlk - 1) / kWavesPerBlk;
-    hipLaunchKernelGGL((sample_small_kernel<IdT, ColT>), dim3(blocks), dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((sample_small_kernel<IdT, ColT, 64>), dim3(blocks), dim3(kBlock), 0, stream, p);
   } else {
     const int M       = std::max(p.max_sample, 1);
     const size_t lds  = static_cast<size_t>(kWavesPerBlk) * 4 * M * sizeof(int);
