@@ -234,8 +234,8 @@ __global__ __launch_bounds__(kBlock) void sample_sparse_kernel(sample_params p)
 // per step of the sequential recurrence (~70 us for the 24 k centres of a papers100M-shaped second hop).
 // G = lanes per centre: 64 (one centre per wave, max_sample <= 64) or 32 (TWO centres per wave, max_sample <= 32 — the fan-outs
 // GNN samplers use). Round 3 counters (profiles/r03_sample_pmc.txt): with one centre per wave a wave lives ~2 300 cycles and the
-// 31.7 k waves of a papers100M-shaped second hop are handed out at ~1.3 waves per ns — the kernel waits for the dispatcher,
-// the machine is 15 % occupied; two centres per wave halve the launches.
+// 31.7 k waves of a papers100M-shaped second hop keep the machine only 15 % occupied (neither shorter load chains nor fewer
+// vector instructions changed its 24 us); two centres per wave halve the waves and the per-centre instruction stream: 19.5 us.
 template <typename IdT, typename ColT, int G>
 __global__ __launch_bounds__(kBlock) void sample_small_kernel(sample_params p)
 {
