@@ -233,9 +233,9 @@ __global__ __launch_bounds__(kBlock) void sample_sparse_kernel(sample_params p)
 // and one v_readlane, an update one predicated move. The LDS version pays two LDS round trips, a fence and a wave barrier
 // per step of the sequential recurrence (~70 us for the 24 k centres of a papers100M-shaped second hop).
 // G = lanes per centre: 64 (one centre per wave, max_sample <= 64) or 32 (TWO centres per wave, max_sample <= 32 — the fan-outs
-// GNN samplers use). Round 3 counters (profiles/r03_sample_pmc.txt): with one centre per wave a wave lives ~2 300 cycles and the
-// 31.7 k waves of a papers100M-shaped second hop keep the machine only 15 % occupied (neither shorter load chains nor fewer
-// vector instructions changed its 24 us); two centres per wave halve the waves and the per-centre instruction stream: 19.5 us.
+// GNN samplers use). With one centre per wave the 31.7 k short waves of a papers100M-shaped second hop took 24 us whatever was
+// done to their load chain or their vector instruction count (round 3, profiles/r03_sample_pmc.txt); two centres per wave
+// halve the waves and the per-centre instruction stream: 19.5 us.
 template <typename IdT, typename ColT, int G>
 __global__ __launch_bounds__(kBlock) void sample_small_kernel(sample_params p)
 {
