@@ -219,3 +219,46 @@ def test_oracle_weighted_sampler_matches_reference_host_statement(m, wdtype):
         want += [s + int(i) for i in order]
     assert np.array_equal(egid, np.array(want, dtype=np.int64))
     assert np.array_equal(ids, col[egid]) and np.array_equal(lid, np.repeat(np.arange(len(centers)), np.diff(off)))
+
+
+def test_sampling_recurrence_closed_form():
+    """The closed form sample_small_kernel evaluates (csrc/kernels/graph.hip) against the sequential recurrence of the reference
+    (unweighted_sample_without_replacement_func.cuh: a[i] = Q[r_i]; Q[r_i] = Q[N-1-i] over a sparse image of Q): lane i looks for
+    the last earlier step whose draw equals its own draw (px) or its own tail position N-1-i (py), the value chains through py
+    are resolved by pointer jumping, a[i] = N-1-root(px) or r_i. Pure Python on random and collision-heavy draws, both group
+    sizes of the kernel (32 and 64 lanes per centre)."""
+    import random
+
+    def sequential(r, n):
+        q, a = {}, []
+        for i, x in enumerate(r):
+            y = n - 1 - i
+            vx, vy = q.get(x, x), q.get(y, y)
+            a.append(vx)
+            q[x] = vy
+        return a
+
+    def closed_form(r, n, group):
+        m = len(r)
+        xs = r + [0] * (group - m)
+        px, py = [-1] * group, [-1] * group
+        for lane in range(group):
+            for k in range(min(m, lane)):
+                if xs[k] == xs[lane]:
+                    px[lane] = k
+                if xs[k] == n - 1 - lane:
+                    py[lane] = k
+        root = [lane if py[lane] < 0 else py[lane] for lane in range(group)]
+        for _ in range(6 if group == 64 else 5):
+            root = [root[root[lane]] for lane in range(group)]
+        return [xs[i] if px[i] < 0 else n - 1 - root[px[i]] for i in range(m)]
+
+    rnd = random.Random(5)
+    for case in range(30000):
+        group = 32 if case % 2 else 64
+        m = rnd.choice([1, 2, 3, 5, 7, 15, 30, 31, 32] if group == 32 else [1, 2, 30, 33, 48, 63, 64])
+        n = m + rnd.choice([1, 1, 2, 3, 5, 10, 40, 1000, 100000])
+        r = [rnd.randrange(0, n - i) for i in range(m)]
+        if case % 3 == 0:   # many collisions: draws on the tail positions and on each other
+            r = [max(0, min(n - 1 - i, rnd.choice([0, 1, n - 1 - i, n - 2 - i, r[0]]))) for i in range(m)]
+        assert closed_form(r, n, group) == sequential(r, n), (case, group, m, n, r)
