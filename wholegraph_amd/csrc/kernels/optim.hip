@@ -115,6 +115,23 @@ __device__ __forceinline__ int tile_heads(const KeyT* sorted, int64_t n, int64_t
   const int64_t first = base + static_cast<int64_t>(threadIdx.x) * kRunItems;
   KeyT prev           = first > 0 && first <= n ? sorted[first - 1] : KeyT(0);
   int heads           = 0;
+  if (first + kRunItems <= n && (reinterpret_cast<uint64_t>(sorted) & 15) == 0) {
+    // the thread's 8 keys as whole 16-byte loads (the sorted array starts on a 256-byte boundary and `first` is a multiple of
+    // 8 keys): element-wise guarded loads at a 32-byte lane stride made the two run-detection kernels 23 + 33 us per 10 M keys
+    typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+    constexpr int kVecs = static_cast<int>(sizeof(KeyT)) * kRunItems / 16;
+    raw4 raw[kVecs];
+#pragma unroll
+    for (int v = 0; v < kVecs; v++) raw[v] = reinterpret_cast<const raw4*>(sorted + first)[v];
+    __builtin_memcpy(key, raw, sizeof(KeyT) * kRunItems);
+#pragma unroll
+    for (int i = 0; i < kRunItems; i++) {
+      head[i] = (first + i == 0) || key[i] != prev;
+      prev    = key[i];
+      heads += head[i] ? 1 : 0;
+    }
+    return heads;
+  }
 #pragma unroll
   for (int i = 0; i < kRunItems; i++) {
     const int64_t g = first + i;
