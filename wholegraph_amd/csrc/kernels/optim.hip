@@ -1246,8 +1246,9 @@ struct long_lane {
 template <typename IdxT>
 void launch_mark_long_runs(const opt_params& p, hipStream_t stream, hipStream_t lstream)
 {
-  // one run per thread, no loop: the kernel is two coalesced reads of run_starts[] and sits on the caller's critical path
-  const int blocks = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, INT64_C(1) << 22));
+  // two coalesced reads of run_starts[] per run, on the caller's critical path: a grid-stride loop over at most 4096 workgroups
+  // (one run per thread and 37 k workgroups for 9.5 M runs took 15 us — the time to hand out 148 k one-load waves)
+  const int blocks = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, 4096));
   hipLaunchKernelGGL((mark_long_runs_kernel<IdxT>), dim3(std::max(blocks, 1)), dim3(256), 0, lstream, p);
   if (lstream != stream) {
     (void)hipEventRecord(long_lane::get().marked, lstream);
