@@ -31,6 +31,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A/B of compile-time variants of the library (scripts/build_variant.sh NAME "-D..."): WHOLEGRAPH_AMD_VARIANT=NAME runs this
+# file against experiments/variants/NAME/wholegraph_amd instead of the product package. Never set by the driver.
+VARIANT = os.environ.get("WHOLEGRAPH_AMD_VARIANT")
+if VARIANT:
+    sys.path.insert(0, os.path.join(ROOT, "experiments", "variants", VARIANT))
 
 import numpy as np
 import torch
@@ -610,6 +615,7 @@ def main():
                     os.environ.pop("WM_GATHER_DEDUP", None)
                 else:
                     os.environ["WM_GATHER_DEDUP"] = env_val
+                wmb.reload_knobs()   # the library reads its knobs once
                 for _ in range(3):
                     emb.gather(zidx, out=out)
                 barrier()
@@ -622,6 +628,7 @@ def main():
                 res[label + "_ms_per_step"] = round(float(dz.item()) / 20 * 1e3, 4)
         finally:
             os.environ.pop("WM_GATHER_DEDUP", None)
+            wmb.reload_knobs()
         res["dedup_auto_value_GBps"] = round(a.indices * world * a.dim * es / (res["dedup_auto_ms_per_step"] * 1e-3) / 1e9, 2)
         return res
 
@@ -681,6 +688,7 @@ def main():
             "placement": placement,   # None: plain single allocations (the default)
             "table_probe": table_probe,
             "launch_shape": "persistent (WM_ROWS_INORDER=0)" if os.environ.get("WM_ROWS_INORDER", "1") == "0" else "in-order",
+            "library_variant": VARIANT or "product",
             "config": {"workload": ("C2 chunked 1-GPU %dx%d %s table, %d %s int64 ids" if world == 1 else
                                     "C3 distributed %dx%d %s table, %d %s int64 ids per rank, RCCL alltoallv")
                                    % (total_rows, a.dim, {"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[a.dtype],

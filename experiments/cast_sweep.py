@@ -24,6 +24,7 @@ def apply(env):
     for k in KEYS:
         os.environ.pop(k, None)
     os.environ.update(env)
+    __import__("wholegraph_amd.binding").binding.reload_knobs()   # knobs are read once
 
 
 for tdt, odt, dim in [(torch.float16, torch.float32, 128), (torch.float16, torch.float32, 256), (torch.float32, torch.float16, 128),

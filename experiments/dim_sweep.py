@@ -59,6 +59,7 @@ def main():
                     for k in knobs:
                         os.environ.pop(k, None)
                     os.environ.update(val)
+                    __import__("wholegraph_amd.binding").binding.reload_knobs()   # knobs are read once
                     for _ in range(3):
                         fn()
                     torch.cuda.synchronize()
@@ -70,6 +71,7 @@ def main():
                     kernels[name] = re.search(r"(rows_\w+<[^(]*>)\(", wmb.lib().wholememory_ext_last_rows_kernel().decode()).group(1)
             for k in knobs:
                 os.environ.pop(k, None)
+            wmb.reload_knobs()
             gb = n * (8 + 2 * dim * es) / 1e9
             for name, _ in settings:
                 ts = sorted(times[name])

@@ -42,5 +42,6 @@ for r in range(3):
         for k in keys:
             os.environ.pop(k, None)
         os.environ.update(env)
+        __import__("wholegraph_amd.binding").binding.reload_knobs()   # knobs are read once
         out.append("%s %.4f" % (name, timed()))
     print("%s %s dim %d %s round %d (ms per call): " % (kind, dist, dim, str(dt).split(".")[1], r) + "   ".join(out), flush=True)

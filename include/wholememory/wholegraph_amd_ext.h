@@ -173,6 +173,11 @@ enum wholememory_error_code_t wholememory_ext_multilayer_sample(
  * WM_ASYNC_OPS=0/1 in the environment overrides the call. */
 enum wholememory_error_code_t wholememory_ext_set_async_completion(int on);
 
+/* Environment knobs (WM_* / WG_* variables) are read ONCE, the first time the code that consults one runs; no op calls
+ * getenv afterwards. A program that changes such a variable later (A/B experiments, tests) calls this to make every knob
+ * read its variable again at its next use. Not to be called while ops run on other threads. */
+enum wholememory_error_code_t wholememory_ext_reload_knobs(void);
+
 /* Placement probe: milliseconds per GiB of pseudo-random 512-byte rows of [ptr, ptr + bytes) touched by a fixed kernel
  * (kind 0 = zeros written: destroys the contents, 1 = read, 2 = read and written back), averaged over `reps` launches after a
  * warm-up; blocks until done. The level the memory system serves random row accesses at depends on where a large allocation

@@ -28,6 +28,11 @@ from wholegraph_amd import binding as wmb
 import wholegraph_amd.torch as wgth
 
 
+def _reload_knobs():
+    """the library reads each WM_* / WG_* variable once: say so after changing one mid-process"""
+    wmb.reload_knobs()
+
+
 def install_test_backend():
     tb = C.CDLL(os.path.join(ROOT, "oracle", "libwm_test_backend.so"))
     tb.wm_test_backend.restype = C.c_void_p
@@ -250,6 +255,7 @@ def scenario_sgd16(comm, rank, world, tdt, dim, lr, wd, mt="distributed"):
     wrapped in exact widenings and that one rounding."""
     n_rows, steps = 1501, 2
     os.environ["WM_GRAD_FOLD"] = "ordered"   # the bits of the receive-order sum (the 16-bit default is the tree fold, round 3)
+    _reload_knobs()
     emb = wgth.create_embedding(comm, mt, "cuda", tdt, [n_rows, dim])
     stride = emb.get_embedding_tensor().stride()[0]
     init16 = torch.from_numpy(np.random.default_rng(8).standard_normal((n_rows, dim)).astype(np.float32)).to(tdt)
@@ -292,6 +298,7 @@ def scenario_sgd16(comm, rank, world, tdt, dim, lr, wd, mt="distributed"):
             comm.barrier()
     comm.barrier()
     del os.environ["WM_GRAD_FOLD"]
+    _reload_knobs()
     wgth.destroy_wholememory_optimizer(opt)
     wgth.destroy_embedding(emb)
 
@@ -302,6 +309,7 @@ def scenario_tree_fold(comm, rank, world, mt, kind, params):
     exact and table + states must equal the ordered multi-rank oracle bit for bit."""
     n_rows, dim, steps = 2003, 64, 2
     os.environ["WM_GRAD_FOLD"] = "tree"
+    _reload_knobs()
     emb = wgth.create_embedding(comm, mt, "cuda", torch.float32, [n_rows, dim])
     stride = emb.get_embedding_tensor().stride()[0]
     init = np.random.default_rng(31).standard_normal((n_rows, dim)).astype(np.float32)
@@ -334,6 +342,7 @@ def scenario_tree_fold(comm, rank, world, mt, kind, params):
             "tree fold (%s, %s) mismatch on rank %d step %d" % (kind, mt, rank, step)
     comm.barrier()
     del os.environ["WM_GRAD_FOLD"]
+    _reload_knobs()
     wgth.destroy_wholememory_optimizer(opt)
     wgth.destroy_embedding(emb)
 
@@ -606,8 +615,10 @@ def rccl_scenarios(comm, rank, world):
     ent[0] += 997 - sum(ent)
     scenario_gather_scatter(comm, rank, world, "distributed", 997, 8, np.int64, np.int32, np.int64, ent)
     os.environ["WM_GATHER_DEDUP"] = "2"
+    _reload_knobs()
     scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)
     del os.environ["WM_GATHER_DEDUP"]
+    _reload_knobs()
     scenario_gather_skewed(comm, rank, world, np.int64)     # automatic decision (duplicate estimate through the exchange)
     scenario_gather_skewed(comm, rank, world, np.int32)
     scenario_gather_scatter(comm, rank, world, "distributed", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
@@ -704,14 +715,18 @@ def main():
     scenario_gather_skewed(comm, rank, world, np.int64)
     scenario_gather_skewed(comm, rank, world, np.int32, ent3 if world > 1 else None)
     os.environ["WM_GATHER_DEDUP"] = "0"
+    _reload_knobs()
     scenario_gather_skewed(comm, rank, world, np.int64)
     del os.environ["WM_GATHER_DEDUP"]
+    _reload_knobs()
     # (4a) the same gathers with request de-duplication before the exchange (WM_GATHER_DEDUP=1)
     os.environ["WM_GATHER_DEDUP"] = "1"
+    _reload_knobs()
     scenario_gather_scatter(comm, rank, world, "distributed", 1003, 11, np.float32, np.float32, np.int64, None)
     scenario_gather_scatter(comm, rank, world, "distributed", 2000, 32, np.float16, np.float32, np.int32, None)
     scenario_gather_scatter(comm, rank, world, "distributed", 997, 8, np.int64, np.int32, np.int64, ent)
     del os.environ["WM_GATHER_DEDUP"]
+    _reload_knobs()
     if HIP_MODE:
         # (4b) CHUNKED over two processes: peers' shards mapped with hipIpc, kernels read them directly;
         #      host-located tables: one POSIX shm segment registered with HIP on every rank
@@ -725,10 +740,12 @@ def main():
         scenario_gather_scatter(comm, rank, world, "distributed", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
         # (4b') the same CHUNKED / CONTINUOUS tables served through the explicit all-to-all-v route
         os.environ["WM_MAPPED_VIA_EXCHANGE"] = "1"
+        _reload_knobs()
         scenario_gather_scatter(comm, rank, world, "chunked", 3001, 128, np.float32, np.float32, np.int64, None)
         scenario_gather_scatter(comm, rank, world, "continuous", 997, 8, np.int64, np.int32, np.int64, ent)
         scenario_gather_scatter(comm, rank, world, "chunked", 2003, 32, np.float32, np.float32, np.int64, None, loc="cpu")
         del os.environ["WM_MAPPED_VIA_EXCHANGE"]
+        _reload_knobs()
         # (4c) neighbour sampling on a CSR spread over the ranks
         scenario_sampling(comm, rank, world, "distributed", np.int64)
         scenario_sampling(comm, rank, world, "distributed", np.int32)
@@ -742,11 +759,13 @@ def main():
     del os.environ["WG_LOAD_THREADS_PER_RANK"]
     # ... and past the page cache (O_DIRECT through aligned bounce buffers; falls back where the file system refuses it)
     os.environ["WG_LOAD_USE_DIRECTIO"] = "1"
+    _reload_knobs()
     scenario_file_io(comm, rank, world, "/var/tmp/wgamd_test_d_%s" % port)
     os.environ["WG_LOAD_THREADS_PER_RANK"] = "2"
     scenario_file_io(comm, rank, world, "/tmp/wgamd_test_dt_%s" % port)
     del os.environ["WG_LOAD_THREADS_PER_RANK"]
     del os.environ["WG_LOAD_USE_DIRECTIO"]
+    _reload_knobs()
     # (5) gradient apply, all optimizers
     for kind, params in [("sgd", {"weight_decay": 0.1}), ("adam", {"weight_decay": 0.01}),
                          ("adam", {"adam_w": 1.0, "weight_decay": 0.02}), ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]:

@@ -27,6 +27,33 @@ def wm_lib():
     return binding.lib()
 
 
+@pytest.fixture
+def knobs(wm_lib):
+    """Environment knobs of the library, changed mid-process: the library reads each WM_* variable once, so every change
+    is followed by wholememory_ext_reload_knobs(); the environment is restored (and reloaded) after the test."""
+    from wholegraph_amd import binding
+    saved = {}
+
+    class Knobs:
+        def set(self, name, value):
+            saved.setdefault(name, os.environ.get(name))
+            os.environ[name] = str(value)
+            binding.reload_knobs()
+
+        def unset(self, name):
+            saved.setdefault(name, os.environ.get(name))
+            os.environ.pop(name, None)
+            binding.reload_knobs()
+
+    yield Knobs()
+    for name, old in saved.items():
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+    binding.reload_knobs()
+
+
 @pytest.fixture(scope="session")
 def gpu_env(wm_lib):
     """Initialised library + single-rank communicator on cuda:0."""

@@ -224,7 +224,7 @@ def test_embedding_training_flow(gpu_env, mt, kind, params):
 @pytest.mark.parametrize("tdt_name", ["float16", "bfloat16"])
 @pytest.mark.parametrize("fold", ["ordered", "default"])
 @pytest.mark.parametrize("dim,lr,wd", [(256, -1.0, 0.0), (256, 0.05, 0.01), (100, -1.0, 0.0), (33, -1.0, 0.0), (64, 0.1, 0.0)])
-def test_sgd_on_16bit_tables(gpu_env, monkeypatch, mt, tdt_name, dim, lr, wd, fold):
+def test_sgd_on_16bit_tables(gpu_env, knobs, mt, tdt_name, dim, lr, wd, fold):
     """Extension (BASELINE config 4, "fp16 scatter-add"): HALF / BF16 embeddings trained with SGD; lr = -1, wd = 0 is
     scatter-add. The reference trains fp32 tables only (embedding.cpp:61-63), so the semantics are this repo's:
     duplicates summed in fp32 in receive order, e' = e - lr (g + wd e) in fp32 from fp32(e), ONE rounding to the table
@@ -237,9 +237,9 @@ def test_sgd_on_16bit_tables(gpu_env, monkeypatch, mt, tdt_name, dim, lr, wd, fo
     import torch
     import wholegraph_amd.torch as wgth
     if fold == "ordered":
-        monkeypatch.setenv("WM_GRAD_FOLD", "ordered")
+        knobs.set("WM_GRAD_FOLD", "ordered")
     else:
-        monkeypatch.delenv("WM_GRAD_FOLD", raising=False)
+        knobs.unset("WM_GRAD_FOLD")
     tdt = getattr(torch, tdt_name)
     n_rows, n_idx = 20011, 50001
     emb = wgth.create_embedding(gpu_env, mt, "cuda", tdt, [n_rows, dim])
@@ -399,6 +399,7 @@ def _dedup_apply_sgd(wmb, torch, ids, grads, table, stride, dim, lr, fold):
     arr = (C.c_float * 6)(0.0, 1e-8, 0.9, 0.999, 0.99, 0.0)
     nu = C.c_int64(-1)
     os.environ["WM_GRAD_FOLD"] = fold
+    wmb.reload_knobs()
     try:
         wmb.check(wmb.lib().wholememory_ext_dedup_apply(
             d_ids.data_ptr(), wmb.DT_INT64, len(ids), d_grads.data_ptr(), grads.shape[1], dim, d_table.data_ptr(), stride, 0,
@@ -406,6 +407,7 @@ def _dedup_apply_sgd(wmb, torch, ids, grads, table, stride, dim, lr, fold):
         torch.cuda.synchronize()
     finally:
         del os.environ["WM_GRAD_FOLD"]
+        wmb.reload_knobs()
     return d_table.cpu().numpy(), nu.value
 
 
@@ -518,13 +520,13 @@ def test_tree_fold_is_the_default_of_the_16bit_extension_and_deterministic(gpu_e
 @pytest.mark.parametrize("kind,code,params", [("adam", 2, {"weight_decay": 0.01}), ("adam", 2, {"weight_decay": 0.02, "adam_w": 1.0}),
                                               ("rmsprop", 3, {"alpha": 0.9}), ("adagrad", 4, {"weight_decay": 0.01})])
 @pytest.mark.parametrize("dim,idt", [(128, np.int64), (36, np.int32)])
-def test_tree_fold_stateful_optimizers_exact_on_integer_gradients(gpu_env, monkeypatch, kind, code, params, dim, idt):
+def test_tree_fold_stateful_optimizers_exact_on_integer_gradients(gpu_env, knobs, kind, code, params, dim, idt):
     """The tree fold in front of the stateful optimizers: with integer-valued gradients the folded sums are exact, so table
     AND optimizer states must equal the ordered oracle bit for bit over several steps (long runs of one and of several
     segments, LazyAdam's per-row beta powers advanced once per listed run)."""
     import torch
     from wholegraph_amd import binding as wmb
-    monkeypatch.setenv("WM_GRAD_FOLD", "tree")
+    knobs.set("WM_GRAD_FOLD", "tree")
     rng = np.random.default_rng(dim + code)
     local_rows, local_off, n_recv = 3001, 777, 60_000
     stride = int(oracle.align_embedding_dim(dim, 4))

@@ -162,13 +162,13 @@ def test_scatter_then_gather_roundtrip(gpu_env, mt, loc, tdt, idt, pdt):
 @pytest.mark.parametrize("dim,stride,np_dt", [(100, 100, "f32"), (256, 256, "f32"), (300, 300, "f32"), (602, 604, "f32"),
                                               (602, 602, "f32"), (513, 513, "f32"), (602, 602, "f16"), (33, 33, "f32"),
                                               (128, 128, "f32")])
-def test_scatter_row_shapes(gpu_env, monkeypatch, mt, dim, stride, np_dt, flat):
+def test_scatter_row_shapes(gpu_env, knobs, mt, dim, stride, np_dt, flat):
     """scatter (and the gather back) over the row shapes above, with the kernel choice forced both ways
     (WM_ROWS_FLAT=1: flat-stream kernel wherever it is legal, 0: never) — all three must agree with the oracle."""
     torch = _torch()
     import wholegraph_amd.torch as wgth
     if flat != "default":
-        monkeypatch.setenv("WM_ROWS_FLAT", flat)
+        knobs.set("WM_ROWS_FLAT", flat)
     n_rows, n_idx = 7001, 6000
     root = wgth.create_wholememory_tensor(gpu_env, mt, "cuda", [n_rows, stride], _tt(NP[np_dt]), [stride, 1])
     view = root.get_sub_tensor([0, 0], [n_rows, dim]) if dim != stride else root

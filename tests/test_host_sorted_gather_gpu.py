@@ -20,9 +20,9 @@ def _torch():
     (7, "int64", "int64", True),
 ])
 @pytest.mark.parametrize("idt", ["int32", "int64"])
-def test_host_gather_takes_the_sorted_route_and_matches(gpu_env, wm_lib, monkeypatch, mt, dim, tdt, odt, taken, idt):
+def test_host_gather_takes_the_sorted_route_and_matches(gpu_env, wm_lib, knobs, mt, dim, tdt, odt, taken, idt):
     torch = _torch()
-    monkeypatch.setenv("WM_HOST_SORTED_MIN", "16384")   # (the default, 2^19 ids, is where the route starts to pay)
+    knobs.set("WM_HOST_SORTED_MIN", "16384")   # (the default, 2^19 ids, is where the route starts to pay)
     import ctypes as C
     import wholegraph_amd.torch as wgth
     from wholegraph_amd import binding as wmb
@@ -56,9 +56,9 @@ def test_host_gather_takes_the_sorted_route_and_matches(gpu_env, wm_lib, monkeyp
 
 
 @pytest.mark.gpu
-def test_default_rule_small_batches_and_device_tables_keep_the_plain_route(gpu_env, wm_lib, monkeypatch):
+def test_default_rule_small_batches_and_device_tables_keep_the_plain_route(gpu_env, wm_lib, knobs):
     torch = _torch()
-    monkeypatch.delenv("WM_HOST_SORTED_MIN", raising=False)
+    knobs.unset("WM_HOST_SORTED_MIN")
     import wholegraph_amd.torch as wgth
     rows, dim = 50_000, 64      # (float32 holds every row number exactly)
     for loc, n, taken in (("cpu", 100_000, 0), ("cuda", 600_000, 0), ("cpu", 600_000, 1)):

@@ -257,6 +257,7 @@ PROTOTYPES = {
     "wholememory_ext_sample_append_unique": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_ulonglong, C.c_void_p,
                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "wholememory_ext_set_async_completion": (_i, [_i]),
+    "wholememory_ext_reload_knobs": (_i, []),
     "wholememory_ext_probe_memory": (_i, [_vp, C.c_size_t, _i, _i, _P(_f)]),
     "wholememory_ext_host_sorted_gathers": (_i64, []),
     "wholememory_ext_multilayer_sample": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -288,6 +289,11 @@ def lib():
 
 
 # ---- small helpers ----------------------------------------------------------------------------
+def reload_knobs():
+    """The library reads its WM_* / WG_* environment knobs once; call this after changing one mid-process."""
+    check(lib().wholememory_ext_reload_knobs())
+
+
 def make_tensor_desc(sizes, dtype, strides=None, storage_offset=0):
     d = TensorDescription()
     lib().wholememory_initialize_tensor_desc(C.byref(d))

@@ -312,6 +312,20 @@ struct wm_device_backend {
 }  // extern "C"
 
 namespace wm {
+// Host copies of a chunked handle's per-rank tables, keyed by the DEVICE pointer array its gref carries (gref.pointer).
+// memory_handle.cpp registers them when it uploads the device arrays; the row kernels of a table of up to
+// kOwnersByValue ranks then get bases and bounds as kernel arguments instead of loading them per row. A gref somebody
+// built by hand is simply not found and takes the device arrays.
+constexpr int kOwnersByValue = 8;
+struct gref_host_tables {
+  int world_size;
+  void* rank_ptrs[kOwnersByValue];
+  size_t rank_offsets[kOwnersByValue + 1];   // bytes
+};
+void register_gref_tables(const void* dev_rank_ptrs, int world_size, void* const* rank_ptrs, const size_t* rank_offsets);
+void unregister_gref_tables(const void* dev_rank_ptrs);
+bool lookup_gref_tables(const void* dev_rank_ptrs, gref_host_tables* out);
+
 const wm_device_backend* backend();      // the installed backend (HIP unless a test replaced it)
 const wm_device_backend* hip_backend();  // kernels/backend_hip.hip
 }  // namespace wm

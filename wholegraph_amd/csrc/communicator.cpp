@@ -8,6 +8,7 @@
 // Host-side helpers (barrier, small allgathers) run on a private stream through a staging buffer,
 // like the reference's host_* family (nccl_comms.cpp:48-53,99-120), but there is exactly one
 // host round trip per call.
+#include "knobs.hpp"
 #include "communicator.hpp"
 
 #include <hip/hip_runtime_api.h>
@@ -71,7 +72,7 @@ class rccl_provider : public collective_provider {
     // WM_RCCL_SELF_SENDRECV=1 (bring-up / tests): the self segment of an all-to-all-v also travels as an
     // ncclSend/ncclRecv pair inside the group instead of a device-to-device copy, so the grouped point-to-point
     // path runs on a box with a single GPU
-    const char* e  = getenv("WM_RCCL_SELF_SENDRECV");
+    const char* e  = WM_KNOB("WM_RCCL_SELF_SENDRECV");
     self_sendrecv_ = e != nullptr && e[0] == '1';
   }
   ~rccl_provider() override
@@ -252,7 +253,7 @@ class ext_provider : public collective_provider {
 
 bool loopback_requested()
 {
-  const char* e = getenv("WM_EXCHANGE_SELF");
+  const char* e = WM_KNOB("WM_EXCHANGE_SELF");
   return e != nullptr && e[0] == '1';
 }
 
@@ -290,7 +291,7 @@ void wholememory_comm_::detect_nodes()
   local_size    = world_size;
   regular_nodes = true;
   if (world_size == 1) return;
-  const char* forced = getenv("WM_LOCAL_SIZE");
+  const char* forced = WM_KNOB("WM_LOCAL_SIZE");
   if (forced != nullptr && atoi(forced) > 0) {
     const int n = atoi(forced);
     if (world_size % n != 0) throw wm::logic_error("WM_LOCAL_SIZE must divide the communicator size");
@@ -445,7 +446,7 @@ wholememory_error_code_t wholememory_create_communicator(wholememory_comm_t* com
   c->loopback   = wm::loopback_requested();
   // WM_FORCE_RCCL=1 builds the RCCL transport even for a single rank (bring-up / smoke testing of the RCCL
   // plumbing on a one-GPU box); normally a single-rank communicator needs no transport at all.
-  const char* force = getenv("WM_FORCE_RCCL");
+  const char* force = WM_KNOB("WM_FORCE_RCCL");
   if (size > 1 || (force != nullptr && force[0] == '1')) {
     ncclUniqueId id;
     memcpy(&id, unique_id.internal, sizeof(id));

@@ -18,6 +18,7 @@
 
 #include <wholememory/embedding.h>
 
+#include "knobs.hpp"
 #include "embedding_cache.hpp"
 #include "ops_internal.hpp"
 
@@ -135,7 +136,7 @@ wholememory_error_code_t create_states(wholememory_embedding_* e)
     }
     // zero the local shard of the packed states (reference zero_local_state_tensor)
     auto* ld = wholememory_tensor_get_tensor_description(e->state_local);
-    if (getenv("WM_STATE_ZERO_MEMSET") != nullptr)
+    if (WM_KNOB("WM_STATE_ZERO_MEMSET") != nullptr)
       WM_BK(bk->memset_async(wholememory_tensor_get_data_pointer(e->state_local), 0,
                              static_cast<size_t>(ld->sizes[0]) * ld->strides[0] * sizeof(float), nullptr));
     else
@@ -298,7 +299,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
 
   // this rank's own rows are not copied at all: the step kernels read them where the caller left them (the receive
   // positions of the self segment are remapped to caller rows after the sort). WM_GRAD_SELF_COPY=1 restores the copy.
-  const char* self_copy_env = getenv("WM_GRAD_SELF_COPY");
+  const char* self_copy_env = WM_KNOB("WM_GRAD_SELF_COPY");
   const bool self_local     = !e->comm->loopback;  // loopback: the self segment is exchanged like a peer's
   const bool self_in_place  = self_local && bk->remap_self_order != nullptr &&
                              !(self_copy_env != nullptr && self_copy_env[0] == '1');
@@ -482,8 +483,8 @@ wholememory_error_code_t remap_round_robin(wholememory_embedding_* e, wholememor
   // holds the same number of rows (create_embedding pads to that), owner = (id / rr) % world. One rank: identical.
   // WM_RR_REFERENCE=1 restores the reference's caller-relative statement (rank_rows = 0 below) for call sites that were
   // written against it: ids are then only right for entries the CALLER owns ("round-robin remap").
-  static const bool reference_statement = [] {
-    const char* v = getenv("WM_RR_REFERENCE");
+  const bool reference_statement = [] {
+    const char* v = WM_KNOB("WM_RR_REFERENCE");
     return v != nullptr && v[0] == '1';
   }();
   const int64_t rank_rows =

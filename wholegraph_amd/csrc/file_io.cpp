@@ -19,6 +19,7 @@
 
 #include <wholememory/wholememory.h>
 
+#include "knobs.hpp"
 #include "backend.hpp"
 #include "communicator.hpp"
 #include "wm_common.hpp"
@@ -100,14 +101,14 @@ wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
   // whatever the files do not cover is preserved. The reads of a chunk are split over WG_LOAD_THREADS_PER_RANK threads
   // (reference file_io.cpp:1954; default 8, capped by the chunk's rows) using pread on shared descriptors.
   const size_t chunk_bytes_target = [] {
-    const char* e = getenv("WG_LOAD_BUFFER_SIZE_MB");  // reference file_io.cpp:1975
+    const char* e = WM_KNOB("WG_LOAD_BUFFER_SIZE_MB");  // reference file_io.cpp:1975
     const long mb = e != nullptr ? atol(e) : 32;
     return static_cast<size_t>(std::max<long>(mb, 1)) << 20;
   }();
   const size_t kChunkRows = std::max<size_t>(1, chunk_bytes_target / memory_entry_size);
   int n_threads             = 8;
   size_t min_rows_per_thread = 1024;  // below that a thread is not worth starting — unless the caller asked for threads
-  if (const char* e = getenv("WG_LOAD_THREADS_PER_RANK")) {
+  if (const char* e = WM_KNOB("WG_LOAD_THREADS_PER_RANK")) {
     n_threads           = std::max(1, atoi(e));
     min_rows_per_thread = 1;
   }
@@ -133,7 +134,7 @@ wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
   // window is read and the wanted bytes are copied out. A file system that refuses O_DIRECT (tmpfs) falls back to
   // buffered reads with a warning.
   bool direct_io = false;
-  if (const char* e = getenv("WG_LOAD_USE_DIRECTIO")) direct_io = e[0] == '1' && e[1] == 0;
+  if (const char* e = WM_KNOB("WG_LOAD_USE_DIRECTIO")) direct_io = e[0] == '1' && e[1] == 0;
   for (int f = 0; f < file_count; f++) {
     fds[f] = open(file_names[f], direct_io ? (O_RDONLY | O_DIRECT) : O_RDONLY);
     if (fds[f] < 0 && direct_io) {

@@ -14,6 +14,7 @@
 #include <wholememory/wholegraph_op.h>
 #include <wholememory/wholememory_op.h>
 
+#include "knobs.hpp"
 #include "ops_internal.hpp"
 #include "pcg.hpp"
 
@@ -458,7 +459,7 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
 
   // (sample_offsets — the counts computed inside the scan's input iterator — exists and is bit-identical, but the look-back
   // scan with random row_ptr loads per element is slower than count kernel + plain scan: 8-19 us against 4 + 6; WM_SAMPLE_FUSED_SCAN=1)
-  if (bk->sample_offsets != nullptr && getenv("WM_SAMPLE_FUSED_SCAN") != nullptr) {
+  if (bk->sample_offsets != nullptr && WM_KNOB("WM_SAMPLE_FUSED_SCAN") != nullptr) {
     WM_BK(bk->sample_offsets(&a.row_gref, a.row_storage_offset, a.centers, a.center_dtype, a.n_center, max_sample_count, offsets,
                              scan_ws_ptr, scan_ws, stream));
   } else {

@@ -13,6 +13,7 @@
 #include <wholememory/wholegraph_amd_ext.h>
 #include <wholememory/wholememory.h>
 
+#include "knobs.hpp"
 #include "backend.hpp"
 #include "wm_common.hpp"
 
@@ -111,7 +112,7 @@ const char* wholememory_ext_backend_name() { return wm::backend()->name; }
 
 wholememory_error_code_t wm_testing_install_backend(const void* backend)
 {
-  const char* e = getenv("WHOLEGRAPH_AMD_TESTING");
+  const char* e = WM_KNOB("WHOLEGRAPH_AMD_TESTING");
   if (e == nullptr || strcmp(e, "1") != 0) {
     WM_ERROR("wm_testing_install_backend refused: WHOLEGRAPH_AMD_TESTING=1 is not set (test-only seam)");
     return WHOLEMEMORY_NOT_SUPPORTED;

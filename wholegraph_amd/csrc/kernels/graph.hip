@@ -23,6 +23,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include "../knobs.hpp"
 #include "../backend.hpp"
 #include "../pcg.hpp"
 
@@ -352,10 +353,10 @@ int launch_sample(const sample_params& p, hipStream_t stream)
   if (p.n_center == 0) return 0;
   if (p.max_sample > kMaxSparse) {
     hipLaunchKernelGGL((sample_large_kernel<IdT, ColT>), dim3(p.n_center), dim3(64), 0, stream, p);
-  } else if (p.max_sample >= 1 && p.max_sample <= 32 && getenv("WM_SAMPLE_LDS") == nullptr && getenv("WM_SAMPLE_ONE_PER_WAVE") == nullptr) {
+  } else if (p.max_sample >= 1 && p.max_sample <= 32 && WM_KNOB("WM_SAMPLE_LDS") == nullptr && WM_KNOB("WM_SAMPLE_ONE_PER_WAVE") == nullptr) {
     const int per_block = 2 * kWavesPerBlk;   // two centres per wave
     hipLaunchKernelGGL((sample_small_kernel<IdT, ColT, 32>), dim3((p.n_center + per_block - 1) / per_block), dim3(kBlock), 0, stream, p);
-  } else if (p.max_sample >= 1 && p.max_sample <= 64 && getenv("WM_SAMPLE_LDS") == nullptr) {
+  } else if (p.max_sample >= 1 && p.max_sample <= 64 && WM_KNOB("WM_SAMPLE_LDS") == nullptr) {
     const int blocks = (p.n_center + kWavesPerBlk - 1) / kWavesPerBlk;
     hipLaunchKernelGGL((sample_small_kernel<IdT, ColT, 64>), dim3(blocks), dim3(kBlock), 0, stream, p);
   } else {
@@ -875,8 +876,8 @@ int aus_phase2(const void* targets, int nt, int nn, void* ws, void* out_unique, 
 // vs 11.0 ms — so it serves up to 128 M keys (a 2 GiB table). WM_AU_TABLE_MAX overrides the limit for both widths.
 inline bool au_use_table(int nt, int nn, wholememory_dtype_t dt)
 {
-  static const int64_t forced = [] {
-    const char* e = getenv("WM_AU_TABLE_MAX");
+  const int64_t forced = [] {
+    const char* e = WM_KNOB("WM_AU_TABLE_MAX");
     return e != nullptr ? static_cast<int64_t>(atoll(e)) : INT64_C(-1);
   }();
   const int64_t limit = forced >= 0 ? forced : (dt == WHOLEMEMORY_DT_INT ? INT64_C(128) << 20 : INT64_C(24) << 20);

@@ -85,6 +85,7 @@ inline bool can_iterators_alias(counting_iterator<I, D>, Out*, const size_t)
 END_ROCPRIM_NAMESPACE
 #include <rocprim/rocprim.hpp>
 
+#include "../knobs.hpp"
 #include "../backend.hpp"
 #include "device_common.cuh"
 
@@ -1501,14 +1502,14 @@ __global__ __launch_bounds__(kBlock) void tree_combine_kernel(opt_params p, tree
 
 inline int tree_threshold()
 {
-  const char* e = getenv("WM_GRAD_FOLD_MIN");
+  const char* e = WM_KNOB("WM_GRAD_FOLD_MIN");
   const int v   = e != nullptr ? atoi(e) : 0;
   return v >= 4 && v <= kLongRun ? v : kTreeMin;
 }
 // ordered (0) or tree (1): WM_GRAD_FOLD overrides, then the caller's fold_mode, then the default of the value dtype
 inline int resolve_fold_mode(const wm_optimizer_args& a)
 {
-  const char* e = getenv("WM_GRAD_FOLD");
+  const char* e = WM_KNOB("WM_GRAD_FOLD");
   if (e != nullptr && (e[0] == 't' || e[0] == 'T')) return 1;
   if (e != nullptr && (e[0] == 'o' || e[0] == 'O')) return 0;
   if (a.fold_mode >= 0) return a.fold_mode;
@@ -1526,7 +1527,7 @@ void launch_tree(const opt_params& p, hipStream_t stream, hipStream_t lstream)
     (void)hipStreamWaitEvent(stream, long_lane::get().marked, 0);
   }
   int fgrid = 2048;
-  if (const char* e = getenv("WM_TREE_GRID")) fgrid = std::max(1, atoi(e));
+  if (const char* e = WM_KNOB("WM_TREE_GRID")) fgrid = std::max(1, atoi(e));
   hipLaunchKernelGGL((tree_fold_kernel<IdxT, OPT, T>), dim3(fgrid), dim3(kBlock), 0, lstream, p, w);
   hipLaunchKernelGGL((tree_combine_kernel<IdxT, OPT, T>), dim3(256), dim3(kBlock), 0, lstream, p, w);
 }
@@ -1543,16 +1544,16 @@ inline void tile_launch_shape(int64_t count_bound, int vecs, int ku, int* tile_r
 {
   const int rps      = vecs > 32 ? 1 : vecs > 16 ? 2 : vecs > 8 ? 4 : 8;
   const int batch    = rps * ku;
-  const char* io_env = getenv("WM_TILE_INORDER");
+  const char* io_env = WM_KNOB("WM_TILE_INORDER");
   const bool inorder = io_env != nullptr && io_env[0] == '1';
   *tile_runs         = inorder ? std::min(64, batch) : 64;
-  if (const char* e = getenv("WM_TILE_RUNS")) {
+  if (const char* e = WM_KNOB("WM_TILE_RUNS")) {
     const int v = atoi(e);
     if (v >= batch && v <= 64 && v % batch == 0) *tile_runs = v;
   }
   const int64_t tiles = (count_bound + *tile_runs - 1) / *tile_runs;
   int b = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, inorder ? INT64_C(0x7fffffff) : INT64_C(256 * 32)));
-  if (const char* e = getenv("WM_STEP_BLOCKS")) b = std::min(b, std::max(1, atoi(e)));
+  if (const char* e = WM_KNOB("WM_STEP_BLOCKS")) b = std::min(b, std::max(1, atoi(e)));
   *tblocks = std::max(b, 1);
 }
 
@@ -1572,7 +1573,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
     const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4;
     const bool rows4 = p.a.dim % 4 == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4 &&
                        p.a.dim <= 65535 * slice4_cols<float>();
-    static const bool old_long = getenv("WM_STEP_LONG_OLD") != nullptr;
+    const bool old_long = WM_KNOB("WM_STEP_LONG_OLD") != nullptr;
     if (rows4 && !old_long) {
       static const bool lds_ok =
         hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, OPT>),
@@ -1582,7 +1583,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
       // run list — with more workgroups than CUs the hottest run may only START after several rounds of others
       const int slices4 = static_cast<int>((p.a.dim + slice4_cols<float>() - 1) / slice4_cols<float>());
       int gx            = std::max(1, 256 / slices4);
-      if (const char* e = getenv("WM_LONG_GRID")) gx = std::max(1, atoi(e));
+      if (const char* e = WM_KNOB("WM_LONG_GRID")) gx = std::max(1, atoi(e));
       hipLaunchKernelGGL((step_long4_kernel<IdxT, OPT>), dim3(gx, slices4), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
     }
     else if (long4)
@@ -1594,7 +1595,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
   // stateful optimizers through register pressure — 8 bytes per lane stay)
   const bool cached = p.a.cache_slot_of != nullptr;
   // rows of whole 16-byte pieces on every side: the tile kernel (WM_STEP_TILE=0 keeps the wave-per-run kernel)
-  static const bool tile_off = getenv("WM_STEP_TILE") != nullptr && getenv("WM_STEP_TILE")[0] == '0';
+  const bool tile_off = WM_KNOB("WM_STEP_TILE") != nullptr && WM_KNOB("WM_STEP_TILE")[0] == '0';
   const bool st_ok = p.a.per_element_state == nullptr ||
                      (p.a.per_element_stride % 4 == 0 && reinterpret_cast<uint64_t>(p.a.per_element_state) % 16 == 0 &&
                       (p.a.cache_state_data == nullptr || (p.a.cache_state_row_elems % 4 == 0 &&
@@ -1613,7 +1614,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
     // 2.99 ms per 10 M rows (experiments/occ_ab.py, interleaved in one process). The other row widths lose with it (dim 32:
     // +7 %, 64: +2 %, 256: +0.5-1 %; 6 waves lose everywhere) and keep their natural budget. WM_TILE_OCC=5 switches it off.
     if constexpr (OPT == WHOLEMEMORY_OPT_SGD) {
-      const char* occ_env = getenv("WM_TILE_OCC");
+      const char* occ_env = WM_KNOB("WM_TILE_OCC");
       const bool natural  = occ_env != nullptr && atoi(occ_env) == 5;
       if (!cached && !natural && vecs > 16 && vecs <= 32) {
         hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, 2, false, float, 0, 7>), dim3(tblocks), dim3(kBlock), 0, stream, tp);
@@ -1672,7 +1673,7 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream, hipStream_t 
   }
   const bool cached = p.a.cache_slot_of != nullptr;
   // rows of whole 16-byte pieces (8 elements) on every side: the tile kernel, as for fp32 tables
-  static const bool tile_off = getenv("WM_STEP_TILE") != nullptr && getenv("WM_STEP_TILE")[0] == '0';
+  const bool tile_off = WM_KNOB("WM_STEP_TILE") != nullptr && WM_KNOB("WM_STEP_TILE")[0] == '0';
   const bool tile_ok = !tile_off && rows16 && p.a.dim >= 64 && p.a.table_stride % 8 == 0 &&
                        reinterpret_cast<uint64_t>(p.a.local_table) % 16 == 0 &&
                        (!cached || (p.a.cache_row_elems % 8 == 0 && reinterpret_cast<uint64_t>(p.a.cache_data) % 16 == 0));
@@ -1873,14 +1874,14 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   }
   // the long-run side goes to its own stream (WM_STEP_SERIAL=1: everything on the caller's stream, for measurements)
   hipStream_t lstream = stream;
-  static const bool serial = getenv("WM_STEP_SERIAL") != nullptr;
+  const bool serial = WM_KNOB("WM_STEP_SERIAL") != nullptr;
   std::unique_lock<std::mutex> lane_lock;
   if (p.long_list != nullptr && !serial) lane_lock = std::unique_lock<std::mutex>(long_lane::get().mu);
   if (p.long_list != nullptr && hipMemsetAsync(p.long_count, 0, p.fold_tree ? 64 : 16, stream) != hipSuccess) return -2;
   if (p.long_list != nullptr && !serial && long_lane::get().fork(stream)) lstream = long_lane::get().stream;
   int64_t waves = a->count;
   int max_blocks = 256 * 8;
-  if (const char* e = getenv("WM_STEP_BLOCKS")) max_blocks = std::max(1, atoi(e));
+  if (const char* e = WM_KNOB("WM_STEP_BLOCKS")) max_blocks = std::max(1, atoi(e));
   int blocks = static_cast<int>(std::min<int64_t>((waves + 3) / 4, max_blocks));
   if (blocks < 1) blocks = 1;
   int rc = -1;

@@ -36,12 +36,19 @@
 #include <cstdlib>
 #include <string>
 
+#include "../knobs.hpp"
 #include "../backend.hpp"
 #include "device_common.cuh"
 
 namespace wm {
 namespace {
 
+#ifndef WM_BATCH_RPS2_BPERMUTE
+#define WM_BATCH_RPS2_BPERMUTE 1
+#endif
+#ifndef WM_BATCH_MAX_WAVES
+#define WM_BATCH_MAX_WAVES 6
+#endif
 constexpr int kBlock  = 256;   // threads per workgroup of the persistent (capped-grid) launches; upper bound for all
 constexpr int kWave   = 64;
 
@@ -78,6 +85,14 @@ struct rows_params {
   size_t chunk_stride;             // 0 = continuous; else bytes per rank
   int world_size;
   int same_chunk;
+  // same_chunk: rank = off / chunk_stride as a multiply-high and a shift (fixed per table: found once on the host)
+  uint64_t chunk_magic;            // ceil(2^(63 + l) / chunk_stride), l = ceil(log2(chunk_stride)); 0: chunk_stride == 1
+  int chunk_shift;                 // l - 1
+  // chunked tables of up to kOwnersByValue ranks whose handle registered host copies of its tables (memory_handle.cpp):
+  // the owner of a row is found by comparing against kernel arguments — no dependent load of a pointer, no division
+  int owners_by_value;
+  uint64_t owner_bound[8];         // byte offset where rank r's memory starts (r >= world_size: ~0)
+  uint64_t owner_delta[8];         // rank r's base address - owner_bound[r]: address = delta[owner] + off
   int64_t table_stride_bytes;
   int64_t table_offset_bytes;
   // index side
@@ -104,19 +119,35 @@ struct rows_params {
   int launch_threads;
   // host side only: 32 / 64 / 128 / 256 = this launch takes rows_batch_kernel<..., that many 16-byte pieces per row>
   int batch_vecs;
-  // 1 = rows_pieces_kernel: flat_slots counts the WHOLE 16-byte pieces only and flat_tail (0 / 4 / 8 / 12) the bytes after them
-  int pieces;
 };
+
+// owner of byte offset `off` of a chunked table from the kernel arguments: bounds ascend, the last rank whose start is <= off
+// owns it (ranks that do not exist: ~0). The table entries are pinned in SGPRs — left alone, hipcc turns the chain of
+// selects into a select of kernarg ADDRESSES and one dependent global load.
+__device__ __forceinline__ char* resolve_by_value(const rows_params& p, size_t off)
+{
+  uint64_t delta = p.owner_delta[0];
+  asm volatile("" : "+s"(delta));
+#pragma unroll
+  for (int r = 1; r < 8; r++) {
+    uint64_t d = p.owner_delta[r], b = p.owner_bound[r];
+    asm volatile("" : "+s"(d), "+s"(b));
+    delta = off >= b ? d : delta;
+  }
+  return reinterpret_cast<char*>(delta + off);
+}
 
 // byte address of the first moved element of table row `idx`
 __device__ __forceinline__ char* resolve_row(const rows_params& p, int64_t idx)
 {
   size_t off = static_cast<size_t>(p.table_offset_bytes) + static_cast<size_t>(idx) * static_cast<size_t>(p.table_stride_bytes);
   if (p.chunk_stride == 0) return p.base + off;
+  if (p.owners_by_value) return resolve_by_value(p, off);
   int rank;
   size_t rank_start;
   if (p.same_chunk) {
-    rank       = static_cast<int>(off / p.chunk_stride);
+    // off / chunk_stride for off < 2^63 (the reference divides, device_reference.cuh:47)
+    rank       = static_cast<int>(p.chunk_magic == 0 ? off : (__umul64hi(off, p.chunk_magic) >> p.chunk_shift));
     rank_start = static_cast<size_t>(rank) * p.chunk_stride;
   } else {
     rank = 0;
@@ -128,7 +159,8 @@ __device__ __forceinline__ char* resolve_row(const rows_params& p, int64_t idx)
   return p.rank_ptrs[rank] + (off - rank_start);
 }
 
-template <typename IdxT>
+// OWNERS: -1 = whatever the gref says (run-time branches), 0 = continuous, 1 = chunked with the owner tables by value
+template <typename IdxT, int OWNERS = -1>
 __device__ __forceinline__ void load_tile_entry(const rows_params& p, int64_t entry, char*& tab, char*& pl)
 {
   tab = nullptr;
@@ -140,7 +172,12 @@ __device__ __forceinline__ void load_tile_entry(const rows_params& p, int64_t en
     int64_t idx = WM_IDX_NT ? static_cast<int64_t>(__builtin_nontemporal_load(static_cast<const IdxT*>(p.indices) + entry))
                             : static_cast<int64_t>(static_cast<const IdxT*>(p.indices)[entry]);
     if (idx >= 0) {
-      tab         = resolve_row(p, idx);
+      if constexpr (OWNERS < 0) {
+        tab = resolve_row(p, idx);
+      } else {
+        const size_t off = static_cast<size_t>(p.table_offset_bytes) + static_cast<size_t>(idx) * static_cast<size_t>(p.table_stride_bytes);
+        tab              = OWNERS == 0 ? p.base + off : resolve_by_value(p, off);
+      }
       int64_t row = p.row_map ? p.row_map[entry] : entry;  // row map is always int64 (raw_indices)
       pl          = p.plain + row * p.plain_stride_bytes;
     }
@@ -177,30 +214,48 @@ __global__ __launch_bounds__(kBlock) void rows_copy_kernel(rows_params p)
   for (int64_t tile = wave; tile < tiles; tile += n_waves) {
     char *my_tab, *my_plain;
     load_tile_entry<IdxT>(p, lane < tile_rows ? tile * tile_rows + lane : p.n, my_tab, my_plain);
+    // every entry of the tile moves (all tiles but the last one of a batch without negative ids): the batch is straight-line
+    // code — loads issued back to back, then the stores, nothing predicated. Lanes without work of their own (columns past
+    // the end of the row, steps past the end of the tile) repeat the row's last vector / the tile's last row: they load and
+    // store the same bytes as the lane that owns them. (A predicated store is enough for hipcc to sink "its" load into the
+    // predicate, behind a wait for the loads before it.)
+    const bool whole = __ballot(lane < tile_rows && my_tab == nullptr) == 0;
     for (int cbase = 0; cbase < p.row_vecs; cbase += lpr) {  // >1 trip only when a row needs > 64 vectors
       const int c        = cbase + col;
       const bool col_ok  = c < p.row_vecs;
-      const int64_t coff = static_cast<int64_t>(c) * VB;
+      const int64_t coff = static_cast<int64_t>(min(c, p.row_vecs - 1)) * VB;
       for (int s0 = 0; s0 < tile_rows; s0 += rps * kU) {
         vec_t data[kU];
         char* dst[kU];
+        if (whole) {
 #pragma unroll
-        for (int u = 0; u < kU; u++) {
-          const int e   = s0 + u * rps + sub;
-          char* t       = shfl_ptr(my_tab, e & (kWave - 1));
-          char* q       = shfl_ptr(my_plain, e & (kWave - 1));
-          const bool ok = col_ok && e < kWave && t != nullptr;
-          char* src     = GATHER ? t : q;
-          dst[u]        = ok ? (GATHER ? q : t) + coff : nullptr;
-          if (ok) data[u] = ld_global<vec_t>(src + coff);
-        }
+          for (int u = 0; u < kU; u++) {
+            const int el = min(s0 + u * rps + sub, tile_rows - 1);
+            char* t      = shfl_ptr(my_tab, el);
+            char* q      = shfl_ptr(my_plain, el);
+            dst[u]       = (GATHER ? q : t) + coff;
+            data[u]      = ld_global<vec_t>((GATHER ? t : q) + coff);
+          }
 #pragma unroll
-        for (int u = 0; u < kU; u++) {
-          if (dst[u] != nullptr) {
+          for (int u = 0; u < kU; u++) {
             if constexpr (GATHER)
               st_global_nt<vec_t>(dst[u], data[u]);
             else
               st_global<vec_t>(dst[u], data[u]);
+          }
+          continue;
+        }
+#pragma unroll 1
+        for (int u = 0; u < kU; u++) {   // a tile with a skipped entry: one step at a time
+          const int e = s0 + u * rps + sub;
+          char* t     = shfl_ptr(my_tab, e & (kWave - 1));
+          char* q     = shfl_ptr(my_plain, e & (kWave - 1));
+          if (col_ok && e < kWave && t != nullptr) {
+            const vec_t d = ld_global<vec_t>((GATHER ? t : q) + coff);
+            if constexpr (GATHER)
+              st_global_nt<vec_t>(q + coff, d);
+            else
+              st_global<vec_t>(t + coff, d);
           }
         }
       }
@@ -253,13 +308,48 @@ __global__ __launch_bounds__(kBlock) void rows_copy16_fast_kernel(rows_params p)
     // the second half of a row then finds its DRAM page still open (scatter of 2 KiB rows 65.8 -> 69.8 % of HBM peak, 4 KiB rows 63.7 -> 70.5 %; gather unchanged).
     const int chunks = RPS == 1 ? (p.row_vecs + kLpr - 1) / kLpr : 1;
     const int total  = (tile_rows / RPS) * chunks;   // a multiple of kU: tile_rows / RPS is (tile_rows >= 8)
+    // every entry of the tile moves: straight-line batches — loads back to back, then the stores, nothing predicated (lanes
+    // past the end of a row repeat its last piece; see rows_copy_kernel)
+    const bool whole = __ballot(lane < tile_rows && my_tab == nullptr) == 0;
     int e = 0, cb = 0;
 #pragma unroll 1
     for (int q0 = 0; q0 < total; q0 += kU) {
       u32x4 data[kU];
       char* dst[kU];
+      if (whole) {
 #pragma unroll
-      for (int u = 0; u < kU; u++) {
+        for (int u = 0; u < kU; u++) {
+          const int e0 = RPS * e;
+          char* t      = readlane_ptr(my_tab, e0);
+          if (RPS == 2) {
+            char* t1 = readlane_ptr(my_tab, e0 + 1);
+            t        = upper ? t1 : t;
+          }
+          char* q;
+          if (HAS_MAP) {
+            q = readlane_ptr(my_plain, e0);
+            if (RPS == 2) {
+              char* q1 = readlane_ptr(my_plain, e0 + 1);
+              q        = upper ? q1 : q;
+            }
+          } else {
+            q = plain_tile + static_cast<int64_t>(e0) * p.plain_stride_bytes;
+          }
+          const int c        = cb * kLpr + col;
+          const int64_t coff = static_cast<int64_t>(min(c, p.row_vecs - 1)) * 16;
+          dst[u]             = (GATHER ? q : t) + coff;
+          data[u]            = ld_global_nt<u32x4>((GATHER ? t : q) + coff);
+          if (++cb == chunks) {  // wave-uniform: stays in SGPRs
+            cb = 0;
+            e++;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++) st_global_nt<u32x4>(dst[u], data[u]);
+        continue;
+      }
+#pragma unroll 1
+      for (int u = 0; u < kU; u++) {   // a tile with a skipped entry: one step at a time
         const int e0 = RPS * e;
         char* t      = readlane_ptr(my_tab, e0);
         if (RPS == 2) {
@@ -278,33 +368,13 @@ __global__ __launch_bounds__(kBlock) void rows_copy16_fast_kernel(rows_params p)
         }
         const int c        = cb * kLpr + col;
         const int64_t coff = static_cast<int64_t>(c) * 16;
-        const bool ok      = c < p.row_vecs && t != nullptr;  // entries past n and negative ids carry a null base
-        const char* src    = (GATHER ? t : q) + coff;
-        dst[u]             = ok ? (GATHER ? q : t) + coff : nullptr;
-#ifndef WM_SCATTER_NT_LOAD
-#define WM_SCATTER_NT_LOAD 1
-#endif
-#ifndef WM_SCATTER_NT_STORE
-#define WM_SCATTER_NT_STORE 1
-#endif
-        if (ok) {
-          if constexpr (GATHER || WM_SCATTER_NT_LOAD)
-            data[u] = ld_global_nt<u32x4>(src);
-          else
-            data[u] = ld_global<u32x4>(src);
+        if (c < p.row_vecs && t != nullptr) {  // entries past n and negative ids carry a null base
+          const u32x4 d = ld_global_nt<u32x4>((GATHER ? t : q) + coff);
+          st_global_nt<u32x4>((GATHER ? q : t) + coff, d);
         }
         if (++cb == chunks) {  // wave-uniform: stays in SGPRs
           cb = 0;
           e++;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kU; u++) {
-        if (dst[u] != nullptr) {
-          if constexpr (GATHER || WM_SCATTER_NT_STORE)
-            st_global_nt<u32x4>(dst[u], data[u]);
-          else
-            st_global<u32x4>(dst[u], data[u]);
         }
       }
     }
@@ -312,57 +382,88 @@ __global__ __launch_bounds__(kBlock) void rows_copy16_fast_kernel(rows_params p)
 }
 
 // The in-order shape of the hot geometry, fully specialised: rows of 512 B, 1, 2 or 4 KiB (ROW_VECS 16-byte pieces), one
-// tile of 4 KiB per wave moved as ONE batch — four 1 KiB wave instructions of loads, then four of stores, no loop, no
-// column test — and the wave is done; the dispatcher hands the next tile to whichever wave slot frees up first, in order.
-// (experiments/placement_pmc.hip: rows_inorder<8, 256> is this kernel for 512 B rows; against the generic fast kernel run
-// with 8-row tiles it is worth another 2-3 % on the 10 M-row gather.)
+// tile of 4 KiB per wave moved as ONE batch and the wave is done; the dispatcher hands the next tile to whichever wave slot
+// frees up first, in order. A tile whose entries all move (the wave-uniform test on the ballot below; every tile but the
+// last one of a batch without negative ids) takes the FAST PATH: four unconditional 1 KiB wave loads into four distinct
+// register quads, issued back to back, then the four stores behind s_waitcnt vmcnt(3..0) — one basic block, no per-step
+// predicate, so nothing makes the compiler merge registers or wait between the loads (round 3 shipped
+// `if (t != nullptr) data[u] = ld(...)`: hipcc then waited for every load before issuing the next and spent 133 of 294 VALU
+// instructions on v_mov; scripts/check_isa.py now gates the shape of this code). Row bases reach the wave through
+// v_readlane into SGPRs; without a row map the streamed side is affine in the tile number (scalar base + a 32-bit lane offset).
+// A tile with a skipped entry takes the predicated path, one step at a time.
 // At most 6 waves per SIMD: with 24 instead of 32 waves per CU the window of tiles in flight is a quarter narrower and the
-// kernel a little faster on every shape (interleaved in one process, profiles/r03_dim_sweep_occupancy.csv: gather 74.8 -> 75.5 %
-// of peak at 512 B, 74.4 -> 75.8 % at 1 KiB, 74.5 -> 75.8 % at 4 KiB; 16 waves per CU: 71-76 %, 8: 45-57 %).
-template <typename IdxT, bool GATHER, int ROW_VECS, bool HAS_MAP>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 6))) void rows_batch_kernel(rows_params p)
+// kernel a little faster on every shape (profiles/r03_dim_sweep_occupancy.csv).
+template <typename IdxT, bool GATHER, int ROW_VECS, bool HAS_MAP, int OWNERS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, WM_BATCH_MAX_WAVES))) void rows_batch_kernel(rows_params p)
 {
   constexpr int kSteps  = 4;                                        // 4 x 1 KiB
   constexpr int RPS     = ROW_VECS == 32 ? 2 : 1;                   // rows per wave instruction
   constexpr int kChunks = ROW_VECS <= 64 ? 1 : ROW_VECS / 64;       // wave instructions per row
   constexpr int kRows   = 256 / ROW_VECS;                           // rows per tile: 8, 4, 2, 1
   const int lane        = threadIdx.x & (kWave - 1);
-  const int64_t tile    = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-  if (tile * kRows >= p.n) return;
+  const int64_t tile    = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t first   = tile * kRows;                             // wave-uniform: lives in SGPRs
+  if (first >= p.n) return;
   char *my_tab, *my_plain;
-  load_tile_entry<IdxT>(p, lane < kRows ? tile * kRows + lane : p.n, my_tab, my_plain);
-  const int col    = RPS == 2 ? (lane & 31) : lane;
-  const bool upper = RPS == 2 && lane >= 32;
-  char* const plain_tile = p.plain + (tile * kRows + (upper ? 1 : 0)) * p.plain_stride_bytes;
-  u32x4 data[kSteps];
-  char* dst[kSteps];
-#pragma unroll
-  for (int u = 0; u < kSteps; u++) {
-    const int e0 = RPS == 2 ? 2 * u : u / kChunks;                  // first row of this step (compile-time)
+  load_tile_entry<IdxT, OWNERS>(p, lane < kRows ? first + lane : p.n, my_tab, my_plain);
+  const bool upper          = RPS == 2 && lane >= 32;
+  const uint32_t col16      = static_cast<uint32_t>(RPS == 2 ? (lane & 31) : lane) * 16u;
+  // the streamed side without a row map: row (first + e) starts at plain_tile + e * stride
+  char* const plain_tile    = p.plain + first * p.plain_stride_bytes;
+  const uint32_t plain_lane = col16 + (upper ? static_cast<uint32_t>(p.plain_stride_bytes) : 0u);   // stride < 2^31: rows_op
+
+  // RPS == 2: the two halves of the wave serve different rows. WM_BATCH_RPS2_BPERMUTE=1: each lane fetches ITS row's base
+  // with ds_bpermute (2 LDS-crossbar instructions per 64-bit base and step); 0: both bases come through v_readlane and a
+  // per-lane select (4 v_readlane + 4 v_mov + 2 v_cndmask per base and step)
+  const int half_lane4 = (lane >> 5) * 4;                           // byte index of lane (lane >= 32 ? 1 : 0) for ds_bpermute
+  auto lane_ptr = [&](char* mine, int e0) -> char* {                // base of row e0 (lower half) / e0 + 1 (upper half)
+#if WM_BATCH_RPS2_BPERMUTE
+    const uint64_t v  = reinterpret_cast<uint64_t>(mine);
+    const uint32_t lo = __builtin_amdgcn_ds_bpermute(half_lane4 + 4 * e0, static_cast<uint32_t>(v));
+    const uint32_t hi = __builtin_amdgcn_ds_bpermute(half_lane4 + 4 * e0, static_cast<uint32_t>(v >> 32));
+    return reinterpret_cast<char*>((static_cast<uint64_t>(hi) << 32) | lo);
+#else
+    char* a = readlane_ptr(mine, e0);
+    char* b = readlane_ptr(mine, e0 + 1);
+    return upper ? b : a;
+#endif
+  };
+  auto tab_addr = [&](int u) -> char* {                             // u is a compile-time constant after unrolling
+    const int e0 = RPS == 2 ? 2 * u : u / kChunks;
     const int cb = RPS == 2 ? 0 : u % kChunks;
-    char* t      = readlane_ptr(my_tab, e0);
-    if (RPS == 2) {
-      char* t1 = readlane_ptr(my_tab, e0 + 1);
-      t        = upper ? t1 : t;
-    }
-    char* q;
+    char* t      = RPS == 2 ? lane_ptr(my_tab, e0) : readlane_ptr(my_tab, e0);
+    return t + (cb * 1024 + col16);
+  };
+  auto plain_addr = [&](int u) -> char* {
+    const int e0 = RPS == 2 ? 2 * u : u / kChunks;
+    const int cb = RPS == 2 ? 0 : u % kChunks;
     if (HAS_MAP) {
-      q = readlane_ptr(my_plain, e0);
-      if (RPS == 2) {
-        char* q1 = readlane_ptr(my_plain, e0 + 1);
-        q        = upper ? q1 : q;
-      }
-    } else {
-      q = plain_tile + static_cast<int64_t>(e0) * p.plain_stride_bytes;
+      char* q = RPS == 2 ? lane_ptr(my_plain, e0) : readlane_ptr(my_plain, e0);
+      return q + (cb * 1024 + col16);
     }
-    const int64_t coff = static_cast<int64_t>(cb * 64 + col) * 16;
-    const char* src    = (GATHER ? t : q) + coff;
-    dst[u]             = t != nullptr ? (GATHER ? q : t) + coff : nullptr;  // entries past n and negative ids carry a null base
-    if (t != nullptr) data[u] = ld_global_nt<u32x4>(src);
-  }
+    return plain_tile + static_cast<int64_t>(e0) * p.plain_stride_bytes + (cb * 1024 + plain_lane);
+  };
+
+  constexpr uint64_t kAll = (1ull << kRows) - 1;
+  const uint64_t moving   = __ballot(my_tab != nullptr);            // entries past n and negative ids carry a null base
+  if ((moving & kAll) == kAll) {
+    u32x4 data[kSteps];
 #pragma unroll
-  for (int u = 0; u < kSteps; u++)
-    if (dst[u] != nullptr) st_global_nt<u32x4>(dst[u], data[u]);
+    for (int u = 0; u < kSteps; u++) data[u] = ld_global_nt<u32x4>(GATHER ? tab_addr(u) : plain_addr(u));
+#pragma unroll
+    for (int u = 0; u < kSteps; u++) st_global_nt<u32x4>(GATHER ? plain_addr(u) : tab_addr(u), data[u]);
+    return;
+  }
+#pragma unroll 1
+  for (int r = 0; r < kRows; r++) {                                 // a tile with a skipped entry: row by row
+    if (((moving >> r) & 1) == 0) continue;                         // wave-uniform
+    char* t = readlane_ptr(my_tab, r);
+    char* q = HAS_MAP ? readlane_ptr(my_plain, r) : plain_tile + static_cast<int64_t>(r) * p.plain_stride_bytes;
+    for (int c = lane; c < ROW_VECS; c += kWave) {
+      const u32x4 d = ld_global_nt<u32x4>((GATHER ? t : q) + c * 16);
+      st_global_nt<u32x4>((GATHER ? q : t) + c * 16, d);
+    }
+  }
 }
 
 
@@ -372,10 +473,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 6))) 
 // step k owns slot 64 k + l. Every lane is busy whatever S is, a row is walked front to back once (DRAM page locality),
 // and a dense output is written as one contiguous stream. Row bases travel with ds_bpermute. Rows whose byte count is
 // only a multiple of 4 use full 16-byte accesses at their natural (4-byte) alignment — legal on gfx950 global memory —
-// plus a dword tail in the last slot, instead of dropping the whole row to 4- or 8-byte vectors.
-// Measured (10 M random ids, 8 GB table, % of 8 TB/s algorithmic): gather 400 B 54 -> 60, 800 B 57 -> 64, 1 KiB 60 -> 72,
-// 1200 B 47 -> 65, 2408 B 42 -> 59, 516 B 27 -> 54; scatter 2408 B 42 -> 55, 516 B 27 -> 47 (for 16-byte-multiple rows
-// scatter keeps the kernels above).
+// and the LAST slot of such a row is shifted back so that it ENDS with the row (bytes [row_bytes - 16, row_bytes)): it
+// overlaps its neighbour by 16 - tail bytes, which both slots read from the same source and write with the same values.
+// No dword tail, no per-lane special case: every slot is one 16-byte load and one 16-byte store (round 3 carried the tail
+// as conditional dword accesses inside the slot loop: 100-104 VGPRs and a wait after every load).
+// A batch is kU x 64 slots: in a tile whose entries all move it is straight-line code, loads issued back to back and then
+// the stores (slots past the end of the tile repeat its last slot).
 template <typename IdxT, bool GATHER, bool HAS_MAP>
 __global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
 {
@@ -387,122 +490,57 @@ __global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
   const int64_t tiles   = (p.n + tile_rows - 1) / tile_rows;
   const int S           = p.flat_slots;
   const int n_slots     = tile_rows * S;
-  const bool ragged     = p.flat_tail != 16;
+  const int last_off    = (S - 1) * 16 + p.flat_tail - 16;   // row_bytes - 16: where the last slot of a row starts
+
+  // slot v -> (row of the tile, byte offset in the row)
+  auto locate = [&](int v, int& row, int& off) {
+    row     = static_cast<int>(static_cast<float>(v) * p.flat_rcp);  // v / S, fixed up below
+    int col = v - row * S;
+    if (col < 0) row--, col += S;
+    if (col >= S) row++, col -= S;
+    off = col == S - 1 ? last_off : col * 16;
+  };
 
   for (int64_t tile = wave; tile < tiles; tile += n_waves) {
     char *my_tab, *my_plain;
     load_tile_entry<IdxT>(p, lane < tile_rows ? tile * tile_rows + lane : p.n, my_tab, my_plain);
     char* const plain_tile = p.plain + tile * tile_rows * p.plain_stride_bytes;
+    const bool whole       = __ballot(lane < tile_rows && my_tab == nullptr) == 0;
 #pragma unroll 1
     for (int v0 = 0; v0 < n_slots; v0 += kWave * kU) {
-      u32x4 data[kU];
-      char* dst[kU];
-      bool part[kU];
+      if (whole) {
+        u32x4 data[kU];
+        char* dst[kU];
 #pragma unroll
-      for (int u = 0; u < kU; u++) {
-        const int v = v0 + u * kWave + lane;
-        int row     = static_cast<int>(static_cast<float>(v) * p.flat_rcp);  // v / S, fixed up below
-        int col     = v - row * S;
-        if (col < 0) {
-          row--;
-          col += S;
+        for (int u = 0; u < kU; u++) {
+          const int v = v0 + u * kWave + lane;
+          int row, off;
+          locate(min(v, n_slots - 1), row, off);
+          char* t = shfl_ptr(my_tab, row);
+          char* q = HAS_MAP ? shfl_ptr(my_plain, row) : plain_tile + row * p.plain_stride_bytes;
+          dst[u]  = (GATHER ? q : t) + off;   // a slot past the end of the tile repeats its last slot: same bytes, same place
+          if constexpr (GATHER)
+            data[u] = ld_global<u32x4>(t + off);  // rows share cache lines with their neighbours: keep them
+          else
+            data[u] = ld_global_nt<u32x4>(q + off);
         }
-        if (col >= S) {
-          row++;
-          col -= S;
-        }
-        char* t         = shfl_ptr(my_tab, row & (kWave - 1));
-        char* q         = HAS_MAP ? shfl_ptr(my_plain, row & (kWave - 1)) : plain_tile + row * p.plain_stride_bytes;
-        const bool ok   = v < n_slots && t != nullptr;  // entries past n and negative ids carry a null base
-        part[u]         = ragged && col == S - 1;
-        const char* src = (GATHER ? t : q) + col * 16;
-        dst[u]          = ok ? (GATHER ? q : t) + col * 16 : nullptr;
-        if (ok) {
-          if (!part[u]) {
-            if constexpr (GATHER)
-              data[u] = ld_global<u32x4>(src);  // rows share cache lines with their neighbours: keep them
-            else
-              data[u] = ld_global_nt<u32x4>(src);
-          } else {
 #pragma unroll
-            for (int w = 0; w < 3; w++)
-              if (w * 4 < p.flat_tail) data[u][w] = ld_global<uint32_t>(src + 4 * w);
-          }
-        }
+        for (int u = 0; u < kU; u++) st_global_nt<u32x4>(dst[u], data[u]);
+        continue;
       }
-#pragma unroll
-      for (int u = 0; u < kU; u++) {
-        if (dst[u] == nullptr) continue;
-        if (!part[u]) {
-          st_global_nt<u32x4>(dst[u], data[u]);
-        } else {
-#pragma unroll
-          for (int w = 0; w < 3; w++)
-            if (w * 4 < p.flat_tail) st_global<uint32_t>(dst[u] + 4 * w, data[u][w]);
-        }
-      }
-    }
-  }
-}
-
-// The in-order shape for rows that are NOT 512 B / 1 / 2 / 4 KiB: a row = `full` whole 16-byte pieces + a tail of 0 / 4 / 8 /
-// 12 bytes. One tile per wave: R rows whose R x full pieces fill up to kPiecesBatches batches of 4 x 64 lanes (piece v of
-// the tile = row v / full, piece v % full; all loads of a batch, then all its stores); the tails are one more, dword-wide
-// step with lane l serving row l. Against rows_flat_kernel (which carries the tail inside its slot loop as a per-lane
-// special case and needs 100-104 VGPRs = 4 waves per SIMD) this one has no per-slot branches and fits 8 waves.
-// Addresses on the dense side may be only 4-byte aligned (516 B rows): 16-byte accesses at such addresses are legal on
-// gfx950 global memory.
-template <typename IdxT, bool GATHER, bool HAS_MAP>
-__global__ __launch_bounds__(kBlock) void rows_pieces_kernel(rows_params p)
-{
-  constexpr int kSteps = 4;
-  const int lane       = threadIdx.x & (kWave - 1);
-  const int64_t tile   = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-  const int R          = p.tile_rows;
-  if (tile * R >= p.n) return;
-  const int full    = p.flat_slots;   // whole 16-byte pieces per row (here: WITHOUT the tail)
-  const int n_slots = R * full;
-  char *my_tab, *my_plain;
-  load_tile_entry<IdxT>(p, lane < R ? tile * R + lane : p.n, my_tab, my_plain);
-  char* const plain_tile = p.plain + tile * R * p.plain_stride_bytes;
 #pragma unroll 1
-  for (int v0 = 0; v0 < n_slots; v0 += kWave * kSteps) {
-    u32x4 data[kSteps];
-    char* dst[kSteps];
-#pragma unroll
-    for (int u = 0; u < kSteps; u++) {
-      const int v = v0 + u * kWave + lane;
-      int row     = static_cast<int>(static_cast<float>(v) * p.flat_rcp);  // v / full, fixed up below
-      int col     = v - row * full;
-      if (col < 0) row--, col += full;
-      if (col >= full) row++, col -= full;
-      char* t         = shfl_ptr(my_tab, row & (kWave - 1));
-      char* q         = HAS_MAP ? shfl_ptr(my_plain, row & (kWave - 1)) : plain_tile + row * p.plain_stride_bytes;
-      const bool ok   = v < n_slots && t != nullptr;  // entries past n and negative ids carry a null base
-      const char* src = (GATHER ? t : q) + col * 16;
-      dst[u]          = ok ? (GATHER ? q : t) + col * 16 : nullptr;
-      if (ok) {
-        if constexpr (GATHER)
-          data[u] = ld_global<u32x4>(src);   // table rows that do not fill their last line share it with the next piece
-        else
-          data[u] = ld_global_nt<u32x4>(src);
+      for (int u = 0; u < kU; u++) {   // a tile with a skipped entry: one step at a time
+        const int v = v0 + u * kWave + lane;
+        int row, off;
+        locate(min(v, n_slots - 1), row, off);
+        char* t = shfl_ptr(my_tab, row);   // (ds_bpermute needs every lane: outside the guard)
+        char* q = HAS_MAP ? shfl_ptr(my_plain, row) : plain_tile + row * p.plain_stride_bytes;
+        if (v < n_slots && t != nullptr) {  // entries past n and negative ids carry a null base
+          const u32x4 d = GATHER ? ld_global<u32x4>(t + off) : ld_global_nt<u32x4>(q + off);
+          st_global_nt<u32x4>((GATHER ? q : t) + off, d);
+        }
       }
     }
-#pragma unroll
-    for (int u = 0; u < kSteps; u++)
-      if (dst[u] != nullptr) st_global_nt<u32x4>(dst[u], data[u]);
-  }
-  if (p.flat_tail > 0 && my_tab != nullptr) {   // lane l < R: the tail dwords of its own row
-    char* q         = HAS_MAP ? my_plain : plain_tile + lane * p.plain_stride_bytes;
-    const char* src = (GATHER ? my_tab : q) + full * 16;
-    char* d         = (GATHER ? q : my_tab) + full * 16;
-    uint32_t w[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-      if (4 * k < p.flat_tail) w[k] = ld_global<uint32_t>(src + 4 * k);
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-      if (4 * k < p.flat_tail) st_global<uint32_t>(d + 4 * k, w[k]);
   }
 }
 
@@ -559,12 +597,11 @@ __global__ __launch_bounds__(kBlock) void rows_staged_gather_kernel(rows_params 
           if (col >= S) row++, col -= S;
           // (ds_bpermute returns 0 for an inactive SOURCE lane: the broadcast must not sit inside the guard)
           const char* t = shfl_ptr(my_tab, r0 + row);
-          nw[i]         = 0;
-          if (lane + i * kWave < chunk_slots) {
-            d[i]       = ld_global_nt<u32x4>(t + col * 16);   // the padded table row holds 16 bytes here even in the tail slot
-            lds_off[i] = row * row_bytes + col * 16;
-            nw[i]      = col == S - 1 ? tail_words : 4;
-          }
+          // unconditional: a lane past the end of the chunk re-reads its last slot (and writes nothing to LDS) — a load under
+          // a per-lane guard is a conditionally defined register, and hipcc then waits for each load before the next
+          d[i]          = ld_global_nt<u32x4>(t + col * 16);   // the padded table row holds 16 bytes here even in the tail slot
+          lds_off[i]    = row * row_bytes + col * 16;
+          nw[i]         = lane + i * kWave < chunk_slots ? (col == S - 1 ? tail_words : 4) : 0;
         }
 #pragma unroll
         for (int i = 0; i < kStageIters; i++) {
@@ -631,10 +668,8 @@ __global__ __launch_bounds__(kBlock) void rows_staged_scatter_kernel(rows_params
         // ---- dense input -> LDS, aligned 16-byte pieces of the contiguous stream
         u32x4 d[kStageIters];
 #pragma unroll
-        for (int i = 0; i < kStageIters; i++) {
-          const int v = lane + i * kWave;
-          if (v < chunk_vecs) d[i] = ld_global_nt<u32x4>(in + v * 16);
-        }
+        for (int i = 0; i < kStageIters; i++)   // unconditional (a lane past the end re-reads the chunk's last piece): see the gather
+          d[i] = ld_global_nt<u32x4>(in + min(lane + i * kWave, chunk_vecs - 1) * 16);
 #pragma unroll
         for (int i = 0; i < kStageIters; i++) {
           const int v = lane + i * kWave;
@@ -738,29 +773,45 @@ __global__ __launch_bounds__(kBlock) void rows_convert_kernel(rows_params p)
   for (int64_t tile = wave; tile < tiles; tile += n_waves) {
     char *my_tab, *my_plain;
     load_tile_entry<IdxT>(p, lane < tile_rows ? tile * tile_rows + lane : p.n, my_tab, my_plain);
+    // every entry of the tile moves: straight-line batches, nothing predicated (idle lanes repeat the row's last vector, steps
+    // past the tile its last row; see rows_copy_kernel)
+    const bool whole = __ballot(lane < tile_rows && my_tab == nullptr) == 0;
     for (int cbase = 0; cbase < p.row_vecs; cbase += lpr) {
       const int c       = cbase + col;
       const bool col_ok = c < p.row_vecs;
+      const int64_t cc  = min(c, p.row_vecs - 1);
       for (int s0 = 0; s0 < tile_rows; s0 += rps * kU) {
-        elt_vec<FromT, V> data[kU];
-        char* dst[kU];
+        if (whole) {
+          elt_vec<FromT, V> data[kU];
+          char* dst[kU];
 #pragma unroll
-        for (int u = 0; u < kU; u++) {
-          const int e   = s0 + u * rps + sub;
-          char* t       = shfl_ptr(my_tab, e & (kWave - 1));
-          char* q       = shfl_ptr(my_plain, e & (kWave - 1));
-          const bool ok = col_ok && e < kWave && t != nullptr;
-          const char* src = GATHER ? t : q;
-          dst[u]        = ok ? (GATHER ? q : t) + static_cast<int64_t>(c) * V * sizeof(ToT) : nullptr;
-          if (ok) data[u] = ld_global_pod<elt_vec<FromT, V>>(src + static_cast<int64_t>(c) * V * sizeof(FromT));
-        }
+          for (int u = 0; u < kU; u++) {
+            const int el = min(s0 + u * rps + sub, tile_rows - 1);
+            char* t      = shfl_ptr(my_tab, el);
+            char* q      = shfl_ptr(my_plain, el);
+            dst[u]       = (GATHER ? q : t) + cc * V * sizeof(ToT);
+            data[u]      = ld_global_pod<elt_vec<FromT, V>>((GATHER ? t : q) + cc * V * sizeof(FromT));
+          }
 #pragma unroll
-        for (int u = 0; u < kU; u++) {
-          if (dst[u] != nullptr) {
+          for (int u = 0; u < kU; u++) {
             elt_vec<ToT, V> o;
 #pragma unroll
             for (int k = 0; k < V; k++) o.v[k] = convert_elt<FromT, ToT>(data[u].v[k]);
             st_global_pod<elt_vec<ToT, V>>(dst[u], o);
+          }
+          continue;
+        }
+#pragma unroll 1
+        for (int u = 0; u < kU; u++) {   // a tile with a skipped entry: one step at a time
+          const int e = s0 + u * rps + sub;
+          char* t     = shfl_ptr(my_tab, e & (kWave - 1));
+          char* q     = shfl_ptr(my_plain, e & (kWave - 1));
+          if (col_ok && e < kWave && t != nullptr) {
+            const elt_vec<FromT, V> d = ld_global_pod<elt_vec<FromT, V>>((GATHER ? t : q) + static_cast<int64_t>(c) * V * sizeof(FromT));
+            elt_vec<ToT, V> o;
+#pragma unroll
+            for (int k = 0; k < V; k++) o.v[k] = convert_elt<FromT, ToT>(d.v[k]);
+            st_global_pod<elt_vec<ToT, V>>((GATHER ? q : t) + static_cast<int64_t>(c) * V * sizeof(ToT), o);
           }
         }
       }
@@ -776,9 +827,43 @@ inline void launch_rows_kernel(K kernel, int blocks, hipStream_t stream, const r
 {
   t_last_rows_kernel = reinterpret_cast<const void*>(kernel);
   // WM_ROWS_LDS=bytes (experiments): dynamic LDS nobody uses, to cap the workgroups resident per CU
-  const char* le   = getenv("WM_ROWS_LDS");
+  const char* le   = WM_KNOB("WM_ROWS_LDS");
   const size_t lds = le != nullptr ? static_cast<size_t>(atoi(le)) : 0;
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(p.launch_threads), lds, stream, p);
+}
+
+// rank = off / chunk_stride as multiply-high + shift (Granlund / Montgomery, dividends below 2^63): with l = ceil(log2 d)
+// and m = ceil(2^(63 + l) / d) (< 2^64), floor(n / d) = (n * m) >> (63 + l) = umulhi64(n, m) >> (l - 1) for every n < 2^63
+inline void magic_for(uint64_t d, uint64_t* m, int* shift)
+{
+  if (d <= 1) {
+    *m = 0, *shift = 0;
+    return;
+  }
+  int l = 0;
+  while (l < 64 && (l == 63 ? false : (uint64_t(1) << l) < d)) l++;
+  if (l >= 63) l = 63;   // d > 2^62: quotients are 0 or 1; m below still satisfies the bound for n < 2^63
+  const unsigned __int128 num = static_cast<unsigned __int128>(1) << (63 + l);
+  *m     = static_cast<uint64_t>((num + d - 1) / d);
+  *shift = l - 1;
+}
+
+// chunked table: the division constants, and — when the handle registered host copies of its tables — bases and bounds
+// by value (wm::lookup_gref_tables, backend.hpp)
+void fill_owner_tables(rows_params* p)
+{
+  magic_for(p->chunk_stride, &p->chunk_magic, &p->chunk_shift);
+  const char* off = WM_KNOB("WM_ROWS_OWNERS_BY_VALUE");   // =0: device arrays only (A/B, tests)
+  gref_host_tables t;
+  if ((off != nullptr && off[0] == '0') || !lookup_gref_tables(p->rank_ptrs, &t) || t.world_size != p->world_size) return;
+  p->owners_by_value = 1;
+  for (int r = 0; r < kOwnersByValue; r++) {
+    const bool exists  = r < t.world_size;
+    p->owner_bound[r]  = exists ? t.rank_offsets[r] : ~uint64_t(0);
+    p->owner_delta[r]  = exists ? reinterpret_cast<uint64_t>(t.rank_ptrs[r]) - t.rank_offsets[r] : 0;
+  }
+  // (a rank without memory shares its start with the next one: the chain of comparisons lands on the LAST rank with that
+  // start, the real owner — the same answer as the search over rank_offsets in resolve_row)
 }
 
 inline int ilog2_ceil(int x)
@@ -813,36 +898,23 @@ int default_max_blocks()
 // unset (-1): the measured rule in rows_op
 int inorder_setting()
 {
-  const char* e = getenv("WM_ROWS_INORDER");
+  const char* e = WM_KNOB("WM_ROWS_INORDER");
   return (e == nullptr || e[0] == '\0') ? -1 : (e[0] == '0' ? 0 : 1);
 }
 // threads per workgroup of the in-order launches (WM_ROWS_BLOCK=64 / 128 / 256; measured: 64 and 256 within 1 %, 512 and
 // 1024 5-12 % slower — the finer the unit the dispatcher hands out, the tighter the window)
 int inorder_block_threads()
 {
-  const char* e = getenv("WM_ROWS_BLOCK");
+  const char* e = WM_KNOB("WM_ROWS_BLOCK");
   const int v   = e != nullptr ? atoi(e) : 0;
   return (v == 64 || v == 128 || v == 256) ? v : 256;
-}
-
-// rows_pieces_kernel for the shapes the flat-stream kernel serves? WM_ROWS_PIECES=0 never, 1 always, unset: the measured rule
-bool pieces_wanted(bool gather, int64_t row_bytes)
-{
-  const char* e = getenv("WM_ROWS_PIECES");
-  if (e != nullptr && e[0] != '\0') return e[0] != '0';
-  // Measured (profiles/r03_dim_sweep_pieces.csv, interleaved with the flat kernel in one process): gathers lose 6-12 points
-  // on every shape (400 B ... 4120 B); scatters win at 1032 B (+4), 1544 B (+1) and 2408 B (+6) and lose at 400 B (-2), 516 B
-  // (-1), 1200 B (-1.5) and 4120 B (-3.5). No rule worth shipping came out of that: the kernel stays opt-in.
-  (void)gather;
-  (void)row_bytes;
-  return false;
 }
 
 // rows per wave tile of rows_copy_kernel / rows_convert_kernel when they are launched in order: about 4 KiB of the (wider) row
 // side, a power of two between one batch of the kernel (rps x 4 rows) and 64. WM_ROWS_SMALL_TILE=0 keeps 64-row tiles (A/B).
 int small_tile_rows(int lpr_log2, int64_t row_bytes)
 {
-  const char* e = getenv("WM_ROWS_SMALL_TILE");
+  const char* e = WM_KNOB("WM_ROWS_SMALL_TILE");
   if (e != nullptr && e[0] == '0') return kWave;
   const int batch = (kWave >> lpr_log2) * 4;
   int t           = kWave;
@@ -853,20 +925,20 @@ int small_tile_rows(int lpr_log2, int64_t row_bytes)
 // 0 = never, 1 = always when legal, -1 (default) = by the measured rule in want_flat()
 int flat_override()
 {
-  const char* e = getenv("WM_ROWS_FLAT");
+  const char* e = WM_KNOB("WM_ROWS_FLAT");
   return e == nullptr ? -1 : atoi(e);
 }
 
 // WM_ROWS_STAGED_SCATTER=0 switches the LDS-staged scatter off (A/B: the flat-stream kernel then)
 bool staged_scatter_enabled()
 {
-  const char* e = getenv("WM_ROWS_STAGED_SCATTER");
+  const char* e = WM_KNOB("WM_ROWS_STAGED_SCATTER");
   return e == nullptr || e[0] != '0';
 }
 // longest row the staged kernels take (WM_ROWS_STAGED_MAXROW overrides, A/B)
 int64_t staged_max_row(bool gather)
 {
-  const char* e = getenv("WM_ROWS_STAGED_MAXROW");
+  const char* e = WM_KNOB("WM_ROWS_STAGED_MAXROW");
   if (e != nullptr && atoll(e) > 0) return atoll(e);
   (void)gather;
   return 5120;
@@ -878,7 +950,7 @@ int64_t staged_max_row(bool gather)
 // or -1; rows of whole 16-byte pieces, scatter: 144 B +0.8, 176 B +2.2, 208 B +3.4, 240 B +5.2, 80 B equal.
 bool staged_row_wanted(bool gather, int64_t row_bytes)
 {
-  const char* e = getenv("WM_ROWS_STAGED_MINROW");
+  const char* e = WM_KNOB("WM_ROWS_STAGED_MINROW");
   if (e != nullptr && atoll(e) > 0) return row_bytes >= atoll(e);
   if (gather) return row_bytes >= 16;
   // (scatter of 64 / 128 / 256 B rows: +1 / +1.2 / +6.6 although 96 B and 112 B lose 1-2: r03_dim_sweep_pow2_small.csv)
@@ -892,14 +964,14 @@ bool staged_row_wanted(bool gather, int64_t row_bytes)
 // WM_ROWS_STAGED_ALIGNED=0 / 1 forces.
 bool staged_aligned_rows(bool gather, int64_t row_bytes)
 {
-  const char* e = getenv("WM_ROWS_STAGED_ALIGNED");
+  const char* e = WM_KNOB("WM_ROWS_STAGED_ALIGNED");
   if (e != nullptr && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
   return !gather || row_bytes < 512;
 }
 // WM_ROWS_STAGED=0 switches the LDS-staged gather off (A/B)
 bool staged_enabled()
 {
-  const char* e = getenv("WM_ROWS_STAGED");
+  const char* e = WM_KNOB("WM_ROWS_STAGED");
   return e == nullptr || e[0] != '0';
 }
 
@@ -924,13 +996,6 @@ bool want_flat(bool gather, int vb, int64_t row_bytes)
 template <typename IdxT, bool GATHER>
 void launch_flat(const rows_params& p, int blocks, hipStream_t stream)
 {
-  if (p.pieces) {
-    if (p.row_map != nullptr)
-      launch_rows_kernel(rows_pieces_kernel<IdxT, GATHER, true>, blocks, stream, p);
-    else
-      launch_rows_kernel(rows_pieces_kernel<IdxT, GATHER, false>, blocks, stream, p);
-    return;
-  }
   if (p.row_map != nullptr)
     launch_rows_kernel(rows_flat_kernel<IdxT, GATHER, true>, blocks, stream, p);
   else
@@ -967,10 +1032,16 @@ void launch_copy(const rows_params& p, int vb, int blocks, hipStream_t stream)
   }
   if (vb == 16 && p.batch_vecs > 0) {  // in-order launch of 512 B / 1 / 2 / 4 KiB rows: the single-batch kernel
     const bool has_map = p.row_map != nullptr;
-#define WM_BATCH(RV)                                                                                   \
-  do {                                                                                                 \
-    if (has_map) launch_rows_kernel(rows_batch_kernel<IdxT, GATHER, RV, true>, blocks, stream, p);     \
-    else launch_rows_kernel(rows_batch_kernel<IdxT, GATHER, RV, false>, blocks, stream, p);            \
+    const bool by_value = p.chunk_stride != 0;   // rows_op takes this kernel for continuous tables and by-value owner tables only
+#define WM_BATCH(RV)                                                                                                  \
+  do {                                                                                                                \
+    if (has_map) {                                                                                                    \
+      if (by_value) launch_rows_kernel(rows_batch_kernel<IdxT, GATHER, RV, true, 1>, blocks, stream, p);              \
+      else launch_rows_kernel(rows_batch_kernel<IdxT, GATHER, RV, true, 0>, blocks, stream, p);                       \
+    } else {                                                                                                          \
+      if (by_value) launch_rows_kernel(rows_batch_kernel<IdxT, GATHER, RV, false, 1>, blocks, stream, p);             \
+      else launch_rows_kernel(rows_batch_kernel<IdxT, GATHER, RV, false, 0>, blocks, stream, p);                      \
+    }                                                                                                                 \
   } while (0)
     switch (p.batch_vecs) {
       case 32: WM_BATCH(32); break;
@@ -1091,6 +1162,7 @@ int rows_op(const wm_rows_args* a, void* stream_v)
   } else {
     p.rank_ptrs    = static_cast<char* const*>(a->gref.pointer);
     p.rank_offsets = a->gref.rank_memory_offsets;
+    fill_owner_tables(&p);
   }
   p.table_stride_bytes = a->table_stride * tes;
   p.table_offset_bytes = a->table_storage_offset * tes;
@@ -1143,7 +1215,7 @@ int rows_op(const wm_rows_args* a, void* stream_v)
     p.row_vecs              = static_cast<int>(row_bytes / vb);
     p.lpr_log2              = std::min(6, ilog2_ceil(p.row_vecs));
     // flat-stream kernel: needs every address 4-byte aligned (then 16-byte accesses are legal at any such address)
-    const bool dword_ok = vb >= 4 && row_bytes < (INT64_C(1) << 24);
+    const bool dword_ok = vb >= 4 && row_bytes >= 16 && row_bytes < (INT64_C(1) << 24);
     const bool flat     = dword_ok && want_flat(GATHER, static_cast<int>(vb), row_bytes);
     // the staged kernels share the flat kernel's slot geometry; they are also tried on rows the flat kernel does not take
     // (rows of whole 16-byte pieces above 256 B: where the flat rule says no, the readlane kernel is at least as good)
@@ -1192,18 +1264,8 @@ int rows_op(const wm_rows_args* a, void* stream_v)
         p.launch_threads = kBlock;
       }
     }
-    // rows_pieces_kernel instead of the flat-stream kernel (in-order launches only; WM_ROWS_PIECES=0 / 1 forces)
-    if (p.stage_rows == 0 && p.flat_slots > 0 && a->max_blocks <= 0 && inorder_mode != 0 && row_bytes >= 16 &&
-        pieces_wanted(GATHER, row_bytes)) {
-      p.pieces         = 1;
-      p.flat_slots     = static_cast<int>(row_bytes / 16);
-      p.flat_tail      = static_cast<int>(row_bytes % 16);
-      p.flat_rcp       = 1.0f / static_cast<float>(p.flat_slots);
-      inorder          = true;
-      p.launch_threads = inorder_block_threads();
-    }
     if (p.stage_rows == 0 && (p.flat_slots > 0 || (vb == 16 && p.row_vecs >= 32))) {  // the two kernels that take tile_rows
-      const char* te    = getenv("WM_ROWS_TILE");  // experiment switch
+      const char* te    = WM_KNOB("WM_ROWS_TILE");  // experiment switch
       const int forced  = te != nullptr ? atoi(te) : 0;
       p.tile_rows = row_bytes <= 768 ? 64 : row_bytes <= 1536 ? 32 : row_bytes <= 3072 ? 16 : 8;
       if (inorder) {
@@ -1216,13 +1278,15 @@ int rows_op(const wm_rows_args* a, void* stream_v)
           const int chunks = p.row_vecs > 32 ? (p.row_vecs + kWave - 1) / kWave : 1;
           p.tile_rows      = p.row_vecs == 32 ? 8 : chunks == 1 ? 4 : chunks == 2 ? 2 : chunks % 4 == 0 ? 1 : 4;
           // 512 B / 1 / 2 / 4 KiB rows: exactly one 4 KiB batch per tile -> the specialised kernel (WM_ROWS_BATCH=0: A/B)
-          const char* be = getenv("WM_ROWS_BATCH");
+          const char* be = WM_KNOB("WM_ROWS_BATCH");
+          // (continuous tables and owner tables by value; plain rows less than 2 GiB apart: 32-bit lane offsets)
           if ((p.row_vecs == 32 || p.row_vecs == 64 || p.row_vecs == 128 || p.row_vecs == 256) && forced == 0 &&
+              (p.chunk_stride == 0 || p.owners_by_value) && p.plain_stride_bytes < (INT64_C(1) << 31) &&
               !(be != nullptr && be[0] == '0')) {
             p.batch_vecs = p.row_vecs;
             // one wave per workgroup for this kernel: the finest unit the dispatcher can hand out (measured against 256
             // threads on 512 B - 4 KiB rows: gather +0.2 ... +1.4 %, scatter +0.5 ... +1 %; the flat kernel loses 2-3 % with it)
-            if (getenv("WM_ROWS_BLOCK") == nullptr) p.launch_threads = kWave;
+            if (WM_KNOB("WM_ROWS_BLOCK") == nullptr) p.launch_threads = kWave;
           }
         }
       }

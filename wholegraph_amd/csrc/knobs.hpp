@@ -1,0 +1,51 @@
+// wholegraph_amd — environment knobs, read ONCE.
+//
+// Every WM_* / WG_* switch of the library goes through WM_KNOB("NAME"): the environment is consulted the first time the
+// call site runs and the answer is kept for the life of the process — no getenv on the path of an op (a dozen of them per
+// row-kernel launch were µs-scale host work on every call of a latency-bound chain, and a knob could change behaviour
+// mid-process). Experiments and tests that flip a switch between calls say so explicitly:
+// wholememory_ext_reload_knobs() (include/wholememory/wholegraph_amd_ext.h) makes every site read its variable again at
+// its next use. Reloading while ops run on other threads is not supported.
+#pragma once
+
+#include <atomic>
+#include <cstdlib>
+#include <string>
+
+namespace wm {
+
+extern std::atomic<unsigned> g_knob_generation;   // wm_common.cpp
+
+class env_knob {
+ public:
+  explicit env_knob(const char* name) : name_(name), gen_(~0u) {}
+  // value of the variable as of the last (re)load, nullptr when unset
+  const char* str() const
+  {
+    const unsigned g = g_knob_generation.load(std::memory_order_acquire);
+    if (gen_ != g) {
+      const char* e = std::getenv(name_);
+      set_          = e != nullptr;
+      value_        = set_ ? e : "";
+      gen_          = g;
+    }
+    return set_ ? value_.c_str() : nullptr;
+  }
+
+ private:
+  const char* name_;
+  mutable unsigned gen_;
+  mutable bool set_ = false;
+  mutable std::string value_;
+};
+
+inline void reload_knobs() { g_knob_generation.fetch_add(1, std::memory_order_acq_rel); }
+
+}  // namespace wm
+
+// one static per call site (the lambda gives each expansion its own)
+#define WM_KNOB(NAME)                      \
+  ([]() -> const char* {                   \
+    static const ::wm::env_knob k(NAME);   \
+    return k.str();                        \
+  }())

@@ -27,6 +27,7 @@
 
 #include <wholememory/wholememory.h>
 
+#include "knobs.hpp"
 #include "backend.hpp"
 #include "communicator.hpp"
 #include "memory_vmm.hpp"
@@ -118,6 +119,8 @@ void upload_tables(wholememory_handle_* h)
   WM_BK(bk->memcpy_async(h->dev_rank_ptrs, h->rank_ptrs.data(), sizeof(void*) * W, nullptr));
   WM_BK(bk->memcpy_async(h->dev_rank_offsets, h->part_offsets.data(), sizeof(size_t) * (W + 1), nullptr));
   WM_BK(bk->stream_sync(nullptr));
+  // host copies for the row kernels (by-value owner tables, kernels/rows.hip)
+  wm::register_gref_tables(h->dev_rank_ptrs, W, h->rank_ptrs.data(), h->part_offsets.data());
 }
 
 void alloc_local(wholememory_handle_* h)
@@ -143,22 +146,22 @@ void alloc_local(wholememory_handle_* h)
   //   WM_MALLOC_PROBE=1      off: the first allocation is the shard
   //   WM_MALLOC_PROBE=K      exactly K candidates (2 ... 8), whatever the first one looks like
   // A candidate that cannot be allocated ends the search. Every rank decides for its own shard; no collective is involved.
-  static const int k_setting = [] {
-    const char* e = getenv("WM_MALLOC_PROBE");
+  const int k_setting = [] {
+    const char* e = WM_KNOB("WM_MALLOC_PROBE");
     if (e == nullptr || e[0] == '\0') return -1;
     return std::min(std::max(atoi(e), 1), 8);
   }();
-  static const size_t min_bytes = [] {
-    const char* e = getenv("WM_MALLOC_PROBE_MIN_BYTES");
+  const size_t min_bytes = [] {
+    const char* e = WM_KNOB("WM_MALLOC_PROBE_MIN_BYTES");
     return e != nullptr && atoll(e) > 0 ? static_cast<size_t>(atoll(e)) : (static_cast<size_t>(1) << 30);
   }();
-  static const float good_ms = [] {
-    const char* e = getenv("WM_MALLOC_PROBE_GOOD");
+  const float good_ms = [] {
+    const char* e = WM_KNOB("WM_MALLOC_PROBE_GOOD");
     return e != nullptr && atof(e) > 0 ? static_cast<float>(atof(e)) : 0.166f;
   }();
   WM_BK(bk->malloc_device(&h->local_ptr, h->local_alloc));
   if (k_setting == 1 || bk->probe_memory == nullptr || h->local_alloc < min_bytes) return;
-  static const bool verbose = getenv("WM_MALLOC_PROBE_VERBOSE") != nullptr;
+  const bool verbose = WM_KNOB("WM_MALLOC_PROBE_VERBOSE") != nullptr;
   int k_candidates = k_setting;
   if (k_setting < 0) {
     size_t free_b = 0, total_b = 0;
@@ -325,7 +328,10 @@ void destroy_memory(wholememory_handle_* h) noexcept
   if (h->local_comm != nullptr) wholememory_destroy_communicator(h->local_comm);
   if (h->cross_comm != nullptr) wholememory_destroy_communicator(h->cross_comm);
   h->local_comm = h->cross_comm = nullptr;
-  if (h->dev_rank_ptrs) bk->free_device(h->dev_rank_ptrs);
+  if (h->dev_rank_ptrs) {
+    wm::unregister_gref_tables(h->dev_rank_ptrs);
+    bk->free_device(h->dev_rank_ptrs);
+  }
   if (h->dev_rank_offsets) bk->free_device(h->dev_rank_offsets);
   if (h->vmm.base != nullptr) {
     vmm_continuous_destroy(h->comm, &h->vmm);

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "knobs.hpp"
 #include "communicator.hpp"
 #include "memory_vmm.hpp"
 #include "wm_common.hpp"
@@ -209,8 +210,8 @@ void vmm_continuous_destroy(wholememory_comm_t comm, vmm_mapping* m) noexcept
   // wrong rows always filled whole 4 KiB pages (rows 576-639 of a 64-byte-row table ...), the values were the previous
   // table's. A range that is never reserved again cannot be hit by a stale translation: what leaks is address space only
   // (the physical pages are released above), 2^47 bytes of it are there, a table takes its padded size.
-  static const bool free_va = [] {
-    const char* e = getenv("WM_VMM_FREE_VA");
+  const bool free_va = [] {
+    const char* e = WM_KNOB("WM_VMM_FREE_VA");
     return e != nullptr && e[0] == '1';
   }();
   if (free_va) (void)hipMemAddressFree(m->base, m->total_alloc);

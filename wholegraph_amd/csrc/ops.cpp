@@ -15,6 +15,7 @@
 //   6 reorder-on-receive: out[raw_indices[j]] = recv[j]
 // DISTRIBUTED scatter mirrors it (rows travel in the input dtype, the owner casts on write) and ends
 // with a stream synchronise like the reference (scatter_op_impl_nccl.cu:168).
+#include "knobs.hpp"
 #include "ops_internal.hpp"
 #include "embedding_cache.hpp"
 
@@ -116,8 +117,8 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   // Small batches are latency-bound and a de-duplicated exchange could not pay for its sort: they skip the estimate (a
   // 16 MiB flag array to clear and count) and publish 0 — a vote for "as they are", not a veto; the other ranks' estimates
   // still decide. WM_GATHER_DEDUP_MIN_IDS moves the limit.
-  static const int64_t estimate_min_ids = [] {
-    const char* e = getenv("WM_GATHER_DEDUP_MIN_IDS");
+  const int64_t estimate_min_ids = [] {
+    const char* e = WM_KNOB("WM_GATHER_DEDUP_MIN_IDS");
     return e != nullptr && atoll(e) >= 0 ? static_cast<int64_t>(atoll(e)) : (INT64_C(1) << 18);
   }();
   const bool estimate = estimate_duplicates && bk->dup_estimate != nullptr && n >= std::max<int64_t>(estimate_min_ids, 2) &&
@@ -300,7 +301,7 @@ wholememory_error_code_t tensor_mapped_gref(wholememory_tensor_t t, wholememory_
 bool mapped_via_exchange(wholememory_tensor_t t, wholememory_memory_type_t mt)
 {
   if (mt != WHOLEMEMORY_MT_CHUNKED && mt != WHOLEMEMORY_MT_CONTINUOUS) return false;
-  const char* e = getenv("WM_MAPPED_VIA_EXCHANGE");
+  const char* e = WM_KNOB("WM_MAPPED_VIA_EXCHANGE");
   if (e == nullptr || e[0] != '1') return false;
   wholememory_comm_t comm;
   if (wholememory_get_communicator(&comm, wholememory_tensor_get_memory_handle(t)) != WHOLEMEMORY_SUCCESS) return false;
@@ -311,7 +312,7 @@ bool mapped_via_exchange(wholememory_tensor_t t, wholememory_memory_type_t mt)
 // use what all ranks know alike: the world size, the environment and id_exchange::global_moved.
 int exchange_chunks(int world_size, int64_t global_moved)
 {
-  const char* e = getenv("WM_EXCHANGE_CHUNKS");
+  const char* e = WM_KNOB("WM_EXCHANGE_CHUNKS");
   if (e != nullptr && atoi(e) >= 1) return std::min(atoi(e), 16);
   if (world_size <= 1) return 1;
   // below ~256 k rows in and out of the average rank the exchange is latency-bound and extra launches only add overhead
@@ -512,7 +513,7 @@ wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const o
   wholememory_comm_t comm;
   WHOLEMEMORY_RETURN_ON_FAIL(wholememory_get_communicator(&comm, handle));
   const int64_t n = d.indices.size;
-  const char* sw  = getenv("WM_GATHER_DEDUP");
+  const char* sw  = WM_KNOB("WM_GATHER_DEDUP");
   const int mode  = sw == nullptr ? -1 : atoi(sw);  // -1 auto, 0 never, 1 always (several ranks), 2 always
   // every condition here is the same on all ranks (the op is collective: a rank with nothing to ask, or with too much,
   // must still walk the same sequence of collectives as the others)
@@ -529,14 +530,14 @@ wholememory_error_code_t gather_distributed(wholememory_handle_t handle, const o
 
   // auto: bucket and exchange the ids as they are, with the duplicate estimate riding along; keep going on that exchange
   // when the batch is not worth de-duplicating (the common case), else start over on the distinct ids
-  static const int64_t threshold = [] {
-    const char* e = getenv("WM_GATHER_DEDUP_PERMILLE");
+  const int64_t threshold = [] {
+    const char* e = WM_KNOB("WM_GATHER_DEDUP_PERMILLE");
     return e != nullptr && atoi(e) > 0 ? static_cast<int64_t>(atoi(e)) : INT64_C(100);
   }();
   id_exchange x(env);
   bucket_and_exchange_ids(comm, d.indices_ptr, d.indices.dtype, n, entry_offsets, env, stream, &x, !comm->loopback, false,
                           nullptr, true, true);   // counts + estimate only: what follows depends on the estimate
-  static const bool trace = getenv("WM_GATHER_DEDUP_TRACE") != nullptr;
+  const bool trace = WM_KNOB("WM_GATHER_DEDUP_TRACE") != nullptr;
   if (trace)
     WM_WARN("gather of %ld ids: duplicate estimate %ld permille (mean over %d ranks), threshold %ld -> %s",
             static_cast<long>(n), static_cast<long>(x.dup_permille), comm->world_size, static_cast<long>(threshold),
