@@ -51,7 +51,8 @@ def parse():
     p.add_argument("--rows", type=int, default=0, help="table rows per GPU (default: 100M at N=1, 125M at N>1)")
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--indices", type=int, default=10_000_000)
-    p.add_argument("--dist", choices=["uniform", "zipf", "zipf_clustered"], default="uniform")
+    p.add_argument("--dist", choices=["uniform", "zipf", "zipf_clustered", "sequential"], default="uniform",
+                   help="sequential (ids 0, 1, 2 ...: the row kernel as a plain streaming copy) is a diagnostic ceiling, not a workload")
     p.add_argument("--memory-type", default="", help="override: continuous|chunked|distributed")
     p.add_argument("--location", default="cuda", help="cuda|cpu (HOST-located table, config C1)")
     p.add_argument("--op", choices=["gather", "scatter", "grad_apply", "sample_gather"], default="gather",
@@ -83,6 +84,8 @@ def parse():
 
 def make_indices(n, total_rows, dist, seed):
     rng = np.random.default_rng(seed)
+    if dist == "sequential":
+        return (np.arange(n, dtype=np.int64) + (seed % 7) * n) % total_rows
     if dist == "uniform":
         return rng.integers(0, total_rows, n, dtype=np.int64)
     # Zipf(s = 1.05) popularity rank k; hashed to a row so hot rows spread over owners,

@@ -31,6 +31,10 @@ struct wholememory_embedding_optimizer_ {
   float beta2        = 0.999f;
   float alpha        = 0.99f;
   float adam_w       = 0.0f;
+  // extension (not in the reference): order of the fp32 sum of a run of duplicate gradient rows, see
+  // wm_optimizer_args::fold_mode — -1 the default of the table dtype (ordered for fp32: the reference's bits), 0 ordered,
+  // 1 tree (deterministic, equal within rounding, 30 % faster under heavy skew). Parameter name "grad_fold".
+  float grad_fold    = -1.0f;
   std::vector<const char*> state_names;  // nullptr-terminated
   std::map<std::string, float*> params;
 };
@@ -176,7 +180,9 @@ void fill_optimizer_args(wm_optimizer_args* a, const wholememory_embedding_optim
   a->alpha        = o->alpha;
   a->adam_w       = o->adam_w > 0.5f ? 1 : 0;
   a->lr           = lr;
-  a->fold_mode    = -1;   // the backend's default for the table dtype (ordered for fp32), WM_GRAD_FOLD overrides
+  // the caller's choice (optimizer parameter "grad_fold"), else the backend's default for the table dtype (ordered for fp32);
+  // WM_GRAD_FOLD in the environment overrides both
+  a->fold_mode    = o->grad_fold < 0.0f ? -1 : (o->grad_fold > 0.5f ? 1 : 0);
 }
 
 // owner side: sort received ids, then the fused duplicate-sum + optimizer kernel
@@ -511,6 +517,7 @@ wholememory_error_code_t wholememory_create_embedding_optimizer(wholememory_embe
   auto* o = new wholememory_embedding_optimizer_();
   o->type = optimizer_type;
   o->params["weight_decay"] = &o->weight_decay;
+  o->params["grad_fold"]    = &o->grad_fold;
   switch (optimizer_type) {
     case WHOLEMEMORY_OPT_SGD: o->state_names = {nullptr}; break;
     case WHOLEMEMORY_OPT_LAZY_ADAM:

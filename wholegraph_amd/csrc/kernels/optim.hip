@@ -701,6 +701,22 @@ __device__ __forceinline__ uint32_t tile_bcast32(uint32_t v, int e0, int sub)
   }
   return __shfl(v, e0 + sub, 64);
 }
+// base pointer of run e0 + sub for this lane: RPS == 1: v_readlane (wave-uniform, SGPRs); else one ds_bpermute per half
+// (2 LDS-crossbar instructions per pointer instead of the 4 v_readlane + 4 v_mov + 2 v_cndmask of tile_bcast_ptr<2>)
+template <int RPS, typename P>
+__device__ __forceinline__ P* tile_lane_ptr(P* p, int e0, int sub)
+{
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  uint32_t lo, hi;
+  if (RPS == 1) {
+    lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), e0);
+    hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(v >> 32), e0);
+  } else {
+    lo = __builtin_amdgcn_ds_bpermute(4 * (e0 + sub), static_cast<uint32_t>(v));
+    hi = __builtin_amdgcn_ds_bpermute(4 * (e0 + sub), static_cast<uint32_t>(v >> 32));
+  }
+  return reinterpret_cast<P*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
 template <int RPS, typename P>
 __device__ __forceinline__ P* tile_bcast_ptr(P* p, int e0, int sub)
 {
@@ -715,6 +731,9 @@ __device__ __forceinline__ P* tile_bcast_ptr(P* p, int e0, int sub)
 #endif
 #ifndef WM_TILE_KU_STATE
 #define WM_TILE_KU_STATE 2
+#endif
+#ifndef WM_TILE_DUP
+#define WM_TILE_DUP 2
 #endif
 // 16 bytes per lane, KU = steps in flight (0: the default for the optimizer). Swept on the 10 M-row SGD / LazyAdam call
 // (profiles/r02_tile_sweep.txt): 16 B x 4 steps (SGD) and 16 B x 2 (stateful) are the defaults; 8 B per lane (a 512-byte row
@@ -772,6 +791,7 @@ void step_tile_kernel(opt_params p)
   constexpr int kLpr         = 64 / RPS;
   constexpr bool kState      = OPT != WHOLEMEMORY_OPT_SGD;
   constexpr bool kAdam       = OPT == WHOLEMEMORY_OPT_LAZY_ADAM;
+  constexpr int kDup         = WM_TILE_DUP;   // later occurrences of a duplicated id prefetched at a time
   static_assert(!k16 || OPT == WHOLEMEMORY_OPT_SGD, "16-bit tables are trained with SGD only");
   const wm_optimizer_args& a = p.a;
   const int lane             = threadIdx.x & 63;
@@ -813,80 +833,76 @@ void step_tile_kernel(opt_params p)
         a.per_row_state[local * 2 + 1] = my_b2;
       }
     }
-    for (int cbase = 0; cbase < row_vecs; cbase += kLpr) {  // > 1 trip only when a row has more pieces than a wave step covers
-      const int c        = cbase + col;
-      const bool col_ok  = c < row_vecs;
-      const int64_t coff = static_cast<int64_t>(c) * kVE;
+    // Every run of the tile is this kernel's (none left to the long-run side, none past the end): the FAST PATH — a batch
+    // of kU steps is straight-line code, 2 kU unconditional row loads (gradient + table) issued back to back, then the
+    // arithmetic, then the stores, nothing predicated. Lanes past the end of a row repeat its last piece: same loads, same
+    // result, same store as the lane that owns it. (Round 3 loaded under `if (ln[k] > 0)`: a conditionally defined
+    // register per load, and hipcc waited for each load before issuing the next.) Duplicates (run length > 1) are folded
+    // behind a wave-uniform test per step.
+    const bool whole = __ballot(lane < tile_runs && my_len <= 0) == 0;
+    for (int cbase = 0; cbase < row_vecs && whole; cbase += kLpr) {
+      const int64_t coff = static_cast<int64_t>(min(cbase + col, row_vecs - 1)) * kVE;
 #pragma unroll 1
       for (int s = 0; s < tile_runs; s += RPS * kU) {
-        tile_vals<kVE> acc[kU];
-        tile_raw4 ev[kU], s0v[kU], s1v[kU];
+        tile_raw4 gv[kU], ev[kU], s0v[kU], s1v[kU];
         T* trow[kU];
         float* srow[kU];
-        int32_t ln[kU], rs[kU];
-        float b1[kU], b2[kU];
 #pragma unroll
         for (int k = 0; k < kU; k++) {
           const int e0 = s + RPS * k;
-          const T* g   = tile_bcast_ptr<RPS>(my_grad, e0, sub);
-          trow[k]      = tile_bcast_ptr<RPS>(my_row, e0, sub);
-          if (kState) srow[k] = tile_bcast_ptr<RPS>(my_st, e0, sub);
-          ln[k]        = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_len), e0, sub));
-          rs[k]        = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_s0), e0, sub));
-          if (kAdam) {
-            b1[k] = __builtin_bit_cast(float, tile_bcast32<RPS>(__builtin_bit_cast(uint32_t, my_b1), e0, sub));
-            b2[k] = __builtin_bit_cast(float, tile_bcast32<RPS>(__builtin_bit_cast(uint32_t, my_b2), e0, sub));
-          }
-          if (!col_ok) ln[k] = 0;
-          if (ln[k] > 0) {
-            // first occurrence copied (DedupIndiceAndGradientsKernel); the table / state pieces are loaded alongside
-            acc[k] = tile_unpack<T>(ld_global_nt<tile_raw4>(g + coff));
-            ev[k] = ld_global_nt<tile_raw4>(trow[k] + coff);
-            if (kState) s0v[k] = ld_global<tile_raw4>(srow[k] + coff);
-            if (kAdam) s1v[k] = ld_global<tile_raw4>(srow[k] + a.table_stride + coff);
-          }
+          const T* g   = tile_lane_ptr<RPS>(my_grad, e0, sub);
+          trow[k]      = tile_lane_ptr<RPS>(my_row, e0, sub);
+          if (kState) srow[k] = tile_lane_ptr<RPS>(my_st, e0, sub);
+          gv[k]        = ld_global_nt<tile_raw4>(g + coff);
+          ev[k]        = ld_global_nt<tile_raw4>(trow[k] + coff);
+          if (kState) s0v[k] = ld_global<tile_raw4>(srow[k] + coff);
+          if (kAdam) s1v[k] = ld_global<tile_raw4>(srow[k] + a.table_stride + coff);
         }
 #pragma unroll
         for (int k = 0; k < kU; k++) {
+          tile_vals<kVE> acc = tile_unpack<T>(gv[k]);   // first occurrence copied (DedupIndiceAndGradientsKernel)
           // longest run of this step's RPS rows, wave-uniform (the rows of a step differ only by `sub`)
           int32_t longest = 0;
 #pragma unroll
           for (int r = 0; r < RPS; r++) longest = max(longest, static_cast<int32_t>(__builtin_amdgcn_readlane(my_len, s + RPS * k + r)));
-          // later occurrences added in receive order, 4 rows prefetched at a time (index clamped into the run)
-          for (int32_t j = 1; j < longest; j += 4) {
-            tile_raw4 gq[4];
+          if (longest > 1) {
+            // later occurrences added in receive order, 4 rows prefetched at a time (index clamped into the run)
+            const int32_t ln = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_len), s + RPS * k, sub));
+            const int32_t rs = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_s0), s + RPS * k, sub));
+            for (int32_t j = 1; j < longest; j += kDup) {
+              tile_raw4 gq[kDup];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-              if (j + q < ln[k]) {
-                const int32_t o = a.order[rs[k] + j + q];
+              for (int q = 0; q < kDup; q++) {
+                const int32_t o = a.order[rs + min(j + q, ln - 1)];
                 gq[q]           = ld_global_nt<tile_raw4>(grad_row<T>(a, o) + coff);
               }
-            }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-              if (j + q < ln[k]) {
-                const tile_vals<kVE> gv = tile_unpack<T>(gq[q]);
+              for (int q = 0; q < kDup; q++) {
+                if (j + q < ln) {
+                  const tile_vals<kVE> gx = tile_unpack<T>(gq[q]);
 #pragma unroll
-                for (int v = 0; v < kVE; v++) acc[k].v[v] += gv.v[v];
+                  for (int v = 0; v < kVE; v++) acc.v[v] += gx.v[v];
+                }
               }
             }
           }
-        }
-#pragma unroll
-        for (int k = 0; k < kU; k++) {
-          if (ln[k] <= 0) continue;
           const tile_vals<kVE> e_in = tile_unpack<T>(ev[k]);
           tile_vals<4> s0_in{}, s1_in{}, so0{}, so1{};
           tile_vals<kVE> eo;
           if (kState) s0_in = tile_unpack<float>(s0v[k]);
           if (kAdam) s1_in = tile_unpack<float>(s1v[k]);
+          float b1 = 0.f, b2 = 0.f;
+          if (kAdam) {
+            b1 = __builtin_bit_cast(float, tile_bcast32<RPS>(__builtin_bit_cast(uint32_t, my_b1), s + RPS * k, sub));
+            b2 = __builtin_bit_cast(float, tile_bcast32<RPS>(__builtin_bit_cast(uint32_t, my_b2), s + RPS * k, sub));
+          }
 #pragma unroll
           for (int v = 0; v < kVE; v++) {
             opt_elem x;
             x.e  = e_in.v[v];
             x.s0 = kState ? s0_in.v[v & 3] : 0.f;
             x.s1 = kAdam ? s1_in.v[v & 3] : 0.f;
-            opt_math<OPT>(a, x, acc[k].v[v], kAdam ? b1[k] : 0.f, kAdam ? b2[k] : 0.f);
+            opt_math<OPT>(a, x, acc.v[v], b1, b2);
             eo.v[v] = x.e;
             if (kState) so0.v[v & 3] = x.s0;
             if (kAdam) so1.v[v & 3] = x.s1;
@@ -895,6 +911,57 @@ void step_tile_kernel(opt_params p)
           if (kAdam) st_global<tile_raw4>(srow[k] + a.table_stride + coff, tile_pack<float>(so1));
           st_global_nt<tile_raw4>(trow[k] + coff, tile_pack<T>(eo));
         }
+      }
+    }
+    // a tile with a run that is not this kernel's (left to the long-run side, or past the end): RPS runs at a time, predicated —
+    // rare (the last tile; under skew the tiles that hold a hot id), kept small so that it does not set the register budget
+    for (int cbase = 0; cbase < row_vecs && !whole; cbase += kLpr) {  // > 1 trip only when a row has more pieces than a wave step covers
+      const int c        = cbase + col;
+      const int64_t coff = static_cast<int64_t>(min(c, row_vecs - 1)) * kVE;
+#pragma unroll 1
+      for (int s = 0; s < tile_runs; s += RPS) {
+        // (the broadcasts need every lane: outside the guard)
+        const T* g       = tile_lane_ptr<RPS>(my_grad, s, sub);
+        T* trow          = tile_lane_ptr<RPS>(my_row, s, sub);
+        float* srow      = kState ? tile_lane_ptr<RPS>(my_st, s, sub) : nullptr;
+        const int32_t rs = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_s0), s, sub));
+        int32_t ln       = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_len), s, sub));
+        float b1 = 0.f, b2 = 0.f;
+        if (kAdam) {
+          b1 = __builtin_bit_cast(float, tile_bcast32<RPS>(__builtin_bit_cast(uint32_t, my_b1), s, sub));
+          b2 = __builtin_bit_cast(float, tile_bcast32<RPS>(__builtin_bit_cast(uint32_t, my_b2), s, sub));
+        }
+        if (c >= row_vecs) ln = 0;
+        if (ln <= 0) continue;
+        tile_vals<kVE> acc = tile_unpack<T>(ld_global_nt<tile_raw4>(g + coff));   // first occurrence copied
+        const tile_raw4 ev = ld_global_nt<tile_raw4>(trow + coff);
+        tile_raw4 s0v{}, s1v{};
+        if (kState) s0v = ld_global<tile_raw4>(srow + coff);
+        if (kAdam) s1v = ld_global<tile_raw4>(srow + a.table_stride + coff);
+        for (int32_t j = 1; j < ln; j++) {   // later occurrences added in receive order
+          const tile_vals<kVE> gx = tile_unpack<T>(ld_global_nt<tile_raw4>(grad_row<T>(a, a.order[rs + j]) + coff));
+#pragma unroll
+          for (int v = 0; v < kVE; v++) acc.v[v] += gx.v[v];
+        }
+        const tile_vals<kVE> e_in = tile_unpack<T>(ev);
+        tile_vals<4> s0_in{}, s1_in{}, so0{}, so1{};
+        tile_vals<kVE> eo;
+        if (kState) s0_in = tile_unpack<float>(s0v);
+        if (kAdam) s1_in = tile_unpack<float>(s1v);
+#pragma unroll
+        for (int v = 0; v < kVE; v++) {
+          opt_elem x;
+          x.e  = e_in.v[v];
+          x.s0 = kState ? s0_in.v[v & 3] : 0.f;
+          x.s1 = kAdam ? s1_in.v[v & 3] : 0.f;
+          opt_math<OPT>(a, x, acc.v[v], b1, b2);
+          eo.v[v] = x.e;
+          if (kState) so0.v[v & 3] = x.s0;
+          if (kAdam) so1.v[v & 3] = x.s1;
+        }
+        if (kState) st_global<tile_raw4>(srow + coff, tile_pack<float>(so0));
+        if (kAdam) st_global<tile_raw4>(srow + a.table_stride + coff, tile_pack<float>(so1));
+        st_global_nt<tile_raw4>(trow + coff, tile_pack<T>(eo));
       }
     }
   }
@@ -1520,7 +1587,8 @@ template <typename IdxT, int OPT, typename T>
 void launch_tree(const opt_params& p, hipStream_t stream, hipStream_t lstream)
 {
   const tree_ws_view w = tree_ws_carve(p.a.long_run_ws, p.a.count, p.long_threshold);
-  const int mblocks    = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, INT64_C(1) << 22));
+  // one run per thread, no grid-stride loop: the grid must cover every run (callers keep count below 2^31 -> at most 2^23 blocks)
+  const int mblocks    = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, INT64_C(1) << 23));
   hipLaunchKernelGGL((tree_mark_kernel<IdxT>), dim3(std::max(mblocks, 1)), dim3(256), 0, lstream, p, w, p.long_threshold);
   if (lstream != stream) {
     (void)hipEventRecord(long_lane::get().marked, lstream);
@@ -1609,18 +1677,10 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
     opt_params tp = p;
     int tblocks   = 1;
     tile_launch_shape(p.a.count, vecs, OPT == WHOLEMEMORY_OPT_SGD ? WM_TILE_KU_SGD : WM_TILE_KU_STATE, &tp.tile_runs, &tblocks);
-    // SGD on 512-byte fp32 rows (two runs per wave instruction), uncached: the same kernel compiled for 7 waves / SIMD — a
-    // 72-register budget, 10 values spilled to scratch — instead of the 5 its natural 84 registers allow: whole call 3.05 ->
-    // 2.99 ms per 10 M rows (experiments/occ_ab.py, interleaved in one process). The other row widths lose with it (dim 32:
-    // +7 %, 64: +2 %, 256: +0.5-1 %; 6 waves lose everywhere) and keep their natural budget. WM_TILE_OCC=5 switches it off.
-    if constexpr (OPT == WHOLEMEMORY_OPT_SGD) {
-      const char* occ_env = WM_KNOB("WM_TILE_OCC");
-      const bool natural  = occ_env != nullptr && atoi(occ_env) == 5;
-      if (!cached && !natural && vecs > 16 && vecs <= 32) {
-        hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, 2, false, float, 0, 7>), dim3(tblocks), dim3(kBlock), 0, stream, tp);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
-      }
-    }
+    // (Round 3 ran SGD on 512-byte rows through a copy of the kernel forced to 7 waves / SIMD, 10 values spilled to scratch:
+    // its loads were serialised and occupancy was the only source of loads in flight. With the straight-line batches the
+    // natural register budget — 84 VGPRs, 5 waves, no scratch — is the faster one: 2.92 vs 2.98 ms per 10 M rows,
+    // profiles/r04_grad_apply_ab_occupancy_launch_shape.txt; the forced build is gone and with it the 1.12 x write traffic.)
 #define WM_TILE(RPS)                                                                                                    \
   do {                                                                                                                  \
     if (cached)                                                                                                         \

@@ -182,6 +182,9 @@ __device__ __forceinline__ void load_tile_entry(const rows_params& p, int64_t en
       pl          = p.plain + row * p.plain_stride_bytes;
     }
   }
+  // both bases are complete HERE (the waits for the index / row-map loads sit in front of the tile's batches, not between
+  // the row loads of its first batch, where hipcc otherwise lets a late use of the row map drag them)
+  asm volatile("" : "+v"(tab), "+v"(pl));
 }
 
 __device__ __forceinline__ char* shfl_ptr(char* p, int src_lane)
@@ -1187,12 +1190,14 @@ int rows_op(const wm_rows_args* a, void* stream_v)
   // launch where it is still used. The LDS-staged kernels run in order, one chunk per wave (measured twice on different
   // boxes, profiles/r03_dim_sweep_staged_scatter.csv: gather +6 ... +10 points, scatter +2 ... +3.5 over the persistent grid).
   const int inorder_mode = inorder_setting();
-  bool inorder           = a->max_blocks <= 0 && inorder_mode != 0;
+  // (a batch of 2^31 entries or more could need more workgroups than a grid has: the persistent launch loops)
+  bool inorder           = a->max_blocks <= 0 && inorder_mode != 0 && a->n < (INT64_C(1) << 31);
   p.launch_threads       = inorder ? inorder_block_threads() : kBlock;
   p.tile_rows            = kWave;
   auto grid_for = [&](int tile_rows) {
     const int64_t tiles = (a->n + tile_rows - 1) / tile_rows;
     const int wpb       = p.launch_threads / kWave;
+    // in order = one tile per wave, no loop in the kernel (n < 2^31 there, so the grid always covers the tiles)
     if (inorder) return static_cast<int>(std::min<int64_t>((tiles + wpb - 1) / wpb, INT64_C(0x7fffffff)));
     int b = static_cast<int>(std::min<int64_t>((tiles + wpb - 1) / wpb, default_max_blocks()));
     if (a->max_blocks > 0) b = std::min(b, a->max_blocks);
@@ -1245,7 +1250,7 @@ int rows_op(const wm_rows_args* a, void* stream_v)
       while (R > need && static_cast<int64_t>(R) * row_bytes > cap) R >>= 1;
       if (static_cast<int64_t>(R) * row_bytes <= cap) {   // bigger rows stay on the flat kernel
         p.stage_rows = R;
-        if (inorder_mode == 0 || a->max_blocks > 0) {
+        if (inorder_mode == 0 || a->max_blocks > 0 || a->n >= (INT64_C(1) << 31)) {
           inorder          = false;
           p.launch_threads = kBlock;
         } else {          // in order: one chunk per wave (the flat branch above may have switched it off for the scatter)

@@ -319,11 +319,16 @@ class WholeMemoryEmbeddingModule(torch.nn.Module):
 
 def create_wholememory_optimizer(embeddings, optimizer_type: str, param_dict: dict):
     """One sparse optimizer ("sgd" | "adam" | "adagrad" | "rmsprop") for an embedding or a list of them; param_dict holds the
-    hyper-parameters by the reference's names (weight_decay, epsilon, beta1, beta2, alpha, adam_w)."""
+    hyper-parameters by the reference's names (weight_decay, epsilon, beta1, beta2, alpha, adam_w). One extension:
+    "grad_fold": "ordered" | "tree" | "default" — the order in which the fp32 sum of a run of duplicate gradient rows is taken
+    ("ordered" = the reference's receive order, bit-identical results, the default for fp32 tables; "tree" = fixed-shape
+    partial sums, deterministic, equal within rounding and much faster when a few ids carry most of the batch)."""
     optimizer = WholeMemoryOptimizer(get_global_communicator())
     kind = str_to_wmb_wholememory_optimizer_type(optimizer_type)
     wmb.check(wmb.lib().wholememory_create_embedding_optimizer(C.byref(optimizer.wmb_opt), kind))
     for name, value in (param_dict or {}).items():
+        if name == "grad_fold" and isinstance(value, str):
+            value = {"default": -1.0, "ordered": 0.0, "tree": 1.0}[value]
         boxed = C.c_float(float(value))
         wmb.check(wmb.lib().wholememory_optimizer_set_parameter(optimizer.wmb_opt, name.encode(), C.byref(boxed)))
     targets = [embeddings] if isinstance(embeddings, WholeMemoryEmbedding) else list(embeddings)
