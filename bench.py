@@ -221,6 +221,51 @@ def gpu_c1_host(wgth, comm):
             "workload": "C1 HOST chunked 10000000x64 fp32 table in pinned host memory, 1000000 uniform int64 ids, output in HBM"}
 
 
+def gpu_c1_host_cached(wgth, comm, ratio=0.1):
+    """config C1 with the device row cache (reference embedding.cpp:564-892): the same HOST-located
+    10 M x 64 fp32 table behind a `local_device` cache of `ratio` of its rows (1 M rows = 256 MB of HBM), gathers of 1 M int64
+    ids with cache adjustment on — steady state after a warm-up, for uniform ids (a 10 % cache serves ~10 % of them: the cache
+    cannot help, and its bookkeeping is in the time) and for Zipf(1.05) ids (the hot rows live in HBM). Same GB/s convention
+    as gpu_c1_host and cpu_baseline.c1_shape."""
+    rows, dim, n = 10_000_000, 64, 1_000_000
+    policy = wgth.create_builtin_cache_policy("local_device", "chunked", "cpu", "readonly", ratio)
+    emb = wgth.create_embedding(comm, "chunked", "cpu", torch.float32, [rows, dim], cache_policy=policy)
+    local, _ = emb.get_embedding_tensor().get_local_tensor(host_view=True)
+    local[:] = (torch.arange(rows, dtype=torch.int64) & 0xFFFFFF).to(torch.float32).unsqueeze(1)
+    out = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    res = {"cache_rows": int(rows * ratio), "cache_ratio": ratio,
+           "workload": "C1 HOST chunked 10000000x64 fp32 table in pinned host memory behind a local_device row cache, 1000000 int64 "
+                       "ids per gather, cache adjusted on every gather, output in HBM"}
+    from wholegraph_amd import binding as _wmb
+    import ctypes
+    for dist in ("uniform", "zipf"):
+        rng = np.random.default_rng(43)
+        # a fresh batch per step (a cache that sees the same batch again and again is not a measurement)
+        batches = [torch.from_numpy(make_indices(n, rows, dist, 100 + k)).cuda() for k in range(8)]
+        for k in range(16):    # warm-up: the cache fills and settles
+            emb.gather(batches[k % 8], out=out)
+        torch.cuda.synchronize()
+        assert torch.equal(out[:, 0], (batches[7] & 0xFFFFFF).to(torch.float32))
+        info0 = [ctypes.c_int64(0) for _ in range(5)]
+        _wmb.check(_wmb.lib().wholememory_ext_embedding_cache_info(emb.wmb_embedding, *[ctypes.byref(x) for x in info0]))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(16):
+            emb.gather(batches[k % 8], out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 16
+        info1 = [ctypes.c_int64(0) for _ in range(5)]
+        _wmb.check(_wmb.lib().wholememory_ext_embedding_cache_info(emb.wmb_embedding, *[ctypes.byref(x) for x in info1]))
+        hits, lookups = info1[3].value - info0[3].value, info1[4].value - info0[4].value
+        res[dist] = {"ms_per_gather": round(ms, 4), "value": round(n * dim * 4 / (ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                     "mlookups_per_s": round(n / (ms * 1e-3) / 1e6, 1),
+                     "hit_rate": round(hits / max(lookups, 1), 4)}
+        del rng
+    wgth.destroy_embedding(emb)
+    return res
+
+
 def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
     """BASELINE config 5 on synthetic data of the ogbn-papers100M shape: CSR (int64 row_ptr, int32 col) and a [nodes, 128] fp32
     feature table in WholeMemory (CHUNKED on one GPU, DISTRIBUTED over several); one step = unweighted 2-hop sample from
@@ -519,9 +564,10 @@ def main():
                                                                  ctypes.byref(ms)))
                 vals.append(round(ms.value, 4))
             table_probe = {"read_ms_per_GiB": vals[0], "read_write_back_ms_per_GiB": vals[1],
-                           "malloc_candidates": os.environ.get("WM_MALLOC_PROBE", "auto (up to 6 within half of the free memory, stops at a well placed one)"),
-                           "note": "random-row probe of the table's allocation; a write-side value near 0.36 is a well placed "
-                                   "table, 0.41-0.43 a badly placed one (scatter / gradient apply up to 20 % slower)"}
+                           "malloc_candidates": os.environ.get("WM_MALLOC_PROBE", "off (one plain allocation, the library's default since round 4; WM_MALLOC_PROBE=auto opts in)"),
+                           "note": "random-row probe of the table's allocation; a write-side value near 0.36 serves random row WRITES "
+                                   "(scatter / gradient apply) best, 0.41-0.43 up to 20 % slower; the gather's random READS do "
+                                   "not follow it (profiles/r04_six_fresh_processes_probe_off_vs_default.txt)"}
             del shard
         except Exception as e:   # a probe that fails must not take the bench line with it
             table_probe = {"error": str(e)[:200]}
@@ -723,6 +769,7 @@ def main():
             if not a.no_cpu_baseline:
                 res["cpu_baseline"] = guarded("cpu_baseline", lambda: cpu_baseline(a.dim, a.cpu_seconds))
                 res["gpu_c1_host"] = guarded("gpu_c1_host", lambda: gpu_c1_host(wgth, comm))
+                res["gpu_c1_host_cached"] = guarded("gpu_c1_host_cached", lambda: gpu_c1_host_cached(wgth, comm))
         if world == 1 and a.op == "scatter":
             achieved = a.indices * algo_bytes / (dev_ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",

@@ -181,8 +181,10 @@ enum wholememory_error_code_t wholememory_ext_reload_knobs(void);
 /* Placement probe: milliseconds per GiB of pseudo-random 512-byte rows of [ptr, ptr + bytes) touched by a fixed kernel
  * (kind 0 = zeros written: destroys the contents, 1 = read, 2 = read and written back), averaged over `reps` launches after a
  * warm-up; blocks until done. The level the memory system serves random row accesses at depends on where a large allocation
- * sits in HBM and stays with it for its lifetime; WM_MALLOC_PROBE=K makes wholememory_malloc pick the
- * best of K candidate allocations with this probe (off by default: the candidates are alive together). */
+ * sits in HBM and stays with it for its lifetime. wholememory_malloc makes ONE allocation per device
+ * shard, like the reference; WM_MALLOC_PROBE=auto (self-calibrating: candidates are added until two agree with the best seen
+ * within 3 %) or =K (exactly K candidates) opts into choosing the shard with this probe — the candidates are alive together,
+ * capped at a quarter of the free memory, one prober per device at a time. */
 enum wholememory_error_code_t wholememory_ext_probe_memory(void* ptr, size_t bytes, int kind, int reps, float* ms_per_gib);
 
 /* Number of wholememory_gather calls of this process that took the sorted-ids route of HOST-located tables (rows of at most

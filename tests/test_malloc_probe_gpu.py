@@ -1,6 +1,6 @@
 """Placement probe (csrc/kernels/probe.hip) and the candidate choice in wholememory_malloc (csrc/memory_handle.cpp:alloc_local;
-automatic by default, WM_MALLOC_PROBE=K forces K candidates, =1 switches it off): the best of the probed candidate allocations
-is kept for a device shard; the table it backs must behave like any other (gather / scatter parity
+OPT-IN since round 4: WM_MALLOC_PROBE=auto is the self-calibrating search, =K forces K candidates, unset / 1 = one plain
+allocation like the reference): the best of the probed candidate allocations is kept for a device shard; the table it backs must behave like any other (gather / scatter parity
 with the closed form of the reference's own tests, wholememory_gather_tests.cu:288-528), and the probe itself must report a
 positive time for every kind without touching memory outside [ptr, ptr + bytes)."""
 import ctypes
@@ -47,22 +47,45 @@ def test_malloc_probe_keeps_a_working_table(wm_lib):
         assert float(l.split(":")[-1].split()[0]) > 0
 
 
-@pytest.mark.parametrize("good,expected", [("1e-9", 6), ("1000", 1)])
-def test_automatic_probe_stops_at_a_well_placed_candidate(wm_lib, good, expected):
-    """WM_MALLOC_PROBE unset = automatic: up to 6 candidates while half of the free memory holds them, none beyond the first
-    one that probes at or under WM_MALLOC_PROBE_GOOD."""
-    env = dict(os.environ, WM_MALLOC_PROBE_MIN_BYTES=str(1 << 20), WM_MALLOC_PROBE_VERBOSE="1", WM_MALLOC_PROBE_GOOD=good)
-    env.pop("WM_MALLOC_PROBE", None)
+@pytest.mark.parametrize("rel,lo,hi", [("1000", 2, 2), ("1e-9", 2, 4)])
+def test_auto_probe_stops_when_two_candidates_agree(wm_lib, rel, lo, hi):
+    """WM_MALLOC_PROBE=auto: candidates are added until two of them are within WM_MALLOC_PROBE_REL of the best seen (a huge
+    tolerance: the second one always agrees; a tiny one: the search runs to its cap of 4) — no absolute threshold."""
+    env = dict(os.environ, WM_MALLOC_PROBE="auto", WM_MALLOC_PROBE_MIN_BYTES=str(1 << 20), WM_MALLOC_PROBE_VERBOSE="1",
+               WM_MALLOC_PROBE_REL=rel)
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK 0" in r.stdout
     lines = [l for l in r.stderr.splitlines() if "malloc probe: candidate" in l]
-    assert len(lines) == expected, r.stderr
+    assert lo <= len(lines) <= hi, r.stderr
+
+
+def test_default_is_one_plain_allocation(wm_lib):
+    """no WM_MALLOC_PROBE in the environment: the reference's behaviour, one allocation, no probe"""
+    env = dict(os.environ, WM_MALLOC_PROBE_MIN_BYTES=str(1 << 20), WM_MALLOC_PROBE_VERBOSE="1")
+    env.pop("WM_MALLOC_PROBE", None)
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK 0" in r.stdout, r.stdout + r.stderr
+    assert "malloc probe: candidate" not in r.stderr
+
+
+def test_three_processes_probe_one_device_at_once(wm_lib):
+    """three processes allocate probed tables on the same GPU at the same time: the per-device file lock makes them probe one
+    after the other, none runs the others (or itself) out of memory, every table works"""
+    rows = (2 << 30) // 256      # 2 GiB shards
+    env = dict(os.environ, WM_MALLOC_PROBE="auto", WM_MALLOC_PROBE_VERBOSE="1", PROBE_TEST_ROWS=str(rows))
+    procs = [subprocess.Popen([sys.executable, "-c", CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(3)]
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0 and "OK 0" in out, out + err
+        assert len([l for l in err.splitlines() if "malloc probe: candidate" in l]) >= 2, err
 
 
 def test_candidates_that_do_not_fit_end_the_search_quietly(wm_lib):
-    """WM_MALLOC_PROBE=8 on a 70 GB shard: the fifth candidate cannot be allocated on a 288 GB device — the search ends there,
-    the best of the ones that fitted is kept, and the failed hipMalloc leaves no error behind for the ops that follow."""
+    """WM_MALLOC_PROBE=8 on a 70 GB shard: the losers alive together are capped at a quarter of the memory that is free after
+    the first allocation (or an allocation fails first) — the search ends there, the best of the candidates tried is kept,
+    and nothing is left behind for the ops that follow."""
     free_b, _ = torch.cuda.mem_get_info()
     rows = 70 * (1 << 30) // (64 * 4)
     if free_b < 3 * rows * 256:
@@ -72,7 +95,7 @@ def test_candidates_that_do_not_fit_end_the_search_quietly(wm_lib):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK 0" in r.stdout
     lines = [l for l in r.stderr.splitlines() if "malloc probe: candidate" in l]
-    assert 2 <= len(lines) < 8, r.stderr
+    assert 1 <= len(lines) < 8, r.stderr
 
 
 def test_probe_switched_off(wm_lib):

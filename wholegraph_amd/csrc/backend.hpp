@@ -307,6 +307,8 @@ struct wm_device_backend {
                   void* sorted_ids, int64_t* raw, void* workspace, void* stream);
   // free / total bytes of the current device's memory right now. nullptr in a backend that does not provide it.
   int (*mem_info)(size_t* free_bytes, size_t* total_bytes);
+  // ordinal of the device the calling thread works on (per-device locks). nullptr in a backend that does not provide it.
+  int (*get_device)(int* device);
 };
 
 }  // extern "C"

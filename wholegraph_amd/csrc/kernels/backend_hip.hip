@@ -142,6 +142,7 @@ int h_host_register(void* host_ptr, size_t bytes, void** dev_ptr)
 }
 int h_host_unregister(void* host_ptr) { return rc(hipHostUnregister(host_ptr)); }
 int h_mem_info(size_t* free_bytes, size_t* total_bytes) { return rc(hipMemGetInfo(free_bytes, total_bytes)); }
+int h_get_device(int* device) { return rc(hipGetDevice(device)); }
 
 const wm_device_backend kHipBackend = {
   "hip-gfx950",
@@ -200,6 +201,7 @@ const wm_device_backend kHipBackend = {
   hip_sort_ids_workspace_bytes,
   hip_sort_ids,
   h_mem_info,
+  h_get_device,
 };
 
 }  // namespace

@@ -17,6 +17,7 @@
 //    a dmabuf fd, fds are passed over AF_UNIX sockets, and every rank maps all runs into one reserved VA
 //    range (memory_vmm.cpp).
 #include <fcntl.h>
+#include <sys/file.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -133,52 +134,84 @@ void alloc_local(wholememory_handle_* h)
     WM_BK(bk->malloc_pinned(&h->local_ptr, h->local_alloc));
     return;
   }
-  // Placement probe. The level the memory system serves random row WRITES at (scatter, gradient
-  // apply) depends on where a big allocation sits in HBM — by up to 20 %, for the allocation's lifetime — so a device shard of
-  // at least WM_MALLOC_PROBE_MIN_BYTES (default 1 GiB) is chosen among up to K candidate allocations: each is timed with the
-  // probe (kernels/probe.hip: pseudo-random 512-byte row writes, a few ms), the fastest is kept, the others are released.
-  // The candidates have to be alive together (an allocation that is freed comes back at the same place).
-  //   WM_MALLOC_PROBE unset  automatic: up to 6 candidates, as many as fit in HALF of the memory that is free after the first
-  //                          one (a 51 GB table on an empty 288 GB device: 3; an 8 GB table: 6 — the first 24-40 GB a fresh
-  //                          process allocates tend to be the badly placed ones, profiles/r03_autoprobe_small_tables.txt),
-  //                          and none at all when the first one already probes as well placed (WM_MALLOC_PROBE_GOOD,
-  //                          default 0.166 ms per GiB: well placed tables probe at 0.160-0.165, badly placed ones at 0.17-0.21)
-  //   WM_MALLOC_PROBE=1      off: the first allocation is the shard
-  //   WM_MALLOC_PROBE=K      exactly K candidates (2 ... 8), whatever the first one looks like
+  // Placement probe — OPT-IN since round 4 (the reference makes one allocation; so does this library
+  // unless asked). The level the memory system serves random row WRITES at (scatter, gradient apply) depends on where a big
+  // allocation sits in HBM — by up to 20 %, for the allocation's lifetime — so a device shard of at least
+  // WM_MALLOC_PROBE_MIN_BYTES (default 1 GiB) can be chosen among several candidate allocations: each is timed with the probe
+  // (kernels/probe.hip: pseudo-random 512-byte row writes, a few ms), the fastest is kept, the others are released. The
+  // candidates have to be alive together (an allocation that is freed comes back at the same place).
+  //   WM_MALLOC_PROBE unset / 0 / 1   off: the first allocation is the shard
+  //   WM_MALLOC_PROBE=auto            self-calibrating: candidates are added until TWO of them agree with the best seen within
+  //                                   WM_MALLOC_PROBE_REL (default 3 %) — the level this device serves well placed memory at is
+  //                                   learnt from the candidates themselves, no absolute threshold — or 4 have been tried
+  //   WM_MALLOC_PROBE=K (2 ... 8)     exactly K candidates
+  // Bounded: the losers alive at any time never exceed a quarter of the memory that was free after the first allocation, and
+  // the whole section runs under a per-device file lock (ranks or processes sharing a GPU probe one after the other instead of
+  // pushing each other, or torch's allocator, into a transient OOM). Why it is not the default: the placement that serves
+  // random WRITES best is not the one that serves the gather's random READS best (profiles/r04_six_fresh_processes_probe_off_
+  // vs_default.txt: gather 77 % of peak on the first allocation in 5 of 6 processes, 74 % on the probe's choice), and a library
+  // call that transiently holds several shards is a behaviour change against the reference. CONTINUOUS tables of more than
+  // one rank (HIP VMM handles, memory_vmm.cpp) are never probed: a candidate would have to be mapped, probed and unmapped,
+  // and unmapped ranges are exactly what memory_vmm.cpp avoids re-using.
   // A candidate that cannot be allocated ends the search. Every rank decides for its own shard; no collective is involved.
-  const int k_setting = [] {
-    const char* e = WM_KNOB("WM_MALLOC_PROBE");
-    if (e == nullptr || e[0] == '\0') return -1;
-    return std::min(std::max(atoi(e), 1), 8);
-  }();
+  const char* setting = WM_KNOB("WM_MALLOC_PROBE");
+  const bool auto_mode = setting != nullptr && (setting[0] == 'a' || setting[0] == 'A');
+  const int k_fixed    = (setting == nullptr || auto_mode) ? 1 : std::min(std::max(atoi(setting), 1), 8);
   const size_t min_bytes = [] {
     const char* e = WM_KNOB("WM_MALLOC_PROBE_MIN_BYTES");
     return e != nullptr && atoll(e) > 0 ? static_cast<size_t>(atoll(e)) : (static_cast<size_t>(1) << 30);
   }();
-  const float good_ms = [] {
-    const char* e = WM_KNOB("WM_MALLOC_PROBE_GOOD");
-    return e != nullptr && atof(e) > 0 ? static_cast<float>(atof(e)) : 0.166f;
+  const float rel = [] {
+    const char* e = WM_KNOB("WM_MALLOC_PROBE_REL");
+    return e != nullptr && atof(e) > 0 ? static_cast<float>(atof(e)) : 0.03f;
   }();
-  WM_BK(bk->malloc_device(&h->local_ptr, h->local_alloc));
-  if (k_setting == 1 || bk->probe_memory == nullptr || h->local_alloc < min_bytes) return;
-  const bool verbose = WM_KNOB("WM_MALLOC_PROBE_VERBOSE") != nullptr;
-  int k_candidates = k_setting;
-  if (k_setting < 0) {
-    size_t free_b = 0, total_b = 0;
-    if (bk->mem_info == nullptr || bk->mem_info(&free_b, &total_b) != 0) return;
-    k_candidates = 1 + static_cast<int>(std::min<size_t>(5, free_b / 2 / h->local_alloc));
-    if (k_candidates <= 1) return;
+  const bool probing = (auto_mode || k_fixed > 1) && bk->probe_memory != nullptr && h->local_alloc >= min_bytes;
+  if (!probing) {
+    WM_BK(bk->malloc_device(&h->local_ptr, h->local_alloc));
+    return;
   }
+  const bool verbose = WM_KNOB("WM_MALLOC_PROBE_VERBOSE") != nullptr;
+  // one prober per device at a time, across processes
+  int dev_id = 0;
+  if (bk->get_device != nullptr) (void)bk->get_device(&dev_id);
+  char lock_path[64];
+  snprintf(lock_path, sizeof(lock_path), "/tmp/wholegraph_amd_probe_dev%d.lock", dev_id);
+  const int lock_fd = open(lock_path, O_CREAT | O_RDWR, 0666);
+  if (lock_fd >= 0) (void)flock(lock_fd, LOCK_EX);
+  struct unlock {
+    int fd;
+    ~unlock()
+    {
+      if (fd >= 0) {
+        (void)flock(fd, LOCK_UN);
+        close(fd);
+      }
+    }
+  } guard{lock_fd};
+  WM_BK(bk->malloc_device(&h->local_ptr, h->local_alloc));
+  size_t free_b = 0, total_b = 0;
+  if (bk->mem_info == nullptr || bk->mem_info(&free_b, &total_b) != 0) return;
+  const int max_losers = static_cast<int>(std::min<size_t>(7, free_b / 4 / h->local_alloc));   // alive at once
+  if (max_losers < 1) {
+    WM_INFO("wholememory_malloc: placement probe skipped, a second %zu-byte candidate would exceed a quarter of the free memory",
+            h->local_alloc);
+    return;
+  }
+  const int k_candidates = auto_mode ? 4 : k_fixed;
   float best_ms = 0;
   if (bk->probe_memory(h->local_ptr, h->local_alloc, 0, 3, &best_ms, nullptr) != 0) return;
   if (verbose) fprintf(stderr, "[wholegraph_amd] malloc probe: candidate 0 at %p: %.4f ms per GiB\n", h->local_ptr, best_ms);
-  if (k_setting < 0 && best_ms <= good_ms) return;   // well placed as it is
   std::vector<void*> losers;
+  std::vector<float> seen{best_ms};
+  size_t peak_losers = 0;
+  int tried = 1;
   for (int k = 1; k < k_candidates; k++) {
+    if (static_cast<int>(losers.size()) >= max_losers) break;
     void* cand = nullptr;
     if (bk->malloc_device(&cand, h->local_alloc) != 0 || cand == nullptr) break;
     float ms = 0;
     const int prc = bk->probe_memory(cand, h->local_alloc, 0, 3, &ms, nullptr);
+    tried++;
     if (verbose) fprintf(stderr, "[wholegraph_amd] malloc probe: candidate %d at %p: %.4f ms per GiB\n", k, cand, ms);
     if (prc == 0 && ms < best_ms) {
       losers.push_back(h->local_ptr);
@@ -187,11 +220,18 @@ void alloc_local(wholememory_handle_* h)
     } else {
       losers.push_back(cand);
     }
-    if (k_setting < 0 && best_ms <= good_ms) break;
+    if (prc == 0) seen.push_back(ms);
+    peak_losers = std::max(peak_losers, losers.size());
+    if (auto_mode) {   // two candidates at the best level: that IS this device's level
+      int at_best = 0;
+      for (float v : seen) at_best += v <= best_ms * (1.0f + rel) ? 1 : 0;
+      if (at_best >= 2) break;
+    }
   }
   for (void* l : losers) (void)bk->free_device(l);
-  WM_INFO("wholememory_malloc: kept the best of %d probed device allocations of %zu bytes (%.4f ms per GiB of random rows)",
-              static_cast<int>(losers.size()) + 1, h->local_alloc, best_ms);
+  WM_INFO("wholememory_malloc: kept the best of %d probed device allocations of %zu bytes (%.4f ms per GiB of random rows; up to "
+          "%zu bytes of candidates were held while probing)",
+          tried, h->local_alloc, best_ms, peak_losers * h->local_alloc);
 }
 
 void map_chunked_device(wholememory_handle_* h)

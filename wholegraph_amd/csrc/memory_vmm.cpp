@@ -10,6 +10,7 @@
 #include <sys/un.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <random>
@@ -30,6 +31,17 @@ namespace wm {
   } while (0)
 
 namespace {
+
+// Virtual address space that destroyed CONTINUOUS tables keep (see vmm_continuous_destroy): counted, announced, and
+// bounded — a process that would run the 47-bit space low fails with a clear error at table creation instead of with an
+// obscure reservation failure (or worse) later. WM_VMM_VA_BUDGET_TIB moves the limit (default 64 TiB = half of 2^47).
+std::atomic<unsigned long long> g_retired_va_bytes{0};
+unsigned long long va_budget_bytes()
+{
+  const char* e = WM_KNOB("WM_VMM_VA_BUDGET_TIB");
+  const unsigned long long tib = e != nullptr && atoll(e) > 0 ? static_cast<unsigned long long>(atoll(e)) : 64ull;
+  return tib << 40;
+}
 
 std::string sock_name(const char* token, int rank) { return std::string("wgamd_vmm_") + token + "_" + std::to_string(rank); }
 
@@ -101,6 +113,12 @@ void vmm_continuous_create(wholememory_comm_t comm, size_t total_size, vmm_mappi
 
   m->page        = page;
   m->total_alloc = round_up<size_t>(total_size, page);
+  if (g_retired_va_bytes.load() + m->total_alloc > va_budget_bytes())
+    throw logic_error(format_string(
+      "CONTINUOUS tables destroyed by this process keep %.1f TiB of virtual address space (ranges are never handed back: "
+      "stale GPU translations, memory_vmm.cpp); another %.1f GiB would pass the budget of %llu TiB (WM_VMM_VA_BUDGET_TIB). "
+      "Create long-lived tables once, or use CHUNKED / DISTRIBUTED tables for create-destroy cycles",
+      g_retired_va_bytes.load() / 1099511627776.0, m->total_alloc / 1073741824.0, va_budget_bytes() >> 40));
   const size_t n_pages = m->total_alloc / page;
   m->alloc_offsets.resize(W);
   m->alloc_sizes.resize(W);
@@ -214,7 +232,16 @@ void vmm_continuous_destroy(wholememory_comm_t comm, vmm_mapping* m) noexcept
     const char* e = WM_KNOB("WM_VMM_FREE_VA");
     return e != nullptr && e[0] == '1';
   }();
-  if (free_va) (void)hipMemAddressFree(m->base, m->total_alloc);
+  if (free_va) {
+    (void)hipMemAddressFree(m->base, m->total_alloc);
+  } else {
+    const unsigned long long before = g_retired_va_bytes.fetch_add(m->total_alloc);
+    const unsigned long long after  = before + m->total_alloc;
+    // one line per TiB crossed (a test suite that cycles small tables stays silent)
+    if ((after >> 40) != (before >> 40))
+      WM_WARN("destroyed CONTINUOUS tables keep %.1f TiB of virtual address space in this process (budget %llu TiB, "
+              "WM_VMM_VA_BUDGET_TIB); physical memory IS released", after / 1099511627776.0, va_budget_bytes() >> 40);
+  }
   (void)hipDeviceSynchronize();
   m->base = nullptr;
 }
