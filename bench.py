@@ -62,6 +62,9 @@ def parse():
     p.add_argument("--avg-degree", type=int, default=29, help="sample_gather: mean out-degree (papers100M, both directions: 29)")
     p.add_argument("--seeds", type=int, default=1024, help="sample_gather: seed nodes per rank per step")
     p.add_argument("--fanouts", default="30,30", help="sample_gather: fan-out per hop, seeds outwards")
+    p.add_argument("--c5-flow", choices=["deferred", "reference"], default="deferred",
+                   help="sample_gather: deferred = sampling chain and feature gather queued back to back, one host round trip after "
+                        "both (extension); reference = sample, wait for the counts, gather (the reference's call sequence)")
     p.add_argument("--optimizer", default="sgd")
     p.add_argument("--dtype", choices=["f32", "f16", "bf16"], default="f32",
                    help="table dtype (side measurements; the contract metric is f32)")
@@ -296,9 +299,19 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
     seeds = torch.randint(0, nodes, (a.seeds,), device="cuda", generator=gen2, dtype=torch.int32)
     stat = {}
 
+    # --c5-flow deferred (the default): the sampling chain is QUEUED (GraphStructure.multilayer_sample_begin), the feature gather
+    # is queued right behind it on the outermost frontier at its upper-bound size (entries behind the sampled nodes are -1 and
+    # skipped), and the step's one host round trip — reading the counts — comes after both. Same outputs as the reference
+    # flow (sample, wait, size the outputs, gather), which --c5-flow reference runs.
     def step():
-        tg, ei, rp, ci = g.multilayer_sample_without_replacement(seeds, fanouts)
-        x = feat.gather(tg[0])
+        if a.c5_flow == "deferred":
+            h = g.multilayer_sample_begin(seeds, fanouts)
+            xp = feat.gather(h.padded_frontier)
+            tg, ei, rp, ci = h.result()
+            x = xp[:tg[0].numel()]
+        else:
+            tg, ei, rp, ci = g.multilayer_sample_without_replacement(seeds, fanouts)
+            x = feat.gather(tg[0])
         stat["nodes"], stat["edges"] = tg[0].numel(), sum(int(c.numel()) for c in ci)
         stat["frontiers"] = [int(t.numel()) for t in tg]
         return x, tg[0]
@@ -370,10 +383,12 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
         "roofline": {"bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(algo / (ms * 1e-3) / 8e12, 4), "traffic": None,
                      "algorithmic_bytes_per_step": algo,
-                     "limited_by": "dependent-load latency (row_ptr -> col -> features) and launch / host-sync latency: a step is "
-                                   "~%d small launches / copies with one host round trip per hop to size the outputs "
-                                   "(rocprofv3 timeline: experiments/trace_c5.sh), far from the HBM "
-                                   "roofline by construction; larger seed batches move it up (see --seeds)" % (14 * len(fanouts) + 2)},
+                     "limited_by": "dependent-load latency (row_ptr -> col -> hash table -> features): a step is %d kernels back to "
+                                   "back (5 per hop: offsets scan, sampler, table insert, ranking scan, emit; + the feature "
+                                   "gather) and ONE host round trip, which in the deferred flow comes after the gather is "
+                                   "queued (rocprofv3 timeline: experiments/trace_c5.sh); far from the HBM roofline by "
+                                   "construction, larger seed batches move it up (see --seeds)" % (5 * len(fanouts) + 1)},
+        "flow": a.c5_flow,
     }
     if per:
         per = np.array(per)

@@ -210,6 +210,44 @@ def test_chain_with_one_host_round_trip_equals_hop_by_hop(gpu_env, monkeypatch, 
     assert got[0][0].untyped_storage().nbytes() >= ref[0][0].untyped_storage().nbytes()
 
 
+@pytest.mark.parametrize("mt", ["chunked", "distributed"])
+@pytest.mark.parametrize("id_dtype,fanouts", [(np.int32, [30, 30]), (np.int64, [7, 5, 3])])
+def test_deferred_chain_feeds_the_gather_before_the_host_knows_the_counts(gpu_env, mt, id_dtype, fanouts):
+    """GraphStructure.multilayer_sample_begin: the chain is queued, the outermost frontier is handed to the feature gather at
+    its upper-bound size with the entries behind the sampled nodes set to -1 (skipped by the gather), and result() — the one
+    host round trip — returns exactly what multilayer_sample_without_replacement returns with the same seeds. On a
+    DISTRIBUTED CSR the chain does not apply: the handle then holds an eager hop-by-hop sample, same contract."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    n_nodes, dim = 20011, 32
+    row_ptr, col = make_csr(n_nodes, 40, 11, id_dtype, heavy=[(3, 3000), (4, 0), (5, 31)])
+    wrow, wcol = _wm_array(gpu_env, mt, row_ptr), _wm_array(gpu_env, mt, col)
+    g = wgth.GraphStructure()
+    g.set_csr_graph(wrow, wcol)
+    emb = wgth.create_embedding(gpu_env, "chunked", "cuda", torch.float32, [n_nodes, dim])
+    local, _ = emb.get_embedding_tensor().get_local_tensor()
+    local.copy_(torch.arange(n_nodes, device="cuda", dtype=torch.float32).unsqueeze(1) + torch.arange(dim, device="cuda") / 64.0)
+    seeds = torch.from_numpy(np.concatenate([[3, 4, 5], np.random.default_rng(5).permutation(n_nodes)[:300]]).astype(id_dtype)).cuda()
+    hop_seeds = [11 + 3 * i for i in range(len(fanouts))]
+    ref = g.multilayer_sample_without_replacement(seeds, fanouts, random_seeds=hop_seeds)
+    h = g.multilayer_sample_begin(seeds, fanouts, random_seeds=hop_seeds)
+    padded = h.padded_frontier
+    out = torch.full((padded.shape[0], dim), -7.0, device="cuda")
+    emb.gather(padded, out=out)                      # queued behind the sampling kernels, before result()
+    got = h.result()
+    torch.cuda.synchronize()
+    for name, a_list, b_list in zip(("target_gids", "edge_indice", "csr_row_ptr", "csr_col_ind"), got, ref):
+        assert len(a_list) == len(b_list)
+        for layer, (a, b) in enumerate(zip(a_list, b_list)):
+            assert a.dtype == b.dtype and torch.equal(a, b), "%s[%d] differs" % (name, layer)
+    n = got[0][0].shape[0]
+    assert torch.equal(padded[:n], got[0][0]) and bool((padded[n:] == -1).all())
+    assert torch.equal(out[:n], emb.gather(got[0][0])) and bool((out[n:] == -7.0).all())   # rows behind the frontier untouched
+    if mt == "chunked":
+        assert padded.shape[0] > n                   # the chain really handed out its upper-bound array
+    wgth.destroy_embedding(emb)
+
+
 def test_chain_declines_upper_bounds_beyond_the_table_route(gpu_env):
     """65536 seeds x [30, 30, 30]: the third hop's upper bound (63 M centres + 1.9 G samples) is past what append_unique's hash
     table takes from device-side counts: the library answers NOT_SUPPORTED to the query, before any buffer is allocated or

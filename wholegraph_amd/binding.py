@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libwholegraph.so")
 # ---- enums (values are ABI; include/wholememory/*.h) -------------------------------------------
 WHOLEMEMORY_SUCCESS = 0
 NOT_SUPPORTED = 9
+OUT_OF_MEMORY = 8
 ERROR_NAMES = {
     0: "WHOLEMEMORY_SUCCESS", 1: "WHOLEMEMORY_UNKNOW_ERROR", 2: "WHOLEMEMORY_NOT_IMPLEMENTED",
     3: "WHOLEMEMORY_LOGIC_ERROR", 4: "WHOLEMEMORY_CUDA_ERROR", 5: "WHOLEMEMORY_COMMUNICATION_ERROR",

@@ -126,6 +126,11 @@ struct wm_sample_args {
   // optional (device): the number of centres in use when `centers` / `sample_offsets` are sized for an upper bound n_center
   // (the frontier of the previous hop of a bounded multi-hop call); nullptr = n_center
   const int* n_center_dev;
+  // optional side job of the sampling kernel: fill_ff_bytes bytes at fill_ff_ptr (both multiples of 16) are set to 0xFF —
+  // the empty hash table of the append_unique that follows in a fused hop (append_unique_table_region), which then skips
+  // its own fill command (wm_au_bounds::table_is_clear): one launch fewer per hop
+  void* fill_ff_ptr;
+  size_t fill_ff_bytes;
 };
 
 // device-side sizes of an append_unique over upper-bound-sized arrays (the hops of wholememory_ext_multilayer_sample: nothing
@@ -138,6 +143,11 @@ struct wm_au_bounds {
   // phase 2's emitting kernel instead of a kernel of their own at the end of phase 1 (the caller runs both phases back to
   // back without looking at the counts in between, and passes no publish_host to phase 1): one tiny launch fewer per hop
   int* publish_host_late;
+  // 1: the hash table region of the workspace (append_unique_table_region) is already all-ones
+  int table_is_clear;
+  // 1: phase 2 also sets the entries of the output array BEHIND the unique ids (up to its room of n_target + n_neighbor) to
+  // -1 ("skip me" for a gather): the array can then be handed to the next op at its full size before the host knows the count
+  int pad_unique_tail;
 };
 
 // device row cache of an embedding (kernels/cache.hip): direct map row -> slot, 64-slot LFU sets
@@ -244,11 +254,12 @@ struct wm_device_backend {
                        int* counts, void* stream);
   // ids[2i] = center i, ids[2i + 1] = center i + 1
   int (*sample_pair_ids)(const void* centers, wholememory_dtype_t center_dtype, int n, int64_t* ids, void* stream);
-  // sample_counts + exclusive scan in one pass (mapped CSR only): offsets[0 .. n]; workspace of scan_i32_workspace_bytes(n + 1).
+  // sample_counts + exclusive scan as ONE launch (mapped CSR only): offsets[0 .. n]; n_dev as in sample_counts; workspace of
+  // scan_i32_workspace_bytes(n + 1) (may go unused). Returns -3 with nothing queued when it does not take the size.
   // Optional: nullptr = run the two steps
   int (*sample_offsets)(const wholememory_gref_t* row_gref, int64_t row_storage_offset, const void* centers,
-                        wholememory_dtype_t center_dtype, int n_center, int max_sample_count, int* offsets, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        wholememory_dtype_t center_dtype, int n_center, const int* n_dev, int max_sample_count, int* offsets,
+                        void* workspace, size_t workspace_bytes, void* stream);
   size_t (*scan_i32_workspace_bytes)(int64_t n);
   int (*exclusive_scan_i32)(const int* in, int* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
   int (*sample_unweighted)(const wm_sample_args* a, void* stream);
@@ -309,6 +320,10 @@ struct wm_device_backend {
   int (*mem_info)(size_t* free_bytes, size_t* total_bytes);
   // ordinal of the device the calling thread works on (per-device locks). nullptr in a backend that does not provide it.
   int (*get_device)(int* device);
+  // the part of an append_unique workspace that must be all-ones before phase 1 (the empty hash table); -3 when the route
+  // these sizes take has none. nullptr in a backend that does not provide it.
+  int (*append_unique_table_region)(int n_target, int n_neighbor, wholememory_dtype_t dtype, void* workspace, void** ptr,
+                                    size_t* bytes);
 };
 
 }  // extern "C"

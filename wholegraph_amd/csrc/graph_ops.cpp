@@ -392,6 +392,25 @@ wholememory_error_code_t graph_append_unique(wholememory_tensor_t target_nodes_t
   WM_API_END
 }
 
+namespace {
+// offsets[0 .. n] of a hop: one launch (counts inside the scan, kernels/graph.hip: chain_scan_kernel) where the backend has
+// it and takes the size, else count kernel + scan. WM_SAMPLE_FUSED_SCAN=0 forces the two steps (A/B).
+int hop_offsets(const wm_device_backend* bk, const wm_sample_args& a, const int* n_dev, int* counts, int* offsets, void* scan_ws,
+                size_t scan_ws_bytes, void* stream)
+{
+  const char* sw = WM_KNOB("WM_SAMPLE_FUSED_SCAN");
+  if (bk->sample_offsets != nullptr && !(sw != nullptr && sw[0] == '0')) {
+    const int rc = bk->sample_offsets(&a.row_gref, a.row_storage_offset, a.centers, a.center_dtype, a.n_center, n_dev,
+                                      a.max_sample_count, offsets, scan_ws, scan_ws_bytes, stream);
+    if (rc != -3) return rc;
+  }
+  int rc = bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, a.n_center, n_dev,
+                             a.max_sample_count, counts, stream);
+  if (rc != 0) return rc;
+  return bk->exclusive_scan_i32(counts, offsets, static_cast<int64_t>(a.n_center) + 1, scan_ws, scan_ws_bytes, stream);
+}
+}  // namespace
+
 // One hop of multi-layer sampling as ONE call (extension; the reference runs the sampler and append_unique as two ops with a
 // host round trip each to size their outputs — wholegraph_ops/unweighted_sample_without_replacement + graph_ops/append_unique,
 // driven by python/.../torch/graph_structure.py:140-196). Here the sampled ids go to scratch sized for the upper bound
@@ -457,16 +476,7 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
   // {samples, new unique ids}: left in pinned memory by the last kernel before the host looks (no copy commands)
   int* host = static_cast<int*>(host_mem.pinned(2, WHOLEMEMORY_DT_INT));
 
-  // (sample_offsets — the counts computed inside the scan's input iterator — exists and is bit-identical, but the look-back
-  // scan with random row_ptr loads per element is slower than count kernel + plain scan: 8-19 us against 4 + 6; WM_SAMPLE_FUSED_SCAN=1)
-  if (bk->sample_offsets != nullptr && WM_KNOB("WM_SAMPLE_FUSED_SCAN") != nullptr) {
-    WM_BK(bk->sample_offsets(&a.row_gref, a.row_storage_offset, a.centers, a.center_dtype, a.n_center, max_sample_count, offsets,
-                             scan_ws_ptr, scan_ws, stream));
-  } else {
-    WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, a.n_center, nullptr, max_sample_count,
-                            counts, stream));
-    WM_BK(bk->exclusive_scan_i32(counts, offsets, n + 1, scan_ws_ptr, scan_ws, stream));
-  }
+  WM_BK(hop_offsets(bk, a, nullptr, counts, offsets, scan_ws_ptr, scan_ws, stream));
   a.out_ids        = ids;
   a.out_center_lid = lid;
   WM_BK(bk->sample_unweighted(&a, stream));   // writes exactly offsets[n] entries of the scratch arrays
@@ -511,6 +521,8 @@ wholememory_error_code_t wholememory_ext_sample_append_unique(
 // synchronises the stream ONCE, reads the counts and trims:
 //   sample_offsets[h]  int32 [cap_c[h] + 1]          first n_c[h] + 1 entries are the hop's csr_row_ptr
 //   unique[h]          ids   [cap_c[h] + cap_s[h]]    first n_c[h] + new[h] entries = centres ++ new neighbours = hop h + 1's centres
+//                                                      (last hop: the entries behind them are -1 up to the array's room, so the
+//                                                      whole array can feed a gather before the host has read the counts)
 //   neighbor_pos[h]    int32 [cap_s[h]]               first samples[h] entries
 //   center_lid[h]      int32 [cap_s[h]]               first samples[h] entries
 // with n_c[0] = seeds, n_c[h + 1] = n_c[h] + new[h]. Outputs equal those of `hops` fused-hop calls bit for bit (same kernels,
@@ -584,14 +596,19 @@ wholememory_error_code_t wholememory_ext_multilayer_sample(
     void* scan_ws_ptr  = scratch(static_cast<int64_t>(scan_ws), WHOLEMEMORY_DT_INT8);
     void* ids          = scratch(ns, col_desc.dtype);
     void* ws = scratch(static_cast<int64_t>(bk->append_unique_workspace_bytes(nc, ns, seed_desc.dtype)), WHOLEMEMORY_DT_INT8);
-    WM_BK(bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, nc, centres_in_use,
-                            a.max_sample_count, counts, stream));
-    WM_BK(bk->exclusive_scan_i32(counts, offsets, nc + 1, scan_ws_ptr, scan_ws, stream));   // offsets[nc] = samples of the hop
+    WM_BK(hop_offsets(bk, a, centres_in_use, counts, offsets, scan_ws_ptr, scan_ws, stream));   // offsets[nc] = samples of the hop
     a.out_ids        = ids;
     a.out_center_lid = center_lid[h];
+    // the sampling kernel empties the hop's hash table on the side (one fill command fewer per hop)
+    a.fill_ff_ptr = nullptr, a.fill_ff_bytes = 0;
+    const bool side_fill = bk->append_unique_table_region != nullptr &&
+                           bk->append_unique_table_region(nc, ns, seed_desc.dtype, ws, &a.fill_ff_ptr, &a.fill_ff_bytes) == 0;
+    if (!side_fill) a.fill_ff_ptr = nullptr, a.fill_ff_bytes = 0;
     WM_BK(bk->sample_unweighted(&a, stream));
     // (the hop's counts are published by phase 2's emitting kernel: one tiny launch fewer per hop)
-    wm_au_bounds b{centres_in_use, offsets + nc, n_dev + h, counts_host + 2 * h};
+    // (the outermost frontier is padded with -1 up to its room: a gather can be queued on the whole array before the host
+    // has read the counts — negative ids are skipped, gather_scatter_func.cuh:296)
+    wm_au_bounds b{centres_in_use, offsets + nc, n_dev + h, counts_host + 2 * h, side_fill ? 1 : 0, h == hops - 1 ? 1 : 0};
     int rc = bk->append_unique_phase1(a.centers, nc, ids, ns, offsets + nc, seed_desc.dtype, ws, nullptr, nullptr, &b, stream);
     if (rc != 0) return rc == -1 ? WHOLEMEMORY_LOGIC_ERROR : WHOLEMEMORY_CUDA_ERROR;
     WM_BK(bk->append_unique_phase2(a.centers, nc, ns, ns, seed_desc.dtype, ws, unique[h], neighbor_pos[h], nullptr, nullptr, &b, stream));

@@ -27,6 +27,9 @@
 #include "../backend.hpp"
 #include "../pcg.hpp"
 
+#include <mutex>
+#include <unordered_map>
+
 namespace wm {
 namespace {
 
@@ -76,6 +79,163 @@ __device__ __forceinline__ T gref_load(const gref_view& v, int64_t elem_index)
     start = v.rank_offsets[rank];
   }
   return *reinterpret_cast<const T*>(v.rank_ptrs[rank] + (off - start));
+}
+
+// ------------------------------------------------------------------------------------------------ single-launch scan
+// Exclusive int32 scan of v[i] = fn(i), i in [0, n), in ONE launch with no workspace to prepare (round 4; rocPRIM's look-back
+// scan is two launches — state initialisation + scan — and a separate kernel has to materialise its input first: on the C5
+// step that was 6 of 20 launches, each at the ~5 us floor of a tiny launch). Decoupled look-back over tiles of
+// kChainTile values:
+//  * a block takes its tile number from a TICKET, so it only ever waits for tiles that are already running — no assumption
+//    about dispatch order or about all blocks being resident;
+//  * the values of a thread (1, 4 or 16) are evaluated before anything else (fn may be a chain of random loads: they are all in flight
+//    together), then thread / wave / block scans, the tile's aggregate is published, wave 0 looks back over the published
+//    words of its predecessors (status in the top two bits: 1 = aggregate, 2 = inclusive prefix), publishes the inclusive
+//    prefix, and the block writes its outputs. A status word carries its whole message (flag + value in one 64-bit atomic),
+//    so the accesses are RELAXED agent-scope atomics: an acquire / release pair at agent scope is an L2 invalidate / write-back
+//    on this part (the XCDs' L2s are not coherent with each other) — with those the 465-tile scan of the C5 hop took 153 us;
+//  * the state (ticket + one word per tile) is SELF-CLEANING: the last block to finish (second counter) zeroes it again, so
+//    it is all-zero between launches. It lives in a small per-stream device buffer owned by the library (scan_state_for),
+//    zeroed once when it is created — nothing per call, and nothing that a hipGraph capture could not replay.
+// `tail(total)` runs once, on the thread that owns value n - 1 (total = the sum of all n values): the place for what used
+// to be a one-thread publishing kernel.
+constexpr int kChainThreads = 256;   // values per tile: 256 x ITEMS, ITEMS = 1 / 4 / 16 by the size of the scan (chain_scan)
+constexpr int kChainMaxTiles = 16384;   // 67 M values at 16 per thread; bigger scans take rocPRIM
+struct chain_state {
+  unsigned int ticket, done, pad[2];
+  unsigned long long status[kChainMaxTiles];
+};
+struct no_tail {
+  __device__ void operator()(int) const {}
+};
+
+template <typename Fn, typename Tail, int kChainItems>
+__global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n, int* out, chain_state* st, Tail tail)
+{
+  constexpr int kChainTile = kChainThreads * kChainItems;
+  __shared__ int s_tile, s_excl, s_last;
+  __shared__ int s_wave[kChainThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) {
+    s_tile = static_cast<int>(atomicAdd(&st->ticket, 1u));
+    s_last = 0;
+  }
+  __syncthreads();
+  const int tile = s_tile;
+  const int i0   = tile * kChainTile + tid * kChainItems;
+  int v[kChainItems];
+#pragma unroll
+  for (int k = 0; k < kChainItems; k++) v[k] = i0 + k < n ? fn(i0 + k) : 0;
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < kChainItems; k++) {   // exclusive within the thread
+    const int x = v[k];
+    v[k]        = sum;
+    sum += x;
+  }
+  int incl = sum;   // inclusive over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += y;
+  }
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  int wave_off = 0, tile_total = 0;
+#pragma unroll
+  for (int w = 0; w < kChainThreads / 64; w++) {
+    if (w < wv) wave_off += s_wave[w];
+    tile_total += s_wave[w];
+  }
+  if (wv == 0) {
+    constexpr unsigned long long kAggregate = 1ull << 62, kInclusive = 2ull << 62;
+    if (lane == 0 && tile > 0)
+      __hip_atomic_store(&st->status[tile], kAggregate | static_cast<uint32_t>(tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int excl = 0;
+    for (int j = tile - 1; j >= 0; j -= 64) {   // wave-uniform; lane l looks at tile j - l
+      const int idx        = j - lane;
+      unsigned long long w = kInclusive;        // "in front of tile 0": inclusive prefix 0
+      if (idx >= 0) {
+        do {
+          w = __hip_atomic_load(&st->status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((w >> 62) == 0);
+      }
+      const unsigned long long incl_mask = __ballot((w >> 62) == 2);
+      const int first = incl_mask != 0 ? __ffsll(static_cast<long long>(incl_mask)) - 1 : 64;   // nearest tile with a full prefix
+      int part        = lane <= first ? static_cast<int>(static_cast<uint32_t>(w)) : 0;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+      excl += part;
+      if (incl_mask != 0) break;
+    }
+    if (lane == 0) {
+      __hip_atomic_store(&st->status[tile], kInclusive | static_cast<uint32_t>(excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_excl = excl;
+    }
+  }
+  __syncthreads();
+  const int base = s_excl + wave_off + incl - sum;   // exclusive prefix of this thread's first value
+  if (kChainItems >= 4 && i0 + kChainItems <= n && (reinterpret_cast<uintptr_t>(out + i0) & 15) == 0) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int k = 0; k + 3 < kChainItems; k += 4) {
+      i32x4 a;
+      a.x = base + v[k], a.y = base + v[k + 1], a.z = base + v[k + 2], a.w = base + v[k + 3];
+      *reinterpret_cast<i32x4*>(out + i0 + k) = a;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kChainItems; k++)
+      if (i0 + k < n) out[i0 + k] = base + v[k];
+  }
+  if (i0 <= n - 1 && n - 1 < i0 + kChainItems) tail(base + sum);
+  // the last block to get here puts the state back to zero (every look-back has ended: a block counts itself done after its own)
+  if (tid == 0 && atomicAdd(&st->done, 1u) == gridDim.x - 1) s_last = 1;
+  __syncthreads();
+  if (s_last) {
+    for (int j = tid; j < static_cast<int>(gridDim.x); j += kChainThreads) st->status[j] = 0;
+    if (tid == 0) st->ticket = 0, st->done = 0;
+  }
+}
+
+// the per-stream scan state: created (and zeroed) the first time a stream scans, kept for the life of the process
+chain_state* scan_state_for(hipStream_t stream)
+{
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, chain_state*> states;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = states.find(stream);
+  if (it != states.end()) return it->second;
+  chain_state* st = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&st), sizeof(chain_state)) != hipSuccess) return nullptr;
+  if (hipMemset(st, 0, sizeof(chain_state)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(st);
+    return nullptr;
+  }
+  states[stream] = st;
+  return st;
+}
+inline bool chain_scan_fits(int64_t n) { return n > 0 && n <= static_cast<int64_t>(kChainMaxTiles) * kChainThreads * 16; }
+
+// Tile size by the size of the scan: a small scan wants MANY small tiles (fn is a chain of random loads: 31 k values in 8
+// tiles of 4096 keep 8 CUs busy and take 18 us, in 124 tiles of 256 they spread over the chip), a big one fewer, larger tiles
+// (every 64 predecessors are one look-back round trip of ~1 us for the last tile). WM_SCAN_ITEMS=1|4|16 forces (A/B).
+template <typename Fn, typename Tail>
+int chain_scan(Fn fn, int n, int* out, Tail tail, hipStream_t stream)
+{
+  chain_state* st = scan_state_for(stream);
+  if (st == nullptr) return -2;
+  int items = n <= (64 << 10) ? 1 : n <= (512 << 10) ? 4 : 16;
+  if (const char* e = WM_KNOB("WM_SCAN_ITEMS")) {
+    const int v = atoi(e);
+    if ((v == 1 || v == 4 || v == 16) && (static_cast<int64_t>(n) + 256 * v - 1) / (256 * v) <= kChainMaxTiles) items = v;
+  }
+  const int tile = kChainThreads * items;
+  const dim3 grid((n + tile - 1) / tile), block(kChainThreads);
+  if (items == 1) hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, 1>), grid, block, 0, stream, fn, n, out, st, tail);
+  else if (items == 4) hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, 4>), grid, block, 0, stream, fn, n, out, st, tail);
+  else hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, 16>), grid, block, 0, stream, fn, n, out, st, tail);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // ------------------------------------------------------------------------------------------------ counts
@@ -129,7 +289,19 @@ struct sample_params {
   int* out_lid;        // optional
   int64_t* out_egid;   // optional
   const int* n_center_dev;  // optional: centres in use (<= n_center)
+  // side job (wm_sample_args::fill_ff_ptr): 16-byte pieces set to all-ones by the sampling kernel's threads before they sample
+  void* fill_ptr;
+  size_t fill_vecs;
 };
+__device__ __forceinline__ void side_fill(const sample_params& p)
+{
+  if (p.fill_ptr == nullptr) return;
+  typedef uint32_t fill4 __attribute__((ext_vector_type(4)));
+  const fill4 ones      = {~0u, ~0u, ~0u, ~0u};
+  const size_t stride   = static_cast<size_t>(gridDim.x) * blockDim.x;
+  fill4* dst            = static_cast<fill4*>(p.fill_ptr);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < p.fill_vecs; i += stride) dst[i] = ones;
+}
 __device__ __forceinline__ int centers_in_use(const sample_params& p)
 {
   return p.n_center_dev != nullptr ? min(p.n_center, *p.n_center_dev) : p.n_center;
@@ -241,6 +413,7 @@ template <typename IdT, typename ColT, int G>
 __global__ __launch_bounds__(kBlock) void sample_small_kernel(sample_params p)
 {
   constexpr int kPerWave = 64 / G;
+  side_fill(p);
   const int M      = p.max_sample;   // 1 ... G
   const int lane   = threadIdx.x & 63;
   const int gl     = lane & (G - 1);          // lane within its centre's group
@@ -348,8 +521,13 @@ __global__ __launch_bounds__(64) void sample_large_kernel(sample_params p)
 }
 
 template <typename IdT, typename ColT>
-int launch_sample(const sample_params& p, hipStream_t stream)
+int launch_sample(sample_params p, hipStream_t stream)
 {
+  const bool small = p.max_sample >= 1 && p.max_sample <= 64 && WM_KNOB("WM_SAMPLE_LDS") == nullptr;
+  if (p.fill_ptr != nullptr && (p.n_center == 0 || !small)) {   // only the small-sample kernels carry the side job
+    if (hipMemsetAsync(p.fill_ptr, 0xFF, p.fill_vecs * 16, stream) != hipSuccess) return -2;
+    p.fill_ptr = nullptr;
+  }
   if (p.n_center == 0) return 0;
   if (p.max_sample > kMaxSparse) {
     hipLaunchKernelGGL((sample_large_kernel<IdT, ColT>), dim3(p.n_center), dim3(64), 0, stream, p);
@@ -636,15 +814,30 @@ __global__ void au_publish_kernel(const int* new_rank_end, const int* nn_dev, in
 
 // (the grid covers max(nt, nn): the same launch copies the targets to the head of the output and, for the fused hop, the
 // centre local ids from their scratch to the exactly sized output — both were copy commands of their own)
-struct au_flag_fn {   // au_flag_kernel as a function of the neighbour position (input iterator of the ranking scan)
+struct au_flag_fn {   // au_flag_kernel as a function of the neighbour position: the input of the ranking scan (chain_scan_kernel)
   const uint32_t* min_pos;
   const uint32_t* slot_of;
-  int nt, nn;
-  const int* nn_dev;
+  int nt, nn, stride;
+  const int *nn_dev, *nt_dev;
   __device__ int operator()(int p) const
   {
-    const int used = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
-    return p < used && min_pos[slot_of[nt + p]] == static_cast<uint32_t>(nt + p) ? 1 : 0;
+    const int used   = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+    const int nt_use = nt_dev != nullptr ? min(nt, *nt_dev) : nt;
+    return p < used && min_pos[static_cast<size_t>(slot_of[nt + p]) * stride] == static_cast<uint32_t>(nt_use + p) ? 1 : 0;
+  }
+};
+struct au_publish_fn {   // au_publish_kernel as the scan's tail: `total` = the number of new unique neighbours
+  const int *nn_dev, *nt_dev;
+  int nn, nt;
+  int *new_count_dev, *publish_host, *n_unique_dev;
+  __device__ void operator()(int total) const
+  {
+    if (new_count_dev != nullptr) *new_count_dev = total;
+    if (publish_host != nullptr) {
+      publish_host[0] = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+      publish_host[1] = total;
+    }
+    if (n_unique_dev != nullptr) *n_unique_dev = (nt_dev != nullptr ? min(nt, *nt_dev) : nt) + total;
   }
 };
 
@@ -653,11 +846,15 @@ __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, cons
                                                          const int* new_rank, int nt, int nn, KeyT* out_unique, int* mapping,
                                                          const KeyT* targets, const int* copy_src, int* copy_dst,
                                                          const int* nt_dev, const int* nn_dev, int* publish_late, int* n_unique_late,
-                                                         int nn_room)
+                                                         int nn_room, int pad_room)
 {
   const int p      = blockIdx.x * blockDim.x + threadIdx.x;
   const int nt_use = nt_dev != nullptr ? min(nt, *nt_dev) : nt;
   const int nn_use = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+  if (pad_room > 0) {   // wm_au_bounds::pad_unique_tail: everything behind the unique ids reads "skip me"
+    const int stride = gridDim.x * blockDim.x;
+    for (int q = nt_use + new_rank[nn_room] + p; q < pad_room; q += stride) out_unique[q] = ~static_cast<KeyT>(0);
+  }
   if (p == 0 && publish_late != nullptr) {   // what au_publish_kernel writes, here (wm_au_bounds::publish_host_late)
     const int c     = new_rank[nn_room];     // the scan ran over the ROOM of the neighbour array: its last entry is the total
     publish_late[0] = nn_use;
@@ -692,15 +889,24 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
   using UKey  = typename std::make_unsigned<KeyT>::type;
   auto l      = au_plan<UKey>(ws, nt, nn);
   const int n = nt + nn;
-  if (hipMemsetAsync(l.slots, 0xFF, l.table_bytes, stream) != hipSuccess) return -2;
+  if (!(bounds != nullptr && bounds->table_is_clear) && hipMemsetAsync(l.slots, 0xFF, l.table_bytes, stream) != hipSuccess) return -2;
   if (n > 0)
     hipLaunchKernelGGL((au_insert_kernel<UKey>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                        static_cast<const UKey*>(targets), nt, static_cast<const UKey*>(neighbors), nn, nn_dev, l.slots,
                        l.min_pos, l.slot_of, l.cap, nt_dev);
-  // (computing the flags inside the scan's input iterator instead — au_flag_fn — was measured: the look-back scan with two
-  // dependent random loads per element takes 19.9 us against 6.8 + 5.9 us for flag kernel + plain scan)
   // 32-bit ids: the positions are the low halves of the (id, position) words that start where `slots` starts
   const uint32_t* positions = sizeof(UKey) == 4 ? reinterpret_cast<const uint32_t*>(l.slots) : l.min_pos;
+  const bool late = bounds != nullptr && bounds->publish_host_late != nullptr && new_count_dev == nullptr && publish_host == nullptr && nt + nn > 0;
+  // flags, ranking scan and the publishing of the count as ONE launch (round 4: chain_scan_kernel evaluates the flag — two
+  // dependent random loads — for a thread's values up front; rocPRIM's look-back scan over the same functor took 19.9 us
+  // against 6.8 + 5.9 us for flag kernel + plain scan, which is why round 3 kept four launches here). WM_AU_FUSED_SCAN=0: A/B.
+  const char* fused_sw = WM_KNOB("WM_AU_FUSED_SCAN");
+  if (chain_scan_fits(static_cast<int64_t>(nn) + 1) && !(fused_sw != nullptr && fused_sw[0] == '0')) {
+    au_flag_fn fn{positions, l.slot_of, nt, nn, sizeof(UKey) == 4 ? 2 : 1, nn_dev, nt_dev};
+    if (late) return chain_scan(fn, nn + 1, l.new_rank, no_tail{}, stream);   // phase 2's kernel publishes
+    au_publish_fn pub{nn_dev, nt_dev, nn, nt, new_count_dev, publish_host, bounds != nullptr ? bounds->n_unique_dev : static_cast<int*>(nullptr)};
+    return chain_scan(fn, nn + 1, l.new_rank, pub, stream);
+  }
   hipLaunchKernelGGL(au_flag_kernel, dim3((nn + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, positions, l.slot_of, nt, nn,
                      nn_dev, l.first_flag, sizeof(UKey) == 4 ? 2 : 1, nt_dev);
   size_t tb = l.temp_bytes;
@@ -729,7 +935,8 @@ int au_phase2(const void* targets, int nt, int nn, int nn_used, void* ws, void* 
     hipLaunchKernelGGL((au_emit_kernel<UKey>), dim3((g + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, l.slots, l.min_pos,
                        l.slot_of, l.new_rank, nt, nn_used, static_cast<UKey*>(out_unique), mapping,
                        static_cast<const UKey*>(targets), copy_src, copy_dst, nt_dev, nn_dev, late,
-                       late != nullptr ? bounds->n_unique_dev : static_cast<int*>(nullptr), nn);
+                       late != nullptr ? bounds->n_unique_dev : static_cast<int*>(nullptr), nn,
+                       bounds != nullptr && bounds->pad_unique_tail ? nt + nn : 0);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -969,9 +1176,11 @@ struct degree_fn {
   int64_t row_off;
   const IdT* centers;
   int n, max_sample;
+  const int* n_dev;   // optional: centres in use of the n the arrays are sized for
   __device__ int operator()(int i) const
   {
-    if (i >= n) return 0;  // the scan runs over n + 1 entries (reference :334-338)
+    const int used = n_dev != nullptr ? min(n, *n_dev) : n;
+    if (i >= used) return 0;  // the scan runs over n + 1 entries (reference :334-338)
     const int64_t nid = static_cast<int64_t>(centers[i]);
     const int64_t s   = gref_load<int64_t>(row_ptr, row_off + nid);
     const int64_t e   = gref_load<int64_t>(row_ptr, row_off + nid + 1);
@@ -981,24 +1190,21 @@ struct degree_fn {
   }
 };
 int hip_sample_offsets(const wholememory_gref_t* row_gref, int64_t row_off, const void* centers, wholememory_dtype_t id_dtype,
-                       int n, int max_sample, int* offsets, void* ws, size_t ws_bytes, void* stream_v)
+                       int n, const int* n_dev, int max_sample, int* offsets, void* ws, size_t ws_bytes, void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const gref_view rv = make_view(*row_gref);
-  size_t b           = ws_bytes;
-  hipError_t rc;
+  (void)ws, (void)ws_bytes;
+  if (!chain_scan_fits(static_cast<int64_t>(n) + 1)) return -3;   // nothing queued: the caller runs count kernel + scan
   if (id_dtype == WHOLEMEMORY_DT_INT) {
-    degree_fn<int32_t> fn{rv, row_off, static_cast<const int32_t*>(centers), n, max_sample};
-    rc = rocprim::exclusive_scan(ws, b, rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn), offsets, 0,
-                                 static_cast<size_t>(n) + 1, rocprim::plus<int>(), stream);
-  } else if (id_dtype == WHOLEMEMORY_DT_INT64) {
-    degree_fn<int64_t> fn{rv, row_off, static_cast<const int64_t*>(centers), n, max_sample};
-    rc = rocprim::exclusive_scan(ws, b, rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn), offsets, 0,
-                                 static_cast<size_t>(n) + 1, rocprim::plus<int>(), stream);
-  } else {
-    return -1;
+    degree_fn<int32_t> fn{rv, row_off, static_cast<const int32_t*>(centers), n, max_sample, n_dev};
+    return chain_scan(fn, n + 1, offsets, no_tail{}, stream);
   }
-  return rc == hipSuccess ? 0 : -2;
+  if (id_dtype == WHOLEMEMORY_DT_INT64) {
+    degree_fn<int64_t> fn{rv, row_off, static_cast<const int64_t*>(centers), n, max_sample, n_dev};
+    return chain_scan(fn, n + 1, offsets, no_tail{}, stream);
+  }
+  return -1;
 }
 
 size_t hip_scan_i32_ws_bytes(int64_t n)
@@ -1023,6 +1229,10 @@ int hip_sample_unweighted(const wm_sample_args* a, void* stream_v)
   p.seed = a->random_seed, p.offsets = a->sample_offsets;
   p.out_ids = a->out_ids, p.out_lid = a->out_center_lid, p.out_egid = a->out_edge_gid;
   p.n_center_dev = a->n_center_dev;
+  if (a->fill_ff_ptr != nullptr && a->fill_ff_bytes > 0) {
+    if ((reinterpret_cast<uintptr_t>(a->fill_ff_ptr) | a->fill_ff_bytes) & 15) return -1;
+    p.fill_ptr = a->fill_ff_ptr, p.fill_vecs = a->fill_ff_bytes / 16;
+  }
   if (a->row_pairs != nullptr) {
     // positions only: row bounds come from the fetched pairs, the caller gathers the columns by edge id afterwards
     if (a->out_ids != nullptr || a->out_edge_gid == nullptr) return -1;
@@ -1061,6 +1271,20 @@ int hip_sample_weighted(const wm_sample_args* a, void* stream_v)
   if (a->weight_dtype == WHOLEMEMORY_DT_FLOAT) return dispatch_weighted<float>(w, id32, col32, stream);
   if (a->weight_dtype == WHOLEMEMORY_DT_DOUBLE) return dispatch_weighted<double>(w, id32, col32, stream);
   return -1;
+}
+
+// the part of an append_unique workspace that has to be all-ones before phase 1 (the empty hash table); -3: the sort route
+int hip_append_unique_table_region(int nt, int nn, wholememory_dtype_t dt, void* ws, void** ptr, size_t* bytes)
+{
+  if (!au_use_table(nt, nn, dt)) return -3;
+  if (dt == WHOLEMEMORY_DT_INT) {
+    const auto l = au_plan<uint32_t>(ws, nt, nn);
+    *ptr = l.slots, *bytes = l.table_bytes;
+  } else {
+    const auto l = au_plan<uint64_t>(ws, nt, nn);
+    *ptr = l.slots, *bytes = l.table_bytes;
+  }
+  return 0;
 }
 
 size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt)

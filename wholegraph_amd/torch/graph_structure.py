@@ -24,6 +24,35 @@ _INDEX_DTYPES = (torch.int32, torch.int64)
 _Hop = namedtuple("_Hop", "targets edge_index row_ptr col_ind")
 
 
+def _layer_lists(layers, node_ids):
+    return ([hop.targets for hop in layers] + [node_ids], [hop.edge_index for hop in layers],
+            [hop.row_ptr for hop in layers], [hop.col_ind for hop in layers])
+
+
+def _chain_layers(chain, hops):
+    layers = [None] * hops
+    for depth, (offsets, widened, neighbour_pos, centre_lid, edge_index) in enumerate(chain):
+        layers[hops - 1 - depth] = _Hop(widened, edge_index, offsets, neighbour_pos)
+    return layers
+
+
+class _DeferredSample(object):
+    """handle of GraphStructure.multilayer_sample_begin"""
+
+    def __init__(self, graph, node_ids, max_neighbors, random_seeds, pending):
+        self._node_ids, self._hops, self._pending, self._lists = node_ids, len(max_neighbors), pending, None
+        if pending is None:      # not queued as one chain: sampled now, hop by hop
+            self._lists = graph._sample_hop_by_hop(node_ids, max_neighbors, None, random_seeds)
+            self.padded_frontier = self._lists[0][0]
+        else:
+            self.padded_frontier = pending.padded_frontier
+
+    def result(self):
+        if self._lists is None:
+            self._lists = _layer_lists(_chain_layers(self._pending.finish(), self._hops), self._node_ids)
+        return self._lists
+
+
 def _checked_csr(row_ptr: WholeMemoryTensor, col_ind: WholeMemoryTensor):
     """(node count, edge count) of a valid CSR pair; raises AssertionError like the reference on a malformed one"""
     problems = []
@@ -117,10 +146,31 @@ class GraphStructure(object):
             chain = wholegraph_ops.multilayer_sample(self.csr_row_ptr.wmb_tensor, self.csr_col_ind.wmb_tensor, node_ids,
                                                      max_neighbors, random_seeds)
             if chain is not None:
-                for depth, (offsets, widened, neighbour_pos, centre_lid, edge_index) in enumerate(chain):
-                    layers[hops - 1 - depth] = _Hop(widened, edge_index, offsets, neighbour_pos)
-                return ([hop.targets for hop in layers] + [node_ids], [hop.edge_index for hop in layers],
-                        [hop.row_ptr for hop in layers], [hop.col_ind for hop in layers])
+                return _layer_lists(_chain_layers(chain, hops), node_ids)
+        return self._sample_hop_by_hop(node_ids, max_neighbors, weight_name, random_seeds)
+
+    def multilayer_sample_begin(self, node_ids: torch.Tensor, max_neighbors: List[int], *,
+                                random_seeds: Optional[Sequence[int]] = None):
+        """Extension: the unweighted multi-layer sample QUEUED, the host not waiting for it. Returns a handle with
+          .padded_frontier   the outermost frontier (what target_gids[0] will be) at its upper-bound size, the entries behind the
+                             sampled nodes set to -1 — hand it to WholeMemoryEmbedding.gather right away: negative ids are
+                             skipped, so rows [0, n) of that gather's output are the features of target_gids[0];
+          .result()          one stream synchronise, then exactly what multilayer_sample_without_replacement returns.
+        The feature gather of a mini-batch then runs back to back with the sampling kernels instead of behind a host round
+        trip. When the one-call chain does not apply (see wholegraph_ops.multilayer_sample_begin) the sample is taken here and
+        now, hop by hop, and padded_frontier is target_gids[0] itself."""
+        hops = len(max_neighbors)
+        if random_seeds is not None:
+            assert len(random_seeds) == hops, "one seed per hop"
+        pending = None
+        if hops > 0 and os.environ.get("WM_MULTILAYER_CHAIN", "1") != "0":
+            pending = wholegraph_ops.multilayer_sample_begin(self.csr_row_ptr.wmb_tensor, self.csr_col_ind.wmb_tensor, node_ids,
+                                                             max_neighbors, random_seeds)
+        return _DeferredSample(self, node_ids, max_neighbors, random_seeds, pending)
+
+    def _sample_hop_by_hop(self, node_ids, max_neighbors, weight_name, random_seeds):
+        hops = len(max_neighbors)
+        layers = [None] * hops
         frontier = node_ids
         for depth, fanout in enumerate(max_neighbors):          # depth 0 = next to the seeds = layer hops - 1
             seed = None if random_seeds is None else random_seeds[depth]
@@ -137,5 +187,4 @@ class GraphStructure(object):
                 widened, neighbour_pos = graph_ops.append_unique(frontier, neighbours, need_neighbor_raw_to_unique=True)
             layers[hops - 1 - depth] = _Hop(widened, torch.stack([neighbour_pos, centre_lid]), offsets, neighbour_pos)
             frontier = widened
-        return ([hop.targets for hop in layers] + [node_ids], [hop.edge_index for hop in layers],
-                [hop.row_ptr for hop in layers], [hop.col_ind for hop in layers])
+        return _layer_lists(layers, node_ids)

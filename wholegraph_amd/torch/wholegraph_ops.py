@@ -77,17 +77,69 @@ def sample_append_unique(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, center_no
     return offset, uniq.get_tensor(), pos.get_tensor(), lid.get_tensor()
 
 
-_pinned_counts = {}
+_pinned_pool = {}     # hops -> idle pinned count buffers (one per chain in flight, handed back by finish())
+_event_pool = []
 
 
-def multilayer_sample(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_tensor: torch.Tensor, max_sample_counts,
-                      random_seeds=None):
-    """Extension (wholememory_ext_multilayer_sample): every hop of an unweighted multi-layer sample in ONE library call with no
-    host round trip inside — buffers sized for their upper bounds, counts kept on the device between hops, ONE stream
-    synchronise here at the end. Returns a list with one (sample_offset, unique, neighbor_pos, center_lid) tuple per hop, hop 0
-    next to the seeds, each tensor a trimmed view of its upper-bound buffer and equal to what `sample_append_unique` returns hop
-    by hop with the same seeds — or None when the library declines (CSR not mapped into this rank, dtypes differ, empty seeds,
-    upper bounds beyond append_unique's hash-table route): run hop by hop then."""
+def _multilayer_budget_bytes():
+    """upper-bound buffers of a chain that the one-call route may allocate (WM_MULTILAYER_MAX_BYTES, default 8 GiB): beyond it
+    the chain is declined and the caller samples hop by hop with exactly sized outputs"""
+    import os
+    try:
+        return int(os.environ.get("WM_MULTILAYER_MAX_BYTES", str(8 << 30)))
+    except ValueError:
+        return 8 << 30
+
+
+def _compact(t):
+    """a trimmed view keeps its whole upper-bound buffer alive: copy out of big, mostly empty ones"""
+    room = t.untyped_storage().nbytes()
+    return t.clone() if room > (16 << 20) and t.numel() * t.element_size() * 2 < room else t
+
+
+class PendingMultilayerSample:
+    """A multi-hop sample whose kernels are queued and whose counts the host has not read yet (multilayer_sample_begin).
+    `padded_frontier` is the outermost frontier at its full upper-bound size, the entries behind the sampled nodes set to -1:
+    it can be handed to a gather right away (negative ids are skipped). `finish()` synchronises the stream once, trims every
+    output and returns what multilayer_sample returns."""
+
+    def __init__(self, hops, n0, offsets, uniques, edges, counts, stream):
+        self._hops, self._n0, self._offsets, self._uniques, self._edges = hops, n0, offsets, uniques, edges
+        self._counts, self._result = counts, None
+        self.padded_frontier = uniques[-1]
+        # finish() waits for THIS chain, not for whatever the caller queues behind it (the feature gather on padded_frontier
+        # keeps running while the host trims the outputs)
+        self._done = _event_pool.pop() if _event_pool else torch.cuda.Event()
+        self._done.record(stream)
+
+    def finish(self):
+        if self._result is not None:
+            return self._result
+        self._done.synchronize()          # the one host round trip of the whole chain
+        _event_pool.append(self._done)
+        self._done = None
+        got = self._counts.tolist()
+        _pinned_pool.setdefault(self._hops, []).append(self._counts)
+        self._counts = None
+        out, n_c = [], self._n0
+        for h in range(self._hops):
+            n_samples, n_new = got[2 * h], got[2 * h + 1]
+            edge = _compact(self._edges[h][:, :n_samples])
+            # (the outermost frontier stays a view of the padded array a gather may still be reading)
+            uniq = self._uniques[h][:n_c + n_new] if h == self._hops - 1 else _compact(self._uniques[h][:n_c + n_new])
+            out.append((_compact(self._offsets[h][:n_c + 1]), uniq, edge[0], edge[1], edge))
+            n_c += n_new
+        self.n_frontier = n_c
+        self._result = out
+        return out
+
+
+def multilayer_sample_begin(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_tensor: torch.Tensor, max_sample_counts,
+                            random_seeds=None):
+    """Queues every hop of an unweighted multi-layer sample (wholememory_ext_multilayer_sample: one library call, counts kept
+    on the device between hops, no host round trip) and returns a PendingMultilayerSample WITHOUT waiting — or None when the
+    library declines (CSR not mapped into this rank, dtypes differ, empty seeds, upper bounds beyond append_unique's hash-table
+    route or beyond the memory budget, allocation failure): run hop by hop then."""
     row, col = _handle(wm_csr_row_ptr_tensor), _handle(wm_csr_col_ptr_tensor)
     assert seed_nodes_tensor.dim() == 1
     hops = len(max_sample_counts)
@@ -102,36 +154,52 @@ def multilayer_sample(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_t
         cap_c.append(cap_c[-1] + cap_s[-1])
     if cap_c[-1] >= (1 << 31) - 1:
         return None
+    idt = seed_nodes_tensor.dtype
+    # outputs + the library's scratch (ids, hash table of 2 slots per key, positions ...): ~ 10 words per sampled neighbour
+    need = sum(4 * (cap_c[h] + 1) + idt.itemsize * cap_c[h + 1] + 8 * cap_s[h] + 40 * (cap_c[h] + cap_s[h]) for h in range(hops))
+    if need > _multilayer_budget_bytes():
+        return None
     fan = (C.c_int * hops)(*[int(m) for m in max_sample_counts])
     ws = wrap_torch_tensor(seed_nodes_tensor)
-    # ask first (no buffers yet: the upper bounds of a declined chain can be tens of GB)
+    # ask first (no buffers yet); anything but SUCCESS is a decline
     if wmb.lib().wholememory_ext_multilayer_sample(row, col, ws.handle, hops, fan, None, None, None, None, None, None, None,
-                                                   None) == wmb.NOT_SUPPORTED:
+                                                   None) != wmb.WHOLEMEMORY_SUCCESS:
         return None
-    dev, idt = op_device(), seed_nodes_tensor.dtype
-    offsets = [torch.empty(cap_c[h] + 1, device=dev, dtype=torch.int) for h in range(hops)]
-    uniques = [torch.empty(cap_c[h + 1], device=dev, dtype=idt) for h in range(hops)]
-    edges = [torch.empty((2, max(cap_s[h], 1)), device=dev, dtype=torch.int) for h in range(hops)]   # row 0 positions, row 1 centre ids
-    counts = _pinned_counts.get(hops)
-    if counts is None:
-        counts = _pinned_counts[hops] = torch.zeros(2 * hops, dtype=torch.int32).pin_memory()
+    dev = op_device()
+    try:
+        offsets = [torch.empty(cap_c[h] + 1, device=dev, dtype=torch.int) for h in range(hops)]
+        uniques = [torch.empty(cap_c[h + 1], device=dev, dtype=idt) for h in range(hops)]
+        edges = [torch.empty((2, max(cap_s[h], 1)), device=dev, dtype=torch.int) for h in range(hops)]   # row 0 positions, row 1 centre ids
+    except torch.OutOfMemoryError:
+        return None
+    pool = _pinned_pool.setdefault(hops, [])
+    counts = pool.pop() if pool else torch.zeros(2 * hops, dtype=torch.int32).pin_memory()
     rng = (C.c_ulonglong * hops)(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in random_seeds])
     ptrs = lambda ts: (C.c_void_p * hops)(*[t.data_ptr() for t in ts])
-    rc = wmb.lib().wholememory_ext_multilayer_sample(
-        row, col, ws.handle, hops, fan, rng, ptrs(offsets), ptrs(uniques), ptrs([e[0] for e in edges]),
-        ptrs([e[1] for e in edges]), C.c_void_p(counts.data_ptr()), get_wholegraph_env_fns(), C.c_void_p(get_stream()))
-    if rc == wmb.NOT_SUPPORTED:
-        return None
-    wmb.check(rc)
-    torch.cuda.current_stream().synchronize()        # the one host round trip of the whole chain
-    got = counts.tolist()
-    out, n_c = [], n0
-    for h in range(hops):
-        n_samples, n_new = got[2 * h], got[2 * h + 1]
-        out.append((offsets[h][:n_c + 1], uniques[h][:n_c + n_new], edges[h][0, :n_samples], edges[h][1, :n_samples],
-                    edges[h][:, :n_samples]))
-        n_c += n_new
-    return out
+    try:
+        rc = wmb.lib().wholememory_ext_multilayer_sample(
+            row, col, ws.handle, hops, fan, rng, ptrs(offsets), ptrs(uniques), ptrs([e[0] for e in edges]),
+            ptrs([e[1] for e in edges]), C.c_void_p(counts.data_ptr()), get_wholegraph_env_fns(), C.c_void_p(get_stream()))
+    except torch.OutOfMemoryError:      # the library's scratch comes from torch's allocator through the env functions
+        rc = wmb.NOT_SUPPORTED
+    if rc != wmb.WHOLEMEMORY_SUCCESS:
+        pool.append(counts)
+        if rc in (wmb.NOT_SUPPORTED, wmb.OUT_OF_MEMORY):
+            return None
+        wmb.check(rc)
+    return PendingMultilayerSample(hops, n0, offsets, uniques, edges, counts, torch.cuda.current_stream())
+
+
+def multilayer_sample(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_tensor: torch.Tensor, max_sample_counts,
+                      random_seeds=None):
+    """Extension (wholememory_ext_multilayer_sample): every hop of an unweighted multi-layer sample in ONE library call with no
+    host round trip inside — buffers sized for their upper bounds, counts kept on the device between hops, ONE stream
+    synchronise here at the end. Returns a list with one (sample_offset, unique, neighbor_pos, center_lid, edge_index) tuple per
+    hop, hop 0 next to the seeds, each tensor trimmed to its size and equal to what `sample_append_unique` returns hop by hop
+    with the same seeds — or None when the library declines (see multilayer_sample_begin): run hop by hop then."""
+    pending = multilayer_sample_begin(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, seed_nodes_tensor, max_sample_counts,
+                                      random_seeds)
+    return None if pending is None else pending.finish()
 
 
 def weighted_sample_without_replacement(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, wm_csr_weight_ptr_tensor,
