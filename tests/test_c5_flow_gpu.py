@@ -248,6 +248,50 @@ def test_deferred_chain_feeds_the_gather_before_the_host_knows_the_counts(gpu_en
     wgth.destroy_embedding(emb)
 
 
+def test_deferred_chain_and_gather_replay_from_a_graph(gpu_env):
+    """The queued chain + the gather on its padded frontier enqueue kernels on the caller's stream and nothing else (scratch
+    from torch's allocator through the env functions, the scans' state in a buffer the library keeps, counts left in pinned
+    memory by the last kernel): the whole C5 step can be captured into a hipGraph once and replayed."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    n_nodes, dim, fanouts, hop_seeds = 20011, 32, [30, 30], [5, 6]
+    row_ptr, col = make_csr(n_nodes, 40, 11, np.int32, heavy=[(3, 3000), (4, 0)])
+    wrow, wcol = _wm_array(gpu_env, "chunked", row_ptr), _wm_array(gpu_env, "chunked", col)
+    g = wgth.GraphStructure()
+    g.set_csr_graph(wrow, wcol)
+    emb = wgth.create_embedding(gpu_env, "chunked", "cuda", torch.float32, [n_nodes, dim])
+    local, _ = emb.get_embedding_tensor().get_local_tensor()
+    local.copy_(torch.arange(n_nodes, device="cuda", dtype=torch.float32).unsqueeze(1).expand(n_nodes, dim))
+    seeds = torch.from_numpy(np.concatenate([[3, 4], np.random.default_rng(5).permutation(n_nodes)[:200]]).astype(np.int32)).cuda()
+    ref = g.multilayer_sample_without_replacement(seeds, fanouts, random_seeds=hop_seeds)
+    room = seeds.shape[0] * 31 * 31
+    out = torch.empty((room, dim), device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up outside the capture (allocator, scan state, pinned counts)
+        h = g.multilayer_sample_begin(seeds, fanouts, random_seeds=hop_seeds)
+        emb.gather(h.padded_frontier, out=out)
+        h.result()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        h = g.multilayer_sample_begin(seeds, fanouts, random_seeds=hop_seeds)
+        emb.gather(h.padded_frontier, out=out)
+    for _ in range(3):
+        out.fill_(-7.0)
+        h.padded_frontier.fill_(123)
+        graph.replay()
+        torch.cuda.synchronize()
+    got = h.result()
+    for a_list, b_list in zip(got, ref):
+        for a, b in zip(a_list, b_list):
+            assert torch.equal(a, b)
+    n = got[0][0].shape[0]
+    assert torch.equal(out[:n, 0], got[0][0].float()) and bool((out[n:] == -7.0).all())
+    wgth.destroy_embedding(emb)
+
+
 def test_chain_declines_upper_bounds_beyond_the_table_route(gpu_env):
     """65536 seeds x [30, 30, 30]: the third hop's upper bound (63 M centres + 1.9 G samples) is past what append_unique's hash
     table takes from device-side counts: the library answers NOT_SUPPORTED to the query, before any buffer is allocated or

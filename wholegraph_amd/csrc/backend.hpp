@@ -255,11 +255,12 @@ struct wm_device_backend {
   // ids[2i] = center i, ids[2i + 1] = center i + 1
   int (*sample_pair_ids)(const void* centers, wholememory_dtype_t center_dtype, int n, int64_t* ids, void* stream);
   // sample_counts + exclusive scan as ONE launch (mapped CSR only): offsets[0 .. n]; n_dev as in sample_counts; workspace of
-  // scan_i32_workspace_bytes(n + 1) (may go unused). Returns -3 with nothing queued when it does not take the size.
-  // Optional: nullptr = run the two steps
+  // scan_i32_workspace_bytes(n + 1). workspace_is_ones = 1: the caller has filled the workspace with 0xFF bytes (the scan's
+  // state; it is left that way) — a chain of hops fills all its workspaces with one command; 0: the call fills it itself.
+  // Returns -3 with nothing queued when it does not take the size. Optional: nullptr = run the two steps
   int (*sample_offsets)(const wholememory_gref_t* row_gref, int64_t row_storage_offset, const void* centers,
                         wholememory_dtype_t center_dtype, int n_center, const int* n_dev, int max_sample_count, int* offsets,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        void* workspace, size_t workspace_bytes, int workspace_is_ones, void* stream);
   size_t (*scan_i32_workspace_bytes)(int64_t n);
   int (*exclusive_scan_i32)(const int* in, int* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
   int (*sample_unweighted)(const wm_sample_args* a, void* stream);
@@ -324,6 +325,9 @@ struct wm_device_backend {
   // these sizes take has none. nullptr in a backend that does not provide it.
   int (*append_unique_table_region)(int n_target, int n_neighbor, wholememory_dtype_t dtype, void* workspace, void** ptr,
                                     size_t* bytes);
+  // bytes set to 0xFF by a KERNEL launch (what memset_async(.., 0xFF, ..) does as a memset command: inside a captured
+  // hipGraph such a command was seen to run out of order with the kernels around it). nullptr: use memset_async.
+  int (*fill_ff_async)(void* ptr, size_t bytes, void* stream);
 };
 
 }  // extern "C"

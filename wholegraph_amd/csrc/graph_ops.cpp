@@ -396,12 +396,12 @@ namespace {
 // offsets[0 .. n] of a hop: one launch (counts inside the scan, kernels/graph.hip: chain_scan_kernel) where the backend has
 // it and takes the size, else count kernel + scan. WM_SAMPLE_FUSED_SCAN=0 forces the two steps (A/B).
 int hop_offsets(const wm_device_backend* bk, const wm_sample_args& a, const int* n_dev, int* counts, int* offsets, void* scan_ws,
-                size_t scan_ws_bytes, void* stream)
+                size_t scan_ws_bytes, void* stream, int ws_is_ones = 0)
 {
   const char* sw = WM_KNOB("WM_SAMPLE_FUSED_SCAN");
   if (bk->sample_offsets != nullptr && !(sw != nullptr && sw[0] == '0')) {
     const int rc = bk->sample_offsets(&a.row_gref, a.row_storage_offset, a.centers, a.center_dtype, a.n_center, n_dev,
-                                      a.max_sample_count, offsets, scan_ws, scan_ws_bytes, stream);
+                                      a.max_sample_count, offsets, scan_ws, scan_ws_bytes, ws_is_ones, stream);
     if (rc != -3) return rc;
   }
   int rc = bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, a.n_center, n_dev,
@@ -581,6 +581,19 @@ wholememory_error_code_t wholememory_ext_multilayer_sample(
     keep.emplace_back(new temp_mem(p_env_fns));
     return keep.back()->device(count, dt);
   };
+  // the offsets scans' workspaces of all hops in one block, initialised (0xFF: the scans' state) by ONE fill command
+  std::vector<size_t> scan_bytes(hops), scan_at(hops);
+  size_t scan_total = 0;
+  for (int h = 0; h < hops; h++) {
+    scan_bytes[h] = bk->scan_i32_workspace_bytes(cap_c[h] + 1);
+    scan_at[h]    = scan_total;
+    scan_total += scan_bytes[h];
+  }
+  char* scan_block = static_cast<char*>(scratch(static_cast<int64_t>(scan_total), WHOLEMEMORY_DT_INT8));
+  if (bk->fill_ff_async != nullptr)
+    WM_BK(bk->fill_ff_async(scan_block, scan_total, stream));
+  else
+    WM_BK(bk->memset_async(scan_block, 0xFF, scan_total, stream));
   for (int h = 0; h < hops; h++) {
     const int nc = static_cast<int>(cap_c[h]), ns = static_cast<int>(cap_s[h]);
     const int* centres_in_use = h == 0 ? nullptr : n_dev + (h - 1);
@@ -592,11 +605,11 @@ wholememory_error_code_t wholememory_ext_multilayer_sample(
     int* offsets       = static_cast<int*>(sample_offsets[h]);
     a.sample_offsets   = offsets;
     int* counts        = static_cast<int*>(scratch(nc + 1, WHOLEMEMORY_DT_INT));
-    const size_t scan_ws = bk->scan_i32_workspace_bytes(nc + 1);
-    void* scan_ws_ptr  = scratch(static_cast<int64_t>(scan_ws), WHOLEMEMORY_DT_INT8);
+    const size_t scan_ws = scan_bytes[h];
+    void* scan_ws_ptr  = scan_block + scan_at[h];
     void* ids          = scratch(ns, col_desc.dtype);
     void* ws = scratch(static_cast<int64_t>(bk->append_unique_workspace_bytes(nc, ns, seed_desc.dtype)), WHOLEMEMORY_DT_INT8);
-    WM_BK(hop_offsets(bk, a, centres_in_use, counts, offsets, scan_ws_ptr, scan_ws, stream));   // offsets[nc] = samples of the hop
+    WM_BK(hop_offsets(bk, a, centres_in_use, counts, offsets, scan_ws_ptr, scan_ws, stream, 1));   // offsets[nc] = samples of the hop
     a.out_ids        = ids;
     a.out_center_lid = center_lid[h];
     // the sampling kernel empties the hop's hash table on the side (one fill command fewer per hop)

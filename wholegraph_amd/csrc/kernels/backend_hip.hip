@@ -34,11 +34,12 @@ int hip_sample_pair_ids(const void* centers, wholememory_dtype_t id_dtype, int n
 size_t hip_scan_i32_ws_bytes(int64_t n);
 int hip_exclusive_scan_i32(const int* in, int* out, int64_t n, void* ws, size_t ws_bytes, void* stream);
 int hip_sample_offsets(const wholememory_gref_t* row_gref, int64_t row_off, const void* centers, wholememory_dtype_t id_dtype,
-                       int n, const int* n_dev, int max_sample, int* offsets, void* ws, size_t ws_bytes, void* stream);
+                       int n, const int* n_dev, int max_sample, int* offsets, void* ws, size_t ws_bytes, int ws_is_ones, void* stream);
 int hip_sample_unweighted(const wm_sample_args* a, void* stream);
 int hip_sample_weighted(const wm_sample_args* a, void* stream);
 size_t hip_append_unique_ws_bytes(int nt, int nn, wholememory_dtype_t dt);
 int hip_append_unique_table_region(int nt, int nn, wholememory_dtype_t dt, void* ws, void** ptr, size_t* bytes);
+int hip_fill_ff(void* ptr, size_t bytes, void* stream);
 int hip_append_unique_phase1(const void* targets, int nt, const void* neighbors, int nn, const int* nn_dev,
                              wholememory_dtype_t dt, void* ws, int* new_count_dev, int* publish_host, const wm_au_bounds* bounds,
                              void* stream);
@@ -204,6 +205,7 @@ const wm_device_backend kHipBackend = {
   h_mem_info,
   h_get_device,
   hip_append_unique_table_region,
+  hip_fill_ff,
 };
 
 }  // namespace

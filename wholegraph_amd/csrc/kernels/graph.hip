@@ -94,17 +94,19 @@ __device__ __forceinline__ T gref_load(const gref_view& v, int64_t elem_index)
 //    prefix, and the block writes its outputs. A status word carries its whole message (flag + value in one 64-bit atomic),
 //    so the accesses are RELAXED agent-scope atomics: an acquire / release pair at agent scope is an L2 invalidate / write-back
 //    on this part (the XCDs' L2s are not coherent with each other) — with those the 465-tile scan of the C5 hop took 153 us;
-//  * the state (ticket + one word per tile) is SELF-CLEANING: the last block to finish (second counter) zeroes it again, so
-//    it is all-zero between launches. It lives in a small per-stream device buffer owned by the library (scan_state_for),
-//    zeroed once when it is created — nothing per call, and nothing that a hipGraph capture could not replay.
+//  * the state (ticket + one word per tile) is caller-provided scratch that must read ALL-ONES on entry (every word is
+//    stored complemented, so that the 0xFF fill which empties append_unique's hash table initialises a scan state lying next
+//    to it in the same stroke) and is SELF-CLEANING: the last block to finish (second counter) puts it back to all-ones.
+//    Nothing is allocated and nothing waits: the launch can be captured into a hipGraph and replayed.
 // `tail(total)` runs once, on the thread that owns value n - 1 (total = the sum of all n values): the place for what used
 // to be a one-thread publishing kernel.
 constexpr int kChainThreads = 256;   // values per tile: 256 x ITEMS, ITEMS = 1 / 4 / 16 by the size of the scan (chain_scan)
 constexpr int kChainMaxTiles = 16384;   // 67 M values at 16 per thread; bigger scans take rocPRIM
-struct chain_state {
+struct chain_state {   // (stored complemented: all-ones = {ticket 0, done 0, no status})
   unsigned int ticket, done, pad[2];
-  unsigned long long status[kChainMaxTiles];
+  unsigned long long status[1];   // one word per tile
 };
+inline size_t chain_state_bytes(int64_t n) { return 16 + 8 * static_cast<size_t>((n + 255) / 256) + 16; }   // room for the smallest tile size
 struct no_tail {
   __device__ void operator()(int) const {}
 };
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n,
   __shared__ int s_wave[kChainThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) {
-    s_tile = static_cast<int>(atomicAdd(&st->ticket, 1u));
+    s_tile = static_cast<int>(~atomicSub(&st->ticket, 1u));   // complemented counter: all-ones = 0, counts down
     s_last = 0;
   }
   __syncthreads();
@@ -150,14 +152,14 @@ __global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n,
   if (wv == 0) {
     constexpr unsigned long long kAggregate = 1ull << 62, kInclusive = 2ull << 62;
     if (lane == 0 && tile > 0)
-      __hip_atomic_store(&st->status[tile], kAggregate | static_cast<uint32_t>(tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&st->status[tile], ~(kAggregate | static_cast<uint32_t>(tile_total)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int excl = 0;
     for (int j = tile - 1; j >= 0; j -= 64) {   // wave-uniform; lane l looks at tile j - l
       const int idx        = j - lane;
       unsigned long long w = kInclusive;        // "in front of tile 0": inclusive prefix 0
       if (idx >= 0) {
         do {
-          w = __hip_atomic_load(&st->status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w = ~__hip_atomic_load(&st->status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } while ((w >> 62) == 0);
       }
       const unsigned long long incl_mask = __ballot((w >> 62) == 2);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n,
       if (incl_mask != 0) break;
     }
     if (lane == 0) {
-      __hip_atomic_store(&st->status[tile], kInclusive | static_cast<uint32_t>(excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&st->status[tile], ~(kInclusive | static_cast<uint32_t>(excl + tile_total)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_excl = excl;
     }
   }
@@ -189,42 +191,44 @@ __global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n,
       if (i0 + k < n) out[i0 + k] = base + v[k];
   }
   if (i0 <= n - 1 && n - 1 < i0 + kChainItems) tail(base + sum);
-  // the last block to get here puts the state back to zero (every look-back has ended: a block counts itself done after its own)
-  if (tid == 0 && atomicAdd(&st->done, 1u) == gridDim.x - 1) s_last = 1;
+  // the last block to get here puts the state back to all-ones (every look-back has ended: a block counts itself done after its own)
+  if (tid == 0 && ~atomicSub(&st->done, 1u) == gridDim.x - 1) s_last = 1;
   __syncthreads();
   if (s_last) {
-    for (int j = tid; j < static_cast<int>(gridDim.x); j += kChainThreads) st->status[j] = 0;
-    if (tid == 0) st->ticket = 0, st->done = 0;
+    for (int j = tid; j < static_cast<int>(gridDim.x); j += kChainThreads) st->status[j] = ~0ull;
+    if (tid == 0) st->ticket = ~0u, st->done = ~0u;
   }
 }
 
-// the per-stream scan state: created (and zeroed) the first time a stream scans, kept for the life of the process
-chain_state* scan_state_for(hipStream_t stream)
+// 0xFF fill as a KERNEL (16-byte pieces; ptr and bytes multiples of 16). Not hipMemsetAsync: inside a captured hipGraph the
+// memset command of a chain was seen to run out of order with the scan kernels that depend on it (replays with other work
+// between them faulted; experiments/r04_capture_bisect.py) — a kernel node is ordered like its neighbours.
+__global__ void fill_ff_kernel(void* ptr, size_t vecs)
 {
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, chain_state*> states;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = states.find(stream);
-  if (it != states.end()) return it->second;
-  chain_state* st = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&st), sizeof(chain_state)) != hipSuccess) return nullptr;
-  if (hipMemset(st, 0, sizeof(chain_state)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-    (void)hipFree(st);
-    return nullptr;
-  }
-  states[stream] = st;
-  return st;
+  typedef uint32_t fill4 __attribute__((ext_vector_type(4)));
+  const fill4 ones    = {~0u, ~0u, ~0u, ~0u};
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < vecs; i += stride) static_cast<fill4*>(ptr)[i] = ones;
 }
+inline int fill_ff(void* ptr, size_t bytes, hipStream_t stream)
+{
+  if (bytes == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(ptr) | bytes) & 15) return hipMemsetAsync(ptr, 0xFF, bytes, stream) == hipSuccess ? 0 : -2;
+  const size_t vecs = bytes / 16;
+  const int blocks  = static_cast<int>(std::min<size_t>((vecs + 255) / 256, 4096));
+  hipLaunchKernelGGL(fill_ff_kernel, dim3(blocks), dim3(256), 0, stream, ptr, vecs);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 inline bool chain_scan_fits(int64_t n) { return n > 0 && n <= static_cast<int64_t>(kChainMaxTiles) * kChainThreads * 16; }
 
 // Tile size by the size of the scan: a small scan wants MANY small tiles (fn is a chain of random loads: 31 k values in 8
 // tiles of 4096 keep 8 CUs busy and take 18 us, in 124 tiles of 256 they spread over the chip), a big one fewer, larger tiles
 // (every 64 predecessors are one look-back round trip of ~1 us for the last tile). WM_SCAN_ITEMS=1|4|16 forces (A/B).
 template <typename Fn, typename Tail>
-int chain_scan(Fn fn, int n, int* out, Tail tail, hipStream_t stream)
+int chain_scan(Fn fn, int n, int* out, Tail tail, void* state, hipStream_t stream)
 {
-  chain_state* st = scan_state_for(stream);
-  if (st == nullptr) return -2;
+  chain_state* st = static_cast<chain_state*>(state);   // chain_state_bytes(n) bytes, all-ones
   int items = n <= (64 << 10) ? 1 : n <= (512 << 10) ? 4 : 16;
   if (const char* e = WM_KNOB("WM_SCAN_ITEMS")) {
     const int v = atoi(e);
@@ -525,7 +529,7 @@ int launch_sample(sample_params p, hipStream_t stream)
 {
   const bool small = p.max_sample >= 1 && p.max_sample <= 64 && WM_KNOB("WM_SAMPLE_LDS") == nullptr;
   if (p.fill_ptr != nullptr && (p.n_center == 0 || !small)) {   // only the small-sample kernels carry the side job
-    if (hipMemsetAsync(p.fill_ptr, 0xFF, p.fill_vecs * 16, stream) != hipSuccess) return -2;
+    if (fill_ff(p.fill_ptr, p.fill_vecs * 16, stream) != 0) return -2;
     p.fill_ptr = nullptr;
   }
   if (p.n_center == 0) return 0;
@@ -681,6 +685,7 @@ int dispatch_weighted(const weighted_params& w, bool id32, bool col32, hipStream
 // the result is deterministic and equals the oracle's bit for bit.
 template <typename KeyT>
 struct au_layout {
+  void* scan_state;   // chain_state of the ranking scan: in front of the table, inside the region the 0xFF fill covers
   KeyT* slots;        // cap + 1 ids (all-ones = empty; slot `cap` is reserved for the id that IS all-ones)
   uint32_t* min_pos;  // cap + 1 smallest positions (0xFFFFFFFF = none yet)
   uint32_t* slot_of;  // nt + nn: where each key landed (phase 2 and the flag pass do not probe again)
@@ -704,7 +709,8 @@ au_layout<KeyT> au_plan(void* ws, int nt, int nn)
   l.cap    = static_cast<uint32_t>(cap);
   char* p  = static_cast<char*>(ws);
   size_t o = 0;
-  // [slots | min_pos] are contiguous: one memset of 0xFF bytes empties both
+  // [scan state | slots | min_pos] are contiguous: one fill of 0xFF bytes initialises the scan state and empties the table
+  l.scan_state = p + o, o += al(chain_state_bytes(static_cast<int64_t>(nn) + 1));
   l.slots = reinterpret_cast<KeyT*>(p + o), o += al(sizeof(KeyT) * (cap + 1));
   l.min_pos = reinterpret_cast<uint32_t*>(p + o), o += al(4 * (cap + 1));
   l.table_bytes = o;
@@ -889,7 +895,7 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
   using UKey  = typename std::make_unsigned<KeyT>::type;
   auto l      = au_plan<UKey>(ws, nt, nn);
   const int n = nt + nn;
-  if (!(bounds != nullptr && bounds->table_is_clear) && hipMemsetAsync(l.slots, 0xFF, l.table_bytes, stream) != hipSuccess) return -2;
+  if (!(bounds != nullptr && bounds->table_is_clear) && fill_ff(l.scan_state, l.table_bytes, stream) != 0) return -2;
   if (n > 0)
     hipLaunchKernelGGL((au_insert_kernel<UKey>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                        static_cast<const UKey*>(targets), nt, static_cast<const UKey*>(neighbors), nn, nn_dev, l.slots,
@@ -903,9 +909,9 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
   const char* fused_sw = WM_KNOB("WM_AU_FUSED_SCAN");
   if (chain_scan_fits(static_cast<int64_t>(nn) + 1) && !(fused_sw != nullptr && fused_sw[0] == '0')) {
     au_flag_fn fn{positions, l.slot_of, nt, nn, sizeof(UKey) == 4 ? 2 : 1, nn_dev, nt_dev};
-    if (late) return chain_scan(fn, nn + 1, l.new_rank, no_tail{}, stream);   // phase 2's kernel publishes
+    if (late) return chain_scan(fn, nn + 1, l.new_rank, no_tail{}, l.scan_state, stream);   // phase 2's kernel publishes
     au_publish_fn pub{nn_dev, nt_dev, nn, nt, new_count_dev, publish_host, bounds != nullptr ? bounds->n_unique_dev : static_cast<int*>(nullptr)};
-    return chain_scan(fn, nn + 1, l.new_rank, pub, stream);
+    return chain_scan(fn, nn + 1, l.new_rank, pub, l.scan_state, stream);
   }
   hipLaunchKernelGGL(au_flag_kernel, dim3((nn + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, positions, l.slot_of, nt, nn,
                      nn_dev, l.first_flag, sizeof(UKey) == 4 ? 2 : 1, nt_dev);
@@ -1190,21 +1196,21 @@ struct degree_fn {
   }
 };
 int hip_sample_offsets(const wholememory_gref_t* row_gref, int64_t row_off, const void* centers, wholememory_dtype_t id_dtype,
-                       int n, const int* n_dev, int max_sample, int* offsets, void* ws, size_t ws_bytes, void* stream_v)
+                       int n, const int* n_dev, int max_sample, int* offsets, void* ws, size_t ws_bytes, int ws_is_ones,
+                       void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const gref_view rv = make_view(*row_gref);
-  (void)ws, (void)ws_bytes;
-  if (!chain_scan_fits(static_cast<int64_t>(n) + 1)) return -3;   // nothing queued: the caller runs count kernel + scan
+  const size_t need  = chain_state_bytes(static_cast<int64_t>(n) + 1);
+  if (!chain_scan_fits(static_cast<int64_t>(n) + 1) || ws == nullptr || ws_bytes < need) return -3;   // nothing queued: count kernel + scan
+  if (id_dtype != WHOLEMEMORY_DT_INT && id_dtype != WHOLEMEMORY_DT_INT64) return -1;
+  if (!ws_is_ones && fill_ff(ws, (need + 15) & ~size_t(15), stream) != 0) return -2;
   if (id_dtype == WHOLEMEMORY_DT_INT) {
     degree_fn<int32_t> fn{rv, row_off, static_cast<const int32_t*>(centers), n, max_sample, n_dev};
-    return chain_scan(fn, n + 1, offsets, no_tail{}, stream);
+    return chain_scan(fn, n + 1, offsets, no_tail{}, ws, stream);
   }
-  if (id_dtype == WHOLEMEMORY_DT_INT64) {
-    degree_fn<int64_t> fn{rv, row_off, static_cast<const int64_t*>(centers), n, max_sample, n_dev};
-    return chain_scan(fn, n + 1, offsets, no_tail{}, stream);
-  }
-  return -1;
+  degree_fn<int64_t> fn{rv, row_off, static_cast<const int64_t*>(centers), n, max_sample, n_dev};
+  return chain_scan(fn, n + 1, offsets, no_tail{}, ws, stream);
 }
 
 size_t hip_scan_i32_ws_bytes(int64_t n)
@@ -1212,8 +1218,9 @@ size_t hip_scan_i32_ws_bytes(int64_t n)
   size_t b = 0;
   (void)rocprim::exclusive_scan(nullptr, b, static_cast<const int*>(nullptr), static_cast<int*>(nullptr), 0,
                                 static_cast<size_t>(n), rocprim::plus<int>(), nullptr);
-  return b + 256;
+  return ((std::max(b, chain_state_bytes(n)) + 255) & ~static_cast<size_t>(255)) + 256;   // (either route's scratch; a multiple of 256)
 }
+int hip_fill_ff(void* ptr, size_t bytes, void* stream) { return fill_ff(ptr, bytes, static_cast<hipStream_t>(stream)); }
 int hip_exclusive_scan_i32(const int* in, int* out, int64_t n, void* ws, size_t ws_bytes, void* stream)
 {
   size_t b = ws_bytes;
@@ -1279,10 +1286,10 @@ int hip_append_unique_table_region(int nt, int nn, wholememory_dtype_t dt, void*
   if (!au_use_table(nt, nn, dt)) return -3;
   if (dt == WHOLEMEMORY_DT_INT) {
     const auto l = au_plan<uint32_t>(ws, nt, nn);
-    *ptr = l.slots, *bytes = l.table_bytes;
+    *ptr = l.scan_state, *bytes = l.table_bytes;
   } else {
     const auto l = au_plan<uint64_t>(ws, nt, nn);
-    *ptr = l.slots, *bytes = l.table_bytes;
+    *ptr = l.scan_state, *bytes = l.table_bytes;
   }
   return 0;
 }

@@ -109,15 +109,22 @@ class PendingMultilayerSample:
         self.padded_frontier = uniques[-1]
         # finish() waits for THIS chain, not for whatever the caller queues behind it (the feature gather on padded_frontier
         # keeps running while the host trims the outputs)
-        self._done = _event_pool.pop() if _event_pool else torch.cuda.Event()
-        self._done.record(stream)
+        # (a chain queued while the stream is being captured into a graph has no event of its own: after the replay the
+        # caller's stream is waited for instead)
+        self._stream, self._done = stream, None
+        if not torch.cuda.is_current_stream_capturing():
+            self._done = _event_pool.pop() if _event_pool else torch.cuda.Event()
+            self._done.record(stream)
 
     def finish(self):
         if self._result is not None:
             return self._result
-        self._done.synchronize()          # the one host round trip of the whole chain
-        _event_pool.append(self._done)
-        self._done = None
+        if self._done is not None:
+            self._done.synchronize()      # the one host round trip of the whole chain
+            _event_pool.append(self._done)
+            self._done = None
+        else:
+            self._stream.synchronize()
         got = self._counts.tolist()
         _pinned_pool.setdefault(self._hops, []).append(self._counts)
         self._counts = None
