@@ -4,8 +4,8 @@
 // the file bytes that land in its own shard (files are logically concatenated and may be re-sharded: any
 // number of files, any sizes; entries of file_entry_size bytes are placed at memory_entry_size strides),
 // with plain or round-robin placement, and stores its own shard. Reads are multi-threaded (WG_LOAD_THREADS_PER_RANK,
-// WG_LOAD_BUFFER_SIZE_MB as in the reference) through pinned double buffers; the O_DIRECT variant
-// (WG_LOAD_USE_DIRECTIO) is not built.
+// WG_LOAD_BUFFER_SIZE_MB as in the reference) through pinned double buffers; WG_LOAD_USE_DIRECTIO=1 opens the files with
+// O_DIRECT and reads block-aligned windows through per-thread bounce buffers (buffered reads where the file system refuses).
 #include <algorithm>
 #include <cerrno>
 #include <cstdio>
