@@ -6,6 +6,8 @@ python experiments/cast_sweep.py --ab       interleaved A/B of the launch shapes
 import os, re, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("WHOLEGRAPH_AMD_VARIANT"):   # scripts/build_variant.sh NAME: A/B of compile-time variants
+    sys.path.insert(0, os.path.join(ROOT, "experiments", "variants", os.environ["WHOLEGRAPH_AMD_VARIANT"]))
 import torch
 import wholegraph_amd.torch as wgth
 from wholegraph_amd import binding as wmb
