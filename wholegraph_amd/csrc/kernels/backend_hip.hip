@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../backend.hpp"
+#include "../knobs.hpp"
 
 namespace wm {
 
@@ -76,6 +77,22 @@ int h_device_count()
 // placement probe that does not fit simply ends the search, memory_handle.cpp:alloc_local)
 int h_malloc_device(void** p, size_t bytes)
 {
+  // WM_MALLOC_CONTIGUOUS=1 (opt-in, round 4): device blocks of WM_MALLOC_CONTIGUOUS_MIN bytes and more (default 1 GiB: table
+  // shards, optimizer states) as PHYSICALLY CONTIGUOUS memory (hipDeviceMallocContiguous), falling back to the plain
+  // allocation when the driver finds no such block. Measured on the 51 GB C2 table: a contiguous table's good level is the
+  // best seen (gather 1.651-1.661 ms = 77.7-78.2 % of peak, scatter 1.56-1.59 ms = 81-82.5 %), but WHICH level a process gets
+  // still varies with where the block lands (gather 4 of 6 processes at the good level, scatter 2 of 6; plain allocations:
+  // 5 of 6 and 0 of 6), creating the table takes 1.5-3.2 s, and the TLB side is unchanged (one UTCL1 miss per random row):
+  // profiles/r04_contiguous_table_ab.txt, r04_six_fresh_processes_contiguous.txt, r04_random_read_pmc.txt. hipIpc export of
+  // such blocks works (the 2- / 3-process tests pass with it). Not the default: the gain is not reliable.
+  const char* c  = WM_KNOB("WM_MALLOC_CONTIGUOUS");
+  const char* cm = WM_KNOB("WM_MALLOC_CONTIGUOUS_MIN");
+  const size_t contiguous_from = cm != nullptr && atoll(cm) > 0 ? static_cast<size_t>(atoll(cm)) : (size_t(1) << 30);
+  if (c != nullptr && c[0] == '1' && bytes >= contiguous_from) {
+    const hipError_t ec = hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
+    if (ec == hipSuccess) return 0;
+    (void)hipGetLastError();
+  }
   const hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) (void)hipGetLastError();
   return rc(e);
