@@ -10,11 +10,13 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 
 namespace wm {
 
 extern std::atomic<unsigned> g_knob_generation;   // wm_common.cpp
+extern std::mutex g_knob_mutex;                    // serialises the (re)loads; the cached read takes no lock
 
 class env_knob {
  public:
@@ -23,18 +25,21 @@ class env_knob {
   const char* str() const
   {
     const unsigned g = g_knob_generation.load(std::memory_order_acquire);
-    if (gen_ != g) {
-      const char* e = std::getenv(name_);
-      set_          = e != nullptr;
-      value_        = set_ ? e : "";
-      gen_          = g;
+    if (gen_.load(std::memory_order_acquire) != g) {   // first use, or a reload was asked for: threads may race to get here
+      std::lock_guard<std::mutex> lk(g_knob_mutex);
+      if (gen_.load(std::memory_order_relaxed) != g) {
+        const char* e = std::getenv(name_);
+        set_          = e != nullptr;
+        value_        = set_ ? e : "";
+        gen_.store(g, std::memory_order_release);
+      }
     }
     return set_ ? value_.c_str() : nullptr;
   }
 
  private:
   const char* name_;
-  mutable unsigned gen_;
+  mutable std::atomic<unsigned> gen_;
   mutable bool set_ = false;
   mutable std::string value_;
 };

@@ -15,6 +15,7 @@
 namespace wm {
 
 std::atomic<unsigned> g_knob_generation{0};
+std::mutex g_knob_mutex;
 
 namespace {
 std::mutex g_gref_mu;
