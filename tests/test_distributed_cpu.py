@@ -50,6 +50,16 @@ def test_multi_rank_on_one_gpu_hip_kernels(wm_lib, world, chunks):
     run_world(world, "hip", {"WM_EXCHANGE_CHUNKS": chunks})
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_on_one_gpu_owner_tables_from_device_arrays(wm_lib, world):
+    """the same scenarios with WM_ROWS_OWNERS_BY_VALUE=0: the row kernels resolve a chunked row's owner from the gref's
+    DEVICE arrays (what a hand-built gref gets) — the multiply-high that replaced the reference's 64-bit divide
+    (device_reference.cuh:47) for equal chunks, the search over rank offsets for custom partitions — instead of from the
+    owner tables passed by value."""
+    run_world(world, "hip", {"WM_EXCHANGE_CHUNKS": "1", "WM_ROWS_OWNERS_BY_VALUE": "0"})
+
+
 @pytest.mark.parametrize("world,chunks", [(1, "1"), (2, "1"), (2, "3"), (3, "1"), (3, "3"), (8, "4")])
 def test_distributed_paths_over_gloo(wm_lib, world, chunks):
     # always through make: the test backend shares struct layouts with csrc/backend.hpp and must be rebuilt when that
