@@ -51,8 +51,10 @@ def parse():
     p.add_argument("--rows", type=int, default=0, help="table rows per GPU (default: 100M at N=1, 125M at N>1)")
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--indices", type=int, default=10_000_000)
-    p.add_argument("--dist", choices=["uniform", "zipf", "zipf_clustered", "sequential"], default="uniform",
-                   help="sequential (ids 0, 1, 2 ...: the row kernel as a plain streaming copy) is a diagnostic ceiling, not a workload")
+    p.add_argument("--dist", choices=["uniform", "zipf", "zipf_clustered", "sequential", "paged", "paged64k"], default="uniform",
+                   help="diagnostics, not workloads: sequential = ids 0, 1, 2 ... (the row kernel as a plain streaming copy); paged = "
+                        "the uniform ids grouped by the 2 MiB page of their row (random inside a page: the DRAM side stays random, "
+                        "the TLB side becomes sequential); paged64k = the same with 64 KiB groups")
     p.add_argument("--memory-type", default="", help="override: continuous|chunked|distributed")
     p.add_argument("--location", default="cuda", help="cuda|cpu (HOST-located table, config C1)")
     p.add_argument("--op", choices=["gather", "scatter", "grad_apply", "sample_gather"], default="gather",
@@ -91,6 +93,9 @@ def make_indices(n, total_rows, dist, seed):
         return (np.arange(n, dtype=np.int64) + (seed % 7) * n) % total_rows
     if dist == "uniform":
         return rng.integers(0, total_rows, n, dtype=np.int64)
+    if dist in ("paged", "paged64k"):   # (512-byte rows: 4096 rows per 2 MiB page, 128 per 64 KiB)
+        ids = rng.integers(0, total_rows, n, dtype=np.int64)
+        return ids[np.argsort(ids >> (12 if dist == "paged" else 7), kind="stable")]
     # Zipf(s = 1.05) popularity rank k; hashed to a row so hot rows spread over owners,
     # or clustered (idx = k: every hot row on rank 0 = worst-case link skew)
     k = rng.zipf(1.05, n).astype(np.uint64)
