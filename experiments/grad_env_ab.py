@@ -5,6 +5,8 @@ a call depends on the process's table placement, so only in-process comparisons 
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("WHOLEGRAPH_AMD_VARIANT"):   # scripts/build_variant.sh NAME: A/B of compile-time variants
+    sys.path.insert(0, os.path.join(ROOT, "experiments", "variants", os.environ["WHOLEGRAPH_AMD_VARIANT"]))
 import numpy as np
 import torch
 import wholegraph_amd.torch as wgth
