@@ -13,8 +13,14 @@
 //    global_store_dwordx4): a 512 B fp32 row is 32 lanes x 16 B, so a step moves two whole rows as
 //    one 1 KiB wave transaction; row base addresses travel between lanes with v_readlane (fast /
 //    batch kernels) or ds_bpermute (generic and flat kernels): no LDS allocation, no barriers;
-//  * all loads of a batch (4 steps = 4 KiB per wave) are issued before its first store (Little's
-//    law: ~10 MB chip-wide are needed to cover ~2 us of loaded HBM latency at 5-6 TB/s);
+//  * all loads of a batch (4 steps = 4 KiB per wave) are issued before its first store — in the ISA, not only in the source:
+//    every kernel tests once per tile whether all its entries move (wave-uniform) and then runs a straight-line batch with
+//    nothing predicated (lanes without work of their own repeat the last piece); a conditionally defined load result or a
+//    predicated store is enough for hipcc to wait for every load (round 3 shipped that). scripts/check_isa.py disassembles
+//    the shipped library and gates the shape; tests/test_isa_gate.py runs it;
+//  * the owner of a row of a chunked table is found from KERNEL ARGUMENTS (bases and bounds of up to 8 ranks, host copies of
+//    the gref's device arrays) — no 64-bit divide, no dependent load of the peer pointer; hand-built grefs take the device
+//    arrays and a multiply-high by a host-computed magic number;
 //  * the streamed side (gather output / scatter input) is touched exactly once: non-temporal on
 //    both sides, which keeps L2 / Infinity Cache for table rows (which DO repeat under skew);
 //  * launch shape (round 3, see rows_op): IN ORDER — one ~4 KiB tile per wave and as many workgroups
