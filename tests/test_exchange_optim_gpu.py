@@ -517,6 +517,47 @@ def test_tree_fold_is_the_default_of_the_16bit_extension_and_deterministic(gpu_e
     assert np.array_equal(results[0].astype(np.float64), want.astype(np.float16).astype(np.float64))
 
 
+def test_grad_fold_is_an_optimizer_parameter(gpu_env):
+    """create_wholememory_optimizer(emb, "sgd", {"grad_fold": "tree"}) (-> wholememory_optimizer_set_parameter(opt, "grad_fold",
+    1.0)): a user selects the tree fold without touching the environment. One id with 20 000 duplicate gradient rows:
+    "ordered" (and the default of an fp32 table) reproduces the receive-order sum bit for bit, "tree" differs from it in the
+    last bits on real-valued gradients (so the parameter did reach the kernels), stays within the fp32 forward-error bound of
+    the exact sum, and is exact — equal to the ordered result — on integer-valued gradients."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    n_rows, dim, n = 5003, 128, 30_000
+    rng = np.random.default_rng(77)
+    ids = rng.integers(0, n_rows, n).astype(np.int64)
+    ids[:20_000] = 1234
+    results = {}
+    for grads_kind in ("real", "integer"):
+        g = rng.standard_normal((n, dim)).astype(np.float32) if grads_kind == "real" else rng.integers(-3, 4, (n, dim)).astype(np.float32)
+        for fold in (None, "ordered", "tree"):
+            emb = wgth.create_embedding(gpu_env, "chunked", "cuda", torch.float32, [n_rows, dim])
+            local, _ = emb.get_embedding_tensor().get_local_tensor()
+            local.zero_()
+            opt = wgth.create_wholememory_optimizer(emb, "sgd", {} if fold is None else {"grad_fold": fold})
+            emb.add_gradients(torch.from_numpy(ids).cuda(), torch.from_numpy(g).cuda())
+            emb.need_apply = True
+            emb.apply_gradients(-1.0)                       # lr = -1, wd = 0: scatter-add
+            torch.cuda.synchronize()
+            results[(grads_kind, fold)] = local[:, :dim].cpu().numpy().copy()
+            wgth.destroy_wholememory_optimizer(opt)
+            wgth.destroy_embedding(emb)
+        exact = np.zeros((n_rows, dim), np.float64)
+        np.add.at(exact, ids, g.astype(np.float64))
+        ordered, tree, default = results[(grads_kind, "ordered")], results[(grads_kind, "tree")], results[(grads_kind, None)]
+        assert default.tobytes() == ordered.tobytes()                      # fp32 tables: the reference's order unless asked
+        uniq, dg = oracle.dedup_grads(ids, g)
+        assert ordered[uniq].tobytes() == dg[:, :dim].astype(np.float32).tobytes()   # the receive-order sum, bit for bit
+        if grads_kind == "integer":
+            assert tree.tobytes() == ordered.tobytes() and np.array_equal(tree.astype(np.float64), exact)
+        else:
+            assert tree.tobytes() != ordered.tobytes(), "the grad_fold parameter did not reach the kernels"
+            bound = 20_000 * np.finfo(np.float32).eps * np.abs(g[:20_000]).sum(axis=0).max()
+            assert np.abs(tree.astype(np.float64) - exact).max() <= bound
+
+
 @pytest.mark.parametrize("kind,code,params", [("adam", 2, {"weight_decay": 0.01}), ("adam", 2, {"weight_decay": 0.02, "adam_w": 1.0}),
                                               ("rmsprop", 3, {"alpha": 0.9}), ("adagrad", 4, {"weight_decay": 0.01})])
 @pytest.mark.parametrize("dim,idt", [(128, np.int64), (36, np.int32)])

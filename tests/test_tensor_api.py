@@ -104,6 +104,9 @@ def test_equal_partition_plan_and_optimizer_objects(wm_lib):
             assert wm_lib.wholememory_optimizer_set_parameter(o, g.encode(), C.byref(val)) == 0
         for b in bad:
             assert wm_lib.wholememory_optimizer_set_parameter(o, b.encode(), C.byref(val)) == 6
+        # extension: the order of the duplicate sum is a parameter of every optimizer (-1 default of the dtype, 0 ordered, 1 tree)
+        for fold in (-1.0, 0.0, 1.0):
+            assert wm_lib.wholememory_optimizer_set_parameter(o, b"grad_fold", C.byref(C.c_float(fold))) == 0
         wm_lib.wholememory_destroy_embedding_optimizer(o)
     o = C.c_void_p()
     assert wm_lib.wholememory_create_embedding_optimizer(C.byref(o), B.OPT_NONE) == 2
