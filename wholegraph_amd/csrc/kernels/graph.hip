@@ -86,24 +86,28 @@ __device__ __forceinline__ T gref_load(const gref_view& v, int64_t elem_index)
 // scan is two launches — state initialisation + scan — and a separate kernel has to materialise its input first: on the C5
 // step that was 6 of 20 launches, each at the ~5 us floor of a tiny launch). Decoupled look-back over tiles of
 // kChainTile values:
-//  * a block takes its tile number from a TICKET, so it only ever waits for tiles that are already running — no assumption
-//    about dispatch order or about all blocks being resident;
+//  * tiles are dealt to blocks STATICALLY — block b takes tiles b, b + G, b + 2 G ... of a grid of G <= 1 x the CU count
+//    blocks, all of which are resident together (256 threads, < 64 VGPRs: a CU holds eight of them), so a block only ever
+//    waits for tiles whose blocks are running. (The first version took tile numbers from an atomic ticket, which needs no
+//    residency argument but serialises: ~27 ns per ticket at the memory-side atomic unit — 100 us for the 3720 tiles of the
+//    952 k-value scan with 256-value tiles, 6 us of the 25 us with 4096-value tiles. profiles/r04_c5_flows.txt);
 //  * the values of a thread (1, 4 or 16) are evaluated before anything else (fn may be a chain of random loads: they are all in flight
 //    together), then thread / wave / block scans, the tile's aggregate is published, wave 0 looks back over the published
 //    words of its predecessors (status in the top two bits: 1 = aggregate, 2 = inclusive prefix), publishes the inclusive
 //    prefix, and the block writes its outputs. A status word carries its whole message (flag + value in one 64-bit atomic),
 //    so the accesses are RELAXED agent-scope atomics: an acquire / release pair at agent scope is an L2 invalidate / write-back
 //    on this part (the XCDs' L2s are not coherent with each other) — with those the 465-tile scan of the C5 hop took 153 us;
-//  * the state (ticket + one word per tile) is caller-provided scratch that must read ALL-ONES on entry (every word is
-//    stored complemented, so that the 0xFF fill which empties append_unique's hash table initialises a scan state lying next
-//    to it in the same stroke) and is SELF-CLEANING: the last block to finish (second counter) puts it back to all-ones.
-//    Nothing is allocated and nothing waits: the launch can be captured into a hipGraph and replayed.
+//  * the state (one word per tile behind a 16-byte header) is caller-provided scratch that must read ALL-ONES on entry — every
+//    word is stored complemented, so that the 0xFF fill which empties append_unique's hash table initialises a scan state
+//    lying next to it in the same stroke — and is left used: the caller fills it again before the next scan (the chain of
+//    hops fills all its scan states with one kernel, the single-hop calls fill their own). Nothing is allocated and nothing
+//    on the host waits: the launch can be captured into a hipGraph and replayed.
 // `tail(total)` runs once, on the thread that owns value n - 1 (total = the sum of all n values): the place for what used
 // to be a one-thread publishing kernel.
 constexpr int kChainThreads = 256;   // values per tile: 256 x ITEMS, ITEMS = 1 / 4 / 16 by the size of the scan (chain_scan)
 constexpr int kChainMaxTiles = 16384;   // 67 M values at 16 per thread; bigger scans take rocPRIM
-struct chain_state {   // (stored complemented: all-ones = {ticket 0, done 0, no status})
-  unsigned int ticket, done, pad[2];
+struct chain_state {   // (stored complemented: all-ones = no status)
+  unsigned int pad[4];
   unsigned long long status[1];   // one word per tile
 };
 inline size_t chain_state_bytes(int64_t n) { return 16 + 8 * static_cast<size_t>((n + 255) / 256) + 16; }   // room for the smallest tile size
@@ -115,19 +119,25 @@ template <typename Fn, typename Tail, int kChainItems>
 __global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n, int* out, chain_state* st, Tail tail)
 {
   constexpr int kChainTile = kChainThreads * kChainItems;
-  __shared__ int s_tile, s_excl, s_last;
+  __shared__ int s_excl;
   __shared__ int s_wave[kChainThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) {
-    s_tile = static_cast<int>(~atomicSub(&st->ticket, 1u));   // complemented counter: all-ones = 0, counts down
-    s_last = 0;
-  }
-  __syncthreads();
-  const int tile = s_tile;
+  const int n_tiles = (n + kChainTile - 1) / kChainTile;
+  // the functor reads its device-side counts ONCE, here; `live` false = every value is 0 and nothing may be read
+  const bool live = fn.prepare();
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
   const int i0   = tile * kChainTile + tid * kChainItems;
   int v[kChainItems];
 #pragma unroll
-  for (int k = 0; k < kChainItems; k++) v[k] = i0 + k < n ? fn(i0 + k) : 0;
+  for (int k = 0; k < kChainItems; k++) v[k] = 0;
+  if (live) {   // ONE guard around the thread's values: inside it the index is clamped and the value masked, nothing is predicated,
+                // so the load chains of all values are in flight together (a guard per value: one waited load after the other)
+#pragma unroll
+    for (int k = 0; k < kChainItems; k++) {
+      const int x = fn(min(i0 + k, n - 1));
+      v[k]        = x & -static_cast<int>(i0 + k < n);   // (arithmetic mask, not a select: hipcc sinks a load into the branch that needs it)
+    }
+  }
   int sum = 0;
 #pragma unroll
   for (int k = 0; k < kChainItems; k++) {   // exclusive within the thread
@@ -191,12 +201,7 @@ __global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n,
       if (i0 + k < n) out[i0 + k] = base + v[k];
   }
   if (i0 <= n - 1 && n - 1 < i0 + kChainItems) tail(base + sum);
-  // the last block to get here puts the state back to all-ones (every look-back has ended: a block counts itself done after its own)
-  if (tid == 0 && ~atomicSub(&st->done, 1u) == gridDim.x - 1) s_last = 1;
-  __syncthreads();
-  if (s_last) {
-    for (int j = tid; j < static_cast<int>(gridDim.x); j += kChainThreads) st->status[j] = ~0ull;
-    if (tid == 0) st->ticket = ~0u, st->done = ~0u;
+  __syncthreads();   // s_excl / s_wave are reused by the block's next tile
   }
 }
 
@@ -235,7 +240,12 @@ int chain_scan(Fn fn, int n, int* out, Tail tail, void* state, hipStream_t strea
     if ((v == 1 || v == 4 || v == 16) && (static_cast<int64_t>(n) + 256 * v - 1) / (256 * v) <= kChainMaxTiles) items = v;
   }
   const int tile = kChainThreads * items;
-  const dim3 grid((n + tile - 1) / tile), block(kChainThreads);
+  static const int cus = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 64;
+  }();
+  const dim3 grid(std::min((n + tile - 1) / tile, std::max(cus, 1))), block(kChainThreads);   // all blocks resident together
   if (items == 1) hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, 1>), grid, block, 0, stream, fn, n, out, st, tail);
   else if (items == 4) hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, 4>), grid, block, 0, stream, fn, n, out, st, tail);
   else hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, 16>), grid, block, 0, stream, fn, n, out, st, tail);
@@ -825,11 +835,20 @@ struct au_flag_fn {   // au_flag_kernel as a function of the neighbour position:
   const uint32_t* slot_of;
   int nt, nn, stride;
   const int *nn_dev, *nt_dev;
+  int used, nt_use;   // filled by prepare()
+  __device__ bool prepare()
+  {
+    used   = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+    nt_use = nt_dev != nullptr ? min(nt, *nt_dev) : nt;
+    return used > 0;
+  }
+  // (clamp the position, mask the result: a load behind a per-lane `p < used` is a conditionally defined value, and the 16
+  // values of a thread would be fetched one after the other — the same trap as in the row kernels)
   __device__ int operator()(int p) const
   {
-    const int used   = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
-    const int nt_use = nt_dev != nullptr ? min(nt, *nt_dev) : nt;
-    return p < used && min_pos[static_cast<size_t>(slot_of[nt + p]) * stride] == static_cast<uint32_t>(nt_use + p) ? 1 : 0;
+    const int pc     = min(p, used - 1);
+    const uint32_t m = min_pos[static_cast<size_t>(slot_of[nt + pc]) * stride];
+    return static_cast<int>(p < used) & static_cast<int>(m == static_cast<uint32_t>(nt_use + p));   // (no short circuit: see chain_scan_kernel)
   }
 };
 struct au_publish_fn {   // au_publish_kernel as the scan's tail: `total` = the number of new unique neighbours
@@ -908,7 +927,7 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
   // against 6.8 + 5.9 us for flag kernel + plain scan, which is why round 3 kept four launches here). WM_AU_FUSED_SCAN=0: A/B.
   const char* fused_sw = WM_KNOB("WM_AU_FUSED_SCAN");
   if (chain_scan_fits(static_cast<int64_t>(nn) + 1) && !(fused_sw != nullptr && fused_sw[0] == '0')) {
-    au_flag_fn fn{positions, l.slot_of, nt, nn, sizeof(UKey) == 4 ? 2 : 1, nn_dev, nt_dev};
+    au_flag_fn fn{positions, l.slot_of, nt, nn, sizeof(UKey) == 4 ? 2 : 1, nn_dev, nt_dev, 0, 0};
     if (late) return chain_scan(fn, nn + 1, l.new_rank, no_tail{}, l.scan_state, stream);   // phase 2's kernel publishes
     au_publish_fn pub{nn_dev, nt_dev, nn, nt, new_count_dev, publish_host, bounds != nullptr ? bounds->n_unique_dev : static_cast<int*>(nullptr)};
     return chain_scan(fn, nn + 1, l.new_rank, pub, l.scan_state, stream);
@@ -1183,16 +1202,21 @@ struct degree_fn {
   const IdT* centers;
   int n, max_sample;
   const int* n_dev;   // optional: centres in use of the n the arrays are sized for
+  int used;           // filled by prepare()
+  __device__ bool prepare()
+  {
+    used = n_dev != nullptr ? min(n, *n_dev) : n;
+    return used > 0;
+  }
   __device__ int operator()(int i) const
   {
-    const int used = n_dev != nullptr ? min(n, *n_dev) : n;
-    if (i >= used) return 0;  // the scan runs over n + 1 entries (reference :334-338)
-    const int64_t nid = static_cast<int64_t>(centers[i]);
+    // clamped index, masked result (see au_flag_fn): the scan runs over n + 1 entries, the ones past `used` count 0 (reference :334-338)
+    const int64_t nid = static_cast<int64_t>(centers[min(i, used - 1)]);
     const int64_t s   = gref_load<int64_t>(row_ptr, row_off + nid);
     const int64_t e   = gref_load<int64_t>(row_ptr, row_off + nid + 1);
     int deg           = static_cast<int>(e - s);
     if (max_sample > 0) deg = min(deg, max_sample);
-    return deg;
+    return deg & -static_cast<int>(i < used);
   }
 };
 int hip_sample_offsets(const wholememory_gref_t* row_gref, int64_t row_off, const void* centers, wholememory_dtype_t id_dtype,
@@ -1206,10 +1230,10 @@ int hip_sample_offsets(const wholememory_gref_t* row_gref, int64_t row_off, cons
   if (id_dtype != WHOLEMEMORY_DT_INT && id_dtype != WHOLEMEMORY_DT_INT64) return -1;
   if (!ws_is_ones && fill_ff(ws, (need + 15) & ~size_t(15), stream) != 0) return -2;
   if (id_dtype == WHOLEMEMORY_DT_INT) {
-    degree_fn<int32_t> fn{rv, row_off, static_cast<const int32_t*>(centers), n, max_sample, n_dev};
+    degree_fn<int32_t> fn{rv, row_off, static_cast<const int32_t*>(centers), n, max_sample, n_dev, 0};
     return chain_scan(fn, n + 1, offsets, no_tail{}, ws, stream);
   }
-  degree_fn<int64_t> fn{rv, row_off, static_cast<const int64_t*>(centers), n, max_sample, n_dev};
+  degree_fn<int64_t> fn{rv, row_off, static_cast<const int64_t*>(centers), n, max_sample, n_dev, 0};
   return chain_scan(fn, n + 1, offsets, no_tail{}, ws, stream);
 }
 
