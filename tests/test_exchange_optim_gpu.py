@@ -600,3 +600,57 @@ def test_tree_fold_stateful_optimizers_exact_on_integer_gradients(gpu_env, knobs
     assert d_pe.cpu().numpy().tobytes() == ref_opt.per_element.tobytes()
     if kind == "adam":
         assert d_pr.cpu().numpy().tobytes() == ref_opt.per_row.tobytes()
+
+
+@pytest.mark.parametrize("mt", ["chunked", "distributed"])
+@pytest.mark.parametrize("kind,params", [("sgd", {}), ("adam", {"weight_decay": 0.01})])
+def test_embedding_row_align_knob(gpu_env, knobs, tmp_path, mt, kind, params):
+    """Extension, opt-in: WM_EMBEDDING_ROW_ALIGN=128 pads the row stride of embeddings (and of their optimizer states) to whole
+    128-byte lines instead of the reference's 16 bytes (embedding.cpp:43-50). Everything a user sees is unchanged: the logical
+    shape, gather / training results (bit for bit against the oracle on the reference's 16-byte stride) and the files."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    knobs.set("WM_EMBEDDING_ROW_ALIGN", 128)
+    n_rows, dim, n_idx = 40001, 50, 30005          # 200 B rows -> stride 64 elements
+    emb = wgth.create_embedding(gpu_env, mt, "cuda", torch.float32, [n_rows, dim])
+    assert emb.get_embedding_tensor().stride() == (64, 1) and emb.shape == (n_rows, dim)
+    rng = np.random.default_rng(5)
+    init = rng.standard_normal((n_rows, dim)).astype(np.float32)
+    local, _ = emb.get_embedding_tensor().get_local_tensor()
+    local.copy_(torch.from_numpy(init).cuda())
+    opt = wgth.create_wholememory_optimizer(emb, kind, params)
+    module = wgth.WholeMemoryEmbeddingModule(emb)
+    module.train()
+    padded = np.zeros((n_rows, 52), np.float32)     # the oracle keeps the reference's stride
+    padded[:, :dim] = init
+    tab = oracle.ShardedTable.from_full(padded, 1)
+    tab.dim = dim
+    ref_opt = oracle.Optimizer(kind, n_rows, 52, **params)
+    for step in range(2):
+        idx = rng.integers(0, n_rows, n_idx).astype(np.int64)
+        idx[::3] = idx[0]
+        w = rng.standard_normal((n_idx, dim)).astype(np.float32)
+        out = module(torch.from_numpy(idx).cuda())
+        exp_out = np.zeros((n_idx, dim), np.float32)
+        oracle.gather(tab, idx, exp_out)
+        assert out.detach().cpu().numpy().tobytes() == exp_out.tobytes()
+        (out * torch.from_numpy(w).cuda()).sum().backward()
+        opt.step(0.02)
+        oracle.gradient_apply(tab, [ref_opt], [idx], [w], 0.02)
+        torch.cuda.synchronize()
+        assert local.cpu().numpy().tobytes() == tab.shards[0][:, :dim].tobytes(), "step %d" % step
+    # files hold logical rows: written with the wide stride, read back into a table with the reference's stride
+    prefix = str(tmp_path / "aligned")
+    emb.save(prefix)
+    raw = np.fromfile(prefix + "_embedding_tensor_part_0_of_1", dtype=np.float32).reshape(n_rows, dim)
+    assert raw.tobytes() == tab.shards[0][:, :dim].tobytes()
+    knobs.unset("WM_EMBEDDING_ROW_ALIGN")
+    emb2 = wgth.create_embedding(gpu_env, mt, "cuda", torch.float32, [n_rows, dim])
+    assert emb2.get_embedding_tensor().stride() == (52, 1)
+    emb2.load(prefix, ignore_embedding=False) if kind == "sgd" else emb2.get_embedding_tensor().from_file_prefix(prefix + "_embedding_tensor")
+    torch.cuda.synchronize()
+    local2, _ = emb2.get_embedding_tensor().get_local_tensor()
+    assert local2.cpu().numpy().tobytes() == raw.tobytes()
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)
+    wgth.destroy_embedding(emb2)

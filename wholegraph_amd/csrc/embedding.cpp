@@ -69,7 +69,17 @@ namespace {
 
 int64_t align_embedding_dim(int64_t dim, size_t element_size)
 {  // rows padded to 16 bytes: reference embedding.cpp:43-50
-  const int64_t a = 16 / static_cast<int64_t>(element_size);
+  // Extension, opt-in: WM_EMBEDDING_ROW_ALIGN=<32 ... 4096, a power of two> pads the row stride to that many bytes instead.
+  // Rows that start on whole 128-byte lines are written without partial lines at either end: scatter / gradient apply of
+  // 800 B rows 56 -> 74 % of the HBM peak at stride 1024, 4000 B rows 60 -> 74 % (profiles/r04_misaligned_rows.txt); the
+  // gather, bound by its dense output, gains nothing. Costs the padding in HBM; files are per logical row and do not change.
+  int64_t bytes = 16;
+  if (const char* e = WM_KNOB("WM_EMBEDDING_ROW_ALIGN")) {
+    const int64_t v = atoll(e);
+    if (v >= 16 && v <= 4096 && (v & (v - 1)) == 0) bytes = v;
+    else WM_WARN("WM_EMBEDDING_ROW_ALIGN=%s ignored: a power of two between 16 and 4096 is expected", e);
+  }
+  const int64_t a = bytes / static_cast<int64_t>(element_size);
   return dim % a == 0 ? dim : (dim / a + 1) * a;
 }
 

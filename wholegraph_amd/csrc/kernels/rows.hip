@@ -476,6 +476,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, WM_BA
 }
 
 
+
 // Rows whose size is not a power of two (400 B, 1200 B, 2408 B ... : dims 100 / 300 / 602 of common GNN datasets), and
 // 1 KiB rows. The pow-of-two lane mapping above leaves lanes idle and walks a big row in several passes; here the tile is
 // a FLAT STREAM of 16-byte slots: slot v of the tile belongs to row v / S, column v % S (S slots per row), lane l of
@@ -488,6 +489,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, WM_BA
 // as conditional dword accesses inside the slot loop: 100-104 VGPRs and a wait after every load).
 // A batch is kU x 64 slots: in a tile whose entries all move it is straight-line code, loads issued back to back and then
 // the stores (slots past the end of the tile repeat its last slot).
+// (A variant without the per-slot division and ds_bpermute — row bases in SGPRs, ceil(S / 64) wave instructions per row with
+// idle lanes — measured equal within +-2 points on 528 B ... 4000 B rows, profiles/r04_misaligned_rows.txt: what these rows
+// lose against the powers of two is partial cache lines, not instructions.)
 template <typename IdxT, bool GATHER, bool HAS_MAP>
 __global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
 {
@@ -1285,6 +1289,13 @@ int rows_op(const wm_rows_args* a, void* stream_v)
           const int r1    = std::max(1, 256 / S), r2 = std::max(1, 512 / S);
           const double f1 = r1 * S / 256.0, f2 = r2 * S / 512.0;
           p.tile_rows     = std::min(kWave, (S > 256 || f1 >= 0.8 || f2 <= f1) ? r1 : r2);
+          // gather of rows of whole 16-byte pieces: 8 rows per tile whatever S is. The dense side of a tile is then a multiple
+          // of 128 bytes and every wave store a whole, aligned 1 KiB of it; with tiles that begin on 32-byte multiples each
+          // wave writes two partial lines (4000 B rows on a packed output 64 % against 71 % on an output padded to 4 KiB,
+          // profiles/r04_misaligned_rows.txt). Measured: 528 B +2.3, 640 B +2.0, 800 B +2.2, 2000 B +3.0, 4000 B +2.0 points,
+          // 960 / 1200 / 1600 B within +-0.7. (WM_ROWS_FLAT_TILE8=0: the batch-filling rule above, A/B)
+          const char* t8 = WM_KNOB("WM_ROWS_FLAT_TILE8");
+          if (GATHER && vb == 16 && p.row_map == nullptr && !(t8 != nullptr && t8[0] == '0')) p.tile_rows = 8;
         } else {                  // readlane kernel: (tile_rows / RPS) x chunks steps, a multiple of its 4-step batch
           const int chunks = p.row_vecs > 32 ? (p.row_vecs + kWave - 1) / kWave : 1;
           p.tile_rows      = p.row_vecs == 32 ? 8 : chunks == 1 ? 4 : chunks == 2 ? 2 : chunks % 4 == 0 ? 1 : 4;
