@@ -121,6 +121,7 @@ struct rows_params {
   int tile_rows;
   // LDS-staged gather (rows_staged_gather_kernel): rows per chunk (a power of two, chunk bytes a multiple of 16), 0 = not used
   int stage_rows;
+  int stage_align;                 // staged gather: wave stores shifted onto the 128-byte lines of the output (1) or begun with the chunk (0)
   // host side only: threads per workgroup of this launch (a multiple of 64, <= kBlock; the kernels read blockDim)
   int launch_threads;
   // host side only: 32 / 64 / 128 / 256 = this launch takes rows_batch_kernel<..., that many 16-byte pieces per row>
@@ -627,9 +628,12 @@ __global__ __launch_bounds__(kBlock) void rows_staged_gather_kernel(rows_params 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- LDS -> the contiguous, 16-byte aligned output stream
-        for (int v = lane; v < chunk_vecs; v += kWave)
-          st_global_nt<u32x4>(out + v * 16, *reinterpret_cast<const u32x4*>(lds + v * 16));
+        // ---- LDS -> the contiguous, 16-byte aligned output stream. The lanes are shifted so that every wave store begins on a
+        // 128-byte line of the output (the chunk itself begins wherever R rows put it): whole-line writes except at the two
+        // ends of the chunk (what writes that begin inside a line cost: profiles/r04_misaligned_rows.txt)
+        const int head = p.stage_align ? __builtin_amdgcn_readfirstlane(static_cast<int>((reinterpret_cast<uint64_t>(out) >> 4) & 7)) : 0;
+        for (int v = lane - head; v < chunk_vecs; v += kWave)
+          if (v >= 0) st_global_nt<u32x4>(out + v * 16, *reinterpret_cast<const u32x4*>(lds + v * 16));
         __builtin_amdgcn_wave_barrier();                      // the next chunk overwrites the region
       } else {
         // ---- a skipped entry inside the chunk: row by row, dword stores at the rows' natural alignment
@@ -1260,6 +1264,10 @@ int rows_op(const wm_rows_args* a, void* stream_v)
       while (R > need && static_cast<int64_t>(R) * row_bytes > cap) R >>= 1;
       if (static_cast<int64_t>(R) * row_bytes <= cap) {   // bigger rows stay on the flat kernel
         p.stage_rows = R;
+        {
+          const char* sa = WM_KNOB("WM_ROWS_STAGED_ALIGN_STORES");
+          p.stage_align  = (sa != nullptr && sa[0] == '0') ? 0 : 1;
+        }
         if (inorder_mode == 0 || a->max_blocks > 0 || a->n >= (INT64_C(1) << 31)) {
           inorder          = false;
           p.launch_threads = kBlock;
