@@ -16,7 +16,8 @@ comm = wgth.create_group_communicator(1)
 es = {torch.float32: 4, torch.float16: 2, torch.bfloat16: 2}
 SETTINGS = [("default", {})]
 if "--ab" in sys.argv:
-    SETTINGS = [("default", {}), ("inorder 64-row tiles", {"WM_ROWS_SMALL_TILE": "0"}), ("persistent", {"WM_ROWS_INORDER": "0"})]
+    SETTINGS = [("default", {}), ("inorder 64-row tiles", {"WM_ROWS_SMALL_TILE": "0"}), ("persistent", {"WM_ROWS_INORDER": "0"}),
+                ("nt", {"WM_ROWS_CONVERT_NT": "1"})]
 if os.environ.get("CAST_SWEEP_SETTINGS"):
     SETTINGS = [x for x in SETTINGS if x[0] in os.environ["CAST_SWEEP_SETTINGS"].split(",")]
 KEYS = sorted({k for _, e in SETTINGS for k in e})

@@ -13,9 +13,8 @@ wmb.check(wmb.lib().wholememory_init(0, wmb.LEVEL_WARN))
 comm = wgth.create_group_communicator(1)
 dims = [int(x) for x in sys.argv[1:]] or [132, 136, 160, 200, 240, 300, 400, 500, 1000]
 SCAT = {"WM_ROWS_STAGED_SCATTER": "0", "WM_ROWS_FLAT": "1", "WM_ROWS_INORDER": "1"}
-settings = {"gather": [("default", {}), ("batch-filling tiles", {"WM_ROWS_FLAT_TILE8": "0"}), ("staged stores from the chunk start", {"WM_ROWS_STAGED_ALIGN_STORES": "0"})],
-            "scatter": [("default", {}), ("flat inorder", SCAT)]}
-knobs = ("WM_ROWS_STAGED_ALIGN_STORES", "WM_ROWS_FLAT_TILE8", "WM_ROWS_STAGED_SCATTER", "WM_ROWS_FLAT", "WM_ROWS_INORDER", "WM_ROWS_TILE")
+settings = {"gather": [("default", {}), ("flat nt loads", {"WM_ROWS_FLAT_NT": "1"})], "scatter": []}
+knobs = ("WM_ROWS_FLAT_NT", "WM_ROWS_COPY_NT", "WM_ROWS_STAGED", "WM_ROWS_STAGED_ALIGN_STORES", "WM_ROWS_FLAT_TILE8", "WM_ROWS_STAGED_SCATTER", "WM_ROWS_FLAT", "WM_ROWS_INORDER", "WM_ROWS_TILE")
 for dim in dims:
     rows = int(8e9 // (dim * 4)); n = int(min(10_000_000, 4e9 // (dim * 4)))
     emb = wgth.create_embedding(comm, "chunked", "cuda", torch.float32, [rows, dim])

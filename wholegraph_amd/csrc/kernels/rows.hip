@@ -244,7 +244,10 @@ __global__ __launch_bounds__(kBlock) void rows_copy_kernel(rows_params p)
             char* t      = shfl_ptr(my_tab, el);
             char* q      = shfl_ptr(my_plain, el);
             dst[u]       = (GATHER ? q : t) + coff;
-            data[u]      = ld_global<vec_t>((GATHER ? t : q) + coff);
+            // gather: the table row is read once (non-temporal: 16 / 32 / 64 B rows 18.1 -> 19.8, 30.2 -> 32.6, 48.1 -> 51.8 % of
+            // peak); scatter: the dense rows stay cached loads and the table stores cached stores (non-temporal loads 100 B
+            // 23.2 -> 22.3, 132 B 26.1 -> 24.5, stores another -0.5: partial lines of neighbouring tiles meet in L2)
+            data[u]      = GATHER ? ld_global_nt<vec_t>(t + coff) : ld_global<vec_t>(q + coff);
           }
 #pragma unroll
           for (int u = 0; u < kU; u++) {
@@ -534,7 +537,9 @@ __global__ __launch_bounds__(kBlock) void rows_flat_kernel(rows_params p)
           char* q = HAS_MAP ? shfl_ptr(my_plain, row) : plain_tile + row * p.plain_stride_bytes;
           dst[u]  = (GATHER ? q : t) + off;   // a slot past the end of the tile repeats its last slot: same bytes, same place
           if constexpr (GATHER)
-            data[u] = ld_global<u32x4>(t + off);  // rows share cache lines with their neighbours: keep them
+            // rows share cache lines with their neighbours: kept (non-temporal: 528-640 B rows +1.3 ... +2.6 points, 800 B - 4000 B
+            // -0.9 ... -1.6 in one session and +3.0 / +1.9 / -0.8 at 800 / 1200 / 4000 B in another: no rule, round 4)
+            data[u] = ld_global<u32x4>(t + off);
           else
             data[u] = ld_global_nt<u32x4>(q + off);
         }
@@ -740,34 +745,42 @@ struct alignas(sizeof(T) * V) elt_vec {
 
 // struct-typed accesses through an address-space pointer fall back to FLAT (the copy goes through a generic reference):
 // move the bytes as a plain vector of the same size and reinterpret them in registers
-template <typename S>
+template <typename S, bool NT = false>
 __device__ __forceinline__ S ld_global_pod(const void* p)
 {
   constexpr size_t N = sizeof(S);
   static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32, "element vector size");
   S out;
   if constexpr (N == 32) {
-    u32x4 r[2] = {ld_global<u32x4>(p), ld_global<u32x4>(static_cast<const char*>(p) + 16)};
+    u32x4 r[2] = {NT ? ld_global_nt<u32x4>(p) : ld_global<u32x4>(p),
+                  NT ? ld_global_nt<u32x4>(static_cast<const char*>(p) + 16) : ld_global<u32x4>(static_cast<const char*>(p) + 16)};
     __builtin_memcpy(&out, r, N);
   } else {
-    typename vec_of<N>::type r = ld_global<typename vec_of<N>::type>(p);
+    using V = typename vec_of<N>::type;
+    V r     = NT ? ld_global_nt<V>(p) : ld_global<V>(p);
     __builtin_memcpy(&out, &r, N);
   }
   return out;
 }
-template <typename S>
+template <typename S, bool NT = false>
 __device__ __forceinline__ void st_global_pod(void* p, const S& v)
 {
   constexpr size_t N = sizeof(S);
   if constexpr (N == 32) {
     u32x4 r[2];
     __builtin_memcpy(r, &v, N);
-    st_global<u32x4>(p, r[0]);
-    st_global<u32x4>(static_cast<char*>(p) + 16, r[1]);
+    if (NT) {
+      st_global_nt<u32x4>(p, r[0]);
+      st_global_nt<u32x4>(static_cast<char*>(p) + 16, r[1]);
+    } else {
+      st_global<u32x4>(p, r[0]);
+      st_global<u32x4>(static_cast<char*>(p) + 16, r[1]);
+    }
   } else {
-    typename vec_of<N>::type r;
+    using V = typename vec_of<N>::type;
+    V r;
     __builtin_memcpy(&r, &v, N);
-    st_global<typename vec_of<N>::type>(p, r);
+    if (NT) st_global_nt<V>(p, r); else st_global<V>(p, r);
   }
 }
 
@@ -807,14 +820,17 @@ __global__ __launch_bounds__(kBlock) void rows_convert_kernel(rows_params p)
             char* t      = shfl_ptr(my_tab, el);
             char* q      = shfl_ptr(my_plain, el);
             dst[u]       = (GATHER ? q : t) + cc * V * sizeof(ToT);
-            data[u]      = ld_global_pod<elt_vec<FromT, V>>((GATHER ? t : q) + cc * V * sizeof(FromT));
+            // non-temporal on both sides, like the copying kernels (round 4, interleaved A/B on 16 <-> 32-bit pairs: gather
+            // 67.3 -> 70.8, 69.5 -> 75.7, 67.8 -> 74.0, 67.3 -> 72.7 % of peak, scatter 76.2 -> 82.4, 78.9 -> 81.0, 74.7 -> 80.8,
+            // 100-element rows +2.4 / +6.5: profiles/r04_cast_sweep_nontemporal_ab.txt)
+            data[u]      = ld_global_pod<elt_vec<FromT, V>, true>((GATHER ? t : q) + cc * V * sizeof(FromT));
           }
 #pragma unroll
           for (int u = 0; u < kU; u++) {
             elt_vec<ToT, V> o;
 #pragma unroll
             for (int k = 0; k < V; k++) o.v[k] = convert_elt<FromT, ToT>(data[u].v[k]);
-            st_global_pod<elt_vec<ToT, V>>(dst[u], o);
+            st_global_pod<elt_vec<ToT, V>, true>(dst[u], o);
           }
           continue;
         }
