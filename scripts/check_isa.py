@@ -42,6 +42,8 @@ RULES = [
     (r"rows_staged_scatter_kernel<", dict(min_loads=4, wide=True, max_valu=400, max_mov_share=0.45, scope="block")),
     # gradient apply: a batch of the tile kernel = 2 x kU row loads (gradient + table [+ states]) back to back; no scratch
     (r"step_tile_kernel<", dict(min_loads=4, wide=True, max_valu=600, max_mov_share=0.45, scope="block", max_scratch=0)),
+    # the tree fold of long runs: 4 gradient rows per thread in flight (round 3 shipped one)
+    (r"tree_fold_kernel<", dict(min_loads=4, wide=True, max_valu=600, max_mov_share=0.45, scope="block", max_scratch=0)),
 ]
 
 

@@ -785,6 +785,10 @@ template <typename IdxT, int OPT, int RPS, bool CACHED, typename T = float, int 
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC > 0 ? OCC : 1, OCC > 0 ? OCC : 8)))
 void step_tile_kernel(opt_params p)
 {
+  // optimizer states move non-temporally like the rows (round 4, interleaved in one process, 10 M uniform rows of 128 floats:
+  // LazyAdam 6.69 -> 6.38 ms, Zipf 4.83 -> 4.56; AdaGrad 4.53 -> 4.49; RMSProp 4.47 -> 4.45)
+  auto ld_state = [](const void* q) { return ld_global_nt<tile_raw4>(q); };
+  auto st_state = [](void* q, tile_raw4 v) { st_global_nt<tile_raw4>(q, v); };
   constexpr int kVE          = 16 / static_cast<int>(sizeof(T));  // elements per lane
   constexpr bool k16         = sizeof(T) == 2;
   constexpr int kU           = KU > 0 ? KU : ((OPT == WHOLEMEMORY_OPT_SGD && !k16) ? WM_TILE_KU_SGD : WM_TILE_KU_STATE);
@@ -855,8 +859,8 @@ void step_tile_kernel(opt_params p)
           if (kState) srow[k] = tile_lane_ptr<RPS>(my_st, e0, sub);
           gv[k]        = ld_global_nt<tile_raw4>(g + coff);
           ev[k]        = ld_global_nt<tile_raw4>(trow[k] + coff);
-          if (kState) s0v[k] = ld_global<tile_raw4>(srow[k] + coff);
-          if (kAdam) s1v[k] = ld_global<tile_raw4>(srow[k] + a.table_stride + coff);
+          if (kState) s0v[k] = ld_state(srow[k] + coff);
+          if (kAdam) s1v[k] = ld_state(srow[k] + a.table_stride + coff);
         }
 #pragma unroll
         for (int k = 0; k < kU; k++) {
@@ -907,8 +911,8 @@ void step_tile_kernel(opt_params p)
             if (kState) so0.v[v & 3] = x.s0;
             if (kAdam) so1.v[v & 3] = x.s1;
           }
-          if (kState) st_global<tile_raw4>(srow[k] + coff, tile_pack<float>(so0));
-          if (kAdam) st_global<tile_raw4>(srow[k] + a.table_stride + coff, tile_pack<float>(so1));
+          if (kState) st_state(srow[k] + coff, tile_pack<float>(so0));
+          if (kAdam) st_state(srow[k] + a.table_stride + coff, tile_pack<float>(so1));
           st_global_nt<tile_raw4>(trow[k] + coff, tile_pack<T>(eo));
         }
       }
@@ -936,8 +940,8 @@ void step_tile_kernel(opt_params p)
         tile_vals<kVE> acc = tile_unpack<T>(ld_global_nt<tile_raw4>(g + coff));   // first occurrence copied
         const tile_raw4 ev = ld_global_nt<tile_raw4>(trow + coff);
         tile_raw4 s0v{}, s1v{};
-        if (kState) s0v = ld_global<tile_raw4>(srow + coff);
-        if (kAdam) s1v = ld_global<tile_raw4>(srow + a.table_stride + coff);
+        if (kState) s0v = ld_state(srow + coff);
+        if (kAdam) s1v = ld_state(srow + a.table_stride + coff);
         for (int32_t j = 1; j < ln; j++) {   // later occurrences added in receive order
           const tile_vals<kVE> gx = tile_unpack<T>(ld_global_nt<tile_raw4>(grad_row<T>(a, a.order[rs + j]) + coff));
 #pragma unroll
@@ -959,8 +963,8 @@ void step_tile_kernel(opt_params p)
           if (kState) so0.v[v & 3] = x.s0;
           if (kAdam) so1.v[v & 3] = x.s1;
         }
-        if (kState) st_global<tile_raw4>(srow + coff, tile_pack<float>(so0));
-        if (kAdam) st_global<tile_raw4>(srow + a.table_stride + coff, tile_pack<float>(so1));
+        if (kState) st_state(srow + coff, tile_pack<float>(so0));
+        if (kAdam) st_state(srow + a.table_stride + coff, tile_pack<float>(so1));
         st_global_nt<tile_raw4>(trow + coff, tile_pack<T>(eo));
       }
     }
@@ -1467,9 +1471,13 @@ __global__ __launch_bounds__(256) void tree_mark_kernel(opt_params p, tree_ws_vi
 
 // one segment per workgroup trip: thread t = (row slot t / LPR, 16-byte piece t % LPR); rows of a slot are added in order,
 // four loads in flight, the row slots meet in LDS in slot order
+#ifndef WM_TREE_DEPTH
+#define WM_TREE_DEPTH 4
+#endif
 template <typename IdxT, int OPT, typename T>
 __global__ __launch_bounds__(kBlock) void tree_fold_kernel(opt_params p, tree_ws_view w)
 {
+  constexpr int kTreeDepth = WM_TREE_DEPTH;
   constexpr int kVE = 16 / static_cast<int>(sizeof(T));
   __shared__ float red[kBlock * kVE];
   const wm_optimizer_args& a = p.a;
@@ -1495,22 +1503,24 @@ __global__ __launch_bounds__(kBlock) void tree_fold_kernel(opt_params p, tree_ws
       float acc[kVE];
 #pragma unroll
       for (int v = 0; v < kVE; v++) acc[v] = 0.f;
-      if (live) {
-        for (int r = rs; r < rows; r += 4 * slots) {
-          tile_raw4 g[4];
+      // kTreeDepth rows per thread in flight: the positions and then the rows are loaded UNCONDITIONALLY (a row slot past the
+      // end of the segment repeats its last row, a thread past the end of the row its last piece) and only the adds are
+      // predicated — a load under `if (rr < rows)` is a conditionally defined register, and hipcc then waited for every
+      // position and every row before issuing the next one (round 3's shape: one 16-byte load in flight per thread)
+      const int64_t poff = static_cast<int64_t>(min(piece, pieces - 1)) * kVE;
+      for (int r0 = 0; r0 < rows; r0 += kTreeDepth * slots) {   // (block-uniform trip count)
+        int32_t pos[kTreeDepth];
+        tile_raw4 g[kTreeDepth];
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int rr = r + q * slots;
-            if (rr < rows) g[q] = ld_global_nt<tile_raw4>(grad_row<T>(a, a.order[s0 + rr]) + static_cast<int64_t>(piece) * kVE);
-          }
+        for (int q = 0; q < kTreeDepth; q++) pos[q] = a.order[s0 + min(r0 + rs + q * slots, rows - 1)];
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            if (r + q * slots < rows) {
-              const tile_vals<kVE> gv = tile_unpack<T>(g[q]);
+        for (int q = 0; q < kTreeDepth; q++) g[q] = ld_global_nt<tile_raw4>(grad_row<T>(a, pos[q]) + poff);
 #pragma unroll
-              for (int v = 0; v < kVE; v++) acc[v] += gv.v[v];
-            }
-          }
+        for (int q = 0; q < kTreeDepth; q++) {
+          const bool in = r0 + rs + q * slots < rows;
+          const tile_vals<kVE> gv = tile_unpack<T>(g[q]);
+#pragma unroll
+          for (int v = 0; v < kVE; v++) acc[v] = in ? acc[v] + gv.v[v] : acc[v];
         }
       }
       __syncthreads();   // (the previous pass / segment has read red[])
