@@ -105,7 +105,7 @@ wholememory_error_code_t row_cache_update(row_cache* c, const void* ids, wholeme
   return WHOLEMEMORY_SUCCESS;
 }
 
-wholememory_error_code_t row_cache_plan(row_cache* c, const void* ids, wholememory_dtype_t index_dtype, int64_t n,
+wholememory_error_code_t row_cache_plan(row_cache* c, const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound,
                                         wholememory_env_func_t* env, void* stream, temp_mem* rows_mem, temp_mem* slots_mem,
                                         int64_t* n_fill)
 {
@@ -123,7 +123,7 @@ wholememory_error_code_t row_cache_plan(row_cache* c, const void* ids, wholememo
   void* d_ws      = ws.device(static_cast<int64_t>(bk->dedup_workspace_bytes(n, index_dtype)), WHOLEMEMORY_DT_INT8);
   auto* d_count   = static_cast<int*>(count.device(1, WHOLEMEMORY_DT_INT));
   WM_BK(bk->memset_async(d_count, 0, sizeof(int), stream));
-  int rc = bk->dedup_ids(ids, index_dtype, n, 0, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
+  int rc = bk->dedup_ids(ids, index_dtype, n, key_upper_bound, 0, d_unique, d_starts, d_order, d_nunique, d_ws, stream);
   if (rc != 0) return rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR;
   rc = bk->cache_update(&c->args, d_unique, index_dtype, d_starts, d_nunique, n, fill_rows, fill_slots, d_count, stream);
   if (rc != 0) return rc == -1 ? WHOLEMEMORY_INVALID_INPUT : WHOLEMEMORY_CUDA_ERROR;

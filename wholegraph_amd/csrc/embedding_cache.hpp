@@ -51,7 +51,7 @@ wholememory_error_code_t row_cache_gather(row_cache* c, const wm_rows_args& a, w
 // them as device lists (global rows / cache slots, *n_fill of them) WITHOUT moving data; the caller fetches the rows and
 // calls row_cache_install. The lists live in `rows_mem` / `slots_mem`.
 wholememory_error_code_t row_cache_plan(row_cache* c, const void* ids, wholememory_dtype_t index_dtype, int64_t n,
-                                        wholememory_env_func_t* env, void* stream, temp_mem* rows_mem, temp_mem* slots_mem,
+                                        int64_t key_upper_bound, wholememory_env_func_t* env, void* stream, temp_mem* rows_mem, temp_mem* slots_mem,
                                         int64_t* n_fill);
 // cache_line[slots[k]] = rows_data[k] for k < n_fill (rows_data: dense [n_fill, row_elems] of the raw dtype)
 wholememory_error_code_t row_cache_install(row_cache* c, const void* rows_data, const int64_t* slots, int64_t n_fill,

@@ -265,6 +265,7 @@ inline unsigned significant_bits(int64_t upper_bound, unsigned full)
 // rocPRIM's onesweep with 9 radix bits per pass and 1024 x 8 keys per workgroup: ids of a 100 M-row shard (27 bits) sort
 // in 3 passes instead of the tuned default's 4 x 8 bits (10 M (key, position) pairs: 398 -> 251 us;
 // experiments/sort_variants.hip has the sweep). 64-bit keys keep the library default.
+constexpr int64_t kSortRadixMin = 3 << 16;   // 196608 (crossover between 131072 and 262144 items: profiles/r04_small_sort.txt)
 template <typename SortKeyT>
 struct sort_config {
   using type = rocprim::default_config;
@@ -276,6 +277,39 @@ struct sort_config<uint32_t> {
     rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 12>, rocprim::kernel_config<1024, 8>, 9,
                                         rocprim::block_radix_rank_algorithm::match>>;
 };
+
+// rocPRIM sorts up to 2^20 items with a MERGE sort (radix_sort_config's MergeSortLimit): block sort + 10 merge passes of two
+// launches each for 1 M (key, position) pairs — 160 us where three onesweep passes over 24 bits take ~70 (the batch of a cached
+// C1 gather, the gradients of a 1024-seed mini-batch: profiles/r04_small_sort.txt). The second configuration never merges;
+// sort_pairs32 picks by size (WM_SORT_RADIX_MIN, items from which the radix passes are taken).
+struct sort_config_radix32 {
+  using type = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 12>, rocprim::kernel_config<1024, 8>, 9,
+                                        rocprim::block_radix_rank_algorithm::match>,
+    0>;
+};
+inline int64_t sort_radix_min()
+{
+  const char* e = WM_KNOB("WM_SORT_RADIX_MIN");
+  return e != nullptr && atoll(e) > 0 ? atoll(e) : kSortRadixMin;
+}
+template <typename KeysIn, typename ValsIn>
+hipError_t sort_pairs32(void* temp, size_t& temp_bytes, KeysIn keys, uint32_t* keys_out, ValsIn vals, int32_t* vals_out, size_t n,
+                        unsigned lo, unsigned hi, hipStream_t stream)
+{
+  if (temp == nullptr) {   // size query: room for either configuration
+    size_t a = 0, b = 0;
+    hipError_t e = rocprim::radix_sort_pairs<sort_config<uint32_t>::type>(nullptr, a, keys, keys_out, vals, vals_out, n, lo, hi, stream);
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs<sort_config_radix32::type>(nullptr, b, keys, keys_out, vals, vals_out, n, lo, hi, stream);
+    temp_bytes = std::max(a, b);
+    return e;
+  }
+  if (static_cast<int64_t>(n) >= sort_radix_min())
+    return rocprim::radix_sort_pairs<sort_config_radix32::type>(temp, temp_bytes, keys, keys_out, vals, vals_out, n, lo, hi, stream);
+  return rocprim::radix_sort_pairs<sort_config<uint32_t>::type>(temp, temp_bytes, keys, keys_out, vals, vals_out, n, lo, hi, stream);
+}
 
 template <typename SortKeyT>
 struct dedup_layout {
@@ -293,10 +327,14 @@ dedup_layout<SortKeyT> layout(void* ws, int64_t n)
 {
   auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
   size_t sort_bytes = 0;
-  (void)rocprim::radix_sort_pairs<typename sort_config<SortKeyT>::type>(
-    nullptr, sort_bytes, static_cast<const SortKeyT*>(nullptr), static_cast<SortKeyT*>(nullptr),
-    rocprim::counting_iterator<int32_t>(0), static_cast<int32_t*>(nullptr), static_cast<size_t>(n), 0, 8 * sizeof(SortKeyT),
-    nullptr);
+  if constexpr (sizeof(SortKeyT) == 4)
+    (void)sort_pairs32(nullptr, sort_bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                       rocprim::counting_iterator<int32_t>(0), static_cast<int32_t*>(nullptr), static_cast<size_t>(n), 0, 32, nullptr);
+  else
+    (void)rocprim::radix_sort_pairs<typename sort_config<SortKeyT>::type>(
+      nullptr, sort_bytes, static_cast<const SortKeyT*>(nullptr), static_cast<SortKeyT*>(nullptr),
+      rocprim::counting_iterator<int32_t>(0), static_cast<int32_t*>(nullptr), static_cast<size_t>(n), 0, 8 * sizeof(SortKeyT),
+      nullptr);
   dedup_layout<SortKeyT> l;
   char* p       = static_cast<char*>(ws);
   size_t o      = 0;
@@ -340,9 +378,7 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
     auto l    = layout<uint32_t>(workspace, n);
     size_t tb = l.temp_bytes;
     narrow_key_iterator<UKey> keys{static_cast<const UKey*>(ids), static_cast<UKey>(key_lower_bound), static_cast<uint32_t>(span)};
-    if (rocprim::radix_sort_pairs<sort_config<uint32_t>::type>(l.temp, tb, keys, l.sorted, positions, order,
-                                                               static_cast<size_t>(n), 0, bits, stream) != hipSuccess)
-      return -2;
+    if (sort_pairs32(l.temp, tb, keys, l.sorted, positions, order, static_cast<size_t>(n), 0, bits, stream) != hipSuccess) return -2;
     return detect_runs<uint32_t, UKey>(l.sorted, l.tile_counts, n, static_cast<UKey*>(unique_ids), run_starts, n_unique_out,
                                        stream, static_cast<UKey>(key_lower_bound), true, static_cast<uint32_t>(span));
   }
@@ -1865,9 +1901,8 @@ sort_ids_layout sort_ids_carve(void* ws, int64_t n)
 {
   auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
   size_t sort_bytes = 0;
-  (void)rocprim::radix_sort_pairs<sort_config<uint32_t>::type>(
-    nullptr, sort_bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
-    rocprim::counting_iterator<int32_t>(0), static_cast<int32_t*>(nullptr), static_cast<size_t>(n), 0, 32, nullptr);
+  (void)sort_pairs32(nullptr, sort_bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                     rocprim::counting_iterator<int32_t>(0), static_cast<int32_t*>(nullptr), static_cast<size_t>(n), 0, 32, nullptr);
   sort_ids_layout l;
   char* p  = static_cast<char*>(ws);
   size_t o = 0;
@@ -1890,8 +1925,7 @@ int run_sort_ids(const void* ids, int64_t n, int64_t key_upper_bound, int low_bi
   narrow_key_iterator<UKey> keys{static_cast<const UKey*>(ids), static_cast<UKey>(0), static_cast<uint32_t>(key_upper_bound)};
   const unsigned bits = significant_bits(key_upper_bound + 1, 32);
   const unsigned lo   = static_cast<unsigned>(std::max(0, std::min<int>(low_bit, static_cast<int>(bits) - 1)));
-  if (rocprim::radix_sort_pairs<sort_config<uint32_t>::type>(l.temp, tb, keys, l.keys, rocprim::counting_iterator<int32_t>(0),
-                                                             l.order, static_cast<size_t>(n), lo, bits, stream) != hipSuccess)
+  if (sort_pairs32(l.temp, tb, keys, l.keys, rocprim::counting_iterator<int32_t>(0), l.order, static_cast<size_t>(n), lo, bits, stream) != hipSuccess)
     return -2;
   hipLaunchKernelGGL((expand_sorted_ids_kernel<KeyT>), dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      stream, static_cast<const KeyT*>(ids), l.order, n, static_cast<KeyT*>(sorted_ids), raw);

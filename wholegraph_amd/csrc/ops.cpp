@@ -823,7 +823,9 @@ wholememory_error_code_t gather_cached(wholememory_tensor_t table, wholememory_t
     return gather_distributed_rows(handle, d, env, stream, gather_sms, cache, adjust_cache);
   if (cache->raw_addressable) {  // local read-only cache of a table that is addressable from here
     if (adjust_cache)
-      WHOLEMEMORY_RETURN_ON_FAIL(row_cache_update(cache, d.indices_ptr, d.indices.dtype, d.indices.size, 0, env, stream));
+      // (the table's row count bounds the sort keys: 24 bits / 3 radix passes for a 10 M-row table instead of all 64; ids
+      // outside [0, rows) are left out of the runs, and they have no business in the cache)
+      WHOLEMEMORY_RETURN_ON_FAIL(row_cache_update(cache, d.indices_ptr, d.indices.dtype, d.indices.size, d.table.sizes[0], env, stream));
     wm_rows_args a{};
     fill_rows_args(&a, cache->args.raw_gref, d.table, d.indices_ptr, d.indices.dtype, d.indices.size, d.plain_ptr, d.plain,
                    gather_sms);
@@ -839,7 +841,7 @@ wholememory_error_code_t gather_cached(wholememory_tensor_t table, wholememory_t
   if (adjust_cache) {
     temp_mem rows_mem(env), slots_mem(env), staging(env);
     int64_t n_fill = 0;
-    WHOLEMEMORY_RETURN_ON_FAIL(row_cache_plan(cache, d.indices_ptr, d.indices.dtype, n, env, stream, &rows_mem, &slots_mem, &n_fill));
+    WHOLEMEMORY_RETURN_ON_FAIL(row_cache_plan(cache, d.indices_ptr, d.indices.dtype, n, d.table.sizes[0], env, stream, &rows_mem, &slots_mem, &n_fill));
     char* rows_data = static_cast<char*>(staging.device(n_fill * cache->row_elems, d.table.dtype));
     op_descs df     = d;
     df.indices_ptr  = rows_mem.get();
