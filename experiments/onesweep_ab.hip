@@ -20,7 +20,7 @@ struct key_of_id {   // the library's narrow_key_iterator in small: ids[i] - bas
 struct narrow_fn { uint64_t base; uint32_t span; __host__ __device__ uint32_t operator()(const uint64_t& v) const { const uint64_t o = v - base; return o < span ? (uint32_t)o : span; } };
 
 using tuned = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 12>, rocprim::kernel_config<1024, 8>, 9, rocprim::block_radix_rank_algorithm::match>>;
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 12>, rocprim::kernel_config<1024, 8>, 9, rocprim::block_radix_rank_algorithm::match>, 0>;   // (round 4: never the merge sort)
 
 static hipEvent_t e0, e1;
 static int g_debug = 0;
@@ -68,7 +68,12 @@ int main(int argc, char** argv)
                       {"uniform 10M of 125M rows, ids outside the range", 10000000, 125000000ull, 3}, {"constant 3M", 3000001, 100000000ull, 2},
                       {"uniform 1000 of 1000 rows", 1000, 1000ull, 0}, {"uniform 1 of 5 rows", 1, 5ull, 0}, {"uniform 65537 of 2^20 rows", 65537, 1ull << 20, 0},
                       {"uniform 5M of 2^31 rows", 5000000, 1ull << 31, 0}, {"uniform 5M of 4e9 rows", 5000000, 4000000000ull, 0},
-                      {"uniform 2M of 70000 rows", 2000003, 70000ull, 0}};
+                      {"uniform 2M of 70000 rows", 2000003, 70000ull, 0},
+                      // round 4: the sizes of one mini-batch
+                      {"uniform 128K of 10M rows", 131072, 10000000ull, 0}, {"uniform 256K of 10M rows", 262144, 10000000ull, 0},
+                      {"uniform 512K of 10M rows", 524288, 10000000ull, 0}, {"uniform 1M of 10M rows", 1048576, 10000000ull, 0},
+                      {"uniform 512K of 100M rows", 524288, 100000000ull, 0}, {"uniform 2M of 100M rows", 2097152, 100000000ull, 0},
+                      {"uniform 4M of 100M rows", 4194304, 100000000ull, 0}, {"skewed 512K of 100M rows", 524288, 100000000ull, 1}};
   const size_t cap = 10000000;
   uint64_t* d_ids; uint32_t *d_sorted, *d_order, *r_sorted; int32_t* r_order; void *ws, *rtemp;
   const size_t ws_cap = 256u << 20;
@@ -103,7 +108,7 @@ int main(int argc, char** argv)
     CK(hipDeviceSynchronize());
     std::vector<uint32_t> rs(c.n), ro(c.n);
     CK(hipMemcpy(rs.data(), r_sorted, c.n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ro.data(), r_order, c.n * 4, hipMemcpyDeviceToHost));
-    const int r = c.n >= 1000000 ? reps : 0;
+    const int r = c.n >= 100000 ? reps : 0;
     printf("%s (n %zu, %u bits)\n", c.name, c.n, bits);
     if (r > 0) printf("  rocPRIM tuned onesweep: %.1f us\n", timed([&] { (void)rocprim::radix_sort_pairs<tuned>(rtemp, need, rkeys, r_sorted, pos, r_order, c.n, 0, bits, nullptr); }, r));
     all &= own<512, 16>("", keys, c.n, bits, d_sorted, d_order, ws, ws_cap, rs.data(), ro.data(), r);
