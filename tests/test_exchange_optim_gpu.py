@@ -654,3 +654,36 @@ def test_embedding_row_align_knob(gpu_env, knobs, tmp_path, mt, kind, params):
     wgth.destroy_wholememory_optimizer(opt)
     wgth.destroy_embedding(emb)
     wgth.destroy_embedding(emb2)
+
+
+@pytest.mark.parametrize("n", [150_000, 300_000, 1_000_000])
+@pytest.mark.parametrize("idt", [np.int64, np.int32])
+def test_id_sort_routes_agree(gpu_env, knobs, n, idt):
+    """The id sort of a mid-sized batch takes rocPRIM's merge sort below WM_SORT_RADIX_MIN (196608) items and the onesweep
+    passes from there up (rocPRIM alone would merge up to 2^20 items). A stable sort has one answer: scatter-add of the same
+    real-valued gradients through either route leaves the same bytes in the table, and they are the receive-order sums of the
+    oracle (reference exchange_embeddings_nccl_func.cu:93-206)."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    n_rows, dim = 200_003, 32
+    rng = np.random.default_rng(n)
+    ids = rng.integers(0, n_rows, n).astype(idt)
+    ids[::7] = 4242                                                 # one long run among the short ones
+    g = rng.standard_normal((n, dim)).astype(np.float32)
+    tables = []
+    for route in ("1", str(1 << 40)):                               # always the radix passes / the merge sort wherever rocPRIM allows it
+        knobs.set("WM_SORT_RADIX_MIN", route)
+        emb = wgth.create_embedding(gpu_env, "chunked", "cuda", torch.float32, [n_rows, dim])
+        local, _ = emb.get_embedding_tensor().get_local_tensor()
+        local.zero_()
+        opt = wgth.create_wholememory_optimizer(emb, "sgd", {})
+        emb.add_gradients(torch.from_numpy(ids).cuda(), torch.from_numpy(g).cuda())
+        emb.need_apply = True
+        emb.apply_gradients(-1.0)                                   # lr = -1, wd = 0: scatter-add
+        torch.cuda.synchronize()
+        tables.append(local[:, :dim].cpu().numpy().copy())
+        wgth.destroy_wholememory_optimizer(opt)
+        wgth.destroy_embedding(emb)
+    assert tables[0].tobytes() == tables[1].tobytes()
+    uniq, dg = oracle.dedup_grads(ids.astype(np.int64), g)
+    assert tables[0][uniq].tobytes() == dg[:, :dim].astype(np.float32).tobytes()
