@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "../backend.hpp"
+#include "../knobs.hpp"
 
 namespace wm {
 namespace {
@@ -37,7 +38,7 @@ constexpr int kBlock      = 256;
 constexpr int kWaves      = kBlock / 64;
 constexpr int kItems      = 4;                       // 64-id groups per wave per block iteration
 constexpr int kIterItems  = kBlock * kItems;         // 1024 ids per block iteration
-constexpr int kMaxBlocks  = 2048;
+constexpr int kMaxBlocks  = 2048;                    // (1024: the scan is quicker, the ballot-bound kernels lose more: 46 vs 33 us)
 constexpr int kMaxBuckets = 257;                     // world_size <= 256
 constexpr int kMaxOwners  = 1024;                    // ranges searched per id (== buckets unless owner_count is set)
 
@@ -73,6 +74,8 @@ __device__ __forceinline__ int owner_of(uint64_t id, const uint64_t* s_off, int 
   return lo;
 }
 
+__device__ __forceinline__ int bucket_of_owner(int o, int world, int owners) { return owners == world ? o : o % world; }
+
 // bucket of an id: its owner, or — when there are more owners than buckets (wm_bucket_args::owner_count) — owner % world
 template <typename IdxT>
 __device__ __forceinline__ int bucket_of(const IdxT* ids, int64_t i, int64_t n, const uint64_t* s_off, int world,
@@ -86,7 +89,12 @@ __device__ __forceinline__ int bucket_of(const IdxT* ids, int64_t i, int64_t n, 
   return owners == world ? o : o % world;
 }
 
-template <typename IdxT>
+// DENSE (world + 1 <= kDenseBuckets, i.e. up to 16 ranks — one node): no peel loop. One ballot per BUCKET and 64-id group,
+// the count of bucket b accumulates in a register of lane b; LDS is touched once per wave, at the end. The peel loop pays
+// an LDS round trip (and in the scatter two) per distinct bucket and group, back to back: 40 / 98 us per 10 M ids over 8
+// owners against 16 / 52 with this (profiles/r04_bucket_dense.txt).
+constexpr int kDenseBuckets = 17;
+template <typename IdxT, bool DENSE>
 __global__ __launch_bounds__(kBlock) void bucket_hist_kernel(const IdxT* ids, int64_t n, const uint64_t* entry_offsets,
                                                              int world, int owners, int64_t chunk,
                                                              int64_t* block_counts)
@@ -100,6 +108,29 @@ __global__ __launch_bounds__(kBlock) void bucket_hist_kernel(const IdxT* ids, in
   const int lane      = threadIdx.x & 63;
   const int64_t begin = static_cast<int64_t>(blockIdx.x) * chunk;
   const int64_t end   = min(begin + chunk, n);
+  if constexpr (DENSE) {
+    constexpr int kU = 4;   // ids per thread in flight, loaded unconditionally (clamped into the chunk)
+    int mine = 0;           // lane b: ids of bucket b this wave has seen
+    for (int64_t base = begin; base < end; base += kBlock * kU) {
+      IdxT id[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) id[u] = ids[min(base + u * kBlock + threadIdx.x, end - 1)];
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        const bool in = base + u * kBlock + threadIdx.x < end;
+        const int b   = !in ? -1 : id[u] < 0 ? world : bucket_of_owner(owner_of(static_cast<uint64_t>(id[u]), s_off, owners), world, owners);
+        for (int k = 0; k < nb; k++) {   // (wave-uniform trip count)
+          const int c = __popcll(__ballot(b == k));
+          mine += lane == k ? c : 0;
+        }
+      }
+    }
+    if (lane < nb && mine != 0) atomicAdd(&s_cnt[lane], mine);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += kBlock)
+      block_counts[static_cast<int64_t>(i) * gridDim.x + blockIdx.x] = s_cnt[i];
+    return;
+  }
   for (int64_t base = begin; base < end; base += kBlock) {
     IdxT id;
     int b            = bucket_of(ids, base + threadIdx.x, end, s_off, world, owners, id);
@@ -118,28 +149,57 @@ __global__ __launch_bounds__(kBlock) void bucket_hist_kernel(const IdxT* ids, in
 }
 
 // exclusive scan of block_counts (bucket-major) in place; totals of the first `world` buckets to counts[]
+// (round 4: a thread's span is read 8 values at a time, unconditionally — the one-load-per-trip loops of the first version
+// paid a memory latency per value, twice: 31 us for the 18 k counts of 8 owners x 2048 blocks — and the 1024 partial sums meet
+// through wave shuffles and two barriers instead of twenty)
 __global__ __launch_bounds__(1024) void bucket_scan_kernel(int64_t* block_counts, int blocks, int world, int64_t* counts)
 {
-  __shared__ int64_t s_part[1024];
+  __shared__ int64_t s_wave[16];
+  constexpr int kV    = 24;   // 8 owners x 2048 blocks: 18 counts per thread, all in registers
   const int64_t total = static_cast<int64_t>(world + 1) * blocks;
   const int64_t per   = (total + 1023) / 1024;
   const int64_t b0    = min(static_cast<int64_t>(threadIdx.x) * per, total);
   const int64_t b1    = min(b0 + per, total);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int64_t sum         = 0;
-  for (int64_t i = b0; i < b1; i++) sum += block_counts[i];
-  s_part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan over 1024 partials
-    int64_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
-    __syncthreads();
-    s_part[threadIdx.x] += v;
-    __syncthreads();
+  int64_t first[kV];   // the first kV values of the span stay in registers for the second pass (the whole span when per <= kV)
+#pragma unroll
+  for (int u = 0; u < kV; u++) first[u] = block_counts[min(b0 + u, total - 1)];
+#pragma unroll
+  for (int u = 0; u < kV; u++) sum += b0 + u < b1 ? first[u] : 0;
+  for (int64_t i = b0 + kV; i < b1; i += kV) {
+    int64_t v[kV];
+#pragma unroll
+    for (int u = 0; u < kV; u++) v[u] = block_counts[min(i + u, total - 1)];
+#pragma unroll
+    for (int u = 0; u < kV; u++) sum += i + u < b1 ? v[u] : 0;
   }
-  int64_t run = s_part[threadIdx.x] - sum;  // exclusive prefix of this thread's span
-  for (int64_t i = b0; i < b1; i++) {
-    int64_t c       = block_counts[i];
-    block_counts[i] = run;
-    run += c;
+  int64_t incl = sum;   // inclusive scan over the wave, then over the 16 wave totals
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int64_t o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  int64_t before = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) before += w < wv ? s_wave[w] : 0;
+  int64_t run = before + incl - sum;  // exclusive prefix of this thread's span
+#pragma unroll
+  for (int u = 0; u < kV; u++) {
+    if (b0 + u < b1) block_counts[b0 + u] = run;
+    run += b0 + u < b1 ? first[u] : 0;
+  }
+  for (int64_t i = b0 + kV; i < b1; i += kV) {
+    int64_t v[kV];
+#pragma unroll
+    for (int u = 0; u < kV; u++) v[u] = block_counts[min(i + u, total - 1)];
+#pragma unroll
+    for (int u = 0; u < kV; u++) {
+      if (i + u < b1) block_counts[i + u] = run;
+      run += i + u < b1 ? v[u] : 0;
+    }
   }
   __syncthreads();
   // bucket totals: offset of next bucket's first block minus own first block
@@ -150,7 +210,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(int64_t* block_counts
   }
 }
 
-template <typename IdxT>
+template <typename IdxT, bool DENSE>
 __global__ __launch_bounds__(kBlock) void bucket_scatter_kernel(const IdxT* ids, int64_t n,
                                                                 const uint64_t* entry_offsets, int world,
                                                                 int owners, int64_t chunk,
@@ -173,14 +233,36 @@ __global__ __launch_bounds__(kBlock) void bucket_scatter_kernel(const IdxT* ids,
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
   for (int64_t it = begin; it < end; it += kIterItems) {
-    for (int i = threadIdx.x; i < kWaves * nb; i += kBlock) s_wcnt[i / nb][i % nb] = 0;
+    if (!DENSE) {
+      for (int i = threadIdx.x; i < kWaves * nb; i += kBlock) s_wcnt[i / nb][i % nb] = 0;
+    }
     __syncthreads();
     // wave `wave` owns ids [it + wave*256, it + wave*256 + 256) as kItems consecutive 64-groups
     IdxT id[kItems];
     int bkt[kItems];
     int rank[kItems];
+    if constexpr (DENSE) {
+      // ids loaded back to back (clamped into the chunk), then per group one ballot per bucket: lane b carries the wave's
+      // running count of bucket b (what s_wcnt[wave][b] is in the peel loop), read with v_readlane — no LDS inside the loop
 #pragma unroll
-    for (int j = 0; j < kItems; j++) {
+      for (int j = 0; j < kItems; j++) id[j] = ids[min(it + static_cast<int64_t>(wave) * (64 * kItems) + j * 64 + lane, end - 1)];
+      int run = 0;
+#pragma unroll
+      for (int j = 0; j < kItems; j++) {
+        const int64_t pos = it + static_cast<int64_t>(wave) * (64 * kItems) + j * 64 + lane;
+        bkt[j]  = pos >= end ? -1 : id[j] < 0 ? world : bucket_of_owner(owner_of(static_cast<uint64_t>(id[j]), s_off, owners), world, owners);
+        rank[j] = 0;
+        for (int k = 0; k < nb; k++) {   // (wave-uniform trip count)
+          const uint64_t mask = __ballot(bkt[j] == k);
+          const int prior     = __builtin_amdgcn_readlane(run, k);
+          if (bkt[j] == k) rank[j] = prior + __popcll(mask & lt_mask);
+          run += lane == k ? __popcll(mask) : 0;
+        }
+      }
+      if (lane < nb) s_wcnt[wave][lane] = run;
+    }
+#pragma unroll
+    for (int j = 0; j < (DENSE ? 0 : kItems); j++) {
       const int64_t pos = it + static_cast<int64_t>(wave) * (64 * kItems) + j * 64 + lane;
       bkt[j]            = bucket_of(ids, pos, end, s_off, world, owners, id[j]);
       rank[j]           = 0;
@@ -227,16 +309,27 @@ int run_bucket(const wm_bucket_args* a, hipStream_t stream)
   int64_t* block_counts = static_cast<int64_t*>(a->workspace);
   const IdxT* ids       = static_cast<const IdxT*>(a->indices);
   const int owners      = a->owner_count > 0 ? a->owner_count : a->world_size;
+  const char* de        = WM_KNOB("WM_BUCKET_DENSE");   // 0: the peel loop for every world size (A/B)
+  const bool dense      = a->world_size + 1 <= kDenseBuckets && !(de != nullptr && de[0] == '0');
   if (!(a->reuse_scan && a->bucketed_ids != nullptr)) {  // (reuse: the counts-only call over the same ids left the scan behind)
-    hipLaunchKernelGGL((bucket_hist_kernel<IdxT>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n, a->entry_offsets,
-                       a->world_size, owners, g.chunk, block_counts);
+    if (dense)
+      hipLaunchKernelGGL((bucket_hist_kernel<IdxT, true>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n, a->entry_offsets,
+                         a->world_size, owners, g.chunk, block_counts);
+    else
+      hipLaunchKernelGGL((bucket_hist_kernel<IdxT, false>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n, a->entry_offsets,
+                         a->world_size, owners, g.chunk, block_counts);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, block_counts, g.blocks, a->world_size,
                        a->counts);
   }
   if (a->bucketed_ids != nullptr && a->raw_indices != nullptr) {
-    hipLaunchKernelGGL((bucket_scatter_kernel<IdxT>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n,
-                       a->entry_offsets, a->world_size, owners, g.chunk, block_counts,
-                       static_cast<IdxT*>(a->bucketed_ids), a->raw_indices);
+    if (dense)
+      hipLaunchKernelGGL((bucket_scatter_kernel<IdxT, true>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n,
+                         a->entry_offsets, a->world_size, owners, g.chunk, block_counts,
+                         static_cast<IdxT*>(a->bucketed_ids), a->raw_indices);
+    else
+      hipLaunchKernelGGL((bucket_scatter_kernel<IdxT, false>), dim3(g.blocks), dim3(kBlock), 0, stream, ids, a->n,
+                         a->entry_offsets, a->world_size, owners, g.chunk, block_counts,
+                         static_cast<IdxT*>(a->bucketed_ids), a->raw_indices);
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
