@@ -1,7 +1,7 @@
 # timeline of ONE C5 step (2-hop sample -> append_unique -> feature gather): everything between two feature-gather launches
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tr5
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tr5 -- python $GRAFT_REPO_ROOT/bench.py --op sample_gather --steps 6 --warmup 2 --stability-steps 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tr5 -- python $GRAFT_REPO_ROOT/bench.py --op sample_gather --steps 6 --warmup 2 --stability-steps 0 ${C5_FLOW:+--c5-flow $C5_FLOW} > /dev/null 2>&1
 f=$(find /tmp/tr5 -name "*kernel_trace.csv" | head -1)
 m=$(find /tmp/tr5 -name "*memory_copy_trace.csv" | head -1)
 python3 - $f $m <<'PY'
