@@ -27,7 +27,9 @@ def _env():
 @pytest.mark.parametrize("idt", [np.int32, np.int64])
 @pytest.mark.parametrize("n,world,kind", [(0, 4, "equal"), (1, 1, "equal"), (63, 2, "equal"), (4097, 8, "equal"),
                                           (100000, 8, "equal"), (250000, 3, "custom"), (99999, 8, "empty_ranks"),
-                                          (300000, 64, "equal"), (1000003, 8, "zipf")])
+                                          (300000, 64, "equal"), (1000003, 8, "zipf"),
+                                          # 16 ranks = the last world size of the one-ballot-per-owner kernels, 17 the first of the peel loop
+                                          (200001, 16, "equal"), (200001, 15, "zipf"), (200001, 17, "equal")])
 def test_bucket_ids(gpu_env, idt, n, world, kind):
     import torch
     from wholegraph_amd import binding as wmb
