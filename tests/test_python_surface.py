@@ -81,3 +81,37 @@ def test_tensor_views_alias_memory(gpu_env, mt, loc):
     assert sub.shape == (10, 7) and sub.stride() == (dim, 1) and sub.storage_offset() == 10 * dim + 2
     wgth.destroy_wholememory_tensor(sub)
     wgth.destroy_wholememory_tensor(wm)
+
+
+def test_wrapped_tensor_handles_are_cached_per_thread_and_outlive_the_cache(wm_lib):
+    """wrap_torch_tensor keeps the wholememory_tensor_t of (pointer, shape, strides, dtype) per thread (an op wraps its index and
+    output tensors on every call): the same tensor wrapped twice yields the same handle, a different view a different one, a
+    wrapper that is still alive keeps its handle when the cache is emptied by 600 other wraps, and the description the library
+    reads back is the tensor's. Another thread has its own cache. No GPU needed: wrapping never touches the memory."""
+    import ctypes as C
+    import threading
+    import torch
+    from wholegraph_amd import binding as wmb
+    from wholegraph_amd.torch import wholegraph_env as E
+    t = torch.zeros((12, 5), dtype=torch.float32)
+    w1, w2 = E.wrap_torch_tensor(t), E.wrap_torch_tensor(t)
+    assert w1.handle.value == w2.handle.value
+    assert E.wrap_torch_tensor(t[:6]).handle.value != w1.handle.value            # same pointer, another shape
+    assert E.wrap_torch_tensor(t[1:]).handle.value != w1.handle.value            # same shape class, another pointer
+
+    def described(w):
+        d = wm_lib.wholememory_tensor_get_tensor_description(w.handle).contents
+        return d.dim, d.sizes[0], d.sizes[1], d.strides[0], d.dtype
+    assert described(w1) == (2, 12, 5, 5, wmb.DT_FLOAT)
+    keep = [torch.zeros(3 + (i % 11), 2 + i // 11) for i in range(600)]          # > the cache's 512 entries: it starts over
+    for k in keep:
+        E.wrap_torch_tensor(k)
+    assert len(E._tls.handles) < 600
+    assert described(w1) == (2, 12, 5, 5, wmb.DT_FLOAT)                          # w1's handle was not destroyed under it
+    w3 = E.wrap_torch_tensor(t)
+    assert described(w3) == (2, 12, 5, 5, wmb.DT_FLOAT)
+    other = {}
+    th = threading.Thread(target=lambda: other.setdefault("h", E.wrap_torch_tensor(t).handle.value))
+    th.start(); th.join()
+    assert other["h"] != w3.handle.value
+    assert isinstance(E.get_stream(), int)
