@@ -1,0 +1,187 @@
+// EXPERIMENT harness (round 5): the split sort of kernels/split_sort.cuh against a CPU stable sort, and its timing.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I wholegraph_amd/csrc experiments/split_sort_test.hip -o experiments/split_sort_test
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <vector>
+#define WM_SPLIT_DEBUG 1
+#include "kernels/split_sort.cuh"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+using namespace wm;
+
+struct result { std::vector<int64_t> uniq; std::vector<int32_t> starts, order; int64_t n_unique; };
+
+static result cpu_ref(const std::vector<int64_t>& ids, int64_t lower, int64_t span)
+{
+  const int64_t n = ids.size();
+  std::vector<uint32_t> key(n);
+  for (int64_t i = 0; i < n; i++) {
+    const uint64_t off = static_cast<uint64_t>(ids[i]) - static_cast<uint64_t>(lower);
+    key[i] = off < static_cast<uint64_t>(span) ? static_cast<uint32_t>(off) : static_cast<uint32_t>(span);
+  }
+  result r;
+  r.order.resize(n);
+  std::iota(r.order.begin(), r.order.end(), 0);
+  std::stable_sort(r.order.begin(), r.order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+  for (int64_t j = 0; j < n; j++) {
+    const uint32_t k = key[r.order[j]];
+    if (k == static_cast<uint32_t>(span)) break;
+    if (j == 0 || k != key[r.order[j - 1]]) { r.uniq.push_back(static_cast<int64_t>(k) + lower); r.starts.push_back(static_cast<int32_t>(j)); }
+  }
+  int64_t valid = 0;
+  for (int64_t i = 0; i < n; i++) valid += key[i] != static_cast<uint32_t>(span);
+  r.n_unique = r.uniq.size();
+  r.starts.push_back(static_cast<int32_t>(valid));
+  return r;
+}
+
+static int run_case(const char* name, const std::vector<int64_t>& ids, int64_t lower, int64_t span, bool timing)
+{
+  const int64_t n = ids.size();
+  split::plan p = split::make_plan(n, span, getenv("SPLIT_IPT") ? atoi(getenv("SPLIT_IPT")) : 0);
+  if (!p.ok) { printf("%-40s n=%ld span=%ld: plan not ok (skipped)\n", name, (long)n, (long)span); return 0; }
+  int64_t* d_ids; void* d_ws; int64_t* d_uniq; int32_t *d_starts, *d_order; int64_t* d_nu;
+  CK(hipMalloc(&d_ids, 8 * n)); CK(hipMalloc(&d_ws, p.total)); CK(hipMalloc(&d_uniq, 8 * n)); CK(hipMalloc(&d_starts, 4 * (n + 1)));
+  CK(hipMalloc(&d_order, 4 * n)); CK(hipMalloc(&d_nu, 8));
+  CK(hipMemcpy(d_ids, ids.data(), 8 * n, hipMemcpyHostToDevice));
+  CK(hipMemset(d_ws, 0xCD, p.total)); CK(hipMemset(d_order, 0xFF, 4 * n)); CK(hipMemset(d_starts, 0xFF, 4 * (n + 1)));
+  hipStream_t st; CK(hipStreamCreate(&st));
+  int rc = split::launch<uint64_t>(p, reinterpret_cast<const uint64_t*>(d_ids), n, static_cast<uint64_t>(lower), static_cast<uint32_t>(span),
+                                   d_uniq, d_starts, d_order, d_nu, d_ws, nullptr, 0, st);
+  CK(hipStreamSynchronize(st));
+  if (rc != 0) { printf("%s: launch rc %d\n", name, rc); return 1; }
+  uint32_t ctl[split::kCtlWords];
+  CK(hipMemcpy(ctl, static_cast<char*>(d_ws) + p.off_ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+  int bad = 0;
+  if (ctl[split::kCtlError]) { printf("%s: look-back timeout flagged\n", name); bad = 1; }
+  result ref = cpu_ref(ids, lower, span);
+  // does the CPU agree about the overflow?
+  {
+    std::vector<int64_t> cnt(p.buckets + 1, 0);
+    for (int64_t i = 0; i < n; i++) {
+      const uint64_t off = static_cast<uint64_t>(ids[i]) - static_cast<uint64_t>(lower);
+      if (off < static_cast<uint64_t>(span)) cnt[off >> p.shift]++;
+    }
+    bool ov = false;
+    for (int b = 0; b < p.buckets; b++) ov |= cnt[b] > split::kCap;
+    if (ov != (ctl[split::kCtlOverflow] != 0)) { printf("%s: overflow flag %u, expected %d\n", name, ctl[split::kCtlOverflow], (int)ov); bad = 1; }
+  }
+  if (ctl[split::kCtlOverflow]) {
+    printf("%-40s n=%ld span=%ld shift=%d buckets=%d: OVERFLOW (as expected: %s)\n", name, (long)n, (long)span, p.shift, p.buckets, bad ? "NO" : "yes");
+  } else {
+    int64_t nu; CK(hipMemcpy(&nu, d_nu, 8, hipMemcpyDeviceToHost));
+    std::vector<int32_t> order(n), starts(n + 1); std::vector<int64_t> uniq(n);
+    CK(hipMemcpy(order.data(), d_order, 4 * n, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(starts.data(), d_starts, 4 * (n + 1), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(uniq.data(), d_uniq, 8 * n, hipMemcpyDeviceToHost));
+    if (nu != ref.n_unique) { printf("%s: n_unique %ld, expected %ld\n", name, (long)nu, (long)ref.n_unique); bad = 1; }
+    else {
+      const int64_t valid = ref.starts.back();
+      int64_t e = 0;
+      for (int64_t j = 0; j < valid && e < 5; j++) if (order[j] != ref.order[j]) { printf("%s: order[%ld] = %d, expected %d\n", name, (long)j, order[j], ref.order[j]); e++; }
+      // the tail holds the dropped positions in receive order
+      for (int64_t j = valid; j < n && e < 5; j++) if (order[j] != ref.order[j]) { printf("%s: tail order[%ld] = %d, expected %d\n", name, (long)j, order[j], ref.order[j]); e++; }
+      for (int64_t j = 0; j <= nu && e < 10; j++) if (starts[j] != ref.starts[j]) { printf("%s: run_starts[%ld] = %d, expected %d\n", name, (long)j, starts[j], ref.starts[j]); e++; }
+      for (int64_t j = 0; j < nu && e < 15; j++) if (uniq[j] != ref.uniq[j]) { printf("%s: unique[%ld] = %ld, expected %ld\n", name, (long)j, (long)uniq[j], (long)ref.uniq[j]); e++; }
+      bad |= e != 0;
+    }
+    printf("%-40s n=%ld span=%ld shift=%d buckets=%d tiles=%d ipt=%d passes=%dx%d n_unique=%ld: %s\n", name, (long)n, (long)span, p.shift,
+           p.buckets, p.tiles, p.ipt, p.passes, p.digit_bits, (long)nu, bad ? "MISMATCH" : "ok");
+  }
+  if (timing && !bad) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; rep++) {
+      CK(hipEventRecord(e0, st));
+      const int K = 20;
+      for (int k = 0; k < K; k++)
+        split::launch<uint64_t>(p, reinterpret_cast<const uint64_t*>(d_ids), n, static_cast<uint64_t>(lower), static_cast<uint32_t>(span), d_uniq,
+                                d_starts, d_order, d_nu, d_ws, nullptr, 0, st);
+      CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("    timing: %.1f us per call (4 launches)\n", ms * 1000.f / K);
+    }
+  }
+  CK(hipFree(d_ids)); CK(hipFree(d_ws)); CK(hipFree(d_uniq)); CK(hipFree(d_starts)); CK(hipFree(d_order)); CK(hipFree(d_nu));
+  CK(hipStreamDestroy(st));
+  return bad;
+}
+
+int main(int argc, char** argv)
+{
+  const bool timing = argc > 1 && strcmp(argv[1], "time") == 0;
+  if (argc > 2) {   // debug mode: only the big case, kernels with parts switched off (results are wrong on purpose)
+    int dbg = atoi(argv[2]);
+    std::mt19937_64 r2(42);
+    std::vector<int64_t> v(10000000);
+    for (auto& x : v) x = static_cast<int64_t>(r2() % 100000000ull);
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(wm::split::g_split_debug), &dbg, sizeof(int)));
+    run_case("10M uniform / 100M rows (debug)", v, 0, 100000000, dbg != 0);
+    if (dbg == 0) {   // phase times of the last (only) call
+      static unsigned long long t[2][4096][12];
+      CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(wm::split::g_split_times), sizeof(t)));
+      const int nph[2] = {7, 11}, nwg[2] = {984, 1527};
+      for (int k = 0; k < 2; k++) {
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double ph[12] = {0};
+        for (int g = 0; g < nwg[k]; g++) {
+          if (t[k][g][0] < t0) t0 = t[k][g][0];
+          if (t[k][g][nph[k] - 1] > t1) t1 = t[k][g][nph[k] - 1];
+          for (int q = 1; q < nph[k]; q++) ph[q] += double(t[k][g][q] - t[k][g][q - 1]);
+        }
+        printf("kernel %d: span %.1f us; mean per-workgroup phase durations (us):", k, (t1 - t0) / 100.0);
+        double tot = 0;
+        for (int q = 1; q < nph[k]; q++) { printf(" %.2f", ph[q] / nwg[k] / 100.0); tot += ph[q] / nwg[k] / 100.0; }
+        printf("  | total %.2f\n", tot);
+      }
+    }
+    return 0;
+  }
+  std::mt19937_64 rng(42);
+  int bad = 0;
+  auto uniform = [&](int64_t n, int64_t lower, int64_t span, double drop_frac) {
+    std::vector<int64_t> v(n);
+    std::uniform_real_distribution<double> u(0.0, 1.0);
+    for (auto& x : v) {
+      x = lower + static_cast<int64_t>(rng() % static_cast<uint64_t>(span));
+      if (u(rng) < drop_frac) x = (rng() & 1) ? -1 - static_cast<int64_t>(rng() % 1000) : lower + span + static_cast<int64_t>(rng() % 1000);
+    }
+    return v;
+  };
+  const int64_t sizes[] = {1, 2, 63, 64, 65, 1000, 4097, 50000, 300000, 1000000};
+  const int64_t spans[] = {1, 7, 100, 65536, 1000003, 100000000, 125000000, INT64_C(1) << 27, (INT64_C(1) << 29) + 12345};
+  for (int64_t n : sizes)
+    for (int64_t sp : spans) {
+      char nm[96];
+      snprintf(nm, sizeof(nm), "uniform");
+      bad |= run_case(nm, uniform(n, 0, sp, 0.0), 0, sp, false);
+      snprintf(nm, sizeof(nm), "uniform+drops+lower");
+      bad |= run_case(nm, uniform(n, 12345678, sp, 0.05), 12345678, sp, false);
+    }
+  // all dropped, all equal
+  bad |= run_case("all dropped", std::vector<int64_t>(5000, -1), 0, 100000000, false);
+  bad |= run_case("all equal (small)", std::vector<int64_t>(9000, 77), 0, 100000000, false);
+  bad |= run_case("all equal (overflow)", std::vector<int64_t>(40000, 77), 0, 100000000, false);
+  // sorted, reversed
+  { std::vector<int64_t> v(200000); for (size_t i = 0; i < v.size(); i++) v[i] = static_cast<int64_t>(i) * 400; bad |= run_case("ascending", v, 0, 100000000, false);
+    std::reverse(v.begin(), v.end()); bad |= run_case("descending", v, 0, 100000000, false); }
+  // zipf (hashed): the hot id overflows its bucket
+  {
+    const int64_t n = 2000000, N = 100000000;
+    std::vector<int64_t> v(n);
+    std::uniform_real_distribution<double> u(0.0, 1.0);
+    for (auto& x : v) { const double r = u(rng); const uint64_t k = static_cast<uint64_t>(1.0 / std::pow(1.0 - r * 0.9999, 20.0)); x = static_cast<int64_t>((k * 2654435761ull) % N); }
+    bad |= run_case("zipf-like hashed", v, 0, N, false);
+  }
+  // the C4-sized batch
+  bad |= run_case("10M uniform / 100M rows", uniform(10000000, 0, 100000000, 0.0), 0, 100000000, timing);
+  bad |= run_case("10M uniform / 125M rows (shard)", uniform(10000000, 375000000, 125000000, 0.0), 375000000, 125000000, timing);
+  bad |= run_case("0.5M uniform / 100M rows", uniform(500000, 0, 100000000, 0.0), 0, 100000000, timing);
+  printf(bad ? "FAILED\n" : "ALL OK\n");
+  return bad;
+}

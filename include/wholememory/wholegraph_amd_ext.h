@@ -192,6 +192,12 @@ enum wholememory_error_code_t wholememory_ext_probe_memory(void* ptr, size_t byt
  * A counter for tests and benchmarks. */
 int64_t wholememory_ext_host_sorted_gathers(void);
 
+/* Number of owner-side id sorts (gradient apply, cached gather) of this process that were queued as the two-stage split sort
+ * (csrc/kernels/split_sort.cuh: bounded ids, at least WM_DEDUP_SPLIT_MIN of them, a bucket plan that fits) rather than as the
+ * generic radix sort. Whether a queued split sort then found a bucket too large and handed the batch to the gated generic path
+ * is decided on the device and not visible here. A counter for tests and benchmarks. */
+int64_t wholememory_ext_split_sorts(void);
+
 /* ---- (3) testing seam ---------------------------------------------------------------------- */
 /* Replaces the device backend. Refuses (WHOLEMEMORY_NOT_SUPPORTED) unless the environment has
  * WHOLEGRAPH_AMD_TESTING=1. `backend` is a const wm_device_backend* (wholegraph_amd/csrc/backend.hpp);

@@ -44,6 +44,19 @@ RULES = [
     (r"step_tile_kernel<", dict(min_loads=4, wide=True, max_valu=600, max_mov_share=0.45, scope="block", max_scratch=0)),
     # the tree fold of long runs: 4 gradient rows per thread in flight (round 3 shipped one)
     (r"tree_fold_kernel<", dict(min_loads=4, wide=True, max_valu=600, max_mov_share=0.45, scope="block", max_scratch=0)),
+    # round 5, the split sort of the owner-side ids (split_sort.cuh). What these kernels need from the compiler:
+    #  * the ids of a tile / the keys of a bucket are loaded as one batch (>= 4 loads with no wait between them);
+    #  * the bucket kernel and the small-tile scatter kernel stay within 64 VGPRs — two 1024-thread workgroups per CU is what
+    #    hides their barriers — the bucket kernel without scratch (the scatter kernel is allowed the 56 bytes hipcc spills at
+    #    that budget: measured equal to the 80-VGPR build at one workgroup per CU less);
+    #  * the histogram kernel: no scratch, loads batched.
+    (r"split::split_hist_kernel<", dict(min_loads=4, wide=False, max_valu=4000, max_mov_share=1.0, scope="block", max_scratch=0)),
+    (r"split::split_scatter_kernel<\w[\w ]*, 12>", dict(min_loads=4, wide=False, max_valu=4000, max_mov_share=1.0, scope="block",
+                                                        max_scratch=64, max_vgprs=64)),
+    (r"split::split_scatter_kernel<\w[\w ]*, 24>", dict(min_loads=4, wide=False, max_valu=4000, max_mov_share=1.0, scope="block",
+                                                        max_scratch=16, max_vgprs=128)),
+    (r"split::split_sort_kernel<", dict(min_loads=4, wide=False, max_valu=4000, max_mov_share=1.0, scope="block", max_scratch=0,
+                                        max_vgprs=64)),
 ]
 
 
@@ -188,6 +201,8 @@ def main():
                     vgprs, spilled, scratch = meta.get(mangled, (-1, -1, -1))
                     ok = loads >= rule["min_loads"] and counted < rule["max_valu"] and (share <= rule["max_mov_share"] or valu < 60)
                     if "max_scratch" in rule and scratch > rule["max_scratch"]:
+                        ok = False
+                    if "max_vgprs" in rule and vgprs > rule["max_vgprs"]:
                         ok = False
                     rows.append((dn.replace("wm::(anonymous namespace)::", "").replace("(wm::(anonymous namespace)::rows_params)", ""),
                                  loads, counted, rule["scope"], valu, share, vgprs, scratch, ok))

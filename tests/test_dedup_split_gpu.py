@@ -1,0 +1,126 @@
+"""The owner-side id sort as a split sort (csrc/kernels/split_sort.cuh) — reference exchange_embeddings_nccl_func.cu:76-174
+(stable radix sort of the received ids, payload = receive position, then unique_by_key and a SEQUENTIAL sum per id).
+
+The raw stage wholememory_ext_dedup_apply is run as an SGD step with lr = -1, weight decay 0 (row += ordered sum of its
+gradients) on RANDOM fp32 gradients: the result depends on the order in which duplicates are summed, so it is bit-identical to
+the oracle (oracle.dedup_grads: stable sort, sums in receive order) only if the sort is stable — on every path:
+  * map path      buckets whose rows appear <= 8 times (uniform ids)
+  * radix path    buckets with a longer run (LDS radix passes inside the same kernel)
+  * generic path  a bucket that does not fit LDS (> 8192 ids): the device-side overflow word switches the split kernels off and
+                  the gated onesweep + run detection on
+each forced to be taken by small batches through WM_DEDUP_SPLIT_MIN=1, and compared with WM_DEDUP_SPLIT=0 (rocPRIM)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    from wholegraph_amd.torch import wholegraph_env
+    import torch
+    return wholegraph_env.get_wholegraph_env_fns(), torch.cuda.current_stream().cuda_stream
+
+
+def _apply(ids, grads, rows, row_offset, idt):
+    import torch
+    from wholegraph_amd import binding as wmb
+    env, stream = _env()
+    dim = grads.shape[1]
+    d_table = torch.zeros((rows, dim), device="cuda")
+    d_ids, d_grads = torch.from_numpy(ids.astype(idt)).cuda(), torch.from_numpy(grads).cuda()
+    arr = (C.c_float * 6)(0.0, 1e-8, 0.9, 0.999, 0.99, 0.0)
+    nu = C.c_int64(-1)
+    wmb.check(wmb.lib().wholememory_ext_dedup_apply(
+        d_ids.data_ptr(), wmb.DT_INT if idt == np.int32 else wmb.DT_INT64, len(ids), d_grads.data_ptr(), dim, dim,
+        d_table.data_ptr(), dim, row_offset, rows, 1, arr, -1.0, None, None, C.byref(nu), env, stream))
+    torch.cuda.synchronize()
+    return d_table.cpu().numpy(), nu.value
+
+
+def _expect(ids, grads, rows, row_offset):
+    keep = (ids >= row_offset) & (ids < row_offset + rows)
+    uniq, dg = oracle.dedup_grads(ids[keep].astype(np.int64), grads[keep])
+    t = np.zeros((rows, grads.shape[1]), np.float32)
+    t[uniq - row_offset] = dg          # 0 - (-1) * sum: exact
+    return t, len(uniq)
+
+
+CASES = {
+    # name: (n, rows, row_offset, generator of ids in [0, rows))
+    "uniform_sparse": (60000, 5_000_000, 0, lambda r, n, rows: r.integers(0, rows, n)),
+    "uniform_offset_int32": (70001, 3_000_000, 40_000_000, lambda r, n, rows: r.integers(0, rows, n)),
+    "runs_up_to_8": (50000, 400_000, 0, lambda r, n, rows: np.repeat(r.integers(0, rows, n // 4), r.integers(1, 9, n // 4))[:n]),
+    "long_runs_radix_path": (40000, 4_000_000, 1000, lambda r, n, rows: np.where(r.random(n) < 0.3, r.integers(0, 40, n) * 70001 % rows,
+                                                                                r.integers(0, rows, n))),
+    "dense_small_table": (30000, 300, 0, lambda r, n, rows: r.integers(0, rows, n)),
+    "hot_id_overflows_bucket": (90000, 6_000_000, 0, lambda r, n, rows: np.where(r.random(n) < 0.25, 4242, r.integers(0, rows, n))),
+    "clustered_overflow": (120000, 100_000_000, 0, lambda r, n, rows: r.integers(0, 30000, n)),
+    "single_id": (20000, 1_000_000, 0, lambda r, n, rows: np.full(n, 777)),
+    "ascending": (50000, 50_000_000, 0, lambda r, n, rows: np.arange(n) * 997),
+    "two_to_27_rows": (65536, 1 << 27, 0, lambda r, n, rows: r.integers(0, rows, n)),
+}
+
+
+@pytest.mark.parametrize("split", ["forced", "off"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_split_sort_keeps_the_reference_order(gpu_env, knobs, name, split):
+    n, rows, off, gen = CASES[name]
+    rng = np.random.default_rng(abs(hash(name)) % (1 << 31))
+    ids = np.asarray(gen(rng, n, rows)).astype(np.int64)[:n] + off
+    # a few ids that address no row of the owner ("skip me" negatives, ids past its range): dropped, not counted
+    ids[rng.integers(0, n, 7)] = -1
+    ids[rng.integers(0, n, 5)] = off + rows + 3
+    grads = rng.standard_normal((n, 8)).astype(np.float32)
+    if split == "forced":
+        knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+    else:
+        knobs.set("WM_DEDUP_SPLIT", 0)
+    idt = np.int32 if "int32" in name else np.int64
+    rows_alloc = min(rows, 6_000_000)   # the table only needs the rows that are hit ...
+    if rows > rows_alloc:               # ... so big row ranges are folded into the head of the range (same keys, same order)
+        ids_eff = np.where((ids >= off) & (ids < off + rows), off + (ids - off) % rows_alloc, ids)
+        want, nu_want = _expect(ids_eff, grads, rows_alloc, off)
+        # sort keys differ after folding: run the device on the folded ids too, but with the FULL row range as its bound
+        got, nu = _apply_bounded(ids_eff, grads, rows_alloc, off, idt, rows)
+    else:
+        want, nu_want = _expect(ids, grads, rows, off)
+        got, nu = _apply(ids, grads, rows, off, idt)
+    assert nu == nu_want
+    assert got.tobytes() == want.tobytes()
+
+
+def _apply_bounded(ids, grads, rows_alloc, row_offset, idt, rows_bound):
+    """as _apply, but the owner's row range (what bounds the sort keys) is rows_bound while only rows_alloc rows are hit"""
+    import torch
+    from wholegraph_amd import binding as wmb
+    env, stream = _env()
+    dim = grads.shape[1]
+    d_table = torch.zeros((rows_alloc, dim), device="cuda")
+    d_ids, d_grads = torch.from_numpy(ids.astype(idt)).cuda(), torch.from_numpy(grads).cuda()
+    arr = (C.c_float * 6)(0.0, 1e-8, 0.9, 0.999, 0.99, 0.0)
+    nu = C.c_int64(-1)
+    # local_entry_count = rows_bound: the kernels only touch rows that occur, all of them < rows_alloc
+    wmb.check(wmb.lib().wholememory_ext_dedup_apply(
+        d_ids.data_ptr(), wmb.DT_INT if idt == np.int32 else wmb.DT_INT64, len(ids), d_grads.data_ptr(), dim, dim,
+        d_table.data_ptr(), dim, row_offset, rows_bound, 1, arr, -1.0, None, None, C.byref(nu), env, stream))
+    torch.cuda.synchronize()
+    return d_table.cpu().numpy(), nu.value
+
+
+def test_default_threshold_takes_the_split_sort_for_big_batches(gpu_env, knobs):
+    """2 M uniform ids on a 100 M-row range, defaults: the split sort (checked through its counter of launches)"""
+    from wholegraph_amd import binding as wmb
+    rng = np.random.default_rng(11)
+    n, rows_alloc, bound = 2_000_000, 4_000_000, 100_000_000
+    ids = rng.integers(0, rows_alloc, n).astype(np.int64)
+    grads = rng.integers(-3, 4, (n, 8)).astype(np.float32)
+    before = wmb.lib().wholememory_ext_split_sorts()
+    got, nu = _apply_bounded(ids, grads, rows_alloc, 0, np.int64, bound)
+    assert wmb.lib().wholememory_ext_split_sorts() == before + 1
+    want = np.zeros((rows_alloc, 8), np.float32)
+    np.add.at(want, ids, grads)        # integer-valued: exact in any order
+    assert nu == len(np.unique(ids)) and got.tobytes() == want.tobytes()

@@ -88,9 +88,13 @@ END_ROCPRIM_NAMESPACE
 #include "../knobs.hpp"
 #include "../backend.hpp"
 #include "device_common.cuh"
+#include "onesweep.cuh"
+#include "split_sort.cuh"
 
+#include <atomic>
 #include <mutex>
 #include <wholememory/embedding.h>
+#include <wholememory/wholegraph_amd_ext.h>
 
 namespace wm {
 namespace {
@@ -167,9 +171,11 @@ __device__ __forceinline__ int block_exclusive_sum(int v, int* total)
   return before + incl - v;
 }
 
+// `gate` (all three kernels): device word, 0 = the split sort has already written the runs, return at once (nullptr: always run)
 template <typename KeyT>
-__global__ __launch_bounds__(kBlock) void run_count_kernel(const KeyT* sorted, int64_t n, int32_t* tile_counts)
+__global__ __launch_bounds__(kBlock) void run_count_kernel(const KeyT* sorted, int64_t n, int32_t* tile_counts, const uint32_t* gate)
 {
+  if (gate != nullptr && *gate == 0u) return;
   bool head[kRunItems];
   KeyT key[kRunItems];
   const int heads = tile_heads(sorted, n, static_cast<int64_t>(blockIdx.x) * kRunTile, head, key);
@@ -181,8 +187,9 @@ __global__ __launch_bounds__(kBlock) void run_count_kernel(const KeyT* sorted, i
 // `last_key` / `drop_key`: when the LAST sorted key equals drop_key (the out-of-range marker of narrow_key_iterator), its run —
 // the last one — does not count (last_key == nullptr: nothing is dropped)
 __global__ __launch_bounds__(1024) void run_scan_kernel(int32_t* tile_counts, int n_tiles, int64_t* n_unique,
-                                                        const uint32_t* last_key, uint32_t drop_key)
+                                                        const uint32_t* last_key, uint32_t drop_key, const uint32_t* gate)
 {
+  if (gate != nullptr && *gate == 0u) return;
   // one workgroup walks the tile counts in chunks of 1024, carrying the running total
   __shared__ int wave_sums[16];
   __shared__ int carry_s;
@@ -213,8 +220,9 @@ __global__ __launch_bounds__(1024) void run_scan_kernel(int32_t* tile_counts, in
 template <typename KeyT, typename OutT>
 __global__ __launch_bounds__(kBlock) void run_compact_kernel(const KeyT* sorted, int64_t n, const int32_t* tile_prefix,
                                                              const int64_t* n_unique, OutT* unique_ids, int32_t* run_starts,
-                                                             OutT key_base, bool drop_last, KeyT drop_key)
+                                                             OutT key_base, bool drop_last, KeyT drop_key, const uint32_t* gate)
 {
+  if (gate != nullptr && *gate == 0u) return;
   // heads are ranked inside the tile, parked in LDS at their rank and written out as two coalesced streams (a thread's
   // own heads are kRunItems apart in rank order: written directly they cost a scattered store per item — 82 us vs ~35)
   __shared__ KeyT s_key[kRunTile];
@@ -320,6 +328,65 @@ struct dedup_layout {
   size_t total;
 };
 
+// ---- the split sort (split_sort.cuh) in front of the generic sort --------------------------------------------------------
+// Batches of bounded ids (the owner's row range is known) from kSplitMin ids up take the two-stage split sort; what it cannot
+// take — a bucket that does not fit LDS — it finds out on the device, so the generic path (onesweep.cuh + the run detection
+// above, every kernel gated on the split sort's overflow word) is enqueued behind it either way: ~7 launches that return at
+// once in the usual case. WM_DEDUP_SPLIT=0 switches the split sort off, WM_DEDUP_SPLIT_MIN moves the threshold.
+constexpr int64_t kSplitMin = 1 << 16;
+constexpr int kOswBlock = 512, kOswIpt = 16;   // profiles/r03_onesweep_ab.txt
+inline int64_t split_min()
+{
+  const char* off = WM_KNOB("WM_DEDUP_SPLIT");
+  if (off != nullptr && off[0] == '0') return INT64_MAX;
+  const char* e = WM_KNOB("WM_DEDUP_SPLIT_MIN");
+  return e != nullptr && atoll(e) > 0 ? atoll(e) : kSplitMin;
+}
+// The generic path's ~7 launches return at once in the usual case, but each still costs 5-8 us of the stream's time (47 us per
+// call in profiles/r05_grad_timeline_serial.txt). They depend on nothing but the overflow word (known after the split sort's
+// SECOND kernel), so they go to a side stream that forks there and joins after the split sort's last kernel: idle, they hide
+// under its two long kernels; when the batch overflowed, those two return at once and the caller's stream waits for the side.
+struct sort_lane {
+  std::mutex mu;   // one fork .. join sequence at a time: the events are shared
+  hipStream_t stream = nullptr;
+  hipEvent_t forked = nullptr, joined = nullptr;
+  bool ok = false;
+  sort_lane()
+  {
+    ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess;
+  }
+  static sort_lane& get()
+  {
+    static sort_lane lane;
+    return lane;
+  }
+};
+std::atomic<int64_t> g_split_sorts{0};
+struct split_layout {
+  void* split_ws;        // split::plan offsets apply; its first two arrays double as the generic sort's second (key, position) pair
+  uint32_t* sorted;      // generic path: sorted keys
+  int32_t* tile_counts;  // generic path: run detection
+  uint32_t* osw_ctrl;    // generic path: control words, zeroed by split_hist_kernel
+  size_t osw_ctrl_words;
+  size_t total;
+};
+inline split_layout split_carve(void* ws, int64_t n)
+{
+  auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  split_layout l;
+  char* p  = static_cast<char*>(ws);
+  size_t o = 0;
+  l.split_ws       = p + o, o += align(split::workspace_bound(n));
+  l.sorted         = reinterpret_cast<uint32_t*>(p + o), o += align(4 * static_cast<size_t>(n));
+  l.tile_counts    = reinterpret_cast<int32_t*>(p + o), o += align(4 * static_cast<size_t>((n + kBlock * 8 - 1) / (kBlock * 8) + 1));
+  l.osw_ctrl_words = osw::ctrl_words_bound<kOswBlock, kOswIpt>(n);
+  l.osw_ctrl       = reinterpret_cast<uint32_t*>(p + o), o += align(4 * l.osw_ctrl_words);
+  l.total          = o + 256;
+  return l;
+}
+
 inline int run_tiles(int64_t n) { return static_cast<int>((n + kRunTile - 1) / kRunTile); }
 
 template <typename SortKeyT>
@@ -348,18 +415,19 @@ dedup_layout<SortKeyT> layout(void* ws, int64_t n)
 
 template <typename SortKeyT, typename OutT>
 int detect_runs(const SortKeyT* sorted, int32_t* tile_counts, int64_t n, OutT* unique_ids, int32_t* run_starts,
-                int64_t* n_unique_out, hipStream_t stream, OutT key_base = 0, bool drop_last = false, SortKeyT drop_key = 0)
+                int64_t* n_unique_out, hipStream_t stream, OutT key_base = 0, bool drop_last = false, SortKeyT drop_key = 0,
+                const uint32_t* gate = nullptr)
 {
   const int tiles = run_tiles(n);
   const uint32_t* last_key = nullptr;
   if constexpr (sizeof(SortKeyT) == 4) {
     if (drop_last) last_key = reinterpret_cast<const uint32_t*>(sorted + (n - 1));
   }
-  hipLaunchKernelGGL((run_count_kernel<SortKeyT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts);
+  hipLaunchKernelGGL((run_count_kernel<SortKeyT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts, gate);
   hipLaunchKernelGGL(run_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, tiles, n_unique_out, last_key,
-                     static_cast<uint32_t>(drop_key));
+                     static_cast<uint32_t>(drop_key), gate);
   hipLaunchKernelGGL((run_compact_kernel<SortKeyT, OutT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts,
-                     n_unique_out, unique_ids, run_starts, key_base, last_key != nullptr, drop_key);
+                     n_unique_out, unique_ids, run_starts, key_base, last_key != nullptr, drop_key, gate);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -372,6 +440,47 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
   // the payload 0, 1, 2 ... is generated by the sort's first pass (counting iterator): no iota array
   rocprim::counting_iterator<int32_t> positions(0);
   const int64_t span = key_upper_bound > 0 ? key_upper_bound - key_lower_bound : 0;
+  if (span > 0 && span < INT64_C(0xFFFFFFFF) && n >= split_min()) {
+    const split::plan sp = split::make_plan(n, span);
+    if (sp.ok) {
+      const split_layout sl = split_carve(workspace, n);
+      const unsigned bits   = significant_bits(span + 1, 32);
+      const size_t ctrl     = osw::ctrl_words<kOswBlock, kOswIpt>(n, bits);
+      // the generic path, gated on the overflow word, between the split sort's second and third kernel — on the side stream
+      // (WM_DEDUP_SERIAL=1: on the caller's stream, for measurements)
+      const uint32_t* gate = split::overflow_word(sp, sl.split_ws);
+      char* sw             = static_cast<char*>(sl.split_ws);
+      narrow_key_iterator<UKey> keys{static_cast<const UKey*>(ids), static_cast<UKey>(key_lower_bound), static_cast<uint32_t>(span)};
+      const bool serial = WM_KNOB("WM_DEDUP_SERIAL") != nullptr;
+      std::unique_lock<std::mutex> lane_lock;
+      if (!serial) lane_lock = std::unique_lock<std::mutex>(sort_lane::get().mu);
+      int generic_rc = 0;
+      auto generic = [&](hipStream_t gs) {
+        generic_rc = osw::sort_pairs<kOswBlock, kOswIpt>(keys, sl.sorted, reinterpret_cast<uint32_t*>(order), n, bits,
+                                                         reinterpret_cast<uint32_t*>(sw + sp.off_keys),
+                                                         reinterpret_cast<uint32_t*>(sw + sp.off_pos), sl.osw_ctrl, gate, gs);
+        if (generic_rc == 0)
+          generic_rc = detect_runs<uint32_t, UKey>(sl.sorted, sl.tile_counts, n, static_cast<UKey*>(unique_ids), run_starts,
+                                                   n_unique_out, gs, static_cast<UKey>(key_lower_bound), true,
+                                                   static_cast<uint32_t>(span), gate);
+      };
+      bool forked = false;
+      auto between = [&]() {
+        sort_lane& lane = sort_lane::get();
+        forked = !serial && lane.ok && hipEventRecord(lane.forked, stream) == hipSuccess &&
+                 hipStreamWaitEvent(lane.stream, lane.forked, 0) == hipSuccess;
+        generic(forked ? lane.stream : stream);
+        if (forked) forked = hipEventRecord(lane.joined, lane.stream) == hipSuccess;
+      };
+      if (split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound), static_cast<uint32_t>(span),
+                              unique_ids, run_starts, order, n_unique_out, sl.split_ws, sl.osw_ctrl, static_cast<int64_t>(ctrl),
+                              stream, between) != 0)
+        return -2;
+      if (forked && hipStreamWaitEvent(stream, sort_lane::get().joined, 0) != hipSuccess) return -2;
+      g_split_sorts.fetch_add(1, std::memory_order_relaxed);
+      return generic_rc;
+    }
+  }
   if (span > 0 && span < INT64_C(0xFFFFFFFF)) {
     // a bounded range of fewer than 2^32 - 1 rows: 32-bit keys relative to its start, the value `span` marks ids outside it
     const unsigned bits = significant_bits(span + 1, 32);
@@ -1346,6 +1455,29 @@ struct long_lane {
   {
     return hipEventRecord(joined, stream) == hipSuccess && hipStreamWaitEvent(into, joined, 0) == hipSuccess;
   }
+  // How many long runs the last finished call listed (pinned; written by a device-to-host copy behind the long-run kernels,
+  // read by the host without synchronising, so it lags a call or two): starts at 1 = "expect long runs".
+  // The side stream costs the USUAL call — the one whose list stays empty — two cross-stream hand-overs in front of the tile
+  // kernel (fork -> fill + listing -> `marked` -> tile: ~40 us, profiles/r05_grad_timeline_serial.txt). While the previous
+  // calls listed nothing, everything is queued on the caller's stream instead (fill, listing, the long-run kernels finding an
+  // empty list, tile kernel: ~20 us). A wrong guess costs time only, once: the long runs are then folded BEFORE the tile
+  // kernel instead of beside it, and the next call sees the count. WM_STEP_SERIAL=1 / 0 forces the choice.
+  volatile int32_t* listed = nullptr;
+  bool expect_long()
+  {
+    if (listed == nullptr) {
+      void* h = nullptr;
+      if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess) return true;
+      listed  = static_cast<volatile int32_t*>(h);
+      *listed = 1;
+    }
+    return *listed != 0;
+  }
+  void report(const int32_t* long_count_dev, hipStream_t s)
+  {
+    if (listed != nullptr)
+      (void)hipMemcpyAsync(const_cast<int32_t*>(listed), long_count_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+  }
 };
 
 // step_short_kernel fills every wave slot of the chip with persistent waves: whatever is to run NEXT to it has to be on
@@ -1858,11 +1990,19 @@ __global__ void fill_float_kernel(float* p, float v, int64_t n)
 
 }  // namespace
 
+}  // namespace wm
+extern "C" int64_t wholememory_ext_split_sorts(void) { return wm::g_split_sorts.load(std::memory_order_relaxed); }
+namespace wm {
+
 size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype)
 {
   if (n <= 0) return 256;
-  if (index_dtype == WHOLEMEMORY_DT_INT) return layout<uint32_t>(nullptr, n).total;
-  return layout<uint64_t>(nullptr, n).total;
+  // the bounded-key path carves the 32-bit layout whatever the index type, and the split sort its own (advisor, round 4:
+  // the 64-bit layout alone can be the smaller one)
+  size_t most = layout<uint32_t>(nullptr, n).total;
+  if (index_dtype != WHOLEMEMORY_DT_INT) most = std::max(most, layout<uint64_t>(nullptr, n).total);
+  if (n < (INT64_C(1) << 30)) most = std::max(most, split_carve(nullptr, n).total);
+  return most;
 }
 
 int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, int64_t key_lower_bound,
@@ -1978,11 +2118,13 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   }
   // the long-run side goes to its own stream (WM_STEP_SERIAL=1: everything on the caller's stream, for measurements)
   hipStream_t lstream = stream;
-  const bool serial = WM_KNOB("WM_STEP_SERIAL") != nullptr;
+  const char* serial_env = WM_KNOB("WM_STEP_SERIAL");
   std::unique_lock<std::mutex> lane_lock;
-  if (p.long_list != nullptr && !serial) lane_lock = std::unique_lock<std::mutex>(long_lane::get().mu);
-  if (p.long_list != nullptr && hipMemsetAsync(p.long_count, 0, p.fold_tree ? 64 : 16, stream) != hipSuccess) return -2;
+  if (p.long_list != nullptr) lane_lock = std::unique_lock<std::mutex>(long_lane::get().mu);
+  const bool serial = serial_env != nullptr ? serial_env[0] != '0' : (p.long_list != nullptr && !long_lane::get().expect_long());
   if (p.long_list != nullptr && !serial && long_lane::get().fork(stream)) lstream = long_lane::get().stream;
+  // (the counters are cleared on the side stream: only the long-run kernels read them)
+  if (p.long_list != nullptr && hipMemsetAsync(p.long_count, 0, p.fold_tree ? 64 : 16, lstream) != hipSuccess) return -2;
   int64_t waves = a->count;
   int max_blocks = 256 * 8;
   if (const char* e = WM_KNOB("WM_STEP_BLOCKS")) max_blocks = std::max(1, atoi(e));
@@ -1991,6 +2133,7 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   int rc = -1;
   if (a->index_dtype == WHOLEMEMORY_DT_INT) rc = launch_step<int32_t>(p, blocks, stream, lstream);
   if (a->index_dtype == WHOLEMEMORY_DT_INT64) rc = launch_step<int64_t>(p, blocks, stream, lstream);
+  if (p.long_list != nullptr) long_lane::get().report(p.long_count, lstream);
   if (lstream != stream && !long_lane::get().join(stream)) return -2;  // the caller's stream continues after both sides
   return rc;
 }

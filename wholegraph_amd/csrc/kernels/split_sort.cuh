@@ -1,0 +1,849 @@
+// wholegraph_amd — the owner-side id sort of the gradient apply as a two-stage "split sort" (gfx950 HIP, wave64).
+//
+// What it computes (reference: exchange_embeddings_nccl_func.cu:76-174 — cub::DeviceRadixSort::SortPairs of the received ids
+// with the receive position as payload, then unique_by_key): the stable ascending order of the ids, the start of every run of
+// equal ids in that order, and the unique ids. A stable sort has exactly one answer, so any algorithm that is stable gives the
+// reference's bits; this one exploits what the owner knows — keys are row numbers of ITS shard (< 2^27 for a 125 M-row shard),
+// the payload is a position < 2^31 — instead of running a generic radix sort three times over the pairs:
+//
+//   stage 1 (three launches, no workgroup waits for another):
+//     split_hist_kernel     per tile of the ids: a histogram over BUCKETS = the top key bits (<= 2047 buckets of 2^shift rows
+//                           each, + one "drop" bucket for ids outside the owner's range), written as one row of a
+//                           tiles x buckets matrix
+//     split_scan_kernel     column-wise exclusive prefix of the matrix (a tile's start inside each bucket), bucket totals,
+//                           the overflow verdict (a bucket that would not fit stage 2's LDS), and the zeroing of the control
+//                           words of what follows
+//     split_scatter_kernel  re-reads its tile, ranks every id among the ids of its bucket in the tile STABLY (the lanes of a
+//                           wave that hold the same bucket find each other with one ballot per bucket bit; per-wave counters
+//                           in LDS), brings the tile into bucket order in LDS and writes keys and positions bucket by bucket,
+//                           each bucket's share of the tile as one contiguous segment: a stable multisplit. (Written straight
+//                           from the registers, one 8-byte word per lane and bucket, the 10 M write requests alone cost
+//                           75 us: profiles/r05_split_sort_steps.txt.)
+//   stage 2 (one launch):
+//     split_sort_kernel     one workgroup per bucket (handed out by an atomic ticket, so a workgroup only ever waits for
+//                           workgroups that already run) brings the bucket's (low key bits << 13 | index in the bucket) words
+//                           into order in LDS. A bucket spans <= 2^16 rows and holds a few thousand ids, so the usual case
+//                           needs no radix pass at all: a 65536-bit map of the rows present (8 KB of LDS) and its prefix
+//                           popcounts give every id the RANK OF ITS ROW among the bucket's rows — which is the run it belongs
+//                           to — an LDS counter per run gives it a slot in the run, an exclusive scan of the counters gives
+//                           the run starts, and runs of more than one id (5 % for 10 M ids on 100 M rows) are put into
+//                           receive order by the thread that owns the run. Buckets with a run of more than kMaxDup ids or
+//                           more than 16 low bits take 2-3 stable least-significant-digit passes of the ballot ranking
+//                           instead. Either way the runs are known THERE: order[], run_starts[], unique_ids[] are written
+//                           by the same kernel; the global rank of a bucket's first run comes from a decoupled look-back
+//                           over the buckets' run counts (one status word per bucket, published as soon as the map is
+//                           counted); the last workgroup publishes the number of runs and the closing run_starts entry.
+//
+// Traffic for 10 M ids: ids read twice (0.16 GB) + words written and read once (0.16 GB) + outputs (0.16 GB), against
+// three read + write passes over (key, position) pairs plus histogram plus three run-detection passes before (~0.75 GB), and
+// 4 launches instead of 11 + 8 fills.
+//
+// When a bucket does not fit (more than kCap ids: a hot id of a Zipf batch, ids clustered in a few thousand rows), the scan
+// kernel raises the overflow word, stages 1c / 2 return at once, and the caller's generic path — gated on the same word, see
+// optim.hip: run_dedup — sorts the batch instead. The decision is taken on the device: no host synchronisation, capturable.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wm {
+namespace split {
+
+#ifdef WM_SPLIT_DEBUG
+__device__ int g_split_debug = 0;   // experiments only: kernels with parts switched off (results are wrong on purpose)
+#define WM_SPLIT_DBG(x) (g_split_debug == (x))
+__device__ unsigned long long g_split_times[2][4096][12];   // [kernel][workgroup][phase] wall_clock64 of thread 0
+#define WM_SPLIT_T(kern, wg, ph) do { if (threadIdx.x == 0 && (wg) < 4096) g_split_times[kern][wg][ph] = wall_clock64(); } while (0)
+#else
+#define WM_SPLIT_DBG(x) false
+#define WM_SPLIT_T(kern, wg, ph) do { } while (0)
+#endif
+
+constexpr int kBlock      = 1024;
+constexpr int kWaves      = kBlock / 64;
+constexpr int kMaxBuckets = 2048;                 // real buckets (the drop bucket comes on top)
+constexpr int kMaxPitch   = kMaxBuckets + 32;
+constexpr int kIdxBits    = 13;
+constexpr int kCap        = 1 << kIdxBits;        // ids of one bucket that stage 2 brings into order in LDS
+constexpr int kMaxLowBits = 32 - kIdxBits;        // low key bits that fit the sort word beside the index
+constexpr int kMapBits    = 16;                   // low key bits the row map of stage 2 covers (2^16 bits = 8 KB)
+constexpr int kMaxDup     = 8;                    // runs of more ids than this send their bucket to the radix passes
+constexpr int kMaxIpt     = 24;                   // ids per thread of a stage-1 tile, at most
+constexpr int kMaxTiles   = 1024;
+constexpr int kSortIpt    = kCap / kBlock;        // 8
+constexpr uint32_t kFlagAggregate = 1u << 30, kFlagPrefix = 2u << 30, kValueMask = (1u << 30) - 1;
+
+// control words (u32), zeroed by split_hist_kernel's first workgroup
+enum { kCtlOverflow = 0, kCtlTicket = 1, kCtlError = 2, kCtlRadixBuckets = 3, kCtlWords = 8 };
+
+struct plan {
+  bool ok;            // false: the batch does not suit the split sort (too many ids per bucket, too many key bits)
+  int shift;          // low key bits (ordered in LDS); bucket = key >> shift
+  int buckets;        // real buckets; the drop bucket has index `buckets`
+  int pitch;          // row pitch of the counts matrix (multiple of 32, >= buckets + 2)
+  int ipt, tile, tiles;
+  int passes, digit_bits;   // of the radix passes of stage 2
+  int bucket_bits;    // ballots per id in the scatter kernel: bits of `buckets`
+  // workspace carve (bytes from the workspace start)
+  size_t off_keys, off_pos, off_counts, off_totals, off_starts, off_state, off_ctl, total;
+};
+
+inline plan make_plan(int64_t n, int64_t span, int ipt_override = 0)
+{
+  plan p{};
+  p.ok = false;
+  if (n <= 0 || span <= 0 || span >= INT64_C(0xFFFFFFFF) || n >= (INT64_C(1) << 30)) return p;
+  auto buckets_at = [&](int s) { return ((span - 1) >> s) + 1; };
+  int s = 0;
+  while (buckets_at(s) > kMaxBuckets) s++;   // as few low bits as the bucket limit allows ...
+  // ... and for small batches fewer, larger buckets, as long as the row map of stage 2 covers them
+  const int64_t want = n / 1536 > 1 ? n / 1536 : 1;
+  while (s < kMapBits && buckets_at(s) > want) s++;
+  if (s > kMaxLowBits) return p;
+  p.shift   = s;
+  p.buckets = static_cast<int>(buckets_at(s));
+  // uniform ids must leave headroom in a bucket (the overflow path is correct but it is the slow one)
+  if (n / p.buckets > kCap * 85 / 100) return p;
+  p.pitch = (p.buckets + 2 + 31) / 32 * 32;
+  // tiles: about two rounds of the 512 workgroups the chip holds (2 per CU while a tile's LDS stays under 80 KB)
+  int ipt = static_cast<int>((n + 1000 * kBlock - 1) / (1000 * kBlock));
+  if (ipt < 4) ipt = 4;
+  if (ipt > kMaxIpt) ipt = kMaxIpt;
+  if (ipt_override > 0 && ipt_override <= kMaxIpt) ipt = ipt_override;   // experiments
+  p.ipt   = ipt;
+  p.tile  = ipt * kBlock;
+  p.tiles = static_cast<int>((n + p.tile - 1) / p.tile);
+  if (p.tiles > kMaxTiles) return p;
+  p.passes      = s == 0 ? 0 : (s + 7) / 8;
+  p.digit_bits  = p.passes == 0 ? 0 : (s + p.passes - 1) / p.passes;
+  p.bucket_bits = 1;
+  while ((1 << p.bucket_bits) <= p.buckets) p.bucket_bits++;
+  auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  size_t o = 0;
+  p.off_keys   = o, o += align(4 * static_cast<size_t>(n));
+  p.off_pos    = o, o += align(4 * static_cast<size_t>(n));
+  p.off_counts = o, o += align(4 * static_cast<size_t>(p.tiles) * p.pitch);
+  p.off_totals = o, o += align(4 * static_cast<size_t>(p.pitch));
+  p.off_starts = o, o += align(4 * static_cast<size_t>(p.pitch + 2));
+  p.off_state  = o, o += align(4 * static_cast<size_t>(p.pitch + 2));
+  p.off_ctl    = o, o += align(4 * kCtlWords);
+  p.total      = o;
+  p.ok         = true;
+  return p;
+}
+
+// upper bound of plan::total over every span (the workspace is sized before the span is known)
+inline size_t workspace_bound(int64_t n)
+{
+  auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  if (n <= 0) return 256;
+  return 2 * align(4 * static_cast<size_t>(n)) + align(4 * static_cast<size_t>(kMaxTiles) * kMaxPitch) +
+         3 * align(4 * (kMaxPitch + 2)) + align(4 * kCtlWords) + 256;
+}
+
+// ids as 32-bit keys relative to the owner's first row; an id outside [base, base + span) reads as the key `span`
+template <typename UKey>
+struct key_source {
+  const UKey* ids;
+  UKey base;
+  uint32_t span;
+  __device__ __forceinline__ uint32_t narrow(UKey id) const
+  {
+    const UKey off = id - base;
+    return off < static_cast<UKey>(span) ? static_cast<uint32_t>(off) : span;
+  }
+  __device__ __forceinline__ uint32_t key(int64_t i) const { return narrow(ids[i]); }
+};
+
+// consecutive tiles on the same XCD (workgroups go to the 8 XCDs round-robin): the segments two neighbouring tiles write
+// into a bucket are neighbours in memory and meet in one L2 instead of in two
+__device__ __forceinline__ int tile_of_block(int bid, int tiles)
+{
+  const int per = (tiles + 7) / 8;
+  return (bid & 7) * per + (bid >> 3);
+}
+inline int tile_grid(int tiles) { return (tiles + 7) / 8 * 8; }
+
+__device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* s_waves /* kWaves words */, uint32_t* total)
+{
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t incl  = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  __syncthreads();   // s_waves may still be read from an earlier call
+  if (lane == 63) s_waves[wv] = incl;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    const uint32_t t = s_waves[w];
+    if (w < wv) before += t;
+    all += t;
+  }
+  if (total != nullptr) *total = all;
+  return before + incl - v;
+}
+
+// lanes of the wave that hold the same `value` (low `bits` bits compared) among the lanes in `among`
+__device__ __forceinline__ uint64_t match_lanes(uint32_t value, int bits, uint64_t among)
+{
+  uint64_t m = among;
+  for (int b = 0; b < bits; b++) {
+    const bool bit     = (value >> b) & 1u;
+    const uint64_t bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+
+// ---- stage 1a: per-tile bucket histogram -------------------------------------------------------------------------------
+template <typename UKey>
+__global__ __launch_bounds__(kBlock) void split_hist_kernel(key_source<UKey> src, int64_t n, int tile, int tiles, int shift,
+                                                            int buckets, int pitch, uint32_t* counts, uint32_t* ctl,
+                                                            uint32_t* zero_words, int64_t n_zero_words)
+{
+  __shared__ uint32_t s_hist[kMaxPitch];
+  if (blockIdx.x == 0 && threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0;
+  // the control words of the caller's generic path (look-back state of its passes): zeroed here, on the way, not by a fill
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_zero_words;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    zero_words[i] = 0;
+  const int t = tile_of_block(blockIdx.x, tiles);
+  if (t >= tiles) return;
+  for (int i = threadIdx.x; i < pitch; i += kBlock) s_hist[i] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(t) * tile;
+  const int64_t end  = base + tile < n ? base + tile : n;
+  int64_t i          = base + threadIdx.x;
+  constexpr int U    = 8;
+  for (; i + (U - 1) * kBlock < end; i += U * kBlock) {
+    uint32_t k[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) k[u] = src.key(i + u * kBlock);
+#pragma unroll
+    for (int u = 0; u < U; u++) atomicAdd(&s_hist[k[u] >= src.span ? buckets : static_cast<int>(k[u] >> shift)], 1u);
+  }
+  for (; i < end; i += kBlock) {
+    const uint32_t k = src.key(i);
+    atomicAdd(&s_hist[k >= src.span ? buckets : static_cast<int>(k >> shift)], 1u);
+  }
+  __syncthreads();
+  uint32_t* row = counts + static_cast<size_t>(t) * pitch;
+  for (int j = threadIdx.x; j < pitch; j += kBlock) row[j] = s_hist[j];
+}
+
+// ---- stage 1b: column-wise exclusive prefix of the counts matrix --------------------------------------------------------
+// one workgroup = 32 columns x all tiles: thread (row group rg, column c) owns rows_per consecutive tiles of its column
+__global__ __launch_bounds__(kBlock) void split_scan_kernel(uint32_t* counts, int tiles, int pitch, int buckets, uint32_t* totals,
+                                                            uint32_t* ctl, int cap, uint32_t* state, int state_words)
+{
+  __shared__ uint32_t s_g[32][33];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int col      = blockIdx.x * 32 + c;
+  const int rows_per = (tiles + 31) / 32;   // <= kMaxTiles / 32 = 32
+  const int r0       = rg * rows_per;
+  uint32_t v[kMaxTiles / 32];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxTiles / 32; k++) {
+    const int r = r0 + k;
+    v[k]        = (k < rows_per && r < tiles && col < pitch) ? counts[static_cast<size_t>(r) * pitch + col] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxTiles / 32; k++) {
+    const uint32_t t = v[k];
+    v[k]             = sum;
+    sum += t;
+  }
+  s_g[rg][c] = sum;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int g = 0; g < 32; g++) {
+    const uint32_t t = s_g[g][c];
+    if (g < rg) before += t;
+    total += t;
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxTiles / 32; k++) {
+    const int r = r0 + k;
+    if (k < rows_per && r < tiles && col < pitch) counts[static_cast<size_t>(r) * pitch + col] = before + v[k];
+  }
+  if (rg == 0 && col < pitch) {
+    totals[col] = total;
+    if (col < buckets && total > static_cast<uint32_t>(cap)) atomicOr(&ctl[kCtlOverflow], 1u);
+  }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < state_words; i += gridDim.x * kBlock) state[i] = 0;
+}
+
+// ---- stage 1c: stable multisplit --------------------------------------------------------------------------------------
+inline size_t scatter_lds_bytes(int pitch, int ipt)
+{
+  // counters, later (same memory) the tile's keys (4 bytes each) + indices in the tile (2 bytes each)
+  const size_t cnt = 4 * static_cast<size_t>(pitch) * (kWaves / 2), buf = 6 * static_cast<size_t>(ipt) * kBlock;
+  return 4 * static_cast<size_t>(pitch) + (cnt > buf ? cnt : buf);
+}
+
+template <typename UKey, int MAXIPT>
+__global__ __launch_bounds__(kBlock, MAXIPT <= 12 ? 8 : 4) void split_scatter_kernel(key_source<UKey> src, int64_t n, int ipt, int tiles, int shift,
+                                                               int buckets, int bucket_bits, int pitch, const uint32_t* counts,
+                                                               const uint32_t* totals, uint32_t* bucket_start, uint32_t* keys_out,
+                                                               uint32_t* pos_out, const uint32_t* ctl)
+{
+  if (ctl[kCtlOverflow] != 0) return;
+  const int t = tile_of_block(blockIdx.x, tiles);
+  if (t >= tiles) return;
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_off = s_mem;           // [pitch]  global position of this tile's segment of a bucket MINUS its start in the tile
+  uint32_t* s_cnt = s_off + pitch;   // [kWaves / 2][pitch] per-wave counters, two 16-bit halves per word (wave w: word w / 2)
+  uint32_t* s_buf = s_cnt;           // [tile]   the tile in bucket order (the counters are dead by then)
+  __shared__ uint32_t s_waves[kWaves];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tile = ipt * kBlock;
+  WM_SPLIT_T(0, blockIdx.x, 0);
+
+  // load, wave-striped: wave w owns ids [w, w + 1) x 64 x ipt of the tile, item j of lane l is id j x 64 + l of that chunk,
+  // so (w, j, l) order is memory order and every load instruction is one contiguous 512-byte read (issued first: the scan of
+  // the totals below runs under their latency)
+  const int64_t base  = static_cast<int64_t>(t) * tile;
+  const int local0    = wv * (64 * ipt) + lane;
+  const int valid_n   = static_cast<int>(n - base < tile ? n - base : tile);
+  uint32_t key[MAXIPT];
+  uint32_t slot[MAXIPT];   // rank in the wave's share of the bucket, later: position in the tile's bucket order
+  // UNCONDITIONAL loads, in batches of up to 8 with nothing between them (a load under a condition is a load the compiler waits
+  // for before it issues the next: scripts/check_isa.py counted ONE load in flight here): lanes past the tile's end and items
+  // past ipt re-read the tile's last id
+#pragma unroll
+  for (int j0 = 0; j0 < MAXIPT; j0 += 8) {
+    UKey raw[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int li  = local0 + (j0 + u) * 64;
+      const bool in = j0 + u < MAXIPT && j0 + u < ipt && li < valid_n;
+      raw[u]        = src.ids[base + (in ? li : valid_n - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (j0 + u < MAXIPT) key[j0 + u] = (j0 + u < ipt && local0 + (j0 + u) * 64 < valid_n) ? src.narrow(raw[u]) : 0xFFFFFFFFu;
+  }
+
+  // bucket starts = exclusive scan of the totals (every workgroup redoes these ~2 k additions rather than wait for a kernel)
+  const int per = (pitch + kBlock - 1) / kBlock;   // <= 3 consecutive buckets per thread
+  const int b0  = threadIdx.x * per;
+  {
+    uint32_t tt[3] = {0, 0, 0}, mine = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      if (i < per && b0 + i < pitch) tt[i] = totals[b0 + i], mine += tt[i];
+    uint32_t run = block_exclusive_sum(mine, s_waves, nullptr);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      if (i < per && b0 + i < pitch) {
+        s_off[b0 + i] = run + counts[static_cast<size_t>(t) * pitch + b0 + i];
+        if (t == 0) bucket_start[b0 + i] = run;   // [buckets] = number of ids inside the range, [buckets + 1] = n
+        run += tt[i];
+      }
+  }
+  for (int i = threadIdx.x; i < (kWaves / 2) * pitch; i += kBlock) s_cnt[i] = 0;
+  __syncthreads();
+  WM_SPLIT_T(0, blockIdx.x, 1);
+
+  const uint64_t lt = (1ull << lane) - 1ull;
+  uint32_t* my_cnt  = s_cnt + (wv >> 1) * pitch;
+  const int half    = (wv & 1) * 16;
+  // rank of an id among the ids of its bucket in this wave's share of the tile, stable. One LDS add per id hands out slots
+  // (the wave's counter of the bucket; lanes of one instruction that share a bucket get theirs in no particular order), the
+  // counter read back tells a lane whether it was alone (2048 buckets, 64 lanes: mostly), and only the buckets that several
+  // lanes of the step share — one ballot each — are put into lane order. (One ballot per bucket BIT for every step, the
+  // usual match, made this loop 17 of the kernel's 37 us per tile: profiles/r05_split_sort_steps.txt.)
+#pragma unroll
+  for (int j = 0; j < MAXIPT; j++) {
+    if (j < ipt) {
+      const bool valid = local0 + j * 64 < valid_n;
+      const uint32_t b = key[j] >= src.span ? static_cast<uint32_t>(buckets) : key[j] >> shift;
+      uint32_t oldc = 0, nowc = 0;
+      if (valid) {
+        oldc = (atomicAdd(&my_cnt[b], 1u << half) >> half) & 0xFFFFu;
+        nowc = (__hip_atomic_load(&my_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> half) & 0xFFFFu;
+      }
+      uint32_t s    = oldc;
+      uint64_t coll = __ballot(valid && nowc - oldc > 1u);
+      while (coll != 0) {
+        const int c        = __ffsll(static_cast<long long>(coll)) - 1;
+        const uint32_t bc  = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(b), c));
+        const uint64_t grp = __ballot(valid && b == bc);
+        if (valid && b == bc) s = nowc - static_cast<uint32_t>(__popcll(grp)) + static_cast<uint32_t>(__popcll(grp & lt));
+        coll &= ~grp;
+      }
+      slot[j] = s;
+    }
+  }
+  __syncthreads();
+  WM_SPLIT_T(0, blockIdx.x, 2);
+  // per bucket: exclusive prefix over the waves (16-bit: a tile has <= 24 K ids), the bucket's start in the tile's bucket order
+  {
+    uint32_t cnt3[3] = {0, 0, 0}, mine = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      if (i < per && b0 + i < pitch) {
+        const int b  = b0 + i;
+        uint32_t run = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kWaves / 2; w2++) {
+          const uint32_t word = s_cnt[w2 * pitch + b];
+          const uint32_t lo = word & 0xFFFFu, hi = word >> 16;
+          s_cnt[w2 * pitch + b] = run | ((run + lo) << 16);
+          run += lo + hi;
+        }
+        cnt3[i] = run;
+        mine += run;
+      }
+    uint32_t lstart = block_exclusive_sum(mine, s_waves, nullptr);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      if (i < per && b0 + i < pitch) {
+        const int b = b0 + i;
+        s_off[b] -= lstart;
+        const uint32_t both = lstart | (lstart << 16);
+#pragma unroll
+        for (int w2 = 0; w2 < kWaves / 2; w2++) s_cnt[w2 * pitch + b] += both;
+        lstart += cnt3[i];
+      }
+  }
+  __syncthreads();
+  WM_SPLIT_T(0, blockIdx.x, 3);
+#pragma unroll
+  for (int j = 0; j < MAXIPT; j++) {
+    if (j < ipt && local0 + j * 64 < valid_n) {
+      const uint32_t b = key[j] >= src.span ? static_cast<uint32_t>(buckets) : key[j] >> shift;
+      slot[j] += (my_cnt[b] >> half) & 0xFFFFu;
+    }
+  }
+  __syncthreads();   // the counters have been read: their memory becomes the tile buffer
+  WM_SPLIT_T(0, blockIdx.x, 4);
+  // keys and 16-bit indices in the tile through LDS together, out as one contiguous segment per bucket
+  uint16_t* s_idx = reinterpret_cast<uint16_t*>(s_buf + tile);   // [tile]
+#pragma unroll
+  for (int j = 0; j < MAXIPT; j++)
+    if (j < ipt && local0 + j * 64 < valid_n) {
+      s_buf[slot[j]] = key[j];
+      s_idx[slot[j]] = static_cast<uint16_t>(local0 + j * 64);
+    }
+  __syncthreads();
+  WM_SPLIT_T(0, blockIdx.x, 5);
+#pragma unroll
+  for (int k = 0; k < MAXIPT; k++) {
+    const int s = k * kBlock + threadIdx.x;
+    if (k < ipt && s < valid_n && !WM_SPLIT_DBG(1)) {
+      const uint32_t x  = s_buf[s];
+      const uint32_t gp = s_off[x >= src.span ? static_cast<uint32_t>(buckets) : x >> shift] + static_cast<uint32_t>(s);
+      keys_out[gp]      = x;
+      pos_out[gp]       = static_cast<uint32_t>(base) + s_idx[s];
+    }
+  }
+  WM_SPLIT_T(0, blockIdx.x, 6);
+}
+
+// ---- stage 2: per-bucket order in LDS + run detection --------------------------------------------------------------------
+// wave-wide decoupled look-back over the run counts of the buckets before `b`; called by wave 0, returns the exclusive prefix
+__device__ __forceinline__ uint32_t look_back(uint32_t* state, int b, uint32_t* ctl)
+{
+  const int lane = threadIdx.x & 63;
+  uint32_t excl  = 0;
+  int look       = b - 1;
+  unsigned spins = 0;
+  constexpr int U = 4;   // windows of 64 buckets loaded together (the buckets of one round of workgroups are all "aggregate")
+  while (look >= 0) {
+    uint32_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int idx = look - 64 * u - lane;
+      v[u]          = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFlagPrefix;
+    }
+    bool done = false, stalled = false;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!done && !stalled) {
+        const uint32_t f     = v[u] >> 30;
+        const uint64_t empty = __ballot(f == 0u), prefix = __ballot(f == 2u);
+        // lanes up to (and with) the nearest bucket that knows its prefix
+        const uint64_t need = prefix != 0 ? ((2ull << (__ffsll(static_cast<long long>(prefix)) - 1)) - 1ull) : ~0ull;
+        if ((empty & need) != 0) {
+          stalled = true;   // a bucket in reach has not published yet: come back to this window
+        } else {
+          uint32_t part = ((need >> lane) & 1ull) ? (v[u] & kValueMask) : 0u;
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+          excl += part;
+          look -= 64;
+          done = prefix != 0;
+        }
+      }
+    }
+    if (done) break;
+    if (stalled) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 24)) {   // never in a healthy run: report instead of hanging the device
+        if (lane == 0) ctl[kCtlError] = 1u;
+        break;
+      }
+    }
+  }
+  return excl;
+}
+
+__device__ __forceinline__ void publish(uint32_t* state, int b, uint32_t flag, uint32_t value)
+{
+  __hip_atomic_store(&state[b], flag | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename OutT>
+// (second launch bound = waves per SIMD: 8 = two workgroups per CU)
+__global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* keys, const uint32_t* pos,
+                                                               const uint32_t* bucket_start, int buckets, int shift, int passes,
+                                                               int digit_bits, OutT key_base, OutT* unique_ids, int32_t* run_starts,
+                                                               int32_t* order, int64_t* n_unique, uint32_t* ctl, uint32_t* state)
+{
+  if (ctl[kCtlOverflow] != 0) return;
+  __shared__ uint32_t s_buf[kCap];   // the bucket's words in order; before that: the row map (2048 words) + its prefix (2048)
+  __shared__ uint32_t s_run[kCap];   // map path: ids per run, then run starts; radix path: per-wave digit counters
+  __shared__ uint32_t s_waves[kWaves];
+  __shared__ uint32_t s_misc[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  WM_SPLIT_T(1, blockIdx.x, 0);
+  if (threadIdx.x == 0) {
+    s_misc[0] = atomicAdd(&ctl[kCtlTicket], 1u);
+    s_misc[2] = 0;
+  }
+  __syncthreads();
+  const int b          = static_cast<int>(s_misc[0]);
+  const uint32_t start = bucket_start[b];
+  const int m          = static_cast<int>(bucket_start[b + 1] - start);
+
+  if (b == buckets) {
+    // the drop bucket: positions of the ids outside the range fill the tail of order[]; then the totals
+    for (int i = threadIdx.x; i < m; i += kBlock) order[start + i] = static_cast<int32_t>(pos[start + i]);
+    if (wv == 0) {
+      const uint32_t total = look_back(state, buckets, ctl);
+      if (lane == 0) {
+        *n_unique         = static_cast<int64_t>(total);
+        run_starts[total] = static_cast<int32_t>(start);
+      }
+    }
+    return;
+  }
+  if (m == 0) {
+    // an empty bucket still takes its place in the chain
+    if (wv == 0) {
+      if (lane == 0) publish(state, b, b == 0 ? kFlagPrefix : kFlagAggregate, 0u);
+      if (b > 0) {
+        const uint32_t excl = look_back(state, b, ctl);
+        if (lane == 0) publish(state, b, kFlagPrefix, excl);
+      }
+    }
+    return;
+  }
+
+  // wave w owns positions [w, w + 1) x chunk of the bucket, chunk = a multiple of 64 with 16 chunks covering m
+  const int steps = (m + kBlock - 1) / kBlock;   // <= kSortIpt
+  const int chunk = steps * 64;
+  const int p0    = wv * chunk + lane;
+  const uint32_t low_mask = (1u << shift) - 1u;   // shift <= kMaxLowBits
+  uint32_t w[kSortIpt], slot[kSortIpt];
+  {
+    uint32_t raw[kSortIpt];   // unconditional loads, all in flight together (positions past the bucket re-read its last key)
+#pragma unroll
+    for (int j = 0; j < kSortIpt; j++) {
+      const int p = p0 + j * 64;
+      raw[j]      = keys[start + (j < steps && p < m ? p : m - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < kSortIpt; j++) {
+      const int p = p0 + j * 64;
+      w[j]        = (j < steps && p < m) ? ((raw[j] & low_mask) << kIdxBits) | static_cast<uint32_t>(p) : 0xFFFFFFFFu;
+    }
+  }
+  const OutT bucket_key = (static_cast<OutT>(b) << shift) + key_base;
+  bool radix            = shift > kMapBits;
+  bool published        = false;
+  uint32_t heads_total  = 0;
+
+  if (!radix) {
+    uint32_t* s_map = s_buf;          // [2048] bit r: row r of the bucket is present
+    uint32_t* s_pre = s_buf + 2048;   // [2048] present rows before the word
+    WM_SPLIT_T(1, blockIdx.x, 1);
+    s_map[threadIdx.x] = 0, s_map[threadIdx.x + kBlock] = 0;
+    for (int i = threadIdx.x; i < m; i += kBlock) s_run[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSortIpt; j++)
+      if (j < steps && p0 + j * 64 < m) atomicOr(&s_map[w[j] >> (kIdxBits + 5)], 1u << ((w[j] >> kIdxBits) & 31u));
+    __syncthreads();
+    WM_SPLIT_T(1, blockIdx.x, 2);
+    {
+      const uint32_t t0 = s_map[2 * threadIdx.x], t1 = s_map[2 * threadIdx.x + 1];
+      const uint32_t c0 = static_cast<uint32_t>(__popc(t0)), c1 = static_cast<uint32_t>(__popc(t1));
+      const uint32_t ex = block_exclusive_sum(c0 + c1, s_waves, &heads_total);
+      s_pre[2 * threadIdx.x]     = ex;
+      s_pre[2 * threadIdx.x + 1] = ex + c0;
+    }
+    // the bucket's run count is known: tell the buckets behind this one now, look back later
+    if (threadIdx.x == 0) publish(state, b, b == 0 ? kFlagPrefix : kFlagAggregate, heads_total);
+    published = true;
+    __syncthreads();
+    WM_SPLIT_T(1, blockIdx.x, 3);
+    bool long_run = false;
+#pragma unroll
+    for (int j = 0; j < kSortIpt; j++)
+      if (j < steps && p0 + j * 64 < m) {
+        const uint32_t k  = w[j] >> kIdxBits;
+        const uint32_t r  = s_pre[k >> 5] + static_cast<uint32_t>(__popc(s_map[k >> 5] & ((1u << (k & 31u)) - 1u)));
+        const uint32_t o  = atomicAdd(&s_run[r], 1u);
+        slot[j]           = r | (o << 16);
+        long_run |= o >= static_cast<uint32_t>(kMaxDup);
+      }
+    if (long_run) s_misc[2] = 1;
+    __syncthreads();   // (also: the map has been read, its memory becomes the word buffer)
+    radix = s_misc[2] != 0;
+    WM_SPLIT_T(1, blockIdx.x, 4);
+    if (!radix) {
+      // run starts: exclusive scan of the ids per run, 8 consecutive runs per thread
+      {
+        const int r0 = threadIdx.x * kSortIpt;
+        uint32_t c[kSortIpt], mine = 0;
+#pragma unroll
+        for (int i = 0; i < kSortIpt; i++) c[i] = r0 + i < static_cast<int>(heads_total) ? s_run[r0 + i] : 0u, mine += c[i];
+        uint32_t run = block_exclusive_sum(mine, s_waves, nullptr);
+#pragma unroll
+        for (int i = 0; i < kSortIpt; i++) {
+          if (r0 + i < static_cast<int>(heads_total)) s_run[r0 + i] = run;
+          run += c[i];
+        }
+      }
+      __syncthreads();
+      WM_SPLIT_T(1, blockIdx.x, 5);
+#pragma unroll
+      for (int j = 0; j < kSortIpt; j++)
+        if (j < steps && p0 + j * 64 < m) s_buf[s_run[slot[j] & 0xFFFFu] + (slot[j] >> 16)] = w[j];
+      __syncthreads();
+      WM_SPLIT_T(1, blockIdx.x, 6);
+      // a run of several ids is in the order its ids reached the counter: put it into receive order (ascending words)
+      for (int r = threadIdx.x; r < static_cast<int>(heads_total); r += kBlock) {
+        const int i0 = static_cast<int>(s_run[r]);
+        const int i1 = r + 1 < static_cast<int>(heads_total) ? static_cast<int>(s_run[r + 1]) : m;
+        for (int i = i0 + 1; i < i1; i++) {
+          const uint32_t x = s_buf[i];
+          int q            = i;
+          while (q > i0 && s_buf[q - 1] > x) {
+            s_buf[q] = s_buf[q - 1];
+            q--;
+          }
+          s_buf[q] = x;
+        }
+      }
+      __syncthreads();
+      WM_SPLIT_T(1, blockIdx.x, 7);
+      if (wv == 0) {
+        const uint32_t excl = look_back(state, b, ctl);
+        if (lane == 0) {
+          if (b > 0) publish(state, b, kFlagPrefix, excl + heads_total);
+          s_misc[1] = excl;
+        }
+      }
+      WM_SPLIT_T(1, blockIdx.x, 8);
+      {
+        uint32_t pv[kSortIpt];   // the positions of the bucket's ids in their new order: 8 gathers in flight, then 8 stores
+#pragma unroll
+        for (int k = 0; k < kSortIpt; k++) {
+          const int i = k * kBlock + threadIdx.x;
+          pv[k]       = pos[start + (i < m ? (s_buf[i] & (kCap - 1)) : 0u)];
+        }
+#pragma unroll
+        for (int k = 0; k < kSortIpt; k++) {
+          const int i = k * kBlock + threadIdx.x;
+          if (i < m) order[start + i] = static_cast<int32_t>(pv[k]);
+        }
+      }
+      __syncthreads();
+      WM_SPLIT_T(1, blockIdx.x, 9);
+      const uint32_t run_base = s_misc[1];
+      for (int r = threadIdx.x; r < static_cast<int>(heads_total); r += kBlock) {
+        const uint32_t i0        = s_run[r];
+        run_starts[run_base + r] = static_cast<int32_t>(start + i0);
+        unique_ids[run_base + r] = bucket_key + static_cast<OutT>(s_buf[i0] >> kIdxBits);
+      }
+      WM_SPLIT_T(1, blockIdx.x, 10);
+      return;
+    }
+    if (threadIdx.x == 0) atomicAdd(&ctl[kCtlRadixBuckets], 1u);   // statistics: buckets the map path handed over
+  }
+
+  // ---- radix path: stable least-significant-digit passes over the low key bits --------------------------------------------
+  {
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t* s_cnt   = s_run;   // [kWaves][256]
+    uint32_t* my_cnt  = s_cnt + wv * 256;
+    const int bins    = 1 << digit_bits;
+    for (int pass = 0; pass < passes; pass++) {
+      const int sh         = kIdxBits + pass * digit_bits;
+      const uint32_t dmask = static_cast<uint32_t>(bins - 1);
+      for (int i = lane; i < bins; i += 64) my_cnt[i] = 0;
+      // (a wave's counters are its own until the scan below: no barrier between the zeroing and the ranking)
+#pragma unroll
+      for (int j = 0; j < kSortIpt; j++) {
+        if (j < steps && wv * chunk + j * 64 < m) {
+          const bool valid = p0 + j * 64 < m;
+          const uint32_t d = (w[j] >> sh) & dmask;
+          const uint64_t g = match_lanes(d, digit_bits, __ballot(valid));
+          const int before = __popcll(g & lt);
+          uint32_t old     = 0;
+          if (valid && before == 0) old = atomicAdd(&my_cnt[d], static_cast<uint32_t>(__popcll(g)));
+          old     = __shfl(old, __ffsll(static_cast<long long>(g | (1ull << 63))) - 1, 64);
+          slot[j] = old + before;
+        }
+      }
+      __syncthreads();
+      // per digit: prefix over the waves, then the exclusive scan over the digits
+      uint32_t mine = 0;
+      if (threadIdx.x < bins) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ww++) {
+          const uint32_t c              = s_cnt[ww * 256 + threadIdx.x];
+          s_cnt[ww * 256 + threadIdx.x] = run;
+          run += c;
+        }
+        mine = run;
+      }
+      const uint32_t dbase = block_exclusive_sum(mine, s_waves, nullptr);
+      if (threadIdx.x < bins) {
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ww++) s_cnt[ww * 256 + threadIdx.x] += dbase;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < kSortIpt; j++) {
+        if (j < steps && p0 + j * 64 < m) {
+          const uint32_t d           = (w[j] >> sh) & dmask;
+          s_buf[my_cnt[d] + slot[j]] = w[j];
+        }
+      }
+      __syncthreads();
+      if (pass + 1 < passes) {
+#pragma unroll
+        for (int j = 0; j < kSortIpt; j++) {
+          const int p = p0 + j * 64;
+          if (j < steps && p < m) w[j] = s_buf[p];
+        }
+        __syncthreads();   // the counters are zeroed and the buffer rewritten by the next pass
+      }
+    }
+    if (passes == 0) {
+      // one row per bucket: the bucket is its own order
+#pragma unroll
+      for (int j = 0; j < kSortIpt; j++) {
+        const int p = p0 + j * 64;
+        if (j < steps && p < m) s_buf[p] = w[j];
+      }
+      __syncthreads();
+    }
+    // runs: position i (striped: i = k x 1024 + thread) is a head when its low key differs from its predecessor's
+    uint64_t head_mask[kSortIpt];
+    uint32_t* s_hc = s_run;   // [kSortIpt][kWaves] head counts, then their exclusive prefix
+#pragma unroll
+    for (int k = 0; k < kSortIpt; k++) {
+      const int i = k * kBlock + threadIdx.x;
+      bool head   = false;
+      w[k]        = 0;
+      if (k < steps && i < m) {
+        w[k]                = s_buf[i];
+        const uint32_t prev = i > 0 ? s_buf[i - 1] : ~w[k];
+        head                = (w[k] >> kIdxBits) != (prev >> kIdxBits);
+        order[start + i]    = static_cast<int32_t>(pos[start + (w[k] & (kCap - 1))]);
+      }
+      head_mask[k] = __ballot(head);
+      if (lane == 0) s_hc[k * kWaves + wv] = static_cast<uint32_t>(__popcll(head_mask[k]));
+    }
+    __syncthreads();
+    const uint32_t hv = threadIdx.x < kSortIpt * kWaves ? s_hc[threadIdx.x] : 0u;
+    uint32_t ht;
+    const uint32_t hx = block_exclusive_sum(hv, s_waves, &ht);
+    if (threadIdx.x < kSortIpt * kWaves) s_hc[threadIdx.x] = hx;
+    __syncthreads();
+    if (wv == 0) {
+      if (lane == 0 && !published) publish(state, b, b == 0 ? kFlagPrefix : kFlagAggregate, ht);
+      const uint32_t excl = look_back(state, b, ctl);
+      if (lane == 0) {
+        if (b > 0) publish(state, b, kFlagPrefix, excl + ht);
+        s_misc[1] = excl;
+      }
+    }
+    __syncthreads();
+    const uint32_t run_base = s_misc[1];
+#pragma unroll
+    for (int k = 0; k < kSortIpt; k++) {
+      const int i = k * kBlock + threadIdx.x;
+      if (k < steps && ((head_mask[k] >> lane) & 1ull)) {
+        const uint32_t r = run_base + s_hc[k * kWaves + wv] + static_cast<uint32_t>(__popcll(head_mask[k] & ((1ull << lane) - 1ull)));
+        run_starts[r]    = static_cast<int32_t>(start + i);
+        unique_ids[r]    = bucket_key + static_cast<OutT>(w[k] >> kIdxBits);
+      }
+    }
+  }
+}
+
+// enqueues the four launches. `zero_words`: control words of the caller's generic path that have to read zero before it
+// runs (may be null). `between`: called after the second launch, when the overflow word is final for whatever is enqueued
+// from then on (the caller forks its generic path there). Returns 0 or -2.
+struct no_hook {
+  void operator()() const {}
+};
+template <typename UKey, typename Hook = no_hook>
+int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint32_t span, void* unique_ids, int32_t* run_starts,
+           int32_t* order, int64_t* n_unique, void* workspace, uint32_t* zero_words, int64_t n_zero_words, hipStream_t stream,
+           Hook between = Hook())
+{
+  char* ws         = static_cast<char*>(workspace);
+  uint32_t* keys   = reinterpret_cast<uint32_t*>(ws + p.off_keys);
+  uint32_t* pos    = reinterpret_cast<uint32_t*>(ws + p.off_pos);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(ws + p.off_counts);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(ws + p.off_totals);
+  uint32_t* starts = reinterpret_cast<uint32_t*>(ws + p.off_starts);
+  uint32_t* state  = reinterpret_cast<uint32_t*>(ws + p.off_state);
+  uint32_t* ctl    = reinterpret_cast<uint32_t*>(ws + p.off_ctl);
+  key_source<UKey> src{ids, key_lower_bound, span};
+  static bool attr_set = [] {
+    const int most = static_cast<int>(scatter_lds_bytes(kMaxPitch, kMaxIpt));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_scatter_kernel<UKey, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_scatter_kernel<UKey, kMaxIpt>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    return true;
+  }();
+  (void)attr_set;
+  const int grid = tile_grid(p.tiles);
+  hipLaunchKernelGGL((split_hist_kernel<UKey>), dim3(grid), dim3(kBlock), 0, stream, src, n, p.tile, p.tiles, p.shift, p.buckets,
+                     p.pitch, counts, ctl, zero_words, n_zero_words);
+  hipLaunchKernelGGL(split_scan_kernel, dim3(p.pitch / 32), dim3(kBlock), 0, stream, counts, p.tiles, p.pitch, p.buckets, totals, ctl,
+                     kCap, state, p.pitch + 2);
+  between();
+  const size_t lds = scatter_lds_bytes(p.pitch, p.ipt);
+  if (p.ipt <= 12)
+    hipLaunchKernelGGL((split_scatter_kernel<UKey, 12>), dim3(grid), dim3(kBlock), lds, stream, src, n, p.ipt, p.tiles, p.shift,
+                       p.buckets, p.bucket_bits, p.pitch, counts, totals, starts, keys, pos, ctl);
+  else
+    hipLaunchKernelGGL((split_scatter_kernel<UKey, kMaxIpt>), dim3(grid), dim3(kBlock), lds, stream, src, n, p.ipt, p.tiles, p.shift,
+                       p.buckets, p.bucket_bits, p.pitch, counts, totals, starts, keys, pos, ctl);
+  hipLaunchKernelGGL((split_sort_kernel<UKey>), dim3(p.buckets + 1), dim3(kBlock), 0, stream, keys, pos, starts, p.buckets, p.shift,
+                     p.passes, p.digit_bits, key_lower_bound, static_cast<UKey*>(unique_ids), run_starts, order, n_unique, ctl,
+                     state);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+inline const uint32_t* overflow_word(const plan& p, void* workspace)
+{
+  return reinterpret_cast<const uint32_t*>(static_cast<char*>(workspace) + p.off_ctl) + kCtlOverflow;
+}
+
+}  // namespace split
+}  // namespace wm
