@@ -44,6 +44,13 @@ def test_every_declared_symbol_is_exported_and_bound(wm_lib):
     assert not stale, "bound but not declared in include/: %s" % stale
     for name in declared:
         assert getattr(wm_lib, name) is not None
+    # ... and nothing else leaves the library (csrc/exports.map): no C++ internals a second copy of the sources could
+    # interpose on, no stray globals
+    every = {line.split()[-1] for line in out.splitlines() if line.split()[-2] in "TDBRVW"}
+    mangled = sorted(n for n in every if n.startswith("_Z"))
+    assert not mangled, "C++ symbols exported: %s ..." % mangled[:5]
+    extra = sorted(every - declared)
+    assert not extra, "exported but not declared in include/: %s" % extra
 
 
 def test_struct_layouts_match_the_c_abi():

@@ -353,7 +353,11 @@ struct sort_lane {
   bool ok = false;
   sort_lane()
   {
-    ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+    int least = 0, greatest = 0;   // lowest priority: its kernels are the ones that usually have nothing to do
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const char* pe = WM_KNOB("WM_DEDUP_LANE_PRIO");
+    ok = (pe != nullptr && pe[0] == 'n' ? hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)
+                                        : hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least)) == hipSuccess &&
          hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess;
   }
@@ -474,7 +478,7 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
       };
       if (split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound), static_cast<uint32_t>(span),
                               unique_ids, run_starts, order, n_unique_out, sl.split_ws, sl.osw_ctrl, static_cast<int64_t>(ctrl),
-                              stream, between) != 0)
+                              stream, between, WM_KNOB("WM_DEDUP_FORK") != nullptr && WM_KNOB("WM_DEDUP_FORK")[0] == '3') != 0)
         return -2;
       if (forked && hipStreamWaitEvent(stream, sort_lane::get().joined, 0) != hipSuccess) return -2;
       g_split_sorts.fetch_add(1, std::memory_order_relaxed);

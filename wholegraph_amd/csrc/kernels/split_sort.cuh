@@ -803,7 +803,7 @@ struct no_hook {
 template <typename UKey, typename Hook = no_hook>
 int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint32_t span, void* unique_ids, int32_t* run_starts,
            int32_t* order, int64_t* n_unique, void* workspace, uint32_t* zero_words, int64_t n_zero_words, hipStream_t stream,
-           Hook between = Hook())
+           Hook between = Hook(), bool hook_after_scatter = false)
 {
   char* ws         = static_cast<char*>(workspace);
   uint32_t* keys   = reinterpret_cast<uint32_t*>(ws + p.off_keys);
@@ -826,7 +826,7 @@ int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint
                      p.pitch, counts, ctl, zero_words, n_zero_words);
   hipLaunchKernelGGL(split_scan_kernel, dim3(p.pitch / 32), dim3(kBlock), 0, stream, counts, p.tiles, p.pitch, p.buckets, totals, ctl,
                      kCap, state, p.pitch + 2);
-  between();
+  if (!hook_after_scatter) between();
   const size_t lds = scatter_lds_bytes(p.pitch, p.ipt);
   if (p.ipt <= 12)
     hipLaunchKernelGGL((split_scatter_kernel<UKey, 12>), dim3(grid), dim3(kBlock), lds, stream, src, n, p.ipt, p.tiles, p.shift,
@@ -834,6 +834,7 @@ int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint
   else
     hipLaunchKernelGGL((split_scatter_kernel<UKey, kMaxIpt>), dim3(grid), dim3(kBlock), lds, stream, src, n, p.ipt, p.tiles, p.shift,
                        p.buckets, p.bucket_bits, p.pitch, counts, totals, starts, keys, pos, ctl);
+  if (hook_after_scatter) between();
   hipLaunchKernelGGL((split_sort_kernel<UKey>), dim3(p.buckets + 1), dim3(kBlock), 0, stream, keys, pos, starts, p.buckets, p.shift,
                      p.passes, p.digit_bits, key_lower_bound, static_cast<UKey*>(unique_ids), run_starts, order, n_unique, ctl,
                      state);
