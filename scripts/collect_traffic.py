@@ -38,7 +38,7 @@ def main():
     try:
         sha = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
-        sha = "worktree"
+        sha = os.environ.get("WM_COMMIT", "worktree")   # no .git on the GPU box: the caller passes the commit it snapshots
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) around `python bench.py "
                   "--no-cpu-baseline --steps 10 --warmup 2`, raw CSVs: profiles/%s_pmc/" % tag,

@@ -34,6 +34,11 @@ def test_single_gpu_line(wm_lib):
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert roof["algorithmic_bytes_per_launch"] == 500000 * (8 + 512 + 512)
     assert "rows_batch_kernel" in roof["kernel"]                # (the in-order kernel of 512 B rows) the name comes from the HIP runtime, not from bench.py
+    # what each time in the object is (round-4 review): the HIP-event time of a step, the rocprofv3 average of the kernel when
+    # profiles/ holds one for this workload (not for this toy size), and the same launch as a sequential copy in this process
+    assert roof["step_ms_hip_events"] > 0 and "kernel_ms" not in roof and "kernel_ms_rocprof" in roof and "kernel_ms_source" in roof
+    assert roof["copy_ms_sequential_ids"] > 0 and 0 < roof["copy_frac"] < 1
+    assert abs(roof["vs_copy"] - roof["copy_ms_sequential_ids"] / roof["step_ms_hip_events"]) < 1e-2
     cpu = r["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu
     assert cpu["c1_shape"]["value"] > 0 and "10000000x64" in cpu["c1_shape"]["sample"]
