@@ -187,6 +187,15 @@ enum wholememory_error_code_t wholememory_ext_reload_knobs(void);
  * capped at a quarter of the free memory, one prober per device at a time. */
 enum wholememory_error_code_t wholememory_ext_probe_memory(void* ptr, size_t bytes, int kind, int reps, float* ms_per_gib);
 
+/* The placement probe of wholememory_malloc (above) without the environment: "auto", "2" ... "8" (that many candidates), "off",
+ * or "env" / NULL (follow WM_MALLOC_PROBE again, the initial state). Applies to the device allocations this process makes from
+ * now on, until changed; WHOLEMEMORY_INVALID_INPUT for anything else. pylibwholegraph: create_embedding(...,
+ * placement_probe="auto") sets it around the one creation. Tables that are written at random — scatter targets, trained
+ * embeddings — are what it is for: their speed follows the placement of the shard by up to 20 %. */
+enum wholememory_error_code_t wholememory_ext_set_malloc_probe(const char* mode);
+/* 1 when the local shard of the handle was chosen among several probed candidates, else 0 */
+int wholememory_ext_handle_was_probed(wholememory_handle_t handle);
+
 /* Number of wholememory_gather calls of this process that took the sorted-ids route of HOST-located tables (rows of at most
  * 512 bytes, batches of at least WM_HOST_SORTED_MIN ids: wholememory_op.h / gather_op.cpp:116-120 of the reference).
  * A counter for tests and benchmarks. */
@@ -197,6 +206,11 @@ int64_t wholememory_ext_host_sorted_gathers(void);
  * generic radix sort. Whether a queued split sort then found a bucket too large and handed the batch to the gated generic path
  * is decided on the device and not visible here. A counter for tests and benchmarks. */
 int64_t wholememory_ext_split_sorts(void);
+
+/* Kernels queued so far by the DISTRIBUTED gather route of this process (owner-side row gathers, reorder-on-receive
+ * scatters, the two chunk-major copies): with C exchange chunks a call costs at most 2 C + 3 of them whatever the number of
+ * ranks (rounds 2-4: 2 (W - 1) C + 1). A counter for tests. */
+int64_t wholememory_ext_distributed_gather_launches(void);
 
 /* ---- (3) testing seam ---------------------------------------------------------------------- */
 /* Replaces the device backend. Refuses (WHOLEMEMORY_NOT_SUPPORTED) unless the environment has

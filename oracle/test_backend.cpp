@@ -343,6 +343,20 @@ int t_sorted_counts(const void* ids, wholememory_dtype_t dt, const int64_t* n_de
   return 0;
 }
 
+// chunk-major copy of per-peer segments (backend.hpp: permute_chunks)
+int t_permute(const void* src, void* dst, int elt_bytes, const int64_t* off, const int64_t* cnt, int n_segs, int n_chunks, void*)
+{
+  int64_t k = 0;
+  for (int c = 0; c < n_chunks; c++)
+    for (int p = 0; p < n_segs; p++) {
+      const int64_t a = cnt[p] * c / n_chunks, b = cnt[p] * (c + 1) / n_chunks;
+      memcpy(static_cast<char*>(dst) + k * elt_bytes, static_cast<const char*>(src) + (off[p] + a) * elt_bytes,
+             static_cast<size_t>(b - a) * elt_bytes);
+      k += b - a;
+    }
+  return 0;
+}
+
 const wm_device_backend kTestBackend = {
   "oracle-test-backend (CPU, tests only)",
   t_device_count, t_malloc, t_free, t_malloc, t_free, t_memcpy, t_memset, t_sync,
@@ -353,6 +367,9 @@ const wm_device_backend kTestBackend = {
   // graph ops: not provided by the CPU backend
   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
   t_env_test,
+  // device cache, placement probe, id sort, memory info, append_unique extras, 0xFF fill: not provided
+  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+  t_permute,
 };
 
 }  // namespace

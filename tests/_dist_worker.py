@@ -92,11 +92,37 @@ def scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, e
     out = dev(torch.full((len(rank_idx[rank]), dim), 5, dtype=tt[odt]))
     from wholegraph_amd.torch.wholegraph_env import wrap_torch_tensor, get_wholegraph_env_fns, get_stream
     wi, wo = wrap_torch_tensor(dev(torch.from_numpy(rank_idx[rank]))), wrap_torch_tensor(out)
+    launches0 = wmb.lib().wholememory_ext_distributed_gather_launches()
     wmb.check(wmb.lib().wholememory_gather(view.wmb_tensor, wi.handle, wo.handle, get_wholegraph_env_fns(),
                                            C.c_void_p(get_stream()), -1))
     if HIP_MODE:
         torch.cuda.synchronize()
     assert host(out).numpy().tobytes() == exp[rank].tobytes(), "%s gather mismatch on rank %d" % (mt, rank)
+    if mt == "distributed" and world > 1 and world <= 16 and loc == "cuda":
+        # one row kernel per exchange chunk and side (+ the rank's own rows, + the two chunk-major copies), whatever the
+        # number of ranks — and the per-peer launches of rounds 2-4 (WM_EXCHANGE_PER_PEER=1) give the same rows
+        chunks = int(os.environ.get("WM_EXCHANGE_CHUNKS", "1"))
+        folded = wmb.lib().wholememory_ext_distributed_gather_launches() - launches0
+        assert folded <= 2 * chunks + 3, "distributed gather queued %d kernels with %d chunks" % (folded, chunks)
+        os.environ["WM_EXCHANGE_PER_PEER"] = "1"
+        _reload_knobs()
+        out2 = dev(torch.full((len(rank_idx[rank]), dim), 5, dtype=tt[odt]))
+        wo2 = wrap_torch_tensor(out2)
+        launches1 = wmb.lib().wholememory_ext_distributed_gather_launches()
+        wmb.check(wmb.lib().wholememory_gather(view.wmb_tensor, wi.handle, wo2.handle, get_wholegraph_env_fns(),
+                                               C.c_void_p(get_stream()), -1))
+        if HIP_MODE:
+            torch.cuda.synchronize()
+        per_peer = wmb.lib().wholememory_ext_distributed_gather_launches() - launches1
+        del os.environ["WM_EXCHANGE_PER_PEER"]
+        _reload_knobs()
+        assert host(out2).numpy().tobytes() == exp[rank].tobytes(), "per-peer gather mismatch on rank %d" % rank
+        if n_rows >= 500 and min(len(ix) for ix in rank_idx) >= 100:   # (tiny batches: most (peer, chunk) pairs are empty)
+            assert per_peer >= folded, (per_peer, folded)
+            if world >= 3 and chunks > 1 and os.environ.get("WM_EXCHANGE_SELF") != "1":
+                # (the second figures: the de-duplicating route, whose rows are received in place — no reorder side)
+                assert per_peer in (1 + 2 * (world - 1) * chunks, 1 + (world - 1) * chunks), (per_peer, folded)
+                assert folded in (3 + 2 * chunks, 2 + chunks), (per_peer, folded)
     # scatter: every rank writes rows of its own ids (closed-form rows: duplicates agree), then everyone checks
     comm.barrier()
     if cnt:

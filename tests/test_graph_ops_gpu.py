@@ -345,3 +345,24 @@ def test_multilayer_sample(gpu_env):
             assert d in col[row_ptr[s]:row_ptr[s + 1]]
     wgth.destroy_wholememory_tensor(wrow)
     wgth.destroy_wholememory_tensor(wcol)
+
+
+def test_append_unique_scan_hands_out_tiles_by_ticket(gpu_env, knobs):
+    """The ranking scan of append_unique is a single-launch chained scan (graph.hip: chain_scan_kernel). Up to 8 tiles per CU
+    it runs one tile per block; beyond that blocks loop over tiles and take their tile numbers from a ticket counter, so that
+    a block never waits for a tile nobody has started (advisor, round 4). WM_SCAN_ITEMS=1 makes the tiles 256 values small:
+    600 k neighbours are ~2400 tiles — past the one-tile-per-block bound on a 256-CU part — and the result must not change."""
+    import torch
+    import wholegraph_amd.torch.graph_ops as gops
+    rng = np.random.default_rng(77)
+    targets = rng.permutation(1 << 20)[:5000].astype(np.int32)
+    neighbors = rng.integers(0, 1 << 20, 600_000).astype(np.int32)
+    o_uniq, o_map = oracle.append_unique(targets, neighbors)
+    for items in ("1", "4", None):
+        if items is None:
+            knobs.unset("WM_SCAN_ITEMS")
+        else:
+            knobs.set("WM_SCAN_ITEMS", items)
+        uniq, mapping = gops.append_unique(torch.from_numpy(targets).cuda(), torch.from_numpy(neighbors).cuda(), True)
+        assert np.array_equal(uniq.cpu().numpy(), o_uniq), items
+        assert np.array_equal(mapping.cpu().numpy(), o_map), items

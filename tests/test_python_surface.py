@@ -20,8 +20,11 @@ def test_names_and_signatures():
                  "torch_dtype_to_wholememory_dtype"]:
         assert hasattr(wgth, name), name
     sig = inspect.signature(wgth.create_embedding)
+    # the reference's parameters, in its order; one keyword-only extension behind them (placement_probe, round 5)
     assert list(sig.parameters) == ["comm", "memory_type", "memory_location", "dtype", "sizes", "cache_policy",
-                                    "embedding_entry_partition", "random_init", "gather_sms", "round_robin_size"]
+                                    "embedding_entry_partition", "random_init", "gather_sms", "round_robin_size",
+                                    "placement_probe"]
+    assert sig.parameters["placement_probe"].kind is inspect.Parameter.KEYWORD_ONLY and sig.parameters["placement_probe"].default is None
     for kw in ("cache_policy", "embedding_entry_partition", "random_init", "gather_sms", "round_robin_size"):
         assert sig.parameters[kw].kind is inspect.Parameter.KEYWORD_ONLY
     g = inspect.signature(wgth.WholeMemoryEmbedding.gather)

@@ -262,6 +262,9 @@ PROTOTYPES = {
     "wholememory_ext_probe_memory": (_i, [_vp, C.c_size_t, _i, _i, _P(_f)]),
     "wholememory_ext_host_sorted_gathers": (_i64, []),
     "wholememory_ext_split_sorts": (_i64, []),
+    "wholememory_ext_distributed_gather_launches": (_i64, []),
+    "wholememory_ext_set_malloc_probe": (_i, [C.c_char_p]),
+    "wholememory_ext_handle_was_probed": (_i, [_vp]),
     "wholememory_ext_multilayer_sample": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wm_testing_install_backend": (_i, [_vp]),
 }

@@ -328,6 +328,13 @@ struct wm_device_backend {
   // bytes set to 0xFF by a KERNEL launch (what memset_async(.., 0xFF, ..) does as a memset command: inside a captured
   // hipGraph such a command was seen to run out of order with the kernels around it). nullptr: use memset_async.
   int (*fill_ff_async)(void* ptr, size_t bytes, void* stream);
+  // dst = src in CHUNK-MAJOR order (ops.cpp: gather_distributed_rows). src holds n_segs segments, segment p = seg_counts[p]
+  // elements from seg_offsets[p]; chunk c of a segment of n elements is [n*c/C, n*(c+1)/C) of it, C = n_chunks. dst lists
+  // chunk 0 of every segment (in segment order), then chunk 1 of every segment ... — each chunk of the exchange pipeline
+  // becomes ONE contiguous range, one kernel launch instead of one per peer. elt_bytes 4 or 8, n_segs <= 16 (the tables travel
+  // as kernel arguments). nullptr in a backend that does not provide it: callers launch per segment.
+  int (*permute_chunks)(const void* src, void* dst, int elt_bytes, const int64_t* seg_offsets, const int64_t* seg_counts,
+                        int n_segs, int n_chunks, void* stream);
 };
 
 }  // extern "C"

@@ -9,6 +9,7 @@
 // step (duplicate-sum in the reference's order + optimizer update, kernels/optim.hip) — there is no
 // intermediate de-duplicated gradient buffer and no host sync to learn the unique count.
 // Cached embeddings: embedding_cache.{hpp,cpp} + kernels/cache.hip (a device row cache with a direct row -> slot map).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -16,7 +17,9 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
 #include <wholememory/embedding.h>
+#include <wholememory/wholegraph_amd_ext.h>
 
 #include "knobs.hpp"
 #include "embedding_cache.hpp"
@@ -68,18 +71,28 @@ namespace {
   } while (0)
 
 int64_t align_embedding_dim(int64_t dim, size_t element_size)
-{  // rows padded to 16 bytes: reference embedding.cpp:43-50
-  // Extension, opt-in: WM_EMBEDDING_ROW_ALIGN=<32 ... 4096, a power of two> pads the row stride to that many bytes instead.
-  // Rows that start on whole 128-byte lines are written without partial lines at either end: scatter / gradient apply of
-  // 800 B rows 56 -> 74 % of the HBM peak at stride 1024, 4000 B rows 60 -> 74 % (profiles/r04_misaligned_rows.txt); the
-  // gather, bound by its dense output, gains nothing. Costs the padding in HBM; files are per logical row and do not change.
-  int64_t bytes = 16;
+{  // rows padded to 16 bytes: reference embedding.cpp:43-50 — and, round 5, to whole 128-byte lines when that is cheap.
+  // A row that does not start on a line boundary is WRITTEN with a partial line at either end; scatter and gradient apply of
+  // such rows run 15-20 points under rows of whole lines (800 B rows 56 -> 74 % of the HBM peak at stride 1024, 4000 B rows
+  // 60 -> 74 %: profiles/r04_misaligned_rows.txt). GloVe / word2vec (100 / 200 / 300 floats) and Reddit (602) tables are such
+  // rows. WM_EMBEDDING_ROW_ALIGN:
+  //   auto (default)  pad the stride to a multiple of 128 bytes when that costs at most 8 % more memory than the reference's
+  //                   16-byte padding (602 floats -> 608, 300 -> 320, 513 -> 544; 100 and 200 floats stay at 400 / 800 bytes)
+  //   16              the reference's padding, always
+  //   32 ... 4096     (a power of two) pad to that many bytes, whatever it costs
+  // Only the STRIDE of tables the library allocates itself changes: the user still sees [N, dim], files are written and read
+  // per logical row (file_io.cpp: file entry size = dim x element size), so they stay interchangeable between alignments.
+  const int64_t row = dim * static_cast<int64_t>(element_size);
+  auto padded = [&](int64_t bytes) { return (row + bytes - 1) / bytes * bytes; };
+  int64_t bytes = 0;   // 0 = auto
   if (const char* e = WM_KNOB("WM_EMBEDDING_ROW_ALIGN")) {
     const int64_t v = atoll(e);
-    if (v >= 16 && v <= 4096 && (v & (v - 1)) == 0) bytes = v;
-    else WM_WARN("WM_EMBEDDING_ROW_ALIGN=%s ignored: a power of two between 16 and 4096 is expected", e);
+    if (e[0] == 'a' || e[0] == 'A') bytes = 0;
+    else if (v >= 16 && v <= 4096 && (v & (v - 1)) == 0) bytes = v;
+    else WM_WARN("WM_EMBEDDING_ROW_ALIGN=%s ignored: auto or a power of two between 16 and 4096 is expected", e);
   }
-  const int64_t a = bytes / static_cast<int64_t>(element_size);
+  if (bytes == 0) bytes = padded(128) * 100 <= padded(16) * 108 ? 128 : 16;
+  const int64_t a = std::max<int64_t>(bytes / static_cast<int64_t>(element_size), 1);
   return dim % a == 0 ? dim : (dim / a + 1) * a;
 }
 
@@ -736,6 +749,24 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
     return WHOLEMEMORY_NOT_IMPLEMENTED;
   }
   e->optimizer = optimizer;
+  {
+    // A trained table is written at random: the one kind of access whose speed follows WHERE the shard sits in HBM (scatter /
+    // gradient apply 81 % or 67 % of the peak by placement). The probe that picks a well placed shard
+    // is opt-in; say so once per process when a big device table was made without it. (No "this table is in the slow class"
+    // claim: telling the classes apart needs a second candidate of the same size to compare with — that IS the probe.)
+    static std::atomic<bool> told{false};
+    auto h = wholememory_tensor_get_memory_handle(e->allocated);
+    size_t local_bytes = 0, local_off = 0;
+    void* local_ptr = nullptr;
+    if (h != nullptr && wholememory_get_memory_location(h) == WHOLEMEMORY_ML_DEVICE && !wholememory_ext_handle_was_probed(h) &&
+        wholememory_get_local_memory(&local_ptr, &local_bytes, &local_off, h) == WHOLEMEMORY_SUCCESS &&
+        local_bytes >= (static_cast<size_t>(1) << 30) && !told.exchange(true))
+      WM_WARN("an optimizer is attached to a %.1f GiB device table that was allocated without the placement probe: scatter and "
+              "gradient apply on it run at either of two levels (about 20 %% apart) depending on where the allocation landed. "
+              "create_embedding(..., placement_probe=\"auto\") / wholememory_ext_set_malloc_probe(\"auto\") / "
+              "WM_MALLOC_PROBE=auto picks a well placed shard (costs a few transient candidate allocations)",
+              local_bytes / 1073741824.0);
+  }
   auto rc      = wm::create_states(e);
   if (rc != WHOLEMEMORY_SUCCESS) {
     wm::destroy_states(e);

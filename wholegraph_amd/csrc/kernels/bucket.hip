@@ -512,4 +512,52 @@ int hip_bucket_ids(const wm_bucket_args* a, void* stream_v)
   return -1;
 }
 
+
+// ---- chunk-major copy of per-peer segments (backend.hpp: permute_chunks) ------------------------------------------------
+namespace {
+constexpr int kPermuteSegs = 16;
+struct permute_table {
+  int64_t off[kPermuteSegs], cnt[kPermuteSegs];
+  int n_segs, n_chunks;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void permute_chunks_kernel(const T* src, T* dst, permute_table t, int64_t total)
+{
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (k >= total) return;
+  // which chunk, which segment: at most n_chunks + n_segs steps over kernel arguments (scalar registers)
+  int64_t base = 0;
+  for (int c = 0; c < t.n_chunks; c++) {
+    for (int p = 0; p < t.n_segs; p++) {
+      const int64_t a = t.cnt[p] * c / t.n_chunks, b = t.cnt[p] * (c + 1) / t.n_chunks;
+      if (k < base + (b - a)) {
+        dst[k] = src[t.off[p] + a + (k - base)];
+        return;
+      }
+      base += b - a;
+    }
+  }
+}
+}  // namespace
+
+int hip_permute_chunks(const void* src, void* dst, int elt_bytes, const int64_t* seg_offsets, const int64_t* seg_counts, int n_segs,
+                       int n_chunks, void* stream_v)
+{
+  if (n_segs < 1 || n_segs > kPermuteSegs || n_chunks < 1 || (elt_bytes != 4 && elt_bytes != 8)) return -1;
+  permute_table t{};
+  int64_t total = 0;
+  for (int p = 0; p < n_segs; p++) t.off[p] = seg_offsets[p], t.cnt[p] = seg_counts[p], total += seg_counts[p];
+  t.n_segs = n_segs, t.n_chunks = n_chunks;
+  if (total == 0) return 0;
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const dim3 grid(static_cast<unsigned>((total + 255) / 256)), block(256);
+  if (elt_bytes == 4)
+    hipLaunchKernelGGL(permute_chunks_kernel<uint32_t>, grid, block, 0, stream, static_cast<const uint32_t*>(src),
+                       static_cast<uint32_t*>(dst), t, total);
+  else
+    hipLaunchKernelGGL(permute_chunks_kernel<uint64_t>, grid, block, 0, stream, static_cast<const uint64_t*>(src),
+                       static_cast<uint64_t*>(dst), t, total);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 }  // namespace wm

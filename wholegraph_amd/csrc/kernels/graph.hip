@@ -115,17 +115,32 @@ struct no_tail {
   __device__ void operator()(int) const {}
 };
 
-template <typename Fn, typename Tail, int kChainItems>
+// TICKETS: a block takes the number of its next tile from a counter in the state header (pad[0], all-ones like the rest: the
+// k-th atomicSub returns ~k), so a tile only ever waits for tiles whose blocks already RUN — forward progress needs no
+// assumption about how many blocks the device holds at once (a CU-masked stream, a persistent kernel such as RCCL's or the
+// optimizer's long-run side holding CUs: advisor, round 4). false = round 4's static mapping (tile = block + k x grid), which
+// completes only if all blocks of the grid are resident together; kept for A/B (WM_SCAN_STATIC=1).
+template <typename Fn, typename Tail, int kChainItems, bool TICKETS>
 __global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n, int* out, chain_state* st, Tail tail)
 {
   constexpr int kChainTile = kChainThreads * kChainItems;
   __shared__ int s_excl;
+  __shared__ int s_tile;
   __shared__ int s_wave[kChainThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n_tiles = (n + kChainTile - 1) / kChainTile;
   // the functor reads its device-side counts ONCE, here; `live` false = every value is 0 and nothing may be read
   const bool live = fn.prepare();
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int round = 0;; round++) {
+  int tile;
+  if (TICKETS) {
+    if (tid == 0) s_tile = static_cast<int>(~atomicSub(&st->pad[0], 1u));
+    __syncthreads();
+    tile = s_tile;
+  } else {
+    tile = blockIdx.x + round * gridDim.x;
+  }
+  if (tile >= n_tiles) break;
   const int i0   = tile * kChainTile + tid * kChainItems;
   int v[kChainItems];
 #pragma unroll
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n,
       if (i0 + k < n) out[i0 + k] = base + v[k];
   }
   if (i0 <= n - 1 && n - 1 < i0 + kChainItems) tail(base + sum);
-  __syncthreads();   // s_excl / s_wave are reused by the block's next tile
+  __syncthreads();   // s_excl / s_wave / s_tile are reused by the block's next tile
   }
 }
 
@@ -240,15 +255,34 @@ int chain_scan(Fn fn, int n, int* out, Tail tail, void* state, hipStream_t strea
     if ((v == 1 || v == 4 || v == 16) && (static_cast<int64_t>(n) + 256 * v - 1) / (256 * v) <= kChainMaxTiles) items = v;
   }
   const int tile = kChainThreads * items;
-  static const int cus = [] {
+  // one block per CU of the CURRENT device (per device ordinal: a process may drive several)
+  static int cus_of[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (cus_of[dev] == 0) {
     hipDeviceProp_t prop;
-    int dev = 0;
-    return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 64;
-  }();
-  const dim3 grid(std::min((n + tile - 1) / tile, std::max(cus, 1))), block(kChainThreads);   // all blocks resident together
-  if (items == 1) hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, 1>), grid, block, 0, stream, fn, n, out, st, tail);
-  else if (items == 4) hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, 4>), grid, block, 0, stream, fn, n, out, st, tail);
-  else hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, 16>), grid, block, 0, stream, fn, n, out, st, tail);
+    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
+  }
+  // One tile per block (tile = block index) while the scan has at most 8 tiles per CU: a block then waits only for blocks
+  // with a smaller index, and workgroups start in index order on every XCD, so the tile with the smallest unfinished index
+  // always runs or is next in line for a slot held by finished-or-running smaller ones — no assumption about how many blocks
+  // are resident together. Bigger scans loop over tiles, and a looping block must not wait for a tile nobody has started:
+  // there the tile numbers come from the ticket counter (see the kernel). WM_SCAN_STATIC=1: round 4's mapping (A/B only).
+  const int n_tiles = (n + tile - 1) / tile;
+  const bool one_to_one = n_tiles <= 8 * cus_of[dev];
+  const bool static_ab = WM_KNOB("WM_SCAN_STATIC") != nullptr && WM_KNOB("WM_SCAN_STATIC")[0] == '1';
+  const dim3 grid(one_to_one && !static_ab ? n_tiles : std::min(n_tiles, cus_of[dev])), block(kChainThreads);
+  const bool tickets = !one_to_one && !static_ab;
+#define WM_CHAIN(ITEMS)                                                                                              \
+  do {                                                                                                               \
+    if (tickets) hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, ITEMS, true>), grid, block, 0, stream, fn, n, out, st, tail); \
+    else hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, ITEMS, false>), grid, block, 0, stream, fn, n, out, st, tail);        \
+  } while (0)
+  if (items == 1) WM_CHAIN(1);
+  else if (items == 4) WM_CHAIN(4);
+  else WM_CHAIN(16);
+#undef WM_CHAIN
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

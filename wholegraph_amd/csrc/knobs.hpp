@@ -5,11 +5,14 @@
 // row-kernel launch were µs-scale host work on every call of a latency-bound chain, and a knob could change behaviour
 // mid-process). Experiments and tests that flip a switch between calls say so explicitly:
 // wholememory_ext_reload_knobs() (include/wholememory/wholegraph_amd_ext.h) makes every site read its variable again at
-// its next use. Reloading while ops run on other threads is not supported.
+// its next use. A reload never frees a value: every (re)load parks its string in a list that lives as long as the process, so a
+// pointer returned to an op on another thread stays valid (advisor, round 4) — that thread simply keeps the old answer until
+// its next look. (A few bytes per reload and variable; reloads are a test / experiment device.)
 #pragma once
 
 #include <atomic>
 #include <cstdlib>
+#include <deque>
 #include <mutex>
 #include <string>
 
@@ -29,19 +32,23 @@ class env_knob {
       std::lock_guard<std::mutex> lk(g_knob_mutex);
       if (gen_.load(std::memory_order_relaxed) != g) {
         const char* e = std::getenv(name_);
-        set_          = e != nullptr;
-        value_        = set_ ? e : "";
+        if (e != nullptr) {
+          history_.emplace_back(e);   // (deque: growing it moves no element)
+          value_.store(history_.back().c_str(), std::memory_order_release);
+        } else {
+          value_.store(nullptr, std::memory_order_release);
+        }
         gen_.store(g, std::memory_order_release);
       }
     }
-    return set_ ? value_.c_str() : nullptr;
+    return value_.load(std::memory_order_acquire);
   }
 
  private:
   const char* name_;
   mutable std::atomic<unsigned> gen_;
-  mutable bool set_ = false;
-  mutable std::string value_;
+  mutable std::atomic<const char*> value_{nullptr};
+  mutable std::deque<std::string> history_;   // every value ever loaded (guarded by g_knob_mutex)
 };
 
 inline void reload_knobs() { g_knob_generation.fetch_add(1, std::memory_order_acq_rel); }

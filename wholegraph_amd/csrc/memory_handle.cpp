@@ -22,6 +22,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cerrno>
+#include <mutex>
+#include <string>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -49,6 +52,7 @@ struct wholememory_handle_ {
   void* local_ptr       = nullptr;
   size_t local_alloc    = 0;
   bool local_is_pinned  = false;
+  bool placement_probed = false;   // the local shard was chosen among several candidates (WM_MALLOC_PROBE / ext_set_malloc_probe)
   // mapped views
   void* global_base = nullptr;        // CONTINUOUS (and HOST chunked): flat pointer usable on device
   std::vector<void*> rank_ptrs;       // CHUNKED: per-rank bases as seen from this process
@@ -124,6 +128,9 @@ void upload_tables(wholememory_handle_* h)
   wm::register_gref_tables(h->dev_rank_ptrs, W, h->rank_ptrs.data(), h->part_offsets.data());
 }
 
+std::mutex g_probe_mode_mutex;
+std::string g_probe_mode;   // "" = follow WM_MALLOC_PROBE
+
 void alloc_local(wholememory_handle_* h)
 {
   const auto* bk  = backend();
@@ -154,7 +161,14 @@ void alloc_local(wholememory_handle_* h)
   // one rank (HIP VMM handles, memory_vmm.cpp) are never probed: a candidate would have to be mapped, probed and unmapped,
   // and unmapped ranges are exactly what memory_vmm.cpp avoids re-using.
   // A candidate that cannot be allocated ends the search. Every rank decides for its own shard; no collective is involved.
-  const char* setting = WM_KNOB("WM_MALLOC_PROBE");
+  // wholememory_ext_set_malloc_probe() (Python: create_embedding(..., placement_probe="auto")) takes precedence over the
+  // environment for the allocations made while it is set
+  std::string api_setting;
+  {
+    std::lock_guard<std::mutex> lk(g_probe_mode_mutex);
+    api_setting = g_probe_mode;
+  }
+  const char* setting = api_setting.empty() ? WM_KNOB("WM_MALLOC_PROBE") : api_setting.c_str();
   const bool auto_mode = setting != nullptr && (setting[0] == 'a' || setting[0] == 'A');
   const int k_fixed    = (setting == nullptr || auto_mode) ? 1 : std::min(std::max(atoi(setting), 1), 8);
   const size_t min_bytes = [] {
@@ -174,10 +188,37 @@ void alloc_local(wholememory_handle_* h)
   // one prober per device at a time, across processes
   int dev_id = 0;
   if (bk->get_device != nullptr) (void)bk->get_device(&dev_id);
-  char lock_path[64];
-  snprintf(lock_path, sizeof(lock_path), "/tmp/wholegraph_amd_probe_dev%d.lock", dev_id);
-  const int lock_fd = open(lock_path, O_CREAT | O_RDWR, 0666);
-  if (lock_fd >= 0) (void)flock(lock_fd, LOCK_EX);
+  // the lock file: in the user's runtime directory when there is one, else /tmp with the uid in the name; never through a
+  // symlink, never inherited by children; waited for at most WM_MALLOC_PROBE_LOCK_WAIT_S seconds (default 120 — a candidate
+  // probe of a 64 GB shard takes ~25 ms, so a longer wait means a stopped or hung holder) and then probed without it, loudly
+  char lock_path[256];
+  const char* run_dir = WM_KNOB("XDG_RUNTIME_DIR");
+  if (run_dir != nullptr && run_dir[0] == '/' && strlen(run_dir) < 200)
+    snprintf(lock_path, sizeof(lock_path), "%s/wholegraph_amd_probe_dev%d.lock", run_dir, dev_id);
+  else
+    snprintf(lock_path, sizeof(lock_path), "/tmp/wholegraph_amd_probe_uid%u_dev%d.lock", static_cast<unsigned>(getuid()), dev_id);
+  int lock_fd = open(lock_path, O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
+  if (lock_fd < 0) {
+    WM_WARN("wholememory_malloc: cannot open the probe lock %s (%s): probing without it", lock_path, strerror(errno));
+  } else {
+    const char* we    = WM_KNOB("WM_MALLOC_PROBE_LOCK_WAIT_S");
+    const int wait_s  = we != nullptr && atoi(we) >= 0 ? atoi(we) : 120;
+    bool locked       = false;
+    for (int tenth = 0; tenth <= wait_s * 10; tenth++) {
+      if (flock(lock_fd, LOCK_EX | LOCK_NB) == 0) {
+        locked = true;
+        break;
+      }
+      if (errno != EWOULDBLOCK && errno != EINTR) break;
+      usleep(100000);
+    }
+    if (!locked) {
+      WM_WARN("wholememory_malloc: the probe lock %s stayed busy for %d s (a stopped process?): probing without it", lock_path,
+              wait_s);
+      close(lock_fd);
+      lock_fd = -1;
+    }
+  }
   struct unlock {
     int fd;
     ~unlock()
@@ -229,6 +270,7 @@ void alloc_local(wholememory_handle_* h)
     }
   }
   for (void* l : losers) (void)bk->free_device(l);
+  h->placement_probed = tried > 1;
   WM_INFO("wholememory_malloc: kept the best of %d probed device allocations of %zu bytes (%.4f ms per GiB of random rows; up to "
           "%zu bytes of candidates were held while probing)",
           tried, h->local_alloc, best_ms, peak_losers * h->local_alloc);
@@ -615,6 +657,20 @@ wholememory_gref_t wholememory_create_continuous_global_reference(void* ptr)
 }
 
 }  // extern "C"
+
+extern "C" wholememory_error_code_t wholememory_ext_set_malloc_probe(const char* mode)
+{
+  std::string m = mode == nullptr ? "" : mode;
+  if (m == "env") m.clear();
+  if (m == "off") m = "0";
+  if (!m.empty() && !(m == "auto" || m == "0" || (m.size() == 1 && m[0] >= '1' && m[0] <= '8'))) return WHOLEMEMORY_INVALID_INPUT;
+  std::lock_guard<std::mutex> lk(wm::g_probe_mode_mutex);
+  wm::g_probe_mode = m;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+// was the local shard of this handle chosen by the placement probe?
+extern "C" int wholememory_ext_handle_was_probed(wholememory_handle_t h) { return h != nullptr && h->placement_probed ? 1 : 0; }
 
 // placement probe on caller memory (experiments, tests; the same probe WM_MALLOC_PROBE uses inside wholememory_malloc)
 extern "C" wholememory_error_code_t wholememory_ext_probe_memory(void* ptr, size_t bytes, int kind, int reps, float* ms_per_gib)

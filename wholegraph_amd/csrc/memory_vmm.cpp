@@ -113,7 +113,20 @@ void vmm_continuous_create(wholememory_comm_t comm, size_t total_size, vmm_mappi
 
   m->page        = page;
   m->total_alloc = round_up<size_t>(total_size, page);
-  if (g_retired_va_bytes.load() + m->total_alloc > va_budget_bytes())
+  // the budget is a per-process count (ranks may have different create / destroy histories, or different
+  // WM_VMM_VA_BUDGET_TIB): the ranks agree before anybody acts, so that all of them fail together instead of one throwing
+  // while the others wait in the fd exchange below (advisor, round 4)
+  const int over_mine = g_retired_va_bytes.load() + m->total_alloc > va_budget_bytes() ? 1 : 0;
+  std::vector<int> over_all(W);
+  comm->allgather_host(&over_mine, over_all.data(), sizeof(int));
+  int over_rank = -1;
+  for (int i = 0; i < W; i++)
+    if (over_all[i] != 0 && over_rank < 0) over_rank = i;
+  if (over_rank >= 0 && !over_mine)
+    throw logic_error(format_string(
+      "CONTINUOUS table not created: rank %d has used up its virtual address budget for destroyed CONTINUOUS tables "
+      "(WM_VMM_VA_BUDGET_TIB, memory_vmm.cpp); every rank of the communicator gives up together", over_rank));
+  if (over_mine)
     throw logic_error(format_string(
       "CONTINUOUS tables destroyed by this process keep %.1f TiB of virtual address space (ranges are never handed back: "
       "stale GPU translations, memory_vmm.cpp); another %.1f GiB would pass the budget of %llu TiB (WM_VMM_VA_BUDGET_TIB). "

@@ -310,6 +310,8 @@ bool mapped_via_exchange(wholememory_tensor_t t, wholememory_memory_type_t mt)
 
 // Every rank of the exchange must arrive at the same number (each chunk is one collective call), so the decision may only
 // use what all ranks know alike: the world size, the environment and id_exchange::global_moved.
+extern std::atomic<int64_t> g_dist_gather_launches;   // kernels queued by gather_distributed_rows (defined with the other counters)
+
 int exchange_chunks(int world_size, int64_t global_moved)
 {
   const char* e = WM_KNOB("WM_EXCHANGE_CHUNKS");
@@ -616,6 +618,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
     else
       sa.row_map = x.raw_indices + x.self_offset;
     local_gather(sa);
+    g_dist_gather_launches.fetch_add(1, std::memory_order_relaxed);
   }
 
   // (b)-(d) the peers' rows, pipelined in C row-chunks so the three legs overlap:
@@ -625,7 +628,7 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
   //   R_c  reorder on receive: out[raw_indices[j]] = recv[j] (gather_op_impl_nccl.cu:151-168) — HBM, caller's stream
   // issue order on the caller's stream: G_0 G_1 R_0 G_2 R_1 ... so that G_{c+1} and R_{c-1} run while A_c is on the
   // links. Chunk c of a segment of n rows is [n*c/C, n*(c+1)/C) on both ends of a pair, so sizes always match.
-  temp_mem local_rows(env), recv_rows(env);
+  temp_mem local_rows(env), recv_rows(env), ids_cm_mem(env), raw_cm_mem(env);
   char* local_buf = static_cast<char*>(local_rows.device(dim * x.total_recv, d.plain.dtype));
   char* recv_buf  = in_place ? static_cast<char*>(d.plain_ptr)   // bucketed layout = the output itself
                              : static_cast<char*>(recv_rows.device(dim * x.total_valid, d.plain.dtype));
@@ -638,18 +641,88 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
     *a = n * c / C;
     *b = n * (c + 1) / C;
   };
+  // ONE launch per chunk and side (round 5; rounds 2-4 launched per peer: 2 (W - 1) C + 1 row kernels per call — 57 at
+  // W = 8, C = 4 — a measurable tax on mini-batch-sized gathers). The received ids (serving side) and the original positions
+  // of the requested rows (requesting side) are brought into CHUNK-MAJOR order once, by one small kernel each (backend:
+  // permute_chunks): chunk c of every peer's segment then lies in one contiguous range of the ids, of the send buffer, of the
+  // receive buffer and of the positions, and the chunk's owner gather / reorder is one row kernel over that range. With one
+  // chunk the peer-major order already is contiguous (and the rows before / after this rank's own segment are two ranges).
+  // Backends without permute_chunks, more than 16 ranks, or WM_EXCHANGE_PER_PEER=1: the per-peer launches as before.
+  const bool per_peer = bk->permute_chunks == nullptr || W > 16 || W <= 2 /* one peer: a chunk is one range already */ ||
+                        (WM_KNOB("WM_EXCHANGE_PER_PEER") != nullptr && WM_KNOB("WM_EXCHANGE_PER_PEER")[0] == '1');
+  const bool fold_serve = !per_peer;                          // serving side: ids -> send buffer
+  const bool fold_recv  = !per_peer && !in_place;            // requesting side: receive buffer -> output rows
+  // chunk-major starts: serve_start[c] over recv_counts, want_start[c] over send_counts (self travels as 0 when kept local)
+  std::vector<int64_t> serve_start(C + 1, 0), want_start(C + 1, 0);
+  for (int c = 0; c < C; c++) {
+    int64_t s1 = 0, s2 = 0;
+    for (int p = 0; p < W; p++) {
+      int64_t a, b;
+      chunk_of(x.recv_counts[p], c, &a, &b), s1 += b - a;
+      chunk_of(x.send_counts[p], c, &a, &b), s2 += b - a;
+    }
+    serve_start[c + 1] = serve_start[c] + s1;
+    want_start[c + 1]  = want_start[c] + s2;
+  }
+  auto serve_pos = [&](int c, int p) {   // where chunk c of peer p's requests starts in the chunk-major order
+    int64_t pos = serve_start[c];
+    for (int q = 0; q < p; q++) {
+      int64_t a, b;
+      chunk_of(x.recv_counts[q], c, &a, &b), pos += b - a;
+    }
+    return pos;
+  };
+  auto want_pos = [&](int c, int p) {
+    int64_t pos = want_start[c];
+    for (int q = 0; q < p; q++) {
+      int64_t a, b;
+      chunk_of(x.send_counts[q], c, &a, &b), pos += b - a;
+    }
+    return pos;
+  };
+  const char* serve_ids  = static_cast<const char*>(x.recv_ids);
+  const int64_t* want_raw = x.raw_indices;
+  if (C > 1 && fold_serve && x.total_recv > 0) {
+    void* cm = ids_cm_mem.device(x.total_recv, d.indices.dtype);
+    WM_BK(bk->permute_chunks(x.recv_ids, cm, static_cast<int>(ies), x.recv_offsets.data(), x.recv_counts.data(), W, C, stream));
+    g_dist_gather_launches.fetch_add(1, std::memory_order_relaxed);
+    serve_ids = static_cast<const char*>(cm);
+  }
+  if (C > 1 && fold_recv && x.total_send > 0) {
+    auto* cm = static_cast<int64_t*>(raw_cm_mem.device(x.total_send, WHOLEMEMORY_DT_INT64));
+    WM_BK(bk->permute_chunks(x.raw_indices, cm, 8, x.bucket_offsets.data(), x.send_counts.data(), W, C, stream));
+    g_dist_gather_launches.fetch_add(1, std::memory_order_relaxed);
+    want_raw = cm;
+  }
+  auto gather_range = [&](const char* ids, int64_t first, int64_t count) {   // ids[first ...] -> send buffer rows first ...
+    if (count <= 0) return;
+    int64_t lsz[2]  = {count, dim};
+    auto local_desc = wholememory_create_matrix_desc(lsz, dim, 0, d.plain.dtype);
+    wm_rows_args ga{};
+    fill_rows_args(&ga, local_gref, d.table, ids + ies * first, d.indices.dtype, count, local_buf + row_bytes * first, local_desc,
+                   gather_sms);
+    local_gather(ga);
+    g_dist_gather_launches.fetch_add(1, std::memory_order_relaxed);
+  };
+  auto reorder_range = [&](const int64_t* raw, int64_t first, int64_t count) {   // receive buffer rows first ... -> out[raw[...]]
+    if (count <= 0) return;
+    int64_t rsz[2]  = {count, dim};
+    auto recv_desc  = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
+    wm_rows_args ra{};
+    fill_rows_args(&ra, out_gref, d.plain, raw + first, WHOLEMEMORY_DT_INT64, count, recv_buf + row_bytes * first, recv_desc, -1);
+    WM_BK(bk->scatter_rows(&ra, stream));
+    g_dist_gather_launches.fetch_add(1, std::memory_order_relaxed);
+  };
   auto gather_chunk = [&](int c) {
+    if (fold_serve) {
+      // (C == 1: the peer-major arrays are contiguous over the peers as they are)
+      gather_range(serve_ids, serve_start[c], serve_start[c + 1] - serve_start[c]);
+      return;
+    }
     for (int p = 0; p < W; p++) {
       int64_t a, b;
       chunk_of(x.recv_counts[p], c, &a, &b);
-      if (b <= a) continue;
-      const int64_t first = x.recv_offsets[p] + a;
-      int64_t lsz[2]      = {b - a, dim};
-      auto local_desc     = wholememory_create_matrix_desc(lsz, dim, 0, d.plain.dtype);
-      wm_rows_args ga{};
-      fill_rows_args(&ga, local_gref, d.table, static_cast<const char*>(x.recv_ids) + ies * first, d.indices.dtype, b - a,
-                     local_buf + row_bytes * first, local_desc, gather_sms);
-      local_gather(ga);
+      gather_range(serve_ids, x.recv_offsets[p] + a, b - a);
     }
   };
   auto exchange_chunk = [&](int c, void* on_stream) {
@@ -657,26 +730,30 @@ wholememory_error_code_t gather_distributed_rows(wholememory_handle_t handle, co
     for (int p = 0; p < W; p++) {
       int64_t a, b;
       chunk_of(x.recv_counts[p], c, &a, &b);  // what this rank serves to p
-      sc[p] = b - a, so[p] = x.recv_offsets[p] + a;
+      sc[p] = b - a, so[p] = (fold_serve && C > 1) ? serve_pos(c, p) : x.recv_offsets[p] + a;
       chunk_of(x.send_counts[p], c, &a, &b);  // what p serves to this rank
-      rc[p] = b - a, ro[p] = x.bucket_offsets[p] + a;
+      rc[p] = b - a, ro[p] = (fold_recv && C > 1) ? want_pos(c, p) : x.bucket_offsets[p] + a;
     }
     exchange_segments(comm, local_buf, sc, so, recv_buf, rc, ro, row_bytes, on_stream);
   };
   auto reorder_chunk = [&](int c) {
     if (in_place) return;  // received where they belong
+    if (fold_recv && C > 1) {
+      reorder_range(want_raw, want_start[c], want_start[c + 1] - want_start[c]);
+      return;
+    }
+    if (fold_recv) {
+      // one chunk: the peers' rows are the bucketed order minus this rank's own segment — the range before it and the one after
+      const int64_t self_b = self_local ? x.self_offset : x.total_valid, self_e = self_local ? x.self_offset + x.self_count : x.total_valid;
+      reorder_range(x.raw_indices, 0, self_b);
+      reorder_range(x.raw_indices, self_e, x.total_valid - self_e);
+      return;
+    }
     for (int p = 0; p < W; p++) {
       if (p == rank && self_local) continue;
       int64_t a, b;
       chunk_of(x.send_counts[p], c, &a, &b);
-      if (b <= a) continue;
-      const int64_t first = x.bucket_offsets[p] + a;
-      int64_t rsz[2]      = {b - a, dim};
-      auto recv_desc      = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
-      wm_rows_args ra{};
-      fill_rows_args(&ra, out_gref, d.plain, x.raw_indices + first, WHOLEMEMORY_DT_INT64, b - a,
-                     recv_buf + row_bytes * first, recv_desc, -1);
-      WM_BK(bk->scatter_rows(&ra, stream));
+      reorder_range(x.raw_indices, x.bucket_offsets[p] + a, b - a);
     }
   };
 
@@ -999,11 +1076,13 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
 
 namespace wm {
 std::atomic<int64_t> g_host_sorted_gathers{0};
+std::atomic<int64_t> g_dist_gather_launches{0};
 }
 
 extern "C" {
 
 int64_t wholememory_ext_host_sorted_gathers(void) { return wm::g_host_sorted_gathers.load(std::memory_order_relaxed); }
+int64_t wholememory_ext_distributed_gather_launches(void) { return wm::g_dist_gather_launches.load(std::memory_order_relaxed); }
 
 wholememory_error_code_t wholememory_gather(wholememory_tensor_t wholememory_tensor,
                                             wholememory_tensor_t indices_tensor,

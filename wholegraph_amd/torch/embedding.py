@@ -256,11 +256,28 @@ def _reconcile_sharding(embedding_entry_partition, cache_policy, round_robin_siz
 def create_embedding(comm: WholeMemoryCommunicator, memory_type: str, memory_location: str, dtype: torch.dtype,
                      sizes: List[int], *, cache_policy: Union[WholeMemoryCachePolicy, None] = None,
                      embedding_entry_partition: Union[List[int], None] = None, random_init: bool = False,
-                     gather_sms: int = -1, round_robin_size: int = 0):
+                     gather_sms: int = -1, round_robin_size: int = 0, placement_probe: Union[str, int, None] = None):
     """Collective over `comm`: a [rows, dim] embedding table (reference embedding.py:380-459, same arguments).
     embedding_entry_partition: rows per rank (default: equal shares); round_robin_size: rows per round-robin block when the
-    table is filled from files in round-robin order; gather_sms: cap on the workgroups of the gather kernels (-1: default)."""
+    table is filled from files in round-robin order; gather_sms: cap on the workgroups of the gather kernels (-1: default).
+    One extension: placement_probe = "auto" | 2 ... 8 | "off" | None (None: what WM_MALLOC_PROBE says, off by default) — for
+    tables that will be WRITTEN at random (trained, scattered into): the device shard is chosen among a few candidate
+    allocations by a short write probe, because the speed of random row writes follows where the allocation sits in HBM
+    (about 20 %, for the table's lifetime). Holds the candidates transiently (at most a quarter of the
+    free memory)."""
     rows, dim = sizes                                            # exactly two dimensions
+    if placement_probe is not None:
+        wmb.check(wmb.lib().wholememory_ext_set_malloc_probe(str(placement_probe).encode()))
+    try:
+        return _create_embedding(comm, memory_type, memory_location, dtype, rows, dim, cache_policy, embedding_entry_partition,
+                                 random_init, gather_sms, round_robin_size)
+    finally:
+        if placement_probe is not None:
+            wmb.check(wmb.lib().wholememory_ext_set_malloc_probe(b"env"))
+
+
+def _create_embedding(comm, memory_type, memory_location, dtype, rows, dim, cache_policy, embedding_entry_partition, random_init,
+                      gather_sms, round_robin_size):
     partition, round_robin_size = _reconcile_sharding(embedding_entry_partition, cache_policy, round_robin_size)
     description = wmb.make_tensor_desc([rows, dim], torch_dtype_to_wholememory_dtype(dtype), [dim, 1], 0)
     handle = C.c_void_p()
