@@ -139,3 +139,28 @@ def test_sample_gather_line(wm_lib, world):
     roof = r["roofline"]
     assert roof["bound"] == "hbm" and "latency" in roof["limited_by"] and 0 < roof["frac"] < 1
     assert r["stability"]["steps"] == 4
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_first_contact_kit_dry_run(wm_lib, world, tmp_path):
+    """scripts/first_contact.sh — what runs first on a multi-GPU node — end to end at toy sizes over gloo (the ranks share this
+    box's GPU): every leg produces its bench line (uniform / Zipf hashed / Zipf clustered at 2 ... N ranks, the CHUNKED table by
+    direct peer loads and through the exchange, C4 in fp16 and fp32, C5) and the report holds them next to the predictions."""
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")},
+               FIRST_CONTACT_DRY="1", FIRST_CONTACT_OUT=str(tmp_path), OMP_NUM_THREADS="1")
+    p = subprocess.run(["bash", os.path.join(ROOT, "scripts", "first_contact.sh"), str(world)], capture_output=True, timeout=3000, env=env)
+    assert p.returncode == 0, p.stdout.decode()[-3000:] + p.stderr.decode()[-2000:]
+    rep = json.load(open(os.path.join(str(tmp_path), "first_contact.json")))
+    assert rep["dry_run"] is True and rep["failed_step"] is None and rep["ranks"] == world
+    m = rep["measured"]
+    want = ["chunked_direct_n%d" % world, "chunked_via_exchange_n%d" % world, "c4_grad_apply_f16_n%d" % world,
+            "c4_grad_apply_f32_n%d" % world, "c5_sample_gather_n%d" % world]
+    k = 2
+    while k <= world:
+        want += ["c3_uniform_n%d" % k, "c3_zipf_n%d" % k, "c3_zipf_clustered_n%d" % k]
+        k *= 2
+    for name in want:
+        assert name in m and m[name].get("value", 0) > 0 and "side_errors" not in m[name], (name, m.get(name))
+    assert m["c3_zipf_clustered_n%d" % world]["config"]["index_distribution"] == "zipf_clustered"
+    assert m["chunked_direct_n%d" % world]["config"]["memory_type"] == "chunked"
+    assert str(world) in rep["predictions_uniform"] and rep["predictions_uniform"]["2"]["link_bound_ms_at_76.8"] > 30
