@@ -155,7 +155,8 @@ wholememory_error_code_t sample_without_replacement(
     const auto wmt = memory_type_of(wm_csr_weight_ptr_tensor);
     if (wmt == WHOLEMEMORY_MT_HIERARCHY) return WHOLEMEMORY_INVALID_INPUT;
     if (wmt == WHOLEMEMORY_MT_DISTRIBUTED) {
-      WM_ERROR("neighbour sampling on DISTRIBUTED CSR tensors is not implemented in this build");
+      WM_ERROR("WEIGHTED sampling with a DISTRIBUTED weight tensor is not implemented (the reference has no such path either; "
+               "unweighted sampling on a DISTRIBUTED CSR is: see via_gather above)");
       return WHOLEMEMORY_NOT_IMPLEMENTED;
     }
     if (weight_desc.dtype != WHOLEMEMORY_DT_FLOAT && weight_desc.dtype != WHOLEMEMORY_DT_DOUBLE) {
