@@ -84,7 +84,7 @@ def main():
                 # algorithmic bytes are the wrong yardstick there — the sector-level roofline counts id + ceil(row / 64) x 64 bytes
                 # on the random (table) side + the row on the dense side
                 row_b, stride_b = dim * es, t.stride()[0] * es
-                sect = (row_b + 63) // 64 * 64 if stride_b % 64 == 0 else (row_b + 63) // 64 * 64 + (64 if row_b % 64 else 0)
+                sect = (row_b + 63) // 64 * 64 if stride_b % 64 == 0 else row_b + 48   # rows start at 16-byte steps: (row + 48) / 64 sectors on average
                 gb_sector = n * (8 + sect + row_b) / 1e9
                 extra = "" if row_b >= 128 else "  | sector-level: %.1f%% of 8 TB/s (%d B per lookup)" % (gb_sector / mn / 8.0 * 100, 8 + sect + row_b)
                 print("%-7s %s dim %4d (%4d B rows, stride %d) n=%8d %-8s: min %.3f ms median %.3f  %.1f%% of 8 TB/s algorithmic  [%s]%s" % (
