@@ -44,7 +44,7 @@ static result cpu_ref(const std::vector<int64_t>& ids, int64_t lower, int64_t sp
 static int run_case(const char* name, const std::vector<int64_t>& ids, int64_t lower, int64_t span, bool timing)
 {
   const int64_t n = ids.size();
-  split::plan p = split::make_plan(n, span, getenv("SPLIT_IPT") ? atoi(getenv("SPLIT_IPT")) : 0);
+  split::plan p = split::make_plan(n, span, getenv("SPLIT_IPT") ? atoi(getenv("SPLIT_IPT")) : 0, getenv("SPLIT_CAPBITS") ? atoi(getenv("SPLIT_CAPBITS")) : 0);
   if (!p.ok) { printf("%-40s n=%ld span=%ld: plan not ok (skipped)\n", name, (long)n, (long)span); return 0; }
   int64_t* d_ids; void* d_ws; int64_t* d_uniq; int32_t *d_starts, *d_order; int64_t* d_nu;
   CK(hipMalloc(&d_ids, 8 * n)); CK(hipMalloc(&d_ws, p.total)); CK(hipMalloc(&d_uniq, 8 * n)); CK(hipMalloc(&d_starts, 4 * (n + 1)));
@@ -69,7 +69,7 @@ static int run_case(const char* name, const std::vector<int64_t>& ids, int64_t l
       if (off < static_cast<uint64_t>(span)) cnt[off >> p.shift]++;
     }
     bool ov = false;
-    for (int b = 0; b < p.buckets; b++) ov |= cnt[b] > split::kCap;
+    for (int b = 0; b < p.buckets; b++) ov |= cnt[b] > (1 << p.cap_bits);
     if (ov != (ctl[split::kCtlOverflow] != 0)) { printf("%s: overflow flag %u, expected %d\n", name, ctl[split::kCtlOverflow], (int)ov); bad = 1; }
   }
   if (ctl[split::kCtlOverflow]) {
@@ -91,8 +91,8 @@ static int run_case(const char* name, const std::vector<int64_t>& ids, int64_t l
       for (int64_t j = 0; j < nu && e < 15; j++) if (uniq[j] != ref.uniq[j]) { printf("%s: unique[%ld] = %ld, expected %ld\n", name, (long)j, (long)uniq[j], (long)ref.uniq[j]); e++; }
       bad |= e != 0;
     }
-    printf("%-40s n=%ld span=%ld shift=%d buckets=%d tiles=%d ipt=%d passes=%dx%d n_unique=%ld: %s\n", name, (long)n, (long)span, p.shift,
-           p.buckets, p.tiles, p.ipt, p.passes, p.digit_bits, (long)nu, bad ? "MISMATCH" : "ok");
+    printf("%-40s n=%ld span=%ld shift=%d buckets=%d cap=%d tiles=%d ipt=%d passes=%dx%d n_unique=%ld: %s\n", name, (long)n, (long)span, p.shift,
+           p.buckets, 1 << p.cap_bits, p.tiles, p.ipt, p.passes, p.digit_bits, (long)nu, bad ? "MISMATCH" : "ok");
   }
   if (timing && !bad) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -125,7 +125,7 @@ int main(int argc, char** argv)
     if (dbg == 0) {   // phase times of the last (only) call
       static unsigned long long t[2][4096][12];
       CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(wm::split::g_split_times), sizeof(t)));
-      const int nph[2] = {7, 11}, nwg[2] = {984, 1527};
+      const int nph[2] = {7, 11}, nwg[2] = {480, 3000};
       for (int k = 0; k < 2; k++) {
         unsigned long long t0 = ~0ull, t1 = 0;
         double ph[12] = {0};

@@ -58,18 +58,20 @@ __device__ unsigned long long g_split_times[2][4096][12];   // [kernel][workgrou
 #define WM_SPLIT_T(kern, wg, ph) do { } while (0)
 #endif
 
-constexpr int kBlock      = 1024;
+constexpr int kBlock      = 1024;                 // threads of a stage-1 workgroup
 constexpr int kWaves      = kBlock / 64;
-constexpr int kMaxBuckets = 2048;                 // real buckets (the drop bucket comes on top)
+constexpr int kMaxBuckets = 4096;                 // real buckets (the drop bucket comes on top)
 constexpr int kMaxPitch   = kMaxBuckets + 32;
-constexpr int kIdxBits    = 13;
-constexpr int kCap        = 1 << kIdxBits;        // ids of one bucket that stage 2 brings into order in LDS
-constexpr int kMaxLowBits = 32 - kIdxBits;        // low key bits that fit the sort word beside the index
+// stage 2 comes in two sizes: up to 4096 ids per bucket with 512 threads (four workgroups per CU: 32 KiB of LDS each) — what a
+// 10 M-id batch on a 100 M-row shard gets, 3052 buckets of 2^15 rows — or up to 8192 ids with 1024 threads (two per CU)
+constexpr int kCapBitsSmall = 12, kCapBitsBig = 13;
+constexpr int kMaxLowBits = 32 - kCapBitsBig;     // low key bits that fit the sort word beside the index
 constexpr int kMapBits    = 16;                   // low key bits the row map of stage 2 covers (2^16 bits = 8 KB)
 constexpr int kMaxDup     = 8;                    // runs of more ids than this send their bucket to the radix passes
 constexpr int kMaxIpt     = 24;                   // ids per thread of a stage-1 tile, at most
 constexpr int kMaxTiles   = 1024;
-constexpr int kSortIpt    = kCap / kBlock;        // 8
+constexpr int kSortIpt    = 8;                    // ids per thread of a stage-2 workgroup
+constexpr size_t kLdsBytes = 160 * 1024;
 constexpr uint32_t kFlagAggregate = 1u << 30, kFlagPrefix = 2u << 30, kValueMask = (1u << 30) - 1;
 
 // control words (u32), zeroed by split_hist_kernel's first workgroup
@@ -82,33 +84,47 @@ struct plan {
   int pitch;          // row pitch of the counts matrix (multiple of 32, >= buckets + 2)
   int ipt, tile, tiles;
   int passes, digit_bits;   // of the radix passes of stage 2
-  int bucket_bits;    // ballots per id in the scatter kernel: bits of `buckets`
+  int bucket_bits;    // bits of `buckets`
+  int cap_bits;       // stage 2: ids per bucket = 1 << cap_bits (kCapBitsSmall or kCapBitsBig)
   // workspace carve (bytes from the workspace start)
   size_t off_keys, off_pos, off_counts, off_totals, off_starts, off_state, off_ctl, total;
 };
 
-inline plan make_plan(int64_t n, int64_t span, int ipt_override = 0)
+inline size_t scatter_lds_bytes(int pitch, int ipt);
+inline plan make_plan(int64_t n, int64_t span, int ipt_override = 0, int cap_bits_override = 0)
 {
   plan p{};
   p.ok = false;
   if (n <= 0 || span <= 0 || span >= INT64_C(0xFFFFFFFF) || n >= (INT64_C(1) << 30)) return p;
   auto buckets_at = [&](int s) { return ((span - 1) >> s) + 1; };
+  // Fewer, larger buckets are the faster ones (a bucket costs stage 2 ~20 us of barrier-separated phases whatever it holds,
+  // and stage 1's segments grow with the bucket: 3052 buckets of 2^15 rows measured 197 us against 184 for 1526 of 2^16 on the
+  // 10 M-id batch), so: at most kPreferBuckets buckets while the average bucket fits the big stage-2 size with headroom, up to
+  // kMaxBuckets otherwise (batches of 14-28 M ids), and for small batches fewer, larger buckets still, as long as the row map
+  // of stage 2 covers them.
+  constexpr int kPreferBuckets = 2048;
   int s = 0;
-  while (buckets_at(s) > kMaxBuckets) s++;   // as few low bits as the bucket limit allows ...
-  // ... and for small batches fewer, larger buckets, as long as the row map of stage 2 covers them
+  while (buckets_at(s) > kPreferBuckets) s++;
+  if (s > 0 && n / buckets_at(s) > (1 << kCapBitsBig) * 85 / 100 && buckets_at(s - 1) <= kMaxBuckets) s--;
   const int64_t want = n / 1536 > 1 ? n / 1536 : 1;
   while (s < kMapBits && buckets_at(s) > want) s++;
   if (s > kMaxLowBits) return p;
   p.shift   = s;
   p.buckets = static_cast<int>(buckets_at(s));
   // uniform ids must leave headroom in a bucket (the overflow path is correct but it is the slow one)
-  if (n / p.buckets > kCap * 85 / 100) return p;
+  const int64_t mean = n / p.buckets;
+  if (mean <= (1 << kCapBitsSmall) * 85 / 100) p.cap_bits = kCapBitsSmall;
+  else if (mean <= (1 << kCapBitsBig) * 85 / 100) p.cap_bits = kCapBitsBig;
+  else return p;
+  if (cap_bits_override == kCapBitsBig) p.cap_bits = kCapBitsBig;   // experiments
   p.pitch = (p.buckets + 2 + 31) / 32 * 32;
-  // tiles: about two rounds of the 512 workgroups the chip holds (2 per CU while a tile's LDS stays under 80 KB)
-  int ipt = static_cast<int>((n + 1000 * kBlock - 1) / (1000 * kBlock));
+  // tiles: about two rounds of the workgroups the chip holds (two per CU while a tile's LDS stays under 80 KB, else one)
+  const bool wide = p.pitch > 2080;
+  int ipt = static_cast<int>((n + (wide ? 500 : 1000) * kBlock - 1) / ((wide ? 500 : 1000) * kBlock));
   if (ipt < 4) ipt = 4;
   if (ipt > kMaxIpt) ipt = kMaxIpt;
   if (ipt_override > 0 && ipt_override <= kMaxIpt) ipt = ipt_override;   // experiments
+  while (ipt > 4 && scatter_lds_bytes(p.pitch, ipt) > kLdsBytes - 1024) ipt--;
   p.ipt   = ipt;
   p.tile  = ipt * kBlock;
   p.tiles = static_cast<int>((n + p.tile - 1) / p.tile);
@@ -163,7 +179,8 @@ __device__ __forceinline__ int tile_of_block(int bid, int tiles)
 }
 inline int tile_grid(int tiles) { return (tiles + 7) / 8 * 8; }
 
-__device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* s_waves /* kWaves words */, uint32_t* total)
+template <int WAVES = kWaves>
+__device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* s_waves /* WAVES words */, uint32_t* total)
 {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t incl  = v;
@@ -177,7 +194,7 @@ __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* s_
   __syncthreads();
   uint32_t before = 0, all = 0;
 #pragma unroll
-  for (int w = 0; w < kWaves; w++) {
+  for (int w = 0; w < WAVES; w++) {
     const uint32_t t = s_waves[w];
     if (w < wv) before += t;
     all += t;
@@ -286,7 +303,8 @@ inline size_t scatter_lds_bytes(int pitch, int ipt)
   return 4 * static_cast<size_t>(pitch) + (cnt > buf ? cnt : buf);
 }
 
-template <typename UKey, int MAXIPT>
+// PER: buckets per thread in the per-bucket loops (3 up to 3072 buckets + pitch slack, 5 up to kMaxBuckets)
+template <typename UKey, int MAXIPT, int PER>
 __global__ __launch_bounds__(kBlock, MAXIPT <= 12 ? 8 : 4) void split_scatter_kernel(key_source<UKey> src, int64_t n, int ipt, int tiles, int shift,
                                                                int buckets, int bucket_bits, int pitch, const uint32_t* counts,
                                                                const uint32_t* totals, uint32_t* bucket_start, uint32_t* keys_out,
@@ -330,16 +348,16 @@ __global__ __launch_bounds__(kBlock, MAXIPT <= 12 ? 8 : 4) void split_scatter_ke
   }
 
   // bucket starts = exclusive scan of the totals (every workgroup redoes these ~2 k additions rather than wait for a kernel)
-  const int per = (pitch + kBlock - 1) / kBlock;   // <= 3 consecutive buckets per thread
+  const int per = (pitch + kBlock - 1) / kBlock;   // <= 5 consecutive buckets per thread
   const int b0  = threadIdx.x * per;
   {
-    uint32_t tt[3] = {0, 0, 0}, mine = 0;
+    uint32_t tt[PER] = {}, mine = 0;
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < PER; i++)
       if (i < per && b0 + i < pitch) tt[i] = totals[b0 + i], mine += tt[i];
     uint32_t run = block_exclusive_sum(mine, s_waves, nullptr);
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < PER; i++)
       if (i < per && b0 + i < pitch) {
         s_off[b0 + i] = run + counts[static_cast<size_t>(t) * pitch + b0 + i];
         if (t == 0) bucket_start[b0 + i] = run;   // [buckets] = number of ids inside the range, [buckets + 1] = n
@@ -384,9 +402,9 @@ __global__ __launch_bounds__(kBlock, MAXIPT <= 12 ? 8 : 4) void split_scatter_ke
   WM_SPLIT_T(0, blockIdx.x, 2);
   // per bucket: exclusive prefix over the waves (16-bit: a tile has <= 24 K ids), the bucket's start in the tile's bucket order
   {
-    uint32_t cnt3[3] = {0, 0, 0}, mine = 0;
+    uint32_t cnt3[PER] = {}, mine = 0;
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < PER; i++)
       if (i < per && b0 + i < pitch) {
         const int b  = b0 + i;
         uint32_t run = 0;
@@ -402,7 +420,7 @@ __global__ __launch_bounds__(kBlock, MAXIPT <= 12 ? 8 : 4) void split_scatter_ke
       }
     uint32_t lstart = block_exclusive_sum(mine, s_waves, nullptr);
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < PER; i++)
       if (i < per && b0 + i < pitch) {
         const int b = b0 + i;
         s_off[b] -= lstart;
@@ -499,32 +517,34 @@ __device__ __forceinline__ void publish(uint32_t* state, int b, uint32_t flag, u
   __hip_atomic_store(&state[b], flag | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename OutT>
-// (second launch bound = waves per SIMD: 8 = two workgroups per CU)
-__global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* keys, const uint32_t* pos,
+// (second launch bound = waves per SIMD: 8 = as many workgroups per CU as 32 waves make: two of 1024 threads, four of 512)
+template <typename OutT, int CAPBITS>
+__global__ __launch_bounds__((1 << CAPBITS) / kSortIpt, 8) void split_sort_kernel(const uint32_t* keys, const uint32_t* pos,
                                                                const uint32_t* bucket_start, int buckets, int shift, int passes,
                                                                int digit_bits, OutT key_base, OutT* unique_ids, int32_t* run_starts,
                                                                int32_t* order, int64_t* n_unique, uint32_t* ctl, uint32_t* state)
 {
   if (ctl[kCtlOverflow] != 0) return;
-  __shared__ uint32_t s_buf[kCap];   // the bucket's words in order; before that: the row map (2048 words) + its prefix (2048)
-  __shared__ uint32_t s_run[kCap];   // map path: ids per run, then run starts; radix path: per-wave digit counters
-  __shared__ uint32_t s_waves[kWaves];
+  constexpr int CAP = 1 << CAPBITS, BLOCK = CAP / kSortIpt, WAVES = BLOCK / 64;
+  __shared__ uint32_t s_buf[CAP];   // the bucket's words in order; before that: the row map (2048 words) + its prefix (2048)
+  __shared__ uint32_t s_run[CAP];   // map path: ids per run, then run starts; radix path: per-wave digit counters
+  __shared__ uint32_t s_waves[WAVES];
   __shared__ uint32_t s_misc[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   WM_SPLIT_T(1, blockIdx.x, 0);
-  if (threadIdx.x == 0) {
-    s_misc[0] = atomicAdd(&ctl[kCtlTicket], 1u);
-    s_misc[2] = 0;
-  }
+  // The bucket IS the workgroup index: a workgroup waits (in look_back) only for smaller indices, and workgroups start in
+  // index order on every XCD, so the smallest unfinished bucket always runs or is next in line for a slot held by finished-or-
+  // running smaller ones — no co-residency assumption (the argument of graph.hip's chain scan). A ticket counter here
+  // serialised the workgroups' starts at ~27 ns each: 14 us per round of 512 workgroups (profiles/r05_split_sort_harness.txt).
+  if (threadIdx.x == 0) s_misc[2] = 0;
   __syncthreads();
-  const int b          = static_cast<int>(s_misc[0]);
+  const int b          = static_cast<int>(blockIdx.x);
   const uint32_t start = bucket_start[b];
   const int m          = static_cast<int>(bucket_start[b + 1] - start);
 
   if (b == buckets) {
     // the drop bucket: positions of the ids outside the range fill the tail of order[]; then the totals
-    for (int i = threadIdx.x; i < m; i += kBlock) order[start + i] = static_cast<int32_t>(pos[start + i]);
+    for (int i = threadIdx.x; i < m; i += BLOCK) order[start + i] = static_cast<int32_t>(pos[start + i]);
     if (wv == 0) {
       const uint32_t total = look_back(state, buckets, ctl);
       if (lane == 0) {
@@ -547,7 +567,7 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
   }
 
   // wave w owns positions [w, w + 1) x chunk of the bucket, chunk = a multiple of 64 with 16 chunks covering m
-  const int steps = (m + kBlock - 1) / kBlock;   // <= kSortIpt
+  const int steps = (m + BLOCK - 1) / BLOCK;   // <= kSortIpt
   const int chunk = steps * 64;
   const int p0    = wv * chunk + lane;
   const uint32_t low_mask = (1u << shift) - 1u;   // shift <= kMaxLowBits
@@ -562,7 +582,7 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
 #pragma unroll
     for (int j = 0; j < kSortIpt; j++) {
       const int p = p0 + j * 64;
-      w[j]        = (j < steps && p < m) ? ((raw[j] & low_mask) << kIdxBits) | static_cast<uint32_t>(p) : 0xFFFFFFFFu;
+      w[j]        = (j < steps && p < m) ? ((raw[j] & low_mask) << CAPBITS) | static_cast<uint32_t>(p) : 0xFFFFFFFFu;
     }
   }
   const OutT bucket_key = (static_cast<OutT>(b) << shift) + key_base;
@@ -571,23 +591,30 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
   uint32_t heads_total  = 0;
 
   if (!radix) {
-    uint32_t* s_map = s_buf;          // [2048] bit r: row r of the bucket is present
-    uint32_t* s_pre = s_buf + 2048;   // [2048] present rows before the word
+    const int map_words = shift > 5 ? 1 << (shift - 5) : 1;   // <= 2048 (shift <= kMapBits)
+    uint32_t* s_map = s_buf;               // [map_words] bit r: row r of the bucket is present
+    uint32_t* s_pre = s_buf + map_words;   // [map_words] present rows before the word
     WM_SPLIT_T(1, blockIdx.x, 1);
-    s_map[threadIdx.x] = 0, s_map[threadIdx.x + kBlock] = 0;
-    for (int i = threadIdx.x; i < m; i += kBlock) s_run[i] = 0;
+    for (int i = threadIdx.x; i < map_words; i += BLOCK) s_map[i] = 0;
+    for (int i = threadIdx.x; i < m; i += BLOCK) s_run[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kSortIpt; j++)
-      if (j < steps && p0 + j * 64 < m) atomicOr(&s_map[w[j] >> (kIdxBits + 5)], 1u << ((w[j] >> kIdxBits) & 31u));
+      if (j < steps && p0 + j * 64 < m) atomicOr(&s_map[w[j] >> (CAPBITS + 5)], 1u << ((w[j] >> CAPBITS) & 31u));
     __syncthreads();
     WM_SPLIT_T(1, blockIdx.x, 2);
     {
-      const uint32_t t0 = s_map[2 * threadIdx.x], t1 = s_map[2 * threadIdx.x + 1];
-      const uint32_t c0 = static_cast<uint32_t>(__popc(t0)), c1 = static_cast<uint32_t>(__popc(t1));
-      const uint32_t ex = block_exclusive_sum(c0 + c1, s_waves, &heads_total);
-      s_pre[2 * threadIdx.x]     = ex;
-      s_pre[2 * threadIdx.x + 1] = ex + c0;
+      // a thread owns wpt consecutive words of the map (2 for the usual shapes: 2048 words / 1024 threads, 1024 / 512)
+      const int wpt = map_words >= BLOCK ? map_words / BLOCK : 1;   // <= 4
+      const int w0  = threadIdx.x * wpt;
+      uint32_t c[4] = {0, 0, 0, 0}, mine = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (q < wpt && w0 + q < map_words) c[q] = static_cast<uint32_t>(__popc(s_map[w0 + q])), mine += c[q];
+      uint32_t ex = block_exclusive_sum<WAVES>(mine, s_waves, &heads_total);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (q < wpt && w0 + q < map_words) s_pre[w0 + q] = ex, ex += c[q];
     }
     // the bucket's run count is known: tell the buckets behind this one now, look back later
     if (threadIdx.x == 0) publish(state, b, b == 0 ? kFlagPrefix : kFlagAggregate, heads_total);
@@ -598,7 +625,7 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
 #pragma unroll
     for (int j = 0; j < kSortIpt; j++)
       if (j < steps && p0 + j * 64 < m) {
-        const uint32_t k  = w[j] >> kIdxBits;
+        const uint32_t k  = w[j] >> CAPBITS;
         const uint32_t r  = s_pre[k >> 5] + static_cast<uint32_t>(__popc(s_map[k >> 5] & ((1u << (k & 31u)) - 1u)));
         const uint32_t o  = atomicAdd(&s_run[r], 1u);
         slot[j]           = r | (o << 16);
@@ -615,7 +642,7 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
         uint32_t c[kSortIpt], mine = 0;
 #pragma unroll
         for (int i = 0; i < kSortIpt; i++) c[i] = r0 + i < static_cast<int>(heads_total) ? s_run[r0 + i] : 0u, mine += c[i];
-        uint32_t run = block_exclusive_sum(mine, s_waves, nullptr);
+        uint32_t run = block_exclusive_sum<WAVES>(mine, s_waves, nullptr);
 #pragma unroll
         for (int i = 0; i < kSortIpt; i++) {
           if (r0 + i < static_cast<int>(heads_total)) s_run[r0 + i] = run;
@@ -630,7 +657,7 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
       __syncthreads();
       WM_SPLIT_T(1, blockIdx.x, 6);
       // a run of several ids is in the order its ids reached the counter: put it into receive order (ascending words)
-      for (int r = threadIdx.x; r < static_cast<int>(heads_total); r += kBlock) {
+      for (int r = threadIdx.x; r < static_cast<int>(heads_total); r += BLOCK) {
         const int i0 = static_cast<int>(s_run[r]);
         const int i1 = r + 1 < static_cast<int>(heads_total) ? static_cast<int>(s_run[r + 1]) : m;
         for (int i = i0 + 1; i < i1; i++) {
@@ -657,22 +684,22 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
         uint32_t pv[kSortIpt];   // the positions of the bucket's ids in their new order: 8 gathers in flight, then 8 stores
 #pragma unroll
         for (int k = 0; k < kSortIpt; k++) {
-          const int i = k * kBlock + threadIdx.x;
-          pv[k]       = pos[start + (i < m ? (s_buf[i] & (kCap - 1)) : 0u)];
+          const int i = k * BLOCK + threadIdx.x;
+          pv[k]       = pos[start + (i < m ? (s_buf[i] & (CAP - 1)) : 0u)];
         }
 #pragma unroll
         for (int k = 0; k < kSortIpt; k++) {
-          const int i = k * kBlock + threadIdx.x;
+          const int i = k * BLOCK + threadIdx.x;
           if (i < m) order[start + i] = static_cast<int32_t>(pv[k]);
         }
       }
       __syncthreads();
       WM_SPLIT_T(1, blockIdx.x, 9);
       const uint32_t run_base = s_misc[1];
-      for (int r = threadIdx.x; r < static_cast<int>(heads_total); r += kBlock) {
+      for (int r = threadIdx.x; r < static_cast<int>(heads_total); r += BLOCK) {
         const uint32_t i0        = s_run[r];
         run_starts[run_base + r] = static_cast<int32_t>(start + i0);
-        unique_ids[run_base + r] = bucket_key + static_cast<OutT>(s_buf[i0] >> kIdxBits);
+        unique_ids[run_base + r] = bucket_key + static_cast<OutT>(s_buf[i0] >> CAPBITS);
       }
       WM_SPLIT_T(1, blockIdx.x, 10);
       return;
@@ -683,11 +710,11 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
   // ---- radix path: stable least-significant-digit passes over the low key bits --------------------------------------------
   {
     const uint64_t lt = (1ull << lane) - 1ull;
-    uint32_t* s_cnt   = s_run;   // [kWaves][256]
+    uint32_t* s_cnt   = s_run;   // [WAVES][256]
     uint32_t* my_cnt  = s_cnt + wv * 256;
     const int bins    = 1 << digit_bits;
     for (int pass = 0; pass < passes; pass++) {
-      const int sh         = kIdxBits + pass * digit_bits;
+      const int sh         = CAPBITS + pass * digit_bits;
       const uint32_t dmask = static_cast<uint32_t>(bins - 1);
       for (int i = lane; i < bins; i += 64) my_cnt[i] = 0;
       // (a wave's counters are its own until the scan below: no barrier between the zeroing and the ranking)
@@ -710,17 +737,17 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
       if (threadIdx.x < bins) {
         uint32_t run = 0;
 #pragma unroll
-        for (int ww = 0; ww < kWaves; ww++) {
+        for (int ww = 0; ww < WAVES; ww++) {
           const uint32_t c              = s_cnt[ww * 256 + threadIdx.x];
           s_cnt[ww * 256 + threadIdx.x] = run;
           run += c;
         }
         mine = run;
       }
-      const uint32_t dbase = block_exclusive_sum(mine, s_waves, nullptr);
+      const uint32_t dbase = block_exclusive_sum<WAVES>(mine, s_waves, nullptr);
       if (threadIdx.x < bins) {
 #pragma unroll
-        for (int ww = 0; ww < kWaves; ww++) s_cnt[ww * 256 + threadIdx.x] += dbase;
+        for (int ww = 0; ww < WAVES; ww++) s_cnt[ww * 256 + threadIdx.x] += dbase;
       }
       __syncthreads();
 #pragma unroll
@@ -751,26 +778,26 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
     }
     // runs: position i (striped: i = k x 1024 + thread) is a head when its low key differs from its predecessor's
     uint64_t head_mask[kSortIpt];
-    uint32_t* s_hc = s_run;   // [kSortIpt][kWaves] head counts, then their exclusive prefix
+    uint32_t* s_hc = s_run;   // [kSortIpt][WAVES] head counts, then their exclusive prefix
 #pragma unroll
     for (int k = 0; k < kSortIpt; k++) {
-      const int i = k * kBlock + threadIdx.x;
+      const int i = k * BLOCK + threadIdx.x;
       bool head   = false;
       w[k]        = 0;
       if (k < steps && i < m) {
         w[k]                = s_buf[i];
         const uint32_t prev = i > 0 ? s_buf[i - 1] : ~w[k];
-        head                = (w[k] >> kIdxBits) != (prev >> kIdxBits);
-        order[start + i]    = static_cast<int32_t>(pos[start + (w[k] & (kCap - 1))]);
+        head                = (w[k] >> CAPBITS) != (prev >> CAPBITS);
+        order[start + i]    = static_cast<int32_t>(pos[start + (w[k] & (CAP - 1))]);
       }
       head_mask[k] = __ballot(head);
-      if (lane == 0) s_hc[k * kWaves + wv] = static_cast<uint32_t>(__popcll(head_mask[k]));
+      if (lane == 0) s_hc[k * WAVES + wv] = static_cast<uint32_t>(__popcll(head_mask[k]));
     }
     __syncthreads();
-    const uint32_t hv = threadIdx.x < kSortIpt * kWaves ? s_hc[threadIdx.x] : 0u;
+    const uint32_t hv = threadIdx.x < kSortIpt * WAVES ? s_hc[threadIdx.x] : 0u;
     uint32_t ht;
-    const uint32_t hx = block_exclusive_sum(hv, s_waves, &ht);
-    if (threadIdx.x < kSortIpt * kWaves) s_hc[threadIdx.x] = hx;
+    const uint32_t hx = block_exclusive_sum<WAVES>(hv, s_waves, &ht);
+    if (threadIdx.x < kSortIpt * WAVES) s_hc[threadIdx.x] = hx;
     __syncthreads();
     if (wv == 0) {
       if (lane == 0 && !published) publish(state, b, b == 0 ? kFlagPrefix : kFlagAggregate, ht);
@@ -784,11 +811,11 @@ __global__ __launch_bounds__(kBlock, 8) void split_sort_kernel(const uint32_t* k
     const uint32_t run_base = s_misc[1];
 #pragma unroll
     for (int k = 0; k < kSortIpt; k++) {
-      const int i = k * kBlock + threadIdx.x;
+      const int i = k * BLOCK + threadIdx.x;
       if (k < steps && ((head_mask[k] >> lane) & 1ull)) {
-        const uint32_t r = run_base + s_hc[k * kWaves + wv] + static_cast<uint32_t>(__popcll(head_mask[k] & ((1ull << lane) - 1ull)));
+        const uint32_t r = run_base + s_hc[k * WAVES + wv] + static_cast<uint32_t>(__popcll(head_mask[k] & ((1ull << lane) - 1ull)));
         run_starts[r]    = static_cast<int32_t>(start + i);
-        unique_ids[r]    = bucket_key + static_cast<OutT>(w[k] >> kIdxBits);
+        unique_ids[r]    = bucket_key + static_cast<OutT>(w[k] >> CAPBITS);
       }
     }
   }
@@ -815,9 +842,10 @@ int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint
   uint32_t* ctl    = reinterpret_cast<uint32_t*>(ws + p.off_ctl);
   key_source<UKey> src{ids, key_lower_bound, span};
   static bool attr_set = [] {
-    const int most = static_cast<int>(scatter_lds_bytes(kMaxPitch, kMaxIpt));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_scatter_kernel<UKey, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_scatter_kernel<UKey, kMaxIpt>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    const int most = static_cast<int>(kLdsBytes - 1024);   // (static LDS comes on top; make_plan keeps a tile below this)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_scatter_kernel<UKey, 12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_scatter_kernel<UKey, kMaxIpt, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_scatter_kernel<UKey, kMaxIpt, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
     return true;
   }();
   (void)attr_set;
@@ -825,19 +853,25 @@ int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint
   hipLaunchKernelGGL((split_hist_kernel<UKey>), dim3(grid), dim3(kBlock), 0, stream, src, n, p.tile, p.tiles, p.shift, p.buckets,
                      p.pitch, counts, ctl, zero_words, n_zero_words);
   hipLaunchKernelGGL(split_scan_kernel, dim3(p.pitch / 32), dim3(kBlock), 0, stream, counts, p.tiles, p.pitch, p.buckets, totals, ctl,
-                     kCap, state, p.pitch + 2);
+                     1 << p.cap_bits, state, p.pitch + 2);
   if (!hook_after_scatter) between();
   const size_t lds = scatter_lds_bytes(p.pitch, p.ipt);
-  if (p.ipt <= 12)
-    hipLaunchKernelGGL((split_scatter_kernel<UKey, 12>), dim3(grid), dim3(kBlock), lds, stream, src, n, p.ipt, p.tiles, p.shift,
-                       p.buckets, p.bucket_bits, p.pitch, counts, totals, starts, keys, pos, ctl);
-  else
-    hipLaunchKernelGGL((split_scatter_kernel<UKey, kMaxIpt>), dim3(grid), dim3(kBlock), lds, stream, src, n, p.ipt, p.tiles, p.shift,
-                       p.buckets, p.bucket_bits, p.pitch, counts, totals, starts, keys, pos, ctl);
+#define WM_SPLIT_SCATTER(MAXI, PERB)                                                                                             \
+  hipLaunchKernelGGL((split_scatter_kernel<UKey, MAXI, PERB>), dim3(grid), dim3(kBlock), lds, stream, src, n, p.ipt, p.tiles, p.shift, \
+                     p.buckets, p.bucket_bits, p.pitch, counts, totals, starts, keys, pos, ctl)
+  if (p.pitch > 3 * kBlock) WM_SPLIT_SCATTER(kMaxIpt, 5);
+  else if (p.ipt <= 12 && lds <= kLdsBytes / 2) WM_SPLIT_SCATTER(12, 3);
+  else WM_SPLIT_SCATTER(kMaxIpt, 3);
+#undef WM_SPLIT_SCATTER
   if (hook_after_scatter) between();
-  hipLaunchKernelGGL((split_sort_kernel<UKey>), dim3(p.buckets + 1), dim3(kBlock), 0, stream, keys, pos, starts, p.buckets, p.shift,
-                     p.passes, p.digit_bits, key_lower_bound, static_cast<UKey*>(unique_ids), run_starts, order, n_unique, ctl,
-                     state);
+  if (p.cap_bits == kCapBitsSmall)
+    hipLaunchKernelGGL((split_sort_kernel<UKey, kCapBitsSmall>), dim3(p.buckets + 1), dim3((1 << kCapBitsSmall) / kSortIpt), 0, stream,
+                       keys, pos, starts, p.buckets, p.shift, p.passes, p.digit_bits, key_lower_bound,
+                       static_cast<UKey*>(unique_ids), run_starts, order, n_unique, ctl, state);
+  else
+    hipLaunchKernelGGL((split_sort_kernel<UKey, kCapBitsBig>), dim3(p.buckets + 1), dim3((1 << kCapBitsBig) / kSortIpt), 0, stream,
+                       keys, pos, starts, p.buckets, p.shift, p.passes, p.digit_bits, key_lower_bound,
+                       static_cast<UKey*>(unique_ids), run_starts, order, n_unique, ctl, state);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
