@@ -36,7 +36,7 @@ namespace osw {
 constexpr int kMaxPasses   = 4;
 constexpr int kMaxRadix    = 10;
 constexpr uint32_t kFlagAggregate = 1u << 30, kFlagPrefix = 2u << 30, kValueMask = (1u << 30) - 1;
-constexpr int kHistBlock = 512, kHistGrid = 512;
+constexpr int kHistBlock = 512, kHistGrid = 256;
 
 struct plan {
   int passes, radix_bits, bins, tiles, tile;
@@ -322,7 +322,7 @@ int sort_pairs(KeyIt keys, uint32_t* keys_sorted, uint32_t* order, int64_t n, un
   a.hist = ctrl + p.hist_off, a.ticket = ctrl + p.ticket_off, a.state = ctrl + p.state_off;
   const uint32_t* kin = nullptr;
   const uint32_t* vin = nullptr;
-  const int grid      = p.tiles < 768 ? p.tiles : 768;   // three workgroups per CU
+  const int grid      = p.tiles < 512 ? p.tiles : 512;   // two workgroups per CU
   for (int pass = 0; pass < p.passes; pass++) {
     const bool to_final = ((p.passes - 1 - pass) & 1) == 0;
     a.pass     = pass;

@@ -176,12 +176,17 @@ template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void run_count_kernel(const KeyT* sorted, int64_t n, int32_t* tile_counts, const uint32_t* gate)
 {
   if (gate != nullptr && *gate == 0u) return;
-  bool head[kRunItems];
-  KeyT key[kRunItems];
-  const int heads = tile_heads(sorted, n, static_cast<int64_t>(blockIdx.x) * kRunTile, head, key);
-  int total;
-  (void)block_exclusive_sum(heads, &total);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+  // (a bounded grid that walks the tiles: gated off, a launch of 4883 workgroups that only read the gate still takes ~7 us of
+  // the machine, of 1024 about 3)
+  const int n_tiles = static_cast<int>((n + kRunTile - 1) / kRunTile);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    bool head[kRunItems];
+    KeyT key[kRunItems];
+    const int heads = tile_heads(sorted, n, static_cast<int64_t>(tile) * kRunTile, head, key);
+    int total;
+    (void)block_exclusive_sum(heads, &total);
+    if (threadIdx.x == 0) tile_counts[tile] = total;
+  }
 }
 
 // `last_key` / `drop_key`: when the LAST sorted key equals drop_key (the out-of-range marker of narrow_key_iterator), its run —
@@ -227,34 +232,38 @@ __global__ __launch_bounds__(kBlock) void run_compact_kernel(const KeyT* sorted,
   // own heads are kRunItems apart in rank order: written directly they cost a scattered store per item — 82 us vs ~35)
   __shared__ KeyT s_key[kRunTile];
   __shared__ int32_t s_pos[kRunTile];
-  bool head[kRunItems];
-  KeyT key[kRunItems];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kRunTile;
-  const int heads    = tile_heads(sorted, n, base, head, key);
-  int total;
-  int rank = block_exclusive_sum(heads, &total);
+  const int n_tiles = static_cast<int>((n + kRunTile - 1) / kRunTile);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    bool head[kRunItems];
+    KeyT key[kRunItems];
+    const int64_t base = static_cast<int64_t>(tile) * kRunTile;
+    const int heads    = tile_heads(sorted, n, base, head, key);
+    int total;
+    int rank = block_exclusive_sum(heads, &total);
 #pragma unroll
-  for (int i = 0; i < kRunItems; i++) {
-    if (head[i]) {
-      s_key[rank] = key[i];
-      s_pos[rank] = static_cast<int32_t>(base + static_cast<int64_t>(threadIdx.x) * kRunItems + i);
-      rank++;
+    for (int i = 0; i < kRunItems; i++) {
+      if (head[i]) {
+        s_key[rank] = key[i];
+        s_pos[rank] = static_cast<int32_t>(base + static_cast<int64_t>(threadIdx.x) * kRunItems + i);
+        rank++;
+      }
     }
+    __syncthreads();
+    const int64_t out0 = tile_prefix[tile];
+    for (int i = threadIdx.x; i < total; i += kBlock) {
+      // ids are stored in the caller's (signed) index type: the keys are its two's-complement bits, possibly narrowed to
+      // 32 bits when the caller bounded them (then they are non-negative and the widening is exact)
+      const KeyT k         = s_key[i];
+      // (key_base: the keys were sorted relative to the first row of the owner's range, see run_dedup)
+      unique_ids[out0 + i] = (sizeof(KeyT) == sizeof(OutT) ? static_cast<OutT>(k) : static_cast<OutT>(static_cast<uint64_t>(k))) + key_base;
+      run_starts[out0 + i] = s_pos[i];
+    }
+    // end marker — unless the out-of-range run was dropped: then its own start (written above, at index *n_unique) ends the
+    // last real run
+    if (tile == n_tiles - 1 && threadIdx.x == 0 && !(drop_last && sorted[n - 1] == drop_key))
+      run_starts[*n_unique] = static_cast<int32_t>(n);
+    __syncthreads();   // s_key / s_pos are reused by the block's next tile
   }
-  __syncthreads();
-  const int64_t out0 = tile_prefix[blockIdx.x];
-  for (int i = threadIdx.x; i < total; i += kBlock) {
-    // ids are stored in the caller's (signed) index type: the keys are its two's-complement bits, possibly narrowed to
-    // 32 bits when the caller bounded them (then they are non-negative and the widening is exact)
-    const KeyT k         = s_key[i];
-    // (key_base: the keys were sorted relative to the first row of the owner's range, see run_dedup)
-    unique_ids[out0 + i] = (sizeof(KeyT) == sizeof(OutT) ? static_cast<OutT>(k) : static_cast<OutT>(static_cast<uint64_t>(k))) + key_base;
-    run_starts[out0 + i] = s_pos[i];
-  }
-  // end marker — unless the out-of-range run was dropped: then its own start (written above, at index *n_unique) ends the
-  // last real run
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && !(drop_last && sorted[n - 1] == drop_key))
-    run_starts[*n_unique] = static_cast<int32_t>(n);
 }
 
 inline unsigned significant_bits(int64_t upper_bound, unsigned full)
@@ -368,6 +377,15 @@ struct sort_lane {
   }
 };
 std::atomic<int64_t> g_split_sorts{0};
+// The optimizer step that follows a split sort on the same thread finds the sort's control words through the run_starts array
+// both were given: its long-run counters live there (zeroed by the sort's first kernel: no fill in front of the step), and
+// the listing kernels return at once when the sort saw neither an overflow nor a bucket with a run of more than kMaxDup ids —
+// then no run is longer than kMaxDup, far below any long-run threshold (fill 5.7 + listing 13 us per call otherwise).
+struct last_split_record {
+  const int32_t* run_starts = nullptr;
+  uint32_t* ctl             = nullptr;
+};
+thread_local last_split_record g_last_split;
 struct split_layout {
   void* split_ws;        // split::plan offsets apply; its first two arrays double as the generic sort's second (key, position) pair
   uint32_t* sorted;      // generic path: sorted keys
@@ -427,10 +445,11 @@ int detect_runs(const SortKeyT* sorted, int32_t* tile_counts, int64_t n, OutT* u
   if constexpr (sizeof(SortKeyT) == 4) {
     if (drop_last) last_key = reinterpret_cast<const uint32_t*>(sorted + (n - 1));
   }
-  hipLaunchKernelGGL((run_count_kernel<SortKeyT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts, gate);
+  const int run_grid = std::min(tiles, 1024);
+  hipLaunchKernelGGL((run_count_kernel<SortKeyT>), dim3(run_grid), dim3(kBlock), 0, stream, sorted, n, tile_counts, gate);
   hipLaunchKernelGGL(run_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, tiles, n_unique_out, last_key,
                      static_cast<uint32_t>(drop_key), gate);
-  hipLaunchKernelGGL((run_compact_kernel<SortKeyT, OutT>), dim3(tiles), dim3(kBlock), 0, stream, sorted, n, tile_counts,
+  hipLaunchKernelGGL((run_compact_kernel<SortKeyT, OutT>), dim3(run_grid), dim3(kBlock), 0, stream, sorted, n, tile_counts,
                      n_unique_out, unique_ids, run_starts, key_base, last_key != nullptr, drop_key, gate);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -482,6 +501,8 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
         return -2;
       if (forked && hipStreamWaitEvent(stream, sort_lane::get().joined, 0) != hipSuccess) return -2;
       g_split_sorts.fetch_add(1, std::memory_order_relaxed);
+      g_last_split.run_starts = run_starts;
+      g_last_split.ctl        = reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl);
       return generic_rc;
     }
   }
@@ -540,6 +561,7 @@ struct opt_params {
   const int64_t* n_unique;  // device scalar (or nullptr -> a.count)
   long_run_entry* long_list;
   int32_t* long_count;
+  const uint32_t* split_ctl;   // control words of the split sort that produced the runs (or nullptr): see last_split_record
   // step_tile_kernel: runs per wave tile. 64 with the persistent grid of round 2; one batch (RPS x kU runs) when the tiles
   // are handed out in order, one per wave (round 3, see launch_step_opt)
   int tile_runs;
@@ -1411,6 +1433,9 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
 template <typename IdxT>
 __global__ void mark_long_runs_kernel(opt_params p)
 {
+  if (p.split_ctl != nullptr && p.split_ctl[split::kCtlOverflow] == 0 && p.split_ctl[split::kCtlRadixBuckets] == 0 &&
+      p.long_threshold >= split::kMaxDup)
+    return;
   const wm_optimizer_args& a = p.a;
   const int64_t count        = p.n_unique ? *p.n_unique : a.count;
   const IdxT* ids            = static_cast<const IdxT*>(a.ids);
@@ -1577,6 +1602,10 @@ inline tree_ws_view tree_ws_carve(void* ws, int64_t n_recv, int threshold)
 template <typename IdxT>
 __global__ __launch_bounds__(256) void tree_mark_kernel(opt_params p, tree_ws_view w, int threshold)
 {
+  // (no bucket of the split sort held a run of more than kMaxDup ids: nothing to list)
+  if (p.split_ctl != nullptr && p.split_ctl[split::kCtlOverflow] == 0 && p.split_ctl[split::kCtlRadixBuckets] == 0 &&
+      threshold >= split::kMaxDup)
+    return;
   const wm_optimizer_args& a = p.a;
   const int64_t count        = p.n_unique ? *p.n_unique : a.count;
   const IdxT* ids            = static_cast<const IdxT*>(a.ids);
@@ -1768,7 +1797,8 @@ inline int resolve_fold_mode(const wm_optimizer_args& a)
 template <typename IdxT, int OPT, typename T>
 void launch_tree(const opt_params& p, hipStream_t stream, hipStream_t lstream)
 {
-  const tree_ws_view w = tree_ws_carve(p.a.long_run_ws, p.a.count, p.long_threshold);
+  tree_ws_view w = tree_ws_carve(p.a.long_run_ws, p.a.count, p.long_threshold);
+  if (p.split_ctl != nullptr) w.counters = p.long_count;   // (the split sort's control words: already zero)
   // one run per thread, no grid-stride loop: the grid must cover every run (callers keep count below 2^31 -> at most 2^23 blocks)
   const int mblocks    = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, INT64_C(1) << 23));
   hipLaunchKernelGGL((tree_mark_kernel<IdxT>), dim3(std::max(mblocks, 1)), dim3(256), 0, lstream, p, w, p.long_threshold);
@@ -2120,6 +2150,14 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
       p.long_list      = reinterpret_cast<long_run_entry*>(static_cast<char*>(a->long_run_ws) + 64);   // (non-null marker; the tree kernels carve the workspace themselves)
     }
   }
+  // runs that a split sort of this thread has just written: its control words hold the long-run counters (already zero) and
+  // say whether a long run can exist at all (last_split_record)
+  if (g_last_split.run_starts == a->run_starts && g_last_split.ctl != nullptr && p.long_list != nullptr &&
+      WM_KNOB("WM_STEP_OWN_COUNTERS") == nullptr) {
+    p.split_ctl  = g_last_split.ctl;
+    p.long_count = reinterpret_cast<int32_t*>(g_last_split.ctl + split::kCtlLongCounters);
+  }
+  g_last_split = last_split_record{};
   // the long-run side goes to its own stream (WM_STEP_SERIAL=1: everything on the caller's stream, for measurements)
   hipStream_t lstream = stream;
   const char* serial_env = WM_KNOB("WM_STEP_SERIAL");
@@ -2128,7 +2166,9 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   const bool serial = serial_env != nullptr ? serial_env[0] != '0' : (p.long_list != nullptr && !long_lane::get().expect_long());
   if (p.long_list != nullptr && !serial && long_lane::get().fork(stream)) lstream = long_lane::get().stream;
   // (the counters are cleared on the side stream: only the long-run kernels read them)
-  if (p.long_list != nullptr && hipMemsetAsync(p.long_count, 0, p.fold_tree ? 64 : 16, lstream) != hipSuccess) return -2;
+  if (p.long_list != nullptr && p.split_ctl == nullptr &&
+      hipMemsetAsync(p.long_count, 0, p.fold_tree ? 64 : 16, lstream) != hipSuccess)
+    return -2;
   int64_t waves = a->count;
   int max_blocks = 256 * 8;
   if (const char* e = WM_KNOB("WM_STEP_BLOCKS")) max_blocks = std::max(1, atoi(e));
