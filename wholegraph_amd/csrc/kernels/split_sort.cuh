@@ -7,29 +7,29 @@
 // the payload is a position < 2^31 — instead of running a generic radix sort three times over the pairs:
 //
 //   stage 1 (three launches, no workgroup waits for another):
-//     split_hist_kernel     per tile of the ids: a histogram over BUCKETS = the top key bits (<= 2047 buckets of 2^shift rows
-//                           each, + one "drop" bucket for ids outside the owner's range), written as one row of a
+//     split_hist_kernel     per tile of the ids: a histogram over BUCKETS = the top key bits (<= 2048 buckets of 2^shift rows
+//                           each — 4096 for the biggest batches — + one "drop" bucket for ids outside the owner's range), written as one row of a
 //                           tiles x buckets matrix
 //     split_scan_kernel     column-wise exclusive prefix of the matrix (a tile's start inside each bucket), bucket totals,
 //                           the overflow verdict (a bucket that would not fit stage 2's LDS), and the zeroing of the control
 //                           words of what follows
-//     split_scatter_kernel  re-reads its tile, ranks every id among the ids of its bucket in the tile STABLY (the lanes of a
-//                           wave that hold the same bucket find each other with one ballot per bucket bit; per-wave counters
-//                           in LDS), brings the tile into bucket order in LDS and writes keys and positions bucket by bucket,
-//                           each bucket's share of the tile as one contiguous segment: a stable multisplit. (Written straight
-//                           from the registers, one 8-byte word per lane and bucket, the 10 M write requests alone cost
-//                           75 us: profiles/r05_split_sort_steps.txt.)
+//     split_scatter_kernel  re-reads its tile, gives every id a slot in its bucket's segment of the tile from one LDS counter
+//                           per bucket (arrival order: the segment is NOT in receive order, stage 2 orders equal ids by
+//                           their position), brings the tile into bucket order in LDS and writes keys and positions bucket
+//                           by bucket, each bucket's share of the tile as one contiguous segment. (Written straight from the
+//                           registers, one 8-byte word per lane and bucket, the 10 M write requests alone cost 75 us.)
 //   stage 2 (one launch):
-//     split_sort_kernel     one workgroup per bucket (handed out by an atomic ticket, so a workgroup only ever waits for
-//                           workgroups that already run) brings the bucket's (low key bits << 13 | index in the bucket) words
-//                           into order in LDS. A bucket spans <= 2^16 rows and holds a few thousand ids, so the usual case
+//     split_sort_kernel     one workgroup per bucket (bucket = workgroup index: a workgroup only ever waits for smaller
+//                           indices, which start first on every XCD) brings the bucket's words — low key bits << 13 |
+//                           index in the bucket — into order in LDS. A bucket spans <= 2^16 rows and holds a few thousand ids, so the usual case
 //                           needs no radix pass at all: a 65536-bit map of the rows present (8 KB of LDS) and its prefix
 //                           popcounts give every id the RANK OF ITS ROW among the bucket's rows — which is the run it belongs
 //                           to — an LDS counter per run gives it a slot in the run, an exclusive scan of the counters gives
-//                           the run starts, and runs of more than one id (5 % for 10 M ids on 100 M rows) are put into
-//                           receive order by the thread that owns the run. Buckets with a run of more than kMaxDup ids or
-//                           more than 16 low bits take 2-3 stable least-significant-digit passes of the ballot ranking
-//                           instead. Either way the runs are known THERE: order[], run_starts[], unique_ids[] are written
+//                           the run starts, and runs of more than one id (5 % for 10 M ids on 100 M rows) are sorted by
+//                           position by the thread that owns the run. Buckets with a run of more than kMaxDup ids or
+//                           more than 16 low bits take stable least-significant-digit passes of the ballot ranking
+//                           instead (position digits first, then the low key bits). Either way the runs are known THERE:
+//                           order[], run_starts[], unique_ids[] are written
 //                           by the same kernel; the global rank of a bucket's first run comes from a decoupled look-back
 //                           over the buckets' run counts (one status word per bucket, published as soon as the map is
 //                           counted); the last workgroup publishes the number of runs and the closing run_starts entry.
@@ -38,7 +38,8 @@
 // three read + write passes over (key, position) pairs plus histogram plus three run-detection passes before (~0.75 GB), and
 // 4 launches instead of 11 + 8 fills.
 //
-// When a bucket does not fit (more than kCap ids: a hot id of a Zipf batch, ids clustered in a few thousand rows), the scan
+// When a bucket does not fit (more than 4096 / 8192 ids, by the size of stage 2: a hot id of a Zipf batch, ids clustered in a few
+// thousand rows), the scan
 // kernel raises the overflow word, stages 1c / 2 return at once, and the caller's generic path — gated on the same word, see
 // optim.hip: run_dedup — sorts the batch instead. The decision is taken on the device: no host synchronisation, capturable.
 #pragma once
