@@ -124,3 +124,26 @@ def test_default_threshold_takes_the_split_sort_for_big_batches(gpu_env, knobs):
     want = np.zeros((rows_alloc, 8), np.float32)
     np.add.at(want, ids, grads)        # integer-valued: exact in any order
     assert nu == len(np.unique(ids)) and got.tobytes() == want.tobytes()
+
+
+def test_long_run_side_follows_the_batches(gpu_env, knobs):
+    """The long-run side of the step is queued on the caller's stream while the previous calls listed no long run, beside the tile
+    kernel once one did (a count that lags a call or two, optim.hip: long_lane::expect_long), and its listing kernel is gated
+    on what the split sort saw. Whatever the sequence of batches — no long run, a 30 k-row run, none again — every call's
+    result is the oracle's, bit for bit."""
+    knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+    rng = np.random.default_rng(99)
+    rows, n = 3_000_000, 120_000
+    for kind in ("uniform", "hot", "uniform", "uniform", "hot", "hot", "radix", "uniform"):
+        ids = rng.integers(0, rows, n).astype(np.int64)
+        if kind == "hot":
+            ids[rng.random(n) < 0.25] = 123_457            # one run of ~30 k rows: the bucket overflows, generic path, long-run fold
+        if kind == "radix":
+            hot = rng.integers(0, rows, 60)
+            sel = rng.random(n) < 0.3
+            ids[sel] = hot[rng.integers(0, 60, int(sel.sum()))]   # 60 runs of ~600 rows: radix path of their buckets, long-run fold
+        grads = rng.standard_normal((n, 8)).astype(np.float32)
+        want, nu_want = _expect(ids, grads, rows, 0)
+        got, nu = _apply(ids, grads, rows, 0, np.int64)
+        assert nu == nu_want, kind
+        assert got.tobytes() == want.tobytes(), kind

@@ -381,8 +381,13 @@ std::atomic<int64_t> g_split_sorts{0};
 // both were given: its long-run counters live there (zeroed by the sort's first kernel: no fill in front of the step), and
 // the listing kernels return at once when the sort saw neither an overflow nor a bucket with a run of more than kMaxDup ids —
 // then no run is longer than kMaxDup, far below any long-run threshold (fill 5.7 + listing 13 us per call otherwise).
+// The record is cleared by EVERY id sort of the thread (whatever path it takes) and consumed by the next step, and it has to
+// match the three arrays a sort hands to a step — run starts, unique ids, run count — so a step can only pick up the control
+// words of the sort that produced exactly its inputs, whose workspace its caller still holds.
 struct last_split_record {
   const int32_t* run_starts = nullptr;
+  const void* unique_ids    = nullptr;
+  const int64_t* n_unique   = nullptr;
   uint32_t* ctl             = nullptr;
 };
 thread_local last_split_record g_last_split;
@@ -502,6 +507,8 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
       if (forked && hipStreamWaitEvent(stream, sort_lane::get().joined, 0) != hipSuccess) return -2;
       g_split_sorts.fetch_add(1, std::memory_order_relaxed);
       g_last_split.run_starts = run_starts;
+      g_last_split.unique_ids = unique_ids;
+      g_last_split.n_unique   = n_unique_out;
       g_last_split.ctl        = reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl);
       return generic_rc;
     }
@@ -2044,6 +2051,7 @@ int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, i
                   void* stream_v)
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  g_last_split = last_split_record{};   // (set again below when this sort is a split sort)
   if (n >= (1ll << 31)) return -1;  // reference casts the receive count to int (exchange_embeddings_nccl_func.cu:118)
   if (n == 0) return hipMemsetAsync(n_unique_out, 0, sizeof(int64_t), stream) == hipSuccess ? 0 : -2;
   if (index_dtype == WHOLEMEMORY_DT_INT)
@@ -2152,7 +2160,8 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   }
   // runs that a split sort of this thread has just written: its control words hold the long-run counters (already zero) and
   // say whether a long run can exist at all (last_split_record)
-  if (g_last_split.run_starts == a->run_starts && g_last_split.ctl != nullptr && p.long_list != nullptr &&
+  if (g_last_split.run_starts == a->run_starts && g_last_split.unique_ids == a->ids && g_last_split.n_unique == n_unique_dev &&
+      n_unique_dev != nullptr && g_last_split.ctl != nullptr && p.long_list != nullptr &&
       WM_KNOB("WM_STEP_OWN_COUNTERS") == nullptr) {
     p.split_ctl  = g_last_split.ctl;
     p.long_count = reinterpret_cast<int32_t*>(g_last_split.ctl + split::kCtlLongCounters);
