@@ -119,6 +119,39 @@ static int run_case(const char* name, const std::vector<int64_t>& ids, int64_t l
 int main(int argc, char** argv)
 {
   const bool timing = argc > 1 && strcmp(argv[1], "time") == 0;
+  if (argc > 1 && strcmp(argv[1], "fuzz") == 0) {   // fuzz <cases> <seed>: random sizes, spans, offsets, id distributions
+    const int cases = argc > 2 ? atoi(argv[2]) : 200;
+    std::mt19937_64 r(argc > 3 ? atoll(argv[3]) : 7);
+    int failed = 0, overflowed = 0;
+    for (int c = 0; c < cases; c++) {
+      const int64_t span = 1 + static_cast<int64_t>(r() % (r() % 3 == 0 ? (1ull << 29) : (r() % 2 ? 200000000ull : 3000000ull)));
+      const int64_t n    = 1 + static_cast<int64_t>(r() % (r() % 4 == 0 ? 3000000ull : 200000ull));
+      const int64_t lower = (r() % 2) ? static_cast<int64_t>(r() % 1000000000ull) : 0;
+      const int kind = static_cast<int>(r() % 6);
+      std::vector<int64_t> v(n);
+      const uint64_t hot = r() % static_cast<uint64_t>(span);
+      const uint64_t width = 1 + r() % static_cast<uint64_t>(span);
+      for (int64_t i = 0; i < n; i++) {
+        uint64_t k;
+        switch (kind) {
+          case 0: k = r() % static_cast<uint64_t>(span); break;                                         // uniform
+          case 1: k = (r() % 100 < 30) ? hot : r() % static_cast<uint64_t>(span); break;                // one hot id
+          case 2: k = (hot + r() % std::min<uint64_t>(width, 5000)) % static_cast<uint64_t>(span); break;   // clustered
+          case 3: k = static_cast<uint64_t>(i) * 7 % static_cast<uint64_t>(span); break;                // ascending
+          case 4: k = (r() % std::max<uint64_t>(1, static_cast<uint64_t>(n) / 3)) * 977 % static_cast<uint64_t>(span); break;   // ~3 ids per row
+          default: k = (r() % 64) * (static_cast<uint64_t>(span) / 64 + 1) % static_cast<uint64_t>(span); break;   // 64 rows
+        }
+        v[i] = lower + static_cast<int64_t>(k);
+        if (r() % 50 == 0) v[i] = (r() & 1) ? -1 - static_cast<int64_t>(r() % 100) : lower + span + static_cast<int64_t>(r() % 100);
+      }
+      char nm[64];
+      snprintf(nm, sizeof(nm), "fuzz %d kind %d", c, kind);
+      failed += run_case(nm, v, lower, span, false);
+    }
+    printf(failed ? "FUZZ FAILED (%d)\n" : "FUZZ OK (%d failures)\n", failed);
+    (void)overflowed;
+    return failed != 0;
+  }
   if (argc > 2) {   // debug mode: only the big case, kernels with parts switched off (results are wrong on purpose)
     int dbg = atoi(argv[2]);
     std::mt19937_64 r2(42);
@@ -186,6 +219,10 @@ int main(int argc, char** argv)
   bad |= run_case("10M uniform / 100M rows", uniform(10000000, 0, 100000000, 0.0), 0, 100000000, timing);
   bad |= run_case("10M uniform / 125M rows (shard)", uniform(10000000, 375000000, 125000000, 0.0), 375000000, 125000000, timing);
   bad |= run_case("0.5M uniform / 100M rows", uniform(500000, 0, 100000000, 0.0), 0, 100000000, timing);
+  // shapes that stress one stage: ids in ascending order (a tile feeds one or two buckets: every id of a tile on the same LDS
+  // counter), and 10 M ids that are 4 M distinct rows (2.5 ids per run: most buckets take the radix passes)
+  { std::vector<int64_t> v(10000000); for (size_t i = 0; i < v.size(); i++) v[i] = static_cast<int64_t>(i) * 10; bad |= run_case("10M ascending / 100M rows", v, 0, 100000000, timing); }
+  { std::vector<int64_t> v(10000000); for (auto& x : v) x = static_cast<int64_t>(rng() % 4000000ull) * 25; bad |= run_case("10M ids on 4M distinct rows", v, 0, 100000000, timing); }
   printf(bad ? "FAILED\n" : "ALL OK\n");
   return bad;
 }
