@@ -20,6 +20,8 @@ timed region as in the reference bench. (`--table-candidates T --out-candidates 
 pairs probed, the fastest kept, every probe in the line as `placement.probe_ms`. Round 3 launches the row kernels in order —
 DESIGN.md section 3.1 — which removed the dependence on the buffers' physical placement, and the default is 1 x 1.)
 """
+import os as _os
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL, hipIpc across ranks): must be set before the HIP runtime loads
 import argparse
 import gc
 import json

@@ -15,6 +15,8 @@
 #   5 C5: --op sample_gather
 #   6 rocprofv3 kernel stats of the N-rank uniform run (rank 0)
 set -u
+# the host driver of these nodes supports dmabuf IPC only: without this RCCL and hipIpc fail with "hipIpcGetMemHandle: invalid argument"
+export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 N=${1:-$(python3 -c "import torch; print(torch.cuda.device_count())")}
