@@ -1,0 +1,15 @@
+#!/bin/bash
+# same box, same session: deferred join on/off x side-stream priority, uniform mini-batch / 10 M and Zipf (ordered, tree)
+cd $GRAFT_REPO_ROOT
+line() { python3 -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.4f' % r['ms_per_step'], end=' ')"; }
+for rep in 1 2; do
+for d in 1 0; do for p in low normal; do
+  echo -n "defer=$d prio=$p: u0.5M "
+  WM_DEDUP_DEFER_JOIN=$d WM_DEDUP_LANE_PRIO=$p python bench.py --op grad_apply --indices 500000 --no-cpu-baseline --stability-steps 0 --steps 50 2>/dev/null | line
+  echo -n " u10M "
+  WM_DEDUP_DEFER_JOIN=$d WM_DEDUP_LANE_PRIO=$p python bench.py --op grad_apply --no-cpu-baseline --stability-steps 0 --steps 30 2>/dev/null | line
+  for f in ordered tree; do echo -n " zipf-$f "
+    WM_GRAD_FOLD=$f WM_DEDUP_DEFER_JOIN=$d WM_DEDUP_LANE_PRIO=$p python bench.py --op grad_apply --dist zipf --no-cpu-baseline --stability-steps 0 --steps 30 2>/dev/null | line
+  done; echo
+done; done
+done

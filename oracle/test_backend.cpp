@@ -370,6 +370,7 @@ const wm_device_backend kTestBackend = {
   // device cache, placement probe, id sort, memory info, append_unique extras, 0xFF fill: not provided
   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
   t_permute,
+  nullptr, nullptr,   // no side stream of its own: nothing to join later
 };
 
 }  // namespace

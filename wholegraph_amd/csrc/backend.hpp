@@ -335,6 +335,13 @@ struct wm_device_backend {
   // as kernel arguments). nullptr in a backend that does not provide it: callers launch per segment.
   int (*permute_chunks)(const void* src, void* dst, int elt_bytes, const int64_t* seg_offsets, const int64_t* seg_counts,
                         int n_segs, int n_chunks, void* stream);
+  // dedup_ids may leave work on a side stream of its own (a generic sort it usually does not need, kernels/optim.hip). By
+  // default it joins that stream before it returns; a caller that has more work of its own to queue behind the sort — the
+  // optimizer step — may ask (dedup_defer_join(1), calling thread only) for the join to be left to dedup_join(stream), which it
+  // then MUST call on the same stream before it frees the sort's workspace or returns to its caller. The outputs of dedup_ids
+  // are valid for work queued on `stream` either way. Both nullptr in a backend without such a side stream.
+  void (*dedup_defer_join)(int on);
+  int (*dedup_join)(void* stream);
 };
 
 }  // extern "C"

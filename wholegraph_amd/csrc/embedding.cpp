@@ -223,10 +223,34 @@ struct self_rows_ref {
 // sorted view of a batch of received ids (unique ids, run starts, sorted order): the scratch lives as long as the object
 struct dedup_result {
   explicit dedup_result(wholememory_env_func_t* env) : unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env) {}
+  // join_later: the caller queues the optimizer step behind the sort and calls join() after it (the sort's side stream is
+  // then joined behind the step instead of in front of it: backend.hpp, dedup_defer_join); the destructor joins in any case
+  ~dedup_result() { join(); }
+  void join()
+  {
+    if (join_owed) {
+      const auto* bk = backend();
+      if (bk->dedup_join != nullptr) (void)bk->dedup_join(deferred_on);
+      join_owed = false;
+    }
+  }
   void run(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, void* stream,
-           int64_t key_lower_bound = 0)
+           int64_t key_lower_bound = 0, bool join_later = false)
   {
     const auto* bk = backend();
+    struct defer_scope {
+      const wm_device_backend* bk;
+      bool on;
+      defer_scope(const wm_device_backend* b, bool o) : bk(b), on(o && b->dedup_defer_join != nullptr && b->dedup_join != nullptr)
+      {
+        if (on) bk->dedup_defer_join(1);
+      }
+      ~defer_scope()
+      {
+        if (on) bk->dedup_defer_join(0);
+      }
+    } scope(bk, join_later);
+    if (scope.on) deferred_on = stream, join_owed = true;
     d_unique  = unique_ids.device(n, index_dtype);
     d_starts  = static_cast<int32_t*>(run_starts.device(n + 1, WHOLEMEMORY_DT_INT));
     d_order   = static_cast<int32_t*>(order.device(n, WHOLEMEMORY_DT_INT));
@@ -237,6 +261,8 @@ struct dedup_result {
     if (rc != 0) throw hip_error("dedup_ids failed");
   }
   temp_mem unique_ids, run_starts, order, n_unique, ws;
+  void* deferred_on  = nullptr;   // stream a deferred join is owed on (the null stream is a stream like any other)
+  bool join_owed     = false;
   void* d_unique     = nullptr;
   int32_t* d_starts  = nullptr;
   int32_t* d_order   = nullptr;
@@ -265,6 +291,7 @@ void step_sorted(dedup_result& r, wholememory_dtype_t index_dtype, int64_t n_rec
   oa->long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n_recv, oa->dim)), WHOLEMEMORY_DT_INT8);
   if (rows_ready != nullptr) WM_BK(bk->stream_wait_event(stream, rows_ready));
   int rc = bk->optimizer_step(oa, r.d_nunique, stream);
+  r.join();   // the sort's side stream, if it left one running: joined behind the step
   if (rc != 0) throw hip_error("optimizer_step failed");
   if (n_unique_host != nullptr) {
     auto* h = static_cast<int64_t*>(host_n.pinned(1, WHOLEMEMORY_DT_INT64));
@@ -286,7 +313,7 @@ void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64
     return;
   }
   dedup_result r(env);
-  r.run(recv_ids, index_dtype, n_recv, key_upper_bound, stream, key_lower_bound);
+  r.run(recv_ids, index_dtype, n_recv, key_upper_bound, stream, key_lower_bound, /*join_later=*/true);
   step_sorted(r, index_dtype, n_recv, recv_grads, grad_stride, oa, env, stream, n_unique_host, rows_ready, self);
 }
 
@@ -342,7 +369,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
       entry_offsets[1] - entry_offsets[0] < UINT64_C(0xFFFFFFFF)) {
     early.reset(new dedup_result(env));
     early->run(idx_ptr, iarr.dtype, iarr.size, static_cast<int64_t>(entry_offsets[1]), stream,
-               static_cast<int64_t>(entry_offsets[0]));
+               static_cast<int64_t>(entry_offsets[0]), /*join_later=*/true);
   }
   id_exchange x(env);
   if (early) {

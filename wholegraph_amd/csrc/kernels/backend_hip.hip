@@ -11,6 +11,8 @@ int hip_gather_rows(const wm_rows_args* a, void* stream);
 int hip_scatter_rows(const wm_rows_args* a, void* stream);
 size_t hip_bucket_workspace_bytes(int64_t n, int world_size);
 int hip_bucket_ids(const wm_bucket_args* a, void* stream);
+void hip_dedup_defer_join(int on);
+int hip_dedup_join(void* stream);
 int hip_permute_chunks(const void* src, void* dst, int elt_bytes, const int64_t* seg_offsets, const int64_t* seg_counts, int n_segs,
                        int n_chunks, void* stream);
 size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype);
@@ -226,6 +228,8 @@ const wm_device_backend kHipBackend = {
   hip_append_unique_table_region,
   hip_fill_ff,
   hip_permute_chunks,
+  hip_dedup_defer_join,
+  hip_dedup_join,
 };
 
 }  // namespace

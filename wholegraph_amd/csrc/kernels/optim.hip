@@ -362,11 +362,16 @@ struct sort_lane {
   bool ok = false;
   sort_lane()
   {
-    int least = 0, greatest = 0;   // lowest priority: its kernels are the ones that usually have nothing to do
+    // a plain stream by default; WM_DEDUP_LANE_PRIO=l|h asks for the lowest / highest priority instead. Measured same box,
+    // same session (profiles/r05_defer_join_ab.txt): lowest priority changes nothing for uniform ids and costs the Zipf
+    // ordered fold 0.03-0.06 ms (the generic sort that really runs there gets behind the join kernel's wave)
+    int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     const char* pe = WM_KNOB("WM_DEDUP_LANE_PRIO");
-    ok = (pe != nullptr && pe[0] == 'n' ? hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)
-                                        : hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least)) == hipSuccess &&
+    const bool with_prio = pe != nullptr && (pe[0] == 'h' || pe[0] == 'l');
+    const int prio       = pe != nullptr && pe[0] == 'h' ? greatest : least;
+    ok = (!with_prio ? hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)
+                     : hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio)) == hipSuccess &&
          hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess;
   }
@@ -391,6 +396,14 @@ struct last_split_record {
   uint32_t* ctl             = nullptr;
 };
 thread_local last_split_record g_last_split;
+// Deferred join (backend: dedup_defer_join / dedup_join). The generic path's launches on the side stream take ~35 us even when
+// they have nothing to do, longer than the split sort of a mini-batch (profiles/r05_grad_timeline_small_batch.txt). A caller
+// that goes on to the optimizer step asks for the join to be split in two: a one-wave kernel on its stream that waits ON THE
+// DEVICE, and only when the batch overflowed; and the event wait, enqueued after the step (dedup_join) — by then the idle
+// launches have long drained under the tile kernel. The event wait still comes before anything else the caller queues, so
+// the sort's workspace is not handed back while a side-stream kernel may still look at it.
+thread_local bool g_defer_join     = false;
+thread_local bool g_join_pending   = false;
 struct split_layout {
   void* split_ws;        // split::plan offsets apply; its first two arrays double as the generic sort's second (key, position) pair
   uint32_t* sorted;      // generic path: sorted keys
@@ -409,8 +422,8 @@ inline split_layout split_carve(void* ws, int64_t n)
   l.sorted         = reinterpret_cast<uint32_t*>(p + o), o += align(4 * static_cast<size_t>(n));
   l.tile_counts    = reinterpret_cast<int32_t*>(p + o), o += align(4 * static_cast<size_t>((n + kBlock * 8 - 1) / (kBlock * 8) + 1));
   l.osw_ctrl_words = osw::ctrl_words_bound<kOswBlock, kOswIpt>(n);
-  l.osw_ctrl       = reinterpret_cast<uint32_t*>(p + o), o += align(4 * l.osw_ctrl_words);
-  l.total          = o + 256;
+  l.osw_ctrl        = reinterpret_cast<uint32_t*>(p + o), o += align(4 * l.osw_ctrl_words);
+  l.total           = o + 256;
   return l;
 }
 
@@ -440,22 +453,32 @@ dedup_layout<SortKeyT> layout(void* ws, int64_t n)
   return l;
 }
 
+__global__ void set_word_kernel(uint32_t* word, uint32_t value)
+{
+  __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename SortKeyT, typename OutT>
 int detect_runs(const SortKeyT* sorted, int32_t* tile_counts, int64_t n, OutT* unique_ids, int32_t* run_starts,
                 int64_t* n_unique_out, hipStream_t stream, OutT key_base = 0, bool drop_last = false, SortKeyT drop_key = 0,
-                const uint32_t* gate = nullptr)
+                const uint32_t* gate = nullptr, uint32_t* done_word = nullptr)
 {
   const int tiles = run_tiles(n);
   const uint32_t* last_key = nullptr;
   if constexpr (sizeof(SortKeyT) == 4) {
     if (drop_last) last_key = reinterpret_cast<const uint32_t*>(sorted + (n - 1));
   }
-  const int run_grid = std::min(tiles, 1024);
+  // (one block per tile: looping 1024 blocks over the tiles made an ACTIVE run_compact_kernel 77 us instead of 18)
+  const int run_grid = tiles;
   hipLaunchKernelGGL((run_count_kernel<SortKeyT>), dim3(run_grid), dim3(kBlock), 0, stream, sorted, n, tile_counts, gate);
   hipLaunchKernelGGL(run_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, tiles, n_unique_out, last_key,
                      static_cast<uint32_t>(drop_key), gate);
   hipLaunchKernelGGL((run_compact_kernel<SortKeyT, OutT>), dim3(run_grid), dim3(kBlock), 0, stream, sorted, n, tile_counts,
                      n_unique_out, unique_ids, run_starts, key_base, last_key != nullptr, drop_key, gate);
+  // the generic path behind a split sort, joined on the device: one more (tiny) kernel says so when everything above has
+  // finished — the end of a kernel makes its writes visible; a fence + counter per block of the kernel above made that kernel
+  // 302 us instead of 18
+  if (done_word != nullptr) hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, stream, done_word, 1u);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -474,6 +497,7 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
       const split_layout sl = split_carve(workspace, n);
       const unsigned bits   = significant_bits(span + 1, 32);
       const size_t ctrl     = osw::ctrl_words<kOswBlock, kOswIpt>(n, bits);
+      const int64_t zero_n  = static_cast<int64_t>(ctrl);
       // the generic path, gated on the overflow word, between the split sort's second and third kernel — on the side stream
       // (WM_DEDUP_SERIAL=1: on the caller's stream, for measurements)
       const uint32_t* gate = split::overflow_word(sp, sl.split_ws);
@@ -490,7 +514,9 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
         if (generic_rc == 0)
           generic_rc = detect_runs<uint32_t, UKey>(sl.sorted, sl.tile_counts, n, static_cast<UKey*>(unique_ids), run_starts,
                                                    n_unique_out, gs, static_cast<UKey>(key_lower_bound), true,
-                                                   static_cast<uint32_t>(span), gate);
+                                                   static_cast<uint32_t>(span), gate,
+                                                   reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl) +
+                                                     split::kCtlGenericDone);
       };
       bool forked = false;
       auto between = [&]() {
@@ -501,10 +527,16 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
         if (forked) forked = hipEventRecord(lane.joined, lane.stream) == hipSuccess;
       };
       if (split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound), static_cast<uint32_t>(span),
-                              unique_ids, run_starts, order, n_unique_out, sl.split_ws, sl.osw_ctrl, static_cast<int64_t>(ctrl),
+                              unique_ids, run_starts, order, n_unique_out, sl.split_ws, sl.osw_ctrl, zero_n,
                               stream, between, WM_KNOB("WM_DEDUP_FORK") != nullptr && WM_KNOB("WM_DEDUP_FORK")[0] == '3') != 0)
         return -2;
-      if (forked && hipStreamWaitEvent(stream, sort_lane::get().joined, 0) != hipSuccess) return -2;
+      if (forked && g_defer_join) {
+        hipLaunchKernelGGL(split::split_join_kernel, dim3(1), dim3(64), 0, stream,
+                           reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl), 1u);   // (set by detect_runs' closing kernel)
+        g_join_pending = true;
+      } else if (forked && hipStreamWaitEvent(stream, sort_lane::get().joined, 0) != hipSuccess) {
+        return -2;
+      }
       g_split_sorts.fetch_add(1, std::memory_order_relaxed);
       g_last_split.run_starts = run_starts;
       g_last_split.unique_ids = unique_ids;
@@ -2035,6 +2067,18 @@ __global__ void fill_float_kernel(float* p, float v, int64_t n)
 extern "C" int64_t wholememory_ext_split_sorts(void) { return wm::g_split_sorts.load(std::memory_order_relaxed); }
 namespace wm {
 
+void hip_dedup_defer_join(int on)
+{
+  const char* e = WM_KNOB("WM_DEDUP_DEFER_JOIN");   // =0: the side stream is joined in front of the step again (A/B switch)
+  g_defer_join  = on != 0 && !(e != nullptr && e[0] == '0');
+}
+int hip_dedup_join(void* stream_v)
+{
+  if (!g_join_pending) return 0;
+  g_join_pending = false;
+  return hipStreamWaitEvent(static_cast<hipStream_t>(stream_v), sort_lane::get().joined, 0) == hipSuccess ? 0 : -2;
+}
+
 size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype)
 {
   if (n <= 0) return 256;
@@ -2052,6 +2096,7 @@ int hip_dedup_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, i
 {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   g_last_split = last_split_record{};   // (set again below when this sort is a split sort)
+  if (hip_dedup_join(stream_v) != 0) return -2;   // (a deferred join nobody collected: before this sort touches anything)
   if (n >= (1ll << 31)) return -1;  // reference casts the receive count to int (exchange_embeddings_nccl_func.cu:118)
   if (n == 0) return hipMemsetAsync(n_unique_out, 0, sizeof(int64_t), stream) == hipSuccess ? 0 : -2;
   if (index_dtype == WHOLEMEMORY_DT_INT)

@@ -78,7 +78,8 @@ constexpr uint32_t kFlagAggregate = 1u << 30, kFlagPrefix = 2u << 30, kValueMask
 // control words (u32), zeroed by split_hist_kernel's first workgroup
 // [kCtlLongCounters, +16): the counters of the optimizer step's long-run side (optim.hip), zeroed here with the rest so that
 // the step needs no fill of its own when it follows a split sort
-enum { kCtlOverflow = 0, kCtlTicket = 1, kCtlError = 2, kCtlRadixBuckets = 3, kCtlLongCounters = 16, kCtlWords = 32 };
+// kCtlGenericDone: blocks of the generic path's LAST kernel that have finished (counted behind a device-wide fence)
+enum { kCtlOverflow = 0, kCtlTicket = 1, kCtlError = 2, kCtlRadixBuckets = 3, kCtlGenericDone = 4, kCtlLongCounters = 16, kCtlWords = 32 };
 
 struct plan {
   bool ok;            // false: the batch does not suit the split sort (too many ids per bucket, too many key bits)
@@ -848,6 +849,25 @@ int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint
                        keys, pos, starts, p.buckets, p.shift, p.passes, p.digit_bits, p.pos_passes, p.pos_digit_bits, key_lower_bound,
                        static_cast<UKey*>(unique_ids), run_starts, order, n_unique, ctl, state);
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// The caller's stream after the split sort, when the generic path runs on a side stream and is NOT joined by an event before
+// the step (optim.hip: deferred join): one wave that returns at once in the usual case and, when the batch overflowed, waits
+// until every block of the generic path's last kernel has counted itself in.
+__global__ void split_join_kernel(uint32_t* ctl, uint32_t expected_blocks)
+{
+  if (ctl[kCtlOverflow] == 0) return;
+  // (RELAXED polls, far apart: an acquire at agent scope invalidates cache lines on every poll, and the kernels this wave is
+  // waiting for ran 30 % slower beside it; one acquire fence at the end is all the ordering needed)
+  unsigned spins = 0;
+  while (__hip_atomic_load(&ctl[kCtlGenericDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected_blocks) {
+    __builtin_amdgcn_s_sleep(127);   // ~8 k cycles = 3.4 us between polls
+    if (++spins > (1u << 26)) {   // never in a healthy run (the generic path takes well under a second): report, do not hang
+      if (threadIdx.x == 0) ctl[kCtlError] = 2u;
+      break;
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 
 inline const uint32_t* overflow_word(const plan& p, void* workspace)
