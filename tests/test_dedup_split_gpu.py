@@ -147,3 +147,55 @@ def test_long_run_side_follows_the_batches(gpu_env, knobs):
         got, nu = _apply(ids, grads, rows, 0, np.int64)
         assert nu == nu_want, kind
         assert got.tobytes() == want.tobytes(), kind
+
+
+@pytest.mark.parametrize("kind", ["uniform", "hot_id"])
+def test_gradient_apply_replays_from_a_hipgraph(gpu_env, knobs, kind):
+    """One rank's gradient apply has no host synchronisation, so it can be captured. While a stream is being captured the
+    split sort forks and joins its side stream with EVENTS only (optim.hip: a wave that waits for a word needs the other branch
+    to be running, and the branches of a graph may be replayed one after the other): the replay must give the eager call's
+    bits on the map path and on the generic path (a hot id that overflows its bucket)."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+    rows, dim, n = 300_000, 32, 120_000
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, rows, n)
+    if kind == "hot_id":
+        ids = np.where(rng.random(n) < 0.3, 4242, ids)
+    idx = torch.from_numpy(ids.astype(np.int64)).cuda()
+    grads = torch.from_numpy(rng.standard_normal((n, dim)).astype(np.float32)).cuda()
+
+    def table():
+        emb = wgth.create_embedding(gpu_env, "chunked", "cuda", torch.float32, [rows, dim])
+        wgth.create_wholememory_optimizer(emb, "sgd", {})
+        local, _ = emb.get_embedding_tensor().get_local_tensor()
+        local.zero_()
+        return emb, local
+
+    def step(emb):
+        emb.add_gradients(idx, grads)
+        emb.need_apply = True
+        emb.apply_gradients(0.5)
+
+    eager, eager_rows = table()
+    step(eager)
+    step(eager)
+    torch.cuda.synchronize()
+    captured, captured_rows = table()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):       # (warm-up outside the capture: lanes, attributes, allocator pools)
+        step(captured)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    captured_rows.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step(captured)
+    torch.cuda.synchronize()
+    captured_rows.zero_()
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert captured_rows.cpu().numpy().tobytes() == eager_rows.cpu().numpy().tobytes()

@@ -357,23 +357,39 @@ inline int64_t split_min()
 // under its two long kernels; when the batch overflowed, those two return at once and the caller's stream waits for the side.
 struct sort_lane {
   std::mutex mu;   // one fork .. join sequence at a time: the events are shared
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream_high = nullptr;
   hipEvent_t forked = nullptr, joined = nullptr;
   bool ok = false;
+  hipStream_t side() const
+  {
+    const char* pe = WM_KNOB("WM_DEDUP_LANE_PRIO");
+    return pe != nullptr && pe[0] == 'h' ? stream_high : stream;
+  }
+  // Fork without an event on the caller's stream: the split sort's scan kernel publishes "verdict final" = the sort's sequence
+  // number in one word of this ring (zero at the start, values only grow, a word comes round again after kRing sorts), and the
+  // side stream's first kernel waits for it (split_wait_kernel). An event recorded between the scan and the scatter kernel
+  // delayed the scatter kernel by ~7 us on every call (profiles/r05_grad_timeline_split_sort.txt: "gap 7.1").
+  static constexpr uint32_t kRing = 4096;
+  uint32_t* ring = nullptr;
+  uint32_t seq   = 0;
   sort_lane()
   {
-    // a plain stream by default; WM_DEDUP_LANE_PRIO=l|h asks for the lowest / highest priority instead. Measured same box,
-    // same session (profiles/r05_defer_join_ab.txt): lowest priority changes nothing for uniform ids and costs the Zipf
-    // ordered fold 0.03-0.06 ms (the generic sort that really runs there gets behind the join kernel's wave)
+    // two streams, plain and highest priority; WM_DEDUP_LANE_PRIO=n|h picks one per call (see side())
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    const char* pe = WM_KNOB("WM_DEDUP_LANE_PRIO");
-    const bool with_prio = pe != nullptr && (pe[0] == 'h' || pe[0] == 'l');
-    const int prio       = pe != nullptr && pe[0] == 'h' ? greatest : least;
-    ok = (!with_prio ? hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)
-                     : hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio)) == hipSuccess &&
+    ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithPriority(&stream_high, hipStreamNonBlocking, greatest) == hipSuccess &&
          hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess;
+    if (ok) {
+      void* r = nullptr;
+      if (hipMalloc(&r, kRing * sizeof(uint32_t)) == hipSuccess) {
+        if (hipMemsetAsync(r, 0, kRing * sizeof(uint32_t), stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess)
+          ring = static_cast<uint32_t*>(r);
+        else
+          (void)hipFree(r);
+      }
+    }
   }
   static sort_lane& get()
   {
@@ -519,18 +535,37 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
                                                      split::kCtlGenericDone);
       };
       bool forked = false;
+      uint32_t* verdict_word = nullptr;
+      uint32_t verdict_value = 0;
+      // (a stream that is being captured gets events only: a wave that waits for a word needs the other side to be RUNNING,
+      // and the branches of a graph may be replayed one after the other)
+      hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+      const bool capturing = hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone;
+      const bool by_event = WM_KNOB("WM_DEDUP_FORK_EVENT") != nullptr && WM_KNOB("WM_DEDUP_FORK_EVENT")[0] == '1';   // (A/B switch)
+      if (!serial && !capturing && !by_event && sort_lane::get().ok && sort_lane::get().ring != nullptr) {
+        sort_lane& lane = sort_lane::get();
+        verdict_value   = ++lane.seq;
+        verdict_word    = lane.ring + (verdict_value % sort_lane::kRing);
+      }
       auto between = [&]() {
         sort_lane& lane = sort_lane::get();
-        forked = !serial && lane.ok && hipEventRecord(lane.forked, stream) == hipSuccess &&
-                 hipStreamWaitEvent(lane.stream, lane.forked, 0) == hipSuccess;
-        generic(forked ? lane.stream : stream);
-        if (forked) forked = hipEventRecord(lane.joined, lane.stream) == hipSuccess;
+        if (verdict_word != nullptr) {
+          hipLaunchKernelGGL(split::split_wait_kernel, dim3(1), dim3(64), 0, lane.side(), verdict_word, verdict_value,
+                             reinterpret_cast<uint32_t*>(sw + sp.off_ctl) + split::kCtlError);
+          forked = hipGetLastError() == hipSuccess;
+        } else {
+          forked = !serial && lane.ok && hipEventRecord(lane.forked, stream) == hipSuccess &&
+                   hipStreamWaitEvent(lane.side(), lane.forked, 0) == hipSuccess;
+        }
+        generic(forked ? lane.side() : stream);
+        if (forked) forked = hipEventRecord(lane.joined, lane.side()) == hipSuccess;
       };
       if (split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound), static_cast<uint32_t>(span),
                               unique_ids, run_starts, order, n_unique_out, sl.split_ws, sl.osw_ctrl, zero_n,
-                              stream, between, WM_KNOB("WM_DEDUP_FORK") != nullptr && WM_KNOB("WM_DEDUP_FORK")[0] == '3') != 0)
+                              stream, between, WM_KNOB("WM_DEDUP_FORK") != nullptr && WM_KNOB("WM_DEDUP_FORK")[0] == '3', verdict_word,
+                              verdict_value) != 0)
         return -2;
-      if (forked && g_defer_join) {
+      if (forked && g_defer_join && !capturing) {
         hipLaunchKernelGGL(split::split_join_kernel, dim3(1), dim3(64), 0, stream,
                            reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl), 1u);   // (set by detect_runs' closing kernel)
         g_join_pending = true;
@@ -607,6 +642,7 @@ struct opt_params {
   // runs of more rows than this are not folded by step_tile_kernel / step_short_kernel but listed for the long-run side
   // (kLongRun with the ordered fold, tree_threshold() with the tree fold)
   int long_threshold;
+  int detached_side;   // 1: the long-run side runs on a side stream the caller's stream does NOT wait for (hip_optimizer_step_dev)
   int fold_tree;   // 1: the long-run side is the tree fold (tree_fold_kernel), 0: the ordered fold (step_long4_kernel)
 };
 
@@ -1558,7 +1594,7 @@ void launch_mark_long_runs(const opt_params& p, hipStream_t stream, hipStream_t 
   // (one run per thread and 37 k workgroups for 9.5 M runs took 15 us — the time to hand out 148 k one-load waves)
   const int blocks = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, 4096));
   hipLaunchKernelGGL((mark_long_runs_kernel<IdxT>), dim3(std::max(blocks, 1)), dim3(256), 0, lstream, p);
-  if (lstream != stream) {
+  if (lstream != stream && !p.detached_side) {
     (void)hipEventRecord(long_lane::get().marked, lstream);
     (void)hipStreamWaitEvent(stream, long_lane::get().marked, 0);
   }
@@ -1841,7 +1877,7 @@ void launch_tree(const opt_params& p, hipStream_t stream, hipStream_t lstream)
   // one run per thread, no grid-stride loop: the grid must cover every run (callers keep count below 2^31 -> at most 2^23 blocks)
   const int mblocks    = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, INT64_C(1) << 23));
   hipLaunchKernelGGL((tree_mark_kernel<IdxT>), dim3(std::max(mblocks, 1)), dim3(256), 0, lstream, p, w, p.long_threshold);
-  if (lstream != stream) {
+  if (lstream != stream && !p.detached_side) {
     (void)hipEventRecord(long_lane::get().marked, lstream);
     (void)hipStreamWaitEvent(stream, long_lane::get().marked, 0);
   }
@@ -2217,7 +2253,23 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   const char* serial_env = WM_KNOB("WM_STEP_SERIAL");
   std::unique_lock<std::mutex> lane_lock;
   if (p.long_list != nullptr) lane_lock = std::unique_lock<std::mutex>(long_lane::get().mu);
-  const bool serial = serial_env != nullptr ? serial_env[0] != '0' : (p.long_list != nullptr && !long_lane::get().expect_long());
+  const bool by_guess = serial_env == nullptr && p.long_list != nullptr && !long_lane::get().expect_long();
+  const bool serial   = serial_env != nullptr ? serial_env[0] != '0' : by_guess;
+  // No long run expected AND the runs come from a split sort whose side stream the caller joins behind this step (deferred
+  // join): listing + long-run kernels + the count's copy — three launches that find nothing to do, 17 us in line — go to that
+  // side stream behind a wave that waits for the sort's "runs are final" word; the caller's stream gets the tile kernel and
+  // nothing else. A wrong guess costs time once, as before: the fold then starts beside a tile kernel that already fills the chip.
+  std::unique_lock<std::mutex> sort_lock;
+  bool detached = false;
+  if (by_guess && p.split_ctl != nullptr && g_join_pending && sort_lane::get().ok &&
+      !(WM_KNOB("WM_STEP_DETACH") != nullptr && WM_KNOB("WM_STEP_DETACH")[0] == '0')) {
+    sort_lock = std::unique_lock<std::mutex>(sort_lane::get().mu);
+    lstream   = sort_lane::get().side();
+    detached  = true;
+    p.detached_side = 1;
+    hipLaunchKernelGGL(split::split_wait_kernel, dim3(1), dim3(64), 0, lstream, p.split_ctl + split::kCtlSortDone, 1u,
+                       const_cast<uint32_t*>(p.split_ctl) + split::kCtlError);
+  }
   if (p.long_list != nullptr && !serial && long_lane::get().fork(stream)) lstream = long_lane::get().stream;
   // (the counters are cleared on the side stream: only the long-run kernels read them)
   if (p.long_list != nullptr && p.split_ctl == nullptr &&
@@ -2232,7 +2284,11 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   if (a->index_dtype == WHOLEMEMORY_DT_INT) rc = launch_step<int32_t>(p, blocks, stream, lstream);
   if (a->index_dtype == WHOLEMEMORY_DT_INT64) rc = launch_step<int64_t>(p, blocks, stream, lstream);
   if (p.long_list != nullptr) long_lane::get().report(p.long_count, lstream);
-  if (lstream != stream && !long_lane::get().join(stream)) return -2;  // the caller's stream continues after both sides
+  if (detached) {   // (the caller's deferred join now waits for the long-run side as well)
+    if (hipEventRecord(sort_lane::get().joined, lstream) != hipSuccess) return -2;
+  } else if (lstream != stream && !long_lane::get().join(stream)) {
+    return -2;  // the caller's stream continues after both sides
+  }
   return rc;
 }
 

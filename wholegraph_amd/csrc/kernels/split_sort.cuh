@@ -78,8 +78,11 @@ constexpr uint32_t kFlagAggregate = 1u << 30, kFlagPrefix = 2u << 30, kValueMask
 // control words (u32), zeroed by split_hist_kernel's first workgroup
 // [kCtlLongCounters, +16): the counters of the optimizer step's long-run side (optim.hip), zeroed here with the rest so that
 // the step needs no fill of its own when it follows a split sort
-// kCtlGenericDone: blocks of the generic path's LAST kernel that have finished (counted behind a device-wide fence)
-enum { kCtlOverflow = 0, kCtlTicket = 1, kCtlError = 2, kCtlRadixBuckets = 3, kCtlGenericDone = 4, kCtlLongCounters = 16, kCtlWords = 32 };
+// kCtlGenericDone: set by the generic path's closing kernel (optim.hip: detect_runs)
+// kCtlScanCount: workgroups of split_scan_kernel that have finished (the last one publishes the caller's verdict word)
+// kCtlSortDone: set by split_join_kernel — the runs are final (whichever path wrote them); side-stream work that needs them
+// waits for this word instead of an event on the caller's stream (optim.hip: the detached long-run side)
+enum { kCtlOverflow = 0, kCtlTicket = 1, kCtlError = 2, kCtlRadixBuckets = 3, kCtlGenericDone = 4, kCtlSortDone = 5, kCtlScanCount = 6, kCtlLongCounters = 16, kCtlWords = 32 };
 
 struct plan {
   bool ok;            // false: the batch does not suit the split sort (too many ids per bucket, too many key bits)
@@ -265,7 +268,8 @@ __global__ __launch_bounds__(kBlock) void split_hist_kernel(key_source<UKey> src
 // ---- stage 1b: column-wise exclusive prefix of the counts matrix --------------------------------------------------------
 // one workgroup = 32 columns x all tiles: thread (row group rg, column c) owns rows_per consecutive tiles of its column
 __global__ __launch_bounds__(kBlock) void split_scan_kernel(uint32_t* counts, int tiles, int pitch, int buckets, uint32_t* totals,
-                                                            uint32_t* ctl, int cap, uint32_t* state, int state_words)
+                                                            uint32_t* ctl, int cap, uint32_t* state, int state_words,
+                                                            uint32_t* verdict_word, uint32_t verdict_value)
 {
   __shared__ uint32_t s_g[32][33];
   const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
@@ -304,6 +308,17 @@ __global__ __launch_bounds__(kBlock) void split_scan_kernel(uint32_t* counts, in
     if (col < buckets && total > static_cast<uint32_t>(cap)) atomicOr(&ctl[kCtlOverflow], 1u);
   }
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < state_words; i += gridDim.x * kBlock) state[i] = 0;
+  // "the overflow word is final": the last workgroup to get here says so in a word of the caller's (a side stream's first
+  // kernel waits for it — split_wait_kernel — instead of an event recorded behind this kernel, which held up the NEXT kernel
+  // of this stream by ~7 us)
+  if (verdict_word != nullptr) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(&ctl[kCtlScanCount], 1u) == gridDim.x - 1)
+        __hip_atomic_store(verdict_word, verdict_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---- stage 1c: stable multisplit --------------------------------------------------------------------------------------
@@ -806,7 +821,7 @@ struct no_hook {
 template <typename UKey, typename Hook = no_hook>
 int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint32_t span, void* unique_ids, int32_t* run_starts,
            int32_t* order, int64_t* n_unique, void* workspace, uint32_t* zero_words, int64_t n_zero_words, hipStream_t stream,
-           Hook between = Hook(), bool hook_after_scatter = false)
+           Hook between = Hook(), bool hook_after_scatter = false, uint32_t* verdict_word = nullptr, uint32_t verdict_value = 0)
 {
   char* ws         = static_cast<char*>(workspace);
   uint32_t* keys   = reinterpret_cast<uint32_t*>(ws + p.off_keys);
@@ -829,7 +844,7 @@ int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint
   hipLaunchKernelGGL((split_hist_kernel<UKey>), dim3(grid), dim3(kBlock), 0, stream, src, n, p.tile, p.tiles, p.shift, p.buckets,
                      p.pitch, counts, ctl, zero_words, n_zero_words);
   hipLaunchKernelGGL(split_scan_kernel, dim3(p.pitch / 32), dim3(kBlock), 0, stream, counts, p.tiles, p.pitch, p.buckets, totals, ctl,
-                     1 << p.cap_bits, state, p.pitch + 2);
+                     1 << p.cap_bits, state, p.pitch + 2, verdict_word, verdict_value);
   if (!hook_after_scatter) between();
   const size_t lds = scatter_lds_bytes(p.pitch, p.ipt);
 #define WM_SPLIT_SCATTER(MAXI, PERB)                                                                                             \
@@ -856,14 +871,33 @@ int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint
 // until every block of the generic path's last kernel has counted itself in.
 __global__ void split_join_kernel(uint32_t* ctl, uint32_t expected_blocks)
 {
-  if (ctl[kCtlOverflow] == 0) return;
-  // (RELAXED polls, far apart: an acquire at agent scope invalidates cache lines on every poll, and the kernels this wave is
-  // waiting for ran 30 % slower beside it; one acquire fence at the end is all the ordering needed)
+  if (ctl[kCtlOverflow] != 0) {
+    // (RELAXED polls, far apart: an acquire at agent scope invalidates cache lines on every poll, and the kernels this wave is
+    // waiting for ran 30 % slower beside it; one acquire fence at the end is all the ordering needed)
+    unsigned spins = 0;
+    while (__hip_atomic_load(&ctl[kCtlGenericDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected_blocks) {
+      __builtin_amdgcn_s_sleep(127);   // ~8 k cycles = 3.4 us between polls
+      if (++spins > (1u << 26)) {   // never in a healthy run (the generic path takes well under a second): report, do not hang
+        if (threadIdx.x == 0) ctl[kCtlError] = 2u;
+        break;
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  // the runs are final: everything that wrote them has finished before this kernel (stream order, or the wait above)
+  if (threadIdx.x == 0) __hip_atomic_store(&ctl[kCtlSortDone], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A side stream's way to wait for a word another stream's kernel sets (no event on that stream: an event record between two
+// kernels of the caller's stream costs ~7 us of its critical path). One wave, polling far apart.
+__global__ void split_wait_kernel(const uint32_t* word, uint32_t value, uint32_t* error_word)
+{
   unsigned spins = 0;
-  while (__hip_atomic_load(&ctl[kCtlGenericDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected_blocks) {
-    __builtin_amdgcn_s_sleep(127);   // ~8 k cycles = 3.4 us between polls
-    if (++spins > (1u << 26)) {   // never in a healthy run (the generic path takes well under a second): report, do not hang
-      if (threadIdx.x == 0) ctl[kCtlError] = 2u;
+  // (signed distance: the words of a ring are re-used with growing values, a stale one is "before")
+  while (static_cast<int32_t>(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+    __builtin_amdgcn_s_sleep(63);
+    if (++spins > (1u << 31)) {   // about an hour: what an event wait would do is wait for ever
+      if (threadIdx.x == 0) *error_word = 3u;
       break;
     }
   }
