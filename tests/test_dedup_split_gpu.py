@@ -199,3 +199,31 @@ def test_gradient_apply_replays_from_a_hipgraph(gpu_env, knobs, kind):
     g.replay()
     torch.cuda.synchronize()
     assert captured_rows.cpu().numpy().tobytes() == eager_rows.cpu().numpy().tobytes()
+
+
+MODES = {
+    # how the sort's side stream is forked / joined and where the step's long-run side runs (optim.hip); the default is
+    # "word fork + deferred join + detached long-run side", every other combination stays selectable for A/B runs
+    "event_fork": {"WM_DEDUP_FORK_EVENT": 1},
+    "join_in_front": {"WM_DEDUP_DEFER_JOIN": 0},
+    "long_side_inline": {"WM_STEP_DETACH": 0},
+    "all_on_one_stream": {"WM_DEDUP_SERIAL": 1, "WM_STEP_SERIAL": 1},
+    "high_priority_side": {"WM_DEDUP_LANE_PRIO": "h"},
+}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("name", ["uniform_sparse", "long_runs_radix_path", "hot_id_overflows_bucket"])
+def test_every_fork_and_join_arrangement_gives_the_same_bits(gpu_env, knobs, name, mode):
+    n, rows, off, gen = CASES[name]
+    rng = np.random.default_rng(abs(hash(name)) % (1 << 31) + 17)
+    ids = np.asarray(gen(rng, n, rows)).astype(np.int64)[:n] + off
+    grads = rng.standard_normal((n, 8)).astype(np.float32)
+    knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+    for k, v in MODES[mode].items():
+        knobs.set(k, v)
+    want, nu_want = _expect(ids, grads, rows, off)
+    for _ in range(3):     # (the long-run side follows the previous calls: let it settle in either arrangement)
+        got, nu = _apply(ids, grads, rows, off, np.int64)
+        assert nu == nu_want
+        assert got.tobytes() == want.tobytes()
