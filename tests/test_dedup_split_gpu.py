@@ -209,6 +209,10 @@ MODES = {
     "long_side_inline": {"WM_STEP_DETACH": 0},
     "all_on_one_stream": {"WM_DEDUP_SERIAL": 1, "WM_STEP_SERIAL": 1},
     "high_priority_side": {"WM_DEDUP_LANE_PRIO": "h"},
+    # no kernel may wait for another stream's kernel: what the library picks by itself under rocprofv3's counter collection
+    # (one kernel runs at a time there; it exports ROCPROF_COUNTER_COLLECTION) — the --pmc passes hang otherwise
+    "no_device_waits": {"WM_DEVICE_WAITS": 0},
+    "under_counter_collection": {"ROCPROF_COUNTER_COLLECTION": 1},
 }
 
 

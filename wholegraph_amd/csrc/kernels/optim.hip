@@ -397,6 +397,17 @@ struct sort_lane {
     return lane;
   }
 };
+// Kernels that wait for a word another stream's kernel sets (split_wait_kernel, split_join_kernel) need that other kernel to be
+// able to RUN beside them. A tool that lets one kernel execute at a time — rocprofv3's counter collection does, and not in
+// submission order: the --pmc passes of scripts/collect_profiles.sh sat in a waiter until their timeout — turns every such
+// wait into a hang. So: events only (the round's first arrangement, ~20 us slower per call) when rocprofv3 collects counters
+// (it exports ROCPROF_COUNTER_COLLECTION to the profiled process) or when WM_DEVICE_WAITS=0 says so.
+inline bool device_waits_allowed()
+{
+  const char* e = WM_KNOB("WM_DEVICE_WAITS");
+  if (e != nullptr) return e[0] != '0';
+  return WM_KNOB("ROCPROF_COUNTER_COLLECTION") == nullptr && WM_KNOB("ROCPROF_COUNTERS") == nullptr;
+}
 std::atomic<int64_t> g_split_sorts{0};
 // The optimizer step that follows a split sort on the same thread finds the sort's control words through the run_starts array
 // both were given: its long-run counters live there (zeroed by the sort's first kernel: no fill in front of the step), and
@@ -542,7 +553,8 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
       hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
       const bool capturing = hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone;
       const bool by_event = WM_KNOB("WM_DEDUP_FORK_EVENT") != nullptr && WM_KNOB("WM_DEDUP_FORK_EVENT")[0] == '1';   // (A/B switch)
-      if (!serial && !capturing && !by_event && sort_lane::get().ok && sort_lane::get().ring != nullptr) {
+      const bool waits_ok = !capturing && device_waits_allowed();
+      if (!serial && waits_ok && !by_event && sort_lane::get().ok && sort_lane::get().ring != nullptr) {
         sort_lane& lane = sort_lane::get();
         verdict_value   = ++lane.seq;
         verdict_word    = lane.ring + (verdict_value % sort_lane::kRing);
@@ -565,7 +577,7 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
                               stream, between, WM_KNOB("WM_DEDUP_FORK") != nullptr && WM_KNOB("WM_DEDUP_FORK")[0] == '3', verdict_word,
                               verdict_value) != 0)
         return -2;
-      if (forked && g_defer_join && !capturing) {
+      if (forked && g_defer_join && waits_ok) {
         hipLaunchKernelGGL(split::split_join_kernel, dim3(1), dim3(64), 0, stream,
                            reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl), 1u);   // (set by detect_runs' closing kernel)
         g_join_pending = true;
