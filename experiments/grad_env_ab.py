@@ -20,7 +20,7 @@ for item in sys.argv[5].split(";"):
     name, _, envs = item.partition(":")
     settings.append((name, dict(kv.split("=") for kv in envs.split(",") if kv)))
 es = 4 if dt == torch.float32 else 2
-rows, n = (int(51.2e9 // (dim * es)) if kind == "sgd" else int(25.6e9 // (dim * es))), 10_000_000
+rows, n = (int(51.2e9 // (dim * es)) if kind == "sgd" else int(25.6e9 // (dim * es))), int(os.environ.get("AB_IDS", "10000000"))
 emb = wgth.create_embedding(comm, "chunked", "cuda", dt, [rows, dim])
 wgth.create_wholememory_optimizer(emb, kind, {})
 if dist == "uniform":
@@ -31,7 +31,7 @@ else:
 g = torch.randn((n, dim), device="cuda").to(dt)
 def step():
     emb.add_gradients(idx, g); emb.need_apply = True; emb.apply_gradients(0.01)
-def timed(reps=20):
+def timed(reps=int(os.environ.get("AB_REPS", "20"))):
     for _ in range(3): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): step()

@@ -565,6 +565,10 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
           hipLaunchKernelGGL(split::split_wait_kernel, dim3(1), dim3(64), 0, lane.side(), verdict_word, verdict_value,
                              reinterpret_cast<uint32_t*>(sw + sp.off_ctl) + split::kCtlError);
           forked = hipGetLastError() == hipSuccess;
+          if (!forked) {   // (the caller's kernels and the join kernel are queued already: nothing of the generic path behind them)
+            generic_rc = -2;
+            return;
+          }
         } else {
           forked = !serial && lane.ok && hipEventRecord(lane.forked, stream) == hipSuccess &&
                    hipStreamWaitEvent(lane.side(), lane.forked, 0) == hipSuccess;
@@ -572,15 +576,29 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
         generic(forked ? lane.side() : stream);
         if (forked) forked = hipEventRecord(lane.joined, lane.side()) == hipSuccess;
       };
-      if (split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound), static_cast<uint32_t>(span),
-                              unique_ids, run_starts, order, n_unique_out, sl.split_ws, sl.osw_ctrl, zero_n,
-                              stream, between, WM_KNOB("WM_DEDUP_FORK") != nullptr && WM_KNOB("WM_DEDUP_FORK")[0] == '3', verdict_word,
-                              verdict_value) != 0)
-        return -2;
-      if (forked && g_defer_join && waits_ok) {
+      // With the fork by a word nothing ties the side stream's launches to a place in the caller's queue: the caller's kernels
+      // are enqueued FIRST (a mini-batch is bound by the host's launch rate — the nine side launches in the middle delayed the
+      // scatter kernel by as many launch times), then the join kernel, then the side stream.
+      const bool side_last = verdict_word != nullptr && !(WM_KNOB("WM_SIDE_FIRST") != nullptr && WM_KNOB("WM_SIDE_FIRST")[0] == '1');
+      auto nothing         = []() {};
+      const bool after_scatter = WM_KNOB("WM_DEDUP_FORK") != nullptr && WM_KNOB("WM_DEDUP_FORK")[0] == '3';
+      const int launched =
+        side_last ? split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
+                                        static_cast<uint32_t>(span), unique_ids, run_starts, order, n_unique_out, sl.split_ws,
+                                        sl.osw_ctrl, zero_n, stream, nothing, false, verdict_word, verdict_value)
+                  : split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
+                                        static_cast<uint32_t>(span), unique_ids, run_starts, order, n_unique_out, sl.split_ws,
+                                        sl.osw_ctrl, zero_n, stream, between, after_scatter, verdict_word, verdict_value);
+      if (launched != 0) return -2;
+      const bool defer = g_defer_join && waits_ok && (side_last || forked);
+      if (defer)
         hipLaunchKernelGGL(split::split_join_kernel, dim3(1), dim3(64), 0, stream,
                            reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl), 1u);   // (set by detect_runs' closing kernel)
+      if (side_last) between();
+      if (defer && forked) {
         g_join_pending = true;
+      } else if (defer) {
+        return -2;   // (the join kernel is queued but the side stream is not: nothing would ever release it after an overflow)
       } else if (forked && hipStreamWaitEvent(stream, sort_lane::get().joined, 0) != hipSuccess) {
         return -2;
       }
@@ -654,7 +672,7 @@ struct opt_params {
   // runs of more rows than this are not folded by step_tile_kernel / step_short_kernel but listed for the long-run side
   // (kLongRun with the ordered fold, tree_threshold() with the tree fold)
   int long_threshold;
-  int detached_side;   // 1: the long-run side runs on a side stream the caller's stream does NOT wait for (hip_optimizer_step_dev)
+  int detached_side;   // 1 / 2: the long-run side runs on a side stream the caller's stream does NOT wait for (hip_optimizer_step_dev)
   int fold_tree;   // 1: the long-run side is the tree fold (tree_fold_kernel), 0: the ordered fold (step_long4_kernel)
 };
 
@@ -1599,9 +1617,19 @@ struct long_lane {
 // step_short_kernel fills every wave slot of the chip with persistent waves: whatever is to run NEXT to it has to be on
 // the machine first. So the caller's stream waits for the (tiny) listing kernel; the long-run kernel is then queued on
 // the high-priority side stream at the moment step_short_kernel is queued on the caller's.
+// detached long-run side: its stream is not ordered behind the sort by anything but this wave, which waits for the sort's
+// "runs are final" word (split_join_kernel sets it on the caller's stream)
+inline void wait_for_final_runs(const opt_params& p, hipStream_t lstream)
+{
+  if (p.detached_side)
+    hipLaunchKernelGGL(split::split_wait_kernel, dim3(1), dim3(64), 0, lstream, p.split_ctl + split::kCtlSortDone, 1u,
+                       const_cast<uint32_t*>(p.split_ctl) + split::kCtlError);
+}
+
 template <typename IdxT>
 void launch_mark_long_runs(const opt_params& p, hipStream_t stream, hipStream_t lstream)
 {
+  wait_for_final_runs(p, lstream);
   // two coalesced reads of run_starts[] per run, on the caller's critical path: a grid-stride loop over at most 4096 workgroups
   // (one run per thread and 37 k workgroups for 9.5 M runs took 15 us — the time to hand out 148 k one-load waves)
   const int blocks = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, 4096));
@@ -1884,6 +1912,7 @@ inline int resolve_fold_mode(const wm_optimizer_args& a)
 template <typename IdxT, int OPT, typename T>
 void launch_tree(const opt_params& p, hipStream_t stream, hipStream_t lstream)
 {
+  wait_for_final_runs(p, lstream);
   tree_ws_view w = tree_ws_carve(p.a.long_run_ws, p.a.count, p.long_threshold);
   if (p.split_ctl != nullptr) w.counters = p.long_count;   // (the split sort's control words: already zero)
   // one run per thread, no grid-stride loop: the grid must cover every run (callers keep count below 2^31 -> at most 2^23 blocks)
@@ -1931,33 +1960,38 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
   const bool self_ok2  = p.a.self_grads == nullptr || p.a.self_grad_stride % 2 == 0;
   const bool self_ok4  = p.a.self_grads == nullptr || p.a.self_grad_stride % 4 == 0;
   const bool vec2      = p.a.dim % 2 == 0 && p.a.grad_stride % 2 == 0 && gaddr % 8 == 0 && self_ok2;
-  // the long runs first, on their own stream: they are listed, then folded while step_short_kernel does the rest
-  if (p.long_list != nullptr && p.fold_tree) {
-    launch_tree<IdxT, OPT, float>(p, stream, lstream);
-  } else if (p.long_list != nullptr) {
-    launch_mark_long_runs<IdxT>(p, stream, lstream);
-    const int slices = static_cast<int>((p.a.dim + kSliceCols - 1) / kSliceCols);
-    const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4;
-    const bool rows4 = p.a.dim % 4 == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4 &&
-                       p.a.dim <= 65535 * slice4_cols<float>();
-    const bool old_long = WM_KNOB("WM_STEP_LONG_OLD") != nullptr;
-    if (rows4 && !old_long) {
-      static const bool lds_ok =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, OPT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLong4LdsBytes)) == hipSuccess;
-      if (!lds_ok) return -2;
-      // 144 KiB of LDS = one workgroup per CU: launch one resident wave of workgroups (256 CUs) and let each walk the
-      // run list — with more workgroups than CUs the hottest run may only START after several rounds of others
-      const int slices4 = static_cast<int>((p.a.dim + slice4_cols<float>() - 1) / slice4_cols<float>());
-      int gx            = std::max(1, 256 / slices4);
-      if (const char* e = WM_KNOB("WM_LONG_GRID")) gx = std::max(1, atoi(e));
-      hipLaunchKernelGGL((step_long4_kernel<IdxT, OPT>), dim3(gx, slices4), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
+  // the long runs first, on their own stream: they are listed, then folded while step_short_kernel does the rest — unless the
+  // side is detached (nothing expected there, the caller's stream does not wait for it): then the tile kernel is enqueued first
+  auto long_side = [&]() -> int {
+    if (p.long_list != nullptr && p.fold_tree) {
+      launch_tree<IdxT, OPT, float>(p, stream, lstream);
+    } else if (p.long_list != nullptr) {
+      launch_mark_long_runs<IdxT>(p, stream, lstream);
+      const int slices = static_cast<int>((p.a.dim + kSliceCols - 1) / kSliceCols);
+      const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4;
+      const bool rows4 = p.a.dim % 4 == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4 &&
+                         p.a.dim <= 65535 * slice4_cols<float>();
+      const bool old_long = WM_KNOB("WM_STEP_LONG_OLD") != nullptr;
+      if (rows4 && !old_long) {
+        static const bool lds_ok =
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, OPT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLong4LdsBytes)) == hipSuccess;
+        if (!lds_ok) return -2;
+        // 144 KiB of LDS = one workgroup per CU: launch one resident wave of workgroups (256 CUs) and let each walk the
+        // run list — with more workgroups than CUs the hottest run may only START after several rounds of others
+        const int slices4 = static_cast<int>((p.a.dim + slice4_cols<float>() - 1) / slice4_cols<float>());
+        int gx            = std::max(1, 256 / slices4);
+        if (const char* e = WM_KNOB("WM_LONG_GRID")) gx = std::max(1, atoi(e));
+        hipLaunchKernelGGL((step_long4_kernel<IdxT, OPT>), dim3(gx, slices4), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
+      }
+      else if (long4)
+        hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, true>), dim3(1024, slices), dim3(kBlock), 0, lstream, p);
+      else
+        hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, false>), dim3(1024, slices), dim3(kBlock), 0, lstream, p);
     }
-    else if (long4)
-      hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, true>), dim3(1024, slices), dim3(kBlock), 0, lstream, p);
-    else
-      hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, false>), dim3(1024, slices), dim3(kBlock), 0, lstream, p);
-  }
+    return 0;
+  };
+  if (p.detached_side != 1 && long_side() != 0) return -2;
   // (a float4-per-lane variant, two runs per wave instruction, was measured too: no gain for SGD, 10-15 % slower for the
   // stateful optimizers through register pressure — 8 bytes per lane stay)
   const bool cached = p.a.cache_slot_of != nullptr;
@@ -1992,6 +2026,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
     else if (vecs > 8) WM_TILE(4);
     else WM_TILE(8);
 #undef WM_TILE
+    if (p.detached_side == 1 && long_side() != 0) return -2;
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (vec2 && !cached)
@@ -2002,6 +2037,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
     hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1, float, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
   else
     hipLaunchKernelGGL((step_short_kernel<IdxT, OPT, 1, float, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  if (p.detached_side == 1 && long_side() != 0) return -2;
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -2018,18 +2054,22 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream, hipStream_t 
   const bool rows16    = p.a.dim % 8 == 0 && p.a.grad_stride % 8 == 0 && sstr % 8 == 0 && gaddr % 16 == 0 &&
                       p.a.dim <= 65535 * kS;
   if (!rows16) p.long_list = nullptr;  // no LDS-DMA path for this shape: the wave-per-run kernel folds every run itself
-  if (p.long_list != nullptr && p.fold_tree) {
-    launch_tree<IdxT, kOpt, T>(p, stream, lstream);
-  } else if (p.long_list != nullptr) {
-    static const bool lds_ok =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, kOpt, T>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLong4LdsBytes)) == hipSuccess;
-    if (!lds_ok) return -2;
-    launch_mark_long_runs<IdxT>(p, stream, lstream);
-    const int slices = static_cast<int>((p.a.dim + kS - 1) / kS);
-    const int gx     = std::max(1, 256 / slices);
-    hipLaunchKernelGGL((step_long4_kernel<IdxT, kOpt, T>), dim3(gx, slices), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
-  }
+  auto long_side = [&]() -> int {   // (first, or behind the tile kernel when detached: launch_step_opt)
+    if (p.long_list != nullptr && p.fold_tree) {
+      launch_tree<IdxT, kOpt, T>(p, stream, lstream);
+    } else if (p.long_list != nullptr) {
+      static const bool lds_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, kOpt, T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLong4LdsBytes)) == hipSuccess;
+      if (!lds_ok) return -2;
+      launch_mark_long_runs<IdxT>(p, stream, lstream);
+      const int slices = static_cast<int>((p.a.dim + kS - 1) / kS);
+      const int gx     = std::max(1, 256 / slices);
+      hipLaunchKernelGGL((step_long4_kernel<IdxT, kOpt, T>), dim3(gx, slices), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
+    }
+    return 0;
+  };
+  if (p.detached_side != 1 && long_side() != 0) return -2;
   const bool cached = p.a.cache_slot_of != nullptr;
   // rows of whole 16-byte pieces (8 elements) on every side: the tile kernel, as for fp32 tables
   const bool tile_off = WM_KNOB("WM_STEP_TILE") != nullptr && WM_KNOB("WM_STEP_TILE")[0] == '0';
@@ -2052,6 +2092,7 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream, hipStream_t 
     else if (vecs > 8) WM_TILE16(4);
     else WM_TILE16(8);
 #undef WM_TILE16
+    if (p.detached_side == 1 && long_side() != 0) return -2;
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (vec4 && !cached)
@@ -2062,6 +2103,7 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream, hipStream_t 
     hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 1, T, false>), dim3(blocks), dim3(kBlock), 0, stream, p);
   else
     hipLaunchKernelGGL((step_short_kernel<IdxT, kOpt, 1, T, true>), dim3(blocks), dim3(kBlock), 0, stream, p);
+  if (p.detached_side == 1 && long_side() != 0) return -2;
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -2278,9 +2320,9 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
     sort_lock = std::unique_lock<std::mutex>(sort_lane::get().mu);
     lstream   = sort_lane::get().side();
     detached  = true;
-    p.detached_side = 1;
-    hipLaunchKernelGGL(split::split_wait_kernel, dim3(1), dim3(64), 0, lstream, p.split_ctl + split::kCtlSortDone, 1u,
-                       const_cast<uint32_t*>(p.split_ctl) + split::kCtlError);
+    // (launch_mark_long_runs / launch_tree queue the waiting wave in front of their first kernel; 1: the side is enqueued
+    // behind the tile kernel, 2 = WM_SIDE_FIRST=1: in front of it, the order of the first version, for A/B runs)
+    p.detached_side = WM_KNOB("WM_SIDE_FIRST") != nullptr && WM_KNOB("WM_SIDE_FIRST")[0] == '1' ? 2 : 1;
   }
   if (p.long_list != nullptr && !serial && long_lane::get().fork(stream)) lstream = long_lane::get().stream;
   // (the counters are cleared on the side stream: only the long-run kernels read them)
