@@ -231,3 +231,34 @@ def test_every_fork_and_join_arrangement_gives_the_same_bits(gpu_env, knobs, nam
         got, nu = _apply(ids, grads, rows, off, np.int64)
         assert nu == nu_want
         assert got.tobytes() == want.tobytes()
+
+
+def test_route_follows_the_batches(gpu_env, knobs):
+    """Adaptive route (optim.hip: run_dedup): once a split sort overflowed a bucket, the next batches of the same row range go
+    straight to rocPRIM's sort (a series of skewed batches is the usual case, and the gated generic path is the slower of the two);
+    every fourth such call probes with the split sort's first two kernels, and the first batch that would not overflow switches
+    back. Whatever the route, every call's result is the oracle's, bit for bit; the route shows in the split sort counter."""
+    from wholegraph_amd import binding as wmb
+    knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+    rng = np.random.default_rng(2024)
+    rows, n = 2_000_000, 80_000
+    uniform = rng.integers(0, rows, n).astype(np.int64)
+    skewed = np.where(rng.random(n) < 0.4, 31337, rng.integers(0, rows, n)).astype(np.int64)
+    grads = rng.standard_normal((n, 8)).astype(np.float32)
+    want_u, want_s = _expect(uniform, grads, rows, 0), _expect(skewed, grads, rows, 0)
+    count = wmb.lib().wholememory_ext_split_sorts
+
+    def call(ids, want):
+        before = count()
+        got, nu = _apply(ids, grads, rows, 0, np.int64)
+        assert nu == want[1] and got.tobytes() == want[0].tobytes()
+        return count() - before
+
+    assert call(uniform, want_u) == 1          # nothing known about this row range: the split sort
+    assert call(skewed, want_s) == 1           # ... which overflows (the generic path sorts the batch) and says so
+    assert call(skewed, want_s) == 0           # the series continues on rocPRIM's sort
+    assert call(skewed, want_s) == 0
+    routes = [call(uniform, want_u) for _ in range(8)]   # the batches stop being skewed: a probe notices within four calls
+    assert routes[0] == 0 and routes[-1] == 1 and sum(routes) >= 3, routes
+    knobs.set("WM_DEDUP_ADAPT", 0)             # (a reload forgets what was learnt; ADAPT=0: always the split sort)
+    assert call(skewed, want_s) == 1 and call(skewed, want_s) == 1

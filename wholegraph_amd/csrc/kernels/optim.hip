@@ -372,6 +372,40 @@ struct sort_lane {
   static constexpr uint32_t kRing = 4096;
   uint32_t* ring = nullptr;
   uint32_t seq   = 0;
+  // Which sort a batch gets follows the batches before it (run_dedup: "adaptive route"). Per row range (lower, upper) of the
+  // sorted ids: did the last split sort (or probe) overflow a bucket? The word is copied to pinned memory behind the kernels
+  // that decide it and read by the host without synchronising, so it lags a call.
+  static constexpr int kAdapt = 8, kProbeEvery = 4;
+  struct adapt_entry {
+    int64_t lower = -1, upper = -1;
+    unsigned calls = 0;
+  };
+  adapt_entry adapt[kAdapt];
+  volatile int32_t* adapt_flags = nullptr;   // pinned, [kAdapt]
+  unsigned adapt_generation     = ~0u;       // a knob reload forgets what was learnt (tests, A/B runs)
+  int adapt_next                = 0;
+  void* probe_ws                = nullptr;   // split::probe_workspace_bytes(), allocated at the first probe
+  int adapt_slot(int64_t lower, int64_t upper)
+  {
+    if (adapt_flags == nullptr) {
+      void* h = nullptr;
+      if (hipHostMalloc(&h, kAdapt * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return -1;
+      adapt_flags = static_cast<volatile int32_t*>(h);
+      for (int i = 0; i < kAdapt; i++) adapt_flags[i] = 0;
+    }
+    const unsigned g = g_knob_generation.load(std::memory_order_acquire);
+    if (g != adapt_generation) {
+      for (int i = 0; i < kAdapt; i++) adapt[i] = adapt_entry{}, adapt_flags[i] = 0;
+      adapt_generation = g;
+    }
+    for (int i = 0; i < kAdapt; i++)
+      if (adapt[i].lower == lower && adapt[i].upper == upper) return i;
+    const int i = adapt_next;
+    adapt_next  = (adapt_next + 1) % kAdapt;
+    adapt[i]    = adapt_entry{lower, upper, 0};
+    adapt_flags[i] = 0;
+    return i;
+  }
   sort_lane()
   {
     // two streams, plain and highest priority; WM_DEDUP_LANE_PRIO=n|h picks one per call (see side())
@@ -518,7 +552,41 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
   // the payload 0, 1, 2 ... is generated by the sort's first pass (counting iterator): no iota array
   rocprim::counting_iterator<int32_t> positions(0);
   const int64_t span = key_upper_bound > 0 ? key_upper_bound - key_lower_bound : 0;
-  if (span > 0 && span < INT64_C(0xFFFFFFFF) && n >= split_min()) {
+  // Adaptive route. A batch that overflows a bucket of the split sort (hot ids of a skewed batch) is sorted by the gated generic
+  // path instead — correct, but 0.11-0.13 ms slower per 10 M ids than rocPRIM's sort on the caller's stream would have been
+  // (its passes take 61-69 us on such ids, the hand-written ones 98-121: profiles/r05_grad_timeline_zipf_*.txt), and skewed
+  // batches come in series (the same power-law rows every step). So while the last split sort of this row range overflowed, the
+  // batch goes straight to rocPRIM (below), and every kProbeEvery-th such call runs the split sort's first two kernels as a
+  // probe in front (30 us / 4); the first batch that would not overflow switches back. A wrong guess costs time, once.
+  // WM_DEDUP_ADAPT=0: always the split sort. Not while a stream is captured (a graph replays ONE route).
+  bool expect_overflow = false;
+  int adapt_slot       = -1;
+  if (span > 0 && span < INT64_C(0xFFFFFFFF) && n >= split_min() && WM_KNOB("WM_DEDUP_SERIAL") == nullptr &&
+      !(WM_KNOB("WM_DEDUP_ADAPT") != nullptr && WM_KNOB("WM_DEDUP_ADAPT")[0] == '0')) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone && sort_lane::get().ok) {
+      sort_lane& lane = sort_lane::get();
+      std::lock_guard<std::mutex> lk(lane.mu);
+      adapt_slot = lane.adapt_slot(key_lower_bound, key_upper_bound);
+      if (adapt_slot >= 0 && lane.adapt_flags[adapt_slot] != 0) {
+        expect_overflow = true;
+        const split::plan sp = split::make_plan(n, span);
+        if (!sp.ok) {
+          lane.adapt_flags[adapt_slot] = 0;   // (a batch the split sort would not take anyway)
+        } else if (++lane.adapt[adapt_slot].calls % sort_lane::kProbeEvery == 0) {
+          if (lane.probe_ws == nullptr && hipMalloc(&lane.probe_ws, split::probe_workspace_bytes()) != hipSuccess) lane.probe_ws = nullptr;
+          if (lane.probe_ws != nullptr) {
+            if (split::launch_probe<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
+                                          static_cast<uint32_t>(span), lane.probe_ws, stream) != 0)
+              return -2;
+            (void)hipMemcpyAsync(const_cast<int32_t*>(lane.adapt_flags) + adapt_slot, split::probe_overflow_word(sp, lane.probe_ws),
+                                 sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+          }
+        }
+      }
+    }
+  }
+  if (!expect_overflow && span > 0 && span < INT64_C(0xFFFFFFFF) && n >= split_min()) {
     const split::plan sp = split::make_plan(n, span);
     if (sp.ok) {
       const split_layout sl = split_carve(workspace, n);
@@ -574,11 +642,14 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
                    hipStreamWaitEvent(lane.side(), lane.forked, 0) == hipSuccess;
         }
         generic(forked ? lane.side() : stream);
+        if (forked && adapt_slot >= 0)   // (what this batch did decides the route of the next: see "adaptive route")
+          (void)hipMemcpyAsync(const_cast<int32_t*>(lane.adapt_flags) + adapt_slot, gate, sizeof(int32_t), hipMemcpyDeviceToHost,
+                               lane.side());
         if (forked) forked = hipEventRecord(lane.joined, lane.side()) == hipSuccess;
       };
       // With the fork by a word nothing ties the side stream's launches to a place in the caller's queue: the caller's kernels
-      // are enqueued FIRST (a mini-batch is bound by the host's launch rate — the nine side launches in the middle delayed the
-      // scatter kernel by as many launch times), then the join kernel, then the side stream.
+      // — the split sort's four — are enqueued FIRST (a mini-batch is bound by the host's launch rate — the nine side launches in the middle delayed the
+      // scatter kernel by as many launch times), then the side stream, then the join kernel.
       const bool side_last = verdict_word != nullptr && !(WM_KNOB("WM_SIDE_FIRST") != nullptr && WM_KNOB("WM_SIDE_FIRST")[0] == '1');
       auto nothing         = []() {};
       const bool after_scatter = WM_KNOB("WM_DEDUP_FORK") != nullptr && WM_KNOB("WM_DEDUP_FORK")[0] == '3';
@@ -590,15 +661,14 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
                                         static_cast<uint32_t>(span), unique_ids, run_starts, order, n_unique_out, sl.split_ws,
                                         sl.osw_ctrl, zero_n, stream, between, after_scatter, verdict_word, verdict_value);
       if (launched != 0) return -2;
-      const bool defer = g_defer_join && waits_ok && (side_last || forked);
-      if (defer)
+      // (every wave that waits is enqueued BEHIND the kernel it waits for — the side stream's behind the split sort's kernels,
+      // the join kernel behind the side stream's last — so that even one in-order hardware queue makes progress)
+      if (side_last) between();
+      const bool defer = g_defer_join && waits_ok && forked;
+      if (defer) {
         hipLaunchKernelGGL(split::split_join_kernel, dim3(1), dim3(64), 0, stream,
                            reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl), 1u);   // (set by detect_runs' closing kernel)
-      if (side_last) between();
-      if (defer && forked) {
         g_join_pending = true;
-      } else if (defer) {
-        return -2;   // (the join kernel is queued but the side stream is not: nothing would ever release it after an overflow)
       } else if (forked && hipStreamWaitEvent(stream, sort_lane::get().joined, 0) != hipSuccess) {
         return -2;
       }

@@ -904,6 +904,45 @@ __global__ void split_wait_kernel(const uint32_t* word, uint32_t value, uint32_t
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 
+// The first two kernels alone, as a PROBE: "would a split sort of this batch overflow a bucket?" — for a caller that has routed
+// a run of skewed batches to another sort and wants to know when the batches stop being skewed (optim.hip: run_dedup).
+// probe_ws: probe_workspace_bytes() bytes of the caller's; the answer is the word probe_overflow_word() points at.
+inline size_t probe_workspace_bytes()
+{
+  auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  return align(4 * static_cast<size_t>(kMaxTiles) * kMaxPitch) + 2 * align(4 * (kMaxPitch + 2)) + align(4 * kCtlWords) + 256;
+}
+inline plan probe_plan(plan p)
+{
+  auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  size_t o = 0;
+  p.off_counts = o, o += align(4 * static_cast<size_t>(p.tiles) * p.pitch);
+  p.off_totals = o, o += align(4 * static_cast<size_t>(p.pitch));
+  p.off_state  = o, o += align(4 * static_cast<size_t>(p.pitch + 2));
+  p.off_ctl    = o, o += align(4 * kCtlWords);
+  p.total      = o;
+  return p;
+}
+template <typename UKey>
+int launch_probe(const plan& full, const UKey* ids, int64_t n, UKey key_lower_bound, uint32_t span, void* probe_ws, hipStream_t stream)
+{
+  const plan p = probe_plan(full);
+  char* ws     = static_cast<char*>(probe_ws);
+  key_source<UKey> src{ids, key_lower_bound, span};
+  uint32_t* counts = reinterpret_cast<uint32_t*>(ws + p.off_counts);
+  uint32_t* ctl    = reinterpret_cast<uint32_t*>(ws + p.off_ctl);
+  hipLaunchKernelGGL((split_hist_kernel<UKey>), dim3(tile_grid(p.tiles)), dim3(kBlock), 0, stream, src, n, p.tile, p.tiles, p.shift,
+                     p.buckets, p.pitch, counts, ctl, static_cast<uint32_t*>(nullptr), static_cast<int64_t>(0));
+  hipLaunchKernelGGL(split_scan_kernel, dim3(p.pitch / 32), dim3(kBlock), 0, stream, counts, p.tiles, p.pitch, p.buckets,
+                     reinterpret_cast<uint32_t*>(ws + p.off_totals), ctl, 1 << p.cap_bits, reinterpret_cast<uint32_t*>(ws + p.off_state),
+                     p.pitch + 2, static_cast<uint32_t*>(nullptr), 0u);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+inline const uint32_t* probe_overflow_word(const plan& full, void* probe_ws)
+{
+  return reinterpret_cast<const uint32_t*>(static_cast<char*>(probe_ws) + probe_plan(full).off_ctl) + kCtlOverflow;
+}
+
 inline const uint32_t* overflow_word(const plan& p, void* workspace)
 {
   return reinterpret_cast<const uint32_t*>(static_cast<char*>(workspace) + p.off_ctl) + kCtlOverflow;
