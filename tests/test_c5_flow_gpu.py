@@ -210,39 +210,6 @@ def test_chain_with_one_host_round_trip_equals_hop_by_hop(gpu_env, monkeypatch, 
     assert got[0][0].untyped_storage().nbytes() >= ref[0][0].untyped_storage().nbytes()
 
 
-@pytest.mark.parametrize("side_fill", ["default", "0"])
-@pytest.mark.parametrize("n_seeds,id_dtype,fanouts", [(200, np.int32, [10, 10]), (1023, np.int64, [5, 5, 5]), (4095, np.int32, [4, 3]),
-                                                      (4096, np.int32, [4, 3]), (9000, np.int64, [3, 3])])
-def test_chain_arms_its_scan_states_without_a_fill_command(gpu_env, knobs, monkeypatch, n_seeds, id_dtype, fanouts, side_fill):
-    """Round 5: the chain no longer starts with a fill command for the scan states of all its hops — hop 0's offsets scan runs
-    as ONE tile (up to 4095 seeds + 1 values: it reads no state) and arms them on the side; a bigger first hop gets the fill
-    command in front of its scan (WM_CHAIN_SIDE_FILL=0: always). Every route equals the hop-by-hop sample bit for bit, on both
-    sides of the one-tile limit and at every items-per-thread setting of the one-tile scan (<= 256, <= 1024, <= 4096 values);
-    twice in a row, so that the second call finds used scratch from the allocator's cache."""
-    import torch
-    import wholegraph_amd.torch as wgth
-    n_nodes = 20011
-    row_ptr, col = make_csr(n_nodes, 40, 11, id_dtype, heavy=[(3, 3000), (4, 0), (5, 700)])
-    wrow, wcol = _wm_array(gpu_env, "chunked", row_ptr, "cuda"), _wm_array(gpu_env, "chunked", col, "cuda")
-    g = wgth.GraphStructure()
-    g.set_csr_graph(wrow, wcol)
-    seeds = torch.from_numpy(np.concatenate([[3, 4, 5], np.random.default_rng(n_seeds).permutation(n_nodes)[:n_seeds - 3]]).astype(id_dtype)).cuda()
-    hop_seeds = [1234 + 7 * i for i in range(len(fanouts))]
-    if side_fill == "0":
-        knobs.set("WM_CHAIN_SIDE_FILL", 0)
-    monkeypatch.setenv("WM_MULTILAYER_CHAIN", "0")
-    ref = g.multilayer_sample_without_replacement(seeds, fanouts, random_seeds=hop_seeds)
-    monkeypatch.setenv("WM_MULTILAYER_CHAIN", "1")
-    for rep in range(2):
-        got = g.multilayer_sample_without_replacement(seeds, fanouts, random_seeds=hop_seeds)
-        torch.cuda.synchronize()
-        for name, a_list, b_list in zip(("target_gids", "edge_indice", "csr_row_ptr", "csr_col_ind"), got, ref):
-            assert len(a_list) == len(b_list)
-            for layer, (a, b) in enumerate(zip(a_list, b_list)):
-                assert tuple(a.shape) == tuple(b.shape) and torch.equal(a, b), "rep %d %s[%d] differs" % (rep, name, layer)
-    assert got[0][0].untyped_storage().nbytes() >= ref[0][0].untyped_storage().nbytes()   # the chain ran as one call
-
-
 @pytest.mark.parametrize("mt", ["chunked", "distributed"])
 @pytest.mark.parametrize("id_dtype,fanouts", [(np.int32, [30, 30]), (np.int64, [7, 5, 3])])
 def test_deferred_chain_feeds_the_gather_before_the_host_knows_the_counts(gpu_env, mt, id_dtype, fanouts):

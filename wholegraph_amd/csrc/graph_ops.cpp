@@ -405,13 +405,6 @@ int hop_offsets(const wm_device_backend* bk, const wm_sample_args& a, const int*
                                       a.max_sample_count, offsets, scan_ws, scan_ws_bytes, ws_is_ones, stream);
     if (rc != -3) return rc;
   }
-  if (ws_is_ones == 2) {   // the chain's first scan does not run as a fused launch: arm the states with a command of their own
-    if (bk->fill_ff_async != nullptr) {
-      if (int frc = bk->fill_ff_async(scan_ws, scan_ws_bytes, stream)) return frc;
-    } else if (int frc = bk->memset_async(scan_ws, 0xFF, scan_ws_bytes, stream)) {
-      return frc;
-    }
-  }
   int rc = bk->sample_counts(&a.row_gref, a.row_storage_offset, nullptr, a.centers, a.center_dtype, a.n_center, n_dev,
                              a.max_sample_count, counts, stream);
   if (rc != 0) return rc;
@@ -598,17 +591,10 @@ wholememory_error_code_t wholememory_ext_multilayer_sample(
     scan_total += scan_bytes[h];
   }
   char* scan_block = static_cast<char*>(scratch(static_cast<int64_t>(scan_total), WHOLEMEMORY_DT_INT8));
-  // round 5: no fill command in front of the chain — hop 0's offsets scan (one tile for up to 4095 seeds: it reads no state)
-  // arms the whole block on the side; a bigger first hop, or the unfused route, queues the fill itself (hop_offsets, chain_scan).
-  // WM_CHAIN_SIDE_FILL=0: the fill command (A/B)
-  const char* sf_env   = WM_KNOB("WM_CHAIN_SIDE_FILL");
-  const bool side_fill = !(sf_env != nullptr && sf_env[0] == '0');
-  if (!side_fill) {
-    if (bk->fill_ff_async != nullptr)
-      WM_BK(bk->fill_ff_async(scan_block, scan_total, stream));
-    else
-      WM_BK(bk->memset_async(scan_block, 0xFF, scan_total, stream));
-  }
+  if (bk->fill_ff_async != nullptr)
+    WM_BK(bk->fill_ff_async(scan_block, scan_total, stream));
+  else
+    WM_BK(bk->memset_async(scan_block, 0xFF, scan_total, stream));
   for (int h = 0; h < hops; h++) {
     const int nc = static_cast<int>(cap_c[h]), ns = static_cast<int>(cap_s[h]);
     const int* centres_in_use = h == 0 ? nullptr : n_dev + (h - 1);
@@ -620,12 +606,11 @@ wholememory_error_code_t wholememory_ext_multilayer_sample(
     int* offsets       = static_cast<int*>(sample_offsets[h]);
     a.sample_offsets   = offsets;
     int* counts        = static_cast<int*>(scratch(nc + 1, WHOLEMEMORY_DT_INT));
-    const bool arm_all   = side_fill && h == 0;   // (scan_at[0] == 0: hop 0's state heads the block)
-    const size_t scan_ws = arm_all ? scan_total : scan_bytes[h];
+    const size_t scan_ws = scan_bytes[h];
     void* scan_ws_ptr  = scan_block + scan_at[h];
     void* ids          = scratch(ns, col_desc.dtype);
     void* ws = scratch(static_cast<int64_t>(bk->append_unique_workspace_bytes(nc, ns, seed_desc.dtype)), WHOLEMEMORY_DT_INT8);
-    WM_BK(hop_offsets(bk, a, centres_in_use, counts, offsets, scan_ws_ptr, scan_ws, stream, arm_all ? 2 : 1));   // offsets[nc] = samples of the hop
+    WM_BK(hop_offsets(bk, a, centres_in_use, counts, offsets, scan_ws_ptr, scan_ws, stream, 1));   // offsets[nc] = samples of the hop
     a.out_ids        = ids;
     a.out_center_lid = center_lid[h];
     // the sampling kernel empties the hop's hash table on the side (one fill command fewer per hop)

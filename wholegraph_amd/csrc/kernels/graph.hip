@@ -121,8 +121,7 @@ struct no_tail {
 // optimizer's long-run side holding CUs: advisor, round 4). false = round 4's static mapping (tile = block + k x grid), which
 // completes only if all blocks of the grid are resident together; kept for A/B (WM_SCAN_STATIC=1).
 template <typename Fn, typename Tail, int kChainItems, bool TICKETS>
-__global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n, int* out, chain_state* st, Tail tail,
-                                                                  void* side_fill, unsigned int side_vecs)
+__global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n, int* out, chain_state* st, Tail tail)
 {
   constexpr int kChainTile = kChainThreads * kChainItems;
   __shared__ int s_excl;
@@ -130,16 +129,6 @@ __global__ __launch_bounds__(kChainThreads) void chain_scan_kernel(Fn fn, int n,
   __shared__ int s_wave[kChainThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n_tiles = (n + kChainTile - 1) / kChainTile;
-  // SIDE JOB of a ONE-TILE scan (chain_scan only passes it then): a one-tile scan reads no status word, so its state need not be
-  // armed — and its block arms the states of the scans that FOLLOW it on the stream (side_vecs 16-byte pieces of 0xFF at
-  // side_fill, which may include its own state: the status word this tile publishes below is never read). The multi-hop sampling
-  // chain started with a fill command for the states of all its hops: one launch fewer per step (round 5).
-  if (side_fill != nullptr) {
-    typedef uint32_t fill4 __attribute__((ext_vector_type(4)));
-    const fill4 ones = {~0u, ~0u, ~0u, ~0u};
-    for (unsigned int i = tid; i < side_vecs; i += kChainThreads) static_cast<fill4*>(side_fill)[i] = ones;
-    __syncthreads();
-  }
   // the functor reads its device-side counts ONCE, here; `live` false = every value is 0 and nothing may be read
   const bool live = fn.prepare();
   for (int round = 0;; round++) {
@@ -256,31 +245,14 @@ inline bool chain_scan_fits(int64_t n) { return n > 0 && n <= static_cast<int64_
 // Tile size by the size of the scan: a small scan wants MANY small tiles (fn is a chain of random loads: 31 k values in 8
 // tiles of 4096 keep 8 CUs busy and take 18 us, in 124 tiles of 256 they spread over the chip), a big one fewer, larger tiles
 // (every 64 predecessors are one look-back round trip of ~1 us for the last tile). WM_SCAN_ITEMS=1|4|16 forces (A/B).
-// side_fill / side_bytes (optional; a multiple of 16 each): bytes that have to read all-ones when this scan's kernel has run —
-// the states of later scans, `state` itself possibly among them, which then need NOT be armed on entry. A scan of up to 4096
-// values runs as one tile and fills them itself (see the kernel); a bigger one gets a fill command in front of it.
-inline bool chain_scan_one_tile(int n) { return n <= kChainThreads * 16; }
 template <typename Fn, typename Tail>
-int chain_scan(Fn fn, int n, int* out, Tail tail, void* state, hipStream_t stream, void* side_fill = nullptr, size_t side_bytes = 0)
+int chain_scan(Fn fn, int n, int* out, Tail tail, void* state, hipStream_t stream)
 {
   chain_state* st = static_cast<chain_state*>(state);   // chain_state_bytes(n) bytes, all-ones
   int items = n <= (64 << 10) ? 1 : n <= (512 << 10) ? 4 : 16;
   if (const char* e = WM_KNOB("WM_SCAN_ITEMS")) {
     const int v = atoi(e);
     if ((v == 1 || v == 4 || v == 16) && (static_cast<int64_t>(n) + 256 * v - 1) / (256 * v) <= kChainMaxTiles) items = v;
-  }
-  unsigned int side_vecs = 0;
-  if (side_fill != nullptr && side_bytes > 0) {
-    if ((reinterpret_cast<uintptr_t>(side_fill) | side_bytes) & 15) return -1;
-    if (chain_scan_one_tile(n) && side_bytes / 16 <= (1u << 20)) {
-      items     = n <= kChainThreads ? 1 : n <= kChainThreads * 4 ? 4 : 16;   // ONE tile whatever WM_SCAN_ITEMS says
-      side_vecs = static_cast<unsigned int>(side_bytes / 16);
-    } else {
-      if (fill_ff(side_fill, side_bytes, stream) != 0) return -2;
-      side_fill = nullptr;
-    }
-  } else {
-    side_fill = nullptr;
   }
   const int tile = kChainThreads * items;
   // one block per CU of the CURRENT device (per device ordinal: a process may drive several)
@@ -304,10 +276,8 @@ int chain_scan(Fn fn, int n, int* out, Tail tail, void* state, hipStream_t strea
   const bool tickets = !one_to_one && !static_ab;
 #define WM_CHAIN(ITEMS)                                                                                              \
   do {                                                                                                               \
-    if (tickets) hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, ITEMS, true>), grid, block, 0, stream, fn, n, out, st, tail,  \
-                                    side_fill, side_vecs);                                                           \
-    else hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, ITEMS, false>), grid, block, 0, stream, fn, n, out, st, tail,         \
-                            side_fill, side_vecs);                                                                   \
+    if (tickets) hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, ITEMS, true>), grid, block, 0, stream, fn, n, out, st, tail); \
+    else hipLaunchKernelGGL((chain_scan_kernel<Fn, Tail, ITEMS, false>), grid, block, 0, stream, fn, n, out, st, tail);        \
   } while (0)
   if (items == 1) WM_CHAIN(1);
   else if (items == 4) WM_CHAIN(4);
@@ -1292,18 +1262,13 @@ int hip_sample_offsets(const wholememory_gref_t* row_gref, int64_t row_off, cons
   const size_t need  = chain_state_bytes(static_cast<int64_t>(n) + 1);
   if (!chain_scan_fits(static_cast<int64_t>(n) + 1) || ws == nullptr || ws_bytes < need) return -3;   // nothing queued: count kernel + scan
   if (id_dtype != WHOLEMEMORY_DT_INT && id_dtype != WHOLEMEMORY_DT_INT64) return -1;
-  // ws_is_ones 0: nothing is armed, this scan's state is filled first; 1: the caller armed it; 2: the FIRST scan of a chain —
-  // all ws_bytes bytes at ws (its own state and those of the chain's later scans) are to read all-ones once its kernel has run
-  if (ws_is_ones == 2 && ((reinterpret_cast<uintptr_t>(ws) | ws_bytes) & 15)) return -1;
   if (!ws_is_ones && fill_ff(ws, (need + 15) & ~size_t(15), stream) != 0) return -2;
-  void* side          = ws_is_ones == 2 ? ws : nullptr;
-  const size_t side_b = ws_is_ones == 2 ? ws_bytes : 0;
   if (id_dtype == WHOLEMEMORY_DT_INT) {
     degree_fn<int32_t> fn{rv, row_off, static_cast<const int32_t*>(centers), n, max_sample, n_dev, 0};
-    return chain_scan(fn, n + 1, offsets, no_tail{}, ws, stream, side, side_b);
+    return chain_scan(fn, n + 1, offsets, no_tail{}, ws, stream);
   }
   degree_fn<int64_t> fn{rv, row_off, static_cast<const int64_t*>(centers), n, max_sample, n_dev, 0};
-  return chain_scan(fn, n + 1, offsets, no_tail{}, ws, stream, side, side_b);
+  return chain_scan(fn, n + 1, offsets, no_tail{}, ws, stream);
 }
 
 size_t hip_scan_i32_ws_bytes(int64_t n)
