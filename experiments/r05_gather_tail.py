@@ -4,6 +4,8 @@ entries cost? One process, the same 51 GB table: gather of n_valid ids ++ pad x 
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("WHOLEGRAPH_AMD_VARIANT"):   # scripts/build_variant.sh validprefix "-DWM_EXP_VALID_PREFIX=1": dead tiles leave on a scalar load
+    sys.path.insert(0, os.path.join(ROOT, "experiments", "variants", os.environ["WHOLEGRAPH_AMD_VARIANT"]))
 import torch
 import wholegraph_amd.torch as wgth
 from wholegraph_amd import binding as wmb
@@ -16,6 +18,7 @@ for n_valid in (600_000, 400_000, 984_064):
     ids = torch.full((room,), -1, dtype=torch.int32, device="cuda")
     ids[:n_valid] = torch.randint(0, rows, (n_valid,), device="cuda", dtype=torch.int32)
     out = torch.empty((room, dim), device="cuda")
+    nv = torch.tensor([n_valid], dtype=torch.int32, device="cuda")
     def run(idx, o, reps=200):
         for _ in range(10): emb.gather(idx, out=o)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -25,4 +28,9 @@ for n_valid in (600_000, 400_000, 984_064):
     for r in range(2):
         a = run(ids, out)
         b = run(ids[:n_valid].contiguous(), out[:n_valid])
-        print("valid %7d of %d: padded %.1f us   trimmed %.1f us   tail costs %.1f us" % (n_valid, room, a, b, a - b), flush=True)
+        c = float("nan")
+        if os.environ.get("WHOLEGRAPH_AMD_VARIANT"):
+            os.environ["WM_EXP_VALID_PTR"] = hex(nv.data_ptr())
+            c = run(ids, out)
+            os.environ.pop("WM_EXP_VALID_PTR")
+        print("valid %7d of %d: padded %.1f us   trimmed %.1f us   tail costs %.1f us   padded + device-side bound %.1f us" % (n_valid, room, a, b, a - b, c), flush=True)
