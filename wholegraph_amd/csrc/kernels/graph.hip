@@ -784,7 +784,7 @@ __device__ __forceinline__ uint64_t au_cas(uint64_t* a, uint64_t expect, uint64_
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, int nt, const KeyT* neighbors, int nn,
                                                            const int* nn_dev, KeyT* slots, uint32_t* min_pos,
-                                                           uint32_t* slot_of, uint32_t cap, const int* nt_dev)
+                                                           uint32_t* slot_of, uint32_t cap, const int* nt_dev, int direct_cas)
 {
   // the arrays hold room for nt targets and nn neighbours; nt_use / nn_use of them are in use (device-side counts of a
   // bounded call, else all). Thread i serves array entry i of targets ++ neighbours; the POSITION of a key — what
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, 
     const unsigned long long mine = (static_cast<unsigned long long>(key) << 32) | static_cast<uint32_t>(pos);
     uint32_t s = au_hash(static_cast<uint64_t>(key)) & (cap - 1);
     for (;;) {
-      unsigned long long cur = table[s];
+      unsigned long long cur = direct_cas ? ~0ull : table[s];   // direct_cas: no look first — one round trip per new id, not two
       if (cur == ~0ull) {
         cur = atomicCAS(&table[s], ~0ull, mine);
         if (cur == ~0ull) break;                       // the slot is mine
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, 
   if (key != kEmpty) {
     s = au_hash(static_cast<uint64_t>(key)) & (cap - 1);
     for (;;) {
-      KeyT cur = slots[s];
+      KeyT cur = direct_cas ? kEmpty : slots[s];
       if (cur == kEmpty) cur = au_cas(&slots[s], kEmpty, key);   // returns what was there: empty = the slot is mine now
       if (cur == kEmpty || cur == key) break;
       s = (s + 1) & (cap - 1);
@@ -939,6 +939,19 @@ __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, cons
   if (mapping != nullptr) mapping[p] = uid;
 }
 
+// The table insert of a key: look at the slot first and compare-and-swap only when it reads empty (two dependent round trips for
+// a new id, none of them an atomic for a repeated one), or compare-and-swap straight away (one round trip, an atomic per key).
+// Mini-batch frontiers are latency-bound and mostly new ids: C5's hops (32 k and 983 k keys, 60 % new) 0.246-0.270 -> 0.234-0.235 ms
+// per step without the look; a 37 M-key hop (65 536 seeds) is bound by the memory-side atomic units and most of its keys are
+// repeats the look filters out: 10.29 -> 11.09 ms without it (profiles/r05_c5_direct_cas_ab.txt). So: no look up to 2 M keys.
+// WM_AU_DIRECT_CAS=0 / 1 forces.
+inline int au_direct_cas(int64_t keys)
+{
+  const char* e = WM_KNOB("WM_AU_DIRECT_CAS");
+  if (e != nullptr && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return keys <= (INT64_C(2) << 20);
+}
+
 template <typename KeyT>
 int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const int* nn_dev, void* ws, int* new_count_dev,
               int* publish_host, const wm_au_bounds* bounds, hipStream_t stream)
@@ -952,7 +965,7 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
   if (n > 0)
     hipLaunchKernelGGL((au_insert_kernel<UKey>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                        static_cast<const UKey*>(targets), nt, static_cast<const UKey*>(neighbors), nn, nn_dev, l.slots,
-                       l.min_pos, l.slot_of, l.cap, nt_dev);
+                       l.min_pos, l.slot_of, l.cap, nt_dev, au_direct_cas(n));
   // 32-bit ids: the positions are the low halves of the (id, position) words that start where `slots` starts
   const uint32_t* positions = sizeof(UKey) == 4 ? reinterpret_cast<const uint32_t*>(l.slots) : l.min_pos;
   const bool late = bounds != nullptr && bounds->publish_host_late != nullptr && new_count_dev == nullptr && publish_host == nullptr && nt + nn > 0;
