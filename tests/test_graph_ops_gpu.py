@@ -263,6 +263,38 @@ def test_append_unique_table_edges(gpu_env, np_dtype, case):
     assert np.array_equal(o_uniq[o_map], neighbors)
 
 
+@pytest.mark.parametrize("np_dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("variant", ["merged_look", "merged_direct", "round4", "round4_direct"])
+@pytest.mark.parametrize("dist", ["uniform", "zipf", "one_id_and_all_ones"])
+def test_append_unique_insert_variants(gpu_env, knobs, np_dtype, variant, dist):
+    """Round 5: the table insert merges a workgroup's keys in LDS before it goes to memory, with or without a look at the slot
+    before the compare-and-swap (graph.hip: au_insert_merged_kernel, au_direct_cas). Every variant — and rounds 3-4's kernel,
+    kept for A/B — gives the oracle's unique list and mapping on uniform ids, on Zipf ids (one id in ~5 % of the positions:
+    every workgroup merges it) and on the degenerate inputs (one id everywhere; the id whose bits are all ones among them)."""
+    import torch
+    import wholegraph_amd.torch.graph_ops as gops
+    env = {"merged_look": {"WM_AU_DIRECT_CAS": 0}, "merged_direct": {"WM_AU_DIRECT_CAS": 1},
+           "round4": {"WM_AU_MERGE": 0, "WM_AU_DIRECT_CAS": 0}, "round4_direct": {"WM_AU_MERGE": 0, "WM_AU_DIRECT_CAS": 2}}[variant]
+    for k, v in env.items():
+        knobs.set(k, v)
+    rng = np.random.default_rng(17)
+    nt, nn, universe = 3001, 200003, 5_000_000
+    targets = rng.permutation(universe)[:nt].astype(np_dtype)
+    if dist == "uniform":
+        neighbors = rng.integers(0, universe, nn).astype(np_dtype)
+    elif dist == "zipf":
+        neighbors = ((rng.zipf(1.05, nn).astype(np.uint64) * np.uint64(2654435761)) % np.uint64(universe)).astype(np_dtype)
+        neighbors[::7] = targets[rng.integers(0, nt, len(neighbors[::7]))]      # and ids the targets hold
+    else:
+        neighbors = np.full(nn, 424242, dtype=np_dtype)
+        neighbors[5::1000] = -1
+        neighbors[9::3000] = targets[0]
+    o_uniq, o_map = oracle.append_unique(targets, neighbors)
+    uniq, mapping = gops.append_unique(torch.from_numpy(targets).cuda(), torch.from_numpy(neighbors).cuda(), True)
+    assert np.array_equal(uniq.cpu().numpy(), o_uniq)
+    assert np.array_equal(mapping.cpu().numpy(), o_map)
+
+
 @pytest.mark.parametrize("limit", ["0", "1000000000"])
 def test_append_unique_both_routes(limit):
     """Both routes of append_unique (hash table / radix sort; the library picks by size and id width) forced over the same

@@ -836,6 +836,96 @@ __global__ __launch_bounds__(kBlock) void au_insert_kernel(const KeyT* targets, 
   if (min_pos[s] > static_cast<uint32_t>(pos)) atomicMin(&min_pos[s], static_cast<uint32_t>(pos));
 }
 
+// The insert, round 5: the keys of a workgroup are first merged in an LDS table of the same shape (id -> smallest position among
+// the workgroup's 256 entries); only the entry that holds an id's smallest position in its workgroup goes to the table in
+// memory, the others take the slot number from it through LDS — so an id offered by many positions (a hub of a power-law graph)
+// costs one same-address operation per workgroup, not per position. look_first: the leader looks at a slot before its
+// compare-and-swap, or not (see au_direct_cas). Results are the same words as au_insert_kernel's (every step is a min or an
+// insert-if-absent), so everything downstream is bit-identical.
+constexpr int kAuLdsSlots = 2 * kBlock;
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void au_insert_merged_kernel(const KeyT* targets, int nt, const KeyT* neighbors, int nn,
+                                                                  const int* nn_dev, KeyT* slots, uint32_t* min_pos,
+                                                                  uint32_t* slot_of, uint32_t cap, const int* nt_dev,
+                                                                  int look_first)
+{
+  __shared__ unsigned long long l_key[kAuLdsSlots];   // 32-bit ids: (id << 32 | smallest position); 64-bit ids: the id
+  __shared__ uint32_t l_pos[kAuLdsSlots];             // 64-bit ids: smallest position
+  __shared__ uint32_t l_slot[kAuLdsSlots];            // where the id landed in the table in memory
+  for (int k = threadIdx.x; k < kAuLdsSlots; k += kBlock) l_key[k] = ~0ull, l_pos[k] = ~0u;
+  const int i          = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nt_use     = nt_dev != nullptr ? min(nt, *nt_dev) : nt;
+  const int nn_use     = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
+  const bool is_target = i < nt;
+  const int entry      = is_target ? i : i - nt;
+  const bool active    = i < nt + nn && entry < (is_target ? nt_use : nn_use);
+  const int pos        = is_target ? entry : nt_use + entry;
+  constexpr KeyT kEmpty = ~static_cast<KeyT>(0);
+  const KeyT key        = active ? (is_target ? targets[entry] : neighbors[entry]) : static_cast<KeyT>(0);
+  // 64-bit ids: the id that looks like "empty" has a slot of its own in memory and does not go through LDS
+  const bool odd_one = sizeof(KeyT) == 8 && key == kEmpty;
+  const unsigned long long mine =
+    sizeof(KeyT) == 4 ? (static_cast<unsigned long long>(key) << 32) | static_cast<uint32_t>(pos) : static_cast<unsigned long long>(key);
+  __syncthreads();
+  uint32_t ls = 0;
+  if (active && !odd_one) {
+    ls = (au_hash(static_cast<uint64_t>(key)) >> 11) & (kAuLdsSlots - 1);
+    for (;;) {
+      unsigned long long cur = l_key[ls];
+      if (cur == ~0ull) {
+        cur = atomicCAS(&l_key[ls], ~0ull, mine);
+        if (cur == ~0ull) break;
+      }
+      if (sizeof(KeyT) == 4) {
+        if (static_cast<uint32_t>(cur >> 32) == static_cast<uint32_t>(key)) {
+          if (cur > mine) atomicMin(&l_key[ls], mine);
+          break;
+        }
+      } else if (cur == mine) {
+        break;
+      }
+      ls = (ls + 1) & (kAuLdsSlots - 1);
+    }
+    if (sizeof(KeyT) == 8) atomicMin(&l_pos[ls], static_cast<uint32_t>(pos));
+  }
+  __syncthreads();
+  const bool leader = active && !odd_one && (sizeof(KeyT) == 4 ? l_key[ls] == mine : l_pos[ls] == static_cast<uint32_t>(pos));
+  if (leader || (active && odd_one)) {
+    uint32_t s = cap;
+    if constexpr (sizeof(KeyT) == 4) {
+      unsigned long long* table = reinterpret_cast<unsigned long long*>(slots);
+      s = au_hash(static_cast<uint64_t>(key)) & (cap - 1);
+      for (;;) {
+        unsigned long long cur = look_first ? table[s] : ~0ull;
+        if (cur == ~0ull) {
+          cur = atomicCAS(&table[s], ~0ull, mine);
+          if (cur == ~0ull) break;                     // the slot is mine
+        }
+        if (static_cast<uint32_t>(cur >> 32) == static_cast<uint32_t>(key)) {   // equal ids: the words compare by position
+          if (cur > mine) atomicMin(&table[s], mine);
+          break;
+        }
+        s = (s + 1) & (cap - 1);
+      }
+    } else {
+      if (!odd_one) {
+        s = au_hash(static_cast<uint64_t>(key)) & (cap - 1);
+        for (;;) {
+          KeyT cur = look_first ? slots[s] : kEmpty;
+          if (cur == kEmpty) cur = au_cas(&slots[s], kEmpty, key);   // returns what was there: empty = the slot is mine now
+          if (cur == kEmpty || cur == key) break;
+          s = (s + 1) & (cap - 1);
+        }
+      }
+      if (!look_first || min_pos[s] > static_cast<uint32_t>(pos)) atomicMin(&min_pos[s], static_cast<uint32_t>(pos));
+    }
+    if (odd_one) slot_of[i] = s;
+    else l_slot[ls] = s;
+  }
+  __syncthreads();
+  if (active && !odd_one) slot_of[i] = l_slot[ls];
+}
+
 __global__ __launch_bounds__(kBlock) void au_flag_kernel(const uint32_t* min_pos, const uint32_t* slot_of, int nt, int nn,
                                                          const int* nn_dev, int* first_flag, int stride, const int* nt_dev)
 {
@@ -941,15 +1031,33 @@ __global__ __launch_bounds__(kBlock) void au_emit_kernel(const KeyT* slots, cons
 
 // The table insert of a key: look at the slot first and compare-and-swap only when it reads empty (two dependent round trips for
 // a new id, none of them an atomic for a repeated one), or compare-and-swap straight away (one round trip, an atomic per key).
-// Mini-batch frontiers are latency-bound and mostly new ids: C5's hops (32 k and 983 k keys, 60 % new) 0.246-0.270 -> 0.234-0.235 ms
-// per step without the look; a 37 M-key hop (65 536 seeds) is bound by the memory-side atomic units and most of its keys are
-// repeats the look filters out: 10.29 -> 11.09 ms without it (profiles/r05_c5_direct_cas_ab.txt). So: no look up to 2 M keys.
-// WM_AU_DIRECT_CAS=0 / 1 forces.
-inline int au_direct_cas(int64_t keys)
+// Either way the keys of a workgroup are merged in LDS first (au_insert_merged_kernel): an id offered by many positions then
+// costs one operation on the table per WORKGROUP that holds it, not one per position — whole append_unique calls of 31.7 k +
+// 952 k keys: uniform ids 132 -> 131 us, Zipf(1.05) ids (the hottest one x 50 k) 357 -> 122 us, Zipf(1.3) 1378 -> 99 us, one id
+// 1.8 ms -> 58 us; 8 M keys: uniform 747 -> 753 us, Zipf(1.05) 740 -> 498 us, Zipf(1.3) 1.52 ms -> 0.22 ms
+// (profiles/r05_au_insert_skew.txt; real graphs are skewed, bench.py's synthetic one is not).
+// Without the look: the hops of the sampling chain (the table was emptied by the sampler on the side, long before) of up to 2 M
+// keys — C5's step 0.243-0.245 -> 0.237-0.240 ms (0.230-0.235 without the merge, which a skewed hop would pay for dearly:
+// Zipf(1.05) 357 -> 652 us). A call that has just filled its table finds the freshly written lines close by and is 10 us
+// faster WITH the look (uniform 131 vs 141 us), and a 37 M-key hop is bound by the memory-side atomic units, most of its keys
+// being repeats the look filters out (10.43 vs 10.95 ms per step at 65 536 seeds): those keep the look
+// (profiles/r05_c5_direct_cas_ab.txt). WM_AU_DIRECT_CAS=0 / 1 forces; WM_AU_MERGE=0 (A/B only): rounds 3-4's kernel.
+inline int au_direct_cas(int64_t keys, bool table_cleared_long_ago = true)
 {
   const char* e = WM_KNOB("WM_AU_DIRECT_CAS");
-  if (e != nullptr && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-  return keys <= (INT64_C(2) << 20);
+  if (e != nullptr && e[0] == '0') return 0;
+  if (e != nullptr && (e[0] == '1' || e[0] == '2')) return 1;
+  return table_cleared_long_ago && keys <= (INT64_C(2) << 20);
+}
+inline bool au_merged()
+{
+  const char* e = WM_KNOB("WM_AU_MERGE");
+  return !(e != nullptr && e[0] == '0');
+}
+inline int au_direct_cas_plain()
+{
+  const char* e = WM_KNOB("WM_AU_DIRECT_CAS");
+  return e != nullptr && e[0] == '2';
 }
 
 template <typename KeyT>
@@ -962,10 +1070,14 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
   auto l      = au_plan<UKey>(ws, nt, nn);
   const int n = nt + nn;
   if (!(bounds != nullptr && bounds->table_is_clear) && fill_ff(l.scan_state, l.table_bytes, stream) != 0) return -2;
-  if (n > 0)
+  if (n > 0 && au_merged())
+    hipLaunchKernelGGL((au_insert_merged_kernel<UKey>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                       static_cast<const UKey*>(targets), nt, static_cast<const UKey*>(neighbors), nn, nn_dev, l.slots,
+                       l.min_pos, l.slot_of, l.cap, nt_dev, au_direct_cas(n, bounds != nullptr && bounds->table_is_clear) ? 0 : 1);
+  else if (n > 0)
     hipLaunchKernelGGL((au_insert_kernel<UKey>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                        static_cast<const UKey*>(targets), nt, static_cast<const UKey*>(neighbors), nn, nn_dev, l.slots,
-                       l.min_pos, l.slot_of, l.cap, nt_dev, au_direct_cas(n));
+                       l.min_pos, l.slot_of, l.cap, nt_dev, au_direct_cas_plain());
   // 32-bit ids: the positions are the low halves of the (id, position) words that start where `slots` starts
   const uint32_t* positions = sizeof(UKey) == 4 ? reinterpret_cast<const uint32_t*>(l.slots) : l.min_pos;
   const bool late = bounds != nullptr && bounds->publish_host_late != nullptr && new_count_dev == nullptr && publish_host == nullptr && nt + nn > 0;
