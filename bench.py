@@ -66,6 +66,11 @@ def parse():
     p.add_argument("--avg-degree", type=int, default=29, help="sample_gather: mean out-degree (papers100M, both directions: 29)")
     p.add_argument("--seeds", type=int, default=1024, help="sample_gather: seed nodes per rank per step")
     p.add_argument("--fanouts", default="30,30", help="sample_gather: fan-out per hop, seeds outwards")
+    p.add_argument("--col-dist", choices=["uniform", "powerlaw"], default="uniform",
+                   help="sample_gather: how the synthetic graph's neighbour ids are drawn. uniform (the default, every earlier line): "
+                        "no node is a hub. powerlaw: node of popularity rank k with probability ~ k^-s (--col-exponent s < 1, ranks "
+                        "hashed over the id range): hubs as in a citation graph — s = 0.8 puts the top node into ~0.5 %% of all edges")
+    p.add_argument("--col-exponent", type=float, default=0.8, help="sample_gather --col-dist powerlaw: the exponent s, 0 < s < 1")
     p.add_argument("--c5-flow", choices=["deferred", "reference"], default="deferred",
                    help="sample_gather: deferred = sampling chain and feature gather queued back to back, one host round trip after "
                         "both (extension); reference = sample, wait for the counts, gather (the reference's call sequence)")
@@ -297,7 +302,14 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
     gen2 = torch.Generator(device="cuda").manual_seed(100 + rank)
     for s0 in range(0, lcol.shape[0], 1 << 28):
         e0 = min(lcol.shape[0], s0 + (1 << 28))
-        lcol[s0:e0] = torch.randint(0, nodes, (e0 - s0,), device="cuda", generator=gen2, dtype=torch.int32)
+        if a.col_dist == "powerlaw":
+            # inverse CDF of the truncated power law: rank = nodes * u^(1 / (1 - s)); ranks hashed over the id range
+            u = torch.rand(e0 - s0, device="cuda", generator=gen2, dtype=torch.float64)
+            rank_k = (u.pow_(1.0 / (1.0 - a.col_exponent)) * nodes).to(torch.int64).clamp_(0, nodes - 1)
+            lcol[s0:e0] = ((rank_k * 2654435761) % nodes).to(torch.int32)
+            del u, rank_k
+        else:
+            lcol[s0:e0] = torch.randint(0, nodes, (e0 - s0,), device="cuda", generator=gen2, dtype=torch.int32)
     feat = wgth.create_embedding(comm, mt, "cuda", torch.float32, [nodes, a.dim])
     lfeat, fstart = feat.get_embedding_tensor().get_local_tensor()
     fill_table(lfeat, fstart)
@@ -386,7 +398,8 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
         "config": {"workload": "C5 %s graph %d nodes / %d edges (int32 col) + %dx%d fp32 features, %d-hop %s unweighted sample "
                                "from %d seeds per rank + append_unique + feature gather" % (
                                    mt, nodes, edges, nodes, a.dim, len(fanouts), fanouts, a.seeds),
-                   "memory_type": mt, "seeds_per_rank": a.seeds, "fanouts": fanouts},
+                   "memory_type": mt, "seeds_per_rank": a.seeds, "fanouts": fanouts,
+                   "neighbour_ids": "uniform" if a.col_dist == "uniform" else "power law, exponent %g" % a.col_exponent},
         "roofline": {"bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(algo / (ms * 1e-3) / 8e12, 4), "traffic": None,
                      "algorithmic_bytes_per_step": algo,
