@@ -852,7 +852,9 @@ __global__ __launch_bounds__(kBlock) void au_insert_merged_kernel(const KeyT* ta
   __shared__ unsigned long long l_key[kAuLdsSlots];   // 32-bit ids: (id << 32 | smallest position); 64-bit ids: the id
   __shared__ uint32_t l_pos[kAuLdsSlots];             // 64-bit ids: smallest position
   __shared__ uint32_t l_slot[kAuLdsSlots];            // where the id landed in the table in memory
+  __shared__ int l_any_repeat;                        // an id occurs twice among the workgroup's entries
   for (int k = threadIdx.x; k < kAuLdsSlots; k += kBlock) l_key[k] = ~0ull, l_pos[k] = ~0u;
+  if (threadIdx.x == 0) l_any_repeat = 0;
   const int i          = blockIdx.x * blockDim.x + threadIdx.x;
   const int nt_use     = nt_dev != nullptr ? min(nt, *nt_dev) : nt;
   const int nn_use     = nn_dev != nullptr ? min(nn, *nn_dev) : nn;
@@ -879,9 +881,11 @@ __global__ __launch_bounds__(kBlock) void au_insert_merged_kernel(const KeyT* ta
       if (sizeof(KeyT) == 4) {
         if (static_cast<uint32_t>(cur >> 32) == static_cast<uint32_t>(key)) {
           if (cur > mine) atomicMin(&l_key[ls], mine);
+          l_any_repeat = 1;
           break;
         }
       } else if (cur == mine) {
+        l_any_repeat = 1;
         break;
       }
       ls = (ls + 1) & (kAuLdsSlots - 1);
@@ -919,11 +923,14 @@ __global__ __launch_bounds__(kBlock) void au_insert_merged_kernel(const KeyT* ta
       }
       if (!look_first || min_pos[s] > static_cast<uint32_t>(pos)) atomicMin(&min_pos[s], static_cast<uint32_t>(pos));
     }
-    if (odd_one) slot_of[i] = s;
-    else l_slot[ls] = s;
+    slot_of[i] = s;
+    if (!odd_one) l_slot[ls] = s;
   }
+  // (the usual workgroup of a mini-batch hop holds no id twice: every entry led, nothing to hand over, no third barrier —
+  // l_any_repeat was written before the second barrier and is read by everybody after it: the branch is uniform)
+  if (!l_any_repeat) return;
   __syncthreads();
-  if (active && !odd_one) slot_of[i] = l_slot[ls];
+  if (active && !odd_one && !leader) slot_of[i] = l_slot[ls];
 }
 
 __global__ __launch_bounds__(kBlock) void au_flag_kernel(const uint32_t* min_pos, const uint32_t* slot_of, int nt, int nn,
