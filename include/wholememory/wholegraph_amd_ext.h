@@ -212,6 +212,16 @@ int64_t wholememory_ext_split_sorts(void);
  * ranks (rounds 2-4: 2 (W - 1) C + 1). A counter for tests. */
 int64_t wholememory_ext_distributed_gather_launches(void);
 
+/* The same for the DISTRIBUTED scatter route (line-up gathers of the rows to send, owner-side writes, this rank's own rows,
+ * the two chunk-major copies): at most 2 C + 3 per call (rounds 1-5: 2 (W - 1) C + 1). A counter for tests. */
+int64_t wholememory_ext_distributed_scatter_launches(void);
+
+/* Row kernels queued so far in FRONT of the gradient exchange of wholememory_embedding_gather_gradient_apply (the chunk-major
+ * copy of the positions, the line-up gathers of the gradient rows to send, a copy of this rank's own rows when they are not
+ * read in place): at most C + 2 per call whatever the number of ranks (rounds 1-5: (W - 1) C + 1). The receive side launches
+ * nothing per chunk: rows arrive in rank-major order, which is the order of the fp32 sum of duplicates. A counter for tests. */
+int64_t wholememory_ext_gradient_exchange_launches(void);
+
 /* ---- (3) testing seam ---------------------------------------------------------------------- */
 /* Replaces the device backend. Refuses (WHOLEMEMORY_NOT_SUPPORTED) unless the environment has
  * WHOLEGRAPH_AMD_TESTING=1. `backend` is a const wm_device_backend* (wholegraph_amd/csrc/backend.hpp);

@@ -140,15 +140,56 @@ def scenario_gather_scatter(comm, rank, world, mt, n_rows, dim, tdt, odt, idt, e
         oracle.scatter(rows, rank_idx[r], ref)
         if r == rank:
             wr, wx = wrap_torch_tensor(dev(torch.from_numpy(rows))), wrap_torch_tensor(dev(torch.from_numpy(rank_idx[r])))
+            s0 = wmb.lib().wholememory_ext_distributed_scatter_launches()
             wmb.check(wmb.lib().wholememory_scatter(wr.handle, wx.handle, view.wmb_tensor, get_wholegraph_env_fns(),
                                                     C.c_void_p(get_stream()), -1))
             if HIP_MODE:
                 torch.cuda.synchronize()
+            if mt == "distributed" and world > 1 and world <= 16 and loc == "cuda":
+                # one row kernel per exchange chunk and side (+ the rank's own rows, + the two chunk-major copies), whatever
+                # the number of ranks (round 6; the per-peer launches of rounds 1-5 are checked against it below)
+                chunks = int(os.environ.get("WM_EXCHANGE_CHUNKS", "1"))
+                folded = wmb.lib().wholememory_ext_distributed_scatter_launches() - s0
+                assert folded <= 2 * chunks + 3, "distributed scatter queued %d kernels with %d chunks" % (folded, chunks)
+                if (world >= 3 and chunks > 1 and os.environ.get("WM_EXCHANGE_SELF") != "1" and n_rows >= 500
+                        and min(len(ix) for ix in rank_idx) >= 100 and entries is None):
+                    assert folded == 2 * chunks + 3, (folded, chunks)
     comm.barrier()
     if cnt:
         assert (local if hv else host(local)).numpy().tobytes() == ref.shards[rank][:cnt].tobytes(), \
             "%s/%s scatter mismatch on rank %d" % (mt, loc, rank)
     comm.barrier()
+    if mt == "distributed" and world > 2 and world <= 16 and loc == "cuda":
+        # the same scatter with the per-peer launches of rounds 1-5: the same table, 2 (W - 1) C + 1 kernels
+        if cnt:
+            local.zero_()
+        if HIP_MODE:
+            torch.cuda.synchronize()
+        comm.barrier()
+        os.environ["WM_EXCHANGE_PER_PEER"] = "1"
+        _reload_knobs()
+        rows = np.zeros((len(rank_idx[rank]), dim), dtype=odt)
+        v = rank_idx[rank] >= 0
+        rows[v] = src[rank_idx[rank][v].astype(np.int64)]
+        wr, wx = wrap_torch_tensor(dev(torch.from_numpy(rows))), wrap_torch_tensor(dev(torch.from_numpy(rank_idx[rank])))
+        s1 = wmb.lib().wholememory_ext_distributed_scatter_launches()
+        wmb.check(wmb.lib().wholememory_scatter(wr.handle, wx.handle, view.wmb_tensor, get_wholegraph_env_fns(),
+                                                C.c_void_p(get_stream()), -1))
+        if HIP_MODE:
+            torch.cuda.synchronize()
+        per_peer = wmb.lib().wholememory_ext_distributed_scatter_launches() - s1
+        del os.environ["WM_EXCHANGE_PER_PEER"]
+        _reload_knobs()
+        comm.barrier()
+        if cnt:
+            assert (local if hv else host(local)).numpy().tobytes() == ref.shards[rank][:cnt].tobytes(), \
+                "%s/%s per-peer scatter mismatch on rank %d" % (mt, loc, rank)
+        chunks = int(os.environ.get("WM_EXCHANGE_CHUNKS", "1"))
+        assert per_peer <= 1 + 2 * world * chunks, (per_peer, world, chunks)   # (loopback: the own segment travels too)
+        if (chunks > 1 and os.environ.get("WM_EXCHANGE_SELF") != "1" and n_rows >= 500
+                and min(len(ix) for ix in rank_idx) >= 100 and entries is None):
+            assert per_peer == 1 + 2 * (world - 1) * chunks, (per_peer, world, chunks)
+        comm.barrier()
     if view is not wm:
         wgth.destroy_wholememory_tensor(view)
     wgth.destroy_wholememory_tensor(wm)
@@ -234,7 +275,25 @@ def scenario_gradient_apply(comm, rank, world, kind, params, idt, entries, mt="d
             rank_grads.append(gr)
         emb.add_gradients(dev(torch.from_numpy(rank_idx[rank])), dev(torch.from_numpy(rank_grads[rank])))
         emb.need_apply = True
+        g0 = wmb.lib().wholememory_ext_gradient_exchange_launches()
+        if step == 2 and world > 2:
+            os.environ["WM_EXCHANGE_PER_PEER"] = "1"   # the last step with the per-peer line-ups of rounds 1-5: the same bits
+            _reload_knobs()
         opt.step(0.05)
+        queued = wmb.lib().wholememory_ext_gradient_exchange_launches() - g0
+        chunks = int(os.environ.get("WM_EXCHANGE_CHUNKS", "1"))
+        if step == 2 and world > 2:
+            del os.environ["WM_EXCHANGE_PER_PEER"]
+            _reload_knobs()
+            assert queued <= world * chunks + 1, (queued, world, chunks)   # (loopback: the own segment travels too)
+            if chunks > 1 and os.environ.get("WM_EXCHANGE_SELF") != "1" and entries is None:   # (equal partition: no empty pair)
+                assert queued in ((world - 1) * chunks, (world - 1) * chunks + 1), (queued, world, chunks)
+        elif world > 1 and world <= 16:
+            # one line-up kernel per chunk whatever the number of ranks (+ the chunk-major copy of the positions, + a copy of
+            # the rank's own rows when they are not read in place); one chunk: the two ranges around the rank's own segment
+            assert queued <= max(chunks + 2, 3), "gradient apply queued %d row kernels in front of %d chunks" % (queued, chunks)
+            if world >= 3 and chunks > 1 and os.environ.get("WM_EXCHANGE_SELF") != "1" and entries is None:
+                assert queued in (chunks + 1, chunks + 2), (queued, chunks)
         oracle.gradient_apply(tab, ref_opts, rank_idx, rank_grads, 0.05)
         if HIP_MODE:
             torch.cuda.synchronize()
@@ -361,7 +420,25 @@ def scenario_tree_fold(comm, rank, world, mt, kind, params):
             rank_grads.append(g.integers(-2, 3, (len(ix), dim)).astype(np.float32))
         emb.add_gradients(dev(torch.from_numpy(rank_idx[rank])), dev(torch.from_numpy(rank_grads[rank])))
         emb.need_apply = True
+        g0 = wmb.lib().wholememory_ext_gradient_exchange_launches()
+        if step == 2 and world > 2:
+            os.environ["WM_EXCHANGE_PER_PEER"] = "1"   # the last step with the per-peer line-ups of rounds 1-5: the same bits
+            _reload_knobs()
         opt.step(0.05)
+        queued = wmb.lib().wholememory_ext_gradient_exchange_launches() - g0
+        chunks = int(os.environ.get("WM_EXCHANGE_CHUNKS", "1"))
+        if step == 2 and world > 2:
+            del os.environ["WM_EXCHANGE_PER_PEER"]
+            _reload_knobs()
+            assert queued <= world * chunks + 1, (queued, world, chunks)   # (loopback: the own segment travels too)
+            if chunks > 1 and os.environ.get("WM_EXCHANGE_SELF") != "1" and entries is None:   # (equal partition: no empty pair)
+                assert queued in ((world - 1) * chunks, (world - 1) * chunks + 1), (queued, world, chunks)
+        elif world > 1 and world <= 16:
+            # one line-up kernel per chunk whatever the number of ranks (+ the chunk-major copy of the positions, + a copy of
+            # the rank's own rows when they are not read in place); one chunk: the two ranges around the rank's own segment
+            assert queued <= max(chunks + 2, 3), "gradient apply queued %d row kernels in front of %d chunks" % (queued, chunks)
+            if world >= 3 and chunks > 1 and os.environ.get("WM_EXCHANGE_SELF") != "1" and entries is None:
+                assert queued in (chunks + 1, chunks + 2), (queued, chunks)
         oracle.gradient_apply(tab, ref_opts, rank_idx, rank_grads, 0.05)
         torch.cuda.synchronize()
         assert host(local).numpy().tobytes() == tab.shards[rank][:cnt, :dim].tobytes(), \

@@ -263,6 +263,8 @@ PROTOTYPES = {
     "wholememory_ext_host_sorted_gathers": (_i64, []),
     "wholememory_ext_split_sorts": (_i64, []),
     "wholememory_ext_distributed_gather_launches": (_i64, []),
+    "wholememory_ext_distributed_scatter_launches": (_i64, []),
+    "wholememory_ext_gradient_exchange_launches": (_i64, []),
     "wholememory_ext_set_malloc_probe": (_i, [C.c_char_p]),
     "wholememory_ext_handle_was_probed": (_i, [_vp]),
     "wholememory_ext_multilayer_sample": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -62,6 +62,7 @@ struct wholememory_embedding_ {
 };
 
 namespace wm {
+extern std::atomic<int64_t> g_grad_exchange_launches;   // row kernels queued in front of the gradient exchange (ops.cpp)
 namespace {
 
 #define WM_BK(call)                                                                                  \
@@ -412,14 +413,14 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   }
   // gradient rows in bucketed order: remote segments into the send buffer, the self segment into recv_buf
   const auto grads_gref = wholememory_create_continuous_global_reference(wholememory_tensor_get_data_pointer(grads));
-  auto launch_rows = [&](int64_t s0, int64_t s1, char* dst) {
+  auto launch_rows = [&](const int64_t* raw, int64_t s0, int64_t s1, char* dst) {   // grads[raw[s0 .. s1)] -> dst rows 0 ..
     if (s1 <= s0) return;
     wm_rows_args ga{};
     ga.gref         = grads_gref;
     ga.table_dtype  = vdt;
     ga.dim          = dim;
     ga.table_stride = gmat.stride;
-    ga.indices      = x.raw_indices + s0;
+    ga.indices      = raw + s0;
     ga.index_dtype  = WHOLEMEMORY_DT_INT64;
     ga.n            = s1 - s0;
     ga.plain        = dst;
@@ -427,6 +428,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     ga.plain_stride = dim;
     ga.max_blocks   = -1;
     WM_BK(bk->gather_rows(&ga, stream));
+    g_grad_exchange_launches.fetch_add(1, std::memory_order_relaxed);
   };
   const bool self_direct = x.self_count > 0 && self_in_place;
   self_rows_ref self_ref;
@@ -437,27 +439,46 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     self_ref.grads  = wholememory_tensor_get_data_pointer(grads);
     self_ref.stride = gmat.stride;
   } else if (self_local) {
-    launch_rows(x.self_offset, x.self_offset + x.self_count, recv_buf + full_recv_offsets[rank] * row_bytes);
+    launch_rows(x.raw_indices, x.self_offset, x.self_offset + x.self_count, recv_buf + full_recv_offsets[rank] * row_bytes);
   }
   // peers' rows: line-up (HBM) and all-to-all-v (xGMI, side stream) pipelined in C row-chunks; the id sort that
-  // follows on the caller's stream overlaps with the tail of the exchange
+  // follows on the caller's stream overlaps with the tail of the exchange.
+  // ONE line-up kernel per chunk whatever the number of ranks (round 6; the distributed gather since round 5): the positions
+  // of the rows to send are brought into chunk-major order once (ops_internal.hpp: chunk_layout, backend: permute_chunks)
+  // and the send buffer is laid out chunk-major — C + 1 kernels in front of the exchange instead of (W - 1) C (28 -> 5 at
+  // W = 8, C = 4). The RECEIVE side keeps the rank-major order: it defines the order of the fp32 sum of duplicates.
   const int W = e->comm->world_size;
   const int C = exchange_chunks(W, x.global_moved);
-  auto chunk_of = [C](int64_t n, int c, int64_t* a, int64_t* b) {
-    *a = n * c / C;
-    *b = n * (c + 1) / C;
-  };
+  const bool per_peer = bk->permute_chunks == nullptr || W > 16 || W <= 2 /* one peer: a chunk is one range already */ ||
+                        (WM_KNOB("WM_EXCHANGE_PER_PEER") != nullptr && WM_KNOB("WM_EXCHANGE_PER_PEER")[0] == '1');
+  const bool folded = !per_peer && C > 1 && !x.identity;
+  const chunk_layout want(x.send_counts, C), serve(x.recv_counts, C);
+  temp_mem raw_cm_mem(env);
+  const int64_t* send_raw = x.raw_indices;
+  if (folded && x.total_send > 0) {
+    auto* cm = static_cast<int64_t*>(raw_cm_mem.device(x.total_send, WHOLEMEMORY_DT_INT64));
+    WM_BK(bk->permute_chunks(x.raw_indices, cm, 8, x.bucket_offsets.data(), x.send_counts.data(), W, C, stream));
+    g_grad_exchange_launches.fetch_add(1, std::memory_order_relaxed);
+    send_raw = cm;
+  }
   void* side = C > 1 ? e->comm->get_side_stream() : stream;
   event_set lined_up(C > 1 ? C : 0), arrived(C > 1 ? 1 : 0);
   for (int c = 0; c < C; c++) {
     std::vector<int64_t> sc(W), so(W), rc(W), ro(W);
     for (int p = 0; p < W; p++) {
-      int64_t a, b;
-      chunk_of(x.send_counts[p], c, &a, &b);
-      sc[p] = b - a, so[p] = x.bucket_offsets[p] + a;
-      if (p != rank || !self_local) launch_rows(so[p], so[p] + sc[p], send_buf + so[p] * row_bytes);
-      chunk_of(x.recv_counts[p], c, &a, &b);
-      rc[p] = b - a, ro[p] = full_recv_offsets[p] + a;
+      sc[p] = want.count(c, p), so[p] = folded ? want.pos(c, p) : x.bucket_offsets[p] + want.first(c, p);
+      rc[p] = serve.count(c, p), ro[p] = full_recv_offsets[p] + serve.first(c, p);
+    }
+    if (folded) {
+      launch_rows(send_raw, want.start(c), want.start(c + 1), send_buf + want.start(c) * row_bytes);
+    } else if (!per_peer && !x.identity) {
+      // one chunk: the rows to send are the bucketed order minus this rank's own segment — the range before it and the one after
+      const int64_t self_b = self_local ? x.self_offset : x.total_valid, self_e = self_local ? x.self_offset + x.self_count : x.total_valid;
+      launch_rows(x.raw_indices, 0, self_b, send_buf);
+      launch_rows(x.raw_indices, self_e, x.total_valid, send_buf + self_e * row_bytes);
+    } else {
+      for (int p = 0; p < W; p++)
+        if (p != rank || !self_local) launch_rows(x.raw_indices, so[p], so[p] + sc[p], send_buf + so[p] * row_bytes);
     }
     if (C > 1) {
       WM_BK(bk->event_record(lined_up[c], stream));

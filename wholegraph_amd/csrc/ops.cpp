@@ -311,6 +311,7 @@ bool mapped_via_exchange(wholememory_tensor_t t, wholememory_memory_type_t mt)
 // Every rank of the exchange must arrive at the same number (each chunk is one collective call), so the decision may only
 // use what all ranks know alike: the world size, the environment and id_exchange::global_moved.
 extern std::atomic<int64_t> g_dist_gather_launches;   // kernels queued by gather_distributed_rows (defined with the other counters)
+extern std::atomic<int64_t> g_dist_scatter_launches;  // ... by scatter_distributed
 
 int exchange_chunks(int world_size, int64_t global_moved)
 {
@@ -988,62 +989,94 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
                    d.indices.dtype, x.self_count, d.plain_ptr, d.plain, scatter_sms);
     sa.row_map = x.raw_indices + x.self_offset;
     WM_BK(bk->scatter_rows(&sa, stream));
+    g_dist_scatter_launches.fetch_add(1, std::memory_order_relaxed);
   }
 
   // (b)-(d) rows for the peers, pipelined in C row-chunks over two streams (same scheme as the gather):
   //   L_c  line up chunk c of every peer's input rows in bucketed order (scatter_op_impl_nccl.cu:118-133) — HBM
   //   A_c  rows all-to-all-v of chunk c                                                              — xGMI, side stream
   //   S_c  owner writes (and casts) chunk c into its shard (scatter_op_impl_nccl.cu:145-166)          — HBM
-  temp_mem send_rows(env), recv_rows(env);
-  char* send_buf = static_cast<char*>(send_rows.device(dim * x.total_valid, d.plain.dtype));
-  char* recv_buf = static_cast<char*>(recv_rows.device(dim * x.total_recv, d.plain.dtype));
+  // ONE launch per chunk and side (round 6, as the gather since round 5): the positions of the rows to send and the received
+  // ids are brought into chunk-major order once (ops_internal.hpp: chunk_layout), the send and receive buffers are laid out
+  // chunk-major, so L_c and S_c are one row kernel each over a contiguous range: 2 C + 3 kernels per call instead of
+  // 2 (W - 1) C + 1 (57 -> 11 at W = 8, C = 4). A scatter overwrites, duplicates are unordered in the reference
+  // (gather_scatter_func.cuh:519-598), so the order in which the owner writes received rows is free.
   const size_t row_bytes = static_cast<size_t>(dim) * pes;
   const int W            = comm->world_size;
   const int rank         = comm->world_rank;
   const int C            = exchange_chunks(W, x.global_moved);
   const auto in_gref     = wholememory_create_continuous_global_reference(d.plain_ptr);
-  auto chunk_of = [C](int64_t n, int c, int64_t* a, int64_t* b) {
-    *a = n * c / C;
-    *b = n * (c + 1) / C;
+  const bool per_peer    = bk->permute_chunks == nullptr || W > 16 || W <= 2 /* one peer: a chunk is one range already */ ||
+                        (WM_KNOB("WM_EXCHANGE_PER_PEER") != nullptr && WM_KNOB("WM_EXCHANGE_PER_PEER")[0] == '1');
+  const bool folded = !per_peer && C > 1;   // chunk-major buffers
+  const chunk_layout want(x.send_counts, C), serve(x.recv_counts, C);
+  temp_mem send_rows(env), recv_rows(env), raw_cm_mem(env), ids_cm_mem(env);
+  // (peer-major: the send buffer keeps the bucketed layout, this rank's own segment stays unused)
+  char* send_buf = static_cast<char*>(send_rows.device(dim * (folded ? x.total_send : x.total_valid), d.plain.dtype));
+  char* recv_buf = static_cast<char*>(recv_rows.device(dim * x.total_recv, d.plain.dtype));
+  const int64_t* send_raw = x.raw_indices;
+  const char* write_ids   = static_cast<const char*>(x.recv_ids);
+  if (folded && x.total_send > 0) {
+    auto* cm = static_cast<int64_t*>(raw_cm_mem.device(x.total_send, WHOLEMEMORY_DT_INT64));
+    WM_BK(bk->permute_chunks(x.raw_indices, cm, 8, x.bucket_offsets.data(), x.send_counts.data(), W, C, stream));
+    g_dist_scatter_launches.fetch_add(1, std::memory_order_relaxed);
+    send_raw = cm;
+  }
+  if (folded && x.total_recv > 0) {
+    void* cm = ids_cm_mem.device(x.total_recv, d.indices.dtype);
+    WM_BK(bk->permute_chunks(x.recv_ids, cm, static_cast<int>(ies), x.recv_offsets.data(), x.recv_counts.data(), W, C, stream));
+    g_dist_scatter_launches.fetch_add(1, std::memory_order_relaxed);
+    write_ids = static_cast<const char*>(cm);
+  }
+  auto lineup_range = [&](const int64_t* raw, int64_t first, int64_t count) {   // in[raw[first ...]] -> send buffer rows first ...
+    if (count <= 0) return;
+    int64_t ssz[2] = {count, dim};
+    auto send_desc = wholememory_create_matrix_desc(ssz, dim, 0, d.plain.dtype);
+    wm_rows_args ga{};
+    fill_rows_args(&ga, in_gref, d.plain, raw + first, WHOLEMEMORY_DT_INT64, count, send_buf + row_bytes * first, send_desc, -1);
+    WM_BK(bk->gather_rows(&ga, stream));
+    g_dist_scatter_launches.fetch_add(1, std::memory_order_relaxed);
+  };
+  auto write_range = [&](const char* ids, int64_t first, int64_t count) {   // receive buffer rows first ... -> table[ids[first ...]]
+    if (count <= 0) return;
+    int64_t rsz[2] = {count, dim};
+    auto recv_desc = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
+    wm_rows_args wa{};
+    fill_rows_args(&wa, local_gref, d.table, ids + ies * first, d.indices.dtype, count, recv_buf + row_bytes * first, recv_desc,
+                   scatter_sms);
+    WM_BK(bk->scatter_rows(&wa, stream));
+    g_dist_scatter_launches.fetch_add(1, std::memory_order_relaxed);
   };
   auto lineup_chunk = [&](int c) {
-    for (int p = 0; p < W; p++) {
-      if (p == rank && self_local) continue;
-      int64_t a, b;
-      chunk_of(x.send_counts[p], c, &a, &b);
-      if (b <= a) continue;
-      const int64_t first = x.bucket_offsets[p] + a;
-      int64_t ssz[2]      = {b - a, dim};
-      auto send_desc      = wholememory_create_matrix_desc(ssz, dim, 0, d.plain.dtype);
-      wm_rows_args ga{};
-      fill_rows_args(&ga, in_gref, d.plain, x.raw_indices + first, WHOLEMEMORY_DT_INT64, b - a,
-                     send_buf + row_bytes * first, send_desc, -1);
-      WM_BK(bk->gather_rows(&ga, stream));
+    if (folded) {
+      lineup_range(send_raw, want.start(c), want.size(c));
+    } else if (!per_peer) {
+      // one chunk: the rows to send are the bucketed order minus this rank's own segment — the range before it and the one after
+      const int64_t self_b = self_local ? x.self_offset : x.total_valid, self_e = self_local ? x.self_offset + x.self_count : x.total_valid;
+      lineup_range(x.raw_indices, 0, self_b);
+      lineup_range(x.raw_indices, self_e, x.total_valid - self_e);
+    } else {
+      for (int p = 0; p < W; p++) {
+        if (p == rank && self_local) continue;
+        lineup_range(x.raw_indices, x.bucket_offsets[p] + want.first(c, p), want.count(c, p));
+      }
     }
   };
   auto exchange_chunk = [&](int c, void* on_stream) {
     std::vector<int64_t> sc(W), so(W), rc(W), ro(W);
     for (int p = 0; p < W; p++) {
-      int64_t a, b;
-      chunk_of(x.send_counts[p], c, &a, &b);
-      sc[p] = b - a, so[p] = x.bucket_offsets[p] + a;
-      chunk_of(x.recv_counts[p], c, &a, &b);
-      rc[p] = b - a, ro[p] = x.recv_offsets[p] + a;
+      sc[p] = want.count(c, p), so[p] = folded ? want.pos(c, p) : x.bucket_offsets[p] + want.first(c, p);
+      rc[p] = serve.count(c, p), ro[p] = folded ? serve.pos(c, p) : x.recv_offsets[p] + serve.first(c, p);
     }
     exchange_segments(comm, send_buf, sc, so, recv_buf, rc, ro, row_bytes, on_stream);
   };
   auto write_chunk = [&](int c) {
-    for (int p = 0; p < W; p++) {
-      int64_t a, b;
-      chunk_of(x.recv_counts[p], c, &a, &b);
-      if (b <= a) continue;
-      const int64_t first = x.recv_offsets[p] + a;
-      int64_t rsz[2]      = {b - a, dim};
-      auto recv_desc      = wholememory_create_matrix_desc(rsz, dim, 0, d.plain.dtype);
-      wm_rows_args wa{};
-      fill_rows_args(&wa, local_gref, d.table, static_cast<const char*>(x.recv_ids) + ies * first, d.indices.dtype, b - a,
-                     recv_buf + row_bytes * first, recv_desc, scatter_sms);
-      WM_BK(bk->scatter_rows(&wa, stream));
+    if (folded) {
+      write_range(write_ids, serve.start(c), serve.size(c));
+    } else if (!per_peer) {
+      write_range(write_ids, 0, x.total_recv);   // one chunk: everything received is one contiguous range
+    } else {
+      for (int p = 0; p < W; p++) write_range(write_ids, x.recv_offsets[p] + serve.first(c, p), serve.count(c, p));
     }
   };
   if (C == 1) {
@@ -1077,12 +1110,16 @@ wholememory_error_code_t scatter_distributed(wholememory_handle_t handle, const 
 namespace wm {
 std::atomic<int64_t> g_host_sorted_gathers{0};
 std::atomic<int64_t> g_dist_gather_launches{0};
+std::atomic<int64_t> g_dist_scatter_launches{0};
+std::atomic<int64_t> g_grad_exchange_launches{0};
 }
 
 extern "C" {
 
 int64_t wholememory_ext_host_sorted_gathers(void) { return wm::g_host_sorted_gathers.load(std::memory_order_relaxed); }
 int64_t wholememory_ext_distributed_gather_launches(void) { return wm::g_dist_gather_launches.load(std::memory_order_relaxed); }
+int64_t wholememory_ext_distributed_scatter_launches(void) { return wm::g_dist_scatter_launches.load(std::memory_order_relaxed); }
+int64_t wholememory_ext_gradient_exchange_launches(void) { return wm::g_grad_exchange_launches.load(std::memory_order_relaxed); }
 
 wholememory_error_code_t wholememory_gather(wholememory_tensor_t wholememory_tensor,
                                             wholememory_tensor_t indices_tensor,

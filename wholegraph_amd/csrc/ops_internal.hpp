@@ -92,6 +92,38 @@ void exchange_rows(wholememory_comm_t comm, const void* send, const std::vector<
 // global_moved = id_exchange::global_moved, so that every rank decides alike
 int exchange_chunks(int world_size, int64_t global_moved);
 
+// Chunk-major order of per-peer segments (backend.hpp: permute_chunks): chunk c of a segment of n rows is rows
+// [n*c/C, n*(c+1)/C) of it — the same cut on both ends of a pair, so the sizes of an exchanged chunk always match — and the
+// chunk-major order lists chunk 0 of every segment (in peer order), then chunk 1 of every segment, ... A chunk of the
+// pipelined exchange is then ONE contiguous range of ids, positions and row buffer: one row kernel per chunk and side
+// whatever the number of ranks (distributed gather since round 5; distributed scatter and gradient apply since round 6).
+struct chunk_layout {
+  chunk_layout(const std::vector<int64_t>& counts, int n_chunks) : counts_(counts), C_(n_chunks), start_(n_chunks + 1, 0)
+  {
+    for (int c = 0; c < C_; c++) {
+      int64_t s = 0;
+      for (size_t p = 0; p < counts_.size(); p++) s += count(c, static_cast<int>(p));
+      start_[c + 1] = start_[c] + s;
+    }
+  }
+  int64_t first(int c, int p) const { return counts_[p] * c / C_; }                 // first row of chunk c inside segment p
+  int64_t count(int c, int p) const { return counts_[p] * (c + 1) / C_ - counts_[p] * c / C_; }
+  int64_t start(int c) const { return start_[c]; }                                   // where chunk c begins, chunk-major
+  int64_t size(int c) const { return start_[c + 1] - start_[c]; }
+  int64_t pos(int c, int p) const                                                    // where chunk c of segment p begins
+  {
+    int64_t at = start_[c];
+    for (int q = 0; q < p; q++) at += count(c, q);
+    return at;
+  }
+  int64_t total() const { return start_[C_]; }
+
+ private:
+  std::vector<int64_t> counts_;
+  int C_;
+  std::vector<int64_t> start_;
+};
+
 // RAII bundle of backend events
 class event_set {
  public:
