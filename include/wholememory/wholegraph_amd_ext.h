@@ -193,6 +193,9 @@ enum wholememory_error_code_t wholememory_ext_probe_memory(void* ptr, size_t byt
  * placement_probe="auto") sets it around the one creation. Tables that are written at random — scatter targets, trained
  * embeddings — are what it is for: their speed follows the placement of the shard by up to 20 %. */
 enum wholememory_error_code_t wholememory_ext_set_malloc_probe(const char* mode);
+/* The mode set by the call above ("env" when none is), written to mode[capacity >= 8]: for callers that set a mode around ONE
+ * allocation and restore what was there before. */
+enum wholememory_error_code_t wholememory_ext_get_malloc_probe(char* mode, size_t capacity);
 /* 1 when the local shard of the handle was chosen among several probed candidates, else 0 */
 int wholememory_ext_handle_was_probed(wholememory_handle_t handle);
 

@@ -393,6 +393,7 @@ def scenario_tree_fold(comm, rank, world, mt, kind, params):
     segments at its owner, self rows read in place beside received ones); gradients are integer-valued, so the tree's sums are
     exact and table + states must equal the ordered multi-rank oracle bit for bit."""
     n_rows, dim, steps = 2003, 64, 2
+    entries = None   # (equal partition)
     os.environ["WM_GRAD_FOLD"] = "tree"
     _reload_knobs()
     emb = wgth.create_embedding(comm, mt, "cuda", torch.float32, [n_rows, dim])

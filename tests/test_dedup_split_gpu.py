@@ -262,3 +262,81 @@ def test_route_follows_the_batches(gpu_env, knobs):
     assert routes[0] == 0 and routes[-1] == 1 and sum(routes) >= 3, routes
     knobs.set("WM_DEDUP_ADAPT", 0)             # (a reload forgets what was learnt; ADAPT=0: always the split sort)
     assert call(skewed, want_s) == 1 and call(skewed, want_s) == 1
+
+
+@pytest.mark.parametrize("gate", ["lookback", "join"])
+def test_a_device_side_wait_that_gives_up_is_an_error_code_not_a_wrong_table(gpu_env, knobs, gate):
+    """The split sort's waiting waves (bucket look-back, join of the generic path) give up after a bounded number of polls.
+    Round 5 wrote a word nobody read and carried on — a stalled wait ended in a silently wrong gradient step. Now the sort's last
+    kernel turns a sort with a timeout into "no runs" (the step behind it does nothing) and leaves the code in pinned memory,
+    which the host reports as WHOLEMEMORY_CUDA_ERROR at its next synchronise / entry. Forced here by a short poll limit
+    (WM_DEBUG_SPIN_LIMIT) and a gate that never opens (WM_DEBUG_STALL): 'lookback' = a stage-2 bucket that never publishes its
+    run count (uniform ids, map path); 'join' = a generic path that never says done (a hot id overflows a bucket)."""
+    import torch
+    from wholegraph_amd import binding as wmb
+    rng = np.random.default_rng(99)
+    n, rows, dim = 90000, 6_000_000, 8
+    ids = rng.integers(0, rows, n).astype(np.int64)
+    if gate == "join":
+        ids = np.where(rng.random(n) < 0.25, 4242, ids)
+    grads = rng.standard_normal((n, dim)).astype(np.float32)
+    knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+    knobs.set("WM_DEDUP_ADAPT", 0)
+    knobs.set("WM_DEBUG_SPIN_LIMIT", 3000)
+    knobs.set("WM_DEBUG_STALL", gate)
+    env, stream = _env()
+    d_table = torch.zeros((rows, dim), device="cuda")
+    d_ids, d_grads = torch.from_numpy(ids).cuda(), torch.from_numpy(grads).cuda()
+    arr = (C.c_float * 6)(0.0, 1e-8, 0.9, 0.999, 0.99, 0.0)
+    nu = C.c_int64(-1)
+    rc = wmb.lib().wholememory_ext_dedup_apply(d_ids.data_ptr(), wmb.DT_INT64, n, d_grads.data_ptr(), dim, dim, d_table.data_ptr(),
+                                               dim, 0, rows, 1, arr, -1.0, None, None, C.byref(nu), env, stream)
+    torch.cuda.synchronize()
+    assert rc == 4, "expected WHOLEMEMORY_CUDA_ERROR from the call whose sort timed out, got %d" % rc
+    assert int(torch.count_nonzero(d_table)) == 0, "the step of a sort that reported a timeout touched the table"
+    # the error is reported once; without the stall the same call is served and right
+    knobs.unset("WM_DEBUG_STALL")
+    knobs.unset("WM_DEBUG_SPIN_LIMIT")
+    want, nu_want = _expect(ids, grads, rows, 0)
+    got, nu2 = _apply(ids, grads, rows, 0, np.int64)
+    assert nu2 == nu_want and got.tobytes() == want.tobytes()
+
+
+def test_a_timeout_of_an_unsynchronised_call_is_reported_by_the_next_one(gpu_env, knobs):
+    """Through the embedding API on one rank nothing synchronises (the reference returns with its kernels queued too): the call
+    whose sort timed out returns success, its step is NOT applied, and the next entry into the gradient path returns the error."""
+    import torch
+    import wholegraph_amd.torch as wgth
+    from wholegraph_amd import binding as wmb
+    rng = np.random.default_rng(5)
+    n_rows, dim, n = 4_000_000, 32, 80000
+    emb = wgth.create_embedding(gpu_env, "distributed", "cuda", torch.float32, [n_rows, dim])
+    opt = wgth.create_wholememory_optimizer(emb, "sgd", {})
+    local, _ = emb.get_embedding_tensor().get_local_tensor()
+    local.zero_()
+    ids = torch.from_numpy(rng.integers(0, n_rows, n).astype(np.int64)).cuda()
+    grads = torch.from_numpy(rng.standard_normal((n, dim)).astype(np.float32)).cuda()
+    knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+    knobs.set("WM_DEDUP_ADAPT", 0)
+    knobs.set("WM_DEBUG_SPIN_LIMIT", 3000)
+    knobs.set("WM_DEBUG_STALL", "lookback")
+    emb.add_gradients(ids, grads)
+    emb.need_apply = True
+    opt.step(1.0)                      # queued; the timeout happens on the device after the call has returned
+    torch.cuda.synchronize()
+    assert int(torch.count_nonzero(local)) == 0, "the step of a sort that reported a timeout touched the table"
+    knobs.unset("WM_DEBUG_STALL")
+    knobs.unset("WM_DEBUG_SPIN_LIMIT")
+    emb.add_gradients(ids, grads)
+    emb.need_apply = True
+    with pytest.raises(wmb.WholeMemoryError):
+        opt.step(1.0)
+    torch.cuda.synchronize()
+    # reported once: the step after that is applied (row -= 1.0 * sum of its gradients; -1 * g exact, one gradient per row mostly)
+    emb.add_gradients(ids, grads)
+    emb.need_apply = True
+    opt.step(1.0)
+    torch.cuda.synchronize()
+    assert int(torch.count_nonzero(local)) > 0
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)

@@ -266,6 +266,7 @@ PROTOTYPES = {
     "wholememory_ext_distributed_scatter_launches": (_i64, []),
     "wholememory_ext_gradient_exchange_launches": (_i64, []),
     "wholememory_ext_set_malloc_probe": (_i, [C.c_char_p]),
+    "wholememory_ext_get_malloc_probe": (_i, [C.c_char_p, C.c_size_t]),
     "wholememory_ext_handle_was_probed": (_i, [_vp]),
     "wholememory_ext_multilayer_sample": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wm_testing_install_backend": (_i, [_vp]),

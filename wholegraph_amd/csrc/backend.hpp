@@ -342,6 +342,11 @@ struct wm_device_backend {
   // are valid for work queued on `stream` either way. Both nullptr in a backend without such a side stream.
   void (*dedup_defer_join)(int on);
   int (*dedup_join)(void* stream);
+  // Device-side waits of the id sort that gave up (kernels/split_sort.cuh: wait_cfg) leave a code in pinned memory after
+  // turning their sort into "no runs". Returns and clears that code for the current device (0 = none; logs one ERROR line
+  // otherwise). Non-blocking: it reports what has FINISHED, so callers ask after they synchronise and when they are entered
+  // (dedup_ids and dedup_join ask too and fail with -2). nullptr in a backend without device-side waits.
+  int (*device_error)(void);
 };
 
 }  // extern "C"

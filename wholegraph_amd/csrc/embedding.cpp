@@ -88,13 +88,26 @@ int64_t align_embedding_dim(int64_t dim, size_t element_size)
   int64_t bytes = 0;   // 0 = auto
   if (const char* e = WM_KNOB("WM_EMBEDDING_ROW_ALIGN")) {
     const int64_t v = atoll(e);
-    if (e[0] == 'a' || e[0] == 'A') bytes = 0;
+    if (strcmp(e, "auto") == 0 || strcmp(e, "AUTO") == 0) bytes = 0;   // (exactly: "a..." anything used to pass, advisor)
     else if (v >= 16 && v <= 4096 && (v & (v - 1)) == 0) bytes = v;
     else WM_WARN("WM_EMBEDDING_ROW_ALIGN=%s ignored: auto or a power of two between 16 and 4096 is expected", e);
   }
+  const bool by_rule = bytes == 0;
   if (bytes == 0) bytes = padded(128) * 100 <= padded(16) * 108 ? 128 : 16;
-  const int64_t a = std::max<int64_t>(bytes / static_cast<int64_t>(element_size), 1);
-  return dim % a == 0 ? dim : (dim / a + 1) * a;
+  const int64_t a      = std::max<int64_t>(bytes / static_cast<int64_t>(element_size), 1);
+  const int64_t stride = dim % a == 0 ? dim : (dim / a + 1) * a;
+  // not a silent change of a default (advisor, round 5): the first table of a process whose stride differs from the
+  // reference's says so, once, with the way back
+  const int64_t ra = std::max<int64_t>(16 / static_cast<int64_t>(element_size), 1);
+  const int64_t reference_stride = dim % ra == 0 ? dim : (dim / ra + 1) * ra;
+  static std::atomic<bool> said{false};
+  if (by_rule && stride != reference_stride && !said.exchange(true))
+    WM_INFO("embedding rows of %ld elements are stored with a stride of %ld elements (whole 128-byte lines, +%.1f %% memory) "
+            "instead of the reference's %ld (16-byte padding): scatter and gradient apply write whole lines. Files are "
+            "unaffected. WM_EMBEDDING_ROW_ALIGN=16 restores the reference stride.",
+            static_cast<long>(dim), static_cast<long>(stride), 100.0 * (stride - reference_stride) / reference_stride,
+            static_cast<long>(reference_stride));
+  return stride;
 }
 
 int per_element_state_count(wholememory_optimizer_type_t t)
@@ -226,14 +239,18 @@ struct dedup_result {
   explicit dedup_result(wholememory_env_func_t* env) : unique_ids(env), run_starts(env), order(env), n_unique(env), ws(env) {}
   // join_later: the caller queues the optimizer step behind the sort and calls join() after it (the sort's side stream is
   // then joined behind the step instead of in front of it: backend.hpp, dedup_defer_join); the destructor joins in any case
-  ~dedup_result() { join(); }
-  void join()
+  ~dedup_result() { (void)join(); }
+  // 0, or the backend's error: the join is also where a device-side wait of the sort that gave up is reported (backend.hpp:
+  // device_error) — by then the sort has turned itself into "no runs", so the step behind it changed nothing
+  int join()
   {
+    int rc = 0;
     if (join_owed) {
       const auto* bk = backend();
-      if (bk->dedup_join != nullptr) (void)bk->dedup_join(deferred_on);
+      if (bk->dedup_join != nullptr) rc = bk->dedup_join(deferred_on);
       join_owed = false;
     }
+    return rc;
   }
   void run(const void* ids, wholememory_dtype_t index_dtype, int64_t n, int64_t key_upper_bound, void* stream,
            int64_t key_lower_bound = 0, bool join_later = false)
@@ -292,13 +309,16 @@ void step_sorted(dedup_result& r, wholememory_dtype_t index_dtype, int64_t n_rec
   oa->long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n_recv, oa->dim)), WHOLEMEMORY_DT_INT8);
   if (rows_ready != nullptr) WM_BK(bk->stream_wait_event(stream, rows_ready));
   int rc = bk->optimizer_step(oa, r.d_nunique, stream);
-  r.join();   // the sort's side stream, if it left one running: joined behind the step
+  const int join_rc = r.join();   // the sort's side stream, if it left one running: joined behind the step
   if (rc != 0) throw hip_error("optimizer_step failed");
+  if (join_rc != 0) throw hip_error("the id sort of an earlier gradient step reported a device-side timeout (see the ERROR line above)");
   if (n_unique_host != nullptr) {
     auto* h = static_cast<int64_t*>(host_n.pinned(1, WHOLEMEMORY_DT_INT64));
     WM_BK(bk->memcpy_async(h, r.d_nunique, sizeof(int64_t), stream));
     WM_BK(bk->stream_sync(stream));
     *n_unique_host = *h;
+    if (bk->device_error != nullptr && bk->device_error() != 0)   // (synchronised: this call's own sort has reported by now)
+      throw hip_error("the id sort of this gradient step reported a device-side timeout (see the ERROR line above)");
   }
 }
 
@@ -540,7 +560,12 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   // was ~0.1 ms of a 3.2 ms step). With several ranks the stream is drained before returning: a peer may read this shard
   // through its own mapping (CHUNKED / CONTINUOUS) right after the barrier that follows the step, and that barrier orders
   // hosts, not this stream.
-  if (e->comm->world_size > 1 || debug_sync_enabled()) WM_BK(bk->stream_sync(stream));
+  if (e->comm->world_size > 1 || debug_sync_enabled()) {
+    WM_BK(bk->stream_sync(stream));
+    // everything of this call has finished: a device-side wait that gave up is reported by THIS call (without the
+    // synchronise — one rank — by the next entry into the sort or its join)
+    if (bk->device_error != nullptr && bk->device_error() != 0) return WHOLEMEMORY_CUDA_ERROR;
+  }
   return WHOLEMEMORY_SUCCESS;
 }
 

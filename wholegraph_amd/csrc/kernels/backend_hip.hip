@@ -13,6 +13,7 @@ size_t hip_bucket_workspace_bytes(int64_t n, int world_size);
 int hip_bucket_ids(const wm_bucket_args* a, void* stream);
 void hip_dedup_defer_join(int on);
 int hip_dedup_join(void* stream);
+int hip_device_error();
 int hip_permute_chunks(const void* src, void* dst, int elt_bytes, const int64_t* seg_offsets, const int64_t* seg_counts, int n_segs,
                        int n_chunks, void* stream);
 size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype);
@@ -230,6 +231,7 @@ const wm_device_backend kHipBackend = {
   hip_permute_chunks,
   hip_dedup_defer_join,
   hip_dedup_join,
+  hip_device_error,
 };
 
 }  // namespace

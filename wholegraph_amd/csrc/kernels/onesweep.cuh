@@ -123,6 +123,7 @@ struct pass_args {
   const uint32_t* gate;      // device word: 0 = this sort is not needed, return at once (nullptr: always run)
   const uint32_t* hist;      // [passes][bins]
   uint32_t* ticket;          // [passes], then the error word at ticket[60]
+  uint32_t look_back_polls;  // how long a digit's look-back polls before it reports (error word) instead of hanging
   uint32_t* state;           // [passes][tiles][bins]
 };
 
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(BLOCK) void pass_kernel(KeyIt keys_in, pass_args a)
           unsigned spins = 0;
           while (((v = __hip_atomic_load(&prev[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 30) == 0u) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 26)) {   // never in a healthy run: report instead of hanging the device
+            if (++spins > a.look_back_polls) {   // never in a healthy run: report instead of hanging the device
               a.ticket[60] = 1u;
               v            = kFlagPrefix;
               break;
@@ -297,9 +298,17 @@ inline size_t ctrl_words_bound(int64_t n)
 // operator[] returning a 32-bit key). tk / tv: a second (keys, payloads) pair of n words each; ctrl: ctrl_words() words that
 // READ ZERO (the caller's business: one fill, or a kernel that runs before anyway). Enqueues 1 + passes kernels on `stream`,
 // every one gated on `gate` (see the file comment); returns 0 or a negative error.
+// the word (of ctrl) a pass sets when its look-back gave up: whoever consumes the sorted pairs must look at it (optim.hip
+// folds it into the split sort's error word in the generic path's closing kernel)
+template <int BLOCK, int IPT>
+inline uint32_t* error_word(uint32_t* ctrl, int64_t n, unsigned bits)
+{
+  return ctrl + make_plan(n, bits, BLOCK * IPT).ticket_off + 60;
+}
+
 template <int BLOCK, int IPT, typename KeyIt>
 int sort_pairs(KeyIt keys, uint32_t* keys_sorted, uint32_t* order, int64_t n, unsigned bits, uint32_t* tk, uint32_t* tv,
-               uint32_t* ctrl, const uint32_t* gate, hipStream_t stream)
+               uint32_t* ctrl, const uint32_t* gate, hipStream_t stream, uint32_t look_back_polls = 1u << 26)
 {
   if (n <= 0) return 0;
   if (n >= (INT64_C(1) << 30)) return -1;
@@ -319,6 +328,7 @@ int sort_pairs(KeyIt keys, uint32_t* keys_sorted, uint32_t* order, int64_t n, un
   pass_args a{};
   a.n = n, a.rb = p.radix_bits, a.tiles = p.tiles;
   a.gate = gate;
+  a.look_back_polls = look_back_polls;
   a.hist = ctrl + p.hist_off, a.ticket = ctrl + p.ticket_off, a.state = ctrl + p.state_off;
   const uint32_t* kin = nullptr;
   const uint32_t* vin = nullptr;

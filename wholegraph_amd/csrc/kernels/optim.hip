@@ -87,6 +87,7 @@ END_ROCPRIM_NAMESPACE
 
 #include "../knobs.hpp"
 #include "../backend.hpp"
+#include "../wm_common.hpp"
 #include "device_common.cuh"
 #include "onesweep.cuh"
 #include "split_sort.cuh"
@@ -355,6 +356,18 @@ inline int64_t split_min()
 // call in profiles/r05_grad_timeline_serial.txt). They depend on nothing but the overflow word (known after the split sort's
 // SECOND kernel), so they go to a side stream that forks there and joins after the split sort's last kernel: idle, they hide
 // under its two long kernels; when the batch overflowed, those two return at once and the caller's stream waits for the side.
+constexpr int kMaxDevices = 64;
+template <typename Lane>
+Lane& per_device()
+{
+  static std::mutex mu;
+  static Lane* lanes[kMaxDevices] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (lanes[dev] == nullptr) lanes[dev] = new Lane();
+  return *lanes[dev];
+}
 struct sort_lane {
   std::mutex mu;   // one fork .. join sequence at a time: the events are shared
   hipStream_t stream = nullptr, stream_high = nullptr;
@@ -406,8 +419,33 @@ struct sort_lane {
     adapt_flags[i] = 0;
     return i;
   }
+  // Device-side waits that gave up (split_sort.cuh: wait_cfg) leave their code in this word of pinned, device-mapped host
+  // memory — split_join_kernel ORs it in after it has turned the failed sort into "no runs", split_wait_kernel when it stops
+  // waiting. The host looks at it (take_error) whenever it enters the sort or the join and after every synchronise of the
+  // gradient path (backend: device_error): a stalled wait becomes WHOLEMEMORY_CUDA_ERROR with one ERROR line, never a step
+  // applied over runs that were not final.
+  volatile uint32_t* host_err = nullptr;   // pinned
+  uint32_t* host_err_dev      = nullptr;   // the same word as the device addresses it
+  uint32_t take_error()
+  {
+    if (host_err == nullptr) return 0;
+    const uint32_t e = *host_err;
+    if (e != 0) *host_err = 0;
+    return e;
+  }
   sort_lane()
   {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
+      void* d = nullptr;
+      if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+        host_err     = static_cast<volatile uint32_t*>(h);
+        *host_err    = 0;
+        host_err_dev = static_cast<uint32_t*>(d);
+      } else {
+        (void)hipHostFree(h);
+      }
+    }
     // two streams, plain and highest priority; WM_DEDUP_LANE_PRIO=n|h picks one per call (see side())
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -425,11 +463,9 @@ struct sort_lane {
       }
     }
   }
-  static sort_lane& get()
-  {
-    static sort_lane lane;
-    return lane;
-  }
+  // one lane per DEVICE (round 6; a process-wide one put device 0's streams, ring and events under device 1's kernels): created
+  // on the device that is current at the first call that needs it there, kept for the life of the process
+  static sort_lane& get() { return per_device<sort_lane>(); }
 };
 // Kernels that wait for a word another stream's kernel sets (split_wait_kernel, split_join_kernel) need that other kernel to be
 // able to RUN beside them. A tool that lets one kernel execute at a time — rocprofv3's counter collection does, and not in
@@ -442,6 +478,21 @@ inline bool device_waits_allowed()
   if (e != nullptr) return e[0] != '0';
   return WM_KNOB("ROCPROF_COUNTER_COLLECTION") == nullptr && WM_KNOB("ROCPROF_COUNTERS") == nullptr;
 }
+// limits of the device-side waits (split_sort.cuh: wait_cfg). WM_DEBUG_SPIN_LIMIT=n shortens every one of them to n polls and
+// WM_DEBUG_STALL=lookback|join keeps a gate shut (a stage-2 bucket that never publishes / a generic path that never reports
+// done): tests/test_dedup_split_gpu.py forces each timeout and sees the error code and an untouched table.
+inline split::wait_cfg wait_limits(const split::plan* sp = nullptr)
+{
+  split::wait_cfg wc;
+  if (const char* e = WM_KNOB("WM_DEBUG_SPIN_LIMIT")) {
+    const long long v = atoll(e);
+    if (v > 0 && v < (1ll << 31)) wc.look_back_polls = wc.join_polls = wc.wait_polls = static_cast<uint32_t>(v);
+  }
+  const char* st = WM_KNOB("WM_DEBUG_STALL");
+  if (st != nullptr && st[0] == 'l' && sp != nullptr) wc.stall_bucket = sp->buckets / 2;
+  return wc;
+}
+inline bool stall_join() { const char* st = WM_KNOB("WM_DEBUG_STALL"); return st != nullptr && st[0] == 'j'; }
 std::atomic<int64_t> g_split_sorts{0};
 // The optimizer step that follows a split sort on the same thread finds the sort's control words through the run_starts array
 // both were given: its long-run counters live there (zeroed by the sort's first kernel: no fill in front of the step), and
@@ -514,15 +565,19 @@ dedup_layout<SortKeyT> layout(void* ws, int64_t n)
   return l;
 }
 
-__global__ void set_word_kernel(uint32_t* word, uint32_t value)
+// closing kernel of the generic path behind a split sort: "done" for split_join_kernel — after the onesweep passes' error word
+// (a look-back that gave up) has been folded into the split sort's, which is the one the join kernel reports
+__global__ void set_word_kernel(uint32_t* word, uint32_t value, const uint32_t* osw_error, uint32_t* ctl_error)
 {
-  __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (osw_error != nullptr && *osw_error != 0u) atomicOr(ctl_error, static_cast<uint32_t>(split::kErrOnesweep));
+  __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <typename SortKeyT, typename OutT>
 int detect_runs(const SortKeyT* sorted, int32_t* tile_counts, int64_t n, OutT* unique_ids, int32_t* run_starts,
                 int64_t* n_unique_out, hipStream_t stream, OutT key_base = 0, bool drop_last = false, SortKeyT drop_key = 0,
-                const uint32_t* gate = nullptr, uint32_t* done_word = nullptr)
+                const uint32_t* gate = nullptr, uint32_t* done_word = nullptr, const uint32_t* osw_error = nullptr,
+                uint32_t* ctl_error = nullptr)
 {
   const int tiles = run_tiles(n);
   const uint32_t* last_key = nullptr;
@@ -539,7 +594,8 @@ int detect_runs(const SortKeyT* sorted, int32_t* tile_counts, int64_t n, OutT* u
   // the generic path behind a split sort, joined on the device: one more (tiny) kernel says so when everything above has
   // finished — the end of a kernel makes its writes visible; a fence + counter per block of the kernel above made that kernel
   // 302 us instead of 18
-  if (done_word != nullptr) hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, stream, done_word, 1u);
+  if (done_word != nullptr)
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, stream, done_word, 1u, osw_error, ctl_error);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -597,6 +653,8 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
       // (WM_DEDUP_SERIAL=1: on the caller's stream, for measurements)
       const uint32_t* gate = split::overflow_word(sp, sl.split_ws);
       char* sw             = static_cast<char*>(sl.split_ws);
+      uint32_t* ctl        = reinterpret_cast<uint32_t*>(sw + sp.off_ctl);
+      const split::wait_cfg wc = wait_limits(&sp);
       narrow_key_iterator<UKey> keys{static_cast<const UKey*>(ids), static_cast<UKey>(key_lower_bound), static_cast<uint32_t>(span)};
       const bool serial = WM_KNOB("WM_DEDUP_SERIAL") != nullptr;
       std::unique_lock<std::mutex> lane_lock;
@@ -605,13 +663,14 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
       auto generic = [&](hipStream_t gs) {
         generic_rc = osw::sort_pairs<kOswBlock, kOswIpt>(keys, sl.sorted, reinterpret_cast<uint32_t*>(order), n, bits,
                                                          reinterpret_cast<uint32_t*>(sw + sp.off_keys),
-                                                         reinterpret_cast<uint32_t*>(sw + sp.off_pos), sl.osw_ctrl, gate, gs);
+                                                         reinterpret_cast<uint32_t*>(sw + sp.off_pos), sl.osw_ctrl, gate, gs,
+                                                         WM_KNOB("WM_DEBUG_SPIN_LIMIT") != nullptr ? wc.look_back_polls : 1u << 26);
         if (generic_rc == 0)
           generic_rc = detect_runs<uint32_t, UKey>(sl.sorted, sl.tile_counts, n, static_cast<UKey*>(unique_ids), run_starts,
                                                    n_unique_out, gs, static_cast<UKey>(key_lower_bound), true,
                                                    static_cast<uint32_t>(span), gate,
-                                                   reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl) +
-                                                     split::kCtlGenericDone);
+                                                   stall_join() ? nullptr : ctl + split::kCtlGenericDone,
+                                                   osw::error_word<kOswBlock, kOswIpt>(sl.osw_ctrl, n, bits), ctl + split::kCtlError);
       };
       bool forked = false;
       uint32_t* verdict_word = nullptr;
@@ -631,7 +690,7 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
         sort_lane& lane = sort_lane::get();
         if (verdict_word != nullptr) {
           hipLaunchKernelGGL(split::split_wait_kernel, dim3(1), dim3(64), 0, lane.side(), verdict_word, verdict_value,
-                             reinterpret_cast<uint32_t*>(sw + sp.off_ctl) + split::kCtlError);
+                             ctl + split::kCtlError, wc.wait_polls, lane.host_err_dev);
           forked = hipGetLastError() == hipSuccess;
           if (!forked) {   // (the caller's kernels and the join kernel are queued already: nothing of the generic path behind them)
             generic_rc = -2;
@@ -656,27 +715,27 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
       const int launched =
         side_last ? split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
                                         static_cast<uint32_t>(span), unique_ids, run_starts, order, n_unique_out, sl.split_ws,
-                                        sl.osw_ctrl, zero_n, stream, nothing, false, verdict_word, verdict_value)
+                                        sl.osw_ctrl, zero_n, stream, nothing, false, verdict_word, verdict_value, wc)
                   : split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
                                         static_cast<uint32_t>(span), unique_ids, run_starts, order, n_unique_out, sl.split_ws,
-                                        sl.osw_ctrl, zero_n, stream, between, after_scatter, verdict_word, verdict_value);
+                                        sl.osw_ctrl, zero_n, stream, between, after_scatter, verdict_word, verdict_value, wc);
       if (launched != 0) return -2;
       // (every wave that waits is enqueued BEHIND the kernel it waits for — the side stream's behind the split sort's kernels,
       // the join kernel behind the side stream's last — so that even one in-order hardware queue makes progress)
       if (side_last) between();
       const bool defer = g_defer_join && waits_ok && forked;
-      if (defer) {
-        hipLaunchKernelGGL(split::split_join_kernel, dim3(1), dim3(64), 0, stream,
-                           reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl), 1u);   // (set by detect_runs' closing kernel)
-        g_join_pending = true;
-      } else if (forked && hipStreamWaitEvent(stream, sort_lane::get().joined, 0) != hipSuccess) {
-        return -2;
-      }
+      if (!defer && forked && hipStreamWaitEvent(stream, sort_lane::get().joined, 0) != hipSuccess) return -2;
+      // the sort's LAST kernel on the caller's stream, whichever way the side stream is joined: waits for the generic path when
+      // the join is deferred and the batch overflowed (1 = what detect_runs' closing kernel sets), and turns any wait of this
+      // sort that gave up into "no runs" + an error word the host will see (split_sort.cuh: split_join_kernel)
+      hipLaunchKernelGGL(split::split_join_kernel, dim3(1), dim3(64), 0, stream, ctl, 1u, wc.join_polls, n_unique_out,
+                         sort_lane::get().host_err_dev);
+      if (defer) g_join_pending = true;
       g_split_sorts.fetch_add(1, std::memory_order_relaxed);
       g_last_split.run_starts = run_starts;
       g_last_split.unique_ids = unique_ids;
       g_last_split.n_unique   = n_unique_out;
-      g_last_split.ctl        = reinterpret_cast<uint32_t*>(static_cast<char*>(sl.split_ws) + sp.off_ctl);
+      g_last_split.ctl        = ctl;
       return generic_rc;
     }
   }
@@ -1611,6 +1670,12 @@ __global__ void mark_long_runs_kernel(opt_params p)
   if (p.split_ctl != nullptr && p.split_ctl[split::kCtlOverflow] == 0 && p.split_ctl[split::kCtlRadixBuckets] == 0 &&
       p.long_threshold >= split::kMaxDup)
     return;
+  // detached side (its stream is ordered behind the sort only by a wave that waits for "runs are final"): list nothing unless
+  // that word says FINAL — not after a wait that gave up (0) and not after a sort that reported a timeout (2). The long-run
+  // kernels behind this one then find an empty list.
+  if (p.detached_side != 0 && p.split_ctl != nullptr &&
+      __hip_atomic_load(&p.split_ctl[split::kCtlSortDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
+    return;
   const wm_optimizer_args& a = p.a;
   const int64_t count        = p.n_unique ? *p.n_unique : a.count;
   const IdxT* ids            = static_cast<const IdxT*>(a.ids);
@@ -1646,11 +1711,7 @@ struct long_lane {
          hipEventCreateWithFlags(&marked, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess;
   }
-  static long_lane& get()
-  {
-    static long_lane lane;
-    return lane;
-  }
+  static long_lane& get() { return per_device<long_lane>(); }   // one per device, as sort_lane
   bool fork(hipStream_t from)
   {
     return ok && hipEventRecord(forked, from) == hipSuccess && hipStreamWaitEvent(stream, forked, 0) == hipSuccess;
@@ -1693,7 +1754,8 @@ inline void wait_for_final_runs(const opt_params& p, hipStream_t lstream)
 {
   if (p.detached_side)
     hipLaunchKernelGGL(split::split_wait_kernel, dim3(1), dim3(64), 0, lstream, p.split_ctl + split::kCtlSortDone, 1u,
-                       const_cast<uint32_t*>(p.split_ctl) + split::kCtlError);
+                       const_cast<uint32_t*>(p.split_ctl) + split::kCtlError, wait_limits().wait_polls,
+                       sort_lane::get().host_err_dev);
 }
 
 template <typename IdxT>
@@ -1790,6 +1852,12 @@ __global__ __launch_bounds__(256) void tree_mark_kernel(opt_params p, tree_ws_vi
   // (no bucket of the split sort held a run of more than kMaxDup ids: nothing to list)
   if (p.split_ctl != nullptr && p.split_ctl[split::kCtlOverflow] == 0 && p.split_ctl[split::kCtlRadixBuckets] == 0 &&
       threshold >= split::kMaxDup)
+    return;
+  // detached side (its stream is ordered behind the sort only by a wave that waits for "runs are final"): list nothing unless
+  // that word says FINAL — not after a wait that gave up (0) and not after a sort that reported a timeout (2). The long-run
+  // kernels behind this one then find an empty list.
+  if (p.detached_side != 0 && p.split_ctl != nullptr &&
+      __hip_atomic_load(&p.split_ctl[split::kCtlSortDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
     return;
   const wm_optimizer_args& a = p.a;
   const int64_t count        = p.n_unique ? *p.n_unique : a.count;
@@ -2232,11 +2300,25 @@ void hip_dedup_defer_join(int on)
   const char* e = WM_KNOB("WM_DEDUP_DEFER_JOIN");   // =0: the side stream is joined in front of the step again (A/B switch)
   g_defer_join  = on != 0 && !(e != nullptr && e[0] == '0');
 }
+// A device-side wait of an earlier sort gave up (sort_lane::host_err): say so ONCE, as an error. Non-blocking — what it sees is
+// what has finished; callers that synchronise (the multi-rank gradient apply, WM_DEBUG_SYNC=1) ask again afterwards.
+int hip_device_error()
+{
+  const uint32_t e = sort_lane::get().take_error();
+  if (e == 0) return 0;
+  WM_ERROR("a device-side wait of the gradient path's id sort timed out (code 0x%x:%s%s%s%s): the optimizer step of that call was "
+           "NOT applied (its run count was zeroed on the device). A tool that runs one kernel at a time (counter collection, some "
+           "debuggers) stalls these waits: set WM_DEVICE_WAITS=0 for event-only synchronisation.",
+           e, (e & split::kErrLookBack) ? " bucket look-back" : "", (e & split::kErrJoin) ? " join of the generic sort" : "",
+           (e & split::kErrWait) ? " side-stream wait" : "", (e & split::kErrOnesweep) ? " radix-pass look-back" : "");
+  return static_cast<int>(e);
+}
 int hip_dedup_join(void* stream_v)
 {
-  if (!g_join_pending) return 0;
+  if (!g_join_pending) return hip_device_error() != 0 ? -2 : 0;
   g_join_pending = false;
-  return hipStreamWaitEvent(static_cast<hipStream_t>(stream_v), sort_lane::get().joined, 0) == hipSuccess ? 0 : -2;
+  if (hipStreamWaitEvent(static_cast<hipStream_t>(stream_v), sort_lane::get().joined, 0) != hipSuccess) return -2;
+  return hip_device_error() != 0 ? -2 : 0;
 }
 
 size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype)
@@ -2246,7 +2328,10 @@ size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype)
   // the 64-bit layout alone can be the smaller one)
   size_t most = layout<uint32_t>(nullptr, n).total;
   if (index_dtype != WHOLEMEMORY_DT_INT) most = std::max(most, layout<uint64_t>(nullptr, n).total);
-  if (n < (INT64_C(1) << 30)) most = std::max(most, split_carve(nullptr, n).total);
+  // (only batches that can take the split sort: its layout has a fixed ~17 MB term — kMaxTiles x kMaxPitch counters — that a
+  // mini-batch of a few hundred ids would otherwise ask the caller's allocator for on every call; run_dedup tests the same
+  // two conditions before it carves that layout: advisor, round 5)
+  if (n < (INT64_C(1) << 30) && n >= split_min()) most = std::max(most, split_carve(nullptr, n).total);
   return most;
 }
 

@@ -84,6 +84,19 @@ constexpr uint32_t kFlagAggregate = 1u << 30, kFlagPrefix = 2u << 30, kValueMask
 // waits for this word instead of an event on the caller's stream (optim.hip: the detached long-run side)
 enum { kCtlOverflow = 0, kCtlTicket = 1, kCtlError = 2, kCtlRadixBuckets = 3, kCtlGenericDone = 4, kCtlSortDone = 5, kCtlScanCount = 6, kCtlLongCounters = 16, kCtlWords = 32 };
 
+// How long the waiting waves of this file poll before they give up and REPORT instead of hanging the device, in polls. A
+// timeout sets ctl[kCtlError]; split_join_kernel (always the last kernel of a sort on the caller's stream) turns that into
+// "no runs" (*n_unique = 0: the optimizer step that follows leaves the table alone) and a word in pinned host memory that the
+// host looks at when it next synchronises or enters the library (optim.hip: sort_lane::take_error): a stall is an ERROR CODE,
+// never a silently wrong step. stall_bucket (tests only, WM_DEBUG_STALL=lookback): the bucket of stage 2 that never publishes.
+struct wait_cfg {
+  uint32_t look_back_polls = 1u << 24;   // x ~0.3 us: a bucket takes 20 us, its predecessors a few rounds of that
+  uint32_t join_polls      = 1u << 24;   // x 3.4 us = about a minute (the generic path takes well under a second)
+  uint32_t wait_polls      = 1u << 25;   // x 1.7 us = about a minute (round 5: 2^31 = an hour)
+  int stall_bucket         = -1;
+};
+enum { kErrLookBack = 1u, kErrJoin = 2u, kErrWait = 4u, kErrOnesweep = 8u };
+
 struct plan {
   bool ok;            // false: the batch does not suit the split sort (too many ids per bucket, too many key bits)
   int shift;          // low key bits (ordered in LDS); bucket = key >> shift
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(kBlock, MAXIPT <= 12 ? 8 : 4) void split_scatter_ke
 
 // ---- stage 2: per-bucket order in LDS + run detection --------------------------------------------------------------------
 // wave-wide decoupled look-back over the run counts of the buckets before `b`; called by wave 0, returns the exclusive prefix
-__device__ __forceinline__ uint32_t look_back(uint32_t* state, int b, uint32_t* ctl)
+__device__ __forceinline__ uint32_t look_back(uint32_t* state, int b, uint32_t* ctl, const wait_cfg& wc)
 {
   const int lane = threadIdx.x & 63;
   uint32_t excl  = 0;
@@ -479,8 +492,8 @@ __device__ __forceinline__ uint32_t look_back(uint32_t* state, int b, uint32_t* 
     if (done) break;
     if (stalled) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 24)) {   // never in a healthy run: report instead of hanging the device
-        if (lane == 0) ctl[kCtlError] = 1u;
+      if (++spins > wc.look_back_polls) {   // never in a healthy run: report instead of hanging the device
+        if (lane == 0) atomicOr(&ctl[kCtlError], static_cast<uint32_t>(kErrLookBack));
         break;
       }
     }
@@ -488,8 +501,9 @@ __device__ __forceinline__ uint32_t look_back(uint32_t* state, int b, uint32_t* 
   return excl;
 }
 
-__device__ __forceinline__ void publish(uint32_t* state, int b, uint32_t flag, uint32_t value)
+__device__ __forceinline__ void publish(const wait_cfg& wc, uint32_t* state, int b, uint32_t flag, uint32_t value)
 {
+  if (b == wc.stall_bucket) return;   // (tests: a gate that never opens)
   __hip_atomic_store(&state[b], flag | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -498,7 +512,8 @@ template <typename OutT, int CAPBITS>
 __global__ __launch_bounds__((1 << CAPBITS) / kSortIpt, 8) void split_sort_kernel(const uint32_t* keys, const uint32_t* pos,
                                                                const uint32_t* bucket_start, int buckets, int shift, int passes,
                                                                int digit_bits, int pos_passes, int pos_digit_bits, OutT key_base, OutT* unique_ids, int32_t* run_starts,
-                                                               int32_t* order, int64_t* n_unique, uint32_t* ctl, uint32_t* state)
+                                                               int32_t* order, int64_t* n_unique, uint32_t* ctl, uint32_t* state,
+                                                               wait_cfg wc)
 {
   if (ctl[kCtlOverflow] != 0) return;
   constexpr int CAP = 1 << CAPBITS, BLOCK = CAP / kSortIpt, WAVES = BLOCK / 64;
@@ -522,7 +537,7 @@ __global__ __launch_bounds__((1 << CAPBITS) / kSortIpt, 8) void split_sort_kerne
     // the drop bucket: positions of the ids outside the range fill the tail of order[]; then the totals
     for (int i = threadIdx.x; i < m; i += BLOCK) order[start + i] = static_cast<int32_t>(pos[start + i]);
     if (wv == 0) {
-      const uint32_t total = look_back(state, buckets, ctl);
+      const uint32_t total = look_back(state, buckets, ctl, wc);
       if (lane == 0) {
         *n_unique         = static_cast<int64_t>(total);
         run_starts[total] = static_cast<int32_t>(start);
@@ -533,10 +548,10 @@ __global__ __launch_bounds__((1 << CAPBITS) / kSortIpt, 8) void split_sort_kerne
   if (m == 0) {
     // an empty bucket still takes its place in the chain
     if (wv == 0) {
-      if (lane == 0) publish(state, b, b == 0 ? kFlagPrefix : kFlagAggregate, 0u);
+      if (lane == 0) publish(wc, state, b, b == 0 ? kFlagPrefix : kFlagAggregate, 0u);
       if (b > 0) {
-        const uint32_t excl = look_back(state, b, ctl);
-        if (lane == 0) publish(state, b, kFlagPrefix, excl);
+        const uint32_t excl = look_back(state, b, ctl, wc);
+        if (lane == 0) publish(wc, state, b, kFlagPrefix, excl);
       }
     }
     return;
@@ -593,7 +608,7 @@ __global__ __launch_bounds__((1 << CAPBITS) / kSortIpt, 8) void split_sort_kerne
         if (q < wpt && w0 + q < map_words) s_pre[w0 + q] = ex, ex += c[q];
     }
     // the bucket's run count is known: tell the buckets behind this one now, look back later
-    if (threadIdx.x == 0) publish(state, b, b == 0 ? kFlagPrefix : kFlagAggregate, heads_total);
+    if (threadIdx.x == 0) publish(wc, state, b, b == 0 ? kFlagPrefix : kFlagAggregate, heads_total);
     published = true;
     __syncthreads();
     WM_SPLIT_T(1, blockIdx.x, 3);
@@ -653,9 +668,9 @@ __global__ __launch_bounds__((1 << CAPBITS) / kSortIpt, 8) void split_sort_kerne
       __syncthreads();
       WM_SPLIT_T(1, blockIdx.x, 7);
       if (wv == 0) {
-        const uint32_t excl = look_back(state, b, ctl);
+        const uint32_t excl = look_back(state, b, ctl, wc);
         if (lane == 0) {
-          if (b > 0) publish(state, b, kFlagPrefix, excl + heads_total);
+          if (b > 0) publish(wc, state, b, kFlagPrefix, excl + heads_total);
           s_misc[1] = excl;
         }
       }
@@ -791,10 +806,10 @@ __global__ __launch_bounds__((1 << CAPBITS) / kSortIpt, 8) void split_sort_kerne
     if (threadIdx.x < kSortIpt * WAVES) s_hc[threadIdx.x] = hx;
     __syncthreads();
     if (wv == 0) {
-      if (lane == 0 && !published) publish(state, b, b == 0 ? kFlagPrefix : kFlagAggregate, ht);
-      const uint32_t excl = look_back(state, b, ctl);
+      if (lane == 0 && !published) publish(wc, state, b, b == 0 ? kFlagPrefix : kFlagAggregate, ht);
+      const uint32_t excl = look_back(state, b, ctl, wc);
       if (lane == 0) {
-        if (b > 0) publish(state, b, kFlagPrefix, excl + ht);
+        if (b > 0) publish(wc, state, b, kFlagPrefix, excl + ht);
         s_misc[1] = excl;
       }
     }
@@ -821,7 +836,8 @@ struct no_hook {
 template <typename UKey, typename Hook = no_hook>
 int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint32_t span, void* unique_ids, int32_t* run_starts,
            int32_t* order, int64_t* n_unique, void* workspace, uint32_t* zero_words, int64_t n_zero_words, hipStream_t stream,
-           Hook between = Hook(), bool hook_after_scatter = false, uint32_t* verdict_word = nullptr, uint32_t verdict_value = 0)
+           Hook between = Hook(), bool hook_after_scatter = false, uint32_t* verdict_word = nullptr, uint32_t verdict_value = 0,
+           const wait_cfg& wc = wait_cfg())
 {
   char* ws         = static_cast<char*>(workspace);
   uint32_t* keys   = reinterpret_cast<uint32_t*>(ws + p.off_keys);
@@ -858,18 +874,21 @@ int launch(const plan& p, const UKey* ids, int64_t n, UKey key_lower_bound, uint
   if (p.cap_bits == kCapBitsSmall)
     hipLaunchKernelGGL((split_sort_kernel<UKey, kCapBitsSmall>), dim3(p.buckets + 1), dim3((1 << kCapBitsSmall) / kSortIpt), 0, stream,
                        keys, pos, starts, p.buckets, p.shift, p.passes, p.digit_bits, p.pos_passes, p.pos_digit_bits, key_lower_bound,
-                       static_cast<UKey*>(unique_ids), run_starts, order, n_unique, ctl, state);
+                       static_cast<UKey*>(unique_ids), run_starts, order, n_unique, ctl, state, wc);
   else
     hipLaunchKernelGGL((split_sort_kernel<UKey, kCapBitsBig>), dim3(p.buckets + 1), dim3((1 << kCapBitsBig) / kSortIpt), 0, stream,
                        keys, pos, starts, p.buckets, p.shift, p.passes, p.digit_bits, p.pos_passes, p.pos_digit_bits, key_lower_bound,
-                       static_cast<UKey*>(unique_ids), run_starts, order, n_unique, ctl, state);
+                       static_cast<UKey*>(unique_ids), run_starts, order, n_unique, ctl, state, wc);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// The caller's stream after the split sort, when the generic path runs on a side stream and is NOT joined by an event before
-// the step (optim.hip: deferred join): one wave that returns at once in the usual case and, when the batch overflowed, waits
-// until every block of the generic path's last kernel has counted itself in.
-__global__ void split_join_kernel(uint32_t* ctl, uint32_t expected_blocks)
+// The LAST kernel of a sort on the caller's stream: one wave that returns at once in the usual case. When the generic path
+// runs on a side stream and is not joined by an event before the step (optim.hip: deferred join) and the batch overflowed, it
+// waits until the generic path's closing kernel has counted itself in. Then it publishes "the runs are final" — or, when any
+// wait of this sort timed out (ctl[kCtlError], which the generic path's closing kernel also folds the onesweep passes' word
+// into), "the sort FAILED": kCtlSortDone = 2, *n_unique = 0 (every consumer reads its run count there: the step that follows
+// does nothing) and the code in *host_err (pinned host memory; optim.hip reports it at the next synchronise / entry).
+__global__ void split_join_kernel(uint32_t* ctl, uint32_t expected_blocks, uint32_t join_polls, int64_t* n_unique, uint32_t* host_err)
 {
   if (ctl[kCtlOverflow] != 0) {
     // (RELAXED polls, far apart: an acquire at agent scope invalidates cache lines on every poll, and the kernels this wave is
@@ -877,27 +896,39 @@ __global__ void split_join_kernel(uint32_t* ctl, uint32_t expected_blocks)
     unsigned spins = 0;
     while (__hip_atomic_load(&ctl[kCtlGenericDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected_blocks) {
       __builtin_amdgcn_s_sleep(127);   // ~8 k cycles = 3.4 us between polls
-      if (++spins > (1u << 26)) {   // never in a healthy run (the generic path takes well under a second): report, do not hang
-        if (threadIdx.x == 0) ctl[kCtlError] = 2u;
+      if (++spins > join_polls) {   // never in a healthy run: report, do not hang
+        if (threadIdx.x == 0) atomicOr(&ctl[kCtlError], static_cast<uint32_t>(kErrJoin));
         break;
       }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
   }
-  // the runs are final: everything that wrote them has finished before this kernel (stream order, or the wait above)
-  if (threadIdx.x == 0) __hip_atomic_store(&ctl[kCtlSortDone], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    const uint32_t err = __hip_atomic_load(&ctl[kCtlError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (err != 0) {
+      if (n_unique != nullptr) *n_unique = 0;
+      if (host_err != nullptr) __hip_atomic_fetch_or(host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // the runs are final: everything that wrote them has finished before this kernel (stream order, or the wait above)
+    __hip_atomic_store(&ctl[kCtlSortDone], err != 0 ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // A side stream's way to wait for a word another stream's kernel sets (no event on that stream: an event record between two
-// kernels of the caller's stream costs ~7 us of its critical path). One wave, polling far apart.
-__global__ void split_wait_kernel(const uint32_t* word, uint32_t value, uint32_t* error_word)
+// kernels of the caller's stream costs ~7 us of its critical path). One wave, polling far apart. A timeout (about a minute: the
+// kernel waited for was SUBMITTED before this one, so only a tool that runs one kernel at a time, out of submission order, can
+// get here — optim.hip: device_waits_allowed) goes to error_word and to *host_err.
+__global__ void split_wait_kernel(const uint32_t* word, uint32_t value, uint32_t* error_word, uint32_t wait_polls, uint32_t* host_err)
 {
   unsigned spins = 0;
   // (signed distance: the words of a ring are re-used with growing values, a stale one is "before")
   while (static_cast<int32_t>(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
     __builtin_amdgcn_s_sleep(63);
-    if (++spins > (1u << 31)) {   // about an hour: what an event wait would do is wait for ever
-      if (threadIdx.x == 0) *error_word = 3u;
+    if (++spins > wait_polls) {
+      if (threadIdx.x == 0) {
+        atomicOr(error_word, static_cast<uint32_t>(kErrWait));
+        if (host_err != nullptr) __hip_atomic_fetch_or(host_err, static_cast<uint32_t>(kErrWait), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       break;
     }
   }

@@ -204,17 +204,24 @@ void alloc_local(wholememory_handle_* h)
     const char* we    = WM_KNOB("WM_MALLOC_PROBE_LOCK_WAIT_S");
     const int wait_s  = we != nullptr && atoi(we) >= 0 ? atoi(we) : 120;
     bool locked       = false;
+    int lock_errno    = 0;   // a real flock failure (ENOLCK, EBADF ...), as opposed to "somebody else holds it"
     for (int tenth = 0; tenth <= wait_s * 10; tenth++) {
       if (flock(lock_fd, LOCK_EX | LOCK_NB) == 0) {
         locked = true;
         break;
       }
-      if (errno != EWOULDBLOCK && errno != EINTR) break;
+      if (errno != EWOULDBLOCK && errno != EINTR) {
+        lock_errno = errno;
+        break;
+      }
       usleep(100000);
     }
     if (!locked) {
-      WM_WARN("wholememory_malloc: the probe lock %s stayed busy for %d s (a stopped process?): probing without it", lock_path,
-              wait_s);
+      if (lock_errno != 0)
+        WM_WARN("wholememory_malloc: flock(%s) failed: %s — probing without the lock", lock_path, strerror(lock_errno));
+      else
+        WM_WARN("wholememory_malloc: the probe lock %s stayed busy for %d s (a stopped process?): probing without it", lock_path,
+                wait_s);
       close(lock_fd);
       lock_fd = -1;
     }
@@ -666,6 +673,16 @@ extern "C" wholememory_error_code_t wholememory_ext_set_malloc_probe(const char*
   if (!m.empty() && !(m == "auto" || m == "0" || (m.size() == 1 && m[0] >= '1' && m[0] <= '8'))) return WHOLEMEMORY_INVALID_INPUT;
   std::lock_guard<std::mutex> lk(wm::g_probe_mode_mutex);
   wm::g_probe_mode = m;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+// the mode wholememory_ext_set_malloc_probe left ("env" when none is set), so that a caller that sets one for a single
+// allocation can put back what the application had chosen before (advisor, round 5)
+extern "C" wholememory_error_code_t wholememory_ext_get_malloc_probe(char* mode, size_t capacity)
+{
+  if (mode == nullptr || capacity < 8) return WHOLEMEMORY_INVALID_INPUT;
+  std::lock_guard<std::mutex> lk(wm::g_probe_mode_mutex);
+  snprintf(mode, capacity, "%s", wm::g_probe_mode.empty() ? "env" : wm::g_probe_mode.c_str());
   return WHOLEMEMORY_SUCCESS;
 }
 

@@ -266,14 +266,18 @@ def create_embedding(comm: WholeMemoryCommunicator, memory_type: str, memory_loc
     (about 20 %, for the table's lifetime). Holds the candidates transiently (at most a quarter of the
     free memory)."""
     rows, dim = sizes                                            # exactly two dimensions
+    previous = None
     if placement_probe is not None:
+        buf = C.create_string_buffer(16)
+        wmb.check(wmb.lib().wholememory_ext_get_malloc_probe(buf, len(buf)))
+        previous = buf.value                     # what the application had set before (or b"env"): put back afterwards
         wmb.check(wmb.lib().wholememory_ext_set_malloc_probe(str(placement_probe).encode()))
     try:
         return _create_embedding(comm, memory_type, memory_location, dtype, rows, dim, cache_policy, embedding_entry_partition,
                                  random_init, gather_sms, round_robin_size)
     finally:
-        if placement_probe is not None:
-            wmb.check(wmb.lib().wholememory_ext_set_malloc_probe(b"env"))
+        if previous is not None:                 # (never raises: an error here would mask the one from the creation)
+            wmb.lib().wholememory_ext_set_malloc_probe(previous)
 
 
 def _create_embedding(comm, memory_type, memory_location, dtype, rows, dim, cache_policy, embedding_entry_partition, random_init,
