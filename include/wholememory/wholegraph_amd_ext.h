@@ -225,6 +225,17 @@ int64_t wholememory_ext_distributed_scatter_launches(void);
  * nothing per chunk: rows arrive in rank-major order, which is the order of the fp32 sum of duplicates. A counter for tests. */
 int64_t wholememory_ext_gradient_exchange_launches(void);
 
+/* Bytes this process has handed to the all-to-all-v transport for OTHER ranks so far (ids and rows of every distributed op;
+ * this rank's own segment counts where it travels like a peer's: WM_EXCHANGE_SELF=1). A counter for tests and for the
+ * first-contact report: the sender-side combination of duplicate gradient rows halves it on a Zipf(1.05) batch. */
+int64_t wholememory_ext_alltoallv_bytes(void);
+
+/* Calls of wholememory_embedding_gather_gradient_apply that took the COMBINED route: several ranks, a fold that is not bound to
+ * the reference's order (optimizer parameter grad_fold = tree / WM_GRAD_FOLD=tree / a 16-bit table) and enough duplicates
+ * (decided by all ranks from the duplicate estimates in the counts exchange; WM_GRAD_COMBINE=0|1 forces): every rank folds ITS
+ * duplicates of an id into one partial sum before the exchange, the owner folds at most world_size partial rows per id. */
+int64_t wholememory_ext_combined_gradient_calls(void);
+
 /* ---- (3) testing seam ---------------------------------------------------------------------- */
 /* Replaces the device backend. Refuses (WHOLEMEMORY_NOT_SUPPORTED) unless the environment has
  * WHOLEGRAPH_AMD_TESTING=1. `backend` is a const wm_device_backend* (wholegraph_amd/csrc/backend.hpp);

@@ -357,6 +357,15 @@ int t_permute(const void* src, void* dst, int elt_bytes, const int64_t* off, con
   return 0;
 }
 
+int t_iota(void* p, wholememory_dtype_t dt, int64_t n, int64_t first, void*)
+{
+  for (int64_t i = 0; i < n; i++) {
+    if (dt == WHOLEMEMORY_DT_INT) static_cast<int32_t*>(p)[i] = static_cast<int32_t>(first + i);
+    else static_cast<int64_t*>(p)[i] = first + i;
+  }
+  return 0;
+}
+
 const wm_device_backend kTestBackend = {
   "oracle-test-backend (CPU, tests only)",
   t_device_count, t_malloc, t_free, t_malloc, t_free, t_memcpy, t_memset, t_sync,
@@ -371,6 +380,9 @@ const wm_device_backend kTestBackend = {
   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
   t_permute,
   nullptr, nullptr,   // no side stream of its own: nothing to join later
+  nullptr,            // ... and no device-side waits that could give up
+  t_iota,
+  nullptr,            // float32 tables only: no float16 partial sums to check
 };
 
 }  // namespace

@@ -451,6 +451,94 @@ def scenario_tree_fold(comm, rank, world, mt, kind, params):
     wgth.destroy_embedding(emb)
 
 
+def scenario_combined_gradients(comm, rank, world, mt, kind, params, tdt=torch.float32, idt=np.int64, overflow=False):
+    """Sender-side combination of duplicate gradient rows (embedding.cpp: combined_gradient_apply; not in the reference, which
+    ships every copy: embedding.cpp:193-247). Tree fold + WM_GRAD_COMBINE=1: every rank folds ITS duplicates of an id into one
+    partial row before the exchange, the owner folds at most `world` partial rows per id. Gradients are integer-valued with
+    partial sums that the exchange dtype represents exactly, so table (and states) must equal the ORDERED multi-rank oracle bit
+    for bit; the bytes handed to the all-to-all-v must shrink (a hot id makes up half of every rank's batch); with
+    WM_GRAD_COMBINE=0 the same step ships every copy and gives the same bits. overflow (float16): one rank's partial sum
+    leaves the float16 range -> its veto rides in the counts exchange and EVERY rank takes the uncombined route for that step."""
+    n_rows, dim, steps = 3001, 32, 3
+    f32 = tdt == torch.float32
+    os.environ["WM_GRAD_FOLD"] = "tree"
+    _reload_knobs()
+    emb = wgth.create_embedding(comm, mt, "cuda", tdt, [n_rows, dim])
+    stride = emb.get_embedding_tensor().stride()[0]
+    init_t = torch.from_numpy(np.random.default_rng(61).integers(-8, 9, (n_rows, dim)).astype(np.float32)).to(tdt)
+    padded = np.zeros((n_rows, stride), dtype=np.float32)
+    padded[:, :dim] = init_t.float().numpy()
+    tab = oracle.ShardedTable.from_full(padded, world, None)
+    tab.dim = dim
+    local, start = emb.get_embedding_tensor().get_local_tensor()
+    cnt = int(tab.entry_offsets[rank + 1] - tab.entry_offsets[rank])
+    local.copy_(dev(init_t[start:start + cnt]))
+    if HIP_MODE:
+        torch.cuda.synchronize()
+    comm.barrier()
+    opt = wgth.create_wholememory_optimizer(emb, kind, params)
+    ref_opts = [oracle.Optimizer(kind, int(tab.entry_offsets[r + 1] - tab.entry_offsets[r]), stride, **params) for r in range(world)]
+    exchanging = world > 1 or os.environ.get("WM_EXCHANGE_SELF") == "1"
+    lr = 0.5 if f32 else 2.0 ** -6
+    sent = {}
+    for step in range(steps):
+        combine = step != 1                      # step 1 ships every copy: the same bits, more bytes
+        os.environ["WM_GRAD_COMBINE"] = "1" if combine else "0"
+        _reload_knobs()
+        rank_idx, rank_grads = [], []
+        for r in range(world):
+            g = np.random.default_rng(4000 + 10 * (step % 2) + r)   # (steps 0 and 1 use different batches, 2 repeats 0's)
+            ix = g.integers(0, n_rows, 4000 + 9 * r).astype(idt)
+            ix[::2] = 17                         # half of every rank's batch is one hot id: one run per sender, `world` rows at its owner
+            ix[1::8] = n_rows - 2 - (r % 2)      # ~500 per rank of two warm ids
+            ix[5::97] = -1                       # "skip me"
+            gr = g.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=(len(ix), dim), p=[0.02, 0.96, 0.02]).astype(np.float32)
+            if overflow and step == 2 and r == world - 1:
+                gr[ix == 17] = 0.0
+                gr[np.nonzero(ix == 17)[0][:3]] = 30000.0      # three copies: each fits float16, their sum does not
+            rank_idx.append(ix)
+            rank_grads.append(gr)
+        if not f32 and not (overflow and step == 2):   # the test's premise: every sender's partial sums are exact in the table dtype
+            for r in range(world):
+                for hot in (17, n_rows - 2, n_rows - 3):
+                    ps = rank_grads[r][rank_idx[r] == hot].sum(axis=0)
+                    assert np.abs(ps).max() <= 128, "partial sums too large for an exact 16-bit test: %g" % np.abs(ps).max()
+        b0, c0 = wmb.lib().wholememory_ext_alltoallv_bytes(), wmb.lib().wholememory_ext_combined_gradient_calls()
+        emb.add_gradients(dev(torch.from_numpy(rank_idx[rank])), dev(torch.from_numpy(rank_grads[rank]).to(tdt)))
+        emb.need_apply = True
+        opt.step(lr)
+        if HIP_MODE:
+            torch.cuda.synchronize()
+        sent[step] = wmb.lib().wholememory_ext_alltoallv_bytes() - b0
+        took = wmb.lib().wholememory_ext_combined_gradient_calls() - c0
+        vetoed = overflow and step == 2
+        assert took == (1 if combine and exchanging and not vetoed else 0), \
+            "step %d: combined route taken %d times (combine %s, exchanging %s, veto %s)" % (step, took, combine, exchanging, vetoed)
+        oracle.gradient_apply(tab, ref_opts, rank_idx, rank_grads, lr)
+        if not f32:
+            for r in range(world):
+                sh = tab.shards[r]
+                sh[:, :dim] = torch.from_numpy(sh[:, :dim].copy()).to(tdt).float().numpy()   # the table's one rounding
+        want = torch.from_numpy(tab.shards[rank][:cnt, :dim].copy()).to(tdt)
+        got = host(local)
+        assert got.numpy().tobytes() == want.numpy().tobytes() if f32 else torch.equal(got.view(torch.int16), want.view(torch.int16)), \
+            "combined gradient apply (%s, %s, %s) mismatch on rank %d step %d" % (kind, mt, tdt, rank, step)
+        comm.barrier()
+    if exchanging and not overflow:
+        # steps 0 and 2 are the same batch with combination, step 1 a batch of the same shape without: half of every batch is one
+        # id, so the combined exchange moves well under two thirds of the bytes
+        assert sent[0] == sent[2] and sent[0] * 3 < sent[1] * 2, sent
+    if kind == "adam":
+        m, _ = emb.get_optimizer_state("m").get_local_tensor()
+        assert host(m).numpy().tobytes() == ref_opts[rank].per_element[:cnt, :dim].tobytes()
+    comm.barrier()
+    del os.environ["WM_GRAD_FOLD"]
+    del os.environ["WM_GRAD_COMBINE"]
+    _reload_knobs()
+    wgth.destroy_wholememory_optimizer(opt)
+    wgth.destroy_embedding(emb)
+
+
 def scenario_cached_embedding(comm, rank, world, mt):
     """HOST embedding with a read-write device cache on every rank (HIP mode): owners serve lookups cache-first through
     the exchange, train through the cache, write back. Bit-exact vs the uncached multi-rank oracle."""
@@ -737,6 +825,9 @@ def rccl_scenarios(comm, rank, world):
             scenario_gradient_apply(comm, rank, world, kind, params, np.int64, None, mt=mt5)
         scenario_sgd16(comm, rank, world, torch.float16, 256, -1.0, 0.0, mt=mt5)
     scenario_tree_fold(comm, rank, world, "distributed", "rmsprop", {"alpha": 0.95})
+    scenario_combined_gradients(comm, rank, world, "distributed", "sgd", {"weight_decay": 0.0})
+    scenario_combined_gradients(comm, rank, world, "distributed", "sgd", {"weight_decay": 0.0}, tdt=torch.float16)
+    scenario_combined_gradients(comm, rank, world, "distributed", "sgd", {"weight_decay": 0.0}, tdt=torch.float16, overflow=True)
     scenario_sampling(comm, rank, world, "distributed", np.int64)
     scenario_cached_embedding(comm, rank, world, "distributed")
     scenario_file_io(comm, rank, world, "/tmp/wgamd_test_rccl_%s" % os.environ["MASTER_PORT"])
@@ -889,6 +980,14 @@ def main():
                                             ("adagrad", {}), ("rmsprop", {"alpha": 0.95})]):
             scenario_gradient_apply(comm, rank, world, kind, params, np.int32 if (j + k) % 2 else np.int64,
                                     gent if (j + k) % 2 == 0 else None, mt=mt5, loc=loc5)
+    # (5'') sender-side combination of duplicate gradient rows (tree fold): fp32 on either backend, 16-bit tables on the HIP one
+    scenario_combined_gradients(comm, rank, world, "distributed", "sgd", {"weight_decay": 0.0})
+    scenario_combined_gradients(comm, rank, world, "distributed", "adam", {"weight_decay": 0.01}, idt=np.int32)
+    if HIP_MODE:
+        scenario_combined_gradients(comm, rank, world, "continuous", "rmsprop", {"alpha": 0.95})
+        scenario_combined_gradients(comm, rank, world, "distributed", "sgd", {"weight_decay": 0.0}, tdt=torch.float16)
+        scenario_combined_gradients(comm, rank, world, "chunked", "sgd", {"weight_decay": 0.0}, tdt=torch.bfloat16, idt=np.int32)
+        scenario_combined_gradients(comm, rank, world, "distributed", "sgd", {"weight_decay": 0.0}, tdt=torch.float16, overflow=True)
     if HIP_MODE:
         scenario_tree_fold(comm, rank, world, "distributed", "sgd", {"weight_decay": 0.0})
         scenario_tree_fold(comm, rank, world, "continuous", "adam", {"weight_decay": 0.01})

@@ -265,6 +265,8 @@ PROTOTYPES = {
     "wholememory_ext_distributed_gather_launches": (_i64, []),
     "wholememory_ext_distributed_scatter_launches": (_i64, []),
     "wholememory_ext_gradient_exchange_launches": (_i64, []),
+    "wholememory_ext_alltoallv_bytes": (_i64, []),
+    "wholememory_ext_combined_gradient_calls": (_i64, []),
     "wholememory_ext_set_malloc_probe": (_i, [C.c_char_p]),
     "wholememory_ext_get_malloc_probe": (_i, [C.c_char_p, C.c_size_t]),
     "wholememory_ext_handle_was_probed": (_i, [_vp]),

@@ -347,6 +347,14 @@ struct wm_device_backend {
   // otherwise). Non-blocking: it reports what has FINISHED, so callers ask after they synchronise and when they are entered
   // (dedup_ids and dedup_join ask too and fail with -2). nullptr in a backend without device-side waits.
   int (*device_error)(void);
+  // p[i] = first + i for i < n (index dtype): the dense row numbers of a batch's runs (embedding.cpp: sender-side combination
+  // of duplicate gradient rows folds run u into row u of a dense buffer)
+  int (*fill_iota)(void* p, wholememory_dtype_t index_dtype, int64_t n, int64_t first, void* stream);
+  // *flag_dev = -1 when row u of `rows` (HALF, [*, stride] elements, dim used) holds a value that is not finite for some run u
+  // < *n_unique_dev of more than one id (run_starts as dedup_ids leaves them): a partial SUM of float16 gradients that left
+  // the float16 range (a single gradient cannot). Leaves the flag alone otherwise. nullptr in a backend without 16-bit tables.
+  int (*partials_nonfinite)(const int32_t* run_starts, const int64_t* n_unique_dev, int64_t n_upper, const void* rows,
+                            int64_t dim, int64_t stride, int64_t* flag_dev, void* stream);
 };
 
 }  // extern "C"

@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <vector>
 
@@ -401,9 +402,18 @@ bool wholememory_comm_::alltoall_counts_device(const int64_t* dev_counts, int64_
   return true;
 }
 
+namespace wm {
+extern std::atomic<int64_t> g_alltoallv_bytes;   // ops.cpp, with the other counters
+}
 void wholememory_comm_::alltoallv_device(const void* send, const size_t* send_bytes, const size_t* send_disp,
                                          void* recv, const size_t* recv_bytes, const size_t* recv_disp, void* stream)
 {
+  {   // bytes handed to the transport for OTHER ranks (and for this one where it travels like a peer: loopback)
+    int64_t out = 0;
+    for (int p = 0; p < world_size; p++)
+      if (p != world_rank || loopback) out += static_cast<int64_t>(send_bytes[p]);
+    wm::g_alltoallv_bytes.fetch_add(out, std::memory_order_relaxed);
+  }
   if (!transport) {
     if (send_bytes[0] > 0) {
       int rc = wm::backend()->memcpy_async(static_cast<char*>(recv) + recv_disp[0],

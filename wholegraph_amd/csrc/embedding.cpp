@@ -338,6 +338,191 @@ void dedup_and_step(const void* recv_ids, wholememory_dtype_t index_dtype, int64
   step_sorted(r, index_dtype, n_recv, recv_grads, grad_stride, oa, env, stream, n_unique_host, rows_ready, self);
 }
 
+// What the owner was given: ids and gradient rows of every requester in rank-major receive order (that order defines the fp32
+// sum of duplicates), or — `sorted` — a batch that was sorted already (one rank: the caller's arrays are the receive buffers)
+struct owner_input {
+  const void* recv_ids            = nullptr;
+  wholememory_dtype_t index_dtype = WHOLEMEMORY_DT_INT64;
+  int64_t n_recv                  = 0;
+  const void* rows                = nullptr;   // [n_recv, row_stride] gradient rows (the table's dtype)
+  int64_t row_stride              = 0;
+  const self_rows_ref* self       = nullptr;   // receive positions that stand for rows of the caller's own tensor
+  void* rows_arrived              = nullptr;   // event: `rows` is complete (the id sort does not wait for it)
+  dedup_result* sorted            = nullptr;
+};
+
+// owner side of gather_gradient_apply (reference embedding.cpp:248-318): fused dedup + optimizer step on the local shard
+wholememory_error_code_t owner_apply(wholememory_embedding_* e, const owner_input& in, const std::vector<size_t>& entry_offsets,
+                                     float lr, wholememory_env_func_t* env, void* stream, bool adjust_cache)
+{
+  const auto* bk    = backend();
+  auto* adesc       = wholememory_tensor_get_tensor_description(e->allocated);
+  const int rank    = e->comm->world_rank;
+  const int64_t dim = wholememory_tensor_get_tensor_description(e->user)->sizes[1];
+  wholememory_tensor_t local_table;
+  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_map_local_tensor(e->user, &local_table));
+  wm_optimizer_args oa{};
+  fill_optimizer_args(&oa, e->optimizer, lr);
+  oa.local_table        = wholememory_tensor_get_data_pointer(local_table);
+  oa.value_dtype        = e->dtype;
+  oa.table_stride       = adesc->strides[0];
+  oa.local_entry_offset = static_cast<int64_t>(entry_offsets[rank]);
+  oa.dim                = dim;
+  if (e->state_local != nullptr) {
+    oa.per_element_state  = static_cast<float*>(wholememory_tensor_get_data_pointer(e->state_local));
+    oa.per_element_stride = wholememory_tensor_get_tensor_description(e->state_local)->strides[0];
+  }
+  if (e->per_row_local != nullptr)
+    oa.per_row_state = static_cast<float*>(wholememory_tensor_get_data_pointer(e->per_row_local));
+  wholememory_destroy_tensor(local_table);
+  if (e->cache != nullptr) {
+    // read-write device cache of this rank's shard (reference: the optimizer kernels work through the cache,
+    // embedding_optimizer_func.cu + embedding.cpp:146-323): resident rows are updated in their cache line and marked
+    // modified, the others in the raw table; the packed per-element states of resident rows live in companion cache lines
+    if (adjust_cache)
+      WHOLEMEMORY_RETURN_ON_FAIL(wm::row_cache_update(e->cache, in.recv_ids, in.index_dtype, in.n_recv,
+                                                      static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream));
+    oa.cache_slot_of   = e->cache->args.slot_of;
+    oa.cache_data      = e->cache->args.data;
+    oa.cache_dirty     = e->cache->args.dirty;
+    oa.cache_row_elems = e->cache->row_elems;
+    if (e->cache->args.data2 != nullptr) {
+      oa.cache_state_data      = reinterpret_cast<float*>(e->cache->args.data2);
+      oa.cache_state_row_elems = e->cache->args.row_bytes2 / static_cast<int64_t>(sizeof(float));
+    }
+  }
+  if (in.sorted != nullptr)
+    step_sorted(*in.sorted, in.index_dtype, in.n_recv, in.rows, in.row_stride, &oa, env, stream, nullptr, in.rows_arrived, nullptr);
+  else
+    dedup_and_step(in.recv_ids, in.index_dtype, in.n_recv, in.rows, in.row_stride, &oa,
+                   static_cast<int64_t>(entry_offsets[rank + 1]), env, stream, nullptr, in.rows_arrived, in.self,
+                   static_cast<int64_t>(entry_offsets[rank]));
+  // The reference returns with the optimizer kernels still queued (embedding.cpp:318-323: its scratch goes back to the env
+  // allocator, which is stream-ordered — include/wholememory/env_func_ptrs.h states that contract). The same here on ONE
+  // rank: no trailing synchronise, so a training loop's next step is prepared while this one runs (the end-of-call bubble
+  // was ~0.1 ms of a 3.2 ms step). With several ranks the stream is drained before returning: a peer may read this shard
+  // through its own mapping (CHUNKED / CONTINUOUS) right after the barrier that follows the step, and that barrier orders
+  // hosts, not this stream.
+  if (e->comm->world_size > 1 || debug_sync_enabled()) {
+    WM_BK(bk->stream_sync(stream));
+    // everything of this call has finished: a device-side wait that gave up is reported by THIS call (without the
+    // synchronise — one rank — by the next entry into the sort or its join)
+    if (bk->device_error != nullptr && bk->device_error() != 0) return WHOLEMEMORY_CUDA_ERROR;
+  }
+  return WHOLEMEMORY_SUCCESS;
+}
+
+// is the fp32 sum of a run's duplicate gradients free of the reference's order? (wm_optimizer_args::fold_mode: WM_GRAD_FOLD
+// overrides, then the optimizer's "grad_fold", then the default of the value dtype — ordered for fp32, tree for 16-bit tables)
+bool fold_is_tree(const wholememory_embedding_optimizer_* o, wholememory_dtype_t vdt)
+{
+  const char* env = WM_KNOB("WM_GRAD_FOLD");
+  if (env != nullptr && (env[0] == 't' || env[0] == 'T')) return true;
+  if (env != nullptr && (env[0] == 'o' || env[0] == 'O')) return false;
+  if (o->grad_fold >= 0.0f) return o->grad_fold > 0.5f;
+  return vdt == WHOLEMEMORY_DT_HALF || vdt == WHOLEMEMORY_DT_BF16;
+}
+
+std::atomic<int64_t> g_grad_combined_calls{0};
+
+// SENDER-SIDE COMBINATION of duplicate gradient rows (round 6; not in the reference, which ships every copy:
+// embedding.cpp:193-247). Under skew every rank holds thousands of gradient rows for the same hot ids — Zipf(1.05), 10 M ids:
+// 49 % distinct, 527 k copies of the hottest — and every copy would cross ONE xGMI link to its owner, who then folds W x 527 k
+// rows (in the reference's order: a dependent chain of ~11 ms at W = 8). When the order of the fp32 sum is not bound to the
+// reference's (fold_is_tree), each rank first folds ITS OWN duplicates:
+//   1 runs of equal ids in the batch (the owner-side id sort, here on the sender: ids sorted, run starts, positions)
+//   2 one partial sum per distinct id: the fused fold + step kernels run as "row u += sum of run u" on a dense zeroed buffer
+//     (SGD with lr = -1, no weight decay: 0 - (-1) x sum, exact) — duplicates summed in fp32 in a fixed order, long runs by
+//     the tree kernels, rounded ONCE to the exchange dtype (= the table's)
+//   3 the distinct ids are sorted, so the owner segments are contiguous pieces of ids and partial rows as they stand: counts by
+//     binary search, no multisplit, no line-up kernel — ids and rows go out by all-to-all-v straight from those arrays
+//   4 the owner folds at most W partial rows per id (rank-major order) and applies the optimizer: runs of <= W rows, no long
+//     dependent chain whatever the skew.
+// Results: a fixed order (deterministic), equal to the ordered sum within the usual bound of fp32 summation — exact whenever the
+// partial sums are exactly representable (integer-valued gradients) — for 16-bit tables plus one rounding of each sender's
+// partial sum to the table's dtype. float16 partial sums can leave the float16 range where single gradients cannot: every
+// rank checks its partial rows and the verdict rides in the counts exchange (slot W, like the duplicate estimate of the
+// gather), so ALL ranks fall back to the uncombined route together for such a batch.
+// Whether to combine is decided per call by all ranks alike: WM_GRAD_COMBINE=0 never, =1 whenever the fold is free, unset:
+// when the mean duplicate estimate that rides in the counts exchange reaches WM_GRAD_COMBINE_PERMILLE (default 100 = 10 %).
+// Returns 1 = the step is done (*rc holds its code), 0 = declined by every rank (nothing changed: take the plain route).
+int combined_gradient_apply(wholememory_embedding_* e, const char* idx_ptr, const wholememory_array_description_t& iarr,
+                            const void* grads_ptr, const wholememory_matrix_description_t& gmat,
+                            const std::vector<size_t>& entry_offsets, float lr, wholememory_env_func_t* env, void* stream,
+                            bool adjust_cache, wholememory_error_code_t* rc)
+{
+  const auto* bk          = backend();
+  const int W             = e->comm->world_size;
+  const int rank          = e->comm->world_rank;
+  const int64_t n         = iarr.size;
+  const int64_t dim       = gmat.sizes[1];
+  const auto vdt          = e->dtype;
+  const size_t ves        = wholememory_dtype_get_element_size(vdt);
+  const size_t ies        = wholememory_dtype_get_element_size(iarr.dtype);
+  const size_t row_bytes  = static_cast<size_t>(dim) * ves;
+  const bool self_local   = !e->comm->loopback;
+  const int64_t all_rows  = static_cast<int64_t>(entry_offsets[W]);
+  // (1) runs of equal ids. Keys bounded by the table's rows when they fit 32 bits (ids that address no row drop out of the runs);
+  // wider tables sort full-width keys: ids outside every owner's range then form runs nobody asks for
+  dedup_result r(env);
+  r.run(idx_ptr, iarr.dtype, n, all_rows < INT64_C(0xFFFFFFFF) ? all_rows : 0, stream, 0, /*join_later=*/false);
+  temp_mem host_n(env), flag_mem(env);
+  auto* h_nu = static_cast<int64_t*>(host_n.pinned(1, WHOLEMEMORY_DT_INT64));
+  WM_BK(bk->memcpy_async(h_nu, r.d_nunique, sizeof(int64_t), stream));
+  WM_BK(bk->stream_sync(stream));   // (the dense buffer of partial sums is sized and zeroed for exactly the distinct ids)
+  const int64_t nu = *h_nu;
+  // (2) partial sums: row u of `partial` = fp32 sum of the gradient rows of run u, rounded once
+  temp_mem partial_mem(env), iota_mem(env), long_ws(env);
+  char* partial = static_cast<char*>(partial_mem.device(dim * nu, vdt));
+  void* iota    = iota_mem.device(nu, iarr.dtype);
+  auto* d_flag  = static_cast<int64_t*>(flag_mem.device(1, WHOLEMEMORY_DT_INT64));
+  WM_BK(bk->memset_async(d_flag, 0, sizeof(int64_t), stream));
+  if (nu > 0) {
+    WM_BK(bk->memset_async(partial, 0, row_bytes * static_cast<size_t>(nu), stream));
+    WM_BK(bk->fill_iota(iota, iarr.dtype, nu, 0, stream));
+    wm_optimizer_args fa{};
+    fa.type = WHOLEMEMORY_OPT_SGD, fa.lr = -1.0f, fa.weight_decay = 0.0f;
+    fa.ids = iota, fa.index_dtype = iarr.dtype, fa.run_starts = r.d_starts, fa.order = r.d_order;
+    fa.value_dtype = vdt, fa.grads = grads_ptr, fa.grad_stride = gmat.stride;
+    fa.count = nu, fa.local_table = partial, fa.table_stride = dim, fa.local_entry_offset = 0, fa.dim = dim;
+    fa.fold_mode   = 1;
+    fa.long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n, dim)), WHOLEMEMORY_DT_INT8);
+    if (bk->optimizer_step(&fa, r.d_nunique, stream) != 0) throw hip_error("folding the duplicate gradient rows failed");
+    if (vdt == WHOLEMEMORY_DT_HALF && bk->partials_nonfinite != nullptr)
+      WM_BK(bk->partials_nonfinite(r.d_starts, r.d_nunique, nu, partial, dim, dim, d_flag, stream));
+  }
+  // (3) owner segments of the sorted distinct ids + their exchange; the verdict on the partial rows travels with the counts
+  sorted_unique su{r.d_nunique, d_flag};
+  id_exchange x(env);
+  bucket_and_exchange_ids(e->comm, r.d_unique, iarr.dtype, nu, entry_offsets, env, stream, &x, self_local, false, &su);
+  if (x.dup_permille < 0) return 0;   // some rank's float16 partial sums left the range: everybody takes the plain route
+  std::vector<int64_t> full_recv_counts = x.recv_counts, full_recv_offsets(W + 1, 0);
+  full_recv_counts[rank]                = x.self_count;
+  for (int i = 0; i < W; i++) full_recv_offsets[i + 1] = full_recv_offsets[i] + full_recv_counts[i];
+  const int64_t n_recv = full_recv_offsets[W];
+  temp_mem recv_rows(env), recv_ids_mem(env);
+  char* recv_buf = static_cast<char*>(recv_rows.device(dim * n_recv, vdt));
+  char* recv_ids = static_cast<char*>(recv_ids_mem.device(n_recv, iarr.dtype));
+  for (int q = 0; q < W; q++) {   // ids: the peers' segments were received compactly (self cut out) — around the self slot
+    const char* src = (q == rank && self_local) ? static_cast<const char*>(x.bucketed_ids) + ies * x.self_offset
+                                                : static_cast<const char*>(x.recv_ids) + ies * x.recv_offsets[q];
+    if (full_recv_counts[q] > 0) WM_BK(bk->memcpy_async(recv_ids + ies * full_recv_offsets[q], src, ies * full_recv_counts[q], stream));
+  }
+  if (self_local && x.self_count > 0)   // this rank's own partial rows: one copy into their rank-major slot
+    WM_BK(bk->memcpy_async(recv_buf + row_bytes * full_recv_offsets[rank], partial + row_bytes * x.self_offset,
+                           row_bytes * static_cast<size_t>(x.self_count), stream));
+  {
+    std::vector<int64_t> ro(full_recv_offsets.begin(), full_recv_offsets.end() - 1);
+    exchange_segments(e->comm, partial, x.send_counts, x.bucket_offsets, recv_buf, x.recv_counts, ro, row_bytes, stream);
+  }
+  g_grad_combined_calls.fetch_add(1, std::memory_order_relaxed);
+  // (4) the owner's step over at most W partial rows per id
+  owner_input in;
+  in.recv_ids = recv_ids, in.index_dtype = iarr.dtype, in.n_recv = n_recv, in.rows = recv_buf, in.row_stride = dim;
+  *rc = owner_apply(e, in, entry_offsets, lr, env, stream, adjust_cache);
+  return 1;
+}
+
 // reference embedding.cpp:146-323
 wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholememory_tensor_t indices,
                                                wholememory_tensor_t grads, float lr, wholememory_env_func_t* env,
@@ -346,7 +531,6 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   const auto* bk  = backend();
   auto* idesc     = wholememory_tensor_get_tensor_description(indices);
   auto* gdesc     = wholememory_tensor_get_tensor_description(grads);
-  auto* adesc     = wholememory_tensor_get_tensor_description(e->allocated);
   WM_CHECK_ABORT(idesc->dim == 1, "indices must be 1-D");
   if (e->optimizer == nullptr) {
     WM_ERROR("gather_gradient_apply: no optimizer set on this embedding");
@@ -392,8 +576,36 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
     early->run(idx_ptr, iarr.dtype, iarr.size, static_cast<int64_t>(entry_offsets[1]), stream,
                static_cast<int64_t>(entry_offsets[0]), /*join_later=*/true);
   }
+  // several ranks and a fold that is free of the reference's order: combine this rank's duplicates before they travel?
+  // (combined_gradient_apply; every condition is the same on all ranks — the op is collective)
   id_exchange x(env);
-  if (early) {
+  bool ids_deferred = false;
+  if (!early && !e->comm->single_rank_direct() && iarr.size < (INT64_C(1) << 31) && bk->fill_iota != nullptr &&
+      bk->sorted_owner_counts != nullptr && fold_is_tree(e->optimizer, vdt)) {
+    const char* sw = WM_KNOB("WM_GRAD_COMBINE");
+    const int mode = sw == nullptr ? -1 : atoi(sw);   // -1 auto, 0 never, 1 always
+    bool combine   = mode >= 1;
+    if (mode < 0) {
+      const int64_t threshold = [] {
+        const char* t = WM_KNOB("WM_GRAD_COMBINE_PERMILLE");
+        return t != nullptr && atoi(t) > 0 ? static_cast<int64_t>(atoi(t)) : INT64_C(100);
+      }();
+      // counts + duplicate estimate only; the grouping pass and the ids exchange follow once the route is known
+      bucket_and_exchange_ids(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x, self_local, false, nullptr,
+                              true, true);
+      ids_deferred = true;
+      combine      = x.dup_permille >= threshold;
+    }
+    if (combine) {
+      wholememory_error_code_t rc = WHOLEMEMORY_SUCCESS;
+      if (combined_gradient_apply(e, idx_ptr, iarr, wholememory_tensor_get_data_pointer(grads), gmat, entry_offsets, lr, env,
+                                  stream, adjust_cache, &rc) == 1)
+        return rc;
+    }
+  }
+  if (ids_deferred) {
+    finish_id_exchange(e->comm, idx_ptr, iarr.dtype, iarr.size, entry_offsets, env, stream, &x);
+  } else if (early) {
     x.identity       = true;
     x.bucketed_ids   = const_cast<char*>(idx_ptr);
     x.raw_indices    = nullptr;
@@ -509,64 +721,17 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
   if (C > 1) WM_BK(bk->event_record(arrived[0], side));
   void* rows_arrived = C > 1 ? arrived[0] : nullptr;
 
-  // owner: fused dedup + step on the local shard (embedding.cpp:248-318)
-  wholememory_tensor_t local_table;
-  WHOLEMEMORY_RETURN_ON_FAIL(wholememory_tensor_map_local_tensor(e->user, &local_table));
-  wm_optimizer_args oa{};
-  fill_optimizer_args(&oa, e->optimizer, lr);
-  oa.local_table        = wholememory_tensor_get_data_pointer(local_table);
-  oa.value_dtype        = vdt;
-  oa.table_stride       = adesc->strides[0];
-  oa.local_entry_offset = static_cast<int64_t>(entry_offsets[e->comm->world_rank]);
-  oa.dim                = dim;
-  if (e->state_local != nullptr) {
-    oa.per_element_state  = static_cast<float*>(wholememory_tensor_get_data_pointer(e->state_local));
-    oa.per_element_stride = wholememory_tensor_get_tensor_description(e->state_local)->strides[0];
-  }
-  if (e->per_row_local != nullptr)
-    oa.per_row_state = static_cast<float*>(wholememory_tensor_get_data_pointer(e->per_row_local));
-  wholememory_destroy_tensor(local_table);
-  if (e->cache != nullptr) {
-    // read-write device cache of this rank's shard (reference: the optimizer kernels work through the cache,
-    // embedding_optimizer_func.cu + embedding.cpp:146-323): resident rows are updated in their cache line and marked
-    // modified, the others in the raw table; the packed per-element states of resident rows live in companion cache lines
-    if (adjust_cache)
-      WHOLEMEMORY_RETURN_ON_FAIL(wm::row_cache_update(e->cache, recv_ids, iarr.dtype, n_recv,
-                                                      static_cast<int64_t>(entry_offsets[e->comm->world_size]), env, stream));
-    oa.cache_slot_of   = e->cache->args.slot_of;
-    oa.cache_data      = e->cache->args.data;
-    oa.cache_dirty     = e->cache->args.dirty;
-    oa.cache_row_elems = e->cache->row_elems;
-    if (e->cache->args.data2 != nullptr) {
-      oa.cache_state_data      = reinterpret_cast<float*>(e->cache->args.data2);
-      oa.cache_state_row_elems = e->cache->args.row_bytes2 / static_cast<int64_t>(sizeof(float));
-    }
-  }
   // Everything this rank was given is its own (one rank; ids that address no row are dropped inside the sort, see above):
   // the receive order IS the caller's order and the caller's gradient tensor IS the receive buffer — no remapping pass
   const bool whole_input_is_self = self_direct && x.self_count == iarr.size && n_recv == iarr.size;
-  if (whole_input_is_self && early)
-    step_sorted(*early, iarr.dtype, n_recv, self_ref.grads, self_ref.stride, &oa, env, stream, nullptr, rows_arrived, nullptr);
-  else if (whole_input_is_self)
-    dedup_and_step(recv_ids, iarr.dtype, n_recv, self_ref.grads, self_ref.stride, &oa,
-                   static_cast<int64_t>(entry_offsets[rank + 1]), env, stream, nullptr, rows_arrived, nullptr,
-                   static_cast<int64_t>(entry_offsets[rank]));
-  else
-    dedup_and_step(recv_ids, iarr.dtype, n_recv, recv_buf, dim, &oa, static_cast<int64_t>(entry_offsets[rank + 1]), env, stream,
-                   nullptr, rows_arrived, self_direct ? &self_ref : nullptr, static_cast<int64_t>(entry_offsets[rank]));
-  // The reference returns with the optimizer kernels still queued (embedding.cpp:318-323: its scratch goes back to the env
-  // allocator, which is stream-ordered — include/wholememory/env_func_ptrs.h states that contract). The same here on ONE
-  // rank: no trailing synchronise, so a training loop's next step is prepared while this one runs (the end-of-call bubble
-  // was ~0.1 ms of a 3.2 ms step). With several ranks the stream is drained before returning: a peer may read this shard
-  // through its own mapping (CHUNKED / CONTINUOUS) right after the barrier that follows the step, and that barrier orders
-  // hosts, not this stream.
-  if (e->comm->world_size > 1 || debug_sync_enabled()) {
-    WM_BK(bk->stream_sync(stream));
-    // everything of this call has finished: a device-side wait that gave up is reported by THIS call (without the
-    // synchronise — one rank — by the next entry into the sort or its join)
-    if (bk->device_error != nullptr && bk->device_error() != 0) return WHOLEMEMORY_CUDA_ERROR;
+  owner_input in;
+  in.recv_ids = recv_ids, in.index_dtype = iarr.dtype, in.n_recv = n_recv, in.rows_arrived = rows_arrived;
+  if (whole_input_is_self) {
+    in.rows = self_ref.grads, in.row_stride = self_ref.stride, in.sorted = early.get();
+  } else {
+    in.rows = recv_buf, in.row_stride = dim, in.self = self_direct ? &self_ref : nullptr;
   }
-  return WHOLEMEMORY_SUCCESS;
+  return owner_apply(e, in, entry_offsets, lr, env, stream, adjust_cache);
 }
 
 wholememory_error_code_t remap_round_robin(wholememory_embedding_* e, wholememory_tensor_t indices, temp_mem* mapped_mem,
@@ -601,6 +766,8 @@ wholememory_error_code_t remap_round_robin(wholememory_embedding_* e, wholememor
 
 }  // namespace
 }  // namespace wm
+
+extern "C" int64_t wholememory_ext_combined_gradient_calls(void) { return wm::g_grad_combined_calls.load(std::memory_order_relaxed); }
 
 extern "C" {
 

@@ -14,6 +14,9 @@ int hip_bucket_ids(const wm_bucket_args* a, void* stream);
 void hip_dedup_defer_join(int on);
 int hip_dedup_join(void* stream);
 int hip_device_error();
+int hip_fill_iota(void* p, wholememory_dtype_t index_dtype, int64_t n, int64_t first, void* stream);
+int hip_partials_nonfinite(const int32_t* run_starts, const int64_t* n_unique_dev, int64_t n_upper, const void* rows, int64_t dim,
+                           int64_t stride, int64_t* flag_dev, void* stream);
 int hip_permute_chunks(const void* src, void* dst, int elt_bytes, const int64_t* seg_offsets, const int64_t* seg_counts, int n_segs,
                        int n_chunks, void* stream);
 size_t hip_dedup_workspace_bytes(int64_t n, wholememory_dtype_t index_dtype);
@@ -232,6 +235,8 @@ const wm_device_backend kHipBackend = {
   hip_dedup_defer_join,
   hip_dedup_join,
   hip_device_error,
+  hip_fill_iota,
+  hip_partials_nonfinite,
 };
 
 }  // namespace

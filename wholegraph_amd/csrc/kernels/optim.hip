@@ -2581,6 +2581,64 @@ int hip_round_robin_map(const void* ids, void* mapped, wholememory_dtype_t index
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+namespace {
+template <typename IdxT>
+__global__ void fill_iota_kernel(IdxT* p, int64_t n, int64_t first)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    p[i] = static_cast<IdxT>(first + i);
+}
+// one wave per run of more than one id: is its row of partial sums finite?
+__global__ __launch_bounds__(256) void partials_nonfinite_kernel(const int32_t* run_starts, const int64_t* n_unique, const half_t* rows,
+                                                                int64_t dim, int64_t stride, int64_t* flag)
+{
+  const int lane     = threadIdx.x & 63;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t step = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  const int64_t nu   = *n_unique;
+  for (int64_t u0 = wave * 64; u0 < nu; u0 += step * 64) {
+    const int64_t u  = u0 + lane;
+    const bool multi = u < nu && run_starts[u + 1] - run_starts[u] > 1;
+    uint64_t todo    = __ballot(multi);
+    while (todo != 0) {
+      const int l = __ffsll(static_cast<long long>(todo)) - 1;
+      todo &= todo - 1;
+      const half_t* row = rows + (u0 + l) * stride;
+      bool bad          = false;
+      for (int64_t d = lane; d < dim; d += 64) {
+        const float v = load_wide<half_t>(row[d]);
+        bad           = bad || !(fabsf(v) <= 65504.f);   // inf or NaN
+      }
+      if (__ballot(bad) != 0 && lane == 0) *flag = -1;
+    }
+  }
+}
+}  // namespace
+
+int hip_fill_iota(void* p, wholememory_dtype_t index_dtype, int64_t n, int64_t first, void* stream_v)
+{
+  if (n <= 0) return 0;
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const int blocks   = static_cast<int>(std::min<int64_t>((n + 255) / 256, 4096));
+  if (index_dtype == WHOLEMEMORY_DT_INT)
+    hipLaunchKernelGGL(fill_iota_kernel<int32_t>, dim3(blocks), dim3(256), 0, stream, static_cast<int32_t*>(p), n, first);
+  else if (index_dtype == WHOLEMEMORY_DT_INT64)
+    hipLaunchKernelGGL(fill_iota_kernel<int64_t>, dim3(blocks), dim3(256), 0, stream, static_cast<int64_t*>(p), n, first);
+  else
+    return -1;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int hip_partials_nonfinite(const int32_t* run_starts, const int64_t* n_unique_dev, int64_t n_upper, const void* rows, int64_t dim,
+                           int64_t stride, int64_t* flag_dev, void* stream_v)
+{
+  if (n_upper <= 0) return 0;
+  const int blocks = static_cast<int>(std::min<int64_t>((n_upper + 255) / 256, 2048));   // 4 waves x 64 runs per block and trip
+  hipLaunchKernelGGL(partials_nonfinite_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, static_cast<hipStream_t>(stream_v), run_starts,
+                     n_unique_dev, static_cast<const half_t*>(rows), dim, stride, flag_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int hip_fill_float(float* p, float value, int64_t count, void* stream_v)
 {
   if (count == 0) return 0;

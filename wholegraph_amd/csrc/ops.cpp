@@ -123,7 +123,9 @@ void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, whole
   }();
   const bool estimate = estimate_duplicates && bk->dup_estimate != nullptr && n >= std::max<int64_t>(estimate_min_ids, 2) &&
                         n < (INT64_C(1) << 31);
-  if (estimate) {
+  if (sorted != nullptr && sorted->vote_dev != nullptr) {
+    WM_BK(bk->memcpy_async(d_cnt + W, sorted->vote_dev, sizeof(int64_t), stream));   // the caller's vote rides in the spare slot
+  } else if (estimate) {
     void* ws = est_ws.device(static_cast<int64_t>(bk->dup_estimate_workspace_bytes(n)), WHOLEMEMORY_DT_INT8);
     WM_BK(bk->dup_estimate(indices, index_dtype, n, ws, d_cnt + W, stream));
   } else {
@@ -1112,6 +1114,7 @@ std::atomic<int64_t> g_host_sorted_gathers{0};
 std::atomic<int64_t> g_dist_gather_launches{0};
 std::atomic<int64_t> g_dist_scatter_launches{0};
 std::atomic<int64_t> g_grad_exchange_launches{0};
+std::atomic<int64_t> g_alltoallv_bytes{0};
 }
 
 extern "C" {
@@ -1120,6 +1123,7 @@ int64_t wholememory_ext_host_sorted_gathers(void) { return wm::g_host_sorted_gat
 int64_t wholememory_ext_distributed_gather_launches(void) { return wm::g_dist_gather_launches.load(std::memory_order_relaxed); }
 int64_t wholememory_ext_distributed_scatter_launches(void) { return wm::g_dist_scatter_launches.load(std::memory_order_relaxed); }
 int64_t wholememory_ext_gradient_exchange_launches(void) { return wm::g_grad_exchange_launches.load(std::memory_order_relaxed); }
+int64_t wholememory_ext_alltoallv_bytes(void) { return wm::g_alltoallv_bytes.load(std::memory_order_relaxed); }
 
 wholememory_error_code_t wholememory_gather(wholememory_tensor_t wholememory_tensor,
                                             wholememory_tensor_t indices_tensor,

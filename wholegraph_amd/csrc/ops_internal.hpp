@@ -70,6 +70,10 @@ struct id_exchange {
 // ids that are already sorted (as unsigned keys) and distinct, their number still on the device: what dedup_ids leaves
 struct sorted_unique {
   const int64_t* n_dev;  // device: number of ids (<= the n passed to bucket_and_exchange_ids)
+  // optional (device): this rank's vote, carried in the spare slot of the counts exchange where the duplicate estimate of a
+  // gather rides — id_exchange::dup_permille is then the mean of the ranks' votes, or -1 when any rank voted below zero (a
+  // veto: every rank learns it from the same W numbers and takes the same way out)
+  const int64_t* vote_dev = nullptr;
 };
 void bucket_and_exchange_ids(wholememory_comm_t comm, const void* indices, wholememory_dtype_t index_dtype, int64_t n,
                              const std::vector<size_t>& entry_offsets, wholememory_env_func_t* env, void* stream,
