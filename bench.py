@@ -66,9 +66,11 @@ def parse():
     p.add_argument("--avg-degree", type=int, default=29, help="sample_gather: mean out-degree (papers100M, both directions: 29)")
     p.add_argument("--seeds", type=int, default=1024, help="sample_gather: seed nodes per rank per step")
     p.add_argument("--fanouts", default="30,30", help="sample_gather: fan-out per hop, seeds outwards")
-    p.add_argument("--col-dist", choices=["uniform", "powerlaw"], default="uniform",
-                   help="sample_gather: how the synthetic graph's neighbour ids are drawn. uniform (the default, every earlier line): "
-                        "no node is a hub. powerlaw: node of popularity rank k with probability ~ k^-s (--col-exponent s < 1, ranks "
+    p.add_argument("--one-graph", action="store_true", help="sample_gather: do not re-time the step on the other --col-dist afterwards")
+    p.add_argument("--col-dist", choices=["uniform", "powerlaw"], default="powerlaw",
+                   help="sample_gather: how the synthetic graph's neighbour ids are drawn. uniform (every line before round 6): "
+                        "no node is a hub. powerlaw (the default since round 6; the other one is re-timed in the same process and "
+                        "reported under other_graph): node of popularity rank k with probability ~ k^-s (--col-exponent s < 1, ranks "
                         "hashed over the id range): hubs as in a citation graph — s = 0.8 puts the top node into ~0.5 %% of all edges")
     p.add_argument("--col-exponent", type=float, default=0.8, help="sample_gather --col-dist powerlaw: the exponent s, 0 < s < 1")
     p.add_argument("--c5-flow", choices=["deferred", "reference"], default="deferred",
@@ -300,16 +302,19 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
     del row
     lcol, _ = wcol.get_local_tensor()
     gen2 = torch.Generator(device="cuda").manual_seed(100 + rank)
-    for s0 in range(0, lcol.shape[0], 1 << 28):
-        e0 = min(lcol.shape[0], s0 + (1 << 28))
-        if a.col_dist == "powerlaw":
-            # inverse CDF of the truncated power law: rank = nodes * u^(1 / (1 - s)); ranks hashed over the id range
-            u = torch.rand(e0 - s0, device="cuda", generator=gen2, dtype=torch.float64)
-            rank_k = (u.pow_(1.0 / (1.0 - a.col_exponent)) * nodes).to(torch.int64).clamp_(0, nodes - 1)
-            lcol[s0:e0] = ((rank_k * 2654435761) % nodes).to(torch.int32)
-            del u, rank_k
-        else:
-            lcol[s0:e0] = torch.randint(0, nodes, (e0 - s0,), device="cuda", generator=gen2, dtype=torch.int32)
+
+    def fill_cols(col_dist):
+        for s0 in range(0, lcol.shape[0], 1 << 28):
+            e0 = min(lcol.shape[0], s0 + (1 << 28))
+            if col_dist == "powerlaw":
+                # inverse CDF of the truncated power law: rank = nodes * u^(1 / (1 - s)); ranks hashed over the id range
+                u = torch.rand(e0 - s0, device="cuda", generator=gen2, dtype=torch.float64)
+                rank_k = (u.pow_(1.0 / (1.0 - a.col_exponent)) * nodes).to(torch.int64).clamp_(0, nodes - 1)
+                lcol[s0:e0] = ((rank_k * 2654435761) % nodes).to(torch.int32)
+                del u, rank_k
+            else:
+                lcol[s0:e0] = torch.randint(0, nodes, (e0 - s0,), device="cuda", generator=gen2, dtype=torch.int32)
+    fill_cols(a.col_dist)
     feat = wgth.create_embedding(comm, mt, "cuda", torch.float32, [nodes, a.dim])
     lfeat, fstart = feat.get_embedding_tensor().get_local_tensor()
     fill_table(lfeat, fstart)
@@ -415,6 +420,24 @@ def run_sample_gather(a, wgth, comm, world, rank, launched, barrier):
         res["stability"] = {"steps": len(per), "min_ms": round(float(per.min()), 4), "median_ms": round(float(np.median(per)), 4),
                             "p95_ms": round(float(np.percentile(per, 95)), 4), "max_ms": round(float(per.max()), 4),
                             "note": "per-step host times (synchronised), separate from the timed region"}
+    if not a.one_graph:
+        # the OTHER synthetic graph in the same process (round-5 review: C5 is papers100M, a graph with hubs — the default — and
+        # every line before round 6 was measured on the hub-free one): neighbour ids redrawn in place, same degrees and seeds
+        other = "uniform" if a.col_dist == "powerlaw" else "powerlaw"
+        fill_cols(other)
+        for _ in range(3):
+            step()
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        barrier()
+        ms2 = (time.perf_counter() - t2) / a.steps * 1e3
+        res["other_graph"] = {"neighbour_ids": "uniform" if other == "uniform" else "power law, exponent %g" % a.col_exponent,
+                              "ms_per_step": round(ms2, 4), "subgraph_nodes_per_step": stat["nodes"],
+                              "sampled_edges_per_step": stat["edges"],
+                              "value": round(stat["nodes"] * row_bytes * world / (ms2 * 1e-3) / 1e9, 2), "unit": "GB/s",
+                              "note": "same process, same degrees and seeds, rank 0's clock (not reduced over ranks)"}
     wgth.destroy_embedding(feat)
     wgth.destroy_wholememory_tensor(wrow)
     wgth.destroy_wholememory_tensor(wcol)
@@ -645,6 +668,7 @@ def main():
     gc.collect()
     gc.freeze()    # (see run_sample_gather: no full collection of the interpreter's long-lived objects inside the timed region)
     allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+    bytes0, comb0 = wmb.lib().wholememory_ext_alltoallv_bytes(), wmb.lib().wholememory_ext_combined_gradient_calls()
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(a.steps):
@@ -653,6 +677,10 @@ def main():
     barrier()
     t1 = time.perf_counter()
     gc.unfreeze()
+    # the library's own counters over the timed region (rank 0's): bytes handed to the all-to-all-v for other ranks, and how many
+    # gradient steps took the route that combines a sender's duplicate rows before they travel
+    a2a_bytes_per_step = (wmb.lib().wholememory_ext_alltoallv_bytes() - bytes0) / a.steps
+    combined_steps = wmb.lib().wholememory_ext_combined_gradient_calls() - comb0
     fresh_allocs = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0   # hipMallocs by the caching allocator: 0 in a steady state
     dt = torch.tensor([t1 - t0], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
     if launched:
@@ -814,21 +842,38 @@ def main():
             # launch gaps are inside it: an upper bound of the kernel's duration, and what `achieved` is computed from);
             # kernel_ms_rocprof = that kernel's average duration in the rocprofv3 kernel trace of this command committed under
             # profiles/ (None until a collection of this round exists)
+            # One box per number (round 6): the committed profile's kernel time is cited as THIS line's kernel_ms_rocprof only when
+            # the collection it comes from ran at this run's speed (its own ms_per_step within 2 % of this run's) and the kernel
+            # time does not exceed this run's step (a kernel cannot take longer than the step that contains it); otherwise it
+            # is reported as what it is — another run's figures, under profile_* — and kernel_ms_rocprof stays null.
             kernel_ms_rocprof, kernel_ms_source = None, None
+            profile = None
             kms = os.path.join(ROOT, "profiles", "kernel_ms.json")
             if os.path.exists(kms) and a.indices == 10_000_000 and a.dim == 128 and a.dist == "uniform":
                 try:
                     rec = json.load(open(kms))
-                    kernel_ms_rocprof = rec.get("average_ms")
-                    kernel_ms_source = "profiles/%s@%s (%d launches)" % (rec.get("file"), rec.get("commit"), rec.get("launches", 0))
+                    p_kernel, p_step = rec.get("average_ms"), rec.get("collection_ms_per_step")
+                    source = "profiles/%s@%s (%d launches)" % (rec.get("file"), rec.get("commit"), rec.get("launches", 0))
+                    this_step = wall / a.steps * 1e3
+                    same_speed = (p_kernel is not None and p_step is not None and abs(p_step - this_step) <= 0.02 * this_step
+                                  and p_kernel <= this_step)
+                    if same_speed:
+                        kernel_ms_rocprof, kernel_ms_source = p_kernel, source
+                    profile = {"profile_kernel_ms": p_kernel, "profile_step_ms": p_step,
+                               "profile_frac": round(a.indices * algo_bytes / (p_kernel * 1e-3) / 8e12, 4) if p_kernel else None,
+                               "profile_source": source,
+                               "profile_note": "rocprofv3 kernel trace of this command in ANOTHER run (its own step time beside "
+                                               "it); cited as kernel_ms_rocprof only when that run was within 2 % of this one"}
                 except Exception:
-                    kernel_ms_rocprof = None
+                    kernel_ms_rocprof, profile = None, None
             copy_ms = guarded("copy_leg", copy_leg)
             res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                                "kernel": rows_kernel, "step_ms_hip_events": round(dev_ms, 4),
                                "kernel_ms_rocprof": kernel_ms_rocprof, "kernel_ms_source": kernel_ms_source,
                                "algorithmic_bytes_per_launch": a.indices * algo_bytes}
+            if profile is not None:
+                res["roofline"].update(profile)
             if copy_ms is not None:
                 # the same launch as a sequential copy in the same process: the ceiling random 512-byte reads are measured against
                 res["roofline"]["copy_ms_sequential_ids"] = round(copy_ms, 4)
@@ -876,6 +921,12 @@ def main():
                                        "owner-side gather and the reorder-on-receive kernels"}
             if a.backend != "nccl":
                 res["exchange"]["note"] = "BRING-UP RUN: collectives over torch.distributed/%s, not RCCL" % a.backend
+        if a2a_bytes_per_step > 0:
+            res.setdefault("exchange", {})["alltoallv_bytes_per_step"] = a2a_bytes_per_step
+        if a.op == "grad_apply" and (world > 1 or a2a_bytes_per_step > 0):
+            res["grad_route"] = {"combined_steps": combined_steps, "of": a.steps,
+                                 "note": "steps whose duplicate gradient rows were folded per sender before the exchange (fold free "
+                                         "of the reference's order + enough duplicates; WM_GRAD_COMBINE=0|1 forces)"}
         if stability is not None:
             res["stability"] = stability
         if c3_zipf is not None:

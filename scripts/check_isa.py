@@ -41,7 +41,10 @@ RULES = [
     (r"rows_staged_gather_kernel<", dict(min_loads=4, wide=True, max_valu=400, max_mov_share=0.45, scope="block")),
     (r"rows_staged_scatter_kernel<", dict(min_loads=4, wide=True, max_valu=400, max_mov_share=0.45, scope="block")),
     # gradient apply: a batch of the tile kernel = 2 x kU row loads (gradient + table [+ states]) back to back; no scratch
-    (r"step_tile_kernel<", dict(min_loads=4, wide=True, max_valu=600, max_mov_share=0.45, scope="block", max_scratch=0)),
+    (r"step_tile_kernel<[^>]*, 16>", dict(min_loads=4, wide=True, max_valu=600, max_mov_share=0.45, scope="block", max_scratch=0)),
+    # ... and its 8-byte-piece instantiation (round 6: fp32 rows of whole 8-byte pieces, 602 floats): the same batch of dwordx2
+    (r"step_tile_kernel<[^>]*, 8>", dict(min_loads=4, wide=False, load_re=r"^global_load_dwordx2\b", max_valu=600, max_mov_share=0.45,
+                                         scope="block", max_scratch=0)),
     # the tree fold of long runs: 4 gradient rows per thread in flight (round 3 shipped one)
     (r"tree_fold_kernel<", dict(min_loads=4, wide=True, max_valu=600, max_mov_share=0.45, scope="block", max_scratch=0)),
     # round 5, the split sort of the owner-side ids (split_sort.cuh). What these kernels need from the compiler:
@@ -131,9 +134,9 @@ def split_functions(txt):
     return funcs
 
 
-def analyse(lines, wide):
+def analyse(lines, wide, load_re=None):
     """returns (best loads-in-flight stretch, its VALU count, static VALU of the kernel, v_mov count, block VALU)"""
-    load_pat = re.compile(r"^global_load_dwordx4\b" if wide else r"^global_load_")
+    load_pat = re.compile(load_re if load_re else (r"^global_load_dwordx4\b" if wide else r"^global_load_"))
     blocks, cur = [], []
     for ln in lines:
         op = ln.split()[0]
@@ -193,7 +196,7 @@ def main():
                     for epat, over in EXCEPTIONS:
                         if re.search(epat, dn):
                             rule.update(over)
-                    loads, valu, movs, block_valu = analyse(lines, rule["wide"])
+                    loads, valu, movs, block_valu = analyse(lines, rule["wide"], rule.get("load_re"))
                     counted = valu if rule["scope"] == "kernel" else block_valu
                     share = movs / max(valu, 1)
                     # (the v_mov share only means something for a kernel of some size: a 30-instruction kernel whose owner

@@ -21,7 +21,7 @@ stats() {  # stats <name> <bench args...>: bench line + kernel stats of the same
 stats n1_bench --no-cpu-baseline
 # the same process, per launch: the placement probes of bench.py run on slower candidate pairs too, so the stats average over
 # ALL launches sits above the timed region's; the tail of the trace (timed region + stability leg) is what `kernel_ms` measures
-WM_TAG=$TAG WM_KERNEL_MS_OUT=$OUT/kernel_ms.json python - $(find /tmp/prof_n1_bench -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_n1_bench_kernel_trace_tail.txt <<'PY'
+WM_TAG=$TAG WM_KERNEL_MS_OUT=$OUT/kernel_ms.json WM_BENCH_LINE=$OUT/${TAG}_n1_bench_under_rocprof.json python - $(find /tmp/prof_n1_bench -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_n1_bench_kernel_trace_tail.txt <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rows_batch_kernel" in r["Kernel_Name"] or "rows_copy16_fast_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -29,7 +29,13 @@ dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows
 tail = dur[-400:]
 print("kernel: %s" % rows[-1]["Kernel_Name"])
 import json, os
+step_ms = None
+try:   # the step time of THIS collection's own bench line: bench.py cites the kernel time only for runs at the same speed
+    step_ms = json.loads(open(os.environ["WM_BENCH_LINE"]).read().strip().splitlines()[-1])["ms_per_step"]
+except Exception:
+    pass
 json.dump({"file": os.environ.get("WM_TAG", "r05") + "_n1_bench_kernel_stats.csv", "commit": os.environ.get("WM_COMMIT", "worktree"),
+           "collection_ms_per_step": step_ms,
            "kernel": rows[-1]["Kernel_Name"], "launches": len(tail), "average_ms": round(sum(tail) / len(tail), 4),
            "min_ms": round(min(tail), 4), "max_ms": round(max(tail), 4),
            "what": "rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`: the last launches of the process "

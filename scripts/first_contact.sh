@@ -58,8 +58,14 @@ done
 run chunked_direct_n$N "" --gpus $N --memory-type chunked --no-cpu-baseline $SIZES
 run chunked_via_exchange_n$N "WM_MAPPED_VIA_EXCHANGE=1" --gpus $N --memory-type chunked --no-cpu-baseline $SIZES
 # 4 C4
+#   f16 x 256 on a CONTINUOUS table (C4 as BASELINE names it; the 16-bit fold is free of the reference's order): with the
+#   sender-side combination of duplicate gradient rows (the default decision from the duplicate estimate) and with every copy
+#   shipped; fp32 x 128 DISTRIBUTED in the reference's order (every copy travels, the hot id's owner folds an ordered chain) and
+#   with grad_fold = tree (combined). Predictions: first_contact_report.py: predicted_zipf, DESIGN.md section 4.
 run c4_grad_apply_f16_n$N "" --gpus $N --op grad_apply --dtype f16 --dim 256 --memory-type continuous --dist zipf --no-cpu-baseline $SIZES
+run c4_grad_apply_f16_every_copy_n$N "WM_GRAD_COMBINE=0" --gpus $N --op grad_apply --dtype f16 --dim 256 --memory-type continuous --dist zipf --no-cpu-baseline $SIZES
 run c4_grad_apply_f32_n$N "" --gpus $N --op grad_apply --dim 128 --memory-type distributed --dist zipf --no-cpu-baseline $SIZES
+run c4_grad_apply_f32_tree_n$N "WM_GRAD_FOLD=tree" --gpus $N --op grad_apply --dim 128 --memory-type distributed --dist zipf --no-cpu-baseline $SIZES
 # 5 C5
 run c5_sample_gather_n$N "" --gpus $N --op sample_gather $C5SIZES
 # 6 kernel stats of the N-rank uniform run

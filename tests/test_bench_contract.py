@@ -37,6 +37,9 @@ def test_single_gpu_line(wm_lib):
     # what each time in the object is (round-4 review): the HIP-event time of a step, the rocprofv3 average of the kernel when
     # profiles/ holds one for this workload (not for this toy size), and the same launch as a sequential copy in this process
     assert roof["step_ms_hip_events"] > 0 and "kernel_ms" not in roof and "kernel_ms_rocprof" in roof and "kernel_ms_source" in roof
+    # one box per number (round-5 review): a kernel time cited for THIS line never exceeds this line's step
+    if roof["kernel_ms_rocprof"] is not None:
+        assert roof["kernel_ms_rocprof"] <= r["ms_per_step"] and abs(roof["profile_step_ms"] - r["ms_per_step"]) <= 0.02 * r["ms_per_step"]
     assert roof["copy_ms_sequential_ids"] > 0 and 0 < roof["copy_frac"] < 1
     assert abs(roof["vs_copy"] - roof["copy_ms_sequential_ids"] / roof["step_ms_hip_events"]) < 1e-2
     cpu = r["cpu_baseline"]
@@ -164,3 +167,11 @@ def test_first_contact_kit_dry_run(wm_lib, world, tmp_path):
     assert m["c3_zipf_clustered_n%d" % world]["config"]["index_distribution"] == "zipf_clustered"
     assert m["chunked_direct_n%d" % world]["config"]["memory_type"] == "chunked"
     assert str(world) in rep["predictions_uniform"] and rep["predictions_uniform"]["2"]["link_bound_ms_at_76.8"] > 30
+
+
+def test_committed_kernel_profile_is_consistent_with_its_own_collection():
+    """profiles/kernel_ms.json (what bench.py may cite as roofline.kernel_ms_rocprof) carries the step time of the collection it
+    was measured in, and inside that collection the kernel does not take longer than the step that contains it."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "kernel_ms.json")))
+    assert rec["collection_ms_per_step"] > 0 and rec["average_ms"] <= rec["collection_ms_per_step"]
+    assert os.path.exists(os.path.join(ROOT, "profiles", rec["file"]))

@@ -3,6 +3,8 @@
 exchange_embeddings_nccl_func.cu:76-103 (duplicates summed sequentially in receive order) + embedding_optimizer_func.cu:178-329,
 331-421, 583-686, 781-884 (the four update rules).
 
+Round 6: rows of whole 8-byte pieces that are not whole 16-byte ones (602, 130, 66 floats) take step_tile_kernel's 8-byte-piece
+instantiation (global_load_dwordx2 batches, ISA-gated) instead of the wave-per-run kernel.
 Row shapes: 75 / 25 / 50 / 250 sixteen-byte pieces (GloVe / word2vec 300 / 100 / 200, 1000 floats), 2408-byte rows (Reddit's
 602 floats: 8-byte pieces, on a 16-byte and on a 128-byte row stride), 513 floats (4-byte pieces), 36 and 130 floats (a row
 shorter / a little longer than a wave step) and the tile kernel's own 128 / 64 floats. Each must give the oracle's bits: tables,
@@ -31,7 +33,11 @@ def _env():
 @pytest.mark.parametrize("kind,code,params", OPTS, ids=lambda x: str(x))
 @pytest.mark.parametrize("dim,align,idt", [(300, 4, np.int64), (100, 4, np.int32), (200, 4, np.int64), (1000, 4, np.int64),
                                            (602, 32, np.int64), (602, 4, np.int32), (513, 4, np.int64), (36, 4, np.int64),
-                                           (130, 32, np.int64), (128, 4, np.int64), (64, 4, np.int32)])
+                                           (130, 32, np.int64), (128, 4, np.int64), (64, 4, np.int32),
+                                           # the reference's own gradient-apply test dims (wholememory_embedding_gradient_apply_tests.cu:
+                                           # 481-501): 127 (stride 128), 129 (stride 132), 392; and the smallest row the 8-byte-piece
+                                           # tile kernel takes (66 floats; 602 and 130 above take it too, round 6)
+                                           (127, 4, np.int64), (129, 4, np.int32), (392, 4, np.int64), (66, 4, np.int64)])
 def test_odd_row_step_bit_exact(gpu_env, kind, code, params, dim, align, idt):
     import torch
     from wholegraph_amd import binding as wmb

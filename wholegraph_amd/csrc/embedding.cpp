@@ -177,7 +177,7 @@ wholememory_error_code_t create_states(wholememory_embedding_* e)
     }
     // zero the local shard of the packed states (reference zero_local_state_tensor)
     auto* ld = wholememory_tensor_get_tensor_description(e->state_local);
-    if (WM_KNOB("WM_STATE_ZERO_MEMSET") != nullptr)
+    if (WM_AB_KNOB("WM_STATE_ZERO_MEMSET") != nullptr)
       WM_BK(bk->memset_async(wholememory_tensor_get_data_pointer(e->state_local), 0,
                              static_cast<size_t>(ld->sizes[0]) * ld->strides[0] * sizeof(float), nullptr));
     else
@@ -560,7 +560,7 @@ wholememory_error_code_t gather_gradient_apply(wholememory_embedding_* e, wholem
 
   // this rank's own rows are not copied at all: the step kernels read them where the caller left them (the receive
   // positions of the self segment are remapped to caller rows after the sort). WM_GRAD_SELF_COPY=1 restores the copy.
-  const char* self_copy_env = WM_KNOB("WM_GRAD_SELF_COPY");
+  const char* self_copy_env = WM_AB_KNOB("WM_GRAD_SELF_COPY");
   const bool self_local     = !e->comm->loopback;  // loopback: the self segment is exchanged like a peer's
   const bool self_in_place  = self_local && bk->remap_self_order != nullptr &&
                              !(self_copy_env != nullptr && self_copy_env[0] == '1');

@@ -399,7 +399,7 @@ namespace {
 int hop_offsets(const wm_device_backend* bk, const wm_sample_args& a, const int* n_dev, int* counts, int* offsets, void* scan_ws,
                 size_t scan_ws_bytes, void* stream, int ws_is_ones = 0)
 {
-  const char* sw = WM_KNOB("WM_SAMPLE_FUSED_SCAN");
+  const char* sw = WM_AB_KNOB("WM_SAMPLE_FUSED_SCAN");
   if (bk->sample_offsets != nullptr && !(sw != nullptr && sw[0] == '0')) {
     const int rc = bk->sample_offsets(&a.row_gref, a.row_storage_offset, a.centers, a.center_dtype, a.n_center, n_dev,
                                       a.max_sample_count, offsets, scan_ws, scan_ws_bytes, ws_is_ones, stream);

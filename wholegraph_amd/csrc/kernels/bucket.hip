@@ -349,7 +349,7 @@ int run_bucket(const wm_bucket_args* a, hipStream_t stream)
   int64_t* block_counts = static_cast<int64_t*>(a->workspace);
   const IdxT* ids       = static_cast<const IdxT*>(a->indices);
   const int owners      = a->owner_count > 0 ? a->owner_count : a->world_size;
-  const char* de        = WM_KNOB("WM_BUCKET_DENSE");   // 0: the peel loop for every world size (A/B)
+  const char* de        = WM_AB_KNOB("WM_BUCKET_DENSE");   // 0: the peel loop for every world size (A/B)
   const bool dense      = a->world_size + 1 <= kDenseBuckets && !(de != nullptr && de[0] == '0');
   if (!(a->reuse_scan && a->bucketed_ids != nullptr)) {  // (reuse: the counts-only call over the same ids left the scan behind)
     if (dense)

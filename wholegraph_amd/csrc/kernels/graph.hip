@@ -271,7 +271,7 @@ int chain_scan(Fn fn, int n, int* out, Tail tail, void* state, hipStream_t strea
   // there the tile numbers come from the ticket counter (see the kernel). WM_SCAN_STATIC=1: round 4's mapping (A/B only).
   const int n_tiles = (n + tile - 1) / tile;
   const bool one_to_one = n_tiles <= 8 * cus_of[dev];
-  const bool static_ab = WM_KNOB("WM_SCAN_STATIC") != nullptr && WM_KNOB("WM_SCAN_STATIC")[0] == '1';
+  const bool static_ab = WM_AB_KNOB("WM_SCAN_STATIC") != nullptr && WM_AB_KNOB("WM_SCAN_STATIC")[0] == '1';
   const dim3 grid(one_to_one && !static_ab ? n_tiles : std::min(n_tiles, cus_of[dev])), block(kChainThreads);
   const bool tickets = !one_to_one && !static_ab;
 #define WM_CHAIN(ITEMS)                                                                                              \
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64) void sample_large_kernel(sample_params p)
 template <typename IdT, typename ColT>
 int launch_sample(sample_params p, hipStream_t stream)
 {
-  const bool small = p.max_sample >= 1 && p.max_sample <= 64 && WM_KNOB("WM_SAMPLE_LDS") == nullptr;
+  const bool small = p.max_sample >= 1 && p.max_sample <= 64 && WM_AB_KNOB("WM_SAMPLE_LDS") == nullptr;
   if (p.fill_ptr != nullptr && (p.n_center == 0 || !small)) {   // only the small-sample kernels carry the side job
     if (fill_ff(p.fill_ptr, p.fill_vecs * 16, stream) != 0) return -2;
     p.fill_ptr = nullptr;
@@ -579,10 +579,10 @@ int launch_sample(sample_params p, hipStream_t stream)
   if (p.n_center == 0) return 0;
   if (p.max_sample > kMaxSparse) {
     hipLaunchKernelGGL((sample_large_kernel<IdT, ColT>), dim3(p.n_center), dim3(64), 0, stream, p);
-  } else if (p.max_sample >= 1 && p.max_sample <= 32 && WM_KNOB("WM_SAMPLE_LDS") == nullptr && WM_KNOB("WM_SAMPLE_ONE_PER_WAVE") == nullptr) {
+  } else if (p.max_sample >= 1 && p.max_sample <= 32 && WM_AB_KNOB("WM_SAMPLE_LDS") == nullptr && WM_AB_KNOB("WM_SAMPLE_ONE_PER_WAVE") == nullptr) {
     const int per_block = 2 * kWavesPerBlk;   // two centres per wave
     hipLaunchKernelGGL((sample_small_kernel<IdT, ColT, 32>), dim3((p.n_center + per_block - 1) / per_block), dim3(kBlock), 0, stream, p);
-  } else if (p.max_sample >= 1 && p.max_sample <= 64 && WM_KNOB("WM_SAMPLE_LDS") == nullptr) {
+  } else if (p.max_sample >= 1 && p.max_sample <= 64 && WM_AB_KNOB("WM_SAMPLE_LDS") == nullptr) {
     const int blocks = (p.n_center + kWavesPerBlk - 1) / kWavesPerBlk;
     hipLaunchKernelGGL((sample_small_kernel<IdT, ColT, 64>), dim3(blocks), dim3(kBlock), 0, stream, p);
   } else {
@@ -1091,7 +1091,7 @@ int au_phase1(const void* targets, int nt, const void* neighbors, int nn, const 
   // flags, ranking scan and the publishing of the count as ONE launch (round 4: chain_scan_kernel evaluates the flag — two
   // dependent random loads — for a thread's values up front; rocPRIM's look-back scan over the same functor took 19.9 us
   // against 6.8 + 5.9 us for flag kernel + plain scan, which is why round 3 kept four launches here). WM_AU_FUSED_SCAN=0: A/B.
-  const char* fused_sw = WM_KNOB("WM_AU_FUSED_SCAN");
+  const char* fused_sw = WM_AB_KNOB("WM_AU_FUSED_SCAN");
   if (chain_scan_fits(static_cast<int64_t>(nn) + 1) && !(fused_sw != nullptr && fused_sw[0] == '0')) {
     au_flag_fn fn{positions, l.slot_of, nt, nn, sizeof(UKey) == 4 ? 2 : 1, nn_dev, nt_dev, 0, 0};
     if (late) return chain_scan(fn, nn + 1, l.new_rank, no_tail{}, l.scan_state, stream);   // phase 2's kernel publishes
@@ -1275,7 +1275,7 @@ int aus_phase2(const void* targets, int nt, int nn, void* ws, void* out_unique, 
 inline bool au_use_table(int nt, int nn, wholememory_dtype_t dt)
 {
   const int64_t forced = [] {
-    const char* e = WM_KNOB("WM_AU_TABLE_MAX");
+    const char* e = WM_AB_KNOB("WM_AU_TABLE_MAX");
     return e != nullptr ? static_cast<int64_t>(atoll(e)) : INT64_C(-1);
   }();
   const int64_t limit = forced >= 0 ? forced : (dt == WHOLEMEMORY_DT_INT ? INT64_C(128) << 20 : INT64_C(24) << 20);

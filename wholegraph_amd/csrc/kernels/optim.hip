@@ -709,9 +709,9 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
       // With the fork by a word nothing ties the side stream's launches to a place in the caller's queue: the caller's kernels
       // — the split sort's four — are enqueued FIRST (a mini-batch is bound by the host's launch rate — the nine side launches in the middle delayed the
       // scatter kernel by as many launch times), then the side stream, then the join kernel.
-      const bool side_last = verdict_word != nullptr && !(WM_KNOB("WM_SIDE_FIRST") != nullptr && WM_KNOB("WM_SIDE_FIRST")[0] == '1');
+      const bool side_last = verdict_word != nullptr && !(WM_AB_KNOB("WM_SIDE_FIRST") != nullptr && WM_AB_KNOB("WM_SIDE_FIRST")[0] == '1');
       auto nothing         = []() {};
-      const bool after_scatter = WM_KNOB("WM_DEDUP_FORK") != nullptr && WM_KNOB("WM_DEDUP_FORK")[0] == '3';
+      const bool after_scatter = WM_AB_KNOB("WM_DEDUP_FORK") != nullptr && WM_AB_KNOB("WM_DEDUP_FORK")[0] == '3';
       const int launched =
         side_last ? split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
                                         static_cast<uint32_t>(span), unique_ids, run_starts, order, n_unique_out, sl.split_ws,
@@ -1146,11 +1146,41 @@ __device__ __forceinline__ P* tile_bcast_ptr(P* p, int e0, int sub)
 // workgroups 5-8 % slower than 8192.
 // T = element type of the table AND of the gradient rows: float, or half / bf16 (SGD only: duplicates are summed in fp32
 // in receive order, the update is computed in fp32 from fp32(e) and rounded once — 8 elements per 16-byte piece).
+// PIECE = bytes a lane moves per step: 16 (rows of whole 16-byte pieces), or — round 6, fp32 only — 8: rows of whole 8-byte
+// pieces that are not whole 16-byte ones (602 floats = 2408 B, the Reddit feature width; any dim = 2 mod 4) used to miss this
+// kernel altogether and took the wave-per-run kernel (global_load_dwordx2, one run at a time).
 typedef uint32_t tile_raw4 __attribute__((ext_vector_type(4)));
+typedef uint32_t tile_raw2 __attribute__((ext_vector_type(2)));
+template <int PIECE>
+struct tile_raw_of {
+  typedef tile_raw4 type;
+};
+template <>
+struct tile_raw_of<8> {
+  typedef tile_raw2 type;
+};
 template <int N>
 struct tile_vals {
   float v[N];
 };
+template <typename T>
+__device__ __forceinline__ tile_vals<2> tile_unpack(tile_raw2 r)
+{
+  static_assert(std::is_same<T, float>::value, "8-byte pieces: fp32 rows only");
+  tile_vals<2> out;
+  out.v[0] = __builtin_bit_cast(float, static_cast<uint32_t>(r.x));
+  out.v[1] = __builtin_bit_cast(float, static_cast<uint32_t>(r.y));
+  return out;
+}
+template <typename T>
+__device__ __forceinline__ tile_raw2 tile_pack(const tile_vals<2>& in)
+{
+  static_assert(std::is_same<T, float>::value, "8-byte pieces: fp32 rows only");
+  tile_raw2 r;
+  r.x = __builtin_bit_cast(uint32_t, in.v[0]);
+  r.y = __builtin_bit_cast(uint32_t, in.v[1]);
+  return r;
+}
 template <typename T>
 __device__ __forceinline__ tile_vals<16 / sizeof(T)> tile_unpack(tile_raw4 r)
 {
@@ -1186,15 +1216,18 @@ __device__ __forceinline__ tile_raw4 tile_pack(const tile_vals<16 / sizeof(T)>& 
   return r;
 }
 
-template <typename IdxT, int OPT, int RPS, bool CACHED, typename T = float, int KU = 0, int OCC = 0>
+template <typename IdxT, int OPT, int RPS, bool CACHED, typename T = float, int KU = 0, int OCC = 0, int PIECE = 16>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC > 0 ? OCC : 1, OCC > 0 ? OCC : 8)))
 void step_tile_kernel(opt_params p)
 {
+  static_assert(PIECE == 16 || (PIECE == 8 && sizeof(T) == 4), "pieces of 16 bytes, or of 8 bytes of fp32 rows");
+  typedef typename tile_raw_of<PIECE>::type raw_t;
+  constexpr int kSV = PIECE / 4;   // fp32 state values per piece
   // optimizer states move non-temporally like the rows (round 4, interleaved in one process, 10 M uniform rows of 128 floats:
   // LazyAdam 6.69 -> 6.38 ms, Zipf 4.83 -> 4.56; AdaGrad 4.53 -> 4.49; RMSProp 4.47 -> 4.45)
-  auto ld_state = [](const void* q) { return ld_global_nt<tile_raw4>(q); };
-  auto st_state = [](void* q, tile_raw4 v) { st_global_nt<tile_raw4>(q, v); };
-  constexpr int kVE          = 16 / static_cast<int>(sizeof(T));  // elements per lane
+  auto ld_state = [](const void* q) { return ld_global_nt<raw_t>(q); };
+  auto st_state = [](void* q, raw_t v) { st_global_nt<raw_t>(q, v); };
+  constexpr int kVE          = PIECE / static_cast<int>(sizeof(T));  // elements per lane
   constexpr bool k16         = sizeof(T) == 2;
   constexpr int kU           = KU > 0 ? KU : ((OPT == WHOLEMEMORY_OPT_SGD && !k16) ? WM_TILE_KU_SGD : WM_TILE_KU_STATE);
   constexpr int kLpr         = 64 / RPS;
@@ -1253,7 +1286,7 @@ void step_tile_kernel(opt_params p)
       const int64_t coff = static_cast<int64_t>(min(cbase + col, row_vecs - 1)) * kVE;
 #pragma unroll 1
       for (int s = 0; s < tile_runs; s += RPS * kU) {
-        tile_raw4 gv[kU], ev[kU], s0v[kU], s1v[kU];
+        raw_t gv[kU], ev[kU], s0v[kU], s1v[kU];
         T* trow[kU];
         float* srow[kU];
 #pragma unroll
@@ -1262,8 +1295,8 @@ void step_tile_kernel(opt_params p)
           const T* g   = tile_lane_ptr<RPS>(my_grad, e0, sub);
           trow[k]      = tile_lane_ptr<RPS>(my_row, e0, sub);
           if (kState) srow[k] = tile_lane_ptr<RPS>(my_st, e0, sub);
-          gv[k]        = ld_global_nt<tile_raw4>(g + coff);
-          ev[k]        = ld_global_nt<tile_raw4>(trow[k] + coff);
+          gv[k]        = ld_global_nt<raw_t>(g + coff);
+          ev[k]        = ld_global_nt<raw_t>(trow[k] + coff);
           if (kState) s0v[k] = ld_state(srow[k] + coff);
           if (kAdam) s1v[k] = ld_state(srow[k] + a.table_stride + coff);
         }
@@ -1279,11 +1312,11 @@ void step_tile_kernel(opt_params p)
             const int32_t ln = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_len), s + RPS * k, sub));
             const int32_t rs = static_cast<int32_t>(tile_bcast32<RPS>(static_cast<uint32_t>(my_s0), s + RPS * k, sub));
             for (int32_t j = 1; j < longest; j += kDup) {
-              tile_raw4 gq[kDup];
+              raw_t gq[kDup];
 #pragma unroll
               for (int q = 0; q < kDup; q++) {
                 const int32_t o = a.order[rs + min(j + q, ln - 1)];
-                gq[q]           = ld_global_nt<tile_raw4>(grad_row<T>(a, o) + coff);
+                gq[q]           = ld_global_nt<raw_t>(grad_row<T>(a, o) + coff);
               }
 #pragma unroll
               for (int q = 0; q < kDup; q++) {
@@ -1296,7 +1329,7 @@ void step_tile_kernel(opt_params p)
             }
           }
           const tile_vals<kVE> e_in = tile_unpack<T>(ev[k]);
-          tile_vals<4> s0_in{}, s1_in{}, so0{}, so1{};
+          tile_vals<kSV> s0_in{}, s1_in{}, so0{}, so1{};
           tile_vals<kVE> eo;
           if (kState) s0_in = tile_unpack<float>(s0v[k]);
           if (kAdam) s1_in = tile_unpack<float>(s1v[k]);
@@ -1309,16 +1342,16 @@ void step_tile_kernel(opt_params p)
           for (int v = 0; v < kVE; v++) {
             opt_elem x;
             x.e  = e_in.v[v];
-            x.s0 = kState ? s0_in.v[v & 3] : 0.f;
-            x.s1 = kAdam ? s1_in.v[v & 3] : 0.f;
+            x.s0 = kState ? s0_in.v[v & (kSV - 1)] : 0.f;
+            x.s1 = kAdam ? s1_in.v[v & (kSV - 1)] : 0.f;
             opt_math<OPT>(a, x, acc.v[v], b1, b2);
             eo.v[v] = x.e;
-            if (kState) so0.v[v & 3] = x.s0;
-            if (kAdam) so1.v[v & 3] = x.s1;
+            if (kState) so0.v[v & (kSV - 1)] = x.s0;
+            if (kAdam) so1.v[v & (kSV - 1)] = x.s1;
           }
           if (kState) st_state(srow[k] + coff, tile_pack<float>(so0));
           if (kAdam) st_state(srow[k] + a.table_stride + coff, tile_pack<float>(so1));
-          st_global_nt<tile_raw4>(trow[k] + coff, tile_pack<T>(eo));
+          st_global_nt<raw_t>(trow[k] + coff, tile_pack<T>(eo));
         }
       }
     }
@@ -1342,18 +1375,18 @@ void step_tile_kernel(opt_params p)
         }
         if (c >= row_vecs) ln = 0;
         if (ln <= 0) continue;
-        tile_vals<kVE> acc = tile_unpack<T>(ld_global_nt<tile_raw4>(g + coff));   // first occurrence copied
-        const tile_raw4 ev = ld_global_nt<tile_raw4>(trow + coff);
-        tile_raw4 s0v{}, s1v{};
+        tile_vals<kVE> acc = tile_unpack<T>(ld_global_nt<raw_t>(g + coff));   // first occurrence copied
+        const raw_t ev = ld_global_nt<raw_t>(trow + coff);
+        raw_t s0v{}, s1v{};
         if (kState) s0v = ld_state(srow + coff);
         if (kAdam) s1v = ld_state(srow + a.table_stride + coff);
         for (int32_t j = 1; j < ln; j++) {   // later occurrences added in receive order
-          const tile_vals<kVE> gx = tile_unpack<T>(ld_global_nt<tile_raw4>(grad_row<T>(a, a.order[rs + j]) + coff));
+          const tile_vals<kVE> gx = tile_unpack<T>(ld_global_nt<raw_t>(grad_row<T>(a, a.order[rs + j]) + coff));
 #pragma unroll
           for (int v = 0; v < kVE; v++) acc.v[v] += gx.v[v];
         }
         const tile_vals<kVE> e_in = tile_unpack<T>(ev);
-        tile_vals<4> s0_in{}, s1_in{}, so0{}, so1{};
+        tile_vals<kSV> s0_in{}, s1_in{}, so0{}, so1{};
         tile_vals<kVE> eo;
         if (kState) s0_in = tile_unpack<float>(s0v);
         if (kAdam) s1_in = tile_unpack<float>(s1v);
@@ -1361,16 +1394,16 @@ void step_tile_kernel(opt_params p)
         for (int v = 0; v < kVE; v++) {
           opt_elem x;
           x.e  = e_in.v[v];
-          x.s0 = kState ? s0_in.v[v & 3] : 0.f;
-          x.s1 = kAdam ? s1_in.v[v & 3] : 0.f;
+          x.s0 = kState ? s0_in.v[v & (kSV - 1)] : 0.f;
+          x.s1 = kAdam ? s1_in.v[v & (kSV - 1)] : 0.f;
           opt_math<OPT>(a, x, acc.v[v], b1, b2);
           eo.v[v] = x.e;
-          if (kState) so0.v[v & 3] = x.s0;
-          if (kAdam) so1.v[v & 3] = x.s1;
+          if (kState) so0.v[v & (kSV - 1)] = x.s0;
+          if (kAdam) so1.v[v & (kSV - 1)] = x.s1;
         }
         if (kState) st_state(srow + coff, tile_pack<float>(so0));
         if (kAdam) st_state(srow + a.table_stride + coff, tile_pack<float>(so1));
-        st_global_nt<tile_raw4>(trow + coff, tile_pack<T>(eo));
+        st_global_nt<raw_t>(trow + coff, tile_pack<T>(eo));
       }
     }
   }
@@ -2033,7 +2066,7 @@ __global__ __launch_bounds__(kBlock) void tree_combine_kernel(opt_params p, tree
 
 inline int tree_threshold()
 {
-  const char* e = WM_KNOB("WM_GRAD_FOLD_MIN");
+  const char* e = WM_AB_KNOB("WM_GRAD_FOLD_MIN");
   const int v   = e != nullptr ? atoi(e) : 0;
   return v >= 4 && v <= kLongRun ? v : kTreeMin;
 }
@@ -2061,7 +2094,7 @@ void launch_tree(const opt_params& p, hipStream_t stream, hipStream_t lstream)
     (void)hipStreamWaitEvent(stream, long_lane::get().marked, 0);
   }
   int fgrid = 2048;
-  if (const char* e = WM_KNOB("WM_TREE_GRID")) fgrid = std::max(1, atoi(e));
+  if (const char* e = WM_AB_KNOB("WM_TREE_GRID")) fgrid = std::max(1, atoi(e));
   hipLaunchKernelGGL((tree_fold_kernel<IdxT, OPT, T>), dim3(fgrid), dim3(kBlock), 0, lstream, p, w);
   hipLaunchKernelGGL((tree_combine_kernel<IdxT, OPT, T>), dim3(256), dim3(kBlock), 0, lstream, p, w);
 }
@@ -2078,16 +2111,16 @@ inline void tile_launch_shape(int64_t count_bound, int vecs, int ku, int* tile_r
 {
   const int rps      = vecs > 32 ? 1 : vecs > 16 ? 2 : vecs > 8 ? 4 : 8;
   const int batch    = rps * ku;
-  const char* io_env = WM_KNOB("WM_TILE_INORDER");
+  const char* io_env = WM_AB_KNOB("WM_TILE_INORDER");
   const bool inorder = io_env != nullptr && io_env[0] == '1';
   *tile_runs         = inorder ? std::min(64, batch) : 64;
-  if (const char* e = WM_KNOB("WM_TILE_RUNS")) {
+  if (const char* e = WM_AB_KNOB("WM_TILE_RUNS")) {
     const int v = atoi(e);
     if (v >= batch && v <= 64 && v % batch == 0) *tile_runs = v;
   }
   const int64_t tiles = (count_bound + *tile_runs - 1) / *tile_runs;
   int b = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, inorder ? INT64_C(0x7fffffff) : INT64_C(256 * 32)));
-  if (const char* e = WM_KNOB("WM_STEP_BLOCKS")) b = std::min(b, std::max(1, atoi(e)));
+  if (const char* e = WM_AB_KNOB("WM_STEP_BLOCKS")) b = std::min(b, std::max(1, atoi(e)));
   *tblocks = std::max(b, 1);
 }
 
@@ -2109,7 +2142,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
       const bool long4 = p.a.dim % kSliceCols == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4;
       const bool rows4 = p.a.dim % 4 == 0 && p.a.grad_stride % 4 == 0 && gaddr % 16 == 0 && self_ok4 &&
                          p.a.dim <= 65535 * slice4_cols<float>();
-      const bool old_long = WM_KNOB("WM_STEP_LONG_OLD") != nullptr;
+      const bool old_long = WM_AB_KNOB("WM_STEP_LONG_OLD") != nullptr;
       if (rows4 && !old_long) {
         static const bool lds_ok =
           hipFuncSetAttribute(reinterpret_cast<const void*>(&step_long4_kernel<IdxT, OPT>),
@@ -2119,7 +2152,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
         // run list — with more workgroups than CUs the hottest run may only START after several rounds of others
         const int slices4 = static_cast<int>((p.a.dim + slice4_cols<float>() - 1) / slice4_cols<float>());
         int gx            = std::max(1, 256 / slices4);
-        if (const char* e = WM_KNOB("WM_LONG_GRID")) gx = std::max(1, atoi(e));
+        if (const char* e = WM_AB_KNOB("WM_LONG_GRID")) gx = std::max(1, atoi(e));
         hipLaunchKernelGGL((step_long4_kernel<IdxT, OPT>), dim3(gx, slices4), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
       }
       else if (long4)
@@ -2134,7 +2167,7 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
   // stateful optimizers through register pressure — 8 bytes per lane stay)
   const bool cached = p.a.cache_slot_of != nullptr;
   // rows of whole 16-byte pieces on every side: the tile kernel (WM_STEP_TILE=0 keeps the wave-per-run kernel)
-  const bool tile_off = WM_KNOB("WM_STEP_TILE") != nullptr && WM_KNOB("WM_STEP_TILE")[0] == '0';
+  const bool tile_off = WM_AB_KNOB("WM_STEP_TILE") != nullptr && WM_AB_KNOB("WM_STEP_TILE")[0] == '0';
   const bool st_ok = p.a.per_element_state == nullptr ||
                      (p.a.per_element_stride % 4 == 0 && reinterpret_cast<uint64_t>(p.a.per_element_state) % 16 == 0 &&
                       (p.a.cache_state_data == nullptr || (p.a.cache_state_row_elems % 4 == 0 &&
@@ -2164,6 +2197,23 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
     else if (vecs > 8) WM_TILE(4);
     else WM_TILE(8);
 #undef WM_TILE
+    if (p.detached_side == 1 && long_side() != 0) return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
+  // rows of whole 8-byte pieces that are not whole 16-byte ones (dim = 2 mod 4: 602 floats, the Reddit feature width): the tile
+  // kernel with 8-byte pieces (round 6) — one 512-byte wave step per row instead of the wave-per-run kernel below.
+  // WM_STEP_TILE8=0 keeps the wave-per-run kernel (A/B).
+  const bool tile8_off = WM_AB_KNOB("WM_STEP_TILE8") != nullptr && WM_AB_KNOB("WM_STEP_TILE8")[0] == '0';
+  const bool tile8_ok  = !tile_off && !tile8_off && !cached && vec2 && p.a.dim >= 66 && p.a.table_stride % 2 == 0 &&
+                        reinterpret_cast<uint64_t>(p.a.local_table) % 8 == 0 &&
+                        (p.a.per_element_state == nullptr ||
+                         (p.a.per_element_stride % 2 == 0 && reinterpret_cast<uint64_t>(p.a.per_element_state) % 8 == 0));
+  if (tile8_ok) {
+    opt_params tp = p;
+    int tblocks   = 1;
+    constexpr int kKu = OPT == WHOLEMEMORY_OPT_SGD ? WM_TILE_KU_SGD : WM_TILE_KU_STATE;
+    tile_launch_shape(p.a.count, static_cast<int>(p.a.dim / 2), kKu, &tp.tile_runs, &tblocks);   // (> 32 pieces: one row per wave step)
+    hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, 1, false, float, 0, 0, 8>), dim3(tblocks), dim3(kBlock), 0, stream, tp);
     if (p.detached_side == 1 && long_side() != 0) return -2;
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
@@ -2210,7 +2260,7 @@ int launch_step_sgd16(opt_params p, int blocks, hipStream_t stream, hipStream_t 
   if (p.detached_side != 1 && long_side() != 0) return -2;
   const bool cached = p.a.cache_slot_of != nullptr;
   // rows of whole 16-byte pieces (8 elements) on every side: the tile kernel, as for fp32 tables
-  const bool tile_off = WM_KNOB("WM_STEP_TILE") != nullptr && WM_KNOB("WM_STEP_TILE")[0] == '0';
+  const bool tile_off = WM_AB_KNOB("WM_STEP_TILE") != nullptr && WM_AB_KNOB("WM_STEP_TILE")[0] == '0';
   const bool tile_ok = !tile_off && rows16 && p.a.dim >= 64 && p.a.table_stride % 8 == 0 &&
                        reinterpret_cast<uint64_t>(p.a.local_table) % 16 == 0 &&
                        (!cached || (p.a.cache_row_elems % 8 == 0 && reinterpret_cast<uint64_t>(p.a.cache_data) % 16 == 0));
@@ -2452,7 +2502,7 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   // say whether a long run can exist at all (last_split_record)
   if (g_last_split.run_starts == a->run_starts && g_last_split.unique_ids == a->ids && g_last_split.n_unique == n_unique_dev &&
       n_unique_dev != nullptr && g_last_split.ctl != nullptr && p.long_list != nullptr &&
-      WM_KNOB("WM_STEP_OWN_COUNTERS") == nullptr) {
+      WM_AB_KNOB("WM_STEP_OWN_COUNTERS") == nullptr) {
     p.split_ctl  = g_last_split.ctl;
     p.long_count = reinterpret_cast<int32_t*>(g_last_split.ctl + split::kCtlLongCounters);
   }
@@ -2477,7 +2527,7 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
     detached  = true;
     // (launch_mark_long_runs / launch_tree queue the waiting wave in front of their first kernel; 1: the side is enqueued
     // behind the tile kernel, 2 = WM_SIDE_FIRST=1: in front of it, the order of the first version, for A/B runs)
-    p.detached_side = WM_KNOB("WM_SIDE_FIRST") != nullptr && WM_KNOB("WM_SIDE_FIRST")[0] == '1' ? 2 : 1;
+    p.detached_side = WM_AB_KNOB("WM_SIDE_FIRST") != nullptr && WM_AB_KNOB("WM_SIDE_FIRST")[0] == '1' ? 2 : 1;
   }
   if (p.long_list != nullptr && !serial && long_lane::get().fork(stream)) lstream = long_lane::get().stream;
   // (the counters are cleared on the side stream: only the long-run kernels read them)
@@ -2486,7 +2536,7 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
     return -2;
   int64_t waves = a->count;
   int max_blocks = 256 * 8;
-  if (const char* e = WM_KNOB("WM_STEP_BLOCKS")) max_blocks = std::max(1, atoi(e));
+  if (const char* e = WM_AB_KNOB("WM_STEP_BLOCKS")) max_blocks = std::max(1, atoi(e));
   int blocks = static_cast<int>(std::min<int64_t>((waves + 3) / 4, max_blocks));
   if (blocks < 1) blocks = 1;
   int rc = -1;

@@ -860,7 +860,7 @@ inline void launch_rows_kernel(K kernel, int blocks, hipStream_t stream, const r
 {
   t_last_rows_kernel = reinterpret_cast<const void*>(kernel);
   // WM_ROWS_LDS=bytes (experiments): dynamic LDS nobody uses, to cap the workgroups resident per CU
-  const char* le   = WM_KNOB("WM_ROWS_LDS");
+  const char* le   = WM_AB_KNOB("WM_ROWS_LDS");
   const size_t lds = le != nullptr ? static_cast<size_t>(atoi(le)) : 0;
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(p.launch_threads), lds, stream, p);
 }
@@ -938,7 +938,7 @@ int inorder_setting()
 // 1024 5-12 % slower — the finer the unit the dispatcher hands out, the tighter the window)
 int inorder_block_threads()
 {
-  const char* e = WM_KNOB("WM_ROWS_BLOCK");
+  const char* e = WM_AB_KNOB("WM_ROWS_BLOCK");
   const int v   = e != nullptr ? atoi(e) : 0;
   return (v == 64 || v == 128 || v == 256) ? v : 256;
 }
@@ -947,7 +947,7 @@ int inorder_block_threads()
 // side, a power of two between one batch of the kernel (rps x 4 rows) and 64. WM_ROWS_SMALL_TILE=0 keeps 64-row tiles (A/B).
 int small_tile_rows(int lpr_log2, int64_t row_bytes)
 {
-  const char* e = WM_KNOB("WM_ROWS_SMALL_TILE");
+  const char* e = WM_AB_KNOB("WM_ROWS_SMALL_TILE");
   if (e != nullptr && e[0] == '0') return kWave;
   const int batch = (kWave >> lpr_log2) * 4;
   int t           = kWave;
@@ -965,13 +965,13 @@ int flat_override()
 // WM_ROWS_STAGED_SCATTER=0 switches the LDS-staged scatter off (A/B: the flat-stream kernel then)
 bool staged_scatter_enabled()
 {
-  const char* e = WM_KNOB("WM_ROWS_STAGED_SCATTER");
+  const char* e = WM_AB_KNOB("WM_ROWS_STAGED_SCATTER");
   return e == nullptr || e[0] != '0';
 }
 // longest row the staged kernels take (WM_ROWS_STAGED_MAXROW overrides, A/B)
 int64_t staged_max_row(bool gather)
 {
-  const char* e = WM_KNOB("WM_ROWS_STAGED_MAXROW");
+  const char* e = WM_AB_KNOB("WM_ROWS_STAGED_MAXROW");
   if (e != nullptr && atoll(e) > 0) return atoll(e);
   (void)gather;
   return 5120;
@@ -983,7 +983,7 @@ int64_t staged_max_row(bool gather)
 // or -1; rows of whole 16-byte pieces, scatter: 144 B +0.8, 176 B +2.2, 208 B +3.4, 240 B +5.2, 80 B equal.
 bool staged_row_wanted(bool gather, int64_t row_bytes)
 {
-  const char* e = WM_KNOB("WM_ROWS_STAGED_MINROW");
+  const char* e = WM_AB_KNOB("WM_ROWS_STAGED_MINROW");
   if (e != nullptr && atoll(e) > 0) return row_bytes >= atoll(e);
   if (gather) return row_bytes >= 16;
   // (scatter of 64 / 128 / 256 B rows: +1 / +1.2 / +6.6 although 96 B and 112 B lose 1-2: r03_dim_sweep_pow2_small.csv)
@@ -997,14 +997,14 @@ bool staged_row_wanted(bool gather, int64_t row_bytes)
 // WM_ROWS_STAGED_ALIGNED=0 / 1 forces.
 bool staged_aligned_rows(bool gather, int64_t row_bytes)
 {
-  const char* e = WM_KNOB("WM_ROWS_STAGED_ALIGNED");
+  const char* e = WM_AB_KNOB("WM_ROWS_STAGED_ALIGNED");
   if (e != nullptr && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
   return !gather || row_bytes < 512;
 }
 // WM_ROWS_STAGED=0 switches the LDS-staged gather off (A/B)
 bool staged_enabled()
 {
-  const char* e = WM_KNOB("WM_ROWS_STAGED");
+  const char* e = WM_AB_KNOB("WM_ROWS_STAGED");
   return e == nullptr || e[0] != '0';
 }
 
@@ -1281,7 +1281,7 @@ int rows_op(const wm_rows_args* a, void* stream_v)
       if (static_cast<int64_t>(R) * row_bytes <= cap) {   // bigger rows stay on the flat kernel
         p.stage_rows = R;
         {
-          const char* sa = WM_KNOB("WM_ROWS_STAGED_ALIGN_STORES");
+          const char* sa = WM_AB_KNOB("WM_ROWS_STAGED_ALIGN_STORES");
           p.stage_align  = (sa != nullptr && sa[0] == '0') ? 0 : 1;
         }
         if (inorder_mode == 0 || a->max_blocks > 0 || a->n >= (INT64_C(1) << 31)) {
@@ -1304,7 +1304,7 @@ int rows_op(const wm_rows_args* a, void* stream_v)
       }
     }
     if (p.stage_rows == 0 && (p.flat_slots > 0 || (vb == 16 && p.row_vecs >= 32))) {  // the two kernels that take tile_rows
-      const char* te    = WM_KNOB("WM_ROWS_TILE");  // experiment switch
+      const char* te    = WM_AB_KNOB("WM_ROWS_TILE");  // experiment switch
       const int forced  = te != nullptr ? atoi(te) : 0;
       p.tile_rows = row_bytes <= 768 ? 64 : row_bytes <= 1536 ? 32 : row_bytes <= 3072 ? 16 : 8;
       if (inorder) {
@@ -1318,13 +1318,13 @@ int rows_op(const wm_rows_args* a, void* stream_v)
           // wave writes two partial lines (4000 B rows on a packed output 64 % against 71 % on an output padded to 4 KiB,
           // profiles/r04_misaligned_rows.txt). Measured: 528 B +2.3, 640 B +2.0, 800 B +2.2, 2000 B +3.0, 4000 B +2.0 points,
           // 960 / 1200 / 1600 B within +-0.7. (WM_ROWS_FLAT_TILE8=0: the batch-filling rule above, A/B)
-          const char* t8 = WM_KNOB("WM_ROWS_FLAT_TILE8");
+          const char* t8 = WM_AB_KNOB("WM_ROWS_FLAT_TILE8");
           if (GATHER && vb == 16 && p.row_map == nullptr && !(t8 != nullptr && t8[0] == '0')) p.tile_rows = 8;
         } else {                  // readlane kernel: (tile_rows / RPS) x chunks steps, a multiple of its 4-step batch
           const int chunks = p.row_vecs > 32 ? (p.row_vecs + kWave - 1) / kWave : 1;
           p.tile_rows      = p.row_vecs == 32 ? 8 : chunks == 1 ? 4 : chunks == 2 ? 2 : chunks % 4 == 0 ? 1 : 4;
           // 512 B / 1 / 2 / 4 KiB rows: exactly one 4 KiB batch per tile -> the specialised kernel (WM_ROWS_BATCH=0: A/B)
-          const char* be = WM_KNOB("WM_ROWS_BATCH");
+          const char* be = WM_AB_KNOB("WM_ROWS_BATCH");
           // (continuous tables and owner tables by value; plain rows less than 2 GiB apart: 32-bit lane offsets)
           if ((p.row_vecs == 32 || p.row_vecs == 64 || p.row_vecs == 128 || p.row_vecs == 256) && forced == 0 &&
               (p.chunk_stride == 0 || p.owners_by_value) && p.plain_stride_bytes < (INT64_C(1) << 31) &&
@@ -1332,7 +1332,7 @@ int rows_op(const wm_rows_args* a, void* stream_v)
             p.batch_vecs = p.row_vecs;
             // one wave per workgroup for this kernel: the finest unit the dispatcher can hand out (measured against 256
             // threads on 512 B - 4 KiB rows: gather +0.2 ... +1.4 %, scatter +0.5 ... +1 %; the flat kernel loses 2-3 % with it)
-            if (WM_KNOB("WM_ROWS_BLOCK") == nullptr) p.launch_threads = kWave;
+            if (WM_AB_KNOB("WM_ROWS_BLOCK") == nullptr) p.launch_threads = kWave;
           }
         }
       }

@@ -61,3 +61,13 @@ inline void reload_knobs() { g_knob_generation.fetch_add(1, std::memory_order_ac
     static const ::wm::env_knob k(NAME);   \
     return k.str();                        \
   }())
+
+// A/B switches of kernel variants (WM_ROWS_*, WM_TILE_*, WM_STEP_TILE*, WM_SAMPLE_*, ... — what rounds 2-5 used to compare code
+// paths inside one process) are NOT part of the product (round-5 review: ~45 variables, two thirds of them branches in hot
+// launchers): in the shipped build such a site is the constant nullptr and its branch folds away. A variant build
+// (scripts/build_variant.sh NAME "..." with AB=1, or make AB=1) compiles them back in for experiments/*.
+#ifdef WM_AB_KNOBS
+#define WM_AB_KNOB(NAME) WM_KNOB(NAME)
+#else
+#define WM_AB_KNOB(NAME) (static_cast<const char*>(nullptr))
+#endif

@@ -107,7 +107,7 @@ int64_t host_sorted_gather_min()
 
 int host_sorted_gather_low_bit()
 {
-  const char* e = WM_KNOB("WM_HOST_SORTED_LOW_BIT");
+  const char* e = WM_AB_KNOB("WM_HOST_SORTED_LOW_BIT");
   return e != nullptr && atoi(e) > 0 ? atoi(e) : 0;
 }
 
