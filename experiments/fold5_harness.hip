@@ -33,18 +33,46 @@ struct store_ep {
   __device__ __forceinline__ void operator()(const job& jb, int col, float acc) const { out[static_cast<int64_t>(jb.user) * dim + col] = acc; }
 };
 
-template <int R>
-float time_fold(const job* jobs, const int32_t* n_jobs, int n_host, int dim, const float* dense, float* out, int reps)
+// a bandwidth hog for the "beside the tile kernel" runs: in-place update of a 5 GB buffer from another, `rounds` times
+typedef float hf4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void hog_kernel(hf4* a, const hf4* b, int64_t n4, int rounds)
 {
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_kernel<R, store_ep>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shape<R>::kLdsBytes)));
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int r = 0; r < rounds; r++)
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += 4 * stride) {
+      hf4 x[4], y[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int64_t j = min(i + u * stride, n4 - 1);
+        x[u] = __builtin_nontemporal_load(a + j), y[u] = __builtin_nontemporal_load(b + j);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (i + u * stride < n4) __builtin_nontemporal_store(x[u] - 0.01f * y[u], a + i + u * stride);
+    }
+}
+struct hog_t { hf4* a; const hf4* b; int64_t n4; hipStream_t stream; };
+
+// hog != nullptr: the fold is launched first (its workgroups get their CUs), the hog right behind it on another stream
+template <int R, int S>
+float time_fold(const job* jobs, const int32_t* n_jobs, int n_host, int dim, const float* dense, float* out, int reps, const hog_t* hog = nullptr)
+{
+  const void* kfn = reinterpret_cast<const void*>(&fold_kernel<R, S, store_ep>);
+  const int lds_bytes = static_cast<int>(shape<R, S>::kLdsBytes);
+  CK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipStream_t fs; int least, greatest; CK(hipDeviceGetStreamPriorityRange(&least, &greatest)); CK(hipStreamCreateWithPriority(&fs, hipStreamNonBlocking, greatest));
   float best = 1e30f;
   for (int r = 0; r < reps; r++) {
-    CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((fold_kernel<R, store_ep>), dim3(n_host, (dim + kSliceCols - 1) / kSliceCols), dim3(kBlock), shape<R>::kLdsBytes, 0, jobs, n_jobs, dim, dense, store_ep{out, dim});
-    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, fs));
+    hipLaunchKernelGGL((fold_kernel<R, S, store_ep>), dim3(n_host * slices_of(dim, S)), dim3(kBlock), lds_bytes, fs, jobs, n_jobs, dim, dense, store_ep{out, dim});
+    CK(hipEventRecord(e1, fs));
+    if (hog != nullptr) hipLaunchKernelGGL(hog_kernel, dim3(8192), dim3(256), 0, hog->stream, hog->a, hog->b, hog->n4, 2);
+    CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
   }
+  CK(hipDeviceSynchronize());
   return best;
 }
 
@@ -108,9 +136,17 @@ int main(int argc, char** argv)
     CK(hipMemset(out, 0, got.size() * 4));
   };
   const int nj = static_cast<int>(jobs.size());
-  check("fold R = 64", time_fold<64>(d_jobs, d_n, nj, dim, dense, out, 5));
-  check("fold R = 128", time_fold<128>(d_jobs, d_n, nj, dim, dense, out, 5));
-  check("fold R = 192", time_fold<192>(d_jobs, d_n, nj, dim, dense, out, 5));
-  check("fold R = 224", time_fold<224>(d_jobs, d_n, nj, dim, dense, out, 5));
+  check("fold R 128 S 32", time_fold<128, 32>(d_jobs, d_n, nj, dim, dense, out, 5));
+  check("fold R 128 S 16", time_fold<128, 16>(d_jobs, d_n, nj, dim, dense, out, 5));
+  check("fold R 128 S 8", time_fold<128, 8>(d_jobs, d_n, nj, dim, dense, out, 5));
+  // beside a kernel that saturates the memory system (2 x 5 GB read + 5 GB written per round, ~5.5 ms for two rounds)
+  hf4 *ha, *hb; const int64_t hn4 = 10000000ll * 32;
+  CK(hipMalloc(&ha, hn4 * 16)); CK(hipMemset(ha, 0, hn4 * 16));
+  hb = reinterpret_cast<hf4*>(grads);
+  hipStream_t hs; CK(hipStreamCreateWithFlags(&hs, hipStreamNonBlocking));
+  hog_t hog{ha, hb, hn4, hs};
+  check("loaded: R 128 S 32", time_fold<128, 32>(d_jobs, d_n, nj, dim, dense, out, 4, &hog));
+  check("loaded: R 128 S 16", time_fold<128, 16>(d_jobs, d_n, nj, dim, dense, out, 4, &hog));
+  check("loaded: R 128 S 8", time_fold<128, 8>(d_jobs, d_n, nj, dim, dense, out, 4, &hog));
   return 0;
 }

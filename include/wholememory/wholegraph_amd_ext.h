@@ -210,6 +210,11 @@ int64_t wholememory_ext_host_sorted_gathers(void);
  * is decided on the device and not visible here. A counter for tests and benchmarks. */
 int64_t wholememory_ext_split_sorts(void);
 
+/* Duplicate runs of the last finished ORDERED gradient step on the current device that were summed through a dense transposed
+ * copy of their gradient rows (csrc/kernels/long_dense.cuh: runs of at least WM_DENSE_FOLD_MIN rows, default 131072, while
+ * n / 8 rows of copies last; WM_DENSE_FOLD=0 switches the route off). Read after a synchronise. A counter for tests. */
+int64_t wholememory_ext_dense_fold_last(void);
+
 /* Kernels queued so far by the DISTRIBUTED gather route of this process (owner-side row gathers, reorder-on-receive
  * scatters, the two chunk-major copies): with C exchange chunks a call costs at most 2 C + 3 of them whatever the number of
  * ranks (rounds 2-4: 2 (W - 1) C + 1). A counter for tests. */

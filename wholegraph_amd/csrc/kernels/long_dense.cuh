@@ -19,8 +19,11 @@
 // receive order, starting from -0.0f (== copying the first row; x + (-0.0f) == x bit for bit for every x), so results are
 // bit-identical to the reference's and to step_long4_kernel's.
 //
-// This header holds the two kernels only, free of the optimizer's types, so that experiments/fold5_harness.hip times them
-// alone: the row address of an order[] entry and what happens to a finished column come in as functors.
+// Measured alone (experiments/fold5_harness.hip, profiles/r06_fold5_harness.txt): copy of 0.65 M rows 0.15 ms (4.4 TB/s in + out),
+// fold of the 527 k-row run 1.28 ms at R = 128 (5.8 cycles per row at 2.4 GHz; step_long4_kernel: 2.32 ms), 1.20 ms at R = 192
+// (spills), 1.52 ms at R = 64.
+// This header holds the two parts free of the optimizer's types, so that the harness times them alone: the row address of an
+// order[] entry and what happens to a finished column come in as functors (optim.hip: step_dense_copy_kernel / _fold_kernel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -48,15 +51,10 @@ __host__ __device__ inline int64_t dense_floats(int64_t rows, int64_t dim) { ret
 // bytes (its four columns' k = 0 .. 3): 2 KiB contiguous per half-wave. Groups are dealt out to the half-waves of the grid in
 // turn, run after run, so one giant run spreads over the whole chip.
 template <typename RowOf>
-__global__ __launch_bounds__(256) void copy_kernel(const job* jobs, const int32_t* n_jobs, const int32_t* order, RowOf row_of,
-                                                   int dim, float* dense)
+__device__ __forceinline__ void copy_part(const job* jobs, int n, const int32_t* order, const RowOf& row_of, int dim, float* dense,
+                                          int64_t hw /* this half-wave among all */, int64_t nhw, int c4l /* lane of the half-wave */)
 {
-  const int half     = threadIdx.x >> 5;                                  // 8 half-waves per workgroup
-  const int c4l      = threadIdx.x & 31;
-  const int64_t hw   = static_cast<int64_t>(blockIdx.x) * 8 + half;       // this half-wave among all
-  const int64_t nhw  = static_cast<int64_t>(gridDim.x) * 8;
   const int quads    = dim >> 2;
-  const int n        = *n_jobs;
   int64_t first      = 0;                                                 // groups of the runs before job j (dealing position)
   for (int j = 0; j < n; j++) {
     const job jb = jobs[j];
@@ -89,50 +87,63 @@ __global__ __launch_bounds__(256) void copy_kernel(const job* jobs, const int32_
     first += G;
   }
 }
+template <typename RowOf>
+__global__ __launch_bounds__(256) void copy_kernel(const job* jobs, const int32_t* n_jobs, const int32_t* order, RowOf row_of,
+                                                   int dim, float* dense)
+{
+  copy_part(jobs, *n_jobs, order, row_of, dim, dense, static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5),
+            static_cast<int64_t>(gridDim.x) * 8, static_cast<int>(threadIdx.x & 31));
+}
 
 // ---- the fold ---------------------------------------------------------------------------------------------------------------
 constexpr int kProducers = 4;                          // waves that only fetch
 constexpr int kFolders   = 2;                          // waves 0 and 1 fold alternate tiles
 constexpr int kBlock     = 64 * (kProducers + kFolders);
-constexpr int kSliceCols = 32;                         // columns per workgroup: 512 B per row group
 constexpr int kRingBytes = 128 * 1024;
 
-template <int R>
+// R = rows a folding wave holds in registers per turn, S = columns of a workgroup's slice (32, 16 or 8: 16 S bytes per row
+// group). The ring is what covers the memory latency — 128 KiB are 8 tiles of 128 rows x 32 columns, 2.5 us of the chain: enough
+// alone, NOT beside the optimizer step's tile kernel (the fold of the 527 k-row run: 1.28 ms alone, 2.2 ms beside it,
+// profiles/r06_grad_timeline_zipf_dense_first.txt) — so the product folds 8-column slices: a quarter of the bytes per row and
+// workgroup, four times the rows in flight (10 us), four times the workgroups per run.
+template <int R, int S>
 struct shape {
-  static_assert(R % 32 == 0, "a tile is a whole number of producer instructions (8 rows each, 4 producers)");
-  static constexpr int kTileBytes = R * kSliceCols * 4;
-  static constexpr int kRing      = kRingBytes / kTileBytes > 8 ? 8 : kRingBytes / kTileBytes;
-  static constexpr int kLoads     = R / 8 / kProducers;   // LDS-DMA pieces per producer lane per tile (1 KiB = 8 rows per wave instruction)
-  static_assert(kLoads * kRing < 64, "vmcnt field");
+  static_assert(S == 32 || S == 16 || S == 8, "a row group of a slice is 512, 256 or 128 bytes");
+  static constexpr int kRowsPerInstr = 256 / S;                            // rows one LDS-DMA wave instruction brings (1 KiB)
+  static_assert(R % (kRowsPerInstr * kProducers) == 0, "a tile is a whole number of instructions per producer");
+  static constexpr int kTileBytes = R * S * 4;
+  static constexpr int kLoads     = R / kRowsPerInstr / kProducers;        // LDS-DMA pieces per producer lane per tile
+  static constexpr int kRingFit   = kRingBytes / kTileBytes;
+  static constexpr int kRing      = kRingFit * kLoads < 64 ? kRingFit : 63 / kLoads;   // (vmcnt counts at most 63 pieces in flight)
   static_assert(kRing >= 3, "tile t in registers, t + 1 landed, t + 2 in flight");
   static constexpr size_t kLdsBytes = static_cast<size_t>(kRing) * kTileBytes + 64 * 4;
 };
+__host__ __device__ inline int slices_of(int dim, int s) { return (dim + s - 1) / s; }
 
-// R = rows a folding wave holds in registers per turn. Epilogue: ep(job, column, sum) for every column of every listed run
-// with a dense copy.
-template <int R, typename Epilogue>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
-void fold_kernel(const job* jobs, const int32_t* n_jobs, int dim, const float* dense, Epilogue ep)
+// Epilogue: ep(job, column, sum) for every column of every listed run with a dense copy. Work items = (run, slice) pairs,
+// dealt to the workgroups `first_item`, `first_item + item_stride`, ...
+template <int R, int S, typename Epilogue>
+__device__ __forceinline__ void fold_part(const job* jobs, int n, int dim, const float* dense, const Epilogue& ep, int first_item,
+                                          int item_stride, float* lds5)
 {
-  typedef shape<R> sh;
-  extern __shared__ __attribute__((aligned(16))) float lds5[];
-  float* const tiles = lds5;                                                    // [kRing][R / 4][32][4]
+  typedef shape<R, S> sh;
+  float* const tiles = lds5;                                                    // [kRing][R / 4][S][4]
   float* const acc_s = lds5 + sh::kRing * (sh::kTileBytes / 4);                 // [64] running sums between the two folders
-  const int n        = *n_jobs;
-  const int col0     = blockIdx.y * kSliceCols;
-  const int cols     = min(kSliceCols, dim - col0);                             // a multiple of 4
   const int lane     = threadIdx.x & 63;
   const int wave_id  = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const bool producer = wave_id >= kFolders;
   const int wv       = wave_id - kFolders;
-  // producer lane: piece i of tile t = row groups 2 (wv + kProducers i) + (lane >> 5) of the tile, column (lane & 31) of the slice
-  const int p_col    = min(lane & 31, cols - 1);   // lanes past a narrow slice re-read its last column
-  const int p_sub    = lane >> 5;
-  const bool folder  = lane < cols;
+  const int slices   = slices_of(dim, S);
+  constexpr int kGpi = 64 / S;                     // row groups per LDS-DMA instruction
+  const int p_sub    = lane / S;                   // producer lane: row group p_sub of its piece, column lane % S of the slice
 
-  for (int li = blockIdx.x; li < n; li += gridDim.x) {
-    const job jb = jobs[li];
+  for (int item = first_item; item < n * slices; item += item_stride) {
+    const job jb = jobs[item / slices];
     if (jb.dense_off < 0) continue;
+    const int col0    = (item % slices) * S;
+    const int cols    = min(S, dim - col0);                                      // a multiple of 4
+    const int p_col   = min(lane & (S - 1), cols - 1);                           // lanes past a narrow slice re-read its last column
+    const bool folder = lane < cols;
     const int64_t G   = groups_of(jb.rows);
     const int n_tiles = static_cast<int>((4 * G + R - 1) / R);
     const f4* src0    = reinterpret_cast<const f4*>(dense + jb.dense_off) + col0 + p_col;   // group g: + g * dim
@@ -141,20 +152,20 @@ void fold_kernel(const job* jobs, const int32_t* n_jobs, int dim, const float* d
       float* slot = tiles + (t % sh::kRing) * (sh::kTileBytes / 4);
 #pragma unroll
       for (int i = 0; i < sh::kLoads; i++) {
-        const int gi     = 2 * (wv + kProducers * i);                                       // row group inside the tile (of this wave's piece)
+        const int gi     = kGpi * (wv + kProducers * i);                                    // first row group of this wave's piece inside the tile
         const int64_t g  = min(static_cast<int64_t>(t) * (R / 4) + gi + p_sub, G - 1);       // tiles past the end re-read the last group
         const f4* src    = src0 + g * dim;
         typedef __attribute__((address_space(1))) void gvoid;
         typedef __attribute__((address_space(3))) void lvoid;
-        __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(slot + gi * (kSliceCols * 4)), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(slot + gi * (S * 4)), 16, 0, 0);
       }
     };
     float v[R];
     auto read_tile = [&](int t) {
-      const f4* src = reinterpret_cast<const f4*>(tiles + (t % sh::kRing) * (sh::kTileBytes / 4)) + (lane & 31);
+      const f4* src = reinterpret_cast<const f4*>(tiles + (t % sh::kRing) * (sh::kTileBytes / 4)) + (lane & (S - 1));
 #pragma clang loop unroll(full)
       for (int q = 0; q < R / 4; q++) {
-        const f4 x = src[q * kSliceCols];
+        const f4 x = src[q * S];
         v[4 * q + 0] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
       }
       const int64_t rows_left = 4 * G - static_cast<int64_t>(t) * R;   // (the copy padded the run to whole groups with -0.0f)
@@ -214,6 +225,13 @@ void fold_kernel(const job* jobs, const int32_t* n_jobs, int dim, const float* d
     if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail tiles must not land in the next run
     if (wave_id == ((n_tiles - 1) & 1) && folder) ep(jb, col0 + lane, acc);
   }
+}
+template <int R, int S, typename Epilogue>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void fold_kernel(const job* jobs, const int32_t* n_jobs, int dim, const float* dense, Epilogue ep)
+{
+  extern __shared__ __attribute__((aligned(16))) float lds5[];
+  fold_part<R, S>(jobs, *n_jobs, dim, dense, ep, blockIdx.x, gridDim.x, lds5);
 }
 
 }  // namespace dense_fold

@@ -91,6 +91,7 @@ END_ROCPRIM_NAMESPACE
 #include "device_common.cuh"
 #include "onesweep.cuh"
 #include "split_sort.cuh"
+#include "long_dense.cuh"
 
 #include <atomic>
 #include <mutex>
@@ -780,13 +781,15 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
 // halved the speed of step_short_kernel beside it; at 256 it gets 1300 (whole call, SGD / LazyAdam / fp16 x 256:
 // 32 -> 4.45 / 6.7 / 5.2 ms, 256 -> 3.85 / 6.1 / 4.2 ms, 1024 -> 3.85 / 6.1 / 4.3 ms, 4096 -> 4.2 / 6.2 / 4.2 ms).
 constexpr int kLongRun   = 256;
+constexpr int kDenseR    = 128;   // dense ordered fold (kernels/long_dense.cuh): rows a folding wave holds per turn (experiments/fold5_harness.hip)
+constexpr int kDenseS    = 8;     // ... and columns per folding workgroup
 constexpr int kSliceCols = 32;    // 128 B of every row per long-run workgroup
 constexpr int kTileRows  = 256;   // rows per LDS tile (32 KiB), double buffered
 
 struct long_run_entry {
   int32_t run;
   float beta1t, beta2t;
-  int32_t pad;
+  int32_t dense;   // 1: folded through its dense copy (dense_fold), step_long4_kernel skips it
 };
 
 struct opt_params {
@@ -803,6 +806,14 @@ struct opt_params {
   int long_threshold;
   int detached_side;   // 1 / 2: the long-run side runs on a side stream the caller's stream does NOT wait for (hip_optimizer_step_dev)
   int fold_tree;   // 1: the long-run side is the tree fold (tree_fold_kernel), 0: the ordered fold (step_long4_kernel)
+  // ordered fold of the very long runs through a dense transposed copy (kernels/long_dense.cuh; round 6): listed runs of at least
+  // dense_min rows get a job and room in dense_buf while it lasts (dense_cap floats), the others stay step_long4_kernel's.
+  // Counters beside long_count[0]: [1] jobs, [2..3] the buffer cursor (64 bit)
+  dense_fold::job* dense_jobs;
+  float* dense_buf;
+  int64_t dense_cap;
+  int dense_min, dense_max_jobs;
+  int dense_x;   // step_long4_kernel: its first dense_x workgroups (per slice) fold the runs with a dense copy
 };
 
 // optimizer statement sequences of the reference kernels (embedding_optimizer_func.cu:212-223, 392-415,
@@ -1525,6 +1536,8 @@ constexpr size_t kLong4LdsBytes = static_cast<size_t>(kRingBytes) + 2 * kOrdChun
 constexpr int kLongProducers = 4;                          // waves that only fetch
 constexpr int kLongFolders   = 2;                          // waves 0 and 1 fold alternate tiles
 constexpr int kLongBlock     = 64 * (kLongProducers + kLongFolders);
+static_assert(kLongBlock == dense_fold::kBlock && kLong4LdsBytes >= dense_fold::shape<kDenseR, kDenseS>::kLdsBytes,
+              "the first workgroups of step_long4_kernel fold the dense copies (kernels/long_dense.cuh): same shape, enough LDS");
 
 template <typename IdxT, int OPT, typename T = float>
 __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
@@ -1562,8 +1575,29 @@ __global__ __launch_bounds__(kLongBlock) void step_long4_kernel(opt_params p)
   constexpr int kPre   = kOrdChunk / 64;          // entries per lane of wave 0 when it carries a whole chunk in registers
   static_assert((kOrdChunk & (kOrdChunk - 1)) == 0 && kOrdChunk % kTile4Rows == 0 && kTpc > kRing + 1 && kTpc % 2 == 0, "a chunk is a whole number of tiles, more than the ring holds");
 
-  for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
+  int first_li = blockIdx.x, li_step = gridDim.x;
+  if constexpr (std::is_same<T, float>::value) {
+    if (p.dense_jobs != nullptr) {
+      // the first dense_x workgroups of every slice: the runs with a dense copy (kernels/long_dense.cuh), started first
+      if (static_cast<int>(blockIdx.x) < p.dense_x) {
+        auto ep = [&](const dense_fold::job& jb, int col, float acc) {
+          const long_run_entry ent = p.long_list[jb.user];
+          const int64_t local      = static_cast<int64_t>(ids[ent.run]) - a.local_entry_offset;
+          apply_optimizer<OPT, float>(a, local, col, acc, ent.beta1t, ent.beta2t);
+        };
+        // (8-column slices: the ring then holds 4096 rows, ~10 us of the chain — beside the tile kernel a load takes ~7 us;
+        // with 32-column slices the 527 k-row run took 2.2 ms here against 1.28 ms alone: profiles/r06_fold5_harness_slices.txt)
+        dense_fold::fold_part<kDenseR, kDenseS>(p.dense_jobs, min(p.long_count[1], p.dense_max_jobs), static_cast<int>(a.dim), p.dense_buf,
+                                                ep, static_cast<int>(blockIdx.y) * p.dense_x + static_cast<int>(blockIdx.x),
+                                                p.dense_x * static_cast<int>(gridDim.y), lds4);
+        return;
+      }
+      first_li -= p.dense_x, li_step -= p.dense_x;
+    }
+  }
+  for (int li = first_li; li < n_long; li += li_step) {
     const long_run_entry ent = p.long_list[li];
+    if (ent.dense != 0) continue;   // folded through its dense copy by the first workgroups
     const int64_t u          = ent.run;
     const int64_t local      = static_cast<int64_t>(ids[u]) - a.local_entry_offset;
     const int32_t s0         = a.run_starts[u];
@@ -1724,10 +1758,46 @@ __global__ void mark_long_runs_kernel(opt_params p)
       a.per_row_state[local * 2 + 1] = beta2t;
     }
     const int slot    = atomicAdd(p.long_count, 1);
-    p.long_list[slot] = long_run_entry{static_cast<int32_t>(u), beta1t, beta2t, 0};
+    int32_t dense     = 0;
+    const int32_t len = a.run_starts[u + 1] - a.run_starts[u];
+    if (p.dense_jobs != nullptr && len >= p.dense_min) {
+      // room in the dense buffer while it lasts (the cursor may overshoot: whoever finds no room leaves the run to step_long4_kernel)
+      const int64_t want = dense_fold::dense_floats(len, a.dim);
+      const int64_t off  = static_cast<int64_t>(atomicAdd(reinterpret_cast<unsigned long long*>(p.long_count + 2), static_cast<unsigned long long>(want)));
+      if (off + want <= p.dense_cap) {
+        const int j = atomicAdd(p.long_count + 1, 1);
+        if (j < p.dense_max_jobs) {
+          p.dense_jobs[j] = dense_fold::job{a.run_starts[u], len, off, slot, 0};
+          dense           = 1;
+        } else {
+          atomicSub(p.long_count + 1, 1);   // (cannot happen: max_jobs covers cap / dense_min)
+        }
+      }
+    }
+    p.long_list[slot] = long_run_entry{static_cast<int32_t>(u), beta1t, beta2t, dense};
   }
 }
 
+// The very long runs of an ordered fp32 fold through their dense transposed copies (kernels/long_dense.cuh): the copy is a launch
+// of its own on the long-run side's stream (the whole chip, at memory speed, no LDS); the fold is the FIRST dense_x workgroups
+// per slice of step_long4_kernel (same workgroup shape: six waves, a 128 KiB ring), so that the hottest chains start first and
+// run beside the other long runs — as a launch of its own in front of step_long4_kernel, that kernel only started when the
+// 1.3 ms chain had finished, behind a tile kernel that by then filled the chip (3.32 -> 3.41 ms, profiles/r06_dense_fold_ab.txt).
+// The folding workgroups have to be ON the machine before the tile kernel fills it (launched behind it they never find a CU:
+// see long_lane), and their input is the copy's output — so the caller's stream waits for the COPY (the event that used to
+// follow the listing kernel follows it now): the tile kernel starts ~0.15 ms later and then has the memory system to itself. (First version, measured and dropped: copy and fold as ONE launch, every workgroup copying its share and
+// the folding ones waiting for a counter — every workgroup of that grid carries the fold's 128 KiB of LDS, so the copy ran one
+// workgroup per CU: Zipf call 3.13 -> 4.44 ms, profiles/r06_dense_fold_ab.txt.)
+template <typename IdxT>
+__global__ __launch_bounds__(256) void step_dense_copy_kernel(opt_params p)
+{
+  const wm_optimizer_args& a = p.a;
+  auto row_of = [&](int32_t o) { return grad_row<float>(a, o); };
+  const int n = min(p.long_count[1], p.dense_max_jobs);
+  dense_fold::copy_part(p.dense_jobs, n, a.order, row_of, static_cast<int>(a.dim), p.dense_buf,
+                        static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5), static_cast<int64_t>(gridDim.x) * 8,
+                        static_cast<int>(threadIdx.x & 31));
+}
 // Side stream + fork/join events for the long-run kernels, created once per process. fork(): the side stream waits for
 // everything the caller's stream has queued so far; join(): the caller's stream waits for the side stream.
 struct long_lane {
@@ -1771,10 +1841,11 @@ struct long_lane {
     }
     return *listed != 0;
   }
+  // (two words: [0] the listed runs, [1] — ordered fold — how many of them went through a dense copy: wholememory_ext_dense_fold_last)
   void report(const int32_t* long_count_dev, hipStream_t s)
   {
     if (listed != nullptr)
-      (void)hipMemcpyAsync(const_cast<int32_t*>(listed), long_count_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+      (void)hipMemcpyAsync(const_cast<int32_t*>(listed), long_count_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
   }
 };
 
@@ -1799,6 +1870,9 @@ void launch_mark_long_runs(const opt_params& p, hipStream_t stream, hipStream_t 
   // (one run per thread and 37 k workgroups for 9.5 M runs took 15 us — the time to hand out 148 k one-load waves)
   const int blocks = static_cast<int>(std::min<int64_t>((p.a.count + 255) / 256, 4096));
   hipLaunchKernelGGL((mark_long_runs_kernel<IdxT>), dim3(std::max(blocks, 1)), dim3(256), 0, lstream, p);
+  // the dense copies of the very long runs (step_dense_copy_kernel: leaves at once when none was listed): in front of the event
+  // the caller's stream waits for — see step_dense_copy_kernel
+  if (p.dense_jobs != nullptr) hipLaunchKernelGGL((step_dense_copy_kernel<IdxT>), dim3(1024), dim3(256), 0, lstream, p);
   if (lstream != stream && !p.detached_side) {
     (void)hipEventRecord(long_lane::get().marked, lstream);
     (void)hipStreamWaitEvent(stream, long_lane::get().marked, 0);
@@ -2153,7 +2227,13 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
         const int slices4 = static_cast<int>((p.a.dim + slice4_cols<float>() - 1) / slice4_cols<float>());
         int gx            = std::max(1, 256 / slices4);
         if (const char* e = WM_AB_KNOB("WM_LONG_GRID")) gx = std::max(1, atoi(e));
-        hipLaunchKernelGGL((step_long4_kernel<IdxT, OPT>), dim3(gx, slices4), dim3(kLongBlock), kLong4LdsBytes, lstream, p);
+        // (the first workgroups per slice fold the dense copies — 16 x slices4 of them take 4 runs of 128 columns in 8-column
+        // slices —, the others walk the list as before; TOGETHER one resident round: with 16 workgroups per slice on top of
+        // the 256 / slices4 the last ones only started when the tile kernel had filled the chip, and finished after it —
+        // profiles/r06_grad_timeline_zipf_dense_second.txt)
+        opt_params lp = p;
+        lp.dense_x    = p.dense_jobs != nullptr ? 16 : 0;   // (dense_jobs is only set for dim <= 256: gx >= 32, hip_optimizer_step_dev)
+        hipLaunchKernelGGL((step_long4_kernel<IdxT, OPT>), dim3(gx, slices4), dim3(kLongBlock), kLong4LdsBytes, lstream, lp);
       }
       else if (long4)
         hipLaunchKernelGGL((step_long_kernel<IdxT, OPT, true>), dim3(1024, slices), dim3(kBlock), 0, lstream, p);
@@ -2343,6 +2423,13 @@ __global__ void fill_float_kernel(float* p, float v, int64_t n)
 
 }  // namespace wm
 extern "C" int64_t wholememory_ext_split_sorts(void) { return wm::g_split_sorts.load(std::memory_order_relaxed); }
+// runs of the last finished ORDERED optimizer step on the current device that were folded through a dense transposed copy
+// (kernels/long_dense.cuh); read after a synchronise. A counter for tests and benchmarks.
+extern "C" int64_t wholememory_ext_dense_fold_last(void)
+{
+  auto& lane = wm::long_lane::get();
+  return lane.listed != nullptr ? static_cast<int64_t>(lane.listed[1]) : 0;
+}
 namespace wm {
 
 void hip_dedup_defer_join(int on)
@@ -2468,9 +2555,45 @@ int hip_sort_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, in
   return -1;
 }
 
+// Dense copies of the very long runs of an ORDERED fp32 fold (kernels/long_dense.cuh): runs of at least dense_min_rows() rows,
+// at most n_recv / 8 rows of them per call (the three hottest ids of a Zipf(1.05) batch of 10 M are 0.95 M rows; what does
+// not fit stays step_long4_kernel's), none for batches without room for one such run. WM_DENSE_FOLD=0 switches it off,
+// WM_DENSE_FOLD_MIN=rows moves the threshold (tests).
+inline int dense_min_rows(int64_t n_recv)
+{
+  if (const char* e = WM_KNOB("WM_DENSE_FOLD")) if (e[0] == '0') return 0;
+  // A run needs the dense route only when its chain would outlast the tile kernel beside it, and every copied row delays that
+  // kernel (the caller's stream waits for the copy): runs of at least 1 / 32 of the batch (131072 rows or more). Zipf(1.05),
+  // 10 M ids: the 527 k-row run alone — the 255 k- and 166 k-row runs take 1.3 and 0.9 ms in step_long4_kernel's ring, well
+  // inside the tile kernel's 2 ms (copying them too measured equal: 2.69 ms either way, profiles/r06_dense_fold_ab_v6_threshold.txt)
+  int v = static_cast<int>(std::min<int64_t>(std::max<int64_t>(131072, n_recv / 32), INT64_C(1) << 30));
+  if (const char* e = WM_KNOB("WM_DENSE_FOLD_MIN")) v = std::max(kLongRun + 1, atoi(e));
+  return v;
+}
+struct dense_carve {
+  size_t off_jobs, off_buf, total;
+  int max_jobs;
+  int64_t cap_floats;
+};
+inline dense_carve dense_layout(size_t base, int64_t n_recv, int64_t dim)
+{
+  dense_carve c{base, base, base, 0, 0};
+  const int dmin = dense_min_rows(n_recv);
+  const int64_t cap_rows = n_recv / 8;
+  if (dmin <= 0 || dim % 4 != 0 || cap_rows < dmin) return c;
+  auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  c.max_jobs   = static_cast<int>(cap_rows / dmin + 2);
+  c.cap_floats = (cap_rows + 4 * c.max_jobs) * dim;   // (every run rounds up to a whole group of four rows)
+  c.off_jobs   = align(base);
+  c.off_buf    = align(c.off_jobs + sizeof(dense_fold::job) * static_cast<size_t>(c.max_jobs));
+  c.total      = c.off_buf + sizeof(float) * static_cast<size_t>(c.cap_floats);
+  return c;
+}
+inline size_t ordered_list_bytes(int64_t n_recv) { return 32 + sizeof(long_run_entry) * static_cast<size_t>(n_recv / (kLongRun + 1) + 2); }
+
 size_t hip_long_run_ws_bytes(int64_t n_recv, int64_t dim)
 {   // the larger of the two layouts (the fold order is only resolved at the step: it may depend on the value dtype)
-  return std::max(16 + sizeof(long_run_entry) * static_cast<size_t>(n_recv / (kLongRun + 1) + 2),
+  return std::max(dense_layout(ordered_list_bytes(n_recv), n_recv, dim).total,
                   tree_ws_bytes(n_recv, dim, std::min(tree_threshold(), kTreeMin)));
 }
 
@@ -2485,7 +2608,7 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   if (a->long_run_ws != nullptr && a->dim <= 65535 * kSliceCols) {
     // [int32 counter | pad to 16 B | entries]; at most count / (kLongRun + 1) long runs can exist
     p.long_count = static_cast<int32_t*>(a->long_run_ws);
-    p.long_list  = reinterpret_cast<long_run_entry*>(static_cast<char*>(a->long_run_ws) + 16);
+    p.long_list  = reinterpret_cast<long_run_entry*>(static_cast<char*>(a->long_run_ws) + 32);
     // tree fold: 16-byte pieces of the gradient rows on every side (else the ordered kernels take the call as before)
     const bool f32     = a->value_dtype != WHOLEMEMORY_DT_HALF && a->value_dtype != WHOLEMEMORY_DT_BF16;
     const int ve       = f32 ? 4 : 8;
@@ -2496,6 +2619,17 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
       p.fold_tree      = 1;
       p.long_threshold = tree_threshold();
       p.long_list      = reinterpret_cast<long_run_entry*>(static_cast<char*>(a->long_run_ws) + 64);   // (non-null marker; the tree kernels carve the workspace themselves)
+    } else if (f32 && pieces && a->dim <= 256 && WM_AB_KNOB("WM_STEP_LONG_OLD") == nullptr) {
+      // (rows of up to 256 columns: the long-run kernel's one resident round — 256 / (dim / 32) workgroups per 32-column slice —
+      // then has 16 per slice to spare for the dense copies, launch_step_opt)
+      const dense_carve dc = dense_layout(ordered_list_bytes(a->count), a->count, a->dim);
+      if (dc.max_jobs > 0) {
+        p.dense_jobs     = reinterpret_cast<dense_fold::job*>(static_cast<char*>(a->long_run_ws) + dc.off_jobs);
+        p.dense_buf      = reinterpret_cast<float*>(static_cast<char*>(a->long_run_ws) + dc.off_buf);
+        p.dense_cap      = dc.cap_floats;
+        p.dense_min      = dense_min_rows(a->count);
+        p.dense_max_jobs = dc.max_jobs;
+      }
     }
   }
   // runs that a split sort of this thread has just written: its control words hold the long-run counters (already zero) and
@@ -2532,7 +2666,7 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
   if (p.long_list != nullptr && !serial && long_lane::get().fork(stream)) lstream = long_lane::get().stream;
   // (the counters are cleared on the side stream: only the long-run kernels read them)
   if (p.long_list != nullptr && p.split_ctl == nullptr &&
-      hipMemsetAsync(p.long_count, 0, p.fold_tree ? 64 : 16, lstream) != hipSuccess)
+      hipMemsetAsync(p.long_count, 0, p.fold_tree ? 64 : 32, lstream) != hipSuccess)
     return -2;
   int64_t waves = a->count;
   int max_blocks = 256 * 8;
