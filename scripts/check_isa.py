@@ -41,9 +41,11 @@ RULES = [
     (r"rows_staged_gather_kernel<", dict(min_loads=4, wide=True, max_valu=400, max_mov_share=0.45, scope="block")),
     (r"rows_staged_scatter_kernel<", dict(min_loads=4, wide=True, max_valu=400, max_mov_share=0.45, scope="block")),
     # gradient apply: a batch of the tile kernel = 2 x kU row loads (gradient + table [+ states]) back to back; no scratch
-    (r"step_tile_kernel<[^>]*, 16>", dict(min_loads=4, wide=True, max_valu=600, max_mov_share=0.45, scope="block", max_scratch=0)),
+    (r"step_tile_kernel<[^>]*, 16, false>", dict(min_loads=4, wide=True, max_valu=600, max_mov_share=0.45, scope="block", max_scratch=0)),
+    # ... its RAGGED instantiation (round 6: dim % 4 != 0 — 513, 129, 127 floats: the same batch on the first dim / 4 pieces)
+    (r"step_tile_kernel<[^>]*, 16, true>", dict(min_loads=4, wide=True, max_valu=700, max_mov_share=0.45, scope="block", max_scratch=0)),
     # ... and its 8-byte-piece instantiation (round 6: fp32 rows of whole 8-byte pieces, 602 floats): the same batch of dwordx2
-    (r"step_tile_kernel<[^>]*, 8>", dict(min_loads=4, wide=False, load_re=r"^global_load_dwordx2\b", max_valu=600, max_mov_share=0.45,
+    (r"step_tile_kernel<[^>]*, 8, false>", dict(min_loads=4, wide=False, load_re=r"^global_load_dwordx2\b", max_valu=600, max_mov_share=0.45,
                                          scope="block", max_scratch=0)),
     # the tree fold of long runs: 4 gradient rows per thread in flight (round 3 shipped one)
     (r"tree_fold_kernel<", dict(min_loads=4, wide=True, max_valu=600, max_mov_share=0.45, scope="block", max_scratch=0)),

@@ -7,8 +7,8 @@ gradients, where the summation order shows in the last bits: with the threshold 
 through copy + fold in one launch, the next ones stay step_long4_kernel's — because they are below the threshold or because the
 dense buffer (n / 8 rows per call) is full —, the rest is the tile kernel's. Every path must give the oracle's bits: table,
 per-element states, per-row beta powers; and the same bits with the dense route switched off (WM_DENSE_FOLD=0). Row shapes: the
-tile kernel's 128 floats, 100 floats (25 sixteen-byte pieces: a last slice of 4 columns), 36 floats (one slice, short rows),
-260 floats (nine slices). Two calls in a row on the same workspace addresses (a stale line of the first call's dense copy in
+tile kernel's 128 floats, 100 floats (25 sixteen-byte pieces: a last 8-column slice of 4 columns), 36 floats (short rows), 200 floats
+and 256 floats (the widest rows the route takes: the long-run kernel's resident round then has just 16 workgroups per slice to spare). Two calls in a row on the same workspace addresses (a stale line of the first call's dense copy in
 another XCD's L2 would show in the second)."""
 import ctypes as C
 
@@ -40,7 +40,7 @@ def _batch(rng, local_rows, local_off, n_recv, idt):
 
 @pytest.mark.parametrize("kind,code,params", OPTS, ids=lambda x: str(x))
 @pytest.mark.parametrize("dim,idt,dense_min,n_recv", [(128, np.int64, 300, 60007), (100, np.int32, 300, 60007), (36, np.int64, 2000, 60007),
-                                                      (260, np.int64, 1000, 60007),
+                                                      (256, np.int64, 1000, 60007), (200, np.int32, 1000, 60007),
                                                       # at least 65536 ids: the split sort (its control words hold the counters),
                                                       # whose buckets these hot ids overflow: the gated generic path / the adaptive route
                                                       (128, np.int64, 2000, 200003)])

@@ -22,9 +22,11 @@ def test_shipped_isa_keeps_its_loads_in_flight(wm_lib):
     assert "all rules hold" in p.stdout
     # the headline kernel is among the checked ones
     assert re.search(r"rows_batch_kernel<long, true, 32, false, 0>.*\bok\b", p.stdout)
-    assert re.search(r"step_tile_kernel<long, 1, 2, false, float, 0, 0, 16>.*\bok\b", p.stdout)
+    assert re.search(r"step_tile_kernel<long, 1, 2, false, float, 0, 0, 16, false>.*\bok\b", p.stdout)
     # ... and the 8-byte-piece instantiation of round 6 (fp32 rows of whole 8-byte pieces: 602 floats)
-    assert re.search(r"step_tile_kernel<long, 1, 1, false, float, 0, 0, 8>.*\bok\b", p.stdout)
+    assert re.search(r"step_tile_kernel<long, 1, 1, false, float, 0, 0, 8, false>.*\bok\b", p.stdout)
+    # ... and the ragged one (rows of dim % 4 != 0 floats: the reference's own test dims 513 / 129 / 127)
+    assert re.search(r"step_tile_kernel<long, 1, 1, false, float, 0, 0, 16, true>.*\bok\b", p.stdout)
 
 
 def test_no_getenv_outside_the_knob_reader():

@@ -3,8 +3,10 @@
 exchange_embeddings_nccl_func.cu:76-103 (duplicates summed sequentially in receive order) + embedding_optimizer_func.cu:178-329,
 331-421, 583-686, 781-884 (the four update rules).
 
-Round 6: rows of whole 8-byte pieces that are not whole 16-byte ones (602, 130, 66 floats) take step_tile_kernel's 8-byte-piece
-instantiation (global_load_dwordx2 batches, ISA-gated) instead of the wave-per-run kernel.
+Round 6: rows of dim % 4 != 0 floats (513, 301 ..., 129, 127: the reference's own test dims; 602, 130, 66) take step_tile_kernel's
+RAGGED instantiation — the first dim / 4 sixteen-byte pieces in the usual straight-line batches (gradient rows only 4-byte
+aligned), the last dim % 4 floats in a lane-per-run pass; WM_STEP_RAGGED=0 keeps the routes it replaced: the 8-byte-piece
+instantiation (global_load_dwordx2 batches, ISA-gated) for dim = 2 mod 4 and the wave-per-run kernel for odd dims.
 Row shapes: 75 / 25 / 50 / 250 sixteen-byte pieces (GloVe / word2vec 300 / 100 / 200, 1000 floats), 2408-byte rows (Reddit's
 602 floats: 8-byte pieces, on a 16-byte and on a 128-byte row stride), 513 floats (4-byte pieces), 36 and 130 floats (a row
 shorter / a little longer than a wave step) and the tile kernel's own 128 / 64 floats. Each must give the oracle's bits: tables,
@@ -39,6 +41,19 @@ def _env():
                                            # tile kernel takes (66 floats; 602 and 130 above take it too, round 6)
                                            (127, 4, np.int64), (129, 4, np.int32), (392, 4, np.int64), (66, 4, np.int64)])
 def test_odd_row_step_bit_exact(gpu_env, kind, code, params, dim, align, idt):
+    _run(kind, code, params, dim, align, idt)
+
+
+@pytest.mark.parametrize("kind,code,params", OPTS, ids=lambda x: str(x))
+@pytest.mark.parametrize("dim,align,idt", [(602, 32, np.int64), (130, 32, np.int32), (66, 4, np.int64), (513, 4, np.int64), (129, 4, np.int32)])
+def test_odd_row_step_without_the_ragged_kernel(gpu_env, knobs, kind, code, params, dim, align, idt):
+    """WM_STEP_RAGGED=0: the routes the ragged tile kernel replaced — the 8-byte-piece tile kernel (dim = 2 mod 4) and the
+    wave-per-run kernel on 4-byte pieces (odd dims) — stay reachable and bit-exact"""
+    knobs.set("WM_STEP_RAGGED", 0)
+    _run(kind, code, params, dim, align, idt)
+
+
+def _run(kind, code, params, dim, align, idt):
     import torch
     from wholegraph_amd import binding as wmb
     rng = np.random.default_rng(dim * 11 + code)

@@ -1162,6 +1162,9 @@ __device__ __forceinline__ P* tile_bcast_ptr(P* p, int e0, int sub)
 // kernel altogether and took the wave-per-run kernel (global_load_dwordx2, one run at a time).
 typedef uint32_t tile_raw4 __attribute__((ext_vector_type(4)));
 typedef uint32_t tile_raw2 __attribute__((ext_vector_type(2)));
+// 16 bytes at an address that is only 4-byte aligned (RAGGED: packed gradient rows of dim % 4 != 0 floats): still ONE
+// global_load_dwordx4 (the hardware takes dword-aligned wide accesses; one that straddles a line costs a second request)
+typedef tile_raw4 tile_raw4_u __attribute__((aligned(4)));
 template <int PIECE>
 struct tile_raw_of {
   typedef tile_raw4 type;
@@ -1227,16 +1230,26 @@ __device__ __forceinline__ tile_raw4 tile_pack(const tile_vals<16 / sizeof(T)>& 
   return r;
 }
 
-template <typename IdxT, int OPT, int RPS, bool CACHED, typename T = float, int KU = 0, int OCC = 0, int PIECE = 16>
+// RAGGED (round 6, fp32, 16-byte pieces): rows of dim % 4 != 0 floats — 513, 129, 127: the reference's own gradient-apply test
+// dims, wholememory_embedding_gradient_apply_tests.cu:481-501 — used to take the wave-per-run kernel on 4-byte pieces (36-47 %
+// of peak). Here the first dim / 4 pieces of every row go through the same straight-line batches (the packed gradient rows are
+// only 4-byte aligned: tile_raw4_u; table and state rows sit on a 16-byte stride), and the last dim % 4 floats of the tile's
+// 64 rows are a pass of their own, one LANE per run (4-byte accesses, duplicates added in receive order as everywhere).
+template <typename IdxT, int OPT, int RPS, bool CACHED, typename T = float, int KU = 0, int OCC = 0, int PIECE = 16, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC > 0 ? OCC : 1, OCC > 0 ? OCC : 8)))
 void step_tile_kernel(opt_params p)
 {
   static_assert(PIECE == 16 || (PIECE == 8 && sizeof(T) == 4), "pieces of 16 bytes, or of 8 bytes of fp32 rows");
+  static_assert(!RAGGED || (PIECE == 16 && sizeof(T) == 4 && !CACHED), "ragged rows: fp32, 16-byte pieces, no row cache");
   typedef typename tile_raw_of<PIECE>::type raw_t;
   constexpr int kSV = PIECE / 4;   // fp32 state values per piece
   // optimizer states move non-temporally like the rows (round 4, interleaved in one process, 10 M uniform rows of 128 floats:
   // LazyAdam 6.69 -> 6.38 ms, Zipf 4.83 -> 4.56; AdaGrad 4.53 -> 4.49; RMSProp 4.47 -> 4.45)
   auto ld_state = [](const void* q) { return ld_global_nt<raw_t>(q); };
+  auto ld_grad  = [](const void* q) -> raw_t {
+    if constexpr (RAGGED) return ld_global_nt<tile_raw4_u>(q);
+    else return ld_global_nt<raw_t>(q);
+  };
   auto st_state = [](void* q, raw_t v) { st_global_nt<raw_t>(q, v); };
   constexpr int kVE          = PIECE / static_cast<int>(sizeof(T));  // elements per lane
   constexpr bool k16         = sizeof(T) == 2;
@@ -1306,7 +1319,7 @@ void step_tile_kernel(opt_params p)
           const T* g   = tile_lane_ptr<RPS>(my_grad, e0, sub);
           trow[k]      = tile_lane_ptr<RPS>(my_row, e0, sub);
           if (kState) srow[k] = tile_lane_ptr<RPS>(my_st, e0, sub);
-          gv[k]        = ld_global_nt<raw_t>(g + coff);
+          gv[k]        = ld_grad(g + coff);
           ev[k]        = ld_global_nt<raw_t>(trow[k] + coff);
           if (kState) s0v[k] = ld_state(srow[k] + coff);
           if (kAdam) s1v[k] = ld_state(srow[k] + a.table_stride + coff);
@@ -1327,7 +1340,7 @@ void step_tile_kernel(opt_params p)
 #pragma unroll
               for (int q = 0; q < kDup; q++) {
                 const int32_t o = a.order[rs + min(j + q, ln - 1)];
-                gq[q]           = ld_global_nt<raw_t>(grad_row<T>(a, o) + coff);
+                gq[q]           = ld_grad(grad_row<T>(a, o) + coff);
               }
 #pragma unroll
               for (int q = 0; q < kDup; q++) {
@@ -1386,13 +1399,13 @@ void step_tile_kernel(opt_params p)
         }
         if (c >= row_vecs) ln = 0;
         if (ln <= 0) continue;
-        tile_vals<kVE> acc = tile_unpack<T>(ld_global_nt<raw_t>(g + coff));   // first occurrence copied
+        tile_vals<kVE> acc = tile_unpack<T>(ld_grad(g + coff));   // first occurrence copied
         const raw_t ev = ld_global_nt<raw_t>(trow + coff);
         raw_t s0v{}, s1v{};
         if (kState) s0v = ld_state(srow + coff);
         if (kAdam) s1v = ld_state(srow + a.table_stride + coff);
         for (int32_t j = 1; j < ln; j++) {   // later occurrences added in receive order
-          const tile_vals<kVE> gx = tile_unpack<T>(ld_global_nt<raw_t>(grad_row<T>(a, a.order[rs + j]) + coff));
+          const tile_vals<kVE> gx = tile_unpack<T>(ld_grad(grad_row<T>(a, a.order[rs + j]) + coff));
 #pragma unroll
           for (int v = 0; v < kVE; v++) acc.v[v] += gx.v[v];
         }
@@ -1415,6 +1428,16 @@ void step_tile_kernel(opt_params p)
         if (kState) st_state(srow + coff, tile_pack<float>(so0));
         if (kAdam) st_state(srow + a.table_stride + coff, tile_pack<float>(so1));
         st_global_nt<raw_t>(trow + coff, tile_pack<T>(eo));
+      }
+    }
+    if constexpr (RAGGED) {
+      // the last dim % 4 floats of the tile's rows: lane = run, 4-byte accesses, duplicates in receive order
+      if (lane < tile_runs && my_len > 0) {
+        for (int c = row_vecs * kVE; c < static_cast<int>(a.dim); c++) {
+          float acc = my_grad[c];   // first occurrence copied
+          for (int32_t j = 1; j < my_len; j++) acc += grad_row<T>(a, a.order[my_s0 + j])[c];
+          update_elem<OPT, T>(a, my_row, my_st, c, load_elem<OPT, T>(a, my_row, my_st, c), acc, my_b1, my_b2);
+        }
       }
     }
   }
@@ -2283,6 +2306,29 @@ int launch_step_opt(const opt_params& p, int blocks, hipStream_t stream, hipStre
   // rows of whole 8-byte pieces that are not whole 16-byte ones (dim = 2 mod 4: 602 floats, the Reddit feature width): the tile
   // kernel with 8-byte pieces (round 6) — one 512-byte wave step per row instead of the wave-per-run kernel below.
   // WM_STEP_TILE8=0 keeps the wave-per-run kernel (A/B).
+  // rows of dim % 4 != 0 floats: the tile kernel on the first dim / 4 sixteen-byte pieces + a lane-per-run pass over the last
+  // dim % 4 floats (RAGGED). Gradient rows may start anywhere (4-byte aligned). Whole calls, 10 M rows, probed placement
+  // (profiles/r06_dim_sweep_ragged.txt): 513 floats 47.8 -> 62-64 % of peak, 301 floats 46 -> 55 %; 129 / 127 floats 36-44 % either
+  // way (rows of ~512 B that start inside a line on every side); dim = 2 mod 4: 602 floats 60.0 -> 61.7 %, 130 floats 41.8 -> 43.7 %
+  // against the 8-byte-piece kernel below, which WM_STEP_RAGGED=0 keeps (with the wave-per-run kernel for odd dims).
+  const char* ragged_env = WM_KNOB("WM_STEP_RAGGED");
+  const bool ragged_ok = !tile_off && !cached && p.a.dim >= 36 && p.a.dim % 4 != 0 && st_ok && tb_ok &&
+                         !(ragged_env != nullptr && ragged_env[0] == '0');
+  if (ragged_ok) {
+    const int vecs = static_cast<int>(p.a.dim / 4);
+    opt_params tp = p;
+    int tblocks   = 1;
+    tile_launch_shape(p.a.count, vecs, OPT == WHOLEMEMORY_OPT_SGD ? WM_TILE_KU_SGD : WM_TILE_KU_STATE, &tp.tile_runs, &tblocks);
+#define WM_TILE_RAGGED(RPS) \
+    hipLaunchKernelGGL((step_tile_kernel<IdxT, OPT, RPS, false, float, 0, 0, 16, true>), dim3(tblocks), dim3(kBlock), 0, stream, tp)
+    if (vecs > 32) WM_TILE_RAGGED(1);
+    else if (vecs > 16) WM_TILE_RAGGED(2);
+    else if (vecs > 8) WM_TILE_RAGGED(4);
+    else WM_TILE_RAGGED(8);
+#undef WM_TILE_RAGGED
+    if (p.detached_side == 1 && long_side() != 0) return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   const bool tile8_off = WM_AB_KNOB("WM_STEP_TILE8") != nullptr && WM_AB_KNOB("WM_STEP_TILE8")[0] == '0';
   const bool tile8_ok  = !tile_off && !tile8_off && !cached && vec2 && p.a.dim >= 66 && p.a.table_stride % 2 == 0 &&
                         reinterpret_cast<uint64_t>(p.a.local_table) % 8 == 0 &&
