@@ -56,31 +56,41 @@ __device__ __forceinline__ void copy_part(const job* jobs, int n, const int32_t*
 {
   const int quads    = dim >> 2;
   int64_t first      = 0;                                                 // groups of the runs before job j (dealing position)
+  constexpr int U    = 2;                                                 // row groups a half-wave has in flight (8 row loads per lane)
   for (int j = 0; j < n; j++) {
     const job jb = jobs[j];
     const int64_t G = groups_of(jb.rows);
     if (jb.dense_off >= 0) {
-      // the first group of this run that is this half-wave's: (first + g) % nhw == hw
+      // the first group of this run that is this half-wave's: (first + g) % nhw == hw; then every nhw-th, U at a time
       int64_t g = (hw - first % nhw + nhw) % nhw;
-      for (; g < G; g += nhw) {
-        int32_t o[4];
+      for (; g < G; g += U * nhw) {
+        int32_t o[U][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int64_t r = 4 * g + k;
-          o[k]            = order[jb.s0 + (r < jb.rows ? r : jb.rows - 1)];
-        }
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int64_t r = 4 * (g + u * nhw) + k;
+            o[u][k]         = order[jb.s0 + (r < jb.rows ? r : jb.rows - 1)];   // (groups past the end re-read the last row: not stored)
+          }
         for (int c4 = c4l; c4 < quads; c4 += 32) {
-          f4 v[4];
+          f4 v[U][4];
 #pragma unroll
-          for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(row_of(o[k]) + 4 * c4));
+          for (int u = 0; u < U; u++)
 #pragma unroll
-          for (int k = 0; k < 4; k++)
-            if (4 * g + k >= jb.rows) v[k] = f4{-0.0f, -0.0f, -0.0f, -0.0f};
-          f4* dst = reinterpret_cast<f4*>(dense + jb.dense_off) + (g * dim + 4 * c4);
-          dst[0]  = f4{v[0].x, v[1].x, v[2].x, v[3].x};
-          dst[1]  = f4{v[0].y, v[1].y, v[2].y, v[3].y};
-          dst[2]  = f4{v[0].z, v[1].z, v[2].z, v[3].z};
-          dst[3]  = f4{v[0].w, v[1].w, v[2].w, v[3].w};
+            for (int k = 0; k < 4; k++) v[u][k] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(row_of(o[u][k]) + 4 * c4));
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int64_t gu = g + u * nhw;
+            if (gu >= G) continue;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if (4 * gu + k >= jb.rows) v[u][k] = f4{-0.0f, -0.0f, -0.0f, -0.0f};
+            f4* dst = reinterpret_cast<f4*>(dense + jb.dense_off) + (gu * dim + 4 * c4);
+            dst[0]  = f4{v[u][0].x, v[u][1].x, v[u][2].x, v[u][3].x};
+            dst[1]  = f4{v[u][0].y, v[u][1].y, v[u][2].y, v[u][3].y};
+            dst[2]  = f4{v[u][0].z, v[u][1].z, v[u][2].z, v[u][3].z};
+            dst[3]  = f4{v[u][0].w, v[u][1].w, v[u][2].w, v[u][3].w};
+          }
         }
       }
     }
