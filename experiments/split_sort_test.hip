@@ -44,7 +44,8 @@ static result cpu_ref(const std::vector<int64_t>& ids, int64_t lower, int64_t sp
 static int run_case(const char* name, const std::vector<int64_t>& ids, int64_t lower, int64_t span, bool timing)
 {
   const int64_t n = ids.size();
-  split::plan p = split::make_plan(n, span, getenv("SPLIT_IPT") ? atoi(getenv("SPLIT_IPT")) : 0, getenv("SPLIT_CAPBITS") ? atoi(getenv("SPLIT_CAPBITS")) : 0);
+  const bool hot = getenv("SPLIT_HOT") != nullptr && getenv("SPLIT_HOT")[0] == '1';   // round 6: hot ids get buckets of their own
+  split::plan p = split::make_plan(n, span, getenv("SPLIT_IPT") ? atoi(getenv("SPLIT_IPT")) : 0, getenv("SPLIT_CAPBITS") ? atoi(getenv("SPLIT_CAPBITS")) : 0, hot);
   if (!p.ok) { printf("%-40s n=%ld span=%ld: plan not ok (skipped)\n", name, (long)n, (long)span); return 0; }
   int64_t* d_ids; void* d_ws; int64_t* d_uniq; int32_t *d_starts, *d_order; int64_t* d_nu;
   CK(hipMalloc(&d_ids, 8 * n)); CK(hipMalloc(&d_ws, p.total)); CK(hipMalloc(&d_uniq, 8 * n)); CK(hipMalloc(&d_starts, 4 * (n + 1)));
@@ -52,17 +53,21 @@ static int run_case(const char* name, const std::vector<int64_t>& ids, int64_t l
   CK(hipMemcpy(d_ids, ids.data(), 8 * n, hipMemcpyHostToDevice));
   CK(hipMemset(d_ws, 0xCD, p.total)); CK(hipMemset(d_order, 0xFF, 4 * n)); CK(hipMemset(d_starts, 0xFF, 4 * (n + 1)));
   hipStream_t st; CK(hipStreamCreate(&st));
-  int rc = split::launch<uint64_t>(p, reinterpret_cast<const uint64_t*>(d_ids), n, static_cast<uint64_t>(lower), static_cast<uint32_t>(span),
+  int rc = hot ? split::launch_hot<uint64_t>(p, reinterpret_cast<const uint64_t*>(d_ids), n, static_cast<uint64_t>(lower), static_cast<uint32_t>(span),
+                                             d_uniq, d_starts, d_order, d_nu, d_ws, nullptr, 0, st)
+               : split::launch<uint64_t>(p, reinterpret_cast<const uint64_t*>(d_ids), n, static_cast<uint64_t>(lower), static_cast<uint32_t>(span),
                                    d_uniq, d_starts, d_order, d_nu, d_ws, nullptr, 0, st);
   CK(hipStreamSynchronize(st));
+  uint32_t hot_n[4] = {0, 0, 0, 0};
+  if (hot) CK(hipMemcpy(hot_n, static_cast<char*>(d_ws) + p.off_hot_n, sizeof(hot_n), hipMemcpyDeviceToHost));
   if (rc != 0) { printf("%s: launch rc %d\n", name, rc); return 1; }
   uint32_t ctl[split::kCtlWords];
   CK(hipMemcpy(ctl, static_cast<char*>(d_ws) + p.off_ctl, sizeof(ctl), hipMemcpyDeviceToHost));
   int bad = 0;
   if (ctl[split::kCtlError]) { printf("%s: look-back timeout flagged\n", name); bad = 1; }
   result ref = cpu_ref(ids, lower, span);
-  // does the CPU agree about the overflow?
-  {
+  // does the CPU agree about the overflow? (HOT mode: which ids were peeled is the device's choice — not checked)
+  if (!hot) {
     std::vector<int64_t> cnt(p.buckets + 1, 0);
     for (int64_t i = 0; i < n; i++) {
       const uint64_t off = static_cast<uint64_t>(ids[i]) - static_cast<uint64_t>(lower);
@@ -73,7 +78,8 @@ static int run_case(const char* name, const std::vector<int64_t>& ids, int64_t l
     if (ov != (ctl[split::kCtlOverflow] != 0)) { printf("%s: overflow flag %u, expected %d\n", name, ctl[split::kCtlOverflow], (int)ov); bad = 1; }
   }
   if (ctl[split::kCtlOverflow]) {
-    printf("%-40s n=%ld span=%ld shift=%d buckets=%d: OVERFLOW (as expected: %s)\n", name, (long)n, (long)span, p.shift, p.buckets, bad ? "NO" : "yes");
+    printf("%-40s n=%ld span=%ld shift=%d buckets=%d: OVERFLOW (as expected: %s)%s\n", name, (long)n, (long)span, p.shift, p.buckets, bad ? "NO" : "yes", hot ? " [hot mode]" : "");
+    if (hot) printf("    hot ids %u (threshold %u samples)\n", hot_n[0], hot_n[1]);
   } else {
     int64_t nu; CK(hipMemcpy(&nu, d_nu, 8, hipMemcpyDeviceToHost));
     std::vector<int32_t> order(n), starts(n + 1); std::vector<int64_t> uniq(n);
@@ -97,6 +103,7 @@ static int run_case(const char* name, const std::vector<int64_t>& ids, int64_t l
     }
     printf("%-40s n=%ld span=%ld shift=%d buckets=%d cap=%d tiles=%d ipt=%d passes=%dx%d n_unique=%ld: %s\n", name, (long)n, (long)span, p.shift,
            p.buckets, 1 << p.cap_bits, p.tiles, p.ipt, p.passes, p.digit_bits, (long)nu, bad ? "MISMATCH" : "ok");
+    if (hot) printf("    hot ids %u (threshold %u samples), segments put in order afterwards %u\n", hot_n[0], hot_n[1], hot_n[2]);
   }
   if (timing && !bad) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -104,11 +111,15 @@ static int run_case(const char* name, const std::vector<int64_t>& ids, int64_t l
       CK(hipEventRecord(e0, st));
       const int K = 20;
       for (int k = 0; k < K; k++)
-        split::launch<uint64_t>(p, reinterpret_cast<const uint64_t*>(d_ids), n, static_cast<uint64_t>(lower), static_cast<uint32_t>(span), d_uniq,
-                                d_starts, d_order, d_nu, d_ws, nullptr, 0, st);
+        if (hot)
+          split::launch_hot<uint64_t>(p, reinterpret_cast<const uint64_t*>(d_ids), n, static_cast<uint64_t>(lower), static_cast<uint32_t>(span), d_uniq,
+                                      d_starts, d_order, d_nu, d_ws, nullptr, 0, st);
+        else
+          split::launch<uint64_t>(p, reinterpret_cast<const uint64_t*>(d_ids), n, static_cast<uint64_t>(lower), static_cast<uint32_t>(span), d_uniq,
+                                  d_starts, d_order, d_nu, d_ws, nullptr, 0, st);
       CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      printf("    timing: %.1f us per call (4 launches)\n", ms * 1000.f / K);
+      printf("    timing: %.1f us per call (%s)\n", ms * 1000.f / K, hot ? "hot mode: 7 launches" : "4 launches");
     }
   }
   CK(hipFree(d_ids)); CK(hipFree(d_ws)); CK(hipFree(d_uniq)); CK(hipFree(d_starts)); CK(hipFree(d_order)); CK(hipFree(d_nu));
@@ -191,7 +202,9 @@ int main(int argc, char** argv)
     return v;
   };
   const int64_t sizes[] = {1, 2, 63, 64, 65, 1000, 4097, 50000, 300000, 1000000};
+  const bool big_only = argc > 1 && strcmp(argv[1], "big") == 0;   // only the 10 M-id cases, timed (for rocprofv3 --stats)
   const int64_t spans[] = {1, 7, 100, 65536, 1000003, 100000000, 125000000, INT64_C(1) << 27, (INT64_C(1) << 29) + 12345};
+  if (!big_only) {
   for (int64_t n : sizes)
     for (int64_t sp : spans) {
       char nm[96];
@@ -215,14 +228,58 @@ int main(int argc, char** argv)
     for (auto& x : v) { const double r = u(rng); const uint64_t k = static_cast<uint64_t>(1.0 / std::pow(1.0 - r * 0.9999, 20.0)); x = static_cast<int64_t>((k * 2654435761ull) % N); }
     bad |= run_case("zipf-like hashed", v, 0, N, false);
   }
+  }
   // the C4-sized batch
-  bad |= run_case("10M uniform / 100M rows", uniform(10000000, 0, 100000000, 0.0), 0, 100000000, timing);
+  bad |= run_case("10M uniform / 100M rows", uniform(10000000, 0, 100000000, 0.0), 0, 100000000, timing || big_only);
+  if (big_only) {
+    const int64_t n = 10000000, N = 100000000;
+    std::vector<int64_t> v(n);
+    std::uniform_real_distribution<double> u(0.0, 1.0);
+    const double a = 1.05, am1 = a - 1.0, b = std::pow(2.0, am1);
+    for (auto& x : v) {
+      for (;;) {
+        const double U = 1.0 - u(rng), V = u(rng);
+        const double X = std::floor(std::pow(U, -1.0 / am1));
+        if (X < 1.0 || X > 9e18) continue;
+        const double T = std::pow(1.0 + 1.0 / X, am1);
+        if (V * X * (T - 1.0) / (b - 1.0) <= T / b) { x = static_cast<int64_t>((static_cast<uint64_t>(X) * 2654435761ull) % N); break; }
+      }
+    }
+    bad |= run_case("10M zipf(1.05) hashed / 100M rows", v, 0, N, true);
+    printf(bad ? "FAILED\n" : "ALL OK\n");
+    return bad;
+  }
   bad |= run_case("10M uniform / 125M rows (shard)", uniform(10000000, 375000000, 125000000, 0.0), 375000000, 125000000, timing);
   bad |= run_case("0.5M uniform / 100M rows", uniform(500000, 0, 100000000, 0.0), 0, 100000000, timing);
   // shapes that stress one stage: ids in ascending order (a tile feeds one or two buckets: every id of a tile on the same LDS
   // counter), and 10 M ids that are 4 M distinct rows (2.5 ids per run: most buckets take the radix passes)
   { std::vector<int64_t> v(10000000); for (size_t i = 0; i < v.size(); i++) v[i] = static_cast<int64_t>(i) * 10; bad |= run_case("10M ascending / 100M rows", v, 0, 100000000, timing); }
   { std::vector<int64_t> v(10000000); for (auto& x : v) x = static_cast<int64_t>(rng() % 4000000ull) * 25; bad |= run_case("10M ids on 4M distinct rows", v, 0, 100000000, timing); }
+  // round 6: the batches the hot mode is for — Zipf(1.05) ids hashed over the table (numpy's rejection sampler), one id everywhere,
+  // a hot id + uniform background, ids clustered in a few thousand rows (overflows whatever is peeled)
+  {
+    const int64_t n = 10000000, N = 100000000;
+    std::vector<int64_t> v(n);
+    std::uniform_real_distribution<double> u(0.0, 1.0);
+    const double a = 1.05, am1 = a - 1.0, b = std::pow(2.0, am1);
+    for (auto& x : v) {
+      for (;;) {
+        const double U = 1.0 - u(rng), V = u(rng);
+        const double X = std::floor(std::pow(U, -1.0 / am1));
+        if (X < 1.0 || X > 9e18) continue;
+        const double T = std::pow(1.0 + 1.0 / X, am1);
+        if (V * X * (T - 1.0) / (b - 1.0) <= T / b) { x = static_cast<int64_t>((static_cast<uint64_t>(X) * 2654435761ull) % N); break; }
+      }
+    }
+    bad |= run_case("10M zipf(1.05) hashed / 100M rows", v, 0, N, timing);
+    std::vector<int64_t> w(v.begin(), v.begin() + 500000);
+    bad |= run_case("0.5M zipf(1.05) hashed / 100M rows", w, 0, N, timing);
+    for (auto& x : v) x = x % 3000;
+    bad |= run_case("10M zipf ids clustered in 3000 rows", v, 0, N, false);
+  }
+  bad |= run_case("10M x one id", std::vector<int64_t>(10000000, 4242), 0, 100000000, timing);
+  { std::vector<int64_t> v = uniform(3000000, 0, 100000000, 0.02); for (size_t i = 0; i < v.size(); i += 7) v[i] = 31337; for (size_t i = 3; i < v.size(); i += 50) v[i] = 31338;
+    bad |= run_case("3M: two hot neighbours + uniform + drops", v, 0, 100000000, false); }
   printf(bad ? "FAILED\n" : "ALL OK\n");
   return bad;
 }

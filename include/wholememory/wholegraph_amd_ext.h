@@ -210,6 +210,12 @@ int64_t wholememory_ext_host_sorted_gathers(void);
  * is decided on the device and not visible here. A counter for tests and benchmarks. */
 int64_t wholememory_ext_split_sorts(void);
 
+/* ... and how many of those ran in HOT mode (round 6): a batch whose plain split sort overflowed a bucket is followed by split
+ * sorts that first sample the batch and give its hot ids buckets of their own (csrc/kernels/split_sort.cuh: launch_hot), so a
+ * Zipf-skewed series no longer goes to the generic sort. Opt-in (WM_DEDUP_HOT=1): correct, not yet faster than rocPRIM's sort on
+ * such batches. A counter for tests and benchmarks. */
+int64_t wholememory_ext_hot_split_sorts(void);
+
 /* Duplicate runs of the last finished ORDERED gradient step on the current device that were summed through a dense transposed
  * copy of their gradient rows (csrc/kernels/long_dense.cuh: runs of at least WM_DENSE_FOLD_MIN rows, default 131072, while
  * n / 8 rows of copies last; WM_DENSE_FOLD=0 switches the route off). Read after a synchronise. A counter for tests. */

@@ -56,9 +56,9 @@ RULES = [
     #    that budget: measured equal to the 80-VGPR build at one workgroup per CU less);
     #  * the histogram kernel: no scratch, loads batched.
     (r"split::split_hist_kernel<", dict(min_loads=4, wide=False, max_valu=4000, max_mov_share=1.0, scope="block", max_scratch=0)),
-    (r"split::split_scatter_kernel<\w[\w ]*, 12, 3>", dict(min_loads=4, wide=False, max_valu=4000, max_mov_share=1.0, scope="block",
+    (r"split::split_scatter_kernel<\w[\w ]*, 12, 3, false>", dict(min_loads=4, wide=False, max_valu=4000, max_mov_share=1.0, scope="block",
                                                         max_scratch=64, max_vgprs=64)),
-    (r"split::split_scatter_kernel<\w[\w ]*, 24, [35]>", dict(min_loads=4, wide=False, max_valu=4000, max_mov_share=1.0, scope="block",
+    (r"split::split_scatter_kernel<\w[\w ]*, 24, [35], (false|true)>", dict(min_loads=4, wide=False, max_valu=4000, max_mov_share=1.0, scope="block",
                                                         max_scratch=16, max_vgprs=128)),
     (r"split::split_sort_kernel<", dict(min_loads=4, wide=False, max_valu=4000, max_mov_share=1.0, scope="block", max_scratch=0,
                                         max_vgprs=64)),

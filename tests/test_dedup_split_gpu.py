@@ -65,7 +65,7 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("split", ["forced", "off"])
+@pytest.mark.parametrize("split", ["forced", "off", "hot"])
 @pytest.mark.parametrize("name", list(CASES))
 def test_split_sort_keeps_the_reference_order(gpu_env, knobs, name, split):
     n, rows, off, gen = CASES[name]
@@ -77,6 +77,9 @@ def test_split_sort_keeps_the_reference_order(gpu_env, knobs, name, split):
     grads = rng.standard_normal((n, 8)).astype(np.float32)
     if split == "forced":
         knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+    elif split == "hot":   # round 6: the split sort with the batch's hot ids peeled into buckets of their own (split::launch_hot)
+        knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+        knobs.set("WM_DEDUP_HOT", 2)
     else:
         knobs.set("WM_DEDUP_SPLIT", 0)
     idt = np.int32 if "int32" in name else np.int64
@@ -240,6 +243,7 @@ def test_route_follows_the_batches(gpu_env, knobs):
     back. Whatever the route, every call's result is the oracle's, bit for bit; the route shows in the split sort counter."""
     from wholegraph_amd import binding as wmb
     knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+    knobs.unset("WM_DEDUP_HOT")                # (the default: round 5's two routes; the opt-in hot-id route of round 6: next test)
     rng = np.random.default_rng(2024)
     rows, n = 2_000_000, 80_000
     uniform = rng.integers(0, rows, n).astype(np.int64)
@@ -262,6 +266,43 @@ def test_route_follows_the_batches(gpu_env, knobs):
     assert routes[0] == 0 and routes[-1] == 1 and sum(routes) >= 3, routes
     knobs.set("WM_DEDUP_ADAPT", 0)             # (a reload forgets what was learnt; ADAPT=0: always the split sort)
     assert call(skewed, want_s) == 1 and call(skewed, want_s) == 1
+
+
+def test_hot_route_follows_the_batches(gpu_env, knobs):
+    """Round 6, three routes per row range: after a plain split sort overflowed, the next batches take the split sort with their
+    hot ids peeled into buckets of their own (counted by wholememory_ext_hot_split_sorts) — a skewed series stays on the
+    hand-written sort; when that overflows too (ids clustered in a few thousand rows) the series goes to rocPRIM's sort and is
+    probed every fourth call; a hot-mode sort that peeled nothing hands the range back to the plain split sort. Every call's
+    result is the oracle's, bit for bit, whatever the route."""
+    from wholegraph_amd import binding as wmb
+    knobs.set("WM_DEDUP_SPLIT_MIN", 1)
+    knobs.set("WM_DEDUP_HOT", 1)               # (opt-in: the hot-mode sort is correct but not faster than rocPRIM's yet)
+    rng = np.random.default_rng(77)
+    rows, n = 3_000_000, 90_000
+    uniform = rng.integers(0, rows, n).astype(np.int64)
+    skewed = np.where(rng.random(n) < 0.3, 31337, rng.integers(0, rows, n)).astype(np.int64)
+    skewed[rng.random(n) < 0.05] = 31338
+    clustered = rng.integers(0, 20000, n).astype(np.int64)
+    grads = rng.standard_normal((n, 8)).astype(np.float32)
+    want = {k: _expect(v, grads, rows, 0) for k, v in (("u", uniform), ("s", skewed), ("c", clustered))}
+    ids = {"u": uniform, "s": skewed, "c": clustered}
+    splits, hots = wmb.lib().wholememory_ext_split_sorts, wmb.lib().wholememory_ext_hot_split_sorts
+
+    def call(k):
+        b_s, b_h = splits(), hots()
+        got, nu = _apply(ids[k], grads, rows, 0, np.int64)
+        assert nu == want[k][1] and got.tobytes() == want[k][0].tobytes(), k
+        return splits() - b_s, hots() - b_h
+
+    assert call("u") == (1, 0)                 # nothing known: the plain split sort
+    assert call("s") == (1, 0)                 # ... which overflows (the generic path sorts the batch) and says so
+    assert call("s") == (1, 1)                 # the series continues on the split sort with the hot ids peeled
+    assert call("s") == (1, 1)
+    assert call("c") == (1, 1)                 # clustered ids overflow a regular bucket whatever is peeled (generic path)
+    assert call("c") == (0, 0)                 # ... and the series goes to rocPRIM's sort
+    routes = [call("u") for _ in range(10)]    # uniform again: a probe notices within four calls, the hot mode finds nothing to peel
+    assert routes[0] == (0, 0) and routes[-1] == (1, 0), routes
+    assert any(r == (1, 1) for r in routes), routes
 
 
 @pytest.mark.parametrize("gate", ["lookback", "join"])

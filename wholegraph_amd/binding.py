@@ -262,6 +262,7 @@ PROTOTYPES = {
     "wholememory_ext_probe_memory": (_i, [_vp, C.c_size_t, _i, _i, _P(_f)]),
     "wholememory_ext_host_sorted_gathers": (_i64, []),
     "wholememory_ext_split_sorts": (_i64, []),
+    "wholememory_ext_hot_split_sorts": (_i64, []),
     "wholememory_ext_dense_fold_last": (_i64, []),
     "wholememory_ext_distributed_gather_launches": (_i64, []),
     "wholememory_ext_distributed_scatter_launches": (_i64, []),

@@ -393,9 +393,12 @@ struct sort_lane {
   struct adapt_entry {
     int64_t lower = -1, upper = -1;
     unsigned calls = 0;
+    int mode = 0;   // round 6: 0 the plain split sort, 1 the split sort with hot ids peeled (split::launch_hot), 2 rocPRIM's sort
   };
   adapt_entry adapt[kAdapt];
-  volatile int32_t* adapt_flags = nullptr;   // pinned, [kAdapt]
+  // pinned, three words per row range: [i] the overflow word of its last PLAIN split sort, [kAdapt + i] of its last HOT split
+  // sort or probe, [2 kAdapt + i] how many ids that one peeled
+  volatile int32_t* adapt_flags = nullptr;
   unsigned adapt_generation     = ~0u;       // a knob reload forgets what was learnt (tests, A/B runs)
   int adapt_next                = 0;
   void* probe_ws                = nullptr;   // split::probe_workspace_bytes(), allocated at the first probe
@@ -403,21 +406,21 @@ struct sort_lane {
   {
     if (adapt_flags == nullptr) {
       void* h = nullptr;
-      if (hipHostMalloc(&h, kAdapt * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return -1;
+      if (hipHostMalloc(&h, 3 * kAdapt * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return -1;
       adapt_flags = static_cast<volatile int32_t*>(h);
-      for (int i = 0; i < kAdapt; i++) adapt_flags[i] = 0;
+      for (int i = 0; i < 3 * kAdapt; i++) adapt_flags[i] = 0;
     }
     const unsigned g = g_knob_generation.load(std::memory_order_acquire);
     if (g != adapt_generation) {
-      for (int i = 0; i < kAdapt; i++) adapt[i] = adapt_entry{}, adapt_flags[i] = 0;
+      for (int i = 0; i < kAdapt; i++) adapt[i] = adapt_entry{}, adapt_flags[i] = adapt_flags[kAdapt + i] = adapt_flags[2 * kAdapt + i] = 0;
       adapt_generation = g;
     }
     for (int i = 0; i < kAdapt; i++)
       if (adapt[i].lower == lower && adapt[i].upper == upper) return i;
     const int i = adapt_next;
     adapt_next  = (adapt_next + 1) % kAdapt;
-    adapt[i]    = adapt_entry{lower, upper, 0};
-    adapt_flags[i] = 0;
+    adapt[i]    = adapt_entry{lower, upper, 0, 0};
+    adapt_flags[i] = adapt_flags[kAdapt + i] = adapt_flags[2 * kAdapt + i] = 0;
     return i;
   }
   // Device-side waits that gave up (split_sort.cuh: wait_cfg) leave their code in this word of pinned, device-mapped host
@@ -495,6 +498,7 @@ inline split::wait_cfg wait_limits(const split::plan* sp = nullptr)
 }
 inline bool stall_join() { const char* st = WM_KNOB("WM_DEBUG_STALL"); return st != nullptr && st[0] == 'j'; }
 std::atomic<int64_t> g_split_sorts{0};
+std::atomic<int64_t> g_hot_split_sorts{0};   // ... of them with hot ids peeled (split::launch_hot)
 // The optimizer step that follows a split sort on the same thread finds the sort's control words through the run_starts array
 // both were given: its long-run counters live there (zeroed by the sort's first kernel: no fill in front of the step), and
 // the listing kernels return at once when the sort saw neither an overflow nor a bucket with a run of more than kMaxDup ids —
@@ -616,35 +620,70 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
   // batch goes straight to rocPRIM (below), and every kProbeEvery-th such call runs the split sort's first two kernels as a
   // probe in front (30 us / 4); the first batch that would not overflow switches back. A wrong guess costs time, once.
   // WM_DEDUP_ADAPT=0: always the split sort. Not while a stream is captured (a graph replays ONE route).
+  // Round 6: three routes per row range. 0 = the plain split sort; when it overflowed, 1 = the split sort with the batch's hot ids
+  // peeled into buckets of their own (split::launch_hot: a Zipf batch then fits; taken only with WM_DEDUP_HOT=1, see below); when THAT
+  // overflowed too (ids clustered in a few thousand rows), 2 = rocPRIM's sort, probed every kProbeEvery-th call with the first
+  // kernels of the hot-mode sort. Back: a hot-mode sort that peeled nothing returns the range to route 0.
   bool expect_overflow = false;
+  bool hot_route       = false;
   int adapt_slot       = -1;
-  if (span > 0 && span < INT64_C(0xFFFFFFFF) && n >= split_min() && WM_KNOB("WM_DEDUP_SERIAL") == nullptr &&
+  // (OPT-IN, WM_DEDUP_HOT=1: correct on every case of the harness and the parity tests, but on the Zipf(1.05) batch of 10 M ids the
+  // hot-mode sort takes 0.54-0.70 ms where rocPRIM's takes 0.36 — putting the ~90 k listed segments into receive order costs more
+  // than the radix passes it avoids: profiles/r06_split_sort_hot_harness.txt. Route 2 follows a plain overflow by default.)
+  const bool hot_allowed = WM_KNOB("WM_DEDUP_HOT") != nullptr && (WM_KNOB("WM_DEDUP_HOT")[0] == '1' || WM_KNOB("WM_DEDUP_HOT")[0] == '2');
+  const bool hot_forced  = WM_KNOB("WM_DEDUP_HOT") != nullptr && WM_KNOB("WM_DEDUP_HOT")[0] == '2';   // (tests: every batch takes route 1)
+  if (hot_forced) {
+    hot_route = span > 0 && span < INT64_C(0xFFFFFFFF) && n >= split_min() && split::make_plan(n, span, 0, 0, true).ok;
+  } else if (span > 0 && span < INT64_C(0xFFFFFFFF) && n >= split_min() && WM_KNOB("WM_DEDUP_SERIAL") == nullptr &&
       !(WM_KNOB("WM_DEDUP_ADAPT") != nullptr && WM_KNOB("WM_DEDUP_ADAPT")[0] == '0')) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone && sort_lane::get().ok) {
       sort_lane& lane = sort_lane::get();
       std::lock_guard<std::mutex> lk(lane.mu);
       adapt_slot = lane.adapt_slot(key_lower_bound, key_upper_bound);
-      if (adapt_slot >= 0 && lane.adapt_flags[adapt_slot] != 0) {
-        expect_overflow = true;
-        const split::plan sp = split::make_plan(n, span);
-        if (!sp.ok) {
-          lane.adapt_flags[adapt_slot] = 0;   // (a batch the split sort would not take anyway)
-        } else if (++lane.adapt[adapt_slot].calls % sort_lane::kProbeEvery == 0) {
-          if (lane.probe_ws == nullptr && hipMalloc(&lane.probe_ws, split::probe_workspace_bytes()) != hipSuccess) lane.probe_ws = nullptr;
-          if (lane.probe_ws != nullptr) {
-            if (split::launch_probe<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
-                                          static_cast<uint32_t>(span), lane.probe_ws, stream) != 0)
-              return -2;
-            (void)hipMemcpyAsync(const_cast<int32_t*>(lane.adapt_flags) + adapt_slot, split::probe_overflow_word(sp, lane.probe_ws),
-                                 sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+      if (adapt_slot >= 0) {
+        auto& e = lane.adapt[adapt_slot];
+        volatile int32_t* f_plain = lane.adapt_flags + adapt_slot;
+        volatile int32_t* f_hot   = lane.adapt_flags + sort_lane::kAdapt + adapt_slot;
+        volatile int32_t* f_nhot  = lane.adapt_flags + 2 * sort_lane::kAdapt + adapt_slot;
+        const split::plan hp = hot_allowed ? split::make_plan(n, span, 0, 0, true) : split::plan{};
+        const bool can_hot   = hot_allowed && hp.ok;
+        if (e.mode == 0 && *f_plain != 0) {
+          e.mode = can_hot ? 1 : 2, e.calls = 0;
+          *f_hot = can_hot ? 0 : 1, *f_nhot = 1;
+        } else if (e.mode == 1 && (!can_hot || *f_hot != 0)) {
+          e.mode = 2, e.calls = 0;
+        } else if (e.mode == 1 && *f_nhot == 0) {
+          e.mode = 0, *f_plain = 0;   // (nothing was peeled: the batches are no longer skewed)
+        }
+        if (e.mode == 2) {
+          const split::plan sp = can_hot ? hp : split::make_plan(n, span);
+          if (!sp.ok) {
+            e.mode = 0, *f_plain = 0;   // (a batch the split sort would not take anyway)
+          } else {
+            volatile int32_t* verdict = can_hot ? f_hot : f_plain;
+            if (*verdict == 0) {
+              e.mode = can_hot ? 1 : 0;   // the last probe found room: back to the split sort
+              if (e.mode == 1) *f_nhot = 1;
+            } else if (++e.calls % sort_lane::kProbeEvery == 0) {
+              if (lane.probe_ws == nullptr && hipMalloc(&lane.probe_ws, split::probe_workspace_bytes()) != hipSuccess) lane.probe_ws = nullptr;
+              if (lane.probe_ws != nullptr) {
+                if (split::launch_probe<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
+                                              static_cast<uint32_t>(span), lane.probe_ws, stream) != 0)
+                  return -2;
+                (void)hipMemcpyAsync(const_cast<int32_t*>(verdict), split::probe_overflow_word(sp, lane.probe_ws), sizeof(int32_t),
+                                     hipMemcpyDeviceToHost, stream);
+              }
+            }
           }
         }
+        expect_overflow = e.mode == 2;
+        hot_route       = e.mode == 1;
       }
     }
   }
   if (!expect_overflow && span > 0 && span < INT64_C(0xFFFFFFFF) && n >= split_min()) {
-    const split::plan sp = split::make_plan(n, span);
+    const split::plan sp = split::make_plan(n, span, 0, 0, hot_route);
     if (sp.ok) {
       const split_layout sl = split_carve(workspace, n);
       const unsigned bits   = significant_bits(span + 1, 32);
@@ -702,9 +741,13 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
                    hipStreamWaitEvent(lane.side(), lane.forked, 0) == hipSuccess;
         }
         generic(forked ? lane.side() : stream);
-        if (forked && adapt_slot >= 0)   // (what this batch did decides the route of the next: see "adaptive route")
-          (void)hipMemcpyAsync(const_cast<int32_t*>(lane.adapt_flags) + adapt_slot, gate, sizeof(int32_t), hipMemcpyDeviceToHost,
-                               lane.side());
+        if (forked && adapt_slot >= 0) {   // (what this batch did decides the route of the next: see "adaptive route")
+          (void)hipMemcpyAsync(const_cast<int32_t*>(lane.adapt_flags) + (hot_route ? sort_lane::kAdapt : 0) + adapt_slot, gate,
+                               sizeof(int32_t), hipMemcpyDeviceToHost, lane.side());
+          if (hot_route)   // ... and how many ids it peeled (none: the range goes back to the plain split sort)
+            (void)hipMemcpyAsync(const_cast<int32_t*>(lane.adapt_flags) + 2 * sort_lane::kAdapt + adapt_slot,
+                                 split::hot_view(sp, sl.split_ws).n_hot, sizeof(int32_t), hipMemcpyDeviceToHost, lane.side());
+        }
         if (forked) forked = hipEventRecord(lane.joined, lane.side()) == hipSuccess;
       };
       // With the fork by a word nothing ties the side stream's launches to a place in the caller's queue: the caller's kernels
@@ -714,6 +757,12 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
       auto nothing         = []() {};
       const bool after_scatter = WM_AB_KNOB("WM_DEDUP_FORK") != nullptr && WM_AB_KNOB("WM_DEDUP_FORK")[0] == '3';
       const int launched =
+        hot_route ? (side_last ? split::launch_hot<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
+                                                         static_cast<uint32_t>(span), unique_ids, run_starts, order, n_unique_out,
+                                                         sl.split_ws, sl.osw_ctrl, zero_n, stream, nothing, verdict_word, verdict_value, wc)
+                               : split::launch_hot<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
+                                                         static_cast<uint32_t>(span), unique_ids, run_starts, order, n_unique_out,
+                                                         sl.split_ws, sl.osw_ctrl, zero_n, stream, between, verdict_word, verdict_value, wc)) :
         side_last ? split::launch<UKey>(sp, static_cast<const UKey*>(ids), n, static_cast<UKey>(key_lower_bound),
                                         static_cast<uint32_t>(span), unique_ids, run_starts, order, n_unique_out, sl.split_ws,
                                         sl.osw_ctrl, zero_n, stream, nothing, false, verdict_word, verdict_value, wc)
@@ -733,6 +782,7 @@ int run_dedup(const void* ids, int64_t n, int64_t key_upper_bound, int64_t key_l
                          sort_lane::get().host_err_dev);
       if (defer) g_join_pending = true;
       g_split_sorts.fetch_add(1, std::memory_order_relaxed);
+      if (hot_route) g_hot_split_sorts.fetch_add(1, std::memory_order_relaxed);
       g_last_split.run_starts = run_starts;
       g_last_split.unique_ids = unique_ids;
       g_last_split.n_unique   = n_unique_out;
@@ -2469,6 +2519,7 @@ __global__ void fill_float_kernel(float* p, float v, int64_t n)
 
 }  // namespace wm
 extern "C" int64_t wholememory_ext_split_sorts(void) { return wm::g_split_sorts.load(std::memory_order_relaxed); }
+extern "C" int64_t wholememory_ext_hot_split_sorts(void) { return wm::g_hot_split_sorts.load(std::memory_order_relaxed); }
 // runs of the last finished ORDERED optimizer step on the current device that were folded through a dense transposed copy
 // (kernels/long_dense.cuh); read after a synchronise. A counter for tests and benchmarks.
 extern "C" int64_t wholememory_ext_dense_fold_last(void)
