@@ -94,6 +94,8 @@ struct wm_optimizer_args {
   int adam_w;
   void* long_run_ws;           // device scratch of long_run_workspace_bytes(n_recv, dim) or nullptr (then every run is
                                // folded by one wave)
+  size_t long_run_ws_bytes;    // its size as long_run_workspace_bytes() returned it (round 6: the answer may include room for
+                               // dense copies of the longest runs, or not — it follows what earlier steps saw; 0 = no such room)
   // Order of the fp32 sum of a run's duplicate gradient rows. 0 = the reference's (receive order, one chain per element:
   // exchange_embeddings_nccl_func.cu:76-103) — bit-identical results, the default for fp32 tables. 1 = "tree": runs of more
   // than a few dozen rows are cut into segments of rows that are summed side by side and combined afterwards — a fixed

@@ -306,7 +306,8 @@ void step_sorted(dedup_result& r, wholememory_dtype_t index_dtype, int64_t n_rec
     oa->self_grad_stride = self->stride;
   }
   oa->count       = n_recv;  // upper bound; the kernel reads the true count from d_nunique
-  oa->long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n_recv, oa->dim)), WHOLEMEMORY_DT_INT8);
+  oa->long_run_ws_bytes = bk->long_run_workspace_bytes(n_recv, oa->dim);
+  oa->long_run_ws       = long_ws.device(static_cast<int64_t>(oa->long_run_ws_bytes), WHOLEMEMORY_DT_INT8);
   if (rows_ready != nullptr) WM_BK(bk->stream_wait_event(stream, rows_ready));
   int rc = bk->optimizer_step(oa, r.d_nunique, stream);
   const int join_rc = r.join();   // the sort's side stream, if it left one running: joined behind the step
@@ -486,7 +487,8 @@ int combined_gradient_apply(wholememory_embedding_* e, const char* idx_ptr, cons
     fa.value_dtype = vdt, fa.grads = grads_ptr, fa.grad_stride = gmat.stride;
     fa.count = nu, fa.local_table = partial, fa.table_stride = dim, fa.local_entry_offset = 0, fa.dim = dim;
     fa.fold_mode   = 1;
-    fa.long_run_ws = long_ws.device(static_cast<int64_t>(bk->long_run_workspace_bytes(n, dim)), WHOLEMEMORY_DT_INT8);
+    fa.long_run_ws_bytes = bk->long_run_workspace_bytes(n, dim);
+    fa.long_run_ws       = long_ws.device(static_cast<int64_t>(fa.long_run_ws_bytes), WHOLEMEMORY_DT_INT8);
     if (bk->optimizer_step(&fa, r.d_nunique, stream) != 0) throw hip_error("folding the duplicate gradient rows failed");
     if (vdt == WHOLEMEMORY_DT_HALF && bk->partials_nonfinite != nullptr)
       WM_BK(bk->partials_nonfinite(r.d_starts, r.d_nunique, nu, partial, dim, dim, d_flag, stream));

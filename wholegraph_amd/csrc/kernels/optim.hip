@@ -2689,9 +2689,17 @@ inline dense_carve dense_layout(size_t base, int64_t n_recv, int64_t dim)
 inline size_t ordered_list_bytes(int64_t n_recv) { return 32 + sizeof(long_run_entry) * static_cast<size_t>(n_recv / (kLongRun + 1) + 2); }
 
 size_t hip_long_run_ws_bytes(int64_t n_recv, int64_t dim)
-{   // the larger of the two layouts (the fold order is only resolved at the step: it may depend on the value dtype)
-  return std::max(dense_layout(ordered_list_bytes(n_recv), n_recv, dim).total,
-                  tree_ws_bytes(n_recv, dim, std::min(tree_threshold(), kTreeMin)));
+{   // the larger of the two layouts (the fold order is only resolved at the step: it may depend on the value dtype). The room for
+    // dense copies (n / 8 rows: 640 MB for 10 M rows of 128 floats) only while the device's recent steps listed long runs at all
+    // (long_lane::expect_long: a uniform series pays nothing for it after its first calls); the step takes the dense route only
+    // when the workspace it is handed is that big (wm_optimizer_args::long_run_ws_bytes)
+  bool expect;
+  {
+    std::lock_guard<std::mutex> lk(long_lane::get().mu);
+    expect = long_lane::get().expect_long();
+  }
+  const size_t ordered = expect ? dense_layout(ordered_list_bytes(n_recv), n_recv, dim).total : ordered_list_bytes(n_recv);
+  return std::max(ordered, tree_ws_bytes(n_recv, dim, std::min(tree_threshold(), kTreeMin)));
 }
 
 // a->count is an UPPER BOUND for the launch geometry; the true run count is read on the device from
@@ -2720,7 +2728,7 @@ int hip_optimizer_step_dev(const wm_optimizer_args* a, const int64_t* n_unique_d
       // (rows of up to 256 columns: the long-run kernel's one resident round — 256 / (dim / 32) workgroups per 32-column slice —
       // then has 16 per slice to spare for the dense copies, launch_step_opt)
       const dense_carve dc = dense_layout(ordered_list_bytes(a->count), a->count, a->dim);
-      if (dc.max_jobs > 0) {
+      if (dc.max_jobs > 0 && a->long_run_ws_bytes >= dc.total) {
         p.dense_jobs     = reinterpret_cast<dense_fold::job*>(static_cast<char*>(a->long_run_ws) + dc.off_jobs);
         p.dense_buf      = reinterpret_cast<float*>(static_cast<char*>(a->long_run_ws) + dc.off_buf);
         p.dense_cap      = dc.cap_floats;
