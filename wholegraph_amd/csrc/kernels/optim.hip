@@ -369,8 +369,15 @@ Lane& per_device()
   if (lanes[dev] == nullptr) lanes[dev] = new Lane();
   return *lanes[dev];
 }
+__global__ void waits_probe_set_kernel(uint32_t* word) { __hip_atomic_store(word, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 struct sort_lane {
   std::mutex mu;   // one fork .. join sequence at a time: the events are shared
+  // Do two kernels on two streams of this device RUN side by side? Every device-side wait of the gradient path needs that (a wave
+  // polls a word another stream's kernel sets). Measured once per device, when the lane is made: a one-wave kernel waits ~10 ms
+  // at most for a word that a kernel on the other stream sets. A tool that executes one kernel at a time (any tool: round 5
+  // only knew rocprofv3's counter collection by its environment variables) lets the wait give up -> events only, for the
+  // life of the process, one WARN line.
+  bool waits_work = true;
   hipStream_t stream = nullptr, stream_high = nullptr;
   hipEvent_t forked = nullptr, joined = nullptr;
   bool ok = false;
@@ -466,6 +473,23 @@ struct sort_lane {
           (void)hipFree(r);
       }
     }
+    if (ok) {
+      uint32_t* probe = nullptr;   // [0] the word waited for, [1] the waiter's error word
+      if (hipMalloc(reinterpret_cast<void**>(&probe), 2 * sizeof(uint32_t)) == hipSuccess) {
+        uint32_t err = 1;
+        if (hipMemsetAsync(probe, 0, 2 * sizeof(uint32_t), stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
+          hipLaunchKernelGGL(split::split_wait_kernel, dim3(1), dim3(64), 0, stream, probe, 1u, probe + 1, 6000u, static_cast<uint32_t*>(nullptr));
+          hipLaunchKernelGGL(waits_probe_set_kernel, dim3(1), dim3(1), 0, stream_high, probe);
+          if (hipStreamSynchronize(stream_high) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess &&
+              hipMemcpy(&err, probe + 1, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess && err != 0) {
+            waits_work = false;
+            WM_WARN("kernels on two streams of this device do not run side by side (a tool that executes one kernel at a time?): "
+                    "the gradient path synchronises its side streams with events only");
+          }
+        }
+        (void)hipFree(probe);
+      }
+    }
   }
   // one lane per DEVICE (round 6; a process-wide one put device 0's streams, ring and events under device 1's kernels): created
   // on the device that is current at the first call that needs it there, kept for the life of the process
@@ -480,7 +504,8 @@ inline bool device_waits_allowed()
 {
   const char* e = WM_KNOB("WM_DEVICE_WAITS");
   if (e != nullptr) return e[0] != '0';
-  return WM_KNOB("ROCPROF_COUNTER_COLLECTION") == nullptr && WM_KNOB("ROCPROF_COUNTERS") == nullptr;
+  if (WM_KNOB("ROCPROF_COUNTER_COLLECTION") != nullptr || WM_KNOB("ROCPROF_COUNTERS") != nullptr) return false;
+  return sort_lane::get().waits_work;   // (round 6: measured per device, whatever the tool is called)
 }
 // limits of the device-side waits (split_sort.cuh: wait_cfg). WM_DEBUG_SPIN_LIMIT=n shortens every one of them to n polls and
 // WM_DEBUG_STALL=lookback|join keeps a gate shut (a stage-2 bucket that never publishes / a generic path that never reports
