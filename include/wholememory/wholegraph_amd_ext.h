@@ -218,7 +218,7 @@ int64_t wholememory_ext_hot_split_sorts(void);
 
 /* Duplicate runs of the last finished ORDERED gradient step on the current device that were summed through a dense transposed
  * copy of their gradient rows (csrc/kernels/long_dense.cuh: runs of at least WM_DENSE_FOLD_MIN rows, default 131072, while
- * n / 8 rows of copies last; WM_DENSE_FOLD=0 switches the route off). Read after a synchronise. A counter for tests. */
+ * 3 n / 8 rows of copies last; WM_DENSE_FOLD=0 switches the route off). Read after a synchronise. A counter for tests. */
 int64_t wholememory_ext_dense_fold_last(void);
 
 /* Kernels queued so far by the DISTRIBUTED gather route of this process (owner-side row gathers, reorder-on-receive

@@ -5,7 +5,7 @@ of one id summed one by one in receive order) + embedding_optimizer_func.cu (the
 A batch whose hottest ids repeat thousands of times (and one a few hundred times, and a tail of runs of 1-6 rows) on RANDOM fp32
 gradients, where the summation order shows in the last bits: with the threshold lowered (WM_DENSE_FOLD_MIN) the hottest runs go
 through copy + fold in one launch, the next ones stay step_long4_kernel's — because they are below the threshold or because the
-dense buffer (n / 8 rows per call) is full —, the rest is the tile kernel's. Every path must give the oracle's bits: table,
+dense buffer (3 n / 8 rows per call) is full —, the rest is the tile kernel's. Every path must give the oracle's bits: table,
 per-element states, per-row beta powers; and the same bits with the dense route switched off (WM_DENSE_FOLD=0). Row shapes: the
 tile kernel's 128 floats, 100 floats (25 sixteen-byte pieces: a last 8-column slice of 4 columns), 36 floats (short rows), 200 floats
 and 256 floats (the widest rows the route takes: the long-run kernel's resident round then has just 16 workgroups per slice to spare). Two calls in a row on the same workspace addresses (a stale line of the first call's dense copy in
@@ -31,10 +31,10 @@ def _batch(rng, local_rows, local_off, n_recv, idt):
     ids = (local_off + rng.integers(0, local_rows, n_recv)).astype(idt)
     hot = local_off + rng.choice(local_rows, 4, replace=False)
     u = rng.random(n_recv)
-    ids[u < 0.07] = hot[0]                       # ~7 % of the batch, ~4.2 k rows: the dense route
-    ids[(u >= 0.07) & (u < 0.11)] = hot[1]        # ~4 %: dense while the buffer lasts (n / 8 rows per call: not all three fit)
-    ids[(u >= 0.11) & (u < 0.14)] = hot[2]        # ~3 %: dense or step_long4_kernel, by the threshold and by the room left
-    ids[(u >= 0.14) & (u < 0.145)] = hot[3]       # ~0.5 %, ~300 rows
+    ids[u < 0.20] = hot[0]                       # ~20 % of the batch, ~12 k rows: the dense route
+    ids[(u >= 0.20) & (u < 0.32)] = hot[1]        # ~12 %: dense while the buffer lasts (3 n / 8 rows per call: not all three fit)
+    ids[(u >= 0.32) & (u < 0.40)] = hot[2]        # ~8 %: dense or step_long4_kernel, by the threshold and by the room left
+    ids[(u >= 0.40) & (u < 0.405)] = hot[3]       # ~0.5 %, ~300 rows
     return ids
 
 
@@ -116,13 +116,13 @@ def test_dense_fold_takes_the_hot_runs(gpu_env, knobs):
 
     knobs.unset("WM_DENSE_FOLD")
     knobs.set("WM_DENSE_FOLD_MIN", 300)
-    # the buffer holds n / 8 = 7500 rows; the runs are ~4.2 k, ~2.4 k, ~1.8 k and ~300 rows: not all of them fit.
+    # the buffer holds 3 n / 8 = 22.5 k rows; the runs are ~12 k, ~7.2 k, ~4.8 k and ~300 rows: not all of them fit.
     # (the room for the copies is only part of a step's scratch while the device's recent steps listed long runs: the first call
     # after a series without any runs them through step_long4_kernel and tells the next one)
     step()
     took = step()
     assert 2 <= took <= 3, took
-    knobs.set("WM_DENSE_FOLD_MIN", 3000)
+    knobs.set("WM_DENSE_FOLD_MIN", 10000)
     step()
     assert step() == 1
     knobs.set("WM_DENSE_FOLD", 0)

@@ -2678,8 +2678,8 @@ int hip_sort_ids(const void* ids, wholememory_dtype_t index_dtype, int64_t n, in
 }
 
 // Dense copies of the very long runs of an ORDERED fp32 fold (kernels/long_dense.cuh): runs of at least dense_min_rows() rows,
-// at most n_recv / 8 rows of them per call (the three hottest ids of a Zipf(1.05) batch of 10 M are 0.95 M rows; what does
-// not fit stays step_long4_kernel's), none for batches without room for one such run. WM_DENSE_FOLD=0 switches it off,
+// at most 3 / 8 of the batch's rows per call (what does not fit stays step_long4_kernel's), none for batches without room for
+// one such run. WM_DENSE_FOLD=0 switches it off,
 // WM_DENSE_FOLD_MIN=rows moves the threshold (tests).
 inline int dense_min_rows(int64_t n_recv)
 {
@@ -2701,7 +2701,8 @@ inline dense_carve dense_layout(size_t base, int64_t n_recv, int64_t dim)
 {
   dense_carve c{base, base, base, 0, 0};
   const int dmin = dense_min_rows(n_recv);
-  const int64_t cap_rows = n_recv / 8;
+  const int64_t cap_rows = n_recv / 8 * 3;   // (3 / 8 of the batch: at 8 ranks the owner of a Zipf(1.05) batch's hottest id receives 8 x 527 k
+                                             // copies among its 13.7 M rows — 31 %; what does not fit stays step_long4_kernel's)
   if (dmin <= 0 || dim % 4 != 0 || cap_rows < dmin) return c;
   auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
   c.max_jobs   = static_cast<int>(cap_rows / dmin + 2);
@@ -2715,7 +2716,7 @@ inline size_t ordered_list_bytes(int64_t n_recv) { return 32 + sizeof(long_run_e
 
 size_t hip_long_run_ws_bytes(int64_t n_recv, int64_t dim)
 {   // the larger of the two layouts (the fold order is only resolved at the step: it may depend on the value dtype). The room for
-    // dense copies (n / 8 rows: 640 MB for 10 M rows of 128 floats) only while the device's recent steps listed long runs at all
+    // dense copies (3 n / 8 rows: 1.9 GB for 10 M rows of 128 floats) only while the device's recent steps listed long runs at all
     // (long_lane::expect_long: a uniform series pays nothing for it after its first calls); the step takes the dense route only
     // when the workspace it is handed is that big (wm_optimizer_args::long_run_ws_bytes)
   bool expect;
