@@ -31,7 +31,8 @@ ZIPF = {
                        4: dict(distinct=4880850, hottest=525979, max_copies=7466266, max_distinct=2369505),
                        8: dict(distinct=4898680, hottest=525979, max_copies=7063196, max_distinct=1976741)},
 }
-ADD_NS = 2.62   # one dependent fp32 add on this part (profiles/r05_fold_floor.txt): the ordered fold of a run is a chain of them
+ADD_NS = 2.4    # per row of the ordered fold of a very long run through its dense copy (round 6: 5.4-5.8 cycles per row at 2.4 GHz,
+                # profiles/r06_fold5_harness_slices.txt, r06_grad_timeline_zipf_dense_third.txt; round 5's chain figure was 2.62)
 
 
 def link_ms(rows, row_bytes, gbps):
