@@ -245,6 +245,10 @@ int main(int argc, char** argv)
         if (V * X * (T - 1.0) / (b - 1.0) <= T / b) { x = static_cast<int64_t>((static_cast<uint64_t>(X) * 2654435761ull) % N); break; }
       }
     }
+    if (getenv("SPLIT_FIX_ONLY")) {   // split_fix_small_kernel with only one class of segments (results wrong on purpose): kernel times from rocprofv3
+      int dbg = atoi(getenv("SPLIT_FIX_ONLY"));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(wm::split::g_split_debug), &dbg, sizeof(int)));
+    }
     bad |= run_case("10M zipf(1.05) hashed / 100M rows", v, 0, N, true);
     printf(bad ? "FAILED\n" : "ALL OK\n");
     return bad;

@@ -110,6 +110,7 @@ constexpr int kHotMax       = 512;   // hot ids, at most
 constexpr int kHotPerBucket = 63;    // ... of one regular bucket (6 bits of the per-bucket word)
 constexpr uint32_t kInfoHot = 1u << 31;
 constexpr int kHotInTile    = 8;    // a hot bucket's share of a tile of up to this many ids is put in order inside stage 1's scatter kernel
+constexpr int kFixSmall     = 2048;  // positions of a listed segment a single wave sorts in its LDS (8 KiB); longer: a workgroup
 constexpr unsigned long long kTaskTile = 1ull << 63;   // fix task: the segment's positions lie inside ONE tile of stage 1
 constexpr int kSelSamples   = 32;    // ids per thread the selection kernel looks at (32768 of the batch; 56: 62 us, mostly load latency)
 
@@ -989,24 +990,32 @@ __global__ __launch_bounds__((1 << CAPBITS) / kSortIpt, 8) void split_sort_kerne
         // long runs (more than kMaxDup ids) are left as they arrived; their pieces of order[] are listed for split_fix_*_kernel —
         // one slot of the global list per workgroup and round trip, the entries written side by side
         uint32_t mine = 0;
+        bool any_big  = false;
         for (int r = threadIdx.x; r < static_cast<int>(heads_total); r += BLOCK) {
           const int i0 = static_cast<int>(s_run[r]);
           const int i1 = r + 1 < static_cast<int>(heads_total) ? static_cast<int>(s_run[r + 1]) : m;
-          mine += i1 - i0 > kMaxDup ? 1u : 0u;
+          mine += i1 - i0 > kMaxDup && i1 - i0 <= kFixSmall ? 1u : 0u;
+          if (i1 - i0 > kFixSmall) {   // (an id the selection missed: rare — its own list, from the END of the array, for split_fix_big_kernel)
+            const uint32_t k = atomicAdd(&ht.n_hot[3], 1u);
+            if (k < ht.max_tasks)
+              ht.tasks[ht.max_tasks - 1 - k] = static_cast<unsigned long long>(start + static_cast<uint32_t>(i0)) | (static_cast<unsigned long long>(i1 - i0) << 32);
+            any_big = true;
+          }
         }
         uint32_t all;
         uint32_t at = block_exclusive_sum<WAVES>(mine, s_waves, &all);
+        if (any_big) atomicAdd(&ctl[kCtlRadixBuckets], 1u);   // "a run of more than kMaxDup ids exists" (the optimizer step's listing kernels)
         if (all > 0) {   // (uniform)
           if (threadIdx.x == 0) {
             s_misc[3] = atomicAdd(&ht.n_hot[2], all);
-            atomicAdd(&ctl[kCtlRadixBuckets], 1u);   // "a run of more than kMaxDup ids exists" (the optimizer step's listing kernels)
+            atomicAdd(&ctl[kCtlRadixBuckets], 1u);
           }
           __syncthreads();
           at += s_misc[3];
           for (int r = threadIdx.x; r < static_cast<int>(heads_total); r += BLOCK) {
             const int i0 = static_cast<int>(s_run[r]);
             const int i1 = r + 1 < static_cast<int>(heads_total) ? static_cast<int>(s_run[r + 1]) : m;
-            if (i1 - i0 > kMaxDup) {
+            if (i1 - i0 > kMaxDup && i1 - i0 <= kFixSmall) {
               if (at < ht.max_tasks)
                 ht.tasks[at] = static_cast<unsigned long long>(start + static_cast<uint32_t>(i0)) | (static_cast<unsigned long long>(i1 - i0) << 32);
               at++;
@@ -1196,7 +1205,6 @@ __global__ __launch_bounds__((1 << CAPBITS) / kSortIpt, 8) void split_sort_kerne
 // up to 1024: a bitonic sort in the wave's 4 KiB of LDS; longer ones (a tile's share of a very hot id, up to the tile; a regular
 // bucket's run of up to 8192 ids) take a workgroup each, split_fix_big_kernel. Both kernels walk the whole list and take what
 // is theirs by length; they return at once when the batch overflowed (the generic path writes order[]) .
-constexpr int kFixSmall = 2048;   // positions a wave sorts in its LDS (8 KiB)
 constexpr int kFixMapWords = kMaxIpt * kBlock / 32;   // bitmap of a tile: 768 words
 // Listed segments of order[] into ascending position, one WAVE per segment:
 //  * a TILE segment (a hot bucket's share of one tile, any length): its positions lie in [t x tile, (t + 1) x tile) — a bitmap of the
@@ -1206,11 +1214,16 @@ constexpr int kFixMapWords = kMaxIpt * kBlock / 32;   // bitmap of a tile: 768 w
 __global__ __launch_bounds__(256) void split_fix_small_kernel(const hot_tables ht, int32_t* order, uint32_t* ctl, int tile)
 {
   if (ctl[kCtlOverflow] != 0) return;
+#ifdef WM_SPLIT_DEBUG
+  const int only = g_split_debug;   // experiments: 11 = tile segments only, 12 = runs of up to 64 only, 13 = bitonic runs only (results wrong)
+#else
+  constexpr int only = 0;
+#endif
   __shared__ uint32_t s_buf[4][kFixSmall];   // per wave: the bitmap of a tile (3 KiB), or the 8 KiB of a bitonic sort
   static_assert(kFixSmall >= kFixMapWords, "the bitmap fits");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t n_tasks = ht.n_hot[2];
-  if (n_tasks > ht.max_tasks) {   // (cannot happen: the list is sized for every segment a batch can produce)
+  if (n_tasks + ht.n_hot[3] > ht.max_tasks) {   // (cannot happen: the list is sized for every segment a batch can produce)
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&ctl[kCtlError], static_cast<uint32_t>(kErrTasks));
     n_tasks = ht.max_tasks;
   }
@@ -1222,6 +1235,7 @@ __global__ __launch_bounds__(256) void split_fix_small_kernel(const hot_tables h
     const unsigned long long task = ht.tasks[t];
     const uint32_t start = static_cast<uint32_t>(task), len = static_cast<uint32_t>(task >> 32) & 0x7FFFFFFFu;
     if ((task & kTaskTile) != 0) {
+      if (only != 0 && only != 11) continue;
       uint32_t* map = s_buf[wv];
       const int words = (tile + 31) >> 5;   // <= kFixMapWords
       const uint32_t base = static_cast<uint32_t>(order[start]) / static_cast<uint32_t>(tile) * static_cast<uint32_t>(tile);
@@ -1268,6 +1282,7 @@ __global__ __launch_bounds__(256) void split_fix_small_kernel(const hot_tables h
       continue;
     }
     if (len > static_cast<uint32_t>(kFixSmall)) continue;
+    if (only != 0 && only != (len <= 64 ? 12 : 13)) continue;
     if (len <= 64) {
       const int32_t x = lane < static_cast<int>(len) ? order[start + lane] : 0x7FFFFFFF;
       int rank        = 0;
@@ -1299,12 +1314,12 @@ __global__ __launch_bounds__(kBlock) void split_fix_big_kernel(const hot_tables 
 {
   if (ctl[kCtlOverflow] != 0) return;
   extern __shared__ int32_t s_big[];
-  uint32_t n_tasks = ht.n_hot[2];
+  uint32_t n_tasks = ht.n_hot[3];   // (the big segments are listed from the END of the array: this kernel does not walk the small ones)
   if (n_tasks > ht.max_tasks) n_tasks = ht.max_tasks;
   for (uint32_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
-    const unsigned long long task = ht.tasks[t];
+    const unsigned long long task = ht.tasks[ht.max_tasks - 1 - t];
     const uint32_t start = static_cast<uint32_t>(task), len = static_cast<uint32_t>(task >> 32) & 0x7FFFFFFFu;
-    if ((task & kTaskTile) != 0 || len <= static_cast<uint32_t>(kFixSmall)) continue;
+    if (len <= static_cast<uint32_t>(kFixSmall)) continue;
     if (len > static_cast<uint32_t>(kFixBigMax)) {   // (no such segment exists)
       if (threadIdx.x == 0) atomicOr(&ctl[kCtlError], static_cast<uint32_t>(kErrTasks));
       continue;
